@@ -1,0 +1,117 @@
+"""Test harness: runs the CHECKER (oracle/pbsim_oracle, the compiled reference
+under oracle/_ref when present) and canonicalises outputs for comparison.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it."""
+import hashlib
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE = os.path.join(ROOT, "oracle", "pbsim_oracle")
+REF_GLIBC = os.path.join(ROOT, "oracle", "_ref", "pbsim_ref")
+REF_PHILOX = os.path.join(ROOT, "oracle", "_ref", "pbsim_ref_philox")
+# model files are inputs (format contract); tests look for them here first and
+# fall back to the read-only reference mount in this container
+MODEL_GZ_DIR = os.path.join(ROOT, "tests", "golden", "models")
+MODEL_CACHE = os.path.join(MODEL_GZ_DIR, "_unpacked")
+
+
+def model_path(name):
+    """FIC-HMM model files are INPUT DATA (format contract); the six
+    used by the tests are committed gzip-compressed and unpacked on first use."""
+    import gzip
+    p = os.path.join(MODEL_CACHE, name)
+    if not os.path.exists(p):
+        src = os.path.join(MODEL_GZ_DIR, name + ".gz")
+        if not os.path.exists(src):
+            raise FileNotFoundError(name)
+        os.makedirs(MODEL_CACHE, exist_ok=True)
+        tmp = p + ".%d.tmp" % os.getpid()
+        with gzip.open(src, "rb") as f, open(tmp, "wb") as g:
+            g.write(f.read())
+        os.replace(tmp, p)
+    return p
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    return ORACLE
+
+
+def strip_report(err: str) -> str:
+    keep = []
+    for line in err.splitlines():
+        if line.startswith((":::: System utilization", "CPU time(s)", "Elapsed time(s)", "oracle draws")):
+            continue
+        if line.split(" : ")[0] in ("prefix", "genome", "transcript", "errhmm", "qshmm", "file name", "template"):
+            continue
+        keep.append(line)
+    return "\n".join(keep).rstrip("\n") + "\n"
+
+
+def resolve(args):
+    out = []
+    for a in args:
+        if a.startswith("MODEL:"):
+            out.append(model_path(a[6:]))
+        elif a.startswith("INPUT:"):
+            out.append(os.path.join(GOLDEN, "inputs", a[6:]))
+        else:
+            out.append(a)
+    return out
+
+
+def collect(workdir, prefix="out"):
+    res = {}
+    for fn in sorted(os.listdir(workdir)):
+        if fn.startswith(prefix) and os.path.isfile(os.path.join(workdir, fn)):
+            key = fn[len(prefix):]
+            key = key.replace(".fq.gz", ".fq").replace(".maf.gz", ".maf").replace(".bam", ".sam")
+            with open(os.path.join(workdir, fn), "rb") as f:
+                res[key] = f.read()
+    return res
+
+
+def run_oracle(args, mode, workdir, extra=()):
+    build_oracle()
+    p = subprocess.run([ORACLE] + resolve(args) + ["--prefix", os.path.join(workdir, "out"), "--rng", mode] + list(extra),
+                       capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError(f"oracle failed ({p.returncode}): {p.stderr[-2000:]}")
+    outs = collect(workdir)
+    outs[".stderr"] = strip_report(p.stderr).encode()
+    return outs
+
+
+def make_stubs(d):
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "gzip"), "w") as f:
+        f.write("#!/bin/sh\nexec cat\n")
+    with open(os.path.join(d, "samtools"), "w") as f:
+        f.write('#!/bin/sh\nexec cat > "$4"\n')
+    for n in ("gzip", "samtools"):
+        os.chmod(os.path.join(d, n), 0o755)
+
+
+def run_reference(args, mode, workdir):
+    exe = REF_GLIBC if mode == "glibc" else REF_PHILOX
+    args = resolve(args)
+    seed = args[args.index("--seed") + 1]
+    stubs = os.path.join(workdir, "stubs")
+    make_stubs(stubs)
+    env = dict(os.environ, PATH=stubs + ":" + os.environ["PATH"], PBSHIM_SEED=seed, PBSHIM_MODE="philox")
+    p = subprocess.run([exe] + args + ["--prefix", os.path.join(workdir, "out")], env=env,
+                       capture_output=True, text=True, check=True)
+    outs = collect(workdir)
+    outs[".stderr"] = strip_report(p.stderr).encode()
+    return outs
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def load_manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
