@@ -1,0 +1,187 @@
+/* pbsim3_amd.h -- C ABI of the MI355X-native pbsim3 hot path.
+ *
+ * The reference (yukiteruono/pbsim3 v3.0.5, one translation unit) has no
+ * plugin or FFI seam: its boundary is the process (argv -> files).  The
+ * internal seam this library replaces is the family
+ *     int simulate_by_errhmm(void)        src/pbsim.cpp:3594
+ *     int simulate_by_qshmm(void)         src/pbsim.cpp:1955
+ *     int simulate_by_errhmm_trans(void)  src/pbsim.cpp:4114
+ * together with the loaders/table builders they consume through globals
+ * (set_errhmm :5640, set_qshmm :5570, set_mut :5471, get_genome_seq :997).
+ * Every entry point below cites the reference lines it stands in for.
+ *
+ * Conventions (mirroring the reference): functions return PBSIM_SUCCEEDED (1)
+ * or PBSIM_FAILED (0) like SUCCEEDED/FAILED (pbsim.cpp:16-17); the message the
+ * reference would have printed as "ERROR: ..." is available from
+ * pbsim_last_error().  A context is single-owner (one host thread, one GPU).
+ * All pointers are plain host pointers unless the name says `_device`.
+ *
+ * The library is the HIP product: there is no CPU fallback.  Every compute
+ * entry point fails (returns 0, pbsim_last_error() says why) when no gfx950
+ * device is usable.
+ */
+#ifndef PBSIM3_AMD_H
+#define PBSIM3_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBSIM_SUCCEEDED 1
+#define PBSIM_FAILED 0
+
+#define PBSIM_STRATEGY_WGS 1   /* pbsim.cpp:34 */
+#define PBSIM_STRATEGY_TRANS 2 /* pbsim.cpp:35 */
+#define PBSIM_STRATEGY_TEMPL 3 /* pbsim.cpp:36 */
+#define PBSIM_METHOD_QS 1      /* pbsim.cpp:37 */
+#define PBSIM_METHOD_ERR 2     /* pbsim.cpp:38 */
+
+/* Validated simulation parameters = the fields of `struct sim_t`
+ * (pbsim.cpp:51-77) that the hot path reads.  pbsim_params_default() applies
+ * set_sim_param()'s defaults (pbsim.cpp:1539-1685). */
+typedef struct pbsim_params {
+  int32_t strategy;     /* PBSIM_STRATEGY_*                       */
+  int32_t method;       /* PBSIM_METHOD_*                         */
+  uint32_t seed;        /* --seed                  (pbsim.cpp:417) */
+  int32_t pass_num;     /* --pass-num              (pbsim.cpp:494) */
+  double depth;         /* --depth                 (pbsim.cpp:351) */
+  double accuracy_mean; /* --accuracy-mean, already int(x*100)*0.01 (pbsim.cpp:1660) */
+  double len_mean;      /* --length-mean           (pbsim.cpp:469) */
+  double len_sd;        /* --length-sd             (pbsim.cpp:477) */
+  double hp_del_bias;   /* --hp-del-bias           (pbsim.cpp:514) */
+  int64_t len_min;      /* --length-min            (pbsim.cpp:363) */
+  int64_t len_max;      /* --length-max            (pbsim.cpp:375) */
+  int64_t sub_ratio;    /* --difference-ratio      (pbsim.cpp:405) */
+  int64_t ins_ratio;
+  int64_t del_ratio;
+  char id_prefix[64];   /* --id-prefix             (pbsim.cpp:347) */
+} pbsim_params;
+
+/* Per-unit results = the `sim.res_*` block (pbsim.cpp:63-70) plus the two
+ * histograms' derived values, computed exactly as pbsim.cpp:4082-4105. */
+typedef struct pbsim_stats {
+  int64_t res_num;       /* reads                                      */
+  int64_t res_pass_num;  /* reads * pass_num                           */
+  int64_t res_len_total; /* simulated bases over all passes            */
+  int64_t res_len_min, res_len_max;
+  int64_t res_sub_num, res_ins_num, res_del_num;
+  double res_depth;
+  double res_len_mean, res_len_sd;
+  double res_accuracy_mean, res_accuracy_sd;
+  double res_sub_rate, res_ins_rate, res_del_rate;
+} pbsim_stats;
+
+/* What one batch produced (device-resident until pbsim_batch_fetch). */
+typedef struct pbsim_batch_info {
+  int64_t first_read;    /* 1-based index of the first read of the batch          */
+  int64_t n_reads;       /* reads simulated speculatively                         */
+  int64_t n_final;       /* leading reads that are final under the quota rule     */
+  int32_t quota_reached; /* 1: the unit's quota loop ends inside this batch       */
+  int32_t need_truncated_read; /* 1: read first_read+n_final must be re-drawn with
+                            the truncated length (pbsim.cpp:3795-3800)            */
+  int64_t len_total_after; /* pass-0 bases accumulated after the n_final reads    */
+  int64_t bases;         /* read bases over all passes of the n_final reads       */
+  int64_t read_text_bytes; /* FASTQ (pass_num==1) or SAM text bytes               */
+  int64_t maf_text_bytes;  /* MAF text bytes                                      */
+  int64_t ref_bases;     /* reference bases consumed (roofline accounting)        */
+  int64_t maf_columns;   /* MAF columns written      (roofline accounting)        */
+} pbsim_batch_info;
+
+/* Receiver of finished text, called in read order; the bytes are exactly what
+ * the reference fprintf()s into its gzip/samtools pipes (pbsim.cpp:4012-4078).
+ * Return 0 from a callback to abort the simulation. */
+typedef struct pbsim_sink {
+  void *user;
+  int (*on_read_text)(void *user, const char *text, int64_t bytes); /* FASTQ or SAM records */
+  int (*on_maf_text)(void *user, const char *text, int64_t bytes);  /* MAF records          */
+} pbsim_sink;
+
+typedef struct pbsim_ctx pbsim_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------- */
+void pbsim_params_default(pbsim_params *p);                     /* pbsim.cpp:1539-1685 */
+pbsim_ctx *pbsim_create(const pbsim_params *p, int device);     /* main() setup, pbsim.cpp:538-578, 662 */
+void pbsim_destroy(pbsim_ctx *ctx);
+const char *pbsim_last_error(void);
+const char *pbsim_version(void);
+
+/* ---- model tables ----------------------------------------------------------- */
+int pbsim_load_errhmm(pbsim_ctx *ctx, const char *path);        /* set_errhmm :5640 + tables :3633-3789 */
+int pbsim_load_qshmm(pbsim_ctx *ctx, const char *path);         /* set_qshmm  :5570 + tables :1991-2170 */
+
+/* ---- reference sequence of the current unit ---------------------------------
+ * `seq` is the raw record (no newlines) as get_genome_seq() assembles it
+ * (pbsim.cpp:1014-1033); upper-casing and the per-base homopolymer length
+ * (pbsim.cpp:1035-1065) are done on the GPU.  record_index is genome.num
+ * (1-based).  The _device form takes a pointer already in this GPU's HBM. */
+int pbsim_set_reference(pbsim_ctx *ctx, const uint8_t *seq, int64_t len, int64_t record_index);
+int pbsim_set_reference_device(pbsim_ctx *ctx, const void *seq_device, int64_t len, int64_t record_index);
+/* --hp-del-bias != 1 needs the homopolymer census of ALL records first
+ * (pbsim.cpp:677-696): call once per record, then pbsim_finish_hp_census(). */
+int pbsim_add_hp_census(pbsim_ctx *ctx, const uint8_t *seq, int64_t len);
+int pbsim_finish_hp_census(pbsim_ctx *ctx);
+
+/* ---- transcriptome units (strategy trans) -----------------------------------
+ * All transcripts are handed over at once; ids are NUL-terminated strings.
+ * Replaces the streaming reader inside simulate_by_errhmm_trans
+ * (pbsim.cpp:4428-4485) and get_transcript_inf (:1075). */
+int pbsim_set_transcripts(pbsim_ctx *ctx, int64_t n, const char *const *ids, const int64_t *plus_exp,
+                          const int64_t *minus_exp, const uint8_t *const *seqs, const int64_t *lens);
+
+/* ---- whole-unit drivers = the reference seam --------------------------------
+ * pbsim_simulate_wgs  : one FASTA record, quota loop included
+ *                       (simulate_by_errhmm :3792-4080 / simulate_by_qshmm :2173-2385)
+ * pbsim_simulate_trans: every transcript (simulate_by_errhmm_trans :4428-4770) */
+int pbsim_simulate_wgs(pbsim_ctx *ctx, const pbsim_sink *sink);
+int pbsim_simulate_trans(pbsim_ctx *ctx, const pbsim_sink *sink);
+int pbsim_get_stats(pbsim_ctx *ctx, pbsim_stats *out);          /* pbsim.cpp:4082-4105, 5541-5562 */
+
+/* ---- batch primitives (used by the drivers above, bench.py, multi-GPU) ------
+ * pbsim_batch_walk     header draw + bucketing + HMM walk of reads
+ *                      [first_read, first_read+n_reads) of the current unit,
+ *                      speculatively un-truncated; *pass0_bases = their pass-0
+ *                      output bases.  truncate_remaining >= 0 (n_reads must be
+ *                      1) applies the quota truncation of pbsim.cpp:3795-3800
+ *                      with quota-len_total = truncate_remaining.
+ * pbsim_batch_finalize places the quota cut given the pass-0 bases simulated
+ *                      before this batch and emits FASTQ|SAM + MAF text for the
+ *                      final reads into device buffers.
+ * pbsim_batch_fetch    copies the text to host memory (either may be NULL). */
+int pbsim_batch_walk(pbsim_ctx *ctx, int64_t first_read, int64_t n_reads, int64_t truncate_remaining,
+                     int64_t *pass0_bases);
+int pbsim_batch_finalize(pbsim_ctx *ctx, int64_t len_total_before, pbsim_batch_info *info);
+int pbsim_batch_fetch(pbsim_ctx *ctx, char *read_text, char *maf_text);
+/* adds the n_final reads of the finalized batch to the unit's statistics */
+int pbsim_batch_account(pbsim_ctx *ctx);
+/* resets the per-unit statistics (init_sim_res, pbsim.cpp:1437) */
+int pbsim_reset_stats(pbsim_ctx *ctx);
+/* quota of the current unit: (long long)(depth*len), pbsim.cpp:705 */
+int64_t pbsim_unit_quota(pbsim_ctx *ctx);
+/* reads the engine sizes one batch to (from the scratch budget) */
+int64_t pbsim_batch_capacity(pbsim_ctx *ctx);
+/* scratch budget in bytes (default: PBSIM_SCRATCH_MB env or 8 GiB) */
+int pbsim_set_scratch_bytes(pbsim_ctx *ctx, int64_t bytes);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------
+ * Accumulated HIP-event time of the walk kernel launches since the last reset,
+ * measured on the engine's own stream, and the number of launches. */
+int pbsim_prof_reset(pbsim_ctx *ctx);
+int pbsim_prof_get(pbsim_ctx *ctx, double *walk_ms, int64_t *walk_launches, double *total_ms);
+/* raw HIP stream handle (hipStream_t) of the engine, for external event timing */
+void *pbsim_stream(pbsim_ctx *ctx);
+
+/* ---- known-answer hooks (tests) ---------------------------------------------
+ * Philox4x32-10 block as the kernels compute it, on the host build of the same
+ * header (no GPU needed). */
+void pbsim_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* sha256-able dumps of the host-built tables (Q13 fixtures): returns bytes
+ * written, or the size needed when buf is NULL. which: 0 prob2len (int32
+ * [len_rand_value+1]), 1 prob2acc (uint8 [acc_rand_value+1]), 2 class tables */
+int64_t pbsim_dump_table(pbsim_ctx *ctx, int which, void *buf, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBSIM3_AMD_H */

@@ -1,0 +1,241 @@
+"""pbsim3_amd -- Python (ctypes) binding of the C ABI in include/pbsim3_amd.h.
+
+The product is the HIP library pbsim3_amd/lib/libpbsim3_amd.so; this module
+only loads it and mirrors its entry points (same names, same SUCCEEDED(1) /
+FAILED(0) convention as the reference, pbsim.cpp:16-17).  There is no Python
+or CPU implementation of the path behind it: if the library is missing, or no
+gfx950 device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+STRATEGY_WGS, STRATEGY_TRANS, STRATEGY_TEMPL = 1, 2, 3
+METHOD_QS, METHOD_ERR = 1, 2
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("strategy", C.c_int32), ("method", C.c_int32), ("seed", C.c_uint32), ("pass_num", C.c_int32),
+        ("depth", C.c_double), ("accuracy_mean", C.c_double), ("len_mean", C.c_double), ("len_sd", C.c_double),
+        ("hp_del_bias", C.c_double), ("len_min", C.c_int64), ("len_max", C.c_int64),
+        ("sub_ratio", C.c_int64), ("ins_ratio", C.c_int64), ("del_ratio", C.c_int64),
+        ("id_prefix", C.c_char * 64),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("res_num", C.c_int64), ("res_pass_num", C.c_int64), ("res_len_total", C.c_int64),
+        ("res_len_min", C.c_int64), ("res_len_max", C.c_int64),
+        ("res_sub_num", C.c_int64), ("res_ins_num", C.c_int64), ("res_del_num", C.c_int64),
+        ("res_depth", C.c_double), ("res_len_mean", C.c_double), ("res_len_sd", C.c_double),
+        ("res_accuracy_mean", C.c_double), ("res_accuracy_sd", C.c_double),
+        ("res_sub_rate", C.c_double), ("res_ins_rate", C.c_double), ("res_del_rate", C.c_double),
+    ]
+
+
+class BatchInfo(C.Structure):
+    _fields_ = [
+        ("first_read", C.c_int64), ("n_reads", C.c_int64), ("n_final", C.c_int64),
+        ("quota_reached", C.c_int32), ("need_truncated_read", C.c_int32),
+        ("len_total_after", C.c_int64), ("bases", C.c_int64),
+        ("read_text_bytes", C.c_int64), ("maf_text_bytes", C.c_int64),
+        ("ref_bases", C.c_int64), ("maf_columns", C.c_int64),
+    ]
+
+
+SINK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_char), C.c_int64)
+
+
+class Sink(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("on_read_text", SINK_CB), ("on_maf_text", SINK_CB)]
+
+
+# every symbol include/pbsim3_amd.h declares: (name, restype, argtypes)
+API = [
+    ("pbsim_params_default", None, [C.POINTER(Params)]),
+    ("pbsim_create", C.c_void_p, [C.POINTER(Params), C.c_int]),
+    ("pbsim_destroy", None, [C.c_void_p]),
+    ("pbsim_last_error", C.c_char_p, []),
+    ("pbsim_version", C.c_char_p, []),
+    ("pbsim_load_errhmm", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("pbsim_load_qshmm", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("pbsim_set_reference", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    ("pbsim_set_reference_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    ("pbsim_add_hp_census", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("pbsim_finish_hp_census", C.c_int, [C.c_void_p]),
+    ("pbsim_set_transcripts", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    ("pbsim_simulate_wgs", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
+    ("pbsim_simulate_trans", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
+    ("pbsim_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    ("pbsim_batch_walk", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    ("pbsim_batch_finalize", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(BatchInfo)]),
+    ("pbsim_batch_fetch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pbsim_batch_account", C.c_int, [C.c_void_p]),
+    ("pbsim_reset_stats", C.c_int, [C.c_void_p]),
+    ("pbsim_unit_quota", C.c_int64, [C.c_void_p]),
+    ("pbsim_batch_capacity", C.c_int64, [C.c_void_p]),
+    ("pbsim_set_scratch_bytes", C.c_int, [C.c_void_p, C.c_int64]),
+    ("pbsim_prof_reset", C.c_int, [C.c_void_p]),
+    ("pbsim_prof_get", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    ("pbsim_stream", C.c_void_p, [C.c_void_p]),
+    ("pbsim_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("pbsim_dump_table", C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+]
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Loads libpbsim3_amd.so (building it in-tree with hipcc when absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.LIB):
+        if not build_if_missing:
+            raise RuntimeError("libpbsim3_amd.so is not built (python -m pbsim3_amd.build)")
+        _build.build()
+    lib = C.CDLL(_build.LIB)
+    for name, res, args in API:
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class PbsimError(RuntimeError):
+    pass
+
+
+def _check(ok):
+    if not ok:
+        raise PbsimError(load().pbsim_last_error().decode(errors="replace"))
+
+
+def default_params(**kw):
+    p = Params()
+    load().pbsim_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k == "id_prefix":
+            v = v.encode() if isinstance(v, str) else v
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """One GPU context (pbsim_ctx).  device=-1 gives a tables-only context that
+    can build and dump host tables but refuses every compute call."""
+
+    def __init__(self, params, device=0):
+        self.lib = load()
+        self.params = params
+        self.h = self.lib.pbsim_create(C.byref(params), device)
+        if not self.h:
+            raise PbsimError(self.lib.pbsim_last_error().decode(errors="replace"))
+
+    def close(self):
+        if self.h:
+            self.lib.pbsim_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def load_errhmm(self, path):
+        _check(self.lib.pbsim_load_errhmm(self.h, os.fsencode(path)))
+
+    def load_qshmm(self, path):
+        _check(self.lib.pbsim_load_qshmm(self.h, os.fsencode(path)))
+
+    def set_reference(self, seq: bytes, record_index: int):
+        buf = C.create_string_buffer(seq, len(seq))
+        _check(self.lib.pbsim_set_reference(self.h, C.cast(buf, C.c_void_p), len(seq), record_index))
+
+    def set_reference_device(self, ptr: int, length: int, record_index: int):
+        _check(self.lib.pbsim_set_reference_device(self.h, C.c_void_p(ptr), length, record_index))
+
+    def add_hp_census(self, seq: bytes):
+        buf = C.create_string_buffer(seq, len(seq))
+        _check(self.lib.pbsim_add_hp_census(self.h, C.cast(buf, C.c_void_p), len(seq)))
+
+    def finish_hp_census(self):
+        _check(self.lib.pbsim_finish_hp_census(self.h))
+
+    def simulate_wgs(self, collect=True):
+        """Runs the quota loop of the current record; returns (read_text, maf_text)."""
+        reads, mafs = [], []
+
+        def on_read(user, text, n):
+            reads.append(C.string_at(text, n))
+            return 1
+
+        def on_maf(user, text, n):
+            mafs.append(C.string_at(text, n))
+            return 1
+
+        sink = Sink(None, SINK_CB(on_read), SINK_CB(on_maf))
+        _check(self.lib.pbsim_simulate_wgs(self.h, C.byref(sink) if collect else None))
+        return b"".join(reads), b"".join(mafs)
+
+    def stats(self):
+        s = Stats()
+        _check(self.lib.pbsim_get_stats(self.h, C.byref(s)))
+        return s
+
+    def batch_walk(self, first_read, n_reads, truncate_remaining=-1):
+        out = C.c_int64(0)
+        _check(self.lib.pbsim_batch_walk(self.h, first_read, n_reads, truncate_remaining, C.byref(out)))
+        return out.value
+
+    def batch_finalize(self, len_total_before):
+        bi = BatchInfo()
+        _check(self.lib.pbsim_batch_finalize(self.h, len_total_before, C.byref(bi)))
+        return bi
+
+    def batch_fetch(self, info):
+        r = C.create_string_buffer(max(1, info.read_text_bytes))
+        m = C.create_string_buffer(max(1, info.maf_text_bytes))
+        _check(self.lib.pbsim_batch_fetch(self.h, C.cast(r, C.c_void_p), C.cast(m, C.c_void_p)))
+        return r.raw[:info.read_text_bytes], m.raw[:info.maf_text_bytes]
+
+    def batch_account(self):
+        _check(self.lib.pbsim_batch_account(self.h))
+
+    def reset_stats(self):
+        _check(self.lib.pbsim_reset_stats(self.h))
+
+    def unit_quota(self):
+        return self.lib.pbsim_unit_quota(self.h)
+
+    def batch_capacity(self):
+        return self.lib.pbsim_batch_capacity(self.h)
+
+    def set_scratch_bytes(self, n):
+        _check(self.lib.pbsim_set_scratch_bytes(self.h, n))
+
+    def prof_reset(self):
+        _check(self.lib.pbsim_prof_reset(self.h))
+
+    def prof_get(self):
+        a, b, c = C.c_double(0), C.c_int64(0), C.c_double(0)
+        _check(self.lib.pbsim_prof_get(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def dump_table(self, which):
+        n = self.lib.pbsim_dump_table(self.h, which, None, 0)
+        if n < 0:
+            raise PbsimError(self.lib.pbsim_last_error().decode(errors="replace"))
+        buf = C.create_string_buffer(n)
+        self.lib.pbsim_dump_table(self.h, which, C.cast(buf, C.c_void_p), n)
+        return buf.raw

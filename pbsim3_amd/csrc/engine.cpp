@@ -1,0 +1,904 @@
+// engine.cpp -- host orchestration of the gfx950 kernels and the C ABI of
+// include/pbsim3_amd.h.  One context = one GPU, one HIP stream, one unit
+// (FASTA record or transcript set) resident in HBM at a time.
+//
+// Data in HBM per context:
+//   reference  seq u8[len+pad] (upper-cased in place by K0), hp u8[len+pad]
+//   tables     prob2len i32[<=100001], prob2acc u8[<=100001], class blobs
+//   batch      per-read header arrays, per-task result arrays, task<->slot maps,
+//              wave scratch pool (wave-transposed rows), text buffers
+// The product has NO CPU fallback: every compute entry point needs the device.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pbsim3_amd.h"
+#include "host_tables.h"
+#include "kernels.h"
+#include "philox.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &m) {
+  g_err = m;
+  return PBSIM_FAILED;
+}
+
+#define NEED_DEVICE(c)                                                                      \
+  do {                                                                                      \
+    if ((c)->device < 0 || !(c)->stream)                                                    \
+      return fail("this context has no HIP device: the gfx950 product path has no CPU fallback"); \
+  } while (0)
+
+#define HIP_OK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);       \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t ensure(size_t n, bool exact = false) {
+    if (n <= bytes) return hipSuccess;
+    release();
+    size_t want = exact ? n : n + n / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return e;
+    }
+    bytes = want;
+    return hipSuccess;
+  }
+  template <class T>
+  T *as() const {
+    return reinterpret_cast<T *>(p);
+  }
+};
+
+struct HostBuf {  // pinned staging
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~HostBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+    size_t want = n + n / 8 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return e;
+    }
+    bytes = want;
+    return hipSuccess;
+  }
+};
+
+}  // namespace
+
+using namespace pbsim;
+
+struct pbsim_ctx {
+  pbsim_params p;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+
+  std::unique_ptr<ErrModel> err;
+  std::unique_ptr<QsModel> qs;
+  HeaderTables hdr;
+  HpBias bias;
+  ErrClassTables ect;
+  QsClassTables qct;
+  bool class_tables_dirty = true;
+  bool header_uploaded = false;
+
+  DevBuf d_prob2len, d_prob2acc, d_cls, d_qs_tabs;
+  // reference
+  DevBuf d_seq_own, d_hp, d_tiles;
+  const uint8_t *d_seq = nullptr;
+  int64_t ref_len = 0;
+  int64_t unit = 0;
+  int64_t census[kHpSlots] = {0};
+  bool census_done = false;
+  // batch
+  DevBuf d_flags, d_ref_flags;
+  DevBuf d_rawlen, d_len, d_off, d_acc;
+  DevBuf d_hist, d_bin_start, d_bin_cursor, d_class_start;
+  DevBuf d_task_of_slot, d_slot_of_task, d_wave_cap, d_wave_off;
+  DevBuf d_out_len, d_maf_len, d_nsub, d_nins, d_ndel, d_qsum;
+  DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len;
+  DevBuf d_scratch, d_read_text, d_maf_text;
+  int64_t scratch_budget = 0;
+  HostBuf h_read_text, h_maf_text, h_stats;
+
+  // state of the current batch
+  int64_t b_first = 0, b_n = 0, b_slots_max = 0;
+  bool b_truncated = false, b_walked = false, b_finalized = false;
+  int64_t b_pass0 = 0;
+  pbsim_batch_info b_info;
+
+  // per-unit statistics (pbsim.cpp:63-70, 195-196)
+  int64_t res_num = 0, res_len_total = 0, res_len_min = LONG_MAX, res_len_max = 0;
+  int64_t res_sub = 0, res_ins = 0, res_del = 0;
+  double accuracy_total = 0.0;
+  std::vector<int64_t> freq_len, freq_acc;
+
+  // profiling
+  double prof_walk_ms = 0, prof_total_ms = 0;
+  int64_t prof_walk_launches = 0;
+};
+
+namespace {
+
+int regions_of(const pbsim_ctx *c) { return c->p.method == PBSIM_METHOD_QS ? 4 : 3; }
+int ncls_of(const pbsim_ctx *c) { return c->hdr.acc_hi - c->hdr.acc_lo + 1; }
+
+int upload(DevBuf &b, const void *src, size_t n, hipStream_t s) {
+  HIP_OK(b.ensure(n));
+  HIP_OK(hipMemcpyAsync(b.p, src, n, hipMemcpyHostToDevice, s));
+  return PBSIM_SUCCEEDED;
+}
+
+int ensure_header_tables(pbsim_ctx *c) {
+  if (c->header_uploaded) return PBSIM_SUCCEEDED;
+  if (!upload(c->d_prob2len, c->hdr.prob2len.data(), c->hdr.prob2len.size() * sizeof(int32_t), c->stream))
+    return PBSIM_FAILED;
+  if (!upload(c->d_prob2acc, c->hdr.prob2acc.data(), c->hdr.prob2acc.size(), c->stream)) return PBSIM_FAILED;
+  HIP_OK(hipStreamSynchronize(c->stream));
+  c->header_uploaded = true;
+  return PBSIM_SUCCEEDED;
+}
+
+int ensure_class_tables(pbsim_ctx *c) {
+  if (!c->class_tables_dirty) return PBSIM_SUCCEEDED;
+  std::string e;
+  if (c->p.method == PBSIM_METHOD_ERR) {
+    if (!c->err) return fail("no ERRHMM model loaded (pbsim_load_errhmm)");
+    const bool wgs = c->p.strategy == PBSIM_STRATEGY_WGS;
+    if (!build_err_class_tables(*c->err, c->hdr, c->bias, wgs, &c->ect, &e)) return fail(e);
+    if (!upload(c->d_cls, c->ect.blob.data(), c->ect.blob.size(), c->stream)) return PBSIM_FAILED;
+  } else {
+    if (!c->qs) return fail("no QSHMM model loaded (pbsim_load_qshmm)");
+    if (!build_qs_class_tables(*c->qs, c->hdr, c->bias, c->p, &c->qct, &e)) return fail(e);
+    if (!upload(c->d_cls, c->qct.blob.data(), c->qct.blob.size(), c->stream)) return PBSIM_FAILED;
+    // [sub 94 u32 | ins 94 u32 | del 94*12 u32 | qprob 94 f64]
+    std::vector<uint8_t> t(94 * 4 * 2 + 94 * 12 * 4 + 94 * 8);
+    memcpy(t.data(), c->qct.sub_thre, 94 * 4);
+    memcpy(t.data() + 94 * 4, c->qct.ins_thre, 94 * 4);
+    memcpy(t.data() + 94 * 8, c->qct.del_thr, 94 * 12 * 4);
+    memcpy(t.data() + 94 * 8 + 94 * 48, c->qct.qprob, 94 * 8);
+    if (!upload(c->d_qs_tabs, t.data(), t.size(), c->stream)) return PBSIM_FAILED;
+  }
+  HIP_OK(hipStreamSynchronize(c->stream));
+  c->class_tables_dirty = false;
+  return PBSIM_SUCCEEDED;
+}
+
+int read_flags(pbsim_ctx *c, DeviceFlags *f) {
+  HIP_OK(hipMemcpyAsync(f, c->d_flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return PBSIM_SUCCEEDED;
+}
+
+// upper-case + homopolymer lengths on the GPU; adds the unit's hp census to `census_out`
+int prepare_reference(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int keep_first_case, int64_t census_out[kHpSlots]) {
+  const int64_t n_tiles = (len + kHpTile - 1) / kHpTile;
+  HIP_OK(c->d_hp.ensure((size_t)len + 64));
+  HIP_OK(c->d_tiles.ensure((size_t)(n_tiles + 1) * 4 * sizeof(int64_t)));
+  HIP_OK(c->d_ref_flags.ensure(sizeof(DeviceFlags)));
+  HIP_OK(hipMemsetAsync(c->d_ref_flags.p, 0, sizeof(DeviceFlags), c->stream));
+  HIP_OK(hipMemsetAsync(c->d_hp.as<uint8_t>() + len, 0, 64, c->stream));
+  int64_t *t = c->d_tiles.as<int64_t>();
+  launch_prepare_reference(d_seq, c->d_hp.as<uint8_t>(), len, t, t + (n_tiles + 1), t + 2 * (n_tiles + 1),
+                           t + 3 * (n_tiles + 1), keep_first_case, c->d_ref_flags.as<DeviceFlags>(), c->stream);
+  HIP_OK(hipGetLastError());
+  DeviceFlags f;
+  HIP_OK(hipMemcpyAsync(&f, c->d_ref_flags.p, sizeof f, hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < kHpSlots; i++) census_out[i] += (int64_t)f.hpfreq[i];
+  return PBSIM_SUCCEEDED;
+}
+
+void note_hp11(pbsim_ctx *c, const int64_t census[kHpSlots]) {
+  // hpfreq[11]++ in get_genome_seq (pbsim.cpp:1058) lands in hp_del_bias[0]:
+  // from then on the Q15 deletion test can fire when the draw is exactly 0
+  if (census[11] > 0 && !c->bias.hp11_seen) {
+    c->bias.hp11_seen = true;
+    if (c->p.method == PBSIM_METHOD_QS) c->class_tables_dirty = true;
+  }
+}
+
+int64_t batch_capacity(const pbsim_ctx *c) {
+  const double mean = std::min<double>(c->hdr.mean_len, (double)std::max<int64_t>(c->ref_len, 1));
+  const double per_task = (double)regions_of(c) * (2.0 * mean + kScratchPad) * 1.12 + 64.0;
+  int64_t n = (int64_t)((double)c->scratch_budget / (per_task * c->p.pass_num));
+  n = std::max<int64_t>(n, 1);
+  n = std::min<int64_t>(n, (int64_t)(0x7fffff00 / std::max(1, c->p.pass_num)));
+  return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pbsim_last_error(void) { return g_err.c_str(); }
+const char *pbsim_version(void) { return "pbsim3_amd 0.1 (gfx950)"; }
+
+void pbsim_params_default(pbsim_params *p) {  // pbsim.cpp:1539-1685
+  memset(p, 0, sizeof(*p));
+  p->strategy = PBSIM_STRATEGY_WGS;
+  p->method = PBSIM_METHOD_ERR;
+  p->seed = 1;
+  p->pass_num = 1;
+  p->depth = 20.0;
+  p->accuracy_mean = 0.85;
+  p->len_mean = 9000;
+  p->len_sd = 7000;
+  p->hp_del_bias = 1;
+  p->len_min = 100;
+  p->len_max = 1000000;
+  p->sub_ratio = 6;
+  p->ins_ratio = 55;
+  p->del_ratio = 39;
+  strcpy(p->id_prefix, "S");
+}
+
+void pbsim_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  const U4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+  out[0] = r.x;
+  out[1] = r.y;
+  out[2] = r.z;
+  out[3] = r.w;
+}
+
+pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
+  if (!p) {
+    fail("pbsim_create: params is NULL");
+    return nullptr;
+  }
+  if (p->strategy < 1 || p->strategy > 3 || (p->method != PBSIM_METHOD_QS && p->method != PBSIM_METHOD_ERR)) {
+    fail("--strategy and --method must be set.");
+    return nullptr;
+  }
+  if (p->len_min > p->len_max || p->len_min < 1 || p->len_max > 1000000) {
+    fail("length min is greater than max, or outside 1-1000000.");
+    return nullptr;
+  }
+  if (p->pass_num < 1) {
+    fail("pass_num: Acceptable range is more than 1.");
+    return nullptr;
+  }
+  if (strnlen(p->id_prefix, sizeof p->id_prefix) >= sizeof p->id_prefix) {
+    fail("id-prefix is too long (max 63)");
+    return nullptr;
+  }
+  std::unique_ptr<pbsim_ctx> c(new pbsim_ctx);
+  c->p = *p;
+  c->device = device;
+  std::string e;
+  if (!build_header_tables(c->p, &c->hdr, &e)) {
+    fail(e);
+    return nullptr;
+  }
+  hp_bias_default(&c->bias);
+  c->freq_len.assign((size_t)c->p.len_max * 2 + 2, 0);
+  c->freq_acc.assign(100001, 0);
+  if (device == -1) return c.release();  // tables-only context: every compute entry point refuses
+  int n = 0;
+  hipError_t he = hipGetDeviceCount(&n);
+  if (he != hipSuccess || n <= 0) {
+    fail("no HIP device available: this library is the gfx950 product path and has no CPU fallback");
+    return nullptr;
+  }
+  if (device < 0 || device >= n) {
+    fail("device index out of range");
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    fail("cannot initialise the HIP device/stream");
+    return nullptr;
+  }
+  (void)hipEventCreate(&c->ev0);
+  (void)hipEventCreate(&c->ev1);
+  (void)hipEventCreate(&c->ev2);
+  (void)hipEventCreate(&c->ev3);
+  const char *mb = getenv("PBSIM_SCRATCH_MB");
+  c->scratch_budget = (mb && atoll(mb) > 0) ? atoll(mb) * (1LL << 20) : (8LL << 30);
+  return c.release();
+}
+
+void pbsim_destroy(pbsim_ctx *c) {
+  if (!c) return;
+  if (c->device >= 0) (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev2) (void)hipEventDestroy(c->ev2);
+  if (c->ev3) (void)hipEventDestroy(c->ev3);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int pbsim_load_errhmm(pbsim_ctx *c, const char *path) {
+  if (!c || !path) return fail("pbsim_load_errhmm: bad argument");
+  std::unique_ptr<ErrModel> m(new ErrModel);
+  std::string e;
+  if (!parse_errhmm(path, m.get(), &e)) return fail(e);
+  c->err = std::move(m);
+  c->class_tables_dirty = true;
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_load_qshmm(pbsim_ctx *c, const char *path) {
+  if (!c || !path) return fail("pbsim_load_qshmm: bad argument");
+  std::unique_ptr<QsModel> m(new QsModel);
+  std::string e;
+  if (!parse_qshmm(path, m.get(), &e)) return fail(e);
+  c->qs = std::move(m);
+  c->class_tables_dirty = true;
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_set_scratch_bytes(pbsim_ctx *c, int64_t bytes) {
+  if (!c || bytes < (1 << 20)) return fail("pbsim_set_scratch_bytes: bad argument");
+  c->scratch_budget = bytes;
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_add_hp_census(pbsim_ctx *c, const uint8_t *seq, int64_t len) {
+  if (!c || !seq || len < 1) return fail("pbsim_add_hp_census: bad argument");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(c->d_seq_own.ensure((size_t)len + 64));
+  HIP_OK(hipMemcpyAsync(c->d_seq_own.p, seq, (size_t)len, hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipMemsetAsync(c->d_seq_own.as<uint8_t>() + len, 0, 64, c->stream));
+  if (!prepare_reference(c, c->d_seq_own.as<uint8_t>(), len, 0, c->census)) return PBSIM_FAILED;
+  note_hp11(c, c->census);
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_finish_hp_census(pbsim_ctx *c) {
+  if (!c) return fail("pbsim_finish_hp_census: bad argument");
+  if (c->p.hp_del_bias != 1) {
+    const bool seen = c->bias.hp11_seen;
+    hp_bias_from_census(c->p.hp_del_bias, c->census, &c->bias);
+    c->bias.hp11_seen = seen;
+    c->class_tables_dirty = true;
+  }
+  c->census_done = true;
+  return PBSIM_SUCCEEDED;
+}
+
+static int set_reference_common(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int64_t record_index) {
+  if (len < 1) return fail("Reference is too short.");
+  if (len > 1000000000LL) return fail("Reference is too long. Acceptable length <= 1000000000.");
+  if (c->p.hp_del_bias != 1 && !c->census_done)
+    return fail("--hp-del-bias != 1 needs pbsim_add_hp_census() for every record and pbsim_finish_hp_census() first");
+  int64_t census[kHpSlots] = {0};
+  if (!prepare_reference(c, d_seq, len, 0, census)) return PBSIM_FAILED;
+  note_hp11(c, census);
+  c->d_seq = d_seq;
+  c->ref_len = len;
+  c->unit = record_index;
+  c->b_walked = c->b_finalized = false;
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_set_reference(pbsim_ctx *c, const uint8_t *seq, int64_t len, int64_t record_index) {
+  if (!c || !seq) return fail("pbsim_set_reference: bad argument");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  if (len < 1) return fail("Reference is too short.");
+  HIP_OK(c->d_seq_own.ensure((size_t)len + 64));
+  HIP_OK(hipMemcpyAsync(c->d_seq_own.p, seq, (size_t)len, hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipMemsetAsync(c->d_seq_own.as<uint8_t>() + len, 0, 64, c->stream));
+  return set_reference_common(c, c->d_seq_own.as<uint8_t>(), len, record_index);
+}
+
+int pbsim_set_reference_device(pbsim_ctx *c, const void *seq_device, int64_t len, int64_t record_index) {
+  if (!c || !seq_device) return fail("pbsim_set_reference_device: bad argument");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  if (len < 1) return fail("Reference is too short.");
+  // the kernels read whole dwords and upper-case in place: keep an owned, padded copy
+  HIP_OK(c->d_seq_own.ensure((size_t)len + 64));
+  HIP_OK(hipMemcpyAsync(c->d_seq_own.p, seq_device, (size_t)len, hipMemcpyDeviceToDevice, c->stream));
+  HIP_OK(hipMemsetAsync(c->d_seq_own.as<uint8_t>() + len, 0, 64, c->stream));
+  return set_reference_common(c, c->d_seq_own.as<uint8_t>(), len, record_index);
+}
+
+int64_t pbsim_unit_quota(pbsim_ctx *c) {  // pbsim.cpp:705
+  return c ? (int64_t)(long long)(c->p.depth * (double)c->ref_len) : 0;
+}
+
+int64_t pbsim_batch_capacity(pbsim_ctx *c) { return c ? batch_capacity(c) : 0; }
+
+int pbsim_reset_stats(pbsim_ctx *c) {  // init_sim_res, pbsim.cpp:1437-1445 + 3626-3631
+  if (!c) return fail("bad argument");
+  c->res_num = 0;
+  c->res_len_total = 0;
+  c->res_len_min = LONG_MAX;
+  c->res_len_max = 0;
+  c->res_sub = c->res_ins = c->res_del = 0;
+  c->accuracy_total = 0.0;
+  std::fill(c->freq_len.begin(), c->freq_len.end(), 0);
+  std::fill(c->freq_acc.begin(), c->freq_acc.end(), 0);
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t truncate_remaining,
+                     int64_t *pass0_bases) {
+  if (!c || n_reads < 1 || first_read < 1) return fail("pbsim_batch_walk: bad argument");
+  NEED_DEVICE(c);
+  if (c->p.strategy != PBSIM_STRATEGY_WGS) return fail("pbsim_batch_walk: wgs strategy only");
+  if (!c->d_seq) return fail("no reference set (pbsim_set_reference)");
+  if (truncate_remaining >= 0 && n_reads != 1) return fail("a truncated batch holds exactly one read");
+  if (first_read + n_reads > 0xffffffffLL) return fail("read index exceeds 32 bits");
+  HIP_OK(hipSetDevice(c->device));
+  if (!ensure_header_tables(c) || !ensure_class_tables(c)) return PBSIM_FAILED;
+  const int P = c->p.pass_num;
+  const int ncls = ncls_of(c);
+  if (ncls > kMaxClasses) return fail("too many accuracy classes");
+  const int64_t n_tasks = n_reads * P;
+  if (n_tasks > 0x7fffff00LL) return fail("batch too large");
+  const int64_t slots_max = ((n_tasks + (int64_t)ncls * (kWG - 1)) / kWG + 1) * kWG;
+  const int64_t waves_max = slots_max / 64;
+  const size_t nbins = (size_t)ncls * kLenBuckets;
+
+  HIP_OK(c->d_flags.ensure(sizeof(DeviceFlags)));
+  HIP_OK(c->d_rawlen.ensure(n_reads * 4));
+  HIP_OK(c->d_len.ensure(n_reads * 4));
+  HIP_OK(c->d_off.ensure(n_reads * 4));
+  HIP_OK(c->d_acc.ensure(n_reads));
+  HIP_OK(c->d_hist.ensure(nbins * 4));
+  HIP_OK(c->d_bin_start.ensure(nbins * 4));
+  HIP_OK(c->d_bin_cursor.ensure(nbins * 4));
+  HIP_OK(c->d_class_start.ensure((ncls + 1) * 4));
+  HIP_OK(c->d_task_of_slot.ensure(slots_max * 4));
+  HIP_OK(c->d_slot_of_task.ensure(n_tasks * 4));
+  HIP_OK(c->d_wave_cap.ensure(waves_max * 4));
+  HIP_OK(c->d_wave_off.ensure(waves_max * 8));
+  HIP_OK(c->d_out_len.ensure(n_tasks * 4));
+  HIP_OK(c->d_maf_len.ensure(n_tasks * 4));
+  HIP_OK(c->d_nsub.ensure(n_tasks * 4));
+  HIP_OK(c->d_nins.ensure(n_tasks * 4));
+  HIP_OK(c->d_ndel.ensure(n_tasks * 4));
+  HIP_OK(c->d_qsum.ensure(n_tasks * 8));
+  HIP_OK(c->d_cum.ensure((n_reads + 1) * 8));
+  HIP_OK(c->d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
+  HIP_OK(c->d_scratch.ensure((size_t)c->scratch_budget, true));
+
+  HIP_OK(hipEventRecord(c->ev0, c->stream));
+  HIP_OK(hipMemsetAsync(c->d_flags.p, 0, sizeof(DeviceFlags), c->stream));
+  DeviceFlags *flags = c->d_flags.as<DeviceFlags>();
+
+  HeaderArgs h;
+  h.seed = c->p.seed;
+  h.unit = (uint32_t)c->unit;
+  h.first_read = first_read;
+  h.n_reads = n_reads;
+  h.prob2len = c->d_prob2len.as<int32_t>();
+  h.len_rv = c->hdr.len_rv;
+  h.prob2acc = c->d_prob2acc.as<uint8_t>();
+  h.acc_rv = c->hdr.acc_rv;
+  h.ref_len = c->ref_len;
+  h.len_min = c->p.len_min;
+  h.truncate_remaining = truncate_remaining;
+  h.rawlen = c->d_rawlen.as<int32_t>();
+  h.len = c->d_len.as<int32_t>();
+  h.off = c->d_off.as<int32_t>();
+  h.acc = c->d_acc.as<uint8_t>();
+  launch_header_wgs(h, c->stream);
+
+  SortArgs s;
+  s.n_reads = n_reads;
+  s.pass_num = P;
+  s.acc_lo = c->hdr.acc_lo;
+  s.ncls = ncls;
+  s.len = h.len;
+  s.acc = h.acc;
+  s.hist = c->d_hist.as<int32_t>();
+  s.bin_start = c->d_bin_start.as<int32_t>();
+  s.bin_cursor = c->d_bin_cursor.as<int32_t>();
+  s.class_start = c->d_class_start.as<int32_t>();
+  s.task_of_slot = c->d_task_of_slot.as<int32_t>();
+  s.slot_of_task = c->d_slot_of_task.as<int32_t>();
+  s.wave_cap = c->d_wave_cap.as<int32_t>();
+  s.wave_off = c->d_wave_off.as<int64_t>();
+  s.n_slots_max = slots_max;
+  s.regions = regions_of(c);
+  s.scratch_bytes = c->scratch_budget;
+  s.flags = flags;
+  launch_task_sort(s, c->stream);
+
+  WalkArgs w;
+  memset(&w, 0, sizeof w);
+  w.seed = c->p.seed;
+  w.unit = (uint32_t)c->unit;
+  w.first_read = first_read;
+  w.pass_num = P;
+  w.ncls = ncls;
+  w.ref.seq = c->d_seq;
+  w.ref.hp = c->d_hp.as<uint8_t>();
+  w.ref.len = c->ref_len;
+  w.len = h.len;
+  w.off = h.off;
+  w.cls_blob = c->d_cls.as<uint8_t>();
+  w.class_start = s.class_start;
+  w.task_of_slot = s.task_of_slot;
+  w.wave_cap = s.wave_cap;
+  w.wave_off = s.wave_off;
+  w.scratch = c->d_scratch.as<uint8_t>();
+  w.out_len = c->d_out_len.as<int32_t>();
+  w.maf_len = c->d_maf_len.as<int32_t>();
+  w.nsub = c->d_nsub.as<int32_t>();
+  w.nins = c->d_nins.as<int32_t>();
+  w.ndel = c->d_ndel.as<int32_t>();
+  w.qsum = c->d_qsum.as<double>();
+  w.flags = flags;
+  HIP_OK(hipEventRecord(c->ev1, c->stream));
+  if (c->p.method == PBSIM_METHOD_ERR) {
+    w.stride = c->ect.stride;
+    w.rows_off = c->ect.rows_off;
+    w.init_off = c->ect.init_off;
+    w.tran_off = c->ect.tran_off;
+    launch_walk_errhmm(w, slots_max, c->ect.stride, c->stream);
+  } else {
+    w.stride = c->qct.stride;
+    w.rv_off = c->qct.rv_off;
+    w.init_off = c->qct.init_off;
+    w.tran_off = c->qct.tran_off;
+    w.emis_off = c->qct.emis_off;
+    w.freq_off = c->qct.freq_off;
+    const uint8_t *t = c->d_qs_tabs.as<uint8_t>();
+    w.sub_thre = reinterpret_cast<const uint32_t *>(t);
+    w.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
+    w.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
+    w.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
+    launch_walk_qshmm(w, slots_max, c->qct.stride + 96 * 8 + 94 * 48 + 94 * 8, c->stream);
+  }
+  HIP_OK(hipEventRecord(c->ev2, c->stream));
+  launch_gather_pass0_scan(w.out_len, n_reads, P, c->d_cum.as<int64_t>(), c->d_scan_tmp.as<int64_t>(),
+                           &flags->sums[0], c->stream);
+  HIP_OK(hipEventRecord(c->ev3, c->stream));
+  HIP_OK(hipGetLastError());
+  DeviceFlags f;
+  if (!read_flags(c, &f)) return PBSIM_FAILED;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev1, c->ev2) == hipSuccess) c->prof_walk_ms += ms;
+  if (hipEventElapsedTime(&ms, c->ev0, c->ev3) == hipSuccess) c->prof_total_ms += ms;
+  c->prof_walk_launches++;
+  if (f.error & kErrScratchBudget) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "scratch budget exceeded: batch needs %lld bytes, pool holds %lld",
+             (long long)f.scratch_need, (long long)c->scratch_budget);
+    return fail(buf);
+  }
+  if (f.error & kErrScratchOverflow)
+    return fail("a read produced more MAF columns than 2*len+64 (the reference's buffers are 2*len_max+1)");
+  c->b_first = first_read;
+  c->b_n = n_reads;
+  c->b_slots_max = slots_max;
+  c->b_truncated = truncate_remaining >= 0;
+  c->b_walked = true;
+  c->b_finalized = false;
+  c->b_pass0 = f.sums[0];
+  if (pass0_bases) *pass0_bases = f.sums[0];
+  return PBSIM_SUCCEEDED;
+}
+
+static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
+  memset(t, 0, sizeof *t);
+  t->first_read = c->b_first;
+  t->n_reads = n_emit;
+  t->pass_num = c->p.pass_num;
+  t->is_wgs = c->p.strategy == PBSIM_STRATEGY_WGS;
+  t->is_qs = c->p.method == PBSIM_METHOD_QS;
+  t->unit = (uint32_t)c->unit;
+  t->ref_len = c->ref_len;
+  t->len = c->d_len.as<int32_t>();
+  t->off = c->d_off.as<int32_t>();
+  t->out_len = c->d_out_len.as<int32_t>();
+  t->maf_len = c->d_maf_len.as<int32_t>();
+  t->slot_of_task = c->d_slot_of_task.as<int32_t>();
+  t->wave_cap = c->d_wave_cap.as<int32_t>();
+  t->wave_off = c->d_wave_off.as<int64_t>();
+  t->scratch = c->d_scratch.as<uint8_t>();
+  t->read_text_len = c->d_rt_len.as<int64_t>();
+  t->maf_text_len = c->d_mt_len.as<int64_t>();
+  t->read_text_off = t->read_text_len;
+  t->maf_text_off = t->maf_text_len;
+  t->id_prefix_len = (int)strlen(c->p.id_prefix);
+  memcpy(t->id_prefix, c->p.id_prefix, sizeof t->id_prefix);
+  t->rq_len = snprintf(t->rq_text, sizeof t->rq_text, "%f", c->p.accuracy_mean);  // pbsim.cpp:4027
+}
+
+int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *info) {
+  if (!c || !c->b_walked) return fail("pbsim_batch_finalize: no walked batch");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  DeviceFlags *flags = c->d_flags.as<DeviceFlags>();
+  const int64_t quota = pbsim_unit_quota(c);
+  const int P = c->p.pass_num;
+  launch_quota_cut(c->d_cum.as<int64_t>(), c->d_rawlen.as<int32_t>(), c->b_n, len_total_before, quota,
+                   c->b_truncated ? 1 : 0, flags, c->stream);
+  DeviceFlags f;
+  if (!read_flags(c, &f)) return PBSIM_FAILED;
+  const int64_t n_final = f.n_final;
+  int64_t cum_final = c->b_pass0;
+  if (n_final < c->b_n) {
+    HIP_OK(hipMemcpyAsync(&cum_final, c->d_cum.as<int64_t>() + n_final, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+  }
+  pbsim_batch_info bi;
+  memset(&bi, 0, sizeof bi);
+  bi.first_read = c->b_first;
+  bi.n_reads = c->b_n;
+  bi.n_final = n_final;
+  bi.len_total_after = len_total_before + cum_final;
+  if (c->b_truncated) {
+    bi.quota_reached = bi.len_total_after >= quota;
+    bi.need_truncated_read = !bi.quota_reached;
+  } else {
+    bi.quota_reached = (n_final < c->b_n) || (bi.len_total_after >= quota);
+    bi.need_truncated_read = (n_final < c->b_n) && (bi.len_total_after < quota);
+  }
+  const int64_t n_tasks = n_final * P;
+  if (n_tasks > 0) {
+    HIP_OK(c->d_rt_len.ensure(n_tasks * 8));
+    HIP_OK(c->d_mt_len.ensure(n_tasks * 8));
+    HIP_OK(hipMemsetAsync(&flags->sums[1], 0, 5 * sizeof(int64_t), c->stream));
+    TextArgs t;
+    fill_text_args(c, &t, n_final);
+    launch_text_sizes(t, flags, c->stream);
+    launch_exclusive_scan_i64(t.read_text_len, t.read_text_len, n_tasks, c->d_scan_tmp.as<int64_t>(), &flags->sums[1],
+                              c->stream);
+    launch_exclusive_scan_i64(t.maf_text_len, t.maf_text_len, n_tasks, c->d_scan_tmp.as<int64_t>(), &flags->sums[2],
+                              c->stream);
+    if (!read_flags(c, &f)) return PBSIM_FAILED;
+    bi.read_text_bytes = f.sums[1];
+    bi.maf_text_bytes = f.sums[2];
+    bi.bases = f.sums[3];
+    bi.ref_bases = f.sums[4];
+    bi.maf_columns = f.sums[5];
+    HIP_OK(c->d_read_text.ensure((size_t)bi.read_text_bytes + 16));
+    HIP_OK(c->d_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
+    t.read_text = c->d_read_text.as<char>();
+    t.maf_text = c->d_maf_text.as<char>();
+    launch_text_emit(t, c->stream);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(c->stream));
+  }
+  c->b_info = bi;
+  c->b_finalized = true;
+  if (info) *info = bi;
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_batch_fetch(pbsim_ctx *c, char *read_text, char *maf_text) {
+  if (!c || !c->b_finalized) return fail("pbsim_batch_fetch: no finalized batch");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  if (read_text && c->b_info.read_text_bytes)
+    HIP_OK(hipMemcpyAsync(read_text, c->d_read_text.p, (size_t)c->b_info.read_text_bytes, hipMemcpyDeviceToHost,
+                          c->stream));
+  if (maf_text && c->b_info.maf_text_bytes)
+    HIP_OK(hipMemcpyAsync(maf_text, c->d_maf_text.p, (size_t)c->b_info.maf_text_bytes, hipMemcpyDeviceToHost,
+                          c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return PBSIM_SUCCEEDED;
+}
+
+// pbsim.cpp:3986-4005 (errhmm) / 2293-2316 (qshmm), applied in read order so the
+// order-dependent double sum `accuracy_total` matches the CPU bit for bit
+int pbsim_batch_account(pbsim_ctx *c) {
+  if (!c || !c->b_finalized) return fail("pbsim_batch_account: no finalized batch");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  const int P = c->p.pass_num;
+  const int64_t n_tasks = c->b_info.n_final * P;
+  if (n_tasks == 0) return PBSIM_SUCCEEDED;
+  HIP_OK(c->h_stats.ensure((size_t)n_tasks * 24));
+  int32_t *ol = reinterpret_cast<int32_t *>(c->h_stats.p);
+  int32_t *ns = ol + n_tasks, *ni = ns + n_tasks, *nd = ni + n_tasks;
+  double *qs = reinterpret_cast<double *>(nd + n_tasks);
+  HIP_OK(hipMemcpyAsync(ol, c->d_out_len.p, n_tasks * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipMemcpyAsync(ns, c->d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipMemcpyAsync(ni, c->d_nins.p, n_tasks * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipMemcpyAsync(nd, c->d_ndel.p, n_tasks * 4, hipMemcpyDeviceToHost, c->stream));
+  if (c->p.method == PBSIM_METHOD_QS)
+    HIP_OK(hipMemcpyAsync(qs, c->d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  c->res_num += c->b_info.n_final;
+  for (int64_t t = 0; t < n_tasks; t++) {
+    const long len = ol[t];
+    c->res_len_total += len;
+    if ((size_t)len < c->freq_len.size()) c->freq_len[len]++;
+    if (len > c->res_len_max) c->res_len_max = len;
+    if (len < c->res_len_min) c->res_len_min = len;
+    c->res_sub += ns[t];
+    c->res_ins += ni[t];
+    c->res_del += nd[t];
+    double value;
+    if (c->p.method == PBSIM_METHOD_QS) value = 1.0 - (qs[t] / len);
+    else value = 1.0 - ((double)((long)ns[t] + ni[t] + nd[t]) / len);
+    c->accuracy_total += value;
+    const double w = value * 100000 + 0.5;
+    if (w >= 0 && w < 100001) c->freq_acc[(int)w]++;
+  }
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_get_stats(pbsim_ctx *c, pbsim_stats *o) {  // pbsim.cpp:4082-4105, 5541-5562
+  if (!c || !o) return fail("pbsim_get_stats: bad argument");
+  memset(o, 0, sizeof *o);
+  o->res_num = c->res_num;
+  o->res_pass_num = c->res_num * c->p.pass_num;
+  o->res_len_total = c->res_len_total;
+  o->res_len_min = c->res_len_min;
+  o->res_len_max = c->res_len_max;
+  o->res_sub_num = c->res_sub;
+  o->res_ins_num = c->res_ins;
+  o->res_del_num = c->res_del;
+  o->res_len_mean = (double)c->res_len_total / o->res_pass_num;
+  o->res_accuracy_mean = c->accuracy_total / o->res_pass_num;
+  if (o->res_pass_num == 1) {
+    o->res_len_sd = 0.0;
+    o->res_accuracy_sd = 0.0;
+  } else {
+    double variance = 0.0;
+    for (long i = 0; i <= (long)c->p.len_max; i++)
+      if (c->freq_len[i] > 0) variance += pow((o->res_len_mean - i), 2) * c->freq_len[i];
+    o->res_len_sd = sqrt(variance / o->res_pass_num);
+    variance = 0.0;
+    for (long i = 0; i <= 100000; i++)
+      if (c->freq_acc[i] > 0) variance += pow((o->res_accuracy_mean - i * 0.00001), 2) * c->freq_acc[i];
+    o->res_accuracy_sd = sqrt(variance / o->res_pass_num);
+  }
+  if (c->p.strategy == PBSIM_STRATEGY_WGS && c->ref_len > 0)
+    o->res_depth = (double)c->res_len_total / c->ref_len / c->p.pass_num;
+  o->res_sub_rate = (double)c->res_sub / c->res_len_total;
+  o->res_ins_rate = (double)c->res_ins / c->res_len_total;
+  o->res_del_rate = (double)c->res_del / c->res_len_total;
+  return PBSIM_SUCCEEDED;
+}
+
+static int deliver(pbsim_ctx *c, const pbsim_sink *sink) {
+  const pbsim_batch_info &bi = c->b_info;
+  if (sink) {
+    HIP_OK(c->h_read_text.ensure((size_t)bi.read_text_bytes + 16));
+    HIP_OK(c->h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
+    if (!pbsim_batch_fetch(c, (char *)c->h_read_text.p, (char *)c->h_maf_text.p)) return PBSIM_FAILED;
+    if (sink->on_read_text && bi.read_text_bytes &&
+        !sink->on_read_text(sink->user, (const char *)c->h_read_text.p, bi.read_text_bytes))
+      return fail("sink aborted (read text)");
+    if (sink->on_maf_text && bi.maf_text_bytes &&
+        !sink->on_maf_text(sink->user, (const char *)c->h_maf_text.p, bi.maf_text_bytes))
+      return fail("sink aborted (MAF text)");
+  }
+  return pbsim_batch_account(c);
+}
+
+// The quota loop `while (len_total < sim.len_quota)` (pbsim.cpp:3792) as
+// speculative bulk batches + prefix scan + a serial tail.
+int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
+  if (!c) return fail("bad argument");
+  NEED_DEVICE(c);
+  if (c->p.strategy != PBSIM_STRATEGY_WGS) return fail("pbsim_simulate_wgs: strategy is not wgs");
+  if (!c->d_seq) return fail("no reference set (pbsim_set_reference)");
+  pbsim_reset_stats(c);
+  const int64_t quota = pbsim_unit_quota(c);
+  int64_t len_total = 0, next_read = 1;
+  bool serial = false;
+  int64_t cap = batch_capacity(c);
+  const double mean = std::min<double>(c->hdr.mean_len, (double)c->ref_len);
+  while (len_total < quota) {
+    pbsim_batch_info bi;
+    if (!serial) {
+      int64_t n = (int64_t)(0.98 * (double)(quota - len_total) / mean);
+      n = std::max<int64_t>(1, std::min(n, cap));
+      int64_t pass0 = 0;
+      if (!pbsim_batch_walk(c, next_read, n, -1, &pass0)) {
+        if (g_err.rfind("scratch budget exceeded", 0) == 0 && n > 1) {
+          cap = std::max<int64_t>(1, n / 2);  // skewed lengths: retry with a smaller batch
+          continue;
+        }
+        return PBSIM_FAILED;
+      }
+      if (!pbsim_batch_finalize(c, len_total, &bi)) return PBSIM_FAILED;
+      if (bi.need_truncated_read) serial = true;
+    } else {
+      if (!pbsim_batch_walk(c, next_read, 1, quota - len_total, nullptr)) return PBSIM_FAILED;
+      if (!pbsim_batch_finalize(c, len_total, &bi)) return PBSIM_FAILED;
+    }
+    if (!deliver(c, sink)) return PBSIM_FAILED;
+    next_read += bi.n_final;
+    len_total = bi.len_total_after;
+  }
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_set_transcripts(pbsim_ctx *, int64_t, const char *const *, const int64_t *, const int64_t *,
+                          const uint8_t *const *, const int64_t *) {
+  return fail("pbsim_set_transcripts: trans strategy is not built yet");
+}
+int pbsim_simulate_trans(pbsim_ctx *, const pbsim_sink *) {
+  return fail("pbsim_simulate_trans: trans strategy is not built yet");
+}
+
+int pbsim_prof_reset(pbsim_ctx *c) {
+  if (!c) return fail("bad argument");
+  c->prof_walk_ms = c->prof_total_ms = 0;
+  c->prof_walk_launches = 0;
+  return PBSIM_SUCCEEDED;
+}
+int pbsim_prof_get(pbsim_ctx *c, double *walk_ms, int64_t *walk_launches, double *total_ms) {
+  if (!c) return fail("bad argument");
+  if (walk_ms) *walk_ms = c->prof_walk_ms;
+  if (walk_launches) *walk_launches = c->prof_walk_launches;
+  if (total_ms) *total_ms = c->prof_total_ms;
+  return PBSIM_SUCCEEDED;
+}
+void *pbsim_stream(pbsim_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int64_t pbsim_dump_table(pbsim_ctx *c, int which, void *buf, int64_t cap) {
+  if (!c) return -1;
+  const void *src = nullptr;
+  int64_t n = 0;
+  std::string e;
+  if (which == 0) {
+    src = c->hdr.prob2len.data();
+    n = (int64_t)c->hdr.prob2len.size() * 4;
+  } else if (which == 1) {
+    src = c->hdr.prob2acc.data();
+    n = (int64_t)c->hdr.prob2acc.size();
+  } else if (which == 2) {
+    // host-only build of the class tables (no device needed)
+    if (c->p.method == PBSIM_METHOD_ERR) {
+      if (!c->err) return -1;
+      if (!build_err_class_tables(*c->err, c->hdr, c->bias, c->p.strategy == PBSIM_STRATEGY_WGS, &c->ect, &e)) {
+        fail(e);
+        return -1;
+      }
+      src = c->ect.blob.data();
+      n = (int64_t)c->ect.blob.size();
+    } else {
+      if (!c->qs) return -1;
+      if (!build_qs_class_tables(*c->qs, c->hdr, c->bias, c->p, &c->qct, &e)) {
+        fail(e);
+        return -1;
+      }
+      src = c->qct.blob.data();
+      n = (int64_t)c->qct.blob.size();
+    }
+  } else {
+    return -1;
+  }
+  if (buf && cap >= n) memcpy(buf, src, (size_t)n);
+  return n;
+}
+
+}  // extern "C"

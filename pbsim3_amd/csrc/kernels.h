@@ -1,0 +1,145 @@
+// kernels.h -- launch interface of the gfx950 kernels (kernels.hip).
+// Everything here is plain pointers + sizes; all pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "modes.h"
+
+namespace pbsim {
+
+constexpr int kWG = 256;            // threads per workgroup of the walk kernels (4 waves)
+constexpr int kLenBuckets = 4096;   // length buckets per accuracy class in the task sort
+constexpr int kLenShift = 8;        // bucket = len >> 8  (len_max 1e6 -> 3907 buckets)
+constexpr int kScratchPad = 64;     // per-task slack: cap = 2*L + kScratchPad columns (pbsim.cpp:5488 uses 2*len_max+1)
+constexpr int kMaxClasses = 64;
+constexpr int kHpTile = 4096;       // bases per workgroup in the homopolymer kernels
+
+// error flag bits written by kernels into EngineFlags::error
+enum : uint32_t {
+  kErrScratchOverflow = 1u,   // a task produced more MAF columns than 2*L+kScratchPad
+  kErrScratchBudget = 2u,     // the batch needs more scratch than the pool holds
+};
+
+struct DeviceFlags {
+  uint32_t error;
+  uint32_t pad;
+  int64_t n_final;        // quota cut (reads)
+  int64_t total_slots;    // slots after class alignment
+  int64_t scratch_need;   // bytes the batch needs
+  int64_t sums[8];        // [0] pass-0 bases of the batch, [1] read-text bytes, [2] maf-text bytes,
+                          // [3] bases all passes (final reads), [4] ref bases, [5] maf columns
+  unsigned long long hpfreq[12];
+};
+
+struct RefView {
+  const uint8_t *seq;  // upper-cased, padded to a multiple of 16 bytes
+  const uint8_t *hp;   // homopolymer length per base, 1..11
+  int64_t len;
+};
+
+struct HeaderArgs {
+  uint32_t seed, unit;
+  int64_t first_read;       // 1-based index of read 0 of the batch
+  int64_t n_reads;
+  const int32_t *prob2len;  // [0..len_rv]
+  int64_t len_rv;
+  const uint8_t *prob2acc;  // [0..acc_rv]
+  int64_t acc_rv;
+  int64_t ref_len;
+  int64_t len_min;
+  int64_t truncate_remaining;  // <0: none
+  int32_t *rawlen, *len, *off;
+  uint8_t *acc;
+};
+
+struct SortArgs {
+  int64_t n_reads;
+  int32_t pass_num;
+  int32_t acc_lo, ncls;
+  const int32_t *len;
+  const uint8_t *acc;
+  int32_t *hist;        // [ncls*kLenBuckets]
+  int32_t *bin_start;   // [ncls*kLenBuckets]
+  int32_t *bin_cursor;  // [ncls*kLenBuckets]
+  int32_t *class_start; // [ncls+1], multiples of kWG
+  int32_t *task_of_slot;
+  int32_t *slot_of_task;
+  int32_t *wave_cap;    // [n_waves_max] dwords per lane per region
+  int64_t *wave_off;    // [n_waves_max] byte offset into the scratch pool
+  int64_t n_slots_max;
+  int32_t regions;      // scratch regions per task (3 errhmm, 4 qshmm)
+  int64_t scratch_bytes;
+  DeviceFlags *flags;
+};
+
+struct WalkArgs {
+  uint32_t seed, unit;
+  int64_t first_read;
+  int32_t pass_num;
+  int32_t ncls;
+  RefView ref;
+  const int32_t *len, *off;
+  const uint8_t *cls_blob;   // ncls blobs of `stride` bytes
+  uint32_t stride, rows_off, init_off, tran_off, emis_off, freq_off, rv_off;
+  const int32_t *class_start;
+  const int32_t *task_of_slot;
+  const int32_t *wave_cap;
+  const int64_t *wave_off;
+  uint8_t *scratch;
+  int32_t *out_len, *maf_len, *nsub, *nins, *ndel;
+  double *qsum;              // qshmm: sum of error probabilities per task
+  // qshmm class-independent tables
+  const uint32_t *sub_thre, *ins_thre, *del_thr;  // [94], [94], [94*12]
+  const double *qprob;                           // [94]
+  DeviceFlags *flags;
+};
+
+struct TextArgs {
+  int64_t first_read;
+  int64_t n_reads;          // reads to emit (n_final)
+  int32_t pass_num;
+  int32_t is_wgs;           // id format
+  int32_t is_qs;            // quality row present
+  uint32_t unit;            // record number (wgs)
+  int64_t ref_len;
+  const int32_t *len, *off;
+  const int32_t *out_len, *maf_len;
+  const int32_t *slot_of_task;
+  const int32_t *wave_cap;
+  const int64_t *wave_off;
+  const uint8_t *scratch;
+  const int64_t *read_text_off, *maf_text_off;  // exclusive scans [n_tasks]
+  int64_t *read_text_len, *maf_text_len;        // sizes [n_tasks]
+  char *read_text, *maf_text;
+  char id_prefix[64];
+  int32_t id_prefix_len;
+  char rq_text[32];         // "%f" of accuracy_mean (SAM rq:f:)
+  int32_t rq_len;
+  // trans: per-read unit table
+  const int32_t *read_unit;     // [n_reads] transcript index of each read (NULL for wgs)
+  const int64_t *unit_len;      // [n_units]
+  const char *unit_names;       // [n_units][132] NUL-terminated ids
+  const uint8_t *read_minus;    // [n_reads] strand for trans (NULL for wgs)
+};
+
+// ---- launches (all asynchronous on `s`) ------------------------------------
+void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int64_t len, int64_t *tile_first, int64_t *tile_last,
+                              int64_t *carry_start, int64_t *carry_next, int keep_first_case, DeviceFlags *flags,
+                              hipStream_t s);
+void launch_header_wgs(const HeaderArgs &a, hipStream_t s);
+void launch_task_sort(const SortArgs &a, hipStream_t s);
+void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s);
+void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s);
+// exclusive scan of int64 (in-place allowed: out may equal in); tmp needs (n/1024+2) int64
+void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total, hipStream_t s);
+// cum[r] = pass-0 output bases of reads < r (exclusive scan), *total = their sum
+void launch_gather_pass0_scan(const int32_t *out_len, int64_t n_reads, int32_t pass_num, int64_t *cum, int64_t *tmp,
+                              int64_t *total, hipStream_t s);
+// flags->n_final = first read r with  before+cum[r] >= quota  or  before+cum[r]+rawlen[r] > quota (else n_reads)
+void launch_quota_cut(const int64_t *cum, const int32_t *rawlen, int64_t n_reads, int64_t len_total_before,
+                      int64_t quota, int force_all, DeviceFlags *flags, hipStream_t s);
+void launch_text_sizes(const TextArgs &a, DeviceFlags *flags, hipStream_t s);
+void launch_text_emit(const TextArgs &a, hipStream_t s);
+
+}  // namespace pbsim

@@ -1,0 +1,1133 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the pbsim3 hot path.
+//
+//   K0  k_hp_*          upper-case + per-base homopolymer length   (pbsim.cpp:1035-1065)
+//   K1  k_header_wgs    read header draw: length, accuracy, start  (pbsim.cpp:3793-3813)
+//   Ks  k_sort_*        bucket tasks by (accuracy class, length) so a workgroup
+//                       walks ONE class (its tables fit LDS) and the 64 lanes of a
+//                       wave finish together; per-wave scratch extents
+//   K2e k_walk_errhmm   the ERRHMM walk, one lane per (read, pass)  (pbsim.cpp:3835-3976)
+//   K2q k_walk_qshmm    the QSHMM walk                              (pbsim.cpp:2209-2282)
+//   K3  k_text_*        quota cut, exclusive scans, and FASTQ|SAM + MAF text
+//                       written in read order                       (pbsim.cpp:3977-4078)
+//
+// Integer/byte work end to end: no MFMA, no floating point in the walk except
+// the ordered double sum of quality error probabilities (pbsim.cpp:2309-2313).
+// Scratch is wave-transposed: dword c of lane l of a wave lives at
+// region[(c*64 + l)*4], so the lock-step MAF stores of a wave are one
+// contiguous 256-byte line per row.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "philox.h"
+
+namespace pbsim {
+
+namespace {
+
+constexpr uint32_t kATGC = 0x43475441u;  // "ATGC" little-endian (mut.ins_nt / sub_nt_n, pbsim.cpp:5485-5486)
+
+__device__ __forceinline__ uint32_t to_upper(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
+
+// revcomp()'s base map (pbsim.cpp:5853-5863): A<->T, G<->C, everything else unchanged
+__device__ __forceinline__ uint32_t complement(uint32_t c) {
+  uint32_t r = c;
+  r = (c == 'A') ? 'T' : r;
+  r = (c == 'T') ? 'A' : r;
+  r = (c == 'G') ? 'C' : r;
+  r = (c == 'C') ? 'G' : r;
+  return r;
+}
+
+// mut.sub_nt_{a,t,g,c} (pbsim.cpp:5481-5484) packed little-endian
+__device__ __forceinline__ uint32_t sub_table(uint32_t nt) {
+  uint32_t t = 0;
+  t = (nt == 'A') ? 0x00434754u : t;  // "TGC"
+  t = (nt == 'T') ? 0x00434741u : t;  // "AGC"
+  t = (nt == 'G') ? 0x00435441u : t;  // "ATC"
+  t = (nt == 'C') ? 0x00475441u : t;  // "ATG"
+  return t;
+}
+
+__device__ __forceinline__ int count_digit(int64_t v) {  // pbsim.cpp:5823-5835
+  int d = 1;
+  while (v >= 10) {
+    v /= 10;
+    d++;
+  }
+  return d;
+}
+
+__device__ __forceinline__ int dec_len(int64_t v) { return v < 0 ? 1 + count_digit(-v) : count_digit(v); }
+
+// SAM record literals (pbsim.cpp:4017-4027)
+#define PB_SAM_MID "\t4\t*\t0\t255\t*\t*\t0\t0\t"
+#define PB_SAM_IP "\tcx:i:3\tip:B:C"
+#define PB_SAM_PW "\tnp:i:1\tpw:B:C"
+#define PB_SAM_T1 "\tqs:i:0\tqe:i:"
+#define PB_SAM_T2 "\trq:f:"
+#define PB_SAM_T3 "\tsn:B:f,10.0,10.0,10.0,10.0\tzm:i:"
+#define PB_SAM_T4 "\tRG:Z:ffffffff\n"
+#define PB_LEN(s) ((int)sizeof(s) - 1)
+
+__device__ __forceinline__ int put_lit(char *dst, const char *lit, int n) {
+  for (int i = 0; i < n; i++) dst[i] = lit[i];
+  return n;
+}
+
+__device__ __forceinline__ int put_dec(char *dst, int64_t v) {
+  int neg = 0;
+  if (v < 0) {
+    dst[0] = '-';
+    dst++;
+    v = -v;
+    neg = 1;
+  }
+  const int d = count_digit(v);
+  for (int i = d - 1; i >= 0; i--) {
+    dst[i] = (char)('0' + (int)(v % 10));
+    v /= 10;
+  }
+  return d + neg;
+}
+
+// ---------------------------------------------------------------------------
+// K0: upper-case + homopolymer length.  A "break" at i starts a new run.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ref_char(const uint8_t *seq, int64_t i, int keep_first_case) {
+  const uint32_t c = seq[i];
+  if (keep_first_case && (i == 0 || seq[i - 1] == '\n')) return c;
+  return to_upper(c);
+}
+
+__global__ __launch_bounds__(256) void k_hp_breaks(const uint8_t *seq, int64_t len, int keep_first_case,
+                                                     int64_t *tile_first, int64_t *tile_last) {
+  __shared__ long long s_first, s_last;
+  if (threadIdx.x == 0) {
+    s_first = 0x7fffffffffffffffLL;
+    s_last = -1;
+  }
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kHpTile + (int64_t)threadIdx.x * 16;
+  long long first = 0x7fffffffffffffffLL, last = -1;
+  if (base < len) {
+    uint32_t prev = (base > 0) ? ref_char(seq, base - 1, keep_first_case) : 0x100u;
+    for (int k = 0; k < 16; k++) {
+      const int64_t i = base + k;
+      if (i >= len) break;
+      const uint32_t c = ref_char(seq, i, keep_first_case);
+      if (c != prev) {
+        if (first > i) first = i;
+        last = i;
+      }
+      prev = c;
+    }
+  }
+  if (last >= 0) {
+    atomicMin(&s_first, first);
+    atomicMax(&s_last, last);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tile_first[blockIdx.x] = s_first;
+    tile_last[blockIdx.x] = s_last;
+  }
+}
+
+// carry_start[t] = last break before tile t; carry_next[t] = first break after tile t
+__global__ void k_hp_carry(const int64_t *tile_first, const int64_t *tile_last, int64_t n_tiles, int64_t len,
+                           int64_t *carry_start, int64_t *carry_next) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t cur = 0;
+    for (int64_t t = 0; t < n_tiles; t++) {
+      carry_start[t] = cur;
+      if (tile_last[t] >= 0) cur = tile_last[t];
+    }
+  }
+  if (threadIdx.x == 64 && blockIdx.x == 0) {
+    int64_t cur = len;
+    for (int64_t t = n_tiles - 1; t >= 0; t--) {
+      carry_next[t] = cur;
+      if (tile_last[t] >= 0) cur = tile_first[t];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int64_t len, int keep_first_case,
+                                                    const int64_t *carry_start, const int64_t *carry_next,
+                                                    DeviceFlags *flags) {
+  __shared__ long long s_last[256], s_first[256];
+  __shared__ unsigned int s_hist[12];
+  const int tid = threadIdx.x;
+  if (tid < 12) s_hist[tid] = 0;
+  const int64_t base = (int64_t)blockIdx.x * kHpTile + (int64_t)tid * 16;
+  uint32_t c[16];
+  bool brk[16];
+  long long first = 0x7fffffffffffffffLL, last = -1;
+  int n = 0;
+  if (base < len) {
+    uint32_t prev = (base > 0) ? ref_char(seq, base - 1, keep_first_case) : 0x100u;
+    for (int k = 0; k < 16; k++) {
+      const int64_t i = base + k;
+      if (i >= len) break;
+      c[k] = ref_char(seq, i, keep_first_case);
+      brk[k] = (c[k] != prev);
+      if (brk[k]) {
+        if (first > i) first = i;
+        last = i;
+      }
+      prev = c[k];
+      n = k + 1;
+    }
+  }
+  s_last[tid] = last;
+  s_first[tid] = first;
+  __syncthreads();
+  // inclusive max-scan of s_last / inclusive suffix min-scan of s_first
+  for (int d = 1; d < 256; d <<= 1) {
+    const long long a = (tid >= d) ? s_last[tid - d] : -1;
+    const long long b = (tid + d < 256) ? s_first[tid + d] : 0x7fffffffffffffffLL;
+    __syncthreads();
+    if (a > s_last[tid]) s_last[tid] = a;
+    if (b < s_first[tid]) s_first[tid] = b;
+    __syncthreads();
+  }
+  if (n > 0) {
+    long long cur_start = (tid > 0 && s_last[tid - 1] >= 0) ? s_last[tid - 1] : carry_start[blockIdx.x];
+    long long nxt = (tid < 255 && s_first[tid + 1] != 0x7fffffffffffffffLL) ? s_first[tid + 1]
+                                                                            : carry_next[blockIdx.x];
+    long long start[16], next_start[16];
+    for (int k = 0; k < n; k++) {
+      if (brk[k]) cur_start = base + k;
+      start[k] = cur_start;
+    }
+    for (int k = n - 1; k >= 0; k--) {
+      next_start[k] = nxt;
+      if (brk[k]) nxt = base + k;
+    }
+    for (int k = 0; k < n; k++) {
+      const long long run = next_start[k] - start[k];
+      // nnum++ ; if (nnum > 11) nnum = 10  (pbsim.cpp:1045-1048): 11,13,.. -> 11 ; 12,14,.. -> 10
+      uint32_t v = (run <= 11) ? (uint32_t)run : ((run & 1) ? 11u : 10u);
+      if (c[k] == 'N') v = 1;  // pbsim.cpp:1050-1054
+      hp[base + k] = (uint8_t)v;
+      seq[base + k] = (uint8_t)c[k];
+      if (c[k] != '\n') atomicAdd(&s_hist[v], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid < 12 && s_hist[tid]) atomicAdd(&flags->hpfreq[tid], (unsigned long long)s_hist[tid]);
+}
+
+// ---------------------------------------------------------------------------
+// K1: read header (WGS).  pbsim.cpp:3793-3813 (= 2174-2194)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_header_wgs(HeaderArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_reads) return;
+  const uint32_t read = (uint32_t)(a.first_read + i);
+  const U4 w = header_block(a.seed, a.unit, read);
+  int64_t L = a.prob2len[(int64_t)(w.x % (uint32_t)a.len_rv) + 1];
+  const int32_t raw = (int32_t)L;
+  if (a.truncate_remaining >= 0 && L > a.truncate_remaining) {  // pbsim.cpp:3795-3800 (Q10)
+    L = a.truncate_remaining;
+    if (L < a.len_min) L = a.len_min;
+  }
+  const uint8_t acc = a.prob2acc[(int64_t)(w.y % (uint32_t)a.acc_rv) + 1];
+  int64_t off;
+  if (L >= a.ref_len) {  // pbsim.cpp:3804-3809
+    off = 0;
+    L = a.ref_len;
+  } else {
+    off = (int64_t)(w.z % (uint32_t)(a.ref_len - L + 1));
+  }
+  a.rawlen[i] = raw;
+  a.len[i] = (int32_t)L;
+  a.off[i] = (int32_t)off;
+  a.acc[i] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// Ks: counting sort of tasks by (class asc, length desc)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int sort_bin(int acc, int acc_lo, int len) {
+  int b = len >> kLenShift;
+  if (b > kLenBuckets - 1) b = kLenBuckets - 1;
+  return (acc - acc_lo) * kLenBuckets + (kLenBuckets - 1 - b);
+}
+
+__global__ __launch_bounds__(256) void k_sort_hist(SortArgs a) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n_reads) return;
+  atomicAdd(&a.hist[sort_bin(a.acc[r], a.acc_lo, a.len[r])], a.pass_num);
+}
+
+// one workgroup of 1024: per class an exclusive scan over its kLenBuckets bins;
+// class starts are rounded up to the walk workgroup size
+__global__ __launch_bounds__(1024) void k_sort_scan(SortArgs a) {
+  __shared__ int s_part[1024];
+  __shared__ int s_base;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  constexpr int kPer = kLenBuckets / 1024;
+  for (int c = 0; c < a.ncls; c++) {
+    int v[kPer], sum = 0;
+    for (int k = 0; k < kPer; k++) {
+      v[k] = a.hist[c * kLenBuckets + tid * kPer + k];
+      sum += v[k];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int t = (tid >= d) ? s_part[tid - d] : 0;
+      __syncthreads();
+      s_part[tid] += t;
+      __syncthreads();
+    }
+    const int base = s_base;
+    int run = base + s_part[tid] - sum;
+    for (int k = 0; k < kPer; k++) {
+      a.bin_start[c * kLenBuckets + tid * kPer + k] = run;
+      run += v[k];
+    }
+    __syncthreads();
+    if (tid == 1023) {
+      a.class_start[c] = base;
+      s_base = (base + s_part[1023] + kWG - 1) / kWG * kWG;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.class_start[a.ncls] = s_base;
+    a.flags->total_slots = s_base;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n_reads) return;
+  const int bin = sort_bin(a.acc[r], a.acc_lo, a.len[r]);
+  const int slot = a.bin_start[bin] + atomicAdd(&a.bin_cursor[bin], a.pass_num);
+  for (int h = 0; h < a.pass_num; h++) {
+    const int task = (int)(r * a.pass_num + h);
+    a.task_of_slot[slot + h] = task;
+    a.slot_of_task[task] = slot + h;
+  }
+}
+
+// per wave: scratch columns needed = 2*Lmax + pad (in dwords per lane)
+__global__ __launch_bounds__(256) void k_wave_cap(SortArgs a) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_waves = a.n_slots_max / 64;
+  if (w >= n_waves) return;
+  int lmax = -1;
+  if (w * 64 < a.flags->total_slots) {
+    for (int l = 0; l < 64; l++) {
+      const int task = a.task_of_slot[w * 64 + l];
+      if (task >= 0) {
+        const int L = a.len[task / a.pass_num];
+        lmax = (L > lmax) ? L : lmax;
+      }
+    }
+  }
+  a.wave_cap[w] = (lmax < 0) ? 0 : (2 * lmax + kScratchPad + 3) / 4;
+}
+
+__global__ __launch_bounds__(1024) void k_wave_scan(SortArgs a) {
+  __shared__ long long s_part[1024];
+  __shared__ long long s_base;
+  const int tid = threadIdx.x;
+  const int64_t n_waves = a.n_slots_max / 64;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int64_t w0 = 0; w0 < n_waves; w0 += 1024) {
+    const int64_t w = w0 + tid;
+    const long long bytes = (w < n_waves) ? (long long)a.wave_cap[w] * 256LL * a.regions : 0;
+    s_part[tid] = bytes;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const long long t = (tid >= d) ? s_part[tid - d] : 0;
+      __syncthreads();
+      s_part[tid] += t;
+      __syncthreads();
+    }
+    if (w < n_waves) a.wave_off[w] = s_base + s_part[tid] - bytes;
+    __syncthreads();
+    if (tid == 1023) s_base += s_part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.flags->scratch_need = s_base;
+    if (s_base > a.scratch_bytes) atomicOr(&a.flags->error, kErrScratchBudget);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2e: ERRHMM walk.  One lane per task (read, pass); the 4 waves of a workgroup
+// share one accuracy class whose tables were staged in LDS.
+//
+//   per step (= one MAF column `m`, pbsim.cpp:3850-3975):
+//     w = Philox(event=m, sub 0): w.x state | w.y deletion test | w.z emission | w.w nucleotide
+//     state  = q==0 ? init[w.x % init_rv] : tran[state][w.x % tran_rv[state]]      (:3853-3859, Q2)
+//     e      = (w.y%1000+1 <= del_thr[state][hp]) ? 3                                (:3861-3863)
+//              : emis_rv==0 ? w.z%3 : cdf(w.z % emis_rv + 1)                         (:3865-3870)
+//     below/above-range classes re-draw from sub-block 1                             (:3892-3925, Q3)
+//     e: 0 match | 1 substitution | 2 insertion | 3 deletion                         (:3929-3973)
+// ---------------------------------------------------------------------------
+struct StepOut {
+  uint32_t b, mr, mf;
+};
+
+__global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int64_t slot0 = (int64_t)blockIdx.x * kWG;
+  if (slot0 >= a.flags->total_slots) return;
+  if (a.flags->error & kErrScratchBudget) return;  // the pool cannot hold this batch: the host retries smaller
+  int cls = 0;
+  while (cls < a.ncls - 1 && slot0 >= a.class_start[cls + 1]) cls++;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.cls_blob + (size_t)cls * a.stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = tid; i < a.stride / 16; i += kWG) dst[i] = src[i];
+  }
+  __syncthreads();
+  const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
+  const uint32_t init_rv = hdr[1], mode = hdr[2], rate_mag = hdr[3];
+
+  const int64_t slot = slot0 + tid;
+  const int lane = tid & 63;
+  const int64_t wave = slot >> 6;
+  const int task = a.task_of_slot[slot];
+  const bool valid = task >= 0;
+  int L = 0;
+  int64_t off = 0;
+  uint32_t read_idx = 0, pass = 0;
+  if (valid) {
+    const int r = task / a.pass_num;
+    pass = (uint32_t)(task - r * a.pass_num);
+    read_idx = (uint32_t)(a.first_read + r);
+    L = a.len[r];
+    off = a.off[r];
+  }
+  const bool minus = valid && ((read_idx & 1u) == 0);  // pbsim.cpp:3820-3826 (Q9)
+  const int cap_dw = a.wave_cap[wave];
+  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
+  uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
+  uint32_t *read_row = maf_ref + (size_t)cap_dw * 64;
+  const int cap = 2 * L + kScratchPad;
+  const uint32_t *seq32 = reinterpret_cast<const uint32_t *>(a.ref.seq);
+  const uint32_t *hp32 = reinterpret_cast<const uint32_t *>(a.ref.hp);
+
+  int ro = 0, q = 0, m = 0;
+  uint32_t state = 0, tran_rv = 1;
+  uint32_t acc_r = 0, acc_f = 0, acc_rd = 0;
+  int nsub = 0, nins = 0, ndel = 0;
+  int64_t cur_wi = -1;
+  uint32_t wseq = 0, whp = 0;
+  bool active = valid && L > 0;
+  int group = 0;
+
+  while (__any(active)) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (active) {
+        const int64_t p = minus ? (off + L - 1 - ro) : (off + ro);
+        const int64_t wi = p >> 2;
+        if (wi != cur_wi) {
+          wseq = seq32[wi];
+          whp = hp32[wi];
+          cur_wi = wi;
+        }
+        const uint32_t sh = ((uint32_t)p & 3u) * 8u;
+        uint32_t nt = (wseq >> sh) & 0xffu;
+        const uint32_t hp = (whp >> sh) & 0xffu;
+        if (minus) nt = complement(nt);
+        const bool acgt = (nt == 'A') | (nt == 'C') | (nt == 'G') | (nt == 'T');
+
+        uint32_t e = 0;
+        U4 w = U4{0, 0, 0, 0}, v = U4{0, 0, 0, 0};
+        if (mode != kModeVerbatim) {
+          w = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 0u);
+          uint32_t mod, base;
+          if (q == 0) {  // Q2: re-initialise while nothing has been emitted yet
+            mod = init_rv;
+            base = a.init_off;
+          } else {
+            mod = tran_rv;
+            base = a.tran_off + (state - 1u) * 1000u;
+          }
+          mod = mod ? mod : 1u;
+          state = lds[base + w.x % mod];
+          const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + state * 32u);
+          tran_rv = row[0];
+          const uint32_t emis_rv = row[1], e0 = row[2], e1 = row[3];
+          const uint32_t thr = row[4 + (hp < 12u ? hp : 11u)];
+          if (w.y % 1000u + 1u <= thr) {
+            e = 3;
+          } else if (emis_rv == 0) {
+            e = w.z % 3u;
+          } else {
+            const uint32_t i = w.z % emis_rv + 1u;
+            e = (uint32_t)(i > e0) + (uint32_t)(i > e1);
+          }
+          const bool need1 =
+              (mode == kModeBelow && e == 0) || (mode == kModeAbove && e != 0) || (!acgt && e == 1);
+          if (need1) {
+            v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 1u);
+            if (mode == kModeBelow && e == 0) {
+              if (v.x % 100u + 1u <= rate_mag) e = v.y % 3u + 1u;
+            } else if (mode == kModeAbove && e != 0) {
+              if (v.x % 100u + 1u <= rate_mag) e = 0;
+            }
+          }
+        }
+        uint32_t b = nt;
+        if (e == 1) {
+          b = acgt ? ((sub_table(nt) >> ((w.w % 3u) * 8u)) & 0xffu) : ((kATGC >> ((v.z & 3u) * 8u)) & 0xffu);
+          nsub++;
+        } else if (e == 2) {
+          const uint32_t k = w.w & 7u;
+          b = (k >= 4u) ? nt : ((kATGC >> (k * 8u)) & 0xffu);
+          nins++;
+        } else if (e == 3) {
+          ndel++;
+        }
+        const uint32_t mr = (e == 3) ? (uint32_t)'-' : b;
+        const uint32_t mf = (e == 2) ? (uint32_t)'-' : nt;
+        acc_r |= mr << (8 * j);
+        acc_f |= mf << (8 * j);
+        if (e != 3) {
+          acc_rd |= b << ((q & 3) * 8);
+          q++;
+          if ((q & 3) == 0) {
+            read_row[(size_t)((q >> 2) - 1) * 64] = acc_rd;
+            acc_rd = 0;
+          }
+        }
+        ro += (e != 2);
+        m++;
+        if (m >= cap) {
+          atomicOr(&a.flags->error, kErrScratchOverflow);
+          ro = L;
+        }
+        active = ro < L;
+      }
+    }
+    if (valid && m > group * 4) {
+      maf_read[(size_t)group * 64] = acc_r;
+      maf_ref[(size_t)group * 64] = acc_f;
+    }
+    acc_r = 0;
+    acc_f = 0;
+    group++;
+  }
+  if (valid) {
+    if (q & 3) read_row[(size_t)(q >> 2) * 64] = acc_rd;
+    a.out_len[task] = q;
+    a.maf_len[task] = m;
+    a.nsub[task] = nsub;
+    a.nins[task] = nins;
+    a.ndel[task] = ndel;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2q: QSHMM walk (pbsim.cpp:2209-2282).  Column m is either an emitted base or
+// a deleted reference base.  Every column m >= 1 first takes the deletion test
+// of sub-block 2 (the inner while of :2268-2281); a column that is not deleted
+// emits a base from sub-block 0: w.x state | w.y quality | w.z error class |
+// w.w nucleotide; sub-block 1 w.x = non-ACGT substitution.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int64_t slot0 = (int64_t)blockIdx.x * kWG;
+  if (slot0 >= a.flags->total_slots) return;
+  if (a.flags->error & kErrScratchBudget) return;  // the pool cannot hold this batch: the host retries smaller
+  int cls = 0;
+  while (cls < a.ncls - 1 && slot0 >= a.class_start[cls + 1]) cls++;
+  // LDS: [class blob | sub_thre 94 u32 | ins_thre 94 u32 | del_thr 94*12 u32 | qprob 94 f64]
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.cls_blob + (size_t)cls * a.stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = tid; i < a.stride / 16; i += kWG) dst[i] = src[i];
+  }
+  uint32_t *s_sub = reinterpret_cast<uint32_t *>(lds + a.stride);
+  uint32_t *s_ins = s_sub + 96;
+  uint32_t *s_del = s_ins + 96;
+  double *s_qprob = reinterpret_cast<double *>(s_del + 94 * 12);
+  for (int i = tid; i < 94; i += kWG) {
+    s_sub[i] = a.sub_thre[i];
+    s_ins[i] = a.ins_thre[i];
+    s_qprob[i] = a.qprob[i];
+  }
+  for (int i = tid; i < 94 * 12; i += kWG) s_del[i] = a.del_thr[i];
+  __syncthreads();
+  const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
+  const uint32_t init_rv = hdr[1], has_model = hdr[2], freq_rv = hdr[3];
+  const uint16_t *rvs = reinterpret_cast<const uint16_t *>(lds + a.rv_off);
+
+  const int64_t slot = slot0 + tid;
+  const int lane = tid & 63;
+  const int64_t wave = slot >> 6;
+  const int task = a.task_of_slot[slot];
+  const bool valid = task >= 0;
+  int L = 0;
+  int64_t off = 0;
+  uint32_t read_idx = 0, pass = 0;
+  if (valid) {
+    const int r = task / a.pass_num;
+    pass = (uint32_t)(task - r * a.pass_num);
+    read_idx = (uint32_t)(a.first_read + r);
+    L = a.len[r];
+    off = a.off[r];
+  }
+  const bool minus = valid && ((read_idx & 1u) == 0);
+  const int cap_dw = a.wave_cap[wave];
+  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
+  uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
+  uint32_t *read_row = maf_ref + (size_t)cap_dw * 64;
+  uint32_t *qual_row = read_row + (size_t)cap_dw * 64;
+  const int cap = 2 * L + kScratchPad;
+
+  int ro = 0, q = 0, m = 0;
+  uint32_t state = 0, last_q = 0;
+  uint32_t acc_r = 0, acc_f = 0, acc_rd = 0, acc_q = 0;
+  int nsub = 0, nins = 0, ndel = 0;
+  double qsum = 0.0;
+  bool active = valid && L > 0;
+  int group = 0;
+
+  while (__any(active)) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (active) {
+        const int64_t p = minus ? (off + L - 1 - ro) : (off + ro);
+        uint32_t nt = a.ref.seq[p];
+        if (minus) nt = complement(nt);
+        bool deleted = false;
+        if (m > 0) {
+          // hp of the previously consumed reference base; none yet -> slot 0 (Q15)
+          uint32_t hp = 0;
+          if (ro > 0) hp = a.ref.hp[minus ? (p + 1) : (p - 1)];
+          const U4 d = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 2u);
+          deleted = (d.x % 1000000u) < s_del[last_q * 12u + (hp < 12u ? hp : 11u)];
+        }
+        uint32_t mr, mf;
+        if (deleted) {  // pbsim.cpp:2272-2277
+          mr = '-';
+          mf = nt;
+          ro++;
+          ndel++;
+        } else {
+          const U4 w = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 0u);
+          uint32_t qv;
+          if (has_model) {
+            uint32_t mod, base;
+            if (q == 0) {
+              mod = init_rv;
+              base = a.init_off;
+            } else {
+              mod = rvs[2 * state];
+              base = a.tran_off + (state - 1u) * 100u;
+            }
+            mod = mod ? mod : 1u;
+            state = lds[base + w.x % mod];
+            uint32_t emod = rvs[2 * state + 1];
+            emod = emod ? emod : 1u;
+            qv = lds[a.emis_off + (state - 1u) * 100u + w.y % emod];
+          } else {
+            qv = lds[a.freq_off + w.y % (freq_rv ? freq_rv : 1u)];
+          }
+          last_q = qv;
+          qsum += s_qprob[qv];
+          const uint32_t x = w.z % 1000000u;
+          uint32_t b = nt;
+          mf = nt;
+          if (x < s_sub[qv]) {  // pbsim.cpp:2233-2249
+            const bool acgt = (nt == 'A') | (nt == 'C') | (nt == 'G') | (nt == 'T');
+            if (acgt) {
+              b = (sub_table(nt) >> ((w.w % 3u) * 8u)) & 0xffu;
+            } else {
+              const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 1u);
+              b = (kATGC >> ((v.x & 3u) * 8u)) & 0xffu;
+            }
+            nsub++;
+            ro++;
+          } else if (x < s_ins[qv]) {  // pbsim.cpp:2250-2258
+            const uint32_t k = w.w & 7u;
+            b = (k >= 4u) ? nt : ((kATGC >> (k * 8u)) & 0xffu);
+            mf = '-';
+            nins++;
+          } else {
+            ro++;
+          }
+          mr = b;
+          acc_rd |= b << ((q & 3) * 8);
+          acc_q |= (qv + 33u) << ((q & 3) * 8);
+          q++;
+          if ((q & 3) == 0) {
+            read_row[(size_t)((q >> 2) - 1) * 64] = acc_rd;
+            qual_row[(size_t)((q >> 2) - 1) * 64] = acc_q;
+            acc_rd = 0;
+            acc_q = 0;
+          }
+        }
+        acc_r |= mr << (8 * j);
+        acc_f |= mf << (8 * j);
+        m++;
+        if (m >= cap) {
+          atomicOr(&a.flags->error, kErrScratchOverflow);
+          ro = L;
+        }
+        active = ro < L;
+      }
+    }
+    if (valid && m > group * 4) {
+      maf_read[(size_t)group * 64] = acc_r;
+      maf_ref[(size_t)group * 64] = acc_f;
+    }
+    acc_r = 0;
+    acc_f = 0;
+    group++;
+  }
+  if (valid) {
+    if (q & 3) {
+      read_row[(size_t)(q >> 2) * 64] = acc_rd;
+      qual_row[(size_t)(q >> 2) * 64] = acc_q;
+    }
+    a.out_len[task] = q;
+    a.maf_len[task] = m;
+    a.nsub[task] = nsub;
+    a.nins[task] = nins;
+    a.ndel[task] = ndel;
+    a.qsum[task] = qsum;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan of int64 (3 phases)
+// ---------------------------------------------------------------------------
+constexpr int kScanTile = 2048;  // 256 threads x 8
+
+__global__ __launch_bounds__(256) void k_scan_sums(const int64_t *in, int64_t n, int64_t *sums) {
+  __shared__ long long s[256];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 8;
+  long long t = 0;
+  for (int k = 0; k < 8; k++)
+    if (base + k < n) t += in[base + k];
+  s[threadIdx.x] = t;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_single(int64_t *sums, int64_t n, int64_t *total) {
+  __shared__ long long s_part[1024];
+  __shared__ long long s_base;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int64_t i0 = 0; i0 < n; i0 += 1024) {
+    const int64_t i = i0 + tid;
+    const long long v = (i < n) ? sums[i] : 0;
+    s_part[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const long long t = (tid >= d) ? s_part[tid - d] : 0;
+      __syncthreads();
+      s_part[tid] += t;
+      __syncthreads();
+    }
+    if (i < n) sums[i] = s_base + s_part[tid] - v;
+    __syncthreads();
+    if (tid == 1023) s_base += s_part[1023];
+    __syncthreads();
+  }
+  if (tid == 0 && total) *total = s_base;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const int64_t *in, int64_t *out, int64_t n, const int64_t *sums) {
+  __shared__ long long s[256];
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)tid * 8;
+  long long v[8], t = 0;
+  for (int k = 0; k < 8; k++) {
+    v[k] = (base + k < n) ? in[base + k] : 0;
+    t += v[k];
+  }
+  s[tid] = t;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const long long x = (tid >= d) ? s[tid - d] : 0;
+    __syncthreads();
+    s[tid] += x;
+    __syncthreads();
+  }
+  long long run = sums[blockIdx.x] + s[tid] - t;
+  for (int k = 0; k < 8; k++) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// quota cut (pbsim.cpp:3792-3800, 3989-3991)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_pass0(const int32_t *out_len, int64_t n_reads, int32_t pass_num,
+                                                        int64_t *cum) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r < n_reads) cum[r] = out_len[r * pass_num];
+}
+
+__global__ void k_quota_init(DeviceFlags *flags, int64_t n_reads) { flags->n_final = n_reads; }
+
+__global__ __launch_bounds__(256) void k_quota_find(const int64_t *cum, const int32_t *rawlen, int64_t n_reads,
+                                                      int64_t before, int64_t quota, DeviceFlags *flags) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_reads) return;
+  const int64_t t = before + cum[r];
+  if (!(t < quota) || (t + rawlen[r] > quota)) atomicMin((long long *)&flags->n_final, (long long)r);
+}
+
+// ---------------------------------------------------------------------------
+// K3: text.  Sizes per task, then one workgroup per task writes the bytes.
+// ---------------------------------------------------------------------------
+struct TaskText {
+  int idl;        // strlen(id)
+  int q0;         // 1 + count_digit(readnum)        (digit_num2[0], pbsim.cpp:4031)
+  int r0;         // 3 ("ref") or strlen(transcript id)
+  int w0, w1, w2, w3, r1, r2, r3, q2;
+  int64_t start0, span, reflen, readnum;
+};
+
+__device__ __forceinline__ int id_length(const TextArgs &a, int64_t readnum, int pass) {
+  int n = a.id_prefix_len + 1 + count_digit(readnum);
+  if (a.is_wgs) n += count_digit((int64_t)a.unit);
+  if (a.pass_num > 1) n += 1 + count_digit(pass);
+  return n;
+}
+
+// id = "<prefix><rec>_<n>" | "<prefix><rec>/<n>/<h>" (wgs, pbsim.cpp:4013,4016)
+//      "<prefix>_<n>"      | "<prefix>/<n>/<h>"      (trans/templ, :4703,4706)
+__device__ __forceinline__ int put_id(char *dst, const TextArgs &a, int64_t readnum, int pass) {
+  int n = 0;
+  for (int i = 0; i < a.id_prefix_len; i++) dst[n++] = a.id_prefix[i];
+  if (a.is_wgs) n += put_dec(dst + n, (int64_t)a.unit);
+  dst[n++] = (a.pass_num > 1) ? '/' : '_';
+  n += put_dec(dst + n, readnum);
+  if (a.pass_num > 1) {
+    dst[n++] = '/';
+    n += put_dec(dst + n, pass);
+  }
+  return n;
+}
+
+__device__ __forceinline__ void task_text(const TextArgs &a, int64_t r, int pass, int q, TaskText *t) {
+  t->readnum = a.first_read + r;
+  t->idl = id_length(a, t->readnum, pass);
+  t->q0 = 1 + count_digit(t->readnum);
+  t->start0 = a.off[r];
+  t->span = a.len[r];
+  if (a.read_unit) {
+    const int u = a.read_unit[r];
+    t->reflen = a.unit_len[u];
+    int n = 0;
+    const char *nm = a.unit_names + (size_t)u * 132;
+    while (nm[n]) n++;
+    t->r0 = n;
+  } else {
+    t->reflen = a.ref_len;
+    t->r0 = 3;
+  }
+  t->r1 = count_digit(t->start0);
+  t->r2 = count_digit(t->span);
+  t->r3 = count_digit(t->reflen);
+  t->q2 = count_digit(q);
+  t->w0 = max(t->r0, t->q0);
+  t->w1 = max(t->r1, 1);
+  t->w2 = max(t->r2, t->q2);
+  t->w3 = max(t->r3, t->q2);
+}
+
+__global__ __launch_bounds__(256) void k_text_sizes(TextArgs a, DeviceFlags *flags) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_tasks = a.n_reads * a.pass_num;
+  if (t >= n_tasks) return;
+  const int64_t r = t / a.pass_num;
+  const int pass = (int)(t - r * a.pass_num);
+  const int q = a.out_len[t], m = a.maf_len[t];
+  TaskText x;
+  task_text(a, r, pass, q, &x);
+  int64_t rt;
+  if (a.pass_num == 1) {
+    rt = 2LL * x.idl + 2LL * q + 6;  // "@id\n" seq "\n+id\n" qual "\n"
+  } else {
+    // pbsim.cpp:4017-4027
+    rt = (int64_t)x.idl + PB_LEN(PB_SAM_MID) + q + 1 + q + PB_LEN(PB_SAM_IP) + 2LL * q + PB_LEN(PB_SAM_PW) + 2LL * q +
+         PB_LEN(PB_SAM_T1) + dec_len((int64_t)q - 1) + PB_LEN(PB_SAM_T2) + a.rq_len + PB_LEN(PB_SAM_T3) +
+         count_digit(x.readnum) + PB_LEN(PB_SAM_T4);
+  }
+  const int64_t mt = (11LL + x.w0 + x.w1 + x.w2 + x.w3 + m) + (10LL + x.idl + (x.w0 - x.q0) + x.w1 + x.w2 + x.w3 + m);
+  a.read_text_len[t] = rt;
+  a.maf_text_len[t] = mt;
+  atomicAdd((unsigned long long *)&flags->sums[3], (unsigned long long)q);
+  atomicAdd((unsigned long long *)&flags->sums[4], (unsigned long long)a.len[r]);
+  atomicAdd((unsigned long long *)&flags->sums[5], (unsigned long long)m);
+}
+
+// byte i of a wave-transposed scratch row
+__device__ __forceinline__ uint32_t row_byte(const uint8_t *row, int64_t i) {
+  return row[(i >> 2) * 256 + (i & 3)];
+}
+
+__global__ __launch_bounds__(256) void k_text_emit(TextArgs a) {
+  __shared__ char s_a[384], s_b[384];
+  __shared__ int s_la, s_lb;
+  const int64_t t = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t r = t / a.pass_num;
+  const int pass = (int)(t - r * a.pass_num);
+  const int q = a.out_len[t], m = a.maf_len[t];
+  const int slot = a.slot_of_task[t];
+  const int64_t wave = slot >> 6;
+  const int lane = slot & 63;
+  const size_t region = (size_t)a.wave_cap[wave] * 256;
+  const uint8_t *maf_read = a.scratch + a.wave_off[wave] + (size_t)lane * 4;
+  const uint8_t *maf_ref = maf_read + region;
+  const uint8_t *read_row = maf_ref + region;
+  const uint8_t *qual_row = read_row + region;
+  const int64_t readnum = a.first_read + r;
+  const bool minus = a.read_minus ? (a.read_minus[r] != 0) : ((readnum & 1) == 0);
+
+  // ---------------- FASTQ / SAM ----------------
+  char *out = a.read_text + a.read_text_off[t];
+  if (a.pass_num == 1) {
+    if (tid == 0) {
+      int n = 0;
+      s_a[n++] = '@';
+      n += put_id(s_a + n, a, readnum, pass);
+      s_a[n++] = '\n';
+      s_la = n;
+    }
+    __syncthreads();
+    const int la = s_la;  // "@id\n"; the '+' line reuses it
+    for (int i = tid; i < la; i += 256) {
+      out[i] = s_a[i];
+      out[la + q + 1 + i] = (i == 0) ? '+' : s_a[i];
+    }
+    for (int i = tid; i < q; i += 256) {
+      out[la + i] = (char)row_byte(read_row, i);
+      out[2 * la + q + 1 + i] = a.is_qs ? (char)row_byte(qual_row, i) : '!';  // pbsim.cpp:4007-4010
+    }
+    if (tid == 0) {
+      out[la + q] = '\n';
+      out[2 * la + 2 * q + 1] = '\n';
+    }
+  } else {
+    if (tid == 0) {
+      int n = put_id(s_a, a, readnum, pass);
+      n += put_lit(s_a + n, PB_SAM_MID, PB_LEN(PB_SAM_MID));
+      s_la = n;
+      n = put_lit(s_b, PB_SAM_T1, PB_LEN(PB_SAM_T1));
+      n += put_dec(s_b + n, (int64_t)q - 1);
+      n += put_lit(s_b + n, PB_SAM_T2, PB_LEN(PB_SAM_T2));
+      for (int i = 0; i < a.rq_len; i++) s_b[n++] = a.rq_text[i];
+      n += put_lit(s_b + n, PB_SAM_T3, PB_LEN(PB_SAM_T3));
+      n += put_dec(s_b + n, readnum);
+      n += put_lit(s_b + n, PB_SAM_T4, PB_LEN(PB_SAM_T4));
+      s_lb = n;
+    }
+    __syncthreads();
+    const int la = s_la, lb = s_lb;
+    const char *ip = PB_SAM_IP;
+    const char *pw = PB_SAM_PW;
+    constexpr int kTagLen = PB_LEN(PB_SAM_IP);
+    static_assert(PB_LEN(PB_SAM_IP) == PB_LEN(PB_SAM_PW), "tag literals");
+    char *o = out;
+    for (int i = tid; i < la; i += 256) o[i] = s_a[i];
+    o += la;
+    for (int i = tid; i < q; i += 256) o[i] = (char)row_byte(read_row, i);
+    o += q;
+    if (tid == 0) o[0] = '\t';
+    o += 1;
+    for (int i = tid; i < q; i += 256) o[i] = a.is_qs ? (char)row_byte(qual_row, i) : '!';
+    o += q;
+    for (int i = tid; i < kTagLen; i += 256) o[i] = ip[i];
+    o += kTagLen;
+    for (int i = tid; i < 2 * q; i += 256) o[i] = (i & 1) ? '9' : ',';
+    o += 2 * q;
+    for (int i = tid; i < kTagLen; i += 256) o[i] = pw[i];
+    o += kTagLen;
+    for (int i = tid; i < 2 * q; i += 256) o[i] = (i & 1) ? '9' : ',';
+    o += 2 * q;
+    for (int i = tid; i < lb; i += 256) o[i] = s_b[i];
+  }
+  __syncthreads();
+
+  // ---------------- MAF (pbsim.cpp:4030-4078) ----------------
+  if (tid == 0) {
+    TaskText x;
+    task_text(a, r, pass, q, &x);
+    int n = 0;
+    s_a[n++] = 'a';
+    s_a[n++] = '\n';
+    s_a[n++] = 's';
+    s_a[n++] = ' ';
+    if (a.read_unit) {
+      const char *nm = a.unit_names + (size_t)a.read_unit[r] * 132;
+      for (int i = 0; i < x.r0; i++) s_a[n++] = nm[i];
+    } else {
+      s_a[n++] = 'r';
+      s_a[n++] = 'e';
+      s_a[n++] = 'f';
+    }
+    for (int i = x.r0; i < x.w0; i++) s_a[n++] = ' ';
+    for (int i = x.r1; i < x.w1; i++) s_a[n++] = ' ';
+    s_a[n++] = ' ';
+    n += put_dec(s_a + n, x.start0);
+    for (int i = x.r2; i < x.w2; i++) s_a[n++] = ' ';
+    s_a[n++] = ' ';
+    n += put_dec(s_a + n, x.span);
+    s_a[n++] = ' ';
+    s_a[n++] = '+';
+    for (int i = x.r3; i < x.w3; i++) s_a[n++] = ' ';
+    s_a[n++] = ' ';
+    n += put_dec(s_a + n, x.reflen);
+    s_a[n++] = ' ';
+    s_la = n;
+    n = 0;
+    s_b[n++] = '\n';
+    s_b[n++] = 's';
+    s_b[n++] = ' ';
+    n += put_id(s_b + n, a, readnum, pass);
+    for (int i = x.q0; i < x.w0; i++) s_b[n++] = ' ';
+    for (int i = 1; i < x.w1; i++) s_b[n++] = ' ';
+    s_b[n++] = ' ';
+    s_b[n++] = '0';
+    for (int i = x.q2; i < x.w2; i++) s_b[n++] = ' ';
+    s_b[n++] = ' ';
+    n += put_dec(s_b + n, q);
+    s_b[n++] = ' ';
+    s_b[n++] = minus ? '-' : '+';
+    for (int i = x.q2; i < x.w3; i++) s_b[n++] = ' ';
+    s_b[n++] = ' ';
+    n += put_dec(s_b + n, q);
+    s_b[n++] = ' ';
+    s_lb = n;
+  }
+  __syncthreads();
+  {
+    const int la = s_la, lb = s_lb;
+    char *o = a.maf_text + a.maf_text_off[t];
+    for (int i = tid; i < la; i += 256) o[i] = s_a[i];
+    for (int i = tid; i < lb; i += 256) o[la + m + i] = s_b[i];
+    char *o1 = o + la, *o2 = o + la + m + lb;
+    // '-' strand rows go back to forward orientation (revcomp, pbsim.cpp:3981-3984)
+    for (int i = tid; i < m; i += 256) {
+      const int64_t src = minus ? (m - 1 - i) : i;
+      uint32_t f = row_byte(maf_ref, src), g = row_byte(maf_read, src);
+      if (minus) {
+        f = complement(f);
+        g = complement(g);
+      }
+      o1[i] = (char)f;
+      o2[i] = (char)g;
+    }
+    if (tid == 0) {
+      o2[m] = '\n';
+      o2[m + 1] = '\n';
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------
+static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int64_t len, int64_t *tile_first, int64_t *tile_last,
+                              int64_t *carry_start, int64_t *carry_next, int keep_first_case, DeviceFlags *flags,
+                              hipStream_t s) {
+  const int64_t n_tiles = (len + kHpTile - 1) / kHpTile;
+  if (n_tiles == 0) return;
+  hipLaunchKernelGGL(k_hp_breaks, dim3((unsigned)n_tiles), dim3(256), 0, s, seq, len, keep_first_case, tile_first,
+                     tile_last);
+  hipLaunchKernelGGL(k_hp_carry, dim3(1), dim3(128), 0, s, tile_first, tile_last, n_tiles, len, carry_start,
+                     carry_next);
+  hipLaunchKernelGGL(k_hp_final, dim3((unsigned)n_tiles), dim3(256), 0, s, seq, hp, len, keep_first_case,
+                     carry_start, carry_next, flags);
+}
+
+void launch_header_wgs(const HeaderArgs &a, hipStream_t s) {
+  if (a.n_reads <= 0) return;
+  hipLaunchKernelGGL(k_header_wgs, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
+}
+
+void launch_task_sort(const SortArgs &a, hipStream_t s) {
+  const size_t nbins = (size_t)a.ncls * kLenBuckets;
+  (void)hipMemsetAsync(a.hist, 0, nbins * sizeof(int32_t), s);
+  (void)hipMemsetAsync(a.bin_cursor, 0, nbins * sizeof(int32_t), s);
+  (void)hipMemsetAsync(a.task_of_slot, 0xff, (size_t)a.n_slots_max * sizeof(int32_t), s);
+  hipLaunchKernelGGL(k_sort_hist, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_wave_cap, dim3(blocks_for(a.n_slots_max / 64, 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_wave_scan, dim3(1), dim3(1024), 0, s, a);
+}
+
+void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_errhmm, dim3((unsigned)(n_slots_max / kWG)), dim3(kWG), lds_bytes, s, a);
+}
+
+void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s) {
+  hipLaunchKernelGGL(k_walk_qshmm, dim3((unsigned)(n_slots_max / kWG)), dim3(kWG), lds_bytes, s, a);
+}
+
+void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total,
+                               hipStream_t s) {
+  if (n <= 0) {
+    if (total) (void)hipMemsetAsync(total, 0, sizeof(int64_t), s);
+    return;
+  }
+  const unsigned nb = blocks_for(n, kScanTile);
+  hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, s, in, n, tmp);
+  hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, s, tmp, (int64_t)nb, total);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, out, n, (const int64_t *)tmp);
+}
+
+void launch_quota_cut(const int64_t *cum, const int32_t *rawlen, int64_t n_reads, int64_t len_total_before,
+                      int64_t quota, int force_all, DeviceFlags *flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_quota_init, dim3(1), dim3(1), 0, s, flags, n_reads);
+  if (!force_all && n_reads > 0)
+    hipLaunchKernelGGL(k_quota_find, dim3(blocks_for(n_reads, 256)), dim3(256), 0, s, cum, rawlen, n_reads,
+                       len_total_before, quota, flags);
+}
+
+void launch_gather_pass0_scan(const int32_t *out_len, int64_t n_reads, int32_t pass_num, int64_t *cum, int64_t *tmp,
+                              int64_t *total, hipStream_t s) {
+  if (n_reads > 0)
+    hipLaunchKernelGGL(k_gather_pass0, dim3(blocks_for(n_reads, 256)), dim3(256), 0, s, out_len, n_reads, pass_num,
+                       cum);
+  launch_exclusive_scan_i64(cum, cum, n_reads, tmp, total, s);
+}
+
+void launch_text_sizes(const TextArgs &a, DeviceFlags *flags, hipStream_t s) {
+  const int64_t n_tasks = a.n_reads * a.pass_num;
+  if (n_tasks <= 0) return;
+  hipLaunchKernelGGL(k_text_sizes, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, a, flags);
+}
+
+void launch_text_emit(const TextArgs &a, hipStream_t s) {
+  const int64_t n_tasks = a.n_reads * a.pass_num;
+  if (n_tasks <= 0) return;
+  hipLaunchKernelGGL(k_text_emit, dim3((unsigned)n_tasks), dim3(256), 0, s, a);
+}
+
+}  // namespace pbsim
