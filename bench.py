@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- simulated bases/s of the HIP hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): --strategy wgs --method errhmm --errhmm
+ERRHMM-ONT.model, default length/accuracy parameters, on a synthetic uniform
+ACGT genome resident in HBM.  One "step" = one batch of reads through the whole
+path: header draw -> (class,length) bucketing -> ERRHMM walk -> quota scan ->
+FASTQ + MAF text emitted into HBM buffers.  Inputs are resident before the timed
+region; outputs stay in HBM (PCIe-inclusive rate: DESIGN.md).
+
+N > 1 (torchrun, one rank per GPU): rank 0's genome is broadcast over RCCL,
+reads shard by contiguous read-index block per rank, the pass-0 base counts are
+all-gathered to place each rank's quota prefix, and the statistics counters are
+all-reduced.  Weak scaling: every rank walks a full batch per step.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+RECORD_LEN = 750_000_000     # one of the 4 records of the 3 Gbp genome (<= REF_SEQ_LEN_MAX, pbsim.cpp:24)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(sample_bp=4_000_000):
+    """Reference pbsim (oracle/_ref/pbsim_ref, compiled from /root/reference in the
+    build container) or, if absent, the C oracle in glibc mode, timed single-threaded
+    on a bounded sample of the same workload with compression bypassed."""
+    import numpy as np
+    import harness
+    ref = harness.REF_GLIBC if os.path.exists(harness.REF_GLIBC) else None
+    if ref is None:
+        harness.build_oracle()
+    with tempfile.TemporaryDirectory() as td:
+        rng = np.random.default_rng(1)
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, sample_bp)]
+        fa = os.path.join(td, "g.fa")
+        with open(fa, "wb") as f:
+            f.write(b">chr1\n")
+            lines = seq.reshape(-1, 80)
+            out = np.concatenate([lines, np.full((lines.shape[0], 1), 10, np.uint8)], axis=1)
+            f.write(out.tobytes())
+        model = harness.model_path("ERRHMM-ONT.model")
+        args = ["--strategy", "wgs", "--method", "errhmm", "--errhmm", model, "--genome", fa,
+                "--depth", "20", "--seed", "1", "--prefix", os.path.join(td, "out")]
+        env = dict(os.environ)
+        if ref:
+            stubs = os.path.join(td, "stubs")
+            harness.make_stubs(stubs)
+            env["PATH"] = stubs + ":" + env["PATH"]
+            cmd = [ref] + args
+        else:
+            cmd = [harness.ORACLE] + args + ["--rng", "glibc"]
+        t0 = time.time()
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        dt = time.time() - t0
+        if p.returncode != 0:
+            return None
+        bases = 0
+        for fn in os.listdir(td):
+            if fn.startswith("out") and (fn.endswith(".fq") or fn.endswith(".fq.gz")):
+                with open(os.path.join(td, fn), "rb") as f:
+                    for i, line in enumerate(f):
+                        if i % 4 == 1:
+                            bases += len(line) - 1
+    return {"value": bases / dt, "unit": "bases/s", "cores": 1, "kind": "reference" if ref else "port",
+            "sample": f"{sample_bp // 1_000_000} Mbp uniform genome x depth 20, ERRHMM-ONT, seed 1, "
+                      f"{bases} bases in {dt:.1f}s, gzip bypassed (cat)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--record-len", type=int, default=RECORD_LEN)
+    ap.add_argument("--scratch-gib", type=float, default=32.0)
+    ap.add_argument("--batch-reads", type=int, default=0, help="reads per step per GPU (0 = what the scratch pool holds)")
+    ap.add_argument("--model", default="ERRHMM-ONT.model")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import harness
+    import pbsim3_amd as P
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- inputs resident in HBM: genome record (rank 0 generates, RCCL broadcasts) ----
+    G = a.record_len
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    if rank == 0:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1)
+        genome = lut[torch.randint(0, 4, (G,), dtype=torch.uint8, device=dev, generator=gen).long()] \
+            if G <= 64_000_000 else torch.cat([
+                lut[torch.randint(0, 4, (min(64_000_000, G - o),), dtype=torch.uint8, device=dev, generator=gen).long()]
+                for o in range(0, G, 64_000_000)])
+    else:
+        genome = torch.empty(G, dtype=torch.uint8, device=dev)
+    if world > 1:
+        dist.broadcast(genome, src=0)          # C1: reference broadcast over xGMI
+    torch.cuda.synchronize()
+
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=20.0)
+    ctx = P.Context(p, local)
+    ctx.set_scratch_bytes(int(a.scratch_gib * (1 << 30)))
+    ctx.load_errhmm(harness.model_path(a.model))
+    ctx.set_reference_device(genome.data_ptr(), G, 1)
+    del genome
+    torch.cuda.empty_cache()
+    B = a.batch_reads or ctx.batch_capacity()
+    quota = ctx.unit_quota()
+
+    def step(i):
+        first = 1 + (i * world + rank) * B
+        pass0 = ctx.batch_walk(first, B)
+        before = 0
+        if world > 1:
+            mine = torch.tensor([pass0], dtype=torch.int64, device=dev)
+            allv = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)        # C3: quota prefix across ranks
+            before = int(sum(int(v.item()) for v in allv[:rank]))
+        # bench batches are far below the record's quota, so none is cut
+        info = ctx.batch_finalize(before % max(1, quota // 4))
+        return info
+
+    for i in range(a.warmup):
+        step(i)
+    ctx.prof_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bases = reads = ref_b = maf_c = text_b = 0
+    for i in range(a.warmup, a.warmup + a.steps):
+        info = step(i)
+        bases += info.bases
+        reads += info.n_final
+        ref_b += info.ref_bases
+        maf_c += info.maf_columns
+        text_b += info.read_text_bytes + info.maf_text_bytes
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    walk_ms, launches, total_ms = ctx.prof_get()
+
+    tot = torch.tensor([bases, reads, ref_b, maf_c, text_b], dtype=torch.int64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot)                   # C2: counters reduced across ranks
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    g_bases, g_reads, g_ref, g_maf, g_text = (int(x) for x in tot.tolist())
+    dt_max = float(tmax.item())
+
+    if rank == 0:
+        # algorithmic bytes: ref_bases*1 + read_bases*2 + maf_columns*2
+        alg_bytes_launch = (ref_b * 1 + bases * 2 + maf_c * 2) / max(1, launches)
+        walk_s = walk_ms / 1e3 / max(1, launches)
+        achieved = alg_bytes_launch / walk_s / 1e9 if walk_s > 0 else 0.0
+        out = {
+            "metric": "simulated bases/sec", "value": g_bases / dt_max, "unit": "bases/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt_max * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "reads_per_sec": g_reads / dt_max,
+            "config": {"workload": "wgs errhmm ERRHMM-ONT depth 20, default length/accuracy, uniform ACGT record "
+                                   f"of {G} bp resident in HBM (one of the 4 records of the 3 Gbp genome)",
+                       "reads_per_step_per_gpu": B, "bases_per_step": g_bases // a.steps,
+                       "text_bytes_per_step": g_text // a.steps, "parallelism": f"read-block x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": walk_s * 1e3,
+                         "walk_share_of_step": (walk_ms / 1e3) / dt if dt > 0 else None},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is reported, never required
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,3 +32,17 @@ def test_wgs_errhmm_matches_oracle_and_golden(case, tmp_path):
     gold = MANIFEST[f"{case}/philox"]
     for k, v in outs.items():
         assert harness.sha(v) == gold[k]["sha256"], (case, k)
+
+
+WGS_OTHER = ["wgs_errhmm_sequel_pass3", "wgs_qshmm_rsii_pass1", "wgs_qshmm_rsii_pass3", "wgs_qshmm_ont_ratio"]
+
+
+@pytest.mark.parametrize("case", WGS_OTHER)
+def test_wgs_qshmm_and_multipass_match_oracle_and_golden(case, tmp_path):
+    args = harness.resolve(CASES[case]["args"])
+    outs, _ = product.run_wgs(args)
+    want = harness.run_oracle(CASES[case]["args"], "philox", str(tmp_path))
+    _cmp(outs, want, case)
+    gold = MANIFEST[f"{case}/philox"]
+    for k, v in outs.items():
+        assert harness.sha(v) == gold[k]["sha256"], (case, k)
