@@ -137,6 +137,10 @@ int pbsim_set_transcripts(pbsim_ctx *ctx, int64_t n, const char *const *ids, con
 int pbsim_simulate_wgs(pbsim_ctx *ctx, const pbsim_sink *sink);
 int pbsim_simulate_trans(pbsim_ctx *ctx, const pbsim_sink *sink);
 int pbsim_get_stats(pbsim_ctx *ctx, pbsim_stats *out);          /* pbsim.cpp:4082-4105, 5541-5562 */
+/* SAM header the reference's main() writes when it opens the samtools pipe for a
+ * unit (pass_num > 1; pbsim.cpp:721-722 wgs, :784-785 trans/templ).  Returns the
+ * byte count (excluding the NUL), or the size needed when buf is NULL/too small. */
+int64_t pbsim_sam_header(pbsim_ctx *ctx, char *buf, int64_t cap);
 
 /* ---- batch primitives (used by the drivers above, bench.py, multi-GPU) ------
  * pbsim_batch_walk     header draw + bucketing + HMM walk of reads

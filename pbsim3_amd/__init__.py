@@ -71,6 +71,7 @@ API = [
     ("pbsim_simulate_wgs", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
     ("pbsim_simulate_trans", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
     ("pbsim_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    ("pbsim_sam_header", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("pbsim_batch_walk", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     ("pbsim_batch_finalize", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(BatchInfo)]),
     ("pbsim_batch_fetch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -187,6 +188,12 @@ class Context:
         sink = Sink(None, SINK_CB(on_read), SINK_CB(on_maf))
         _check(self.lib.pbsim_simulate_wgs(self.h, C.byref(sink) if collect else None))
         return b"".join(reads), b"".join(mafs)
+
+    def sam_header(self):
+        n = self.lib.pbsim_sam_header(self.h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.lib.pbsim_sam_header(self.h, buf, n + 1)
+        return buf.raw[:n]
 
     def stats(self):
         s = Stats()

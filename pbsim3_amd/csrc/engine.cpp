@@ -786,6 +786,18 @@ int pbsim_get_stats(pbsim_ctx *c, pbsim_stats *o) {  // pbsim.cpp:4082-4105, 554
   return PBSIM_SUCCEEDED;
 }
 
+int64_t pbsim_sam_header(pbsim_ctx *c, char *buf, int64_t cap) {  // pbsim.cpp:721-722, 784-785
+  if (!c) return -1;
+  std::string h = "@HD\tVN:1.5\tSO:unknown\tpb:3.0.7\n";
+  h += "@RG\tID:ffffffff\tPL:PACBIO\tDS:READTYPE=SUBREAD;Ipd:CodecV1=ip;PulseWidth:CodecV1=pw;"
+       "BINDINGKIT=101-789-500;SEQUENCINGKIT=101-826-100;BASECALLERVERSION=5.0.0;FRAMERATEHZ=100.000000\tPU:";
+  h += c->p.id_prefix;
+  if (c->p.strategy == PBSIM_STRATEGY_WGS) h += std::to_string((long)c->unit);
+  h += "\tPM:SEQUELII\n";
+  if (buf && cap > (int64_t)h.size()) memcpy(buf, h.c_str(), h.size() + 1);
+  return (int64_t)h.size();
+}
+
 static int deliver(pbsim_ctx *c, const pbsim_sink *sink) {
   const pbsim_batch_info &bi = c->b_info;
   if (sink) {

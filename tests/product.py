@@ -70,6 +70,8 @@ def run_wgs(args, device=0, scratch_mb=None):
         for i, r in enumerate(recs, 1):
             ctx.set_reference(r, i)
             rt, mt = ctx.simulate_wgs()
+            if p.pass_num > 1:
+                rt = ctx.sam_header() + rt  # main() writes it when opening the pipe (pbsim.cpp:721-722)
             outs["_%04d.%s" % (i, "fq" if p.pass_num == 1 else "sam")] = rt
             outs["_%04d.maf" % i] = mt
             stats.append(ctx.stats())
