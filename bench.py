@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--batch-reads", type=int, default=0, help="reads per step per GPU (0 = what the scratch pool holds)")
     ap.add_argument("--model", default="ERRHMM-ONT.model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--param", action="append", default=[],
+                    help="experiment only: override a pbsim_params field, e.g. --param len_sd=0 (not the headline workload)")
     a = ap.parse_args()
 
     import torch
@@ -120,6 +122,9 @@ def main():
     torch.cuda.synchronize()
 
     p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=20.0)
+    for kv in a.param:
+        k, v = kv.split("=")
+        setattr(p, k, type(getattr(p, k))(float(v)))
     ctx = P.Context(p, local)
     ctx.set_scratch_bytes(int(a.scratch_gib * (1 << 30)))
     ctx.load_errhmm(harness.model_path(a.model))
@@ -184,7 +189,7 @@ def main():
             "reads_per_sec": g_reads / dt_max,
             "config": {"workload": "wgs errhmm ERRHMM-ONT depth 20, default length/accuracy, uniform ACGT record "
                                    f"of {G} bp resident in HBM (one of the 4 records of the 3 Gbp genome)",
-                       "reads_per_step_per_gpu": B, "bases_per_step": g_bases // a.steps,
+                       "param_overrides": a.param, "reads_per_step_per_gpu": B, "bases_per_step": g_bases // a.steps,
                        "text_bytes_per_step": g_text // a.steps, "parallelism": f"read-block x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

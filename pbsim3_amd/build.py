@@ -36,7 +36,10 @@ def _deps():
 def _assert_gfx950(path):
     """The fat binary must carry a gfx950 code object (and nothing else)."""
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", path],
-                         capture_output=True, text=True).stdout
+                         capture_output=True, text=True, cwd=os.path.dirname(path)).stdout
+    for f in os.listdir(os.path.dirname(path)):   # llvm-objdump drops the extracted bundles next to the input
+        if f.startswith(os.path.basename(path) + "."):
+            os.remove(os.path.join(os.path.dirname(path), f))
     if f"{ARCH}" not in out:
         raise RuntimeError(f"{path}: no {ARCH} code object in the fat binary:\n{out[-2000:]}")
 

@@ -127,9 +127,9 @@ struct pbsim_ctx {
   DevBuf d_flags, d_ref_flags;
   DevBuf d_rawlen, d_len, d_off, d_acc;
   DevBuf d_hist, d_bin_start, d_bin_cursor, d_class_start;
-  DevBuf d_task_of_slot, d_slot_of_task, d_wave_cap, d_wave_off;
+  DevBuf d_task_of_slot, d_slot_of_task, d_wave_cap, d_wave_off, d_wg_tmp, d_wg_order;
   DevBuf d_out_len, d_maf_len, d_nsub, d_nins, d_ndel, d_qsum;
-  DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len;
+  DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len, d_row_dst;
   DevBuf d_scratch, d_read_text, d_maf_text;
   int64_t scratch_budget = 0;
   HostBuf h_read_text, h_maf_text, h_stats;
@@ -481,6 +481,8 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   HIP_OK(c->d_slot_of_task.ensure(n_tasks * 4));
   HIP_OK(c->d_wave_cap.ensure(waves_max * 4));
   HIP_OK(c->d_wave_off.ensure(waves_max * 8));
+  HIP_OK(c->d_wg_tmp.ensure((size_t)(kLenBuckets + 1) * 2 * 4));
+  HIP_OK(c->d_wg_order.ensure((size_t)(slots_max / kWG) * 4));
   HIP_OK(c->d_out_len.ensure(n_tasks * 4));
   HIP_OK(c->d_maf_len.ensure(n_tasks * 4));
   HIP_OK(c->d_nsub.ensure(n_tasks * 4));
@@ -529,6 +531,9 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   s.wave_cap = c->d_wave_cap.as<int32_t>();
   s.wave_off = c->d_wave_off.as<int64_t>();
   s.n_slots_max = slots_max;
+  s.wg_hist = c->d_wg_tmp.as<int32_t>();
+  s.wg_start = s.wg_hist + (kLenBuckets + 1);
+  s.wg_order = c->d_wg_order.as<int32_t>();
   s.regions = regions_of(c);
   s.scratch_bytes = c->scratch_budget;
   s.flags = flags;
@@ -549,6 +554,8 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   w.cls_blob = c->d_cls.as<uint8_t>();
   w.class_start = s.class_start;
   w.task_of_slot = s.task_of_slot;
+  w.wg_order = s.wg_order;
+  w.mean_len = (int32_t)c->hdr.mean_len;
   w.wave_cap = s.wave_cap;
   w.wave_off = s.wave_off;
   w.scratch = c->d_scratch.as<uint8_t>();
@@ -624,6 +631,8 @@ static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
   t->out_len = c->d_out_len.as<int32_t>();
   t->maf_len = c->d_maf_len.as<int32_t>();
   t->slot_of_task = c->d_slot_of_task.as<int32_t>();
+  t->task_of_slot = c->d_task_of_slot.as<int32_t>();
+  t->row_dst = c->d_row_dst.as<int64_t>();
   t->wave_cap = c->d_wave_cap.as<int32_t>();
   t->wave_off = c->d_wave_off.as<int64_t>();
   t->scratch = c->d_scratch.as<uint8_t>();
@@ -670,6 +679,7 @@ int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_inf
   if (n_tasks > 0) {
     HIP_OK(c->d_rt_len.ensure(n_tasks * 8));
     HIP_OK(c->d_mt_len.ensure(n_tasks * 8));
+    HIP_OK(c->d_row_dst.ensure(n_tasks * 6 * 8));
     HIP_OK(hipMemsetAsync(&flags->sums[1], 0, 5 * sizeof(int64_t), c->stream));
     TextArgs t;
     fill_text_args(c, &t, n_final);
@@ -688,7 +698,7 @@ int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_inf
     HIP_OK(c->d_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
     t.read_text = c->d_read_text.as<char>();
     t.maf_text = c->d_maf_text.as<char>();
-    launch_text_emit(t, c->stream);
+    launch_text_emit(t, c->b_slots_max, flags, c->stream);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(c->stream));
   }

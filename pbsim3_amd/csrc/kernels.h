@@ -68,6 +68,8 @@ struct SortArgs {
   int32_t *wave_cap;    // [n_waves_max] dwords per lane per region
   int64_t *wave_off;    // [n_waves_max] byte offset into the scratch pool
   int64_t n_slots_max;
+  int32_t *wg_hist, *wg_start;  // [kLenBuckets+1] each
+  int32_t *wg_order;            // [n_slots_max/kWG] walk workgroups, longest reads first
   int32_t regions;      // scratch regions per task (3 errhmm, 4 qshmm)
   int64_t scratch_bytes;
   DeviceFlags *flags;
@@ -84,6 +86,8 @@ struct WalkArgs {
   uint32_t stride, rows_off, init_off, tran_off, emis_off, freq_off, rv_off;
   const int32_t *class_start;
   const int32_t *task_of_slot;
+  const int32_t *wg_order;
+  int32_t mean_len;          // E[L] of the length table (priority thresholds)
   const int32_t *wave_cap;
   const int64_t *wave_off;
   uint8_t *scratch;
@@ -106,6 +110,8 @@ struct TextArgs {
   const int32_t *len, *off;
   const int32_t *out_len, *maf_len;
   const int32_t *slot_of_task;
+  const int32_t *task_of_slot;
+  int64_t *row_dst;             // [n_tasks][6] byte offsets of the big rows inside the text buffers
   const int32_t *wave_cap;
   const int64_t *wave_off;
   const uint8_t *scratch;
@@ -140,6 +146,6 @@ void launch_gather_pass0_scan(const int32_t *out_len, int64_t n_reads, int32_t p
 void launch_quota_cut(const int64_t *cum, const int32_t *rawlen, int64_t n_reads, int64_t len_total_before,
                       int64_t quota, int force_all, DeviceFlags *flags, hipStream_t s);
 void launch_text_sizes(const TextArgs &a, DeviceFlags *flags, hipStream_t s);
-void launch_text_emit(const TextArgs &a, hipStream_t s);
+void launch_text_emit(const TextArgs &a, int64_t n_slots_max, const DeviceFlags *flags, hipStream_t s);
 
 }  // namespace pbsim

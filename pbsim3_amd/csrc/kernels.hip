@@ -362,6 +362,67 @@ __global__ __launch_bounds__(1024) void k_wave_scan(SortArgs a) {
   }
 }
 
+// Longest-processing-time-first launch order of the walk workgroups: the kernel
+// ends when its longest read ends, so workgroups holding long reads go first
+// (and their waves run at raised priority, see walk_priority()).
+__global__ __launch_bounds__(256) void k_wg_hist(SortArgs a, int32_t *wg_hist) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.n_slots_max / kWG) return;
+  const int task = a.task_of_slot[g * kWG];
+  int key = kLenBuckets;  // empty workgroups last
+  if (task >= 0) {
+    int b = a.len[task / a.pass_num] >> kLenShift;
+    if (b > kLenBuckets - 1) b = kLenBuckets - 1;
+    key = kLenBuckets - 1 - b;
+  }
+  atomicAdd(&wg_hist[key], 1);
+}
+
+__global__ __launch_bounds__(1024) void k_wg_scan(int32_t *wg_hist, int32_t *wg_start) {
+  __shared__ int s_part[1024];
+  __shared__ int s_base;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < kLenBuckets + 1; i0 += 1024) {
+    const int i = i0 + tid;
+    const int v = (i < kLenBuckets + 1) ? wg_hist[i] : 0;
+    s_part[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int t = (tid >= d) ? s_part[tid - d] : 0;
+      __syncthreads();
+      s_part[tid] += t;
+      __syncthreads();
+    }
+    if (i < kLenBuckets + 1) wg_start[i] = s_base + s_part[tid] - v;
+    __syncthreads();
+    if (tid == 1023) s_base += s_part[1023];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wg_scatter(SortArgs a, int32_t *wg_start, int32_t *wg_order) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.n_slots_max / kWG) return;
+  const int task = a.task_of_slot[g * kWG];
+  int key = kLenBuckets;
+  if (task >= 0) {
+    int b = a.len[task / a.pass_num] >> kLenShift;
+    if (b > kLenBuckets - 1) b = kLenBuckets - 1;
+    key = kLenBuckets - 1 - b;
+  }
+  wg_order[atomicAdd(&wg_start[key], 1)] = (int32_t)g;
+}
+
+// waves that carry the longest reads are the kernel's critical path: raise them
+__device__ __forceinline__ void walk_priority(int lmax_wave, int mean_len) {
+  const int r = lmax_wave / (2 * (mean_len > 0 ? mean_len : 1));
+  if (r >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (r == 2) __builtin_amdgcn_s_setprio(2);
+  else if (r == 1) __builtin_amdgcn_s_setprio(1);
+}
+
 // ---------------------------------------------------------------------------
 // K2e: ERRHMM walk.  One lane per task (read, pass); the 4 waves of a workgroup
 // share one accuracy class whose tables were staged in LDS.
@@ -381,7 +442,7 @@ struct StepOut {
 __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
-  const int64_t slot0 = (int64_t)blockIdx.x * kWG;
+  const int64_t slot0 = (int64_t)a.wg_order[blockIdx.x] * kWG;
   if (slot0 >= a.flags->total_slots) return;
   if (a.flags->error & kErrScratchBudget) return;  // the pool cannot hold this batch: the host retries smaller
   int cls = 0;
@@ -412,6 +473,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   }
   const bool minus = valid && ((read_idx & 1u) == 0);  // pbsim.cpp:3820-3826 (Q9)
   const int cap_dw = a.wave_cap[wave];
+  walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
   uint32_t *read_row = maf_ref + (size_t)cap_dw * 64;
@@ -542,7 +604,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
 __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
-  const int64_t slot0 = (int64_t)blockIdx.x * kWG;
+  const int64_t slot0 = (int64_t)a.wg_order[blockIdx.x] * kWG;
   if (slot0 >= a.flags->total_slots) return;
   if (a.flags->error & kErrScratchBudget) return;  // the pool cannot hold this batch: the host retries smaller
   int cls = 0;
@@ -585,6 +647,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   }
   const bool minus = valid && ((read_idx & 1u) == 0);
   const int cap_dw = a.wave_cap[wave];
+  walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
   uint32_t *read_row = maf_ref + (size_t)cap_dw * 64;
@@ -880,168 +943,224 @@ __global__ __launch_bounds__(256) void k_text_sizes(TextArgs a, DeviceFlags *fla
   atomicAdd((unsigned long long *)&flags->sums[5], (unsigned long long)m);
 }
 
-// byte i of a wave-transposed scratch row
-__device__ __forceinline__ uint32_t row_byte(const uint8_t *row, int64_t i) {
-  return row[(i >> 2) * 256 + (i & 3)];
+// ---- small pieces: one thread per task writes every header/separator and
+// records where the four (six for SAM) big rows of the task go
+__device__ __forceinline__ char *g_lit(char *o, const char *lit, int n) {
+  for (int i = 0; i < n; i++) o[i] = lit[i];
+  return o + n;
+}
+__device__ __forceinline__ char *g_pad(char *o, int n) {
+  for (int i = 0; i < n; i++) o[i] = ' ';
+  return o + (n > 0 ? n : 0);
 }
 
-__global__ __launch_bounds__(256) void k_text_emit(TextArgs a) {
-  __shared__ char s_a[384], s_b[384];
-  __shared__ int s_la, s_lb;
-  const int64_t t = blockIdx.x;
-  const int tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_text_headers(TextArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_tasks = a.n_reads * a.pass_num;
+  if (t >= n_tasks) return;
   const int64_t r = t / a.pass_num;
   const int pass = (int)(t - r * a.pass_num);
   const int q = a.out_len[t], m = a.maf_len[t];
-  const int slot = a.slot_of_task[t];
-  const int64_t wave = slot >> 6;
-  const int lane = slot & 63;
-  const size_t region = (size_t)a.wave_cap[wave] * 256;
-  const uint8_t *maf_read = a.scratch + a.wave_off[wave] + (size_t)lane * 4;
-  const uint8_t *maf_ref = maf_read + region;
-  const uint8_t *read_row = maf_ref + region;
-  const uint8_t *qual_row = read_row + region;
   const int64_t readnum = a.first_read + r;
   const bool minus = a.read_minus ? (a.read_minus[r] != 0) : ((readnum & 1) == 0);
+  int64_t *rd = a.row_dst + t * 6;
+  char idbuf[160];
+  const int idl = put_id(idbuf, a, readnum, pass);
 
-  // ---------------- FASTQ / SAM ----------------
-  char *out = a.read_text + a.read_text_off[t];
+  // ---------------- FASTQ (pbsim.cpp:4013-4014) / SAM (:4016-4027) ----------------
+  char *base = a.read_text + a.read_text_off[t];
+  char *o = base;
   if (a.pass_num == 1) {
-    if (tid == 0) {
-      int n = 0;
-      s_a[n++] = '@';
-      n += put_id(s_a + n, a, readnum, pass);
-      s_a[n++] = '\n';
-      s_la = n;
-    }
-    __syncthreads();
-    const int la = s_la;  // "@id\n"; the '+' line reuses it
-    for (int i = tid; i < la; i += 256) {
-      out[i] = s_a[i];
-      out[la + q + 1 + i] = (i == 0) ? '+' : s_a[i];
-    }
-    for (int i = tid; i < q; i += 256) {
-      out[la + i] = (char)row_byte(read_row, i);
-      out[2 * la + q + 1 + i] = a.is_qs ? (char)row_byte(qual_row, i) : '!';  // pbsim.cpp:4007-4010
-    }
-    if (tid == 0) {
-      out[la + q] = '\n';
-      out[2 * la + 2 * q + 1] = '\n';
-    }
+    *o++ = '@';
+    o = g_lit(o, idbuf, idl);
+    *o++ = '\n';
+    rd[0] = o - a.read_text;
+    o += q;
+    *o++ = '\n';
+    *o++ = '+';
+    o = g_lit(o, idbuf, idl);
+    *o++ = '\n';
+    rd[1] = o - a.read_text;
+    o += q;
+    *o++ = '\n';
+    rd[4] = rd[5] = 0;
   } else {
-    if (tid == 0) {
-      int n = put_id(s_a, a, readnum, pass);
-      n += put_lit(s_a + n, PB_SAM_MID, PB_LEN(PB_SAM_MID));
-      s_la = n;
-      n = put_lit(s_b, PB_SAM_T1, PB_LEN(PB_SAM_T1));
-      n += put_dec(s_b + n, (int64_t)q - 1);
-      n += put_lit(s_b + n, PB_SAM_T2, PB_LEN(PB_SAM_T2));
-      for (int i = 0; i < a.rq_len; i++) s_b[n++] = a.rq_text[i];
-      n += put_lit(s_b + n, PB_SAM_T3, PB_LEN(PB_SAM_T3));
-      n += put_dec(s_b + n, readnum);
-      n += put_lit(s_b + n, PB_SAM_T4, PB_LEN(PB_SAM_T4));
-      s_lb = n;
-    }
-    __syncthreads();
-    const int la = s_la, lb = s_lb;
-    const char *ip = PB_SAM_IP;
-    const char *pw = PB_SAM_PW;
-    constexpr int kTagLen = PB_LEN(PB_SAM_IP);
-    static_assert(PB_LEN(PB_SAM_IP) == PB_LEN(PB_SAM_PW), "tag literals");
-    char *o = out;
-    for (int i = tid; i < la; i += 256) o[i] = s_a[i];
-    o += la;
-    for (int i = tid; i < q; i += 256) o[i] = (char)row_byte(read_row, i);
+    o = g_lit(o, idbuf, idl);
+    o = g_lit(o, PB_SAM_MID, PB_LEN(PB_SAM_MID));
+    rd[0] = o - a.read_text;
     o += q;
-    if (tid == 0) o[0] = '\t';
-    o += 1;
-    for (int i = tid; i < q; i += 256) o[i] = a.is_qs ? (char)row_byte(qual_row, i) : '!';
+    *o++ = '\t';
+    rd[1] = o - a.read_text;
     o += q;
-    for (int i = tid; i < kTagLen; i += 256) o[i] = ip[i];
-    o += kTagLen;
-    for (int i = tid; i < 2 * q; i += 256) o[i] = (i & 1) ? '9' : ',';
+    o = g_lit(o, PB_SAM_IP, PB_LEN(PB_SAM_IP));
+    rd[4] = o - a.read_text;
     o += 2 * q;
-    for (int i = tid; i < kTagLen; i += 256) o[i] = pw[i];
-    o += kTagLen;
-    for (int i = tid; i < 2 * q; i += 256) o[i] = (i & 1) ? '9' : ',';
+    o = g_lit(o, PB_SAM_PW, PB_LEN(PB_SAM_PW));
+    rd[5] = o - a.read_text;
     o += 2 * q;
-    for (int i = tid; i < lb; i += 256) o[i] = s_b[i];
+    o = g_lit(o, PB_SAM_T1, PB_LEN(PB_SAM_T1));
+    o += put_dec(o, (int64_t)q - 1);
+    o = g_lit(o, PB_SAM_T2, PB_LEN(PB_SAM_T2));
+    o = g_lit(o, a.rq_text, a.rq_len);
+    o = g_lit(o, PB_SAM_T3, PB_LEN(PB_SAM_T3));
+    o += put_dec(o, readnum);
+    o = g_lit(o, PB_SAM_T4, PB_LEN(PB_SAM_T4));
   }
-  __syncthreads();
 
   // ---------------- MAF (pbsim.cpp:4030-4078) ----------------
-  if (tid == 0) {
-    TaskText x;
-    task_text(a, r, pass, q, &x);
+  TaskText x;
+  task_text(a, r, pass, q, &x);
+  o = a.maf_text + a.maf_text_off[t];
+  *o++ = 'a';
+  *o++ = '\n';
+  *o++ = 's';
+  *o++ = ' ';
+  if (a.read_unit) {
+    o = g_lit(o, a.unit_names + (size_t)a.read_unit[r] * 132, x.r0);
+  } else {
+    *o++ = 'r';
+    *o++ = 'e';
+    *o++ = 'f';
+  }
+  o = g_pad(o, x.w0 - x.r0);
+  o = g_pad(o, x.w1 - x.r1);
+  *o++ = ' ';
+  o += put_dec(o, x.start0);
+  o = g_pad(o, x.w2 - x.r2);
+  *o++ = ' ';
+  o += put_dec(o, x.span);
+  *o++ = ' ';
+  *o++ = '+';
+  o = g_pad(o, x.w3 - x.r3);
+  *o++ = ' ';
+  o += put_dec(o, x.reflen);
+  *o++ = ' ';
+  rd[2] = o - a.maf_text;
+  o += m;
+  *o++ = '\n';
+  *o++ = 's';
+  *o++ = ' ';
+  o = g_lit(o, idbuf, idl);
+  o = g_pad(o, x.w0 - x.q0);
+  o = g_pad(o, x.w1 - 1);
+  *o++ = ' ';
+  *o++ = '0';
+  o = g_pad(o, x.w2 - x.q2);
+  *o++ = ' ';
+  o += put_dec(o, q);
+  *o++ = ' ';
+  *o++ = minus ? '-' : '+';
+  o = g_pad(o, x.w3 - x.q2);
+  *o++ = ' ';
+  o += put_dec(o, q);
+  *o++ = ' ';
+  rd[3] = o - a.maf_text;
+  o += m;
+  *o++ = '\n';
+  *o++ = '\n';
+}
+
+// ---- big rows: one workgroup per (scratch wave, row kind).  A 64-task x 256-byte
+// tile is read as coalesced 256-byte lines of the wave-transposed scratch, turned
+// through LDS, and written as aligned dwords into each task's text position.
+//   kind 0 read bases | 1 quality ('!' fill for ERRHMM, pbsim.cpp:4007-4010)
+//   kind 2 MAF reference row | 3 MAF read row   ('-' strand: reverse-complemented
+//          back to forward orientation, pbsim.cpp:3981-3984)
+//   kind 4,5 the two ",9" x len SAM tag fills (pbsim.cpp:4019-4025)
+constexpr int kTileStride = 65;  // dwords per task row in LDS (64 + 1 pad: conflict-free turn)
+
+__global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags *flags) {
+  __shared__ uint32_t s_tile[64 * kTileStride];
+  __shared__ int s_n[64];
+  __shared__ long long s_dst[64];
+  __shared__ int s_minus[64];
+  __shared__ int s_nmax;
+  const int64_t wave = blockIdx.x;
+  const int kind = blockIdx.y;
+  if (wave * 64 >= flags->total_slots) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_nmax = 0;
+  __syncthreads();
+  if (tid < 64) {
+    const int task = a.task_of_slot[wave * 64 + tid];
     int n = 0;
-    s_a[n++] = 'a';
-    s_a[n++] = '\n';
-    s_a[n++] = 's';
-    s_a[n++] = ' ';
-    if (a.read_unit) {
-      const char *nm = a.unit_names + (size_t)a.read_unit[r] * 132;
-      for (int i = 0; i < x.r0; i++) s_a[n++] = nm[i];
-    } else {
-      s_a[n++] = 'r';
-      s_a[n++] = 'e';
-      s_a[n++] = 'f';
+    long long dst = 0;
+    int minus = 0;
+    if (task >= 0) {
+      const int64_t r = task / a.pass_num;
+      if (r < a.n_reads) {
+        const int64_t readnum = a.first_read + r;
+        const bool mi = a.read_minus ? (a.read_minus[r] != 0) : ((readnum & 1) == 0);
+        n = (kind == 2 || kind == 3) ? a.maf_len[task] : a.out_len[task];
+        if (kind >= 4) n *= 2;
+        minus = (kind == 2 || kind == 3) && mi;
+        dst = a.row_dst[(int64_t)task * 6 + kind];
+      }
     }
-    for (int i = x.r0; i < x.w0; i++) s_a[n++] = ' ';
-    for (int i = x.r1; i < x.w1; i++) s_a[n++] = ' ';
-    s_a[n++] = ' ';
-    n += put_dec(s_a + n, x.start0);
-    for (int i = x.r2; i < x.w2; i++) s_a[n++] = ' ';
-    s_a[n++] = ' ';
-    n += put_dec(s_a + n, x.span);
-    s_a[n++] = ' ';
-    s_a[n++] = '+';
-    for (int i = x.r3; i < x.w3; i++) s_a[n++] = ' ';
-    s_a[n++] = ' ';
-    n += put_dec(s_a + n, x.reflen);
-    s_a[n++] = ' ';
-    s_la = n;
-    n = 0;
-    s_b[n++] = '\n';
-    s_b[n++] = 's';
-    s_b[n++] = ' ';
-    n += put_id(s_b + n, a, readnum, pass);
-    for (int i = x.q0; i < x.w0; i++) s_b[n++] = ' ';
-    for (int i = 1; i < x.w1; i++) s_b[n++] = ' ';
-    s_b[n++] = ' ';
-    s_b[n++] = '0';
-    for (int i = x.q2; i < x.w2; i++) s_b[n++] = ' ';
-    s_b[n++] = ' ';
-    n += put_dec(s_b + n, q);
-    s_b[n++] = ' ';
-    s_b[n++] = minus ? '-' : '+';
-    for (int i = x.q2; i < x.w3; i++) s_b[n++] = ' ';
-    s_b[n++] = ' ';
-    n += put_dec(s_b + n, q);
-    s_b[n++] = ' ';
-    s_lb = n;
+    s_n[tid] = n;
+    s_dst[tid] = dst;
+    s_minus[tid] = minus;
+    if (n > 0) atomicMax(&s_nmax, n);
   }
   __syncthreads();
-  {
-    const int la = s_la, lb = s_lb;
-    char *o = a.maf_text + a.maf_text_off[t];
-    for (int i = tid; i < la; i += 256) o[i] = s_a[i];
-    for (int i = tid; i < lb; i += 256) o[la + m + i] = s_b[i];
-    char *o1 = o + la, *o2 = o + la + m + lb;
-    // '-' strand rows go back to forward orientation (revcomp, pbsim.cpp:3981-3984)
-    for (int i = tid; i < m; i += 256) {
-      const int64_t src = minus ? (m - 1 - i) : i;
-      uint32_t f = row_byte(maf_ref, src), g = row_byte(maf_read, src);
-      if (minus) {
-        f = complement(f);
-        g = complement(g);
+  const int nmax = s_nmax;
+  if (nmax == 0) return;
+  const bool fill = (kind == 1 && !a.is_qs) || kind >= 4;
+  char *text = (kind == 2 || kind == 3) ? a.maf_text : a.read_text;
+  const int cap_dw = a.wave_cap[wave];
+  const int region_idx = (kind == 0) ? 2 : (kind == 1) ? 3 : (kind == 2) ? 1 : 0;
+  const uint32_t *region =
+      reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave] + (size_t)region_idx * cap_dw * 256);
+  const uint8_t *tile8 = reinterpret_cast<const uint8_t *>(s_tile);
+
+  for (int s0 = 0; s0 < nmax; s0 += 256) {
+    if (!fill) {
+      const int c0 = s0 >> 2;
+      for (int c = wv; c < 64; c += 4) {
+        const int cc = c0 + c;
+        s_tile[lane * kTileStride + c] = (cc < cap_dw) ? region[(size_t)cc * 64 + lane] : 0u;
       }
-      o1[i] = (char)f;
-      o2[i] = (char)g;
+      __syncthreads();
     }
-    if (tid == 0) {
-      o2[m] = '\n';
-      o2[m + 1] = '\n';
+    for (int i = 0; i < 16; i++) {
+      const int j = wv * 16 + i;
+      const int n = s_n[j];
+      if (s0 >= n) continue;
+      const int s1 = (n < s0 + 256) ? n : s0 + 256;
+      const long long dst = s_dst[j];
+      const int minus = s_minus[j];
+      const long long D0 = minus ? dst + (n - s1) : dst + s0;
+      const long long D1 = D0 + (s1 - s0);
+      for (long long d = (D0 >> 2) + lane; d * 4 < D1; d += 64) {
+        const long long A = d * 4;
+        uint32_t word = 0;
+        bool all_in = (A >= D0) && (A + 4 <= D1);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const long long pos = A + b;
+          uint32_t v = 0;
+          if (pos >= D0 && pos < D1) {
+            const int rel = (int)(pos - dst);  // byte index within the row, destination order
+            if (fill) {
+              v = (kind == 1) ? (uint32_t)'!' : ((rel & 1) ? (uint32_t)'9' : (uint32_t)',');
+            } else {
+              const int s = (minus ? (n - 1 - rel) : rel) - s0;
+              v = tile8[j * (kTileStride * 4) + s];
+              if (minus) v = complement(v);
+            }
+          }
+          word |= v << (8 * b);
+        }
+        if (all_in) {
+          *reinterpret_cast<uint32_t *>(text + A) = word;
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            if (A + b >= D0 && A + b < D1) text[A + b] = (char)(word >> (8 * b));
+        }
+      }
     }
+    if (!fill) __syncthreads();
   }
 }
 
@@ -1080,6 +1199,11 @@ void launch_task_sort(const SortArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_sort_scatter, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_wave_cap, dim3(blocks_for(a.n_slots_max / 64, 256)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_wave_scan, dim3(1), dim3(1024), 0, s, a);
+  const int64_t n_wg = a.n_slots_max / kWG;
+  (void)hipMemsetAsync(a.wg_hist, 0, (kLenBuckets + 1) * sizeof(int32_t), s);
+  hipLaunchKernelGGL(k_wg_hist, dim3(blocks_for(n_wg, 256)), dim3(256), 0, s, a, a.wg_hist);
+  hipLaunchKernelGGL(k_wg_scan, dim3(1), dim3(1024), 0, s, a.wg_hist, a.wg_start);
+  hipLaunchKernelGGL(k_wg_scatter, dim3(blocks_for(n_wg, 256)), dim3(256), 0, s, a, a.wg_start, a.wg_order);
 }
 
 void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s) {
@@ -1124,10 +1248,12 @@ void launch_text_sizes(const TextArgs &a, DeviceFlags *flags, hipStream_t s) {
   hipLaunchKernelGGL(k_text_sizes, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, a, flags);
 }
 
-void launch_text_emit(const TextArgs &a, hipStream_t s) {
+void launch_text_emit(const TextArgs &a, int64_t n_slots_max, const DeviceFlags *flags, hipStream_t s) {
   const int64_t n_tasks = a.n_reads * a.pass_num;
   if (n_tasks <= 0) return;
-  hipLaunchKernelGGL(k_text_emit, dim3((unsigned)n_tasks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_text_headers, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_text_rows, dim3((unsigned)(n_slots_max / 64), a.pass_num == 1 ? 4 : 6), dim3(256), 0, s, a,
+                     flags);
 }
 
 }  // namespace pbsim
