@@ -1,0 +1,341 @@
+// cli.cpp -- `pbsim`: the reference's command line (23 long options,
+// pbsim.cpp:257-282) in front of the C ABI of include/pbsim3_amd.h.  This is
+// INTEGRATION.md written out: option parsing and validation (pbsim.cpp:286-530,
+// set_sim_param :1451-1688), the stderr report blocks (:5397-5465, :5541-5564),
+// the FASTA splitter, the per-record driver loop of main() (:666-759) and the
+// gzip/samtools pipes (:708-730).  Everything per read and per base happens in
+// libpbsim3_amd.so on the GPU.  Extra options: --device N, --no-gzip (write the
+// text plainly to <prefix>_NNNN.{fq,maf,sam} instead of piping into gzip/samtools).
+#include <getopt.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/resource.h>
+#include <sys/time.h>
+#include <time.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pbsim3_amd.h"
+#include "unit_io.h"
+
+namespace {
+
+struct Cli {
+  int set_flg[32] = {0};
+  pbsim_params p;
+  std::string genome, transcript, templ, prefix = "sd", model, sample;
+  int device = 0;
+  bool no_gzip = false;
+};
+
+[[noreturn]] void die(const char *fmt, const char *a = "", const char *b = "") {
+  fprintf(stderr, "ERROR");
+  fprintf(stderr, fmt, a, b);
+  fprintf(stderr, "\n");
+  exit(-1);
+}
+
+FILE *open_sink(const Cli &c, const std::string &plain_name, const std::string &pipe_cmd_target, bool bam) {
+  FILE *fp;
+  if (c.no_gzip) {
+    fp = fopen(plain_name.c_str(), "w");
+  } else {
+    std::string cmd = bam ? "samtools view -b -o " + pipe_cmd_target + " -" : "gzip > " + pipe_cmd_target;
+    fp = popen(cmd.c_str(), "w");
+  }
+  if (!fp) die(": Cannot open output file: %s", c.no_gzip ? plain_name.c_str() : pipe_cmd_target.c_str());
+  return fp;
+}
+
+void close_sink(const Cli &c, FILE *fp) {
+  if (c.no_gzip) fclose(fp);
+  else pclose(fp);
+}
+
+int write_cb(void *user, const char *text, int64_t n) { return fwrite(text, 1, (size_t)n, (FILE *)user) == (size_t)n; }
+
+void print_sim_param(const Cli &c) {  // pbsim.cpp:5397-5465
+  const pbsim_params &p = c.p;
+  fprintf(stderr, ":::: Simulation parameters :::\n\n");
+  fprintf(stderr, "strategy : %s\n",
+          p.strategy == PBSIM_STRATEGY_WGS ? "wgs" : p.strategy == PBSIM_STRATEGY_TRANS ? "trans" : "templ");
+  if (p.method == PBSIM_METHOD_QS) fprintf(stderr, "method : qshmm\nqshmm : %s\n", c.model.c_str());
+  else fprintf(stderr, "method : errhmm\nerrhmm : %s\n", c.model.c_str());
+  if (p.strategy == PBSIM_STRATEGY_WGS) fprintf(stderr, "genome : %s\n", c.genome.c_str());
+  else if (p.strategy == PBSIM_STRATEGY_TRANS) fprintf(stderr, "transcript : %s\n", c.transcript.c_str());
+  else fprintf(stderr, "template : %s\n", c.templ.c_str());
+  fprintf(stderr, "prefix : %s\n", c.prefix.c_str());
+  fprintf(stderr, "id-prefix : %s\n", p.id_prefix);
+  if (p.strategy == PBSIM_STRATEGY_WGS) fprintf(stderr, "depth : %lf\n", p.depth);
+  if (p.strategy != PBSIM_STRATEGY_TEMPL) {
+    fprintf(stderr, "length-mean : %f\n", p.len_mean);
+    fprintf(stderr, "length-sd : %f\n", p.len_sd);
+    fprintf(stderr, "length-min : %ld\n", (long)p.len_min);
+    fprintf(stderr, "length-max : %ld\n", (long)p.len_max);
+  }
+  if (p.method != PBSIM_METHOD_ERR)
+    fprintf(stderr, "difference-ratio : %ld:%ld:%ld\n", (long)p.sub_ratio, (long)p.ins_ratio, (long)p.del_ratio);
+  fprintf(stderr, "seed : %d\n", p.seed);
+  fprintf(stderr, "accuracy-mean : %f\n", p.accuracy_mean);
+  fprintf(stderr, "pass_num : %d\n", p.pass_num);
+  fprintf(stderr, "hp-del-bias : %f\n", p.hp_del_bias);
+  fprintf(stderr, "\n");
+}
+
+void print_simulation_stats(const Cli &c, const pbsim_stats &s, long unit) {  // pbsim.cpp:5541-5564
+  if (c.p.strategy == PBSIM_STRATEGY_WGS) {
+    fprintf(stderr, ":::: Simulation stats (ref.%ld) ::::\n\n", unit);
+    fprintf(stderr, "read num. : %ld\n", (long)s.res_num);
+    fprintf(stderr, "depth : %lf\n", s.res_depth);
+  } else {
+    fprintf(stderr, ":::: Simulation stats ::::\n\n");
+    fprintf(stderr, "read num. : %ld\n", (long)s.res_num);
+  }
+  fprintf(stderr, "read length mean (SD) : %f (%f)\n", s.res_len_mean, s.res_len_sd);
+  fprintf(stderr, "read length min : %ld\n", (long)s.res_len_min);
+  fprintf(stderr, "read length max : %ld\n", (long)s.res_len_max);
+  fprintf(stderr, "read accuracy mean (SD) : %f (%f)\n", s.res_accuracy_mean, s.res_accuracy_sd);
+  fprintf(stderr, "substitution rate. : %f\n", s.res_sub_rate);
+  fprintf(stderr, "insertion rate. : %f\n", s.res_ins_rate);
+  fprintf(stderr, "deletion rate. : %f\n", s.res_del_rate);
+  fprintf(stderr, "\n");
+}
+
+void print_help() {
+  fprintf(stderr,
+          "\nUSAGE: pbsim [options]\n\n"
+          "  --prefix --id-prefix --seed\n"
+          "  --strategy wgs   --genome FASTA --depth (20.0) --length-min (100) --length-max (1000000)\n"
+          "  --strategy trans --transcript TSV (id, plus, minus, sequence)\n"
+          "  --method errhmm  --errhmm MODEL   |   --method qshmm --qshmm MODEL --difference-ratio (6:55:39)\n"
+          "  --length-mean (9000.0) --length-sd (7000.0) --accuracy-mean (0.85) --pass-num (1) --hp-del-bias (1)\n"
+          "  --device N (0)   --no-gzip (plain .fq/.maf/.sam instead of gzip/samtools pipes)\n\n");
+}
+
+void check(int ok) {
+  if (!ok) {
+    fprintf(stderr, "ERROR: %s\n", pbsim_last_error());
+    exit(-1);
+  }
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  struct timeval tv0;
+  gettimeofday(&tv0, NULL);
+  Cli c;
+  pbsim_params_default(&c.p);
+  c.p.strategy = 0;
+  c.p.method = 0;
+  c.p.seed = (unsigned int)time(NULL);  // pbsim.cpp:253
+  static struct option long_options[] = {
+      {"strategy", 1, NULL, 0},   {"method", 1, NULL, 0},        {"genome", 1, NULL, 0},
+      {"transcript", 1, NULL, 0}, {"prefix", 1, NULL, 0},        {"id-prefix", 1, NULL, 0},
+      {"depth", 1, NULL, 0},      {"length-min", 1, NULL, 0},    {"length-max", 1, NULL, 0},
+      {"difference-ratio", 1, NULL, 0}, {"seed", 1, NULL, 0},    {"sample", 1, NULL, 0},
+      {"sample-profile-id", 1, NULL, 0}, {"accuracy-min", 1, NULL, 0}, {"accuracy-max", 1, NULL, 0},
+      {"qshmm", 1, NULL, 0},      {"errhmm", 1, NULL, 0},        {"length-mean", 1, NULL, 0},
+      {"length-sd", 1, NULL, 0},  {"accuracy-mean", 1, NULL, 0}, {"pass-num", 1, NULL, 0},
+      {"template", 1, NULL, 0},   {"hp-del-bias", 1, NULL, 0},   {"device", 1, NULL, 0},
+      {"no-gzip", 0, NULL, 0},    {0, 0, 0, 0}};
+  int opt, idx = 0;
+  while ((opt = getopt_long(argc, argv, "", long_options, &idx)) != -1) {
+    if (opt != 0) exit(-1);
+    c.set_flg[idx] = 1;
+    switch (idx) {
+    case 0:
+      if (!strncmp(optarg, "wgs", 3)) c.p.strategy = PBSIM_STRATEGY_WGS;
+      else if (!strncmp(optarg, "trans", 5)) c.p.strategy = PBSIM_STRATEGY_TRANS;
+      else if (!strncmp(optarg, "templ", 5)) c.p.strategy = PBSIM_STRATEGY_TEMPL;
+      else die(" (strategy: %s): Acceptable value: wgs, trans, templ.", optarg);
+      break;
+    case 1:
+      if (!strncmp(optarg, "qshmm", 5)) c.p.method = PBSIM_METHOD_QS;
+      else if (!strncmp(optarg, "errhmm", 6)) c.p.method = PBSIM_METHOD_ERR;
+      else if (!strncmp(optarg, "sample", 6)) die(": --method sample is not provided by the MI355X path (SURVEY 2 row 19)");
+      else die(" (method: %s): Acceptable value: qshmm, errhmm, sample.", optarg);
+      break;
+    case 2: c.genome = optarg; break;
+    case 3: c.transcript = optarg; break;
+    case 4: c.prefix = optarg; break;
+    case 5:
+      if (strlen(optarg) >= sizeof c.p.id_prefix) die(" (id-prefix: %s): too long.", optarg);
+      strcpy(c.p.id_prefix, optarg);
+      break;
+    case 6:
+      c.p.depth = atof(optarg);
+      if (c.p.depth <= 0.0) die(" (depth: %s): Acceptable range is more than 0.", optarg);
+      break;
+    case 7:
+      c.p.len_min = atoi(optarg);
+      if (strlen(optarg) >= 8 || c.p.len_min < 1 || c.p.len_min > 1000000)
+        die(" (length-min: %s): Acceptable range is 1-1000000.", optarg);
+      break;
+    case 8:
+      c.p.len_max = atoi(optarg);
+      if (strlen(optarg) >= 8 || c.p.len_max < 1 || c.p.len_max > 1000000)
+        die(" (length-max: %s): Acceptable range is 1-1000000.", optarg);
+      break;
+    case 9: {
+      std::string buf = optarg;
+      char *tp = strtok(&buf[0], ":");
+      for (int num = 0; num < 3; num++) {
+        if (!tp) die(" (difference-ratio: %s): Format is sub:ins:del.", optarg);
+        long r = atoi(tp);
+        if (strlen(tp) >= 5 || r < 0 || r > 1000) die(" (difference-ratio: %s): Acceptable range is 0-1000.", optarg);
+        (num == 0 ? c.p.sub_ratio : num == 1 ? c.p.ins_ratio : c.p.del_ratio) = r;
+        tp = strtok(NULL, ":");
+      }
+      break;
+    }
+    case 10: c.p.seed = (unsigned int)atoi(optarg); break;
+    case 11: c.sample = optarg; break;
+    case 15: case 16: c.model = optarg; break;
+    case 17:
+      c.p.len_mean = atof(optarg);
+      if (c.p.len_mean < 1 || c.p.len_mean > 1000000) die(" (length-mean: %s): Acceptable range is 1-1000000.", optarg);
+      break;
+    case 18:
+      c.p.len_sd = atof(optarg);
+      if (c.p.len_sd < 0 || c.p.len_sd > 1000000) die(" (length-sd: %s): Acceptable range is 0-1000000.", optarg);
+      break;
+    case 19:
+      c.p.accuracy_mean = atof(optarg);
+      if (c.p.accuracy_mean < 0.0 || c.p.accuracy_mean > 1.0)
+        die(" (accuracy-mean: %s): Acceptable range is 0.0-1.0.", optarg);
+      break;
+    case 20:
+      c.p.pass_num = atoi(optarg);
+      if (c.p.pass_num < 1) die(" (pass_num: %s): Acceptable range is more than 1.", optarg);
+      break;
+    case 21: c.templ = optarg; break;
+    case 22:
+      c.p.hp_del_bias = atof(optarg);
+      if (strlen(optarg) >= 8 || c.p.hp_del_bias < 1 || c.p.hp_del_bias > 10)
+        die(" (hp-del-bias: %s): Acceptable range is 1-10.", optarg);
+      break;
+    case 23: c.device = atoi(optarg); break;
+    case 24: c.no_gzip = true; break;
+    default: break;
+    }
+  }
+  if (argc == 1) {
+    print_help();
+    exit(-1);
+  }
+  // ---- set_sim_param (pbsim.cpp:1451-1688)
+  if (!c.set_flg[0] || !c.set_flg[1]) die(": --strategy and --method must be set.");
+  if (c.p.strategy == PBSIM_STRATEGY_WGS && !c.set_flg[2]) die(": for --strategy wgs, --genome must be set.");
+  if (c.p.strategy == PBSIM_STRATEGY_TRANS && !c.set_flg[3]) die(": for --strategy trans, --transcript must be set.");
+  if (c.p.strategy == PBSIM_STRATEGY_TEMPL) die(": --strategy templ is not provided by the MI355X path yet (SURVEY 8f row 2)");
+  if (c.p.method == PBSIM_METHOD_QS && !c.set_flg[15]) die(": for --method qshmm, --qshmm must be set.");
+  if (c.p.method == PBSIM_METHOD_ERR && !c.set_flg[16]) die(": for --method errhmm, --errhmm must be set.");
+  if (c.set_flg[19]) c.p.accuracy_mean = (int)(c.p.accuracy_mean * 100) * 0.01;
+  if (c.p.len_min > c.p.len_max) {
+    fprintf(stderr, "ERROR: length min(%ld) is greater than max(%ld).\n", (long)c.p.len_min, (long)c.p.len_max);
+    exit(-1);
+  }
+  print_sim_param(c);
+
+  pbsim_ctx *ctx = pbsim_create(&c.p, c.device);
+  if (!ctx) check(0);
+  check(c.p.method == PBSIM_METHOD_ERR ? pbsim_load_errhmm(ctx, c.model.c_str()) : pbsim_load_qshmm(ctx, c.model.c_str()));
+  std::string err;
+  char name[4096];
+
+  if (c.p.strategy == PBSIM_STRATEGY_WGS) {  // pbsim.cpp:667-759
+    pbsim::GenomeInfo gi;
+    if (!pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
+    std::string seq;
+    if (c.p.hp_del_bias != 1) {
+      for (long n = 1; n <= gi.num_seq; n++) {
+        if (!pbsim::load_ref_record(c.prefix.c_str(), n, &seq, &err)) die(": %s", err.c_str());
+        check(pbsim_add_hp_census(ctx, (const uint8_t *)seq.data(), (int64_t)seq.size()));
+      }
+      check(pbsim_finish_hp_census(ctx));
+    }
+    for (long n = 1; n <= gi.num_seq; n++) {
+      if (!pbsim::load_ref_record(c.prefix.c_str(), n, &seq, &err)) die(": %s", err.c_str());
+      check(pbsim_set_reference(ctx, (const uint8_t *)seq.data(), (int64_t)seq.size(), n));
+      FILE *fp_read, *fp_maf;
+      if (c.p.pass_num == 1) {
+        snprintf(name, sizeof name, "%s_%04ld.fq", c.prefix.c_str(), n);
+        fp_read = open_sink(c, name, std::string(name) + ".gz", false);
+      } else {
+        snprintf(name, sizeof name, "%s_%04ld", c.prefix.c_str(), n);
+        fp_read = open_sink(c, std::string(name) + ".sam", std::string(name) + ".bam", true);
+        std::vector<char> h((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
+        pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
+        fwrite(h.data(), 1, h.size() - 1, fp_read);
+      }
+      snprintf(name, sizeof name, "%s_%04ld.maf", c.prefix.c_str(), n);
+      fp_maf = open_sink(c, name, std::string(name) + ".gz", false);
+      pbsim_sink sink = {NULL, write_cb, write_cb};
+      // the two callbacks need different FILE*: wrap through a tiny adapter
+      struct Two { FILE *r, *m; } two = {fp_read, fp_maf};
+      sink.user = &two;
+      sink.on_read_text = [](void *u, const char *t, int64_t k) { return write_cb(((Two *)u)->r, t, k); };
+      sink.on_maf_text = [](void *u, const char *t, int64_t k) { return write_cb(((Two *)u)->m, t, k); };
+      check(pbsim_simulate_wgs(ctx, &sink));
+      pbsim_stats st;
+      check(pbsim_get_stats(ctx, &st));
+      print_simulation_stats(c, st, n);
+      close_sink(c, fp_read);
+      close_sink(c, fp_maf);
+    }
+  } else {  // pbsim.cpp:761-812
+    std::vector<pbsim::Transcript> tr;
+    long total_exp = 0;
+    if (!pbsim::read_transcripts(c.transcript.c_str(), &tr, &total_exp, &err)) die(": %s", err.c_str());
+    fprintf(stderr, ":::: transcript stats ::::\n\n");
+    fprintf(stderr, "file name : %s\n", c.transcript.c_str());
+    fprintf(stderr, "transcript num : %ld\n", (long)tr.size());
+    fprintf(stderr, "total expression value : %ld\n", total_exp);
+    fprintf(stderr, "\n");
+    std::vector<const char *> ids;
+    std::vector<int64_t> plus, minus, lens;
+    std::vector<const uint8_t *> seqs;
+    for (auto &t : tr) {
+      ids.push_back(t.id.c_str());
+      plus.push_back(t.plus);
+      minus.push_back(t.minus);
+      seqs.push_back((const uint8_t *)t.seq.data());
+      lens.push_back((int64_t)strlen(t.seq.c_str()));
+    }
+    check(pbsim_set_transcripts(ctx, (int64_t)tr.size(), ids.data(), plus.data(), minus.data(), seqs.data(), lens.data()));
+    FILE *fp_read, *fp_maf;
+    if (c.p.pass_num == 1) {
+      fp_read = open_sink(c, c.prefix + ".fq", c.prefix + ".fq.gz", false);
+    } else {
+      fp_read = open_sink(c, c.prefix + ".sam", c.prefix + ".bam", true);
+      std::vector<char> h((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
+      pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
+      fwrite(h.data(), 1, h.size() - 1, fp_read);
+    }
+    fp_maf = open_sink(c, c.prefix + ".maf", c.prefix + ".maf.gz", false);
+    struct Two { FILE *r, *m; } two = {fp_read, fp_maf};
+    pbsim_sink sink;
+    sink.user = &two;
+    sink.on_read_text = [](void *u, const char *t, int64_t k) { return write_cb(((Two *)u)->r, t, k); };
+    sink.on_maf_text = [](void *u, const char *t, int64_t k) { return write_cb(((Two *)u)->m, t, k); };
+    check(pbsim_simulate_trans(ctx, &sink));
+    pbsim_stats st;
+    check(pbsim_get_stats(ctx, &st));
+    print_simulation_stats(c, st, 0);
+    close_sink(c, fp_read);
+    close_sink(c, fp_maf);
+  }
+  pbsim_destroy(ctx);
+
+  struct rusage ru;
+  getrusage(RUSAGE_SELF, &ru);
+  struct timeval tv1;
+  gettimeofday(&tv1, NULL);
+  fprintf(stderr, ":::: System utilization ::::\n\n");
+  fprintf(stderr, "CPU time(s) : %ld\n", (long)ru.ru_utime.tv_sec);
+  fprintf(stderr, "Elapsed time(s) : %ld\n", (long)(tv1.tv_sec - tv0.tv_sec));
+  return 0;
+}

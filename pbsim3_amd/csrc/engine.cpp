@@ -123,6 +123,9 @@ struct pbsim_ctx {
   int64_t unit = 0;
   int64_t census[kHpSlots] = {0};
   bool census_done = false;
+  // trans units (pbsim_set_transcripts)
+  int64_t n_units = 0, trans_reads = 0;
+  DevBuf d_read_unit, d_read_minus, d_read_base, d_unit_len, d_unit_rank, d_unit_names, d_off_table, d_ssp, d_ssp_rv;
   // batch
   DevBuf d_flags, d_ref_flags;
   DevBuf d_rawlen, d_len, d_off, d_acc;
@@ -453,8 +456,11 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
                      int64_t *pass0_bases) {
   if (!c || n_reads < 1 || first_read < 1) return fail("pbsim_batch_walk: bad argument");
   NEED_DEVICE(c);
-  if (c->p.strategy != PBSIM_STRATEGY_WGS) return fail("pbsim_batch_walk: wgs strategy only");
-  if (!c->d_seq) return fail("no reference set (pbsim_set_reference)");
+  const bool trans = c->p.strategy == PBSIM_STRATEGY_TRANS;
+  if (c->p.strategy == PBSIM_STRATEGY_TEMPL) return fail("pbsim_batch_walk: templ strategy is not provided");
+  if (!c->d_seq) return fail(trans ? "no transcripts set (pbsim_set_transcripts)" : "no reference set (pbsim_set_reference)");
+  if (trans && (truncate_remaining >= 0 || first_read + n_reads - 1 > c->trans_reads))
+    return fail("pbsim_batch_walk: read range outside the transcript set");
   if (truncate_remaining >= 0 && n_reads != 1) return fail("a truncated batch holds exactly one read");
   if (first_read + n_reads > 0xffffffffLL) return fail("read index exceeds 32 bits");
   HIP_OK(hipSetDevice(c->device));
@@ -513,7 +519,18 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   h.len = c->d_len.as<int32_t>();
   h.off = c->d_off.as<int32_t>();
   h.acc = c->d_acc.as<uint8_t>();
-  launch_header_wgs(h, c->stream);
+  h.read_unit = nullptr;
+  if (trans) {
+    h.read_unit = c->d_read_unit.as<int32_t>() + (first_read - 1);
+    h.unit_len = c->d_unit_len.as<int64_t>();
+    h.unit_rank = c->d_unit_rank.as<int32_t>();
+    h.off_table = c->d_off_table.as<int32_t>();
+    h.ssp = c->d_ssp.as<uint8_t>();
+    h.ssp_rv = c->d_ssp_rv.as<int32_t>();
+    launch_header_trans(h, c->stream);
+  } else {
+    launch_header_wgs(h, c->stream);
+  }
 
   SortArgs s;
   s.n_reads = n_reads;
@@ -542,7 +559,7 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   WalkArgs w;
   memset(&w, 0, sizeof w);
   w.seed = c->p.seed;
-  w.unit = (uint32_t)c->unit;
+  w.unit = trans ? 0u : (uint32_t)c->unit;
   w.first_read = first_read;
   w.pass_num = P;
   w.ncls = ncls;
@@ -551,6 +568,10 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   w.ref.len = c->ref_len;
   w.len = h.len;
   w.off = h.off;
+  if (trans) {
+    w.read_base = c->d_read_base.as<int64_t>() + (first_read - 1);
+    w.read_minus = c->d_read_minus.as<uint8_t>() + (first_read - 1);
+  }
   w.cls_blob = c->d_cls.as<uint8_t>();
   w.class_start = s.class_start;
   w.task_of_slot = s.task_of_slot;
@@ -609,7 +630,7 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   c->b_first = first_read;
   c->b_n = n_reads;
   c->b_slots_max = slots_max;
-  c->b_truncated = truncate_remaining >= 0;
+  c->b_truncated = truncate_remaining >= 0 || trans;  // trans has no quota: every read is final
   c->b_walked = true;
   c->b_finalized = false;
   c->b_pass0 = f.sums[0];
@@ -643,6 +664,12 @@ static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
   t->id_prefix_len = (int)strlen(c->p.id_prefix);
   memcpy(t->id_prefix, c->p.id_prefix, sizeof t->id_prefix);
   t->rq_len = snprintf(t->rq_text, sizeof t->rq_text, "%f", c->p.accuracy_mean);  // pbsim.cpp:4027
+  if (c->p.strategy == PBSIM_STRATEGY_TRANS) {
+    t->read_unit = c->d_read_unit.as<int32_t>() + (c->b_first - 1);
+    t->read_minus = c->d_read_minus.as<uint8_t>() + (c->b_first - 1);
+    t->unit_len = c->d_unit_len.as<int64_t>();
+    t->unit_names = c->d_unit_names.as<char>();
+  }
 }
 
 int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *info) {
@@ -668,7 +695,10 @@ int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_inf
   bi.n_reads = c->b_n;
   bi.n_final = n_final;
   bi.len_total_after = len_total_before + cum_final;
-  if (c->b_truncated) {
+  if (c->p.strategy == PBSIM_STRATEGY_TRANS) {
+    bi.quota_reached = 0;
+    bi.need_truncated_read = 0;
+  } else if (c->b_truncated) {
     bi.quota_reached = bi.len_total_after >= quota;
     bi.need_truncated_read = !bi.quota_reached;
   } else {
@@ -863,12 +893,122 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
   return PBSIM_SUCCEEDED;
 }
 
-int pbsim_set_transcripts(pbsim_ctx *, int64_t, const char *const *, const int64_t *, const int64_t *,
-                          const uint8_t *const *, const int64_t *) {
-  return fail("pbsim_set_transcripts: trans strategy is not built yet");
+// Replaces get_transcript_inf (pbsim.cpp:1075-1136) + the streaming reader and
+// per-transcript hp of simulate_by_*_trans (:4428-4485): all units are concatenated
+// with '\n' separators (a byte no sequence contains, so homopolymer runs never
+// join across units) and made resident once.
+int pbsim_set_transcripts(pbsim_ctx *c, int64_t n, const char *const *ids, const int64_t *plus_exp,
+                          const int64_t *minus_exp, const uint8_t *const *seqs, const int64_t *lens) {
+  if (!c || n < 1 || !ids || !plus_exp || !minus_exp || !seqs || !lens) return fail("pbsim_set_transcripts: bad argument");
+  NEED_DEVICE(c);
+  if (c->p.strategy != PBSIM_STRATEGY_TRANS) return fail("pbsim_set_transcripts: strategy is not trans");
+  if (c->p.method == PBSIM_METHOD_ERR && c->hdr.acc_hi == 100)
+    return fail("errhmm trans with accuracy class 100 clobbers the reference's loop counter (pbsim.cpp:4533); refused");
+  HIP_OK(hipSetDevice(c->device));
+  const int keep_first = c->p.method == PBSIM_METHOD_ERR;  // SURVEY Q6 (pbsim.cpp:4457 vs 2778)
+  int64_t total = 0, reads = 0, max_len = 0;
+  for (int64_t u = 0; u < n; u++) {
+    if (lens[u] < 1 || lens[u] > 1000000) return fail("transcript length outside 1-1000000");
+    total += lens[u] + 1;
+    reads += (int64_t)(int)(plus_exp[u] + minus_exp[u]);  // `int read_num` (pbsim.cpp:4149)
+    max_len = std::max(max_len, lens[u]);
+  }
+  if (reads < 1) return fail("transcript set has no expression");
+  if (reads > 0x7fffff00LL) return fail("too many reads");
+  std::vector<uint8_t> cat((size_t)total);
+  std::vector<int64_t> ubase(n), ulen(n);
+  std::vector<int32_t> urank(n), offt((size_t)n * 21), runit((size_t)reads);
+  std::vector<int64_t> rbase((size_t)reads);
+  std::vector<uint8_t> rminus((size_t)reads);
+  std::vector<char> names((size_t)n * 132, 0);
+  int64_t pos = 0, r = 0;
+  for (int64_t u = 0; u < n; u++) {
+    memcpy(cat.data() + pos, seqs[u], (size_t)lens[u]);
+    cat[pos + lens[u]] = '\n';
+    ubase[u] = pos;
+    ulen[u] = lens[u];
+    urank[u] = (int32_t)ceil((double)lens[u] / 1000);  // pbsim.cpp:4494
+    for (int k = 0; k < 21; k++) {                      // pbsim.cpp:4496-4501
+      const double value = (k == 0) ? 0.0 : ((double)(k * 5) - 2.5) / 100;
+      offt[(size_t)u * 21 + k] = (int32_t)(int)((double)lens[u] * value + 0.5);
+    }
+    strncpy(&names[(size_t)u * 132], ids[u], 128);
+    const int64_t rn = (int64_t)(int)(plus_exp[u] + minus_exp[u]);
+    for (int64_t i = 1; i <= rn; i++, r++) {
+      runit[r] = (int32_t)u;
+      rbase[r] = pos;
+      rminus[r] = (i > plus_exp[u]) ? 1 : 0;  // pbsim.cpp:4516-4522
+    }
+    pos += lens[u] + 1;
+  }
+  // start-position buckets per rank (pbsim.cpp:4200-4224)
+  const int rank_max = (int)ceil((float)max_len / 1000);  // pbsim.cpp:1133
+  SspTables st;
+  build_ssp_tables(rank_max, &st);
+  std::vector<uint8_t> ssp((size_t)(rank_max + 1) * 1000, 0);
+  for (int k = 1; k <= rank_max; k++)
+    for (int i = 1; i <= 1000; i++) ssp[(size_t)k * 1000 + (i - 1)] = (uint8_t)(st.value[(size_t)k * 1001 + i] / 5);
+
+  // hp-del-bias census weighted by expression (pbsim.cpp:4352-4426)
+  hp_bias_default(&c->bias);
+  c->bias.hp11_seen = false;
+  if (c->p.hp_del_bias != 1) {
+    int64_t freq[kHpSlots] = {0};
+    for (int64_t u = 0; u < n; u++)
+      hp_census_weighted(seqs[u], lens[u], (int64_t)(int)(plus_exp[u] + minus_exp[u]), keep_first, freq);
+    hp_bias_from_census(c->p.hp_del_bias, freq, &c->bias);
+    c->bias.hp11_seen = freq[11] > 0;  // hpfreq[11] aliases hp_del_bias[0] (Q15)
+  }
+  c->class_tables_dirty = true;
+
+  HIP_OK(c->d_seq_own.ensure((size_t)total + 64));
+  HIP_OK(hipMemcpyAsync(c->d_seq_own.p, cat.data(), (size_t)total, hipMemcpyHostToDevice, c->stream));
+  HIP_OK(hipMemsetAsync(c->d_seq_own.as<uint8_t>() + total, 0, 64, c->stream));
+  int64_t census[kHpSlots] = {0};
+  if (!prepare_reference(c, c->d_seq_own.as<uint8_t>(), total, keep_first, census)) return PBSIM_FAILED;
+  if (!upload(c->d_read_unit, runit.data(), runit.size() * 4, c->stream)) return PBSIM_FAILED;
+  if (!upload(c->d_read_base, rbase.data(), rbase.size() * 8, c->stream)) return PBSIM_FAILED;
+  if (!upload(c->d_read_minus, rminus.data(), rminus.size(), c->stream)) return PBSIM_FAILED;
+  if (!upload(c->d_unit_len, ulen.data(), ulen.size() * 8, c->stream)) return PBSIM_FAILED;
+  if (!upload(c->d_unit_rank, urank.data(), urank.size() * 4, c->stream)) return PBSIM_FAILED;
+  if (!upload(c->d_unit_names, names.data(), names.size(), c->stream)) return PBSIM_FAILED;
+  if (!upload(c->d_off_table, offt.data(), offt.size() * 4, c->stream)) return PBSIM_FAILED;
+  if (!upload(c->d_ssp, ssp.data(), ssp.size(), c->stream)) return PBSIM_FAILED;
+  if (!upload(c->d_ssp_rv, st.rv.data(), st.rv.size() * 4, c->stream)) return PBSIM_FAILED;
+  HIP_OK(hipStreamSynchronize(c->stream));
+  c->d_seq = c->d_seq_own.as<uint8_t>();
+  c->ref_len = total;  // only sizes the batches; record lengths come from unit_len
+  c->unit = 0;
+  c->n_units = n;
+  c->trans_reads = reads;
+  c->b_walked = c->b_finalized = false;
+  return PBSIM_SUCCEEDED;
 }
-int pbsim_simulate_trans(pbsim_ctx *, const pbsim_sink *) {
-  return fail("pbsim_simulate_trans: trans strategy is not built yet");
+
+// simulate_by_errhmm_trans / simulate_by_qshmm_trans (pbsim.cpp:4428-4770, 2738-3017): fixed read
+// count per transcript, no quota; reads are numbered globally like sim.res_num
+int pbsim_simulate_trans(pbsim_ctx *c, const pbsim_sink *sink) {
+  if (!c) return fail("bad argument");
+  NEED_DEVICE(c);
+  if (c->p.strategy != PBSIM_STRATEGY_TRANS) return fail("pbsim_simulate_trans: strategy is not trans");
+  if (!c->d_seq || c->trans_reads < 1) return fail("no transcripts set (pbsim_set_transcripts)");
+  pbsim_reset_stats(c);
+  int64_t next_read = 1, cap = batch_capacity(c);
+  while (next_read <= c->trans_reads) {
+    const int64_t n = std::min(cap, c->trans_reads - next_read + 1);
+    if (!pbsim_batch_walk(c, next_read, n, -1, nullptr)) {
+      if (g_err.rfind("scratch budget exceeded", 0) == 0 && n > 1) {
+        cap = std::max<int64_t>(1, n / 2);
+        continue;
+      }
+      return PBSIM_FAILED;
+    }
+    pbsim_batch_info bi;
+    if (!pbsim_batch_finalize(c, 0, &bi)) return PBSIM_FAILED;
+    if (!deliver(c, sink)) return PBSIM_FAILED;
+    next_read += bi.n_final;
+  }
+  return PBSIM_SUCCEEDED;
 }
 
 int pbsim_prof_reset(pbsim_ctx *c) {

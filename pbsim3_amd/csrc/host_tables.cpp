@@ -272,6 +272,23 @@ void hp_bias_from_census(double hp_del_bias, const int64_t hpfreq[kHpSlots], HpB
   for (int i = 1; i <= 10; i++) b->bias[i] *= rate;
 }
 
+void hp_census_weighted(const uint8_t *seq, int64_t len, int64_t weight, int keep_first_case, int64_t hpfreq[kHpSlots]) {
+  auto at = [&](int64_t i) -> int {
+    int ch = seq[i];
+    if (!(keep_first_case && i == 0) && ch >= 'a' && ch <= 'z') ch -= 32;
+    return ch;
+  };
+  int64_t start = 0;
+  for (int64_t i = 1; i <= len; i++) {
+    if (i < len && at(i - 1) == at(i)) continue;
+    const int64_t run = i - start;
+    int v = (run <= 11) ? (int)run : ((run & 1) ? 11 : 10);  // nnum oscillation, pbsim.cpp:4396-4398
+    if (at(i - 1) == 'N') v = 1;
+    hpfreq[v] += weight * run;
+    start = i;
+  }
+}
+
 bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBias &b, bool emis_skip_le,
                             ErrClassTables *t, std::string *err) {
   t->acc_lo = h.acc_lo;

@@ -66,6 +66,8 @@ struct HpBias {
 };
 void hp_bias_default(HpBias *b);
 void hp_bias_from_census(double hp_del_bias, const int64_t hpfreq[kHpSlots], HpBias *b);
+// trans pre-pass (pbsim.cpp:4385-4409): hpfreq[v] += weight * (run length) per homopolymer run
+void hp_census_weighted(const uint8_t *seq, int64_t len, int64_t weight, int keep_first_case, int64_t hpfreq[kHpSlots]);
 
 // ---- device class tables -------------------------------------------------------
 // ERRHMM: one blob per accuracy class acc_lo..acc_hi, uniform stride.

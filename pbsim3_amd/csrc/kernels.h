@@ -51,6 +51,13 @@ struct HeaderArgs {
   int64_t truncate_remaining;  // <0: none
   int32_t *rawlen, *len, *off;
   uint8_t *acc;
+  // trans (pbsim.cpp:4488-4504): per-read unit, per-unit length / rank / the 21 start offsets
+  const int32_t *read_unit;   // [n_reads] (already offset to the batch)
+  const int64_t *unit_len;    // [n_units]
+  const int32_t *unit_rank;   // [n_units] ceil(len/1000)
+  const int32_t *off_table;   // [n_units][21] int(len*((5k-2.5)/100)+0.5), k=0 -> 0
+  const uint8_t *ssp;         // [rank_max+1][1000] start bucket k (prob2ssp/5)
+  const int32_t *ssp_rv;      // [rank_max+1]
 };
 
 struct SortArgs {
@@ -82,6 +89,8 @@ struct WalkArgs {
   int32_t ncls;
   RefView ref;
   const int32_t *len, *off;
+  const int64_t *read_base;  // trans: offset of the read's unit inside the concatenated reference (NULL: 0)
+  const uint8_t *read_minus; // trans: strand per read (NULL: wgs parity rule)
   const uint8_t *cls_blob;   // ncls blobs of `stride` bytes
   uint32_t stride, rows_off, init_off, tran_off, emis_off, freq_off, rv_off;
   const int32_t *class_start;
@@ -134,6 +143,7 @@ void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int64_t len, int64_t *t
                               int64_t *carry_start, int64_t *carry_next, int keep_first_case, DeviceFlags *flags,
                               hipStream_t s);
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s);
+void launch_header_trans(const HeaderArgs &a, hipStream_t s);
 void launch_task_sort(const SortArgs &a, hipStream_t s);
 void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s);
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s);

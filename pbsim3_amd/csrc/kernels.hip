@@ -246,6 +246,29 @@ __global__ __launch_bounds__(256) void k_header_wgs(HeaderArgs a) {
   a.acc[i] = acc;
 }
 
+// K1t: read header (trans).  pbsim.cpp:4488-4504 (= 2809-2825): no quota, start
+// position from the rank's bucket table, length clipped to the transcript end.
+__global__ __launch_bounds__(256) void k_header_trans(HeaderArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_reads) return;
+  const uint32_t read = (uint32_t)(a.first_read + i);
+  const U4 w = header_block(a.seed, 0u, read);
+  const int u = a.read_unit[i];
+  const int64_t G = a.unit_len[u];
+  int64_t L = a.prob2len[(int64_t)(w.x % (uint32_t)a.len_rv) + 1];
+  const uint8_t acc = a.prob2acc[(int64_t)(w.y % (uint32_t)a.acc_rv) + 1];
+  const int rank = a.unit_rank[u];
+  const uint32_t rv = (uint32_t)a.ssp_rv[rank];
+  const uint32_t k = a.ssp[(size_t)rank * 1000 + w.z % (rv ? rv : 1u)];
+  const int64_t off = a.off_table[(size_t)u * 21 + k];
+  if (off + L > G) L = G - off;
+  if (L < 0) L = 0;
+  a.rawlen[i] = (int32_t)L;
+  a.len[i] = (int32_t)L;
+  a.off[i] = (int32_t)off;
+  a.acc[i] = acc;
+}
+
 // ---------------------------------------------------------------------------
 // Ks: counting sort of tasks by (class asc, length desc)
 // ---------------------------------------------------------------------------
@@ -464,14 +487,16 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   int L = 0;
   int64_t off = 0;
   uint32_t read_idx = 0, pass = 0;
+  bool minus = false;
   if (valid) {
     const int r = task / a.pass_num;
     pass = (uint32_t)(task - r * a.pass_num);
     read_idx = (uint32_t)(a.first_read + r);
     L = a.len[r];
-    off = a.off[r];
+    off = a.off[r] + (a.read_base ? a.read_base[r] : 0);
+    // strand: wgs by parity of the read number (pbsim.cpp:3820-3826, Q9); trans by expression (:4516-4522)
+    minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
   }
-  const bool minus = valid && ((read_idx & 1u) == 0);  // pbsim.cpp:3820-3826 (Q9)
   const int cap_dw = a.wave_cap[wave];
   walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
@@ -638,14 +663,16 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   int L = 0;
   int64_t off = 0;
   uint32_t read_idx = 0, pass = 0;
+  bool minus = false;
   if (valid) {
     const int r = task / a.pass_num;
     pass = (uint32_t)(task - r * a.pass_num);
     read_idx = (uint32_t)(a.first_read + r);
     L = a.len[r];
-    off = a.off[r];
+    off = a.off[r] + (a.read_base ? a.read_base[r] : 0);
+    // strand: wgs by parity of the read number (pbsim.cpp:3820-3826, Q9); trans by expression (:4516-4522)
+    minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
   }
-  const bool minus = valid && ((read_idx & 1u) == 0);
   const int cap_dw = a.wave_cap[wave];
   walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
@@ -1187,6 +1214,11 @@ void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int64_t len, int64_t *t
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s) {
   if (a.n_reads <= 0) return;
   hipLaunchKernelGGL(k_header_wgs, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
+}
+
+void launch_header_trans(const HeaderArgs &a, hipStream_t s) {
+  if (a.n_reads <= 0) return;
+  hipLaunchKernelGGL(k_header_trans, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
 }
 
 void launch_task_sort(const SortArgs &a, hipStream_t s) {

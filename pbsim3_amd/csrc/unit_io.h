@@ -1,0 +1,32 @@
+// unit_io.h -- host loaders of the CLI shim: multi-FASTA splitter / record
+// loader (get_genome_inf pbsim.cpp:896-991, get_genome_seq :997-1033) and the
+// transcript TSV reader (get_transcript_inf :1075-1136, the in-loop reader
+// :4428-4455).  Plain host C++; the per-base work (toupper, hp) is on the GPU.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace pbsim {
+
+struct GenomeInfo {
+  long num_seq = 0;
+  long max_len = 0;
+  std::vector<long> len;          // per record
+  std::vector<std::string> id;    // per record (truncated to 128 chars)
+};
+
+// Splits <file> into <prefix>_NNNN.ref, printing the reference's ":::: Reference stats ::::" block.
+bool split_genome(const char *file, const char *prefix, GenomeInfo *info, std::string *err);
+// Re-reads <prefix>_NNNN.ref into one contiguous record (no newlines, case preserved).
+bool load_ref_record(const char *prefix, long num, std::string *seq, std::string *err);
+
+struct Transcript {
+  std::string id;
+  long plus = 0, minus = 0;
+  std::string seq;
+};
+bool read_transcripts(const char *file, std::vector<Transcript> *out, long *total_exp, std::string *err);
+
+}  // namespace pbsim

@@ -45,9 +45,10 @@ def test_fat_binary_is_gfx950_only():
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", P.lib_path()],
                          capture_output=True, text=True, cwd="/tmp").stdout
     archs = set(re.findall(r"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", out))
-    for f in os.listdir("/tmp"):
+    d = os.path.dirname(P.lib_path())   # llvm-objdump drops the extracted bundles next to the input
+    for f in os.listdir(d):
         if f.startswith(os.path.basename(P.lib_path()) + "."):
-            os.remove(os.path.join("/tmp", f))
+            os.remove(os.path.join(d, f))
     assert archs == {"gfx950"}, archs
 
 

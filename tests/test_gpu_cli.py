@@ -1,0 +1,47 @@
+"""The `pbsim` CLI shim (pbsim3_amd/bin/pbsim, C++ over the C ABI) against the
+golden vectors the reference produced in keyed-Philox mode: every output file
+(.ref, FASTQ or SAM text, MAF) and the stderr report, byte for byte."""
+import os
+import subprocess
+
+import pytest
+
+import harness
+from cases import CASES
+
+MANIFEST = harness.load_manifest()
+CLI = os.path.join(harness.ROOT, "pbsim3_amd", "bin", "pbsim")
+
+pytestmark = pytest.mark.gpu
+
+
+def run_cli(args, workdir):
+    import pbsim3_amd.build as b
+    b.build()
+    p = subprocess.run([CLI] + harness.resolve(args) + ["--prefix", os.path.join(workdir, "out"), "--no-gzip"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    outs = harness.collect(workdir)
+    outs[".stderr"] = harness.strip_report(p.stderr).encode()
+    return outs
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_cli_matches_reference_golden(case, tmp_path):
+    outs = run_cli(CASES[case]["args"], str(tmp_path))
+    want = MANIFEST[f"{case}/philox"]
+    assert sorted(outs) == sorted(want), (sorted(outs), sorted(want))
+    for k, v in outs.items():
+        if harness.sha(v) != want[k]["sha256"]:
+            ref = harness.run_oracle(CASES[case]["args"], "philox", str(tmp_path / "o"))[k] if (tmp_path / "o").mkdir() is None else b""
+            n = next((i for i, (x, y) in enumerate(zip(v, ref)) if x != y), min(len(v), len(ref)))
+            raise AssertionError(f"{case}{k}: differs at byte {n} (sizes {len(v)} vs {len(ref)}):\n"
+                                 f"  got  {v[max(0, n - 80):n + 60]!r}\n  want {ref[max(0, n - 80):n + 60]!r}")
+
+
+def test_cli_error_convention(tmp_path):
+    """ERROR: message on stderr and exit status 255 like the reference's exit(-1)."""
+    p = subprocess.run([CLI, "--strategy", "wgs", "--method", "errhmm", "--genome", "/nonexistent",
+                        "--errhmm", "/nonexistent.model"], capture_output=True, text=True)
+    assert p.returncode == 255
+    assert "ERROR: Cannot open file" in p.stderr
