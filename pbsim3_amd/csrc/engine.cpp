@@ -593,7 +593,7 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
     w.rows_off = c->ect.rows_off;
     w.init_off = c->ect.init_off;
     w.tran_off = c->ect.tran_off;
-    launch_walk_errhmm(w, slots_max, c->ect.stride, c->stream);
+    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->stream);
   } else {
     w.stride = c->qct.stride;
     w.rv_off = c->qct.rv_off;

@@ -418,7 +418,6 @@ bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBi
       }
       if (j <= m.state_max[mc]) {
         if (r.tran_rv[j] != 1000) t->all_rv_1000 = false;
-        if (r.emis_rv[j] != 1000 && r.emis_rv[j] != 0) t->all_rv_1000 = false;
       }
       for (long s = 1; s <= 1000; s++) dst[t->tran_off + 1000u * (uint32_t)(j - 1) + (s - 1)] = r.tran[j][s];
     }

@@ -145,7 +145,7 @@ void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int64_t len, int64_t *t
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s);
 void launch_header_trans(const HeaderArgs &a, hipStream_t s);
 void launch_task_sort(const SortArgs &a, hipStream_t s);
-void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s);
+void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, hipStream_t s);
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s);
 // exclusive scan of int64 (in-place allowed: out may equal in); tmp needs (n/1024+2) int64
 void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total, hipStream_t s);

@@ -462,6 +462,15 @@ struct StepOut {
   uint32_t b, mr, mf;
 };
 
+// kFastRv: every init/transition modulus of the class tables is 1000 (true for
+// all shipped models, checked on the host): `% 1000` folds to a multiply-high.
+//
+// The step body is written branch-free (selects on the lane's `act` flag): the
+// kernel is VALU/SALU-issue bound, and every divergent `if` costs exec-mask
+// bookkeeping for all 64 lanes.  Only three rare paths stay as real branches:
+// states whose emission modulus is not 1000, the sub-block-1 draws (out-of-range
+// accuracy classes, non-ACGT substitutions), and the look-ahead refill.
+template <bool kFastRv>
 __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -474,6 +483,20 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     const uint4 *src = reinterpret_cast<const uint4 *>(a.cls_blob + (size_t)cls * a.stride);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = tid; i < a.stride / 16; i += kWG) dst[i] = src[i];
+  }
+  // byte LUTs behind the class blob: s_comp[0..255] identity, [256..511] revcomp's
+  // base map; s_sub[c*4+k] = substitution k of base c (pbsim.cpp:5481-5484), 0 for non-ACGT
+  uint8_t *s_comp = lds + a.stride;
+  uint8_t *s_sub = s_comp + 512;
+  {
+    const uint32_t c = (uint32_t)tid;
+    s_comp[c] = (uint8_t)c;
+    s_comp[256 + c] = (uint8_t)complement(c);
+    const uint32_t t = sub_table(c);
+    s_sub[c * 4 + 0] = (uint8_t)(t & 0xffu);
+    s_sub[c * 4 + 1] = (uint8_t)((t >> 8) & 0xffu);
+    s_sub[c * 4 + 2] = (uint8_t)((t >> 16) & 0xffu);
+    s_sub[c * 4 + 3] = 0;
   }
   __syncthreads();
   const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
@@ -503,114 +526,142 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
   uint32_t *read_row = maf_ref + (size_t)cap_dw * 64;
   const int cap = 2 * L + kScratchPad;
-  const uint32_t *seq32 = reinterpret_cast<const uint32_t *>(a.ref.seq);
-  const uint32_t *hp32 = reinterpret_cast<const uint32_t *>(a.ref.hp);
 
   int ro = 0, q = 0, m = 0;
   uint32_t state = 0, tran_rv = 1;
-  uint32_t acc_r = 0, acc_f = 0, acc_rd = 0;
+  uint32_t acc_r = 0, acc_f = 0;
+  unsigned long long acc_rd = 0;  // read bases not yet stored: q & 3 old ones + this group's
   int nsub = 0, nins = 0, ndel = 0;
-  int64_t cur_wi = -1;
-  uint32_t wseq = 0, whp = 0;
-  bool active = valid && L > 0;
+  bool act = valid && L > 0;
   int group = 0;
 
-  while (__any(active)) {
+  // Reference window: the dword under the cursor plus the next one in walking
+  // direction, fetched one group ahead so a lone long read never waits on HBM.
+  const int64_t p_first = minus ? (off + L - 1) : off;
+  const uint32_t pl0 = (uint32_t)p_first;  // low bits are all the cursor arithmetic needs
+  const int wstep = minus ? -1 : 1;
+  const uint32_t comp_off = minus ? 256u : 0u;
+  const uint32_t *lane_seq = reinterpret_cast<const uint32_t *>(a.ref.seq) + (p_first >> 2);
+  const uint32_t *lane_hp = reinterpret_cast<const uint32_t *>(a.ref.hp) + (p_first >> 2);
+  int rel = 0;  // current dword, relative to the lane's first one
+  uint32_t cur_wl = pl0 >> 2;
+  uint32_t wseq = 0, whp = 0, nseq = 0, nhp = 0;
+  bool need_next = false;
+  if (act) {
+    wseq = lane_seq[0];
+    whp = lane_hp[0];
+    const int nrel = ((p_first >> 2) + wstep < 0) ? 0 : wstep;
+    nseq = lane_seq[nrel];
+    nhp = lane_hp[nrel];
+  }
+
+  while (__any(act)) {
+    // One Philox block per MAF column; the four columns of this group are
+    // independent of the walk, so their 4 x 20 multiplies interleave.
+    U4 W[4];
+    if (mode != kModeVerbatim) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) W[j] = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 0u);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) W[j] = U4{0, 0, 0, 0};
+    }
+    const int q_group = q;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      if (active) {
-        const int64_t p = minus ? (off + L - 1 - ro) : (off + ro);
-        const int64_t wi = p >> 2;
-        if (wi != cur_wi) {
-          wseq = seq32[wi];
-          whp = hp32[wi];
-          cur_wi = wi;
-        }
-        const uint32_t sh = ((uint32_t)p & 3u) * 8u;
-        uint32_t nt = (wseq >> sh) & 0xffu;
-        const uint32_t hp = (whp >> sh) & 0xffu;
-        if (minus) nt = complement(nt);
-        const bool acgt = (nt == 'A') | (nt == 'C') | (nt == 'G') | (nt == 'T');
+      const U4 w = W[j];
+      // ---- reference base under the cursor
+      const uint32_t pl = minus ? (pl0 - (uint32_t)ro) : (pl0 + (uint32_t)ro);
+      const bool cross = act && ((pl >> 2) != cur_wl);  // at most one dword boundary per group
+      wseq = cross ? nseq : wseq;
+      whp = cross ? nhp : whp;
+      cur_wl = cross ? (pl >> 2) : cur_wl;
+      rel += cross ? wstep : 0;
+      need_next = need_next || cross;
+      const uint32_t sh = (pl & 3u) * 8u;
+      const uint32_t nt = s_comp[((wseq >> sh) & 0xffu) + comp_off];
+      const uint32_t hp = (whp >> sh) & 0xffu;
 
-        uint32_t e = 0;
-        U4 w = U4{0, 0, 0, 0}, v = U4{0, 0, 0, 0};
-        if (mode != kModeVerbatim) {
-          w = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 0u);
-          uint32_t mod, base;
-          if (q == 0) {  // Q2: re-initialise while nothing has been emitted yet
-            mod = init_rv;
-            base = a.init_off;
-          } else {
-            mod = tran_rv;
-            base = a.tran_off + (state - 1u) * 1000u;
-          }
+      // ---- state, deletion test, emission class
+      uint32_t e = 0;
+      if (mode != kModeVerbatim) {
+        uint32_t idx;
+        if (kFastRv) {
+          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 1000u) + w.x % 1000u;
+        } else {
+          uint32_t mod = (q == 0) ? init_rv : tran_rv;  // Q2: re-initialise while nothing has been emitted
           mod = mod ? mod : 1u;
-          state = lds[base + w.x % mod];
-          const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + state * 32u);
-          tran_rv = row[0];
-          const uint32_t emis_rv = row[1], e0 = row[2], e1 = row[3];
-          const uint32_t thr = row[4 + (hp < 12u ? hp : 11u)];
-          if (w.y % 1000u + 1u <= thr) {
-            e = 3;
-          } else if (emis_rv == 0) {
+          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 1000u) + w.x % mod;
+        }
+        const uint32_t st = lds[idx];
+        state = act ? st : state;
+        const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + state * 32u);
+        tran_rv = row[0];
+        const uint32_t emis_rv = row[1], e0 = row[2], e1 = row[3];
+        const uint32_t thr = row[4 + (hp < 12u ? hp : 11u)];
+        const bool del = (w.y % 1000u + 1u) <= thr;
+        const uint32_t i1000 = w.z % 1000u + 1u;
+        e = (uint32_t)(i1000 > e0) + (uint32_t)(i1000 > e1);
+        if (!del && emis_rv != 1000u) {  // near-pure-deletion states (rare)
+          if (emis_rv == 0) {
             e = w.z % 3u;
           } else {
             const uint32_t i = w.z % emis_rv + 1u;
             e = (uint32_t)(i > e0) + (uint32_t)(i > e1);
           }
-          const bool need1 =
-              (mode == kModeBelow && e == 0) || (mode == kModeAbove && e != 0) || (!acgt && e == 1);
-          if (need1) {
-            v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 1u);
-            if (mode == kModeBelow && e == 0) {
-              if (v.x % 100u + 1u <= rate_mag) e = v.y % 3u + 1u;
-            } else if (mode == kModeAbove && e != 0) {
-              if (v.x % 100u + 1u <= rate_mag) e = 0;
-            }
-          }
         }
-        uint32_t b = nt;
-        if (e == 1) {
-          b = acgt ? ((sub_table(nt) >> ((w.w % 3u) * 8u)) & 0xffu) : ((kATGC >> ((v.z & 3u) * 8u)) & 0xffu);
-          nsub++;
-        } else if (e == 2) {
-          const uint32_t k = w.w & 7u;
-          b = (k >= 4u) ? nt : ((kATGC >> (k * 8u)) & 0xffu);
-          nins++;
-        } else if (e == 3) {
-          ndel++;
-        }
-        const uint32_t mr = (e == 3) ? (uint32_t)'-' : b;
-        const uint32_t mf = (e == 2) ? (uint32_t)'-' : nt;
-        acc_r |= mr << (8 * j);
-        acc_f |= mf << (8 * j);
-        if (e != 3) {
-          acc_rd |= b << ((q & 3) * 8);
-          q++;
-          if ((q & 3) == 0) {
-            read_row[(size_t)((q >> 2) - 1) * 64] = acc_rd;
-            acc_rd = 0;
-          }
-        }
-        ro += (e != 2);
-        m++;
-        if (m >= cap) {
-          atomicOr(&a.flags->error, kErrScratchOverflow);
-          ro = L;
-        }
-        active = ro < L;
+        e = del ? 3u : e;
       }
+      uint32_t subb = s_sub[nt * 4u + w.w % 3u];  // 0 for a non-ACGT reference base
+      const bool need1 =
+          act && ((mode == kModeBelow && e == 0) || (mode == kModeAbove && e != 0) || (subb == 0 && e == 1));
+      if (need1) {
+        const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 1u);
+        if (mode == kModeBelow && e == 0) {
+          if (v.x % 100u + 1u <= rate_mag) e = v.y % 3u + 1u;
+        } else if (mode == kModeAbove && e != 0) {
+          if (v.x % 100u + 1u <= rate_mag) e = 0;
+        }
+        if (subb == 0) subb = (kATGC >> ((v.z & 3u) * 8u)) & 0xffu;
+      }
+      // ---- emit
+      const uint32_t insb = (w.w & 4u) ? nt : ((kATGC >> ((w.w & 3u) * 8u)) & 0xffu);
+      const uint32_t b = (e == 1) ? subb : (e == 2) ? insb : nt;
+      const uint32_t mr = (e == 3) ? (uint32_t)'-' : b;
+      const uint32_t mf = (e == 2) ? (uint32_t)'-' : nt;
+      acc_r |= act ? (mr << (8 * j)) : 0u;
+      acc_f |= act ? (mf << (8 * j)) : 0u;
+      const bool has = act && (e != 3);
+      acc_rd |= has ? ((unsigned long long)b << (((uint32_t)(q - q_group) + ((uint32_t)q_group & 3u)) * 8u)) : 0ull;
+      q += has ? 1 : 0;
+      nsub += (act && e == 1) ? 1 : 0;
+      nins += (act && e == 2) ? 1 : 0;
+      ndel += (act && e == 3) ? 1 : 0;
+      ro += (act && e != 2) ? 1 : 0;
+      m += act ? 1 : 0;
+      act = act && (ro < L) && (m < cap);
     }
     if (valid && m > group * 4) {
       maf_read[(size_t)group * 64] = acc_r;
       maf_ref[(size_t)group * 64] = acc_f;
+      // the low dword of the pending read bases is final once 4 are present; storing it
+      // early is harmless (same slot is rewritten when it completes)
+      read_row[(size_t)(q_group >> 2) * 64] = (uint32_t)acc_rd;
+    }
+    if ((q >> 2) != (q_group >> 2)) acc_rd >>= 32;
+    if (need_next && act) {  // refill the look-ahead dword; consumed at the next boundary
+      const int nrel = ((p_first >> 2) + rel + wstep < 0) ? rel : rel + wstep;
+      nseq = lane_seq[nrel];
+      nhp = lane_hp[nrel];
+      need_next = false;
     }
     acc_r = 0;
     acc_f = 0;
     group++;
   }
   if (valid) {
-    if (q & 3) read_row[(size_t)(q >> 2) * 64] = acc_rd;
+    if (q & 3) read_row[(size_t)(q >> 2) * 64] = (uint32_t)acc_rd;
+    if (ro < L) atomicOr(&a.flags->error, kErrScratchOverflow);
     a.out_len[task] = q;
     a.maf_len[task] = m;
     a.nsub[task] = nsub;
@@ -1238,8 +1289,11 @@ void launch_task_sort(const SortArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_wg_scatter, dim3(blocks_for(n_wg, 256)), dim3(256), 0, s, a, a.wg_start, a.wg_order);
 }
 
-void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_errhmm, dim3((unsigned)(n_slots_max / kWG)), dim3(kWG), lds_bytes, s, a);
+void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, hipStream_t s) {
+  if (fast_rv)
+    hipLaunchKernelGGL(k_walk_errhmm<true>, dim3((unsigned)(n_slots_max / kWG)), dim3(kWG), lds_bytes, s, a);
+  else
+    hipLaunchKernelGGL(k_walk_errhmm<false>, dim3((unsigned)(n_slots_max / kWG)), dim3(kWG), lds_bytes, s, a);
 }
 
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s) {
