@@ -79,7 +79,8 @@ def cpu_baseline(sample_bp=4_000_000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--slots", type=int, default=2, help="batches kept in flight per GPU (engine slots)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--record-len", type=int, default=RECORD_LEN)
     ap.add_argument("--scratch-gib", type=float, default=32.0)
@@ -134,9 +135,15 @@ def main():
     B = a.batch_reads or ctx.batch_capacity()
     quota = ctx.unit_quota()
 
-    def step(i):
-        first = 1 + (i * world + rank) * B
-        pass0 = ctx.batch_walk(first, B)
+    S = max(1, min(a.slots, P.load().pbsim_slot_count()))
+
+    def begin(i):
+        ctx.select_slot(i % S)
+        ctx.batch_walk_begin(1 + (i * world + rank) * B, B)
+
+    def finish(i):
+        ctx.select_slot(i % S)
+        pass0 = ctx.batch_walk_end()
         before = 0
         if world > 1:
             mine = torch.tensor([pass0], dtype=torch.int64, device=dev)
@@ -144,19 +151,28 @@ def main():
             dist.all_gather(allv, mine)        # C3: quota prefix across ranks
             before = int(sum(int(v.item()) for v in allv[:rank]))
         # bench batches are far below the record's quota, so none is cut
-        info = ctx.batch_finalize(before % max(1, quota // 4))
-        return info
+        return ctx.batch_finalize(before % max(1, quota // 4))
 
-    for i in range(a.warmup):
-        step(i)
+    def run(first_step, n_steps):
+        """n_steps batches through an S-deep pipeline; returns their BatchInfos."""
+        infos, pending, nxt = [], [], first_step
+        while len(infos) < n_steps:
+            while len(pending) < S and nxt < first_step + n_steps:
+                begin(nxt)
+                pending.append(nxt)
+                nxt += 1
+            infos.append(finish(pending.pop(0)))
+        return infos
+
+    run(0, S)                 # untimed setup: every slot allocates its pools once
+    run(S, a.warmup)          # the W untimed warmup steps
     ctx.prof_reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     bases = reads = ref_b = maf_c = text_b = 0
-    for i in range(a.warmup, a.warmup + a.steps):
-        info = step(i)
+    for info in run(S + a.warmup, a.steps):
         bases += info.bases
         reads += info.n_final
         ref_b += info.ref_bases
@@ -190,7 +206,7 @@ def main():
             "config": {"workload": "wgs errhmm ERRHMM-ONT depth 20, default length/accuracy, uniform ACGT record "
                                    f"of {G} bp resident in HBM (one of the 4 records of the 3 Gbp genome)",
                        "param_overrides": a.param, "reads_per_step_per_gpu": B, "bases_per_step": g_bases // a.steps,
-                       "text_bytes_per_step": g_text // a.steps, "parallelism": f"read-block x{world}"},
+                       "text_bytes_per_step": g_text // a.steps, "parallelism": f"read-block x{world}", "slots_in_flight": S},
             "roofline": {"bound": "hbm", "kernel": "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": walk_s * 1e3,

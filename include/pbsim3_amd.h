@@ -155,6 +155,15 @@ int64_t pbsim_sam_header(pbsim_ctx *ctx, char *buf, int64_t cap);
  * pbsim_batch_fetch    copies the text to host memory (either may be NULL). */
 int pbsim_batch_walk(pbsim_ctx *ctx, int64_t first_read, int64_t n_reads, int64_t truncate_remaining,
                      int64_t *pass0_bases);
+/* Asynchronous halves of pbsim_batch_walk, and batch slots: a context owns
+ * pbsim_slot_count() independent batch slots (buffers + HIP stream each);
+ * pbsim_select_slot() chooses the one the pbsim_batch_* calls act on.  Beginning
+ * batch k+1 on another slot before ending batch k keeps the GPU busy while the
+ * longest reads of batch k drain (the drivers above do exactly that). */
+int pbsim_slot_count(void);
+int pbsim_select_slot(pbsim_ctx *ctx, int slot);
+int pbsim_batch_walk_begin(pbsim_ctx *ctx, int64_t first_read, int64_t n_reads, int64_t truncate_remaining);
+int pbsim_batch_walk_end(pbsim_ctx *ctx, int64_t *pass0_bases);
 int pbsim_batch_finalize(pbsim_ctx *ctx, int64_t len_total_before, pbsim_batch_info *info);
 int pbsim_batch_fetch(pbsim_ctx *ctx, char *read_text, char *maf_text);
 /* adds the n_final reads of the finalized batch to the unit's statistics */
@@ -165,7 +174,7 @@ int pbsim_reset_stats(pbsim_ctx *ctx);
 int64_t pbsim_unit_quota(pbsim_ctx *ctx);
 /* reads the engine sizes one batch to (from the scratch budget) */
 int64_t pbsim_batch_capacity(pbsim_ctx *ctx);
-/* scratch budget in bytes (default: PBSIM_SCRATCH_MB env or 8 GiB) */
+/* scratch pool per slot in bytes (default: PBSIM_SCRATCH_MB env or 8 GiB) */
 int pbsim_set_scratch_bytes(pbsim_ctx *ctx, int64_t bytes);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------

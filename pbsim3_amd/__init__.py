@@ -73,6 +73,10 @@ API = [
     ("pbsim_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("pbsim_sam_header", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("pbsim_batch_walk", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    ("pbsim_slot_count", C.c_int, []),
+    ("pbsim_select_slot", C.c_int, [C.c_void_p, C.c_int]),
+    ("pbsim_batch_walk_begin", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    ("pbsim_batch_walk_end", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("pbsim_batch_finalize", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(BatchInfo)]),
     ("pbsim_batch_fetch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pbsim_batch_account", C.c_int, [C.c_void_p]),
@@ -203,6 +207,17 @@ class Context:
     def batch_walk(self, first_read, n_reads, truncate_remaining=-1):
         out = C.c_int64(0)
         _check(self.lib.pbsim_batch_walk(self.h, first_read, n_reads, truncate_remaining, C.byref(out)))
+        return out.value
+
+    def select_slot(self, slot):
+        _check(self.lib.pbsim_select_slot(self.h, slot))
+
+    def batch_walk_begin(self, first_read, n_reads, truncate_remaining=-1):
+        _check(self.lib.pbsim_batch_walk_begin(self.h, first_read, n_reads, truncate_remaining))
+
+    def batch_walk_end(self):
+        out = C.c_int64(0)
+        _check(self.lib.pbsim_batch_walk_end(self.h, C.byref(out)))
         return out.value
 
     def batch_finalize(self, len_total_before):

@@ -100,11 +100,35 @@ struct HostBuf {  // pinned staging
 
 using namespace pbsim;
 
+constexpr int kMaxSlots = 4;
+
+// Everything one in-flight batch owns.  Several slots (each with its own stream)
+// let the walk of batch k+1 fill the GPU while the longest reads of batch k
+// are still draining and while batch k's text is being emitted.
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  DevBuf d_flags;
+  DevBuf d_rawlen, d_len, d_off, d_acc;
+  DevBuf d_hist, d_bin_start, d_bin_cursor, d_class_start;
+  DevBuf d_task_of_slot, d_slot_of_task, d_wave_cap, d_wave_off, d_wg_tmp, d_wg_order;
+  DevBuf d_out_len, d_maf_len, d_nsub, d_nins, d_ndel, d_qsum;
+  DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len, d_row_dst;
+  DevBuf d_scratch, d_read_text, d_maf_text;
+  HostBuf h_read_text, h_maf_text, h_stats;
+  int64_t b_first = 0, b_n = 0, b_slots_max = 0;
+  bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
+  int64_t b_pass0 = 0;
+  pbsim_batch_info b_info;
+};
+
 struct pbsim_ctx {
   pbsim_params p;
   int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  hipStream_t stream = nullptr;  // reference preparation and table uploads
+  Slot slots[kMaxSlots];
+  int cur = 0;
+  Slot &s() { return slots[cur]; }
 
   std::unique_ptr<ErrModel> err;
   std::unique_ptr<QsModel> qs;
@@ -117,7 +141,7 @@ struct pbsim_ctx {
 
   DevBuf d_prob2len, d_prob2acc, d_cls, d_qs_tabs;
   // reference
-  DevBuf d_seq_own, d_hp, d_tiles;
+  DevBuf d_seq_own, d_hp, d_tiles, d_ref_flags;
   const uint8_t *d_seq = nullptr;
   int64_t ref_len = 0;
   int64_t unit = 0;
@@ -126,22 +150,8 @@ struct pbsim_ctx {
   // trans units (pbsim_set_transcripts)
   int64_t n_units = 0, trans_reads = 0;
   DevBuf d_read_unit, d_read_minus, d_read_base, d_unit_len, d_unit_rank, d_unit_names, d_off_table, d_ssp, d_ssp_rv;
-  // batch
-  DevBuf d_flags, d_ref_flags;
-  DevBuf d_rawlen, d_len, d_off, d_acc;
-  DevBuf d_hist, d_bin_start, d_bin_cursor, d_class_start;
-  DevBuf d_task_of_slot, d_slot_of_task, d_wave_cap, d_wave_off, d_wg_tmp, d_wg_order;
-  DevBuf d_out_len, d_maf_len, d_nsub, d_nins, d_ndel, d_qsum;
-  DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len, d_row_dst;
-  DevBuf d_scratch, d_read_text, d_maf_text;
-  int64_t scratch_budget = 0;
-  HostBuf h_read_text, h_maf_text, h_stats;
-
-  // state of the current batch
-  int64_t b_first = 0, b_n = 0, b_slots_max = 0;
-  bool b_truncated = false, b_walked = false, b_finalized = false;
-  int64_t b_pass0 = 0;
-  pbsim_batch_info b_info;
+  int64_t scratch_budget = 0;  // bytes of wave scratch per slot
+  int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
 
   // per-unit statistics (pbsim.cpp:63-70, 195-196)
   int64_t res_num = 0, res_len_total = 0, res_len_min = LONG_MAX, res_len_max = 0;
@@ -201,8 +211,8 @@ int ensure_class_tables(pbsim_ctx *c) {
 }
 
 int read_flags(pbsim_ctx *c, DeviceFlags *f) {
-  HIP_OK(hipMemcpyAsync(f, c->d_flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost, c->stream));
-  HIP_OK(hipStreamSynchronize(c->stream));
+  HIP_OK(hipMemcpyAsync(f, c->s().d_flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost, c->s().stream));
+  HIP_OK(hipStreamSynchronize(c->s().stream));
   return PBSIM_SUCCEEDED;
 }
 
@@ -324,12 +334,20 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
     fail("cannot initialise the HIP device/stream");
     return nullptr;
   }
-  (void)hipEventCreate(&c->ev0);
-  (void)hipEventCreate(&c->ev1);
-  (void)hipEventCreate(&c->ev2);
-  (void)hipEventCreate(&c->ev3);
+  for (Slot &sl : c->slots) {
+    if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) {
+      fail("cannot create a HIP stream");
+      return nullptr;
+    }
+    (void)hipEventCreate(&sl.ev0);
+    (void)hipEventCreate(&sl.ev1);
+    (void)hipEventCreate(&sl.ev2);
+    (void)hipEventCreate(&sl.ev3);
+  }
   const char *mb = getenv("PBSIM_SCRATCH_MB");
   c->scratch_budget = (mb && atoll(mb) > 0) ? atoll(mb) * (1LL << 20) : (8LL << 30);
+  const char *pd = getenv("PBSIM_PIPELINE_DEPTH");
+  if (pd && atoi(pd) >= 1) c->pipeline_depth = std::min(kMaxSlots, atoi(pd));
   return c.release();
 }
 
@@ -337,10 +355,14 @@ void pbsim_destroy(pbsim_ctx *c) {
   if (!c) return;
   if (c->device >= 0) (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->ev2) (void)hipEventDestroy(c->ev2);
-  if (c->ev3) (void)hipEventDestroy(c->ev3);
+  for (Slot &sl : c->slots) {
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+    if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+    if (sl.ev2) (void)hipEventDestroy(sl.ev2);
+    if (sl.ev3) (void)hipEventDestroy(sl.ev3);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -406,7 +428,7 @@ static int set_reference_common(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int64
   c->d_seq = d_seq;
   c->ref_len = len;
   c->unit = record_index;
-  c->b_walked = c->b_finalized = false;
+  for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
   return PBSIM_SUCCEEDED;
 }
 
@@ -454,8 +476,22 @@ int pbsim_reset_stats(pbsim_ctx *c) {  // init_sim_res, pbsim.cpp:1437-1445 + 36
 
 int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t truncate_remaining,
                      int64_t *pass0_bases) {
+  if (!pbsim_batch_walk_begin(c, first_read, n_reads, truncate_remaining)) return PBSIM_FAILED;
+  return pbsim_batch_walk_end(c, pass0_bases);
+}
+
+int pbsim_select_slot(pbsim_ctx *c, int slot) {
+  if (!c || slot < 0 || slot >= kMaxSlots) return fail("pbsim_select_slot: slot out of range (0-3)");
+  c->cur = slot;
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_slot_count(void) { return kMaxSlots; }
+
+int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t truncate_remaining) {
   if (!c || n_reads < 1 || first_read < 1) return fail("pbsim_batch_walk: bad argument");
   NEED_DEVICE(c);
+  if (c->s().b_enqueued) return fail("pbsim_batch_walk_begin: this slot still has a batch in flight (pbsim_batch_walk_end)");
   const bool trans = c->p.strategy == PBSIM_STRATEGY_TRANS;
   if (c->p.strategy == PBSIM_STRATEGY_TEMPL) return fail("pbsim_batch_walk: templ strategy is not provided");
   if (!c->d_seq) return fail(trans ? "no transcripts set (pbsim_set_transcripts)" : "no reference set (pbsim_set_reference)");
@@ -474,34 +510,34 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   const int64_t waves_max = slots_max / 64;
   const size_t nbins = (size_t)ncls * kLenBuckets;
 
-  HIP_OK(c->d_flags.ensure(sizeof(DeviceFlags)));
-  HIP_OK(c->d_rawlen.ensure(n_reads * 4));
-  HIP_OK(c->d_len.ensure(n_reads * 4));
-  HIP_OK(c->d_off.ensure(n_reads * 4));
-  HIP_OK(c->d_acc.ensure(n_reads));
-  HIP_OK(c->d_hist.ensure(nbins * 4));
-  HIP_OK(c->d_bin_start.ensure(nbins * 4));
-  HIP_OK(c->d_bin_cursor.ensure(nbins * 4));
-  HIP_OK(c->d_class_start.ensure((ncls + 1) * 4));
-  HIP_OK(c->d_task_of_slot.ensure(slots_max * 4));
-  HIP_OK(c->d_slot_of_task.ensure(n_tasks * 4));
-  HIP_OK(c->d_wave_cap.ensure(waves_max * 4));
-  HIP_OK(c->d_wave_off.ensure(waves_max * 8));
-  HIP_OK(c->d_wg_tmp.ensure((size_t)(kLenBuckets + 1) * 2 * 4));
-  HIP_OK(c->d_wg_order.ensure((size_t)(slots_max / kWG) * 4));
-  HIP_OK(c->d_out_len.ensure(n_tasks * 4));
-  HIP_OK(c->d_maf_len.ensure(n_tasks * 4));
-  HIP_OK(c->d_nsub.ensure(n_tasks * 4));
-  HIP_OK(c->d_nins.ensure(n_tasks * 4));
-  HIP_OK(c->d_ndel.ensure(n_tasks * 4));
-  HIP_OK(c->d_qsum.ensure(n_tasks * 8));
-  HIP_OK(c->d_cum.ensure((n_reads + 1) * 8));
-  HIP_OK(c->d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
-  HIP_OK(c->d_scratch.ensure((size_t)c->scratch_budget, true));
+  HIP_OK(c->s().d_flags.ensure(sizeof(DeviceFlags)));
+  HIP_OK(c->s().d_rawlen.ensure(n_reads * 4));
+  HIP_OK(c->s().d_len.ensure(n_reads * 4));
+  HIP_OK(c->s().d_off.ensure(n_reads * 4));
+  HIP_OK(c->s().d_acc.ensure(n_reads));
+  HIP_OK(c->s().d_hist.ensure(nbins * 4));
+  HIP_OK(c->s().d_bin_start.ensure(nbins * 4));
+  HIP_OK(c->s().d_bin_cursor.ensure(nbins * 4));
+  HIP_OK(c->s().d_class_start.ensure((ncls + 1) * 4));
+  HIP_OK(c->s().d_task_of_slot.ensure(slots_max * 4));
+  HIP_OK(c->s().d_slot_of_task.ensure(n_tasks * 4));
+  HIP_OK(c->s().d_wave_cap.ensure(waves_max * 4));
+  HIP_OK(c->s().d_wave_off.ensure(waves_max * 8));
+  HIP_OK(c->s().d_wg_tmp.ensure((size_t)(kLenBuckets + 1) * 2 * 4));
+  HIP_OK(c->s().d_wg_order.ensure((size_t)(slots_max / kWG) * 4));
+  HIP_OK(c->s().d_out_len.ensure(n_tasks * 4));
+  HIP_OK(c->s().d_maf_len.ensure(n_tasks * 4));
+  HIP_OK(c->s().d_nsub.ensure(n_tasks * 4));
+  HIP_OK(c->s().d_nins.ensure(n_tasks * 4));
+  HIP_OK(c->s().d_ndel.ensure(n_tasks * 4));
+  HIP_OK(c->s().d_qsum.ensure(n_tasks * 8));
+  HIP_OK(c->s().d_cum.ensure((n_reads + 1) * 8));
+  HIP_OK(c->s().d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
+  HIP_OK(c->s().d_scratch.ensure((size_t)c->scratch_budget, true));
 
-  HIP_OK(hipEventRecord(c->ev0, c->stream));
-  HIP_OK(hipMemsetAsync(c->d_flags.p, 0, sizeof(DeviceFlags), c->stream));
-  DeviceFlags *flags = c->d_flags.as<DeviceFlags>();
+  HIP_OK(hipEventRecord(c->s().ev0, c->s().stream));
+  HIP_OK(hipMemsetAsync(c->s().d_flags.p, 0, sizeof(DeviceFlags), c->s().stream));
+  DeviceFlags *flags = c->s().d_flags.as<DeviceFlags>();
 
   HeaderArgs h;
   h.seed = c->p.seed;
@@ -515,10 +551,10 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   h.ref_len = c->ref_len;
   h.len_min = c->p.len_min;
   h.truncate_remaining = truncate_remaining;
-  h.rawlen = c->d_rawlen.as<int32_t>();
-  h.len = c->d_len.as<int32_t>();
-  h.off = c->d_off.as<int32_t>();
-  h.acc = c->d_acc.as<uint8_t>();
+  h.rawlen = c->s().d_rawlen.as<int32_t>();
+  h.len = c->s().d_len.as<int32_t>();
+  h.off = c->s().d_off.as<int32_t>();
+  h.acc = c->s().d_acc.as<uint8_t>();
   h.read_unit = nullptr;
   if (trans) {
     h.read_unit = c->d_read_unit.as<int32_t>() + (first_read - 1);
@@ -527,9 +563,9 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
     h.off_table = c->d_off_table.as<int32_t>();
     h.ssp = c->d_ssp.as<uint8_t>();
     h.ssp_rv = c->d_ssp_rv.as<int32_t>();
-    launch_header_trans(h, c->stream);
+    launch_header_trans(h, c->s().stream);
   } else {
-    launch_header_wgs(h, c->stream);
+    launch_header_wgs(h, c->s().stream);
   }
 
   SortArgs s;
@@ -539,22 +575,22 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   s.ncls = ncls;
   s.len = h.len;
   s.acc = h.acc;
-  s.hist = c->d_hist.as<int32_t>();
-  s.bin_start = c->d_bin_start.as<int32_t>();
-  s.bin_cursor = c->d_bin_cursor.as<int32_t>();
-  s.class_start = c->d_class_start.as<int32_t>();
-  s.task_of_slot = c->d_task_of_slot.as<int32_t>();
-  s.slot_of_task = c->d_slot_of_task.as<int32_t>();
-  s.wave_cap = c->d_wave_cap.as<int32_t>();
-  s.wave_off = c->d_wave_off.as<int64_t>();
+  s.hist = c->s().d_hist.as<int32_t>();
+  s.bin_start = c->s().d_bin_start.as<int32_t>();
+  s.bin_cursor = c->s().d_bin_cursor.as<int32_t>();
+  s.class_start = c->s().d_class_start.as<int32_t>();
+  s.task_of_slot = c->s().d_task_of_slot.as<int32_t>();
+  s.slot_of_task = c->s().d_slot_of_task.as<int32_t>();
+  s.wave_cap = c->s().d_wave_cap.as<int32_t>();
+  s.wave_off = c->s().d_wave_off.as<int64_t>();
   s.n_slots_max = slots_max;
-  s.wg_hist = c->d_wg_tmp.as<int32_t>();
+  s.wg_hist = c->s().d_wg_tmp.as<int32_t>();
   s.wg_start = s.wg_hist + (kLenBuckets + 1);
-  s.wg_order = c->d_wg_order.as<int32_t>();
+  s.wg_order = c->s().d_wg_order.as<int32_t>();
   s.regions = regions_of(c);
   s.scratch_bytes = c->scratch_budget;
   s.flags = flags;
-  launch_task_sort(s, c->stream);
+  launch_task_sort(s, c->s().stream);
 
   WalkArgs w;
   memset(&w, 0, sizeof w);
@@ -579,21 +615,21 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   w.mean_len = (int32_t)c->hdr.mean_len;
   w.wave_cap = s.wave_cap;
   w.wave_off = s.wave_off;
-  w.scratch = c->d_scratch.as<uint8_t>();
-  w.out_len = c->d_out_len.as<int32_t>();
-  w.maf_len = c->d_maf_len.as<int32_t>();
-  w.nsub = c->d_nsub.as<int32_t>();
-  w.nins = c->d_nins.as<int32_t>();
-  w.ndel = c->d_ndel.as<int32_t>();
-  w.qsum = c->d_qsum.as<double>();
+  w.scratch = c->s().d_scratch.as<uint8_t>();
+  w.out_len = c->s().d_out_len.as<int32_t>();
+  w.maf_len = c->s().d_maf_len.as<int32_t>();
+  w.nsub = c->s().d_nsub.as<int32_t>();
+  w.nins = c->s().d_nins.as<int32_t>();
+  w.ndel = c->s().d_ndel.as<int32_t>();
+  w.qsum = c->s().d_qsum.as<double>();
   w.flags = flags;
-  HIP_OK(hipEventRecord(c->ev1, c->stream));
+  HIP_OK(hipEventRecord(c->s().ev1, c->s().stream));
   if (c->p.method == PBSIM_METHOD_ERR) {
     w.stride = c->ect.stride;
     w.rows_off = c->ect.rows_off;
     w.init_off = c->ect.init_off;
     w.tran_off = c->ect.tran_off;
-    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->stream);
+    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->s().stream);
   } else {
     w.stride = c->qct.stride;
     w.rv_off = c->qct.rv_off;
@@ -606,18 +642,34 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
     w.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
     w.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     w.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
-    launch_walk_qshmm(w, slots_max, c->qct.stride + 96 * 8 + 94 * 48 + 94 * 8, c->stream);
+    launch_walk_qshmm(w, slots_max, c->qct.stride + 96 * 8 + 94 * 48 + 94 * 8, c->s().stream);
   }
-  HIP_OK(hipEventRecord(c->ev2, c->stream));
-  launch_gather_pass0_scan(w.out_len, n_reads, P, c->d_cum.as<int64_t>(), c->d_scan_tmp.as<int64_t>(),
-                           &flags->sums[0], c->stream);
-  HIP_OK(hipEventRecord(c->ev3, c->stream));
+  HIP_OK(hipEventRecord(c->s().ev2, c->s().stream));
+  launch_gather_pass0_scan(w.out_len, n_reads, P, c->s().d_cum.as<int64_t>(), c->s().d_scan_tmp.as<int64_t>(),
+                           &flags->sums[0], c->s().stream);
+  HIP_OK(hipEventRecord(c->s().ev3, c->s().stream));
   HIP_OK(hipGetLastError());
+  c->s().b_first = first_read;
+  c->s().b_n = n_reads;
+  c->s().b_slots_max = slots_max;
+  c->s().b_truncated = truncate_remaining >= 0 || trans;  // trans has no quota: every read is final
+  c->s().b_enqueued = true;
+  c->s().b_walked = false;
+  c->s().b_finalized = false;
+  return PBSIM_SUCCEEDED;
+}
+
+int pbsim_batch_walk_end(pbsim_ctx *c, int64_t *pass0_bases) {
+  if (!c) return fail("pbsim_batch_walk_end: bad argument");
+  NEED_DEVICE(c);
+  if (!c->s().b_enqueued) return fail("pbsim_batch_walk_end: no batch was begun on this slot");
+  HIP_OK(hipSetDevice(c->device));
+  c->s().b_enqueued = false;
   DeviceFlags f;
   if (!read_flags(c, &f)) return PBSIM_FAILED;
   float ms = 0;
-  if (hipEventElapsedTime(&ms, c->ev1, c->ev2) == hipSuccess) c->prof_walk_ms += ms;
-  if (hipEventElapsedTime(&ms, c->ev0, c->ev3) == hipSuccess) c->prof_total_ms += ms;
+  if (hipEventElapsedTime(&ms, c->s().ev1, c->s().ev2) == hipSuccess) c->prof_walk_ms += ms;
+  if (hipEventElapsedTime(&ms, c->s().ev0, c->s().ev3) == hipSuccess) c->prof_total_ms += ms;
   c->prof_walk_launches++;
   if (f.error & kErrScratchBudget) {
     char buf[160];
@@ -627,152 +679,147 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
   }
   if (f.error & kErrScratchOverflow)
     return fail("a read produced more MAF columns than 2*len+64 (the reference's buffers are 2*len_max+1)");
-  c->b_first = first_read;
-  c->b_n = n_reads;
-  c->b_slots_max = slots_max;
-  c->b_truncated = truncate_remaining >= 0 || trans;  // trans has no quota: every read is final
-  c->b_walked = true;
-  c->b_finalized = false;
-  c->b_pass0 = f.sums[0];
+  c->s().b_walked = true;
+  c->s().b_pass0 = f.sums[0];
   if (pass0_bases) *pass0_bases = f.sums[0];
   return PBSIM_SUCCEEDED;
 }
 
 static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
   memset(t, 0, sizeof *t);
-  t->first_read = c->b_first;
+  t->first_read = c->s().b_first;
   t->n_reads = n_emit;
   t->pass_num = c->p.pass_num;
   t->is_wgs = c->p.strategy == PBSIM_STRATEGY_WGS;
   t->is_qs = c->p.method == PBSIM_METHOD_QS;
   t->unit = (uint32_t)c->unit;
   t->ref_len = c->ref_len;
-  t->len = c->d_len.as<int32_t>();
-  t->off = c->d_off.as<int32_t>();
-  t->out_len = c->d_out_len.as<int32_t>();
-  t->maf_len = c->d_maf_len.as<int32_t>();
-  t->slot_of_task = c->d_slot_of_task.as<int32_t>();
-  t->task_of_slot = c->d_task_of_slot.as<int32_t>();
-  t->row_dst = c->d_row_dst.as<int64_t>();
-  t->wave_cap = c->d_wave_cap.as<int32_t>();
-  t->wave_off = c->d_wave_off.as<int64_t>();
-  t->scratch = c->d_scratch.as<uint8_t>();
-  t->read_text_len = c->d_rt_len.as<int64_t>();
-  t->maf_text_len = c->d_mt_len.as<int64_t>();
+  t->len = c->s().d_len.as<int32_t>();
+  t->off = c->s().d_off.as<int32_t>();
+  t->out_len = c->s().d_out_len.as<int32_t>();
+  t->maf_len = c->s().d_maf_len.as<int32_t>();
+  t->slot_of_task = c->s().d_slot_of_task.as<int32_t>();
+  t->task_of_slot = c->s().d_task_of_slot.as<int32_t>();
+  t->row_dst = c->s().d_row_dst.as<int64_t>();
+  t->wave_cap = c->s().d_wave_cap.as<int32_t>();
+  t->wave_off = c->s().d_wave_off.as<int64_t>();
+  t->scratch = c->s().d_scratch.as<uint8_t>();
+  t->read_text_len = c->s().d_rt_len.as<int64_t>();
+  t->maf_text_len = c->s().d_mt_len.as<int64_t>();
   t->read_text_off = t->read_text_len;
   t->maf_text_off = t->maf_text_len;
   t->id_prefix_len = (int)strlen(c->p.id_prefix);
   memcpy(t->id_prefix, c->p.id_prefix, sizeof t->id_prefix);
   t->rq_len = snprintf(t->rq_text, sizeof t->rq_text, "%f", c->p.accuracy_mean);  // pbsim.cpp:4027
   if (c->p.strategy == PBSIM_STRATEGY_TRANS) {
-    t->read_unit = c->d_read_unit.as<int32_t>() + (c->b_first - 1);
-    t->read_minus = c->d_read_minus.as<uint8_t>() + (c->b_first - 1);
+    t->read_unit = c->d_read_unit.as<int32_t>() + (c->s().b_first - 1);
+    t->read_minus = c->d_read_minus.as<uint8_t>() + (c->s().b_first - 1);
     t->unit_len = c->d_unit_len.as<int64_t>();
     t->unit_names = c->d_unit_names.as<char>();
   }
 }
 
 int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *info) {
-  if (!c || !c->b_walked) return fail("pbsim_batch_finalize: no walked batch");
+  if (!c || !c->s().b_walked) return fail("pbsim_batch_finalize: no walked batch");
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
-  DeviceFlags *flags = c->d_flags.as<DeviceFlags>();
+  DeviceFlags *flags = c->s().d_flags.as<DeviceFlags>();
   const int64_t quota = pbsim_unit_quota(c);
   const int P = c->p.pass_num;
-  launch_quota_cut(c->d_cum.as<int64_t>(), c->d_rawlen.as<int32_t>(), c->b_n, len_total_before, quota,
-                   c->b_truncated ? 1 : 0, flags, c->stream);
+  launch_quota_cut(c->s().d_cum.as<int64_t>(), c->s().d_rawlen.as<int32_t>(), c->s().b_n, len_total_before, quota,
+                   c->s().b_truncated ? 1 : 0, flags, c->s().stream);
   DeviceFlags f;
   if (!read_flags(c, &f)) return PBSIM_FAILED;
   const int64_t n_final = f.n_final;
-  int64_t cum_final = c->b_pass0;
-  if (n_final < c->b_n) {
-    HIP_OK(hipMemcpyAsync(&cum_final, c->d_cum.as<int64_t>() + n_final, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
+  int64_t cum_final = c->s().b_pass0;
+  if (n_final < c->s().b_n) {
+    HIP_OK(hipMemcpyAsync(&cum_final, c->s().d_cum.as<int64_t>() + n_final, 8, hipMemcpyDeviceToHost, c->s().stream));
+    HIP_OK(hipStreamSynchronize(c->s().stream));
   }
   pbsim_batch_info bi;
   memset(&bi, 0, sizeof bi);
-  bi.first_read = c->b_first;
-  bi.n_reads = c->b_n;
+  bi.first_read = c->s().b_first;
+  bi.n_reads = c->s().b_n;
   bi.n_final = n_final;
   bi.len_total_after = len_total_before + cum_final;
   if (c->p.strategy == PBSIM_STRATEGY_TRANS) {
     bi.quota_reached = 0;
     bi.need_truncated_read = 0;
-  } else if (c->b_truncated) {
+  } else if (c->s().b_truncated) {
     bi.quota_reached = bi.len_total_after >= quota;
     bi.need_truncated_read = !bi.quota_reached;
   } else {
-    bi.quota_reached = (n_final < c->b_n) || (bi.len_total_after >= quota);
-    bi.need_truncated_read = (n_final < c->b_n) && (bi.len_total_after < quota);
+    bi.quota_reached = (n_final < c->s().b_n) || (bi.len_total_after >= quota);
+    bi.need_truncated_read = (n_final < c->s().b_n) && (bi.len_total_after < quota);
   }
   const int64_t n_tasks = n_final * P;
   if (n_tasks > 0) {
-    HIP_OK(c->d_rt_len.ensure(n_tasks * 8));
-    HIP_OK(c->d_mt_len.ensure(n_tasks * 8));
-    HIP_OK(c->d_row_dst.ensure(n_tasks * 6 * 8));
-    HIP_OK(hipMemsetAsync(&flags->sums[1], 0, 5 * sizeof(int64_t), c->stream));
+    HIP_OK(c->s().d_rt_len.ensure(n_tasks * 8));
+    HIP_OK(c->s().d_mt_len.ensure(n_tasks * 8));
+    HIP_OK(c->s().d_row_dst.ensure(n_tasks * 6 * 8));
+    HIP_OK(hipMemsetAsync(&flags->sums[1], 0, 5 * sizeof(int64_t), c->s().stream));
     TextArgs t;
     fill_text_args(c, &t, n_final);
-    launch_text_sizes(t, flags, c->stream);
-    launch_exclusive_scan_i64(t.read_text_len, t.read_text_len, n_tasks, c->d_scan_tmp.as<int64_t>(), &flags->sums[1],
-                              c->stream);
-    launch_exclusive_scan_i64(t.maf_text_len, t.maf_text_len, n_tasks, c->d_scan_tmp.as<int64_t>(), &flags->sums[2],
-                              c->stream);
+    launch_text_sizes(t, flags, c->s().stream);
+    launch_exclusive_scan_i64(t.read_text_len, t.read_text_len, n_tasks, c->s().d_scan_tmp.as<int64_t>(), &flags->sums[1],
+                              c->s().stream);
+    launch_exclusive_scan_i64(t.maf_text_len, t.maf_text_len, n_tasks, c->s().d_scan_tmp.as<int64_t>(), &flags->sums[2],
+                              c->s().stream);
     if (!read_flags(c, &f)) return PBSIM_FAILED;
     bi.read_text_bytes = f.sums[1];
     bi.maf_text_bytes = f.sums[2];
     bi.bases = f.sums[3];
     bi.ref_bases = f.sums[4];
     bi.maf_columns = f.sums[5];
-    HIP_OK(c->d_read_text.ensure((size_t)bi.read_text_bytes + 16));
-    HIP_OK(c->d_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
-    t.read_text = c->d_read_text.as<char>();
-    t.maf_text = c->d_maf_text.as<char>();
-    launch_text_emit(t, c->b_slots_max, flags, c->stream);
+    HIP_OK(c->s().d_read_text.ensure((size_t)bi.read_text_bytes + 16));
+    HIP_OK(c->s().d_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
+    t.read_text = c->s().d_read_text.as<char>();
+    t.maf_text = c->s().d_maf_text.as<char>();
+    launch_text_emit(t, c->s().b_slots_max, flags, c->s().stream);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipStreamSynchronize(c->s().stream));
   }
-  c->b_info = bi;
-  c->b_finalized = true;
+  c->s().b_info = bi;
+  c->s().b_finalized = true;
   if (info) *info = bi;
   return PBSIM_SUCCEEDED;
 }
 
 int pbsim_batch_fetch(pbsim_ctx *c, char *read_text, char *maf_text) {
-  if (!c || !c->b_finalized) return fail("pbsim_batch_fetch: no finalized batch");
+  if (!c || !c->s().b_finalized) return fail("pbsim_batch_fetch: no finalized batch");
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
-  if (read_text && c->b_info.read_text_bytes)
-    HIP_OK(hipMemcpyAsync(read_text, c->d_read_text.p, (size_t)c->b_info.read_text_bytes, hipMemcpyDeviceToHost,
-                          c->stream));
-  if (maf_text && c->b_info.maf_text_bytes)
-    HIP_OK(hipMemcpyAsync(maf_text, c->d_maf_text.p, (size_t)c->b_info.maf_text_bytes, hipMemcpyDeviceToHost,
-                          c->stream));
-  HIP_OK(hipStreamSynchronize(c->stream));
+  if (read_text && c->s().b_info.read_text_bytes)
+    HIP_OK(hipMemcpyAsync(read_text, c->s().d_read_text.p, (size_t)c->s().b_info.read_text_bytes, hipMemcpyDeviceToHost,
+                          c->s().stream));
+  if (maf_text && c->s().b_info.maf_text_bytes)
+    HIP_OK(hipMemcpyAsync(maf_text, c->s().d_maf_text.p, (size_t)c->s().b_info.maf_text_bytes, hipMemcpyDeviceToHost,
+                          c->s().stream));
+  HIP_OK(hipStreamSynchronize(c->s().stream));
   return PBSIM_SUCCEEDED;
 }
 
 // pbsim.cpp:3986-4005 (errhmm) / 2293-2316 (qshmm), applied in read order so the
 // order-dependent double sum `accuracy_total` matches the CPU bit for bit
 int pbsim_batch_account(pbsim_ctx *c) {
-  if (!c || !c->b_finalized) return fail("pbsim_batch_account: no finalized batch");
+  if (!c || !c->s().b_finalized) return fail("pbsim_batch_account: no finalized batch");
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
   const int P = c->p.pass_num;
-  const int64_t n_tasks = c->b_info.n_final * P;
+  const int64_t n_tasks = c->s().b_info.n_final * P;
   if (n_tasks == 0) return PBSIM_SUCCEEDED;
-  HIP_OK(c->h_stats.ensure((size_t)n_tasks * 24));
-  int32_t *ol = reinterpret_cast<int32_t *>(c->h_stats.p);
+  HIP_OK(c->s().h_stats.ensure((size_t)n_tasks * 24));
+  int32_t *ol = reinterpret_cast<int32_t *>(c->s().h_stats.p);
   int32_t *ns = ol + n_tasks, *ni = ns + n_tasks, *nd = ni + n_tasks;
   double *qs = reinterpret_cast<double *>(nd + n_tasks);
-  HIP_OK(hipMemcpyAsync(ol, c->d_out_len.p, n_tasks * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_OK(hipMemcpyAsync(ns, c->d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_OK(hipMemcpyAsync(ni, c->d_nins.p, n_tasks * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_OK(hipMemcpyAsync(nd, c->d_ndel.p, n_tasks * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipMemcpyAsync(ol, c->s().d_out_len.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
+  HIP_OK(hipMemcpyAsync(ns, c->s().d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
+  HIP_OK(hipMemcpyAsync(ni, c->s().d_nins.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
+  HIP_OK(hipMemcpyAsync(nd, c->s().d_ndel.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
   if (c->p.method == PBSIM_METHOD_QS)
-    HIP_OK(hipMemcpyAsync(qs, c->d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_OK(hipStreamSynchronize(c->stream));
-  c->res_num += c->b_info.n_final;
+    HIP_OK(hipMemcpyAsync(qs, c->s().d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, c->s().stream));
+  HIP_OK(hipStreamSynchronize(c->s().stream));
+  c->res_num += c->s().b_info.n_final;
   for (int64_t t = 0; t < n_tasks; t++) {
     const long len = ol[t];
     c->res_len_total += len;
@@ -839,23 +886,27 @@ int64_t pbsim_sam_header(pbsim_ctx *c, char *buf, int64_t cap) {  // pbsim.cpp:7
 }
 
 static int deliver(pbsim_ctx *c, const pbsim_sink *sink) {
-  const pbsim_batch_info &bi = c->b_info;
+  const pbsim_batch_info &bi = c->s().b_info;
   if (sink) {
-    HIP_OK(c->h_read_text.ensure((size_t)bi.read_text_bytes + 16));
-    HIP_OK(c->h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
-    if (!pbsim_batch_fetch(c, (char *)c->h_read_text.p, (char *)c->h_maf_text.p)) return PBSIM_FAILED;
+    HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
+    HIP_OK(c->s().h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
+    if (!pbsim_batch_fetch(c, (char *)c->s().h_read_text.p, (char *)c->s().h_maf_text.p)) return PBSIM_FAILED;
     if (sink->on_read_text && bi.read_text_bytes &&
-        !sink->on_read_text(sink->user, (const char *)c->h_read_text.p, bi.read_text_bytes))
+        !sink->on_read_text(sink->user, (const char *)c->s().h_read_text.p, bi.read_text_bytes))
       return fail("sink aborted (read text)");
     if (sink->on_maf_text && bi.maf_text_bytes &&
-        !sink->on_maf_text(sink->user, (const char *)c->h_maf_text.p, bi.maf_text_bytes))
+        !sink->on_maf_text(sink->user, (const char *)c->s().h_maf_text.p, bi.maf_text_bytes))
       return fail("sink aborted (MAF text)");
   }
   return pbsim_batch_account(c);
 }
 
 // The quota loop `while (len_total < sim.len_quota)` (pbsim.cpp:3792) as
-// speculative bulk batches + prefix scan + a serial tail.
+// speculative bulk batches + prefix scan + a serial tail.  Batches
+// are pipelined over the slots: batch k+1 is enqueued (assuming batch k will not
+// be cut) before batch k is finalised, so the GPU never idles on a batch's
+// longest read or on the host round trips; a batch enqueued past the cut is
+// simply dropped.
 int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
   if (!c) return fail("bad argument");
   NEED_DEVICE(c);
@@ -863,33 +914,97 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
   if (!c->d_seq) return fail("no reference set (pbsim_set_reference)");
   pbsim_reset_stats(c);
   const int64_t quota = pbsim_unit_quota(c);
-  int64_t len_total = 0, next_read = 1;
-  bool serial = false;
-  int64_t cap = batch_capacity(c);
   const double mean = std::min<double>(c->hdr.mean_len, (double)c->ref_len);
+  const int n_slots = std::max(1, std::min(kMaxSlots, c->pipeline_depth));
+  int64_t cap = batch_capacity(c);
+  int64_t len_total = 0, next_read = 1;
+  struct Pending {
+    int slot;
+    int64_t first, n;
+  };
+  std::vector<Pending> fifo;
+  auto drop_pending = [&]() {  // speculative batches beyond a cut or after an error
+    for (const Pending &pd : fifo) {
+      c->cur = pd.slot;
+      (void)hipStreamSynchronize(c->s().stream);
+      c->s().b_enqueued = false;
+    }
+    fifo.clear();
+    c->cur = 0;
+  };
+  int next_slot = 0;
+  int64_t spec_read = 1;          // first read not yet enqueued
+  double spec_total = 0;          // expected pass-0 bases once everything enqueued has finished
+  bool serial = false;
   while (len_total < quota) {
-    pbsim_batch_info bi;
-    if (!serial) {
-      int64_t n = (int64_t)(0.98 * (double)(quota - len_total) / mean);
-      n = std::max<int64_t>(1, std::min(n, cap));
-      int64_t pass0 = 0;
-      if (!pbsim_batch_walk(c, next_read, n, -1, &pass0)) {
-        if (g_err.rfind("scratch budget exceeded", 0) == 0 && n > 1) {
-          cap = std::max<int64_t>(1, n / 2);  // skewed lengths: retry with a smaller batch
-          continue;
-        }
-        return PBSIM_FAILED;
-      }
-      if (!pbsim_batch_finalize(c, len_total, &bi)) return PBSIM_FAILED;
-      if (bi.need_truncated_read) serial = true;
-    } else {
+    if (serial) {
+      c->cur = 0;
+      pbsim_batch_info bi;
       if (!pbsim_batch_walk(c, next_read, 1, quota - len_total, nullptr)) return PBSIM_FAILED;
       if (!pbsim_batch_finalize(c, len_total, &bi)) return PBSIM_FAILED;
+      if (!deliver(c, sink)) return PBSIM_FAILED;
+      next_read += bi.n_final;
+      len_total = bi.len_total_after;
+      continue;
     }
-    if (!deliver(c, sink)) return PBSIM_FAILED;
+    // keep the pipeline full with speculative batches
+    while ((int)fifo.size() < n_slots) {
+      const double remaining = (double)quota - spec_total;
+      int64_t n = (int64_t)(0.98 * remaining / mean);
+      if (n < 1) {
+        if (!fifo.empty()) break;
+        n = 1;
+      }
+      n = std::min(n, cap);
+      c->cur = next_slot;
+      if (!pbsim_batch_walk_begin(c, spec_read, n, -1)) {
+        drop_pending();
+        return PBSIM_FAILED;
+      }
+      fifo.push_back(Pending{next_slot, spec_read, n});
+      next_slot = (next_slot + 1) % n_slots;
+      spec_read += n;
+      spec_total += (double)n * mean;
+    }
+    const Pending pd = fifo.front();
+    fifo.erase(fifo.begin());
+    c->cur = pd.slot;
+    int64_t pass0 = 0;
+    if (!pbsim_batch_walk_end(c, &pass0)) {
+      const bool budget = g_err.rfind("scratch budget exceeded", 0) == 0 && pd.n > 1;
+      const std::string keep = g_err;
+      drop_pending();
+      if (!budget) {
+        g_err = keep;
+        return PBSIM_FAILED;
+      }
+      cap = std::max<int64_t>(1, pd.n / 2);  // skewed lengths: retry from this batch with smaller ones
+      spec_read = pd.first;
+      spec_total = (double)len_total;
+      next_slot = 0;
+      continue;
+    }
+    pbsim_batch_info bi;
+    if (!pbsim_batch_finalize(c, len_total, &bi)) {
+      drop_pending();
+      return PBSIM_FAILED;
+    }
+    if (!deliver(c, sink)) {
+      drop_pending();
+      return PBSIM_FAILED;
+    }
     next_read += bi.n_final;
     len_total = bi.len_total_after;
+    spec_total += (double)pass0 - (double)pd.n * mean;  // replace the estimate by what the batch produced
+    if (bi.n_final < pd.n) {  // the quota was reached inside this batch: later speculation is void
+      drop_pending();
+      spec_read = next_read;
+      spec_total = (double)len_total;
+      next_slot = 0;
+      if (bi.need_truncated_read) serial = true;
+    }
   }
+  drop_pending();
   return PBSIM_SUCCEEDED;
 }
 
@@ -981,7 +1096,7 @@ int pbsim_set_transcripts(pbsim_ctx *c, int64_t n, const char *const *ids, const
   c->unit = 0;
   c->n_units = n;
   c->trans_reads = reads;
-  c->b_walked = c->b_finalized = false;
+  for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
   return PBSIM_SUCCEEDED;
 }
 
