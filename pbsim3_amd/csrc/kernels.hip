@@ -38,6 +38,17 @@ __device__ __forceinline__ uint32_t complement(uint32_t c) {
   return r;
 }
 
+// the same map on four packed bytes (SWAR): 0x80 marks the bytes equal to k
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t k) {
+  const uint32_t z = w ^ (k * 0x01010101u);
+  return ~((((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z)) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t complement4(uint32_t w) {
+  const uint32_t at = (eq_bytes(w, 'A') | eq_bytes(w, 'T')) >> 7;  // 0x01 per matching byte
+  const uint32_t cg = (eq_bytes(w, 'C') | eq_bytes(w, 'G')) >> 7;
+  return w ^ (at * 0x15u) ^ (cg * 0x04u);                          // 'A'^'T' = 0x15, 'C'^'G' = 0x04
+}
+
 // mut.sub_nt_{a,t,g,c} (pbsim.cpp:5481-5484) packed little-endian
 __device__ __forceinline__ uint32_t sub_table(uint32_t nt) {
   uint32_t t = 0;
@@ -1208,33 +1219,44 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
       const long long dst = s_dst[j];
       const int minus = s_minus[j];
       const long long D0 = minus ? dst + (n - s1) : dst + s0;
-      const long long D1 = D0 + (s1 - s0);
-      for (long long d = (D0 >> 2) + lane; d * 4 < D1; d += 64) {
-        const long long A = d * 4;
-        uint32_t word = 0;
-        bool all_in = (A >= D0) && (A + 4 <= D1);
+      const long long base_al = D0 & ~3LL;         // wave-uniform
+      const int d0r = (int)(D0 - base_al);          // 0..3
+      const int d1r = d0r + (s1 - s0);              // <= 259
+      const int rel0 = (int)(base_al - dst);        // row byte index of base_al (may be -3..)
+      char *out = text + base_al;
+      const uint32_t *trow = s_tile + j * kTileStride;
+      for (int a4 = lane * 4; a4 < d1r; a4 += 256) {
+        const int rel = rel0 + a4;                  // row byte index (destination order) of this dword
+        if (a4 >= d0r && a4 + 4 <= d1r) {           // interior: one aligned dword store
+          uint32_t word;
+          if (fill) {
+            word = (kind == 1) ? 0x21212121u : ((rel & 1) ? 0x2C392C39u : 0x392C392Cu);
+          } else if (!minus) {
+            const int s = rel - s0;
+            word = __builtin_amdgcn_alignbyte(trow[(s >> 2) + 1], trow[s >> 2], (uint32_t)(s & 3));
+          } else {
+            const int sb = (n - 1 - rel) - s0 - 3;  // lowest of the four source bytes
+            const uint32_t w = __builtin_amdgcn_alignbyte(trow[(sb >> 2) + 1], trow[sb >> 2], (uint32_t)(sb & 3));
+            word = complement4(__builtin_bswap32(w));
+          }
+          *reinterpret_cast<uint32_t *>(out + a4) = word;
+        } else {                                    // the (at most two) edge dwords of the segment
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const long long pos = A + b;
-          uint32_t v = 0;
-          if (pos >= D0 && pos < D1) {
-            const int rel = (int)(pos - dst);  // byte index within the row, destination order
-            if (fill) {
-              v = (kind == 1) ? (uint32_t)'!' : ((rel & 1) ? (uint32_t)'9' : (uint32_t)',');
-            } else {
-              const int s = (minus ? (n - 1 - rel) : rel) - s0;
-              v = tile8[j * (kTileStride * 4) + s];
-              if (minus) v = complement(v);
+          for (int b = 0; b < 4; b++) {
+            const int pos = a4 + b;
+            if (pos >= d0r && pos < d1r) {
+              const int rb = rel + b;
+              uint32_t v;
+              if (fill) {
+                v = (kind == 1) ? (uint32_t)'!' : ((rb & 1) ? (uint32_t)'9' : (uint32_t)',');
+              } else {
+                const int s = (minus ? (n - 1 - rb) : rb) - s0;
+                v = tile8[j * (kTileStride * 4) + s];
+                if (minus) v = complement(v);
+              }
+              out[pos] = (char)v;
             }
           }
-          word |= v << (8 * b);
-        }
-        if (all_in) {
-          *reinterpret_cast<uint32_t *>(text + A) = word;
-        } else {
-#pragma unroll
-          for (int b = 0; b < 4; b++)
-            if (A + b >= D0 && A + b < D1) text[A + b] = (char)(word >> (8 * b));
         }
       }
     }
