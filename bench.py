@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--scratch-gib", type=float, default=32.0)
     ap.add_argument("--batch-reads", type=int, default=0, help="reads per step per GPU (0 = what the scratch pool holds)")
     ap.add_argument("--model", default="ERRHMM-ONT.model")
+    ap.add_argument("--workload", default="errhmm", choices=["errhmm", "qshmm10"],
+                    help="errhmm = BASELINE configs[1] (headline); qshmm10 = configs[2]: QSHMM-RSII, --pass-num 10")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[],
                     help="experiment only: override a pbsim_params field, e.g. --param len_sd=0 (not the headline workload)")
@@ -122,13 +124,18 @@ def main():
         dist.broadcast(genome, src=0)          # C1: reference broadcast over xGMI
     torch.cuda.synchronize()
 
-    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=20.0)
+    qs = a.workload == "qshmm10"
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=1, depth=20.0,
+                         pass_num=10 if qs else 1)
     for kv in a.param:
         k, v = kv.split("=")
         setattr(p, k, type(getattr(p, k))(float(v)))
     ctx = P.Context(p, local)
     ctx.set_scratch_bytes(int(a.scratch_gib * (1 << 30)))
-    ctx.load_errhmm(harness.model_path(a.model))
+    if qs:
+        ctx.load_qshmm(harness.model_path("QSHMM-RSII.model"))
+    else:
+        ctx.load_errhmm(harness.model_path(a.model))
     ctx.set_reference_device(genome.data_ptr(), G, 1)
     del genome
     torch.cuda.empty_cache()
@@ -203,11 +210,12 @@ def main():
             "ms_per_step": dt_max * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "reads_per_sec": g_reads / dt_max,
-            "config": {"workload": "wgs errhmm ERRHMM-ONT depth 20, default length/accuracy, uniform ACGT record "
+            "config": {"workload": ("wgs qshmm QSHMM-RSII pass-num 10" if qs else "wgs errhmm ERRHMM-ONT") +
+                                   " depth 20, default length/accuracy, uniform ACGT record "
                                    f"of {G} bp resident in HBM (one of the 4 records of the 3 Gbp genome)",
                        "param_overrides": a.param, "reads_per_step_per_gpu": B, "bases_per_step": g_bases // a.steps,
                        "text_bytes_per_step": g_text // a.steps, "parallelism": f"read-block x{world}", "slots_in_flight": S},
-            "roofline": {"bound": "hbm", "kernel": "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_walk_qshmm" if qs else "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": walk_s * 1e3,
                          "walk_share_of_step": (walk_ms / 1e3) / dt if dt > 0 else None},

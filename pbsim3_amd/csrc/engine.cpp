@@ -141,7 +141,7 @@ struct pbsim_ctx {
 
   DevBuf d_prob2len, d_prob2acc, d_cls, d_qs_tabs;
   // reference
-  DevBuf d_seq_own, d_hp, d_tiles, d_ref_flags;
+  DevBuf d_seq_own, d_hp, d_hp11, d_tiles, d_ref_flags;
   const uint8_t *d_seq = nullptr;
   int64_t ref_len = 0;
   int64_t unit = 0;
@@ -220,12 +220,14 @@ int read_flags(pbsim_ctx *c, DeviceFlags *f) {
 int prepare_reference(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int keep_first_case, int64_t census_out[kHpSlots]) {
   const int64_t n_tiles = (len + kHpTile - 1) / kHpTile;
   HIP_OK(c->d_hp.ensure((size_t)len + 64));
+  HIP_OK(c->d_hp11.ensure((size_t)len / 8 + 64));
+  HIP_OK(hipMemsetAsync(c->d_hp11.p, 0, (size_t)len / 8 + 64, c->stream));
   HIP_OK(c->d_tiles.ensure((size_t)(n_tiles + 1) * 4 * sizeof(int64_t)));
   HIP_OK(c->d_ref_flags.ensure(sizeof(DeviceFlags)));
   HIP_OK(hipMemsetAsync(c->d_ref_flags.p, 0, sizeof(DeviceFlags), c->stream));
   HIP_OK(hipMemsetAsync(c->d_hp.as<uint8_t>() + len, 0, 64, c->stream));
   int64_t *t = c->d_tiles.as<int64_t>();
-  launch_prepare_reference(d_seq, c->d_hp.as<uint8_t>(), len, t, t + (n_tiles + 1), t + 2 * (n_tiles + 1),
+  launch_prepare_reference(d_seq, c->d_hp.as<uint8_t>(), c->d_hp11.as<uint16_t>(), len, t, t + (n_tiles + 1), t + 2 * (n_tiles + 1),
                            t + 3 * (n_tiles + 1), keep_first_case, c->d_ref_flags.as<DeviceFlags>(), c->stream);
   HIP_OK(hipGetLastError());
   DeviceFlags f;
@@ -601,6 +603,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   w.ncls = ncls;
   w.ref.seq = c->d_seq;
   w.ref.hp = c->d_hp.as<uint8_t>();
+  w.hp11 = c->d_hp11.as<uint16_t>();
   w.ref.len = c->ref_len;
   w.len = h.len;
   w.off = h.off;
@@ -629,7 +632,8 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
     w.rows_off = c->ect.rows_off;
     w.init_off = c->ect.init_off;
     w.tran_off = c->ect.tran_off;
-    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->s().stream);
+    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->p.hp_del_bias == 1,
+                       c->s().stream);
   } else {
     w.stride = c->qct.stride;
     w.rv_off = c->qct.rv_off;

@@ -38,6 +38,7 @@ struct RefView {
   int64_t len;
 };
 
+
 struct HeaderArgs {
   uint32_t seed, unit;
   int64_t first_read;       // 1-based index of read 0 of the batch
@@ -88,6 +89,7 @@ struct WalkArgs {
   int32_t pass_num;
   int32_t ncls;
   RefView ref;
+  const uint16_t *hp11;      // 1 bit per base: hp == 11
   const int32_t *len, *off;
   const int64_t *read_base;  // trans: offset of the read's unit inside the concatenated reference (NULL: 0)
   const uint8_t *read_minus; // trans: strand per read (NULL: wgs parity rule)
@@ -139,13 +141,14 @@ struct TextArgs {
 };
 
 // ---- launches (all asynchronous on `s`) ------------------------------------
-void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int64_t len, int64_t *tile_first, int64_t *tile_last,
+void launch_prepare_reference(uint8_t *seq, uint8_t *hp, uint16_t *hp11, int64_t len, int64_t *tile_first, int64_t *tile_last,
                               int64_t *carry_start, int64_t *carry_next, int keep_first_case, DeviceFlags *flags,
                               hipStream_t s);
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s);
 void launch_header_trans(const HeaderArgs &a, hipStream_t s);
 void launch_task_sort(const SortArgs &a, hipStream_t s);
-void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, hipStream_t s);
+void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
+                        hipStream_t s);
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s);
 // exclusive scan of int64 (in-place allowed: out may equal in); tmp needs (n/1024+2) int64
 void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total, hipStream_t s);

@@ -163,9 +163,9 @@ __global__ void k_hp_carry(const int64_t *tile_first, const int64_t *tile_last, 
   }
 }
 
-__global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int64_t len, int keep_first_case,
-                                                    const int64_t *carry_start, const int64_t *carry_next,
-                                                    DeviceFlags *flags) {
+__global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, uint16_t *hp11, int64_t len,
+                                                    int keep_first_case, const int64_t *carry_start,
+                                                    const int64_t *carry_next, DeviceFlags *flags) {
   __shared__ long long s_last[256], s_first[256];
   __shared__ unsigned int s_hist[12];
   const int tid = threadIdx.x;
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int
       next_start[k] = nxt;
       if (brk[k]) nxt = base + k;
     }
+    uint32_t bits11 = 0;
     for (int k = 0; k < n; k++) {
       const long long run = next_start[k] - start[k];
       // nnum++ ; if (nnum > 11) nnum = 10  (pbsim.cpp:1045-1048): 11,13,.. -> 11 ; 12,14,.. -> 10
@@ -222,8 +223,10 @@ __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int
       if (c[k] == 'N') v = 1;  // pbsim.cpp:1050-1054
       hp[base + k] = (uint8_t)v;
       seq[base + k] = (uint8_t)c[k];
+      bits11 |= (v == 11u) ? (1u << k) : 0u;
       if (c[k] != '\n') atomicAdd(&s_hist[v], 1u);
     }
+    hp11[base >> 4] = (uint16_t)bits11;  // one bit per base: hp == 11 (the only class the default bias treats apart, Q1)
   }
   __syncthreads();
   if (tid < 12 && s_hist[tid]) atomicAdd(&flags->hpfreq[tid], (unsigned long long)s_hist[tid]);
@@ -481,7 +484,9 @@ struct StepOut {
 // bookkeeping for all 64 lanes.  Only three rare paths stay as real branches:
 // states whose emission modulus is not 1000, the sub-block-1 draws (out-of-range
 // accuracy classes, non-ACGT substitutions), and the look-ahead refill.
-template <bool kFastRv>
+// kHpBits: --hp-del-bias 1 (default): the deletion threshold depends on hp only through
+// hp == 11 (Q1), so the walk reads the 1-bit-per-base mask instead of the hp byte array.
+template <bool kFastRv, bool kHpBits>
 __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -546,24 +551,35 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   bool act = valid && L > 0;
   int group = 0;
 
-  // Reference window: the dword under the cursor plus the next one in walking
-  // direction, fetched one group ahead so a lone long read never waits on HBM.
+  // Reference window: the 8 bases under the cursor plus the next 8 in walking
+  // direction, fetched ahead so a lone long read never waits on HBM; wider loads
+  // than the 1 byte a step consumes keep the L2->fabric request count down (each
+  // request moves a 64-byte sector whatever the load width).  The hp window is
+  // either the byte array (same shape) or, with kHpBits, 32 bases of the hp==11 mask.
   const int64_t p_first = minus ? (off + L - 1) : off;
   const uint32_t pl0 = (uint32_t)p_first;  // low bits are all the cursor arithmetic needs
   const int wstep = minus ? -1 : 1;
   const uint32_t comp_off = minus ? 256u : 0u;
-  const uint32_t *lane_seq = reinterpret_cast<const uint32_t *>(a.ref.seq) + (p_first >> 2);
-  const uint32_t *lane_hp = reinterpret_cast<const uint32_t *>(a.ref.hp) + (p_first >> 2);
-  int rel = 0;  // current dword, relative to the lane's first one
-  uint32_t cur_wl = pl0 >> 2;
-  uint32_t wseq = 0, whp = 0, nseq = 0, nhp = 0;
-  bool need_next = false;
+  const uint64_t *lane_seq = reinterpret_cast<const uint64_t *>(a.ref.seq) + (p_first >> 3);
+  const uint64_t *lane_hp = reinterpret_cast<const uint64_t *>(a.ref.hp) + (p_first >> 3);
+  const uint32_t *lane_bits = reinterpret_cast<const uint32_t *>(a.hp11) + (p_first >> 5);
+  int rel = 0, brel = 0;  // current qword / mask dword, relative to the lane's first one
+  uint32_t cur_wl = pl0 >> 3, cur_bl = pl0 >> 5;
+  uint64_t wseq = 0, whp = 0, nseq = 0, nhp = 0;
+  uint32_t wbits = 0, nbits = 0;
+  bool need_next = false, need_nbits = false;
   if (act) {
     wseq = lane_seq[0];
-    whp = lane_hp[0];
-    const int nrel = ((p_first >> 2) + wstep < 0) ? 0 : wstep;
+    const int nrel = ((p_first >> 3) + wstep < 0) ? 0 : wstep;
     nseq = lane_seq[nrel];
-    nhp = lane_hp[nrel];
+    if (kHpBits) {
+      wbits = lane_bits[0];
+      const int nb = ((p_first >> 5) + wstep < 0) ? 0 : wstep;
+      nbits = lane_bits[nb];
+    } else {
+      whp = lane_hp[0];
+      nhp = lane_hp[nrel];
+    }
   }
 
   while (__any(act)) {
@@ -583,15 +599,25 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
       const U4 w = W[j];
       // ---- reference base under the cursor
       const uint32_t pl = minus ? (pl0 - (uint32_t)ro) : (pl0 + (uint32_t)ro);
-      const bool cross = act && ((pl >> 2) != cur_wl);  // at most one dword boundary per group
+      const bool cross = act && ((pl >> 3) != cur_wl);  // at most one window boundary per group
       wseq = cross ? nseq : wseq;
-      whp = cross ? nhp : whp;
-      cur_wl = cross ? (pl >> 2) : cur_wl;
+      cur_wl = cross ? (pl >> 3) : cur_wl;
       rel += cross ? wstep : 0;
       need_next = need_next || cross;
-      const uint32_t sh = (pl & 3u) * 8u;
-      const uint32_t nt = s_comp[((wseq >> sh) & 0xffu) + comp_off];
-      const uint32_t hp = (whp >> sh) & 0xffu;
+      const uint32_t sh = (pl & 7u) * 8u;
+      const uint32_t nt = s_comp[((uint32_t)(wseq >> sh) & 0xffu) + comp_off];
+      uint32_t hp;
+      if (kHpBits) {
+        const bool bcross = act && ((pl >> 5) != cur_bl);
+        wbits = bcross ? nbits : wbits;
+        cur_bl = bcross ? (pl >> 5) : cur_bl;
+        brel += bcross ? wstep : 0;
+        need_nbits = need_nbits || bcross;
+        hp = ((wbits >> (pl & 31u)) & 1u) ? 11u : 1u;
+      } else {
+        whp = cross ? nhp : whp;
+        hp = (uint32_t)(whp >> sh) & 0xffu;
+      }
 
       // ---- state, deletion test, emission class
       uint32_t e = 0;
@@ -660,11 +686,16 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
       read_row[(size_t)(q_group >> 2) * 64] = (uint32_t)acc_rd;
     }
     if ((q >> 2) != (q_group >> 2)) acc_rd >>= 32;
-    if (need_next && act) {  // refill the look-ahead dword; consumed at the next boundary
-      const int nrel = ((p_first >> 2) + rel + wstep < 0) ? rel : rel + wstep;
+    if (need_next && act) {  // refill the look-ahead window; consumed at the next boundary
+      const int nrel = ((p_first >> 3) + rel + wstep < 0) ? rel : rel + wstep;
       nseq = lane_seq[nrel];
-      nhp = lane_hp[nrel];
+      if (!kHpBits) nhp = lane_hp[nrel];
       need_next = false;
+    }
+    if (kHpBits && need_nbits && act) {
+      const int nb = ((p_first >> 5) + brel + wstep < 0) ? brel : brel + wstep;
+      nbits = lane_bits[nb];
+      need_nbits = false;
     }
     acc_r = 0;
     acc_f = 0;
@@ -1271,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
 // ---------------------------------------------------------------------------
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int64_t len, int64_t *tile_first, int64_t *tile_last,
+void launch_prepare_reference(uint8_t *seq, uint8_t *hp, uint16_t *hp11, int64_t len, int64_t *tile_first, int64_t *tile_last,
                               int64_t *carry_start, int64_t *carry_next, int keep_first_case, DeviceFlags *flags,
                               hipStream_t s) {
   const int64_t n_tiles = (len + kHpTile - 1) / kHpTile;
@@ -1280,7 +1311,7 @@ void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int64_t len, int64_t *t
                      tile_last);
   hipLaunchKernelGGL(k_hp_carry, dim3(1), dim3(128), 0, s, tile_first, tile_last, n_tiles, len, carry_start,
                      carry_next);
-  hipLaunchKernelGGL(k_hp_final, dim3((unsigned)n_tiles), dim3(256), 0, s, seq, hp, len, keep_first_case,
+  hipLaunchKernelGGL(k_hp_final, dim3((unsigned)n_tiles), dim3(256), 0, s, seq, hp, hp11, len, keep_first_case,
                      carry_start, carry_next, flags);
 }
 
@@ -1311,11 +1342,13 @@ void launch_task_sort(const SortArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_wg_scatter, dim3(blocks_for(n_wg, 256)), dim3(256), 0, s, a, a.wg_start, a.wg_order);
 }
 
-void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, hipStream_t s) {
-  if (fast_rv)
-    hipLaunchKernelGGL(k_walk_errhmm<true>, dim3((unsigned)(n_slots_max / kWG)), dim3(kWG), lds_bytes, s, a);
-  else
-    hipLaunchKernelGGL(k_walk_errhmm<false>, dim3((unsigned)(n_slots_max / kWG)), dim3(kWG), lds_bytes, s, a);
+void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
+                        hipStream_t s) {
+  const dim3 grid((unsigned)(n_slots_max / kWG)), block(kWG);
+  if (fast_rv && hp_bits) hipLaunchKernelGGL((k_walk_errhmm<true, true>), grid, block, lds_bytes, s, a);
+  else if (fast_rv) hipLaunchKernelGGL((k_walk_errhmm<true, false>), grid, block, lds_bytes, s, a);
+  else if (hp_bits) hipLaunchKernelGGL((k_walk_errhmm<false, true>), grid, block, lds_bytes, s, a);
+  else hipLaunchKernelGGL((k_walk_errhmm<false, false>), grid, block, lds_bytes, s, a);
 }
 
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s) {
