@@ -17,7 +17,7 @@ ARCH = "gfx950"
 HIP_SOURCES = ["kernels.hip", "engine.cpp"]
 CXX_SOURCES = ["host_tables.cpp", "unit_io.cpp"]
 CLI_SOURCES = ["cli.cpp"]
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("PBSIM_EXTRA_CFLAGS", "").split()
 
 
 def _newer(target, deps):

@@ -166,7 +166,7 @@ struct pbsim_ctx {
 
 namespace {
 
-int regions_of(const pbsim_ctx *c) { return c->p.method == PBSIM_METHOD_QS ? 4 : 3; }
+int regions_of(const pbsim_ctx *c) { return c->p.method == PBSIM_METHOD_QS ? 3 : 2; }
 int ncls_of(const pbsim_ctx *c) { return c->hdr.acc_hi - c->hdr.acc_lo + 1; }
 
 int upload(DevBuf &b, const void *src, size_t n, hipStream_t s) {

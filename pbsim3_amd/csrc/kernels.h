@@ -78,7 +78,7 @@ struct SortArgs {
   int64_t n_slots_max;
   int32_t *wg_hist, *wg_start;  // [kLenBuckets+1] each
   int32_t *wg_order;            // [n_slots_max/kWG] walk workgroups, longest reads first
-  int32_t regions;      // scratch regions per task (3 errhmm, 4 qshmm)
+  int32_t regions;      // scratch rows per task (2 errhmm, 3 qshmm)
   int64_t scratch_bytes;
   DeviceFlags *flags;
 };

@@ -12,9 +12,11 @@
 //
 // Integer/byte work end to end: no MFMA, no floating point in the walk except
 // the ordered double sum of quality error probabilities (pbsim.cpp:2309-2313).
-// Scratch is wave-transposed: dword c of lane l of a wave lives at
-// region[(c*64 + l)*4], so the lock-step MAF stores of a wave are one
-// contiguous 256-byte line per row.
+// Scratch is wave-transposed and column-aligned: dword c (MAF columns 4c..4c+3)
+// of lane l of a wave lives at region[(c*64 + l)*4], so every store of the walk
+// is one contiguous 256-byte line per row per wave.  Rows: MAF read row (byte 0 =
+// deleted column), MAF reference row, and for QSHMM the quality per column; the
+// read sequence is the MAF read row with the deleted columns squeezed out (K3).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -540,13 +542,11 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
-  uint32_t *read_row = maf_ref + (size_t)cap_dw * 64;
   const int cap = 2 * L + kScratchPad;
 
   int ro = 0, q = 0, m = 0;
   uint32_t state = 0, tran_rv = 1;
   uint32_t acc_r = 0, acc_f = 0;
-  unsigned long long acc_rd = 0;  // read bases not yet stored: q & 3 old ones + this group's
   int nsub = 0, nins = 0, ndel = 0;
   bool act = valid && L > 0;
   int group = 0;
@@ -593,7 +593,6 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; j++) W[j] = U4{0, 0, 0, 0};
     }
-    const int q_group = q;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const U4 w = W[j];
@@ -664,12 +663,11 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
       // ---- emit
       const uint32_t insb = (w.w & 4u) ? nt : ((kATGC >> ((w.w & 3u) * 8u)) & 0xffu);
       const uint32_t b = (e == 1) ? subb : (e == 2) ? insb : nt;
-      const uint32_t mr = (e == 3) ? (uint32_t)'-' : b;
+      const uint32_t mr = (e == 3) ? 0u : b;  // 0 marks a deleted column; the text kernel prints '-' there
       const uint32_t mf = (e == 2) ? (uint32_t)'-' : nt;
       acc_r |= act ? (mr << (8 * j)) : 0u;
       acc_f |= act ? (mf << (8 * j)) : 0u;
       const bool has = act && (e != 3);
-      acc_rd |= has ? ((unsigned long long)b << (((uint32_t)(q - q_group) + ((uint32_t)q_group & 3u)) * 8u)) : 0ull;
       q += has ? 1 : 0;
       nsub += (act && e == 1) ? 1 : 0;
       nins += (act && e == 2) ? 1 : 0;
@@ -681,11 +679,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     if (valid && m > group * 4) {
       maf_read[(size_t)group * 64] = acc_r;
       maf_ref[(size_t)group * 64] = acc_f;
-      // the low dword of the pending read bases is final once 4 are present; storing it
-      // early is harmless (same slot is rewritten when it completes)
-      read_row[(size_t)(q_group >> 2) * 64] = (uint32_t)acc_rd;
     }
-    if ((q >> 2) != (q_group >> 2)) acc_rd >>= 32;
     if (need_next && act) {  // refill the look-ahead window; consumed at the next boundary
       const int nrel = ((p_first >> 3) + rel + wstep < 0) ? rel : rel + wstep;
       nseq = lane_seq[nrel];
@@ -702,7 +696,6 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     group++;
   }
   if (valid) {
-    if (q & 3) read_row[(size_t)(q >> 2) * 64] = (uint32_t)acc_rd;
     if (ro < L) atomicOr(&a.flags->error, kErrScratchOverflow);
     a.out_len[task] = q;
     a.maf_len[task] = m;
@@ -770,13 +763,12 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
-  uint32_t *read_row = maf_ref + (size_t)cap_dw * 64;
-  uint32_t *qual_row = read_row + (size_t)cap_dw * 64;
+  uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;  // quality per MAF column (0 in deleted columns)
   const int cap = 2 * L + kScratchPad;
 
   int ro = 0, q = 0, m = 0;
   uint32_t state = 0, last_q = 0;
-  uint32_t acc_r = 0, acc_f = 0, acc_rd = 0, acc_q = 0;
+  uint32_t acc_r = 0, acc_f = 0, acc_q = 0;
   int nsub = 0, nins = 0, ndel = 0;
   double qsum = 0.0;
   bool active = valid && L > 0;
@@ -799,7 +791,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
         }
         uint32_t mr, mf;
         if (deleted) {  // pbsim.cpp:2272-2277
-          mr = '-';
+          mr = 0;  // deleted column marker
           mf = nt;
           ro++;
           ndel++;
@@ -847,15 +839,8 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
             ro++;
           }
           mr = b;
-          acc_rd |= b << ((q & 3) * 8);
-          acc_q |= (qv + 33u) << ((q & 3) * 8);
+          acc_q |= (qv + 33u) << (8 * j);
           q++;
-          if ((q & 3) == 0) {
-            read_row[(size_t)((q >> 2) - 1) * 64] = acc_rd;
-            qual_row[(size_t)((q >> 2) - 1) * 64] = acc_q;
-            acc_rd = 0;
-            acc_q = 0;
-          }
         }
         acc_r |= mr << (8 * j);
         acc_f |= mf << (8 * j);
@@ -870,16 +855,14 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
     if (valid && m > group * 4) {
       maf_read[(size_t)group * 64] = acc_r;
       maf_ref[(size_t)group * 64] = acc_f;
+      qual_row[(size_t)group * 64] = acc_q;
     }
     acc_r = 0;
     acc_f = 0;
+    acc_q = 0;
     group++;
   }
   if (valid) {
-    if (q & 3) {
-      read_row[(size_t)(q >> 2) * 64] = acc_rd;
-      qual_row[(size_t)(q >> 2) * 64] = acc_q;
-    }
     a.out_len[task] = q;
     a.maf_len[task] = m;
     a.nsub[task] = nsub;
@@ -1180,18 +1163,75 @@ __global__ __launch_bounds__(256) void k_text_headers(TextArgs a) {
   *o++ = '\n';
 }
 
-// ---- big rows: one workgroup per (scratch wave, row kind).  A 64-task x 256-byte
+// ---- big rows: one workgroup per (scratch wave, row kind).  A 64-task x 256-column
 // tile is read as coalesced 256-byte lines of the wave-transposed scratch, turned
 // through LDS, and written as aligned dwords into each task's text position.
-//   kind 0 read bases | 1 quality ('!' fill for ERRHMM, pbsim.cpp:4007-4010)
-//   kind 2 MAF reference row | 3 MAF read row   ('-' strand: reverse-complemented
-//          back to forward orientation, pbsim.cpp:3981-3984)
+//   kind 0 read bases  = MAF read row with the deleted columns (byte 0) squeezed out
+//   kind 1 qualities   = quality row squeezed the same way (QSHMM), '!' fill for ERRHMM
+//                        (pbsim.cpp:4007-4010)
+//   kind 2 MAF reference row | 3 MAF read row (0 -> '-'); '-' strand rows are
+//          reverse-complemented back to forward orientation (pbsim.cpp:3981-3984)
 //   kind 4,5 the two ",9" x len SAM tag fills (pbsim.cpp:4019-4025)
 constexpr int kTileStride = 65;  // dwords per task row in LDS (64 + 1 pad: conflict-free turn)
 
+// zero bytes (deleted columns) of a MAF read row print as '-'
+__device__ __forceinline__ uint32_t dash_zero_bytes(uint32_t w) { return w | ((eq_bytes(w, 0u) >> 7) * 0x2Du); }
+
+// Writes `len` bytes at text[D0..): plus: text[D0+i] = row[i]; minus: text[D0+i] =
+// complement(row[len-1-i]).  `row` is an LDS row (dword aligned); interior bytes go out as
+// aligned dwords, the <=2 edge dwords as bytes.  fill_kind: 0 copy, 1 '!', 2 ",9" pattern
+// (phase from `rel_first`, the row byte index of D0).
+__device__ __forceinline__ void write_segment(char *text, long long D0, int len, const uint32_t *row, int minus,
+                                              int fill_kind, bool dash_zero, int rel_first, int lane) {
+  const long long base_al = D0 & ~3LL;
+  const int d0r = (int)(D0 - base_al);  // 0..3
+  const int d1r = d0r + len;
+  char *out = text + base_al;
+  const uint8_t *row8 = reinterpret_cast<const uint8_t *>(row);
+  for (int a4 = lane * 4; a4 < d1r; a4 += 256) {
+    const int i0 = a4 - d0r;  // segment byte index of this dword's first byte (may be negative at the head)
+    if (a4 >= d0r && a4 + 4 <= d1r) {
+      uint32_t word;
+      if (fill_kind == 1) {
+        word = 0x21212121u;
+      } else if (fill_kind == 2) {
+        word = ((rel_first + i0) & 1) ? 0x2C392C39u : 0x392C392Cu;
+      } else if (!minus) {
+        word = __builtin_amdgcn_alignbyte(row[(i0 >> 2) + 1], row[i0 >> 2], (uint32_t)(i0 & 3));
+      } else {
+        const int sb = len - 1 - i0 - 3;  // lowest of the four source bytes
+        const uint32_t w = __builtin_amdgcn_alignbyte(row[(sb >> 2) + 1], row[sb >> 2], (uint32_t)(sb & 3));
+        word = complement4(__builtin_bswap32(w));
+      }
+      if (dash_zero) word = dash_zero_bytes(word);
+      *reinterpret_cast<uint32_t *>(out + a4) = word;
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int pos = a4 + b;
+        if (pos >= d0r && pos < d1r) {
+          const int i = pos - d0r;
+          uint32_t v;
+          if (fill_kind == 1) {
+            v = '!';
+          } else if (fill_kind == 2) {
+            v = ((rel_first + i) & 1) ? (uint32_t)'9' : (uint32_t)',';
+          } else {
+            v = row8[minus ? (len - 1 - i) : i];
+            if (minus) v = complement(v);
+            if (dash_zero && v == 0) v = '-';
+          }
+          out[pos] = (char)v;
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags *flags) {
   __shared__ uint32_t s_tile[64 * kTileStride];
-  __shared__ int s_n[64];
+  __shared__ uint32_t s_out[64 * kTileStride];  // squeezed rows (kinds 0/1)
+  __shared__ int s_n[64], s_m[64], s_done[64];
   __shared__ long long s_dst[64];
   __shared__ int s_minus[64];
   __shared__ int s_nmax;
@@ -1201,9 +1241,11 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) s_nmax = 0;
   __syncthreads();
+  const bool fill = (kind == 1 && !a.is_qs) || kind >= 4;
+  const bool squeeze = (kind == 0) || (kind == 1 && a.is_qs);
   if (tid < 64) {
     const int task = a.task_of_slot[wave * 64 + tid];
-    int n = 0;
+    int n = 0, m = 0;
     long long dst = 0;
     int minus = 0;
     if (task >= 0) {
@@ -1211,27 +1253,30 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
       if (r < a.n_reads) {
         const int64_t readnum = a.first_read + r;
         const bool mi = a.read_minus ? (a.read_minus[r] != 0) : ((readnum & 1) == 0);
-        n = (kind == 2 || kind == 3) ? a.maf_len[task] : a.out_len[task];
+        m = a.maf_len[task];
+        n = (kind == 2 || kind == 3) ? m : a.out_len[task];
         if (kind >= 4) n *= 2;
         minus = (kind == 2 || kind == 3) && mi;
         dst = a.row_dst[(int64_t)task * 6 + kind];
       }
     }
     s_n[tid] = n;
+    s_m[tid] = m;
+    s_done[tid] = 0;
     s_dst[tid] = dst;
     s_minus[tid] = minus;
-    if (n > 0) atomicMax(&s_nmax, n);
+    const int extent = squeeze ? m : n;  // source columns to sweep
+    if (extent > 0 && n > 0) atomicMax(&s_nmax, extent);
   }
   __syncthreads();
   const int nmax = s_nmax;
   if (nmax == 0) return;
-  const bool fill = (kind == 1 && !a.is_qs) || kind >= 4;
   char *text = (kind == 2 || kind == 3) ? a.maf_text : a.read_text;
   const int cap_dw = a.wave_cap[wave];
-  const int region_idx = (kind == 0) ? 2 : (kind == 1) ? 3 : (kind == 2) ? 1 : 0;
+  // scratch regions: 0 MAF read row (0 = deleted column) | 1 MAF reference row | 2 quality per column
+  const int region_idx = (kind == 0 || kind == 3) ? 0 : (kind == 1) ? 2 : 1;
   const uint32_t *region =
       reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave] + (size_t)region_idx * cap_dw * 256);
-  const uint8_t *tile8 = reinterpret_cast<const uint8_t *>(s_tile);
 
   for (int s0 = 0; s0 < nmax; s0 += 256) {
     if (!fill) {
@@ -1245,50 +1290,43 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     for (int i = 0; i < 16; i++) {
       const int j = wv * 16 + i;
       const int n = s_n[j];
-      if (s0 >= n) continue;
-      const int s1 = (n < s0 + 256) ? n : s0 + 256;
-      const long long dst = s_dst[j];
-      const int minus = s_minus[j];
-      const long long D0 = minus ? dst + (n - s1) : dst + s0;
-      const long long base_al = D0 & ~3LL;         // wave-uniform
-      const int d0r = (int)(D0 - base_al);          // 0..3
-      const int d1r = d0r + (s1 - s0);              // <= 259
-      const int rel0 = (int)(base_al - dst);        // row byte index of base_al (may be -3..)
-      char *out = text + base_al;
-      const uint32_t *trow = s_tile + j * kTileStride;
-      for (int a4 = lane * 4; a4 < d1r; a4 += 256) {
-        const int rel = rel0 + a4;                  // row byte index (destination order) of this dword
-        if (a4 >= d0r && a4 + 4 <= d1r) {           // interior: one aligned dword store
-          uint32_t word;
-          if (fill) {
-            word = (kind == 1) ? 0x21212121u : ((rel & 1) ? 0x2C392C39u : 0x392C392Cu);
-          } else if (!minus) {
-            const int s = rel - s0;
-            word = __builtin_amdgcn_alignbyte(trow[(s >> 2) + 1], trow[s >> 2], (uint32_t)(s & 3));
-          } else {
-            const int sb = (n - 1 - rel) - s0 - 3;  // lowest of the four source bytes
-            const uint32_t w = __builtin_amdgcn_alignbyte(trow[(sb >> 2) + 1], trow[sb >> 2], (uint32_t)(sb & 3));
-            word = complement4(__builtin_bswap32(w));
-          }
-          *reinterpret_cast<uint32_t *>(out + a4) = word;
-        } else {                                    // the (at most two) edge dwords of the segment
+      if (squeeze) {
+        // columns s0..s1 of the task -> the read bases among them, packed into s_out row j
+        const int mcols = s_m[j];
+        if (s0 >= mcols || n == 0) continue;
+        const int ncol = (mcols - s0 < 256) ? mcols - s0 : 256;
+        const uint32_t w = s_tile[j * kTileStride + lane];
+        uint32_t keep = 0;  // bit b: column lane*4+b holds a read base
 #pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const int pos = a4 + b;
-            if (pos >= d0r && pos < d1r) {
-              const int rb = rel + b;
-              uint32_t v;
-              if (fill) {
-                v = (kind == 1) ? (uint32_t)'!' : ((rb & 1) ? (uint32_t)'9' : (uint32_t)',');
-              } else {
-                const int s = (minus ? (n - 1 - rb) : rb) - s0;
-                v = tile8[j * (kTileStride * 4) + s];
-                if (minus) v = complement(v);
-              }
-              out[pos] = (char)v;
-            }
-          }
+        for (int b = 0; b < 4; b++)
+          keep |= ((lane * 4 + b) < ncol && ((w >> (8 * b)) & 0xffu) != 0) ? (1u << b) : 0u;
+        const int cnt = __popc(keep);
+        int pre = cnt;  // inclusive wave prefix sum
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(pre, d, 64);
+          if (lane >= d) pre += t;
         }
+        const int total = __shfl(pre, 63, 64);
+        uint8_t *orow = reinterpret_cast<uint8_t *>(s_out + j * kTileStride);
+        int o = pre - cnt;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if (keep & (1u << b)) orow[o++] = (uint8_t)(w >> (8 * b));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int done = s_done[j];
+        write_segment(text, s_dst[j] + done, total, s_out + j * kTileStride, 0, 0, false, done, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) s_done[j] = done + total;
+      } else {
+        if (s0 >= n) continue;
+        const int s1 = (n < s0 + 256) ? n : s0 + 256;
+        const int minus = s_minus[j];
+        const long long D0 = minus ? s_dst[j] + (n - s1) : s_dst[j] + s0;
+        write_segment(text, D0, s1 - s0, s_tile + j * kTileStride, minus, fill ? (kind == 1 ? 1 : 2) : 0, kind == 3,
+                      (int)(D0 - s_dst[j]), lane);
       }
     }
     if (!fill) __syncthreads();
