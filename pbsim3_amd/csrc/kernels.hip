@@ -1228,108 +1228,129 @@ __device__ __forceinline__ void write_segment(char *text, long long D0, int len,
   }
 }
 
+// One workgroup = one scratch wave (64 tasks); each of its 4 waves owns 16 tasks and
+// runs on its own (no workgroup barrier in the tile loop).  blockIdx.y selects the pass:
+//   pass 0  MAF read row of the scratch -> MAF read line (kind 3) AND, squeezed, the read
+//           bases (kind 0); for ERRHMM also the '!' quality fill (kind 1)
+//   pass 1  MAF reference row -> MAF reference line (kind 2); SAM ",9" fills (kinds 4, 5)
+//   pass 2  QSHMM quality row, squeezed -> qualities (kind 1)
 __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags *flags) {
   __shared__ uint32_t s_tile[64 * kTileStride];
-  __shared__ uint32_t s_out[64 * kTileStride];  // squeezed rows (kinds 0/1)
-  __shared__ int s_n[64], s_m[64], s_done[64];
-  __shared__ long long s_dst[64];
+  __shared__ uint32_t s_out[4 * kTileStride];  // one squeezed row per wave
+  __shared__ int s_q[64], s_m[64], s_task[64], s_done[64];
   __shared__ int s_minus[64];
-  __shared__ int s_nmax;
   const int64_t wave = blockIdx.x;
-  const int kind = blockIdx.y;
+  const int pass = blockIdx.y;
   if (wave * 64 >= flags->total_slots) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) s_nmax = 0;
-  __syncthreads();
-  const bool fill = (kind == 1 && !a.is_qs) || kind >= 4;
-  const bool squeeze = (kind == 0) || (kind == 1 && a.is_qs);
   if (tid < 64) {
     const int task = a.task_of_slot[wave * 64 + tid];
-    int n = 0, m = 0;
-    long long dst = 0;
-    int minus = 0;
+    int q = 0, m = 0, minus = 0, tk = -1;
     if (task >= 0) {
       const int64_t r = task / a.pass_num;
       if (r < a.n_reads) {
         const int64_t readnum = a.first_read + r;
-        const bool mi = a.read_minus ? (a.read_minus[r] != 0) : ((readnum & 1) == 0);
+        minus = a.read_minus ? (a.read_minus[r] != 0) : ((readnum & 1) == 0);
         m = a.maf_len[task];
-        n = (kind == 2 || kind == 3) ? m : a.out_len[task];
-        if (kind >= 4) n *= 2;
-        minus = (kind == 2 || kind == 3) && mi;
-        dst = a.row_dst[(int64_t)task * 6 + kind];
+        q = a.out_len[task];
+        tk = task;
       }
     }
-    s_n[tid] = n;
+    s_q[tid] = q;
     s_m[tid] = m;
+    s_task[tid] = tk;
     s_done[tid] = 0;
-    s_dst[tid] = dst;
     s_minus[tid] = minus;
-    const int extent = squeeze ? m : n;  // source columns to sweep
-    if (extent > 0 && n > 0) atomicMax(&s_nmax, extent);
   }
   __syncthreads();
-  const int nmax = s_nmax;
-  if (nmax == 0) return;
-  char *text = (kind == 2 || kind == 3) ? a.maf_text : a.read_text;
+  // extent of this wave's 16 tasks
+  int mmax = 0;
+  {
+    const int j = wv * 16 + (lane & 15);
+    int v = (s_task[j] >= 0) ? s_m[j] : 0;
+    if (pass == 1 && a.pass_num > 1 && 2 * s_q[j] > v && s_task[j] >= 0) v = 2 * s_q[j];
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) {
+      const int t = __shfl_xor(v, d, 64);
+      v = (t > v) ? t : v;
+    }
+    mmax = __shfl(v, 0, 64);
+  }
+  if (mmax == 0) return;
   const int cap_dw = a.wave_cap[wave];
-  // scratch regions: 0 MAF read row (0 = deleted column) | 1 MAF reference row | 2 quality per column
-  const int region_idx = (kind == 0 || kind == 3) ? 0 : (kind == 1) ? 2 : 1;
+  const int region_idx = (pass == 0) ? 0 : (pass == 1) ? 1 : 2;
   const uint32_t *region =
       reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave] + (size_t)region_idx * cap_dw * 256);
+  uint32_t *tile = s_tile + wv * 16 * kTileStride;
+  uint32_t *outb = s_out + wv * kTileStride;
+  const int lt = lane & 15, lc = lane >> 4;  // load role: task-in-wave, chunk-in-quad
 
-  for (int s0 = 0; s0 < nmax; s0 += 256) {
-    if (!fill) {
-      const int c0 = s0 >> 2;
-      for (int c = wv; c < 64; c += 4) {
-        const int cc = c0 + c;
-        s_tile[lane * kTileStride + c] = (cc < cap_dw) ? region[(size_t)cc * 64 + lane] : 0u;
-      }
-      __syncthreads();
+  for (int s0 = 0; s0 < mmax; s0 += 256) {
+    const int c0 = s0 >> 2;
+#pragma unroll 4
+    for (int c = 0; c < 64; c += 4) {
+      const int cc = c0 + c + lc;
+      tile[lt * kTileStride + c + lc] = (cc < cap_dw) ? region[(size_t)cc * 64 + wv * 16 + lt] : 0u;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     for (int i = 0; i < 16; i++) {
       const int j = wv * 16 + i;
-      const int n = s_n[j];
-      if (squeeze) {
-        // columns s0..s1 of the task -> the read bases among them, packed into s_out row j
-        const int mcols = s_m[j];
-        if (s0 >= mcols || n == 0) continue;
-        const int ncol = (mcols - s0 < 256) ? mcols - s0 : 256;
-        const uint32_t w = s_tile[j * kTileStride + lane];
-        uint32_t keep = 0;  // bit b: column lane*4+b holds a read base
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-          keep |= ((lane * 4 + b) < ncol && ((w >> (8 * b)) & 0xffu) != 0) ? (1u << b) : 0u;
-        const int cnt = __popc(keep);
-        int pre = cnt;  // inclusive wave prefix sum
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int t = __shfl_up(pre, d, 64);
-          if (lane >= d) pre += t;
+      const int task = s_task[j];
+      if (task < 0) continue;
+      const int m = s_m[j], q = s_q[j], minus = s_minus[j];
+      const int64_t *rd = a.row_dst + (int64_t)task * 6;
+      const uint32_t *trow = tile + i * kTileStride;
+      if (pass == 1) {
+        if (s0 < m) {  // MAF reference line
+          const int s1 = (m < s0 + 256) ? m : s0 + 256;
+          const long long D0 = minus ? rd[2] + (m - s1) : rd[2] + s0;
+          write_segment(a.maf_text, D0, s1 - s0, trow, minus, 0, false, 0, lane);
         }
-        const int total = __shfl(pre, 63, 64);
-        uint8_t *orow = reinterpret_cast<uint8_t *>(s_out + j * kTileStride);
-        int o = pre - cnt;
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-          if (keep & (1u << b)) orow[o++] = (uint8_t)(w >> (8 * b));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int done = s_done[j];
-        write_segment(text, s_dst[j] + done, total, s_out + j * kTileStride, 0, 0, false, done, lane);
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) s_done[j] = done + total;
-      } else {
-        if (s0 >= n) continue;
-        const int s1 = (n < s0 + 256) ? n : s0 + 256;
-        const int minus = s_minus[j];
-        const long long D0 = minus ? s_dst[j] + (n - s1) : s_dst[j] + s0;
-        write_segment(text, D0, s1 - s0, s_tile + j * kTileStride, minus, fill ? (kind == 1 ? 1 : 2) : 0, kind == 3,
-                      (int)(D0 - s_dst[j]), lane);
+        if (a.pass_num > 1 && s0 < 2 * q) {  // ",9" x len, twice (pbsim.cpp:4019-4025)
+          const int s1 = (2 * q < s0 + 256) ? 2 * q : s0 + 256;
+          write_segment(a.read_text, rd[4] + s0, s1 - s0, trow, 0, 2, false, s0, lane);
+          write_segment(a.read_text, rd[5] + s0, s1 - s0, trow, 0, 2, false, s0, lane);
+        }
+        continue;
       }
+      if (s0 >= m) continue;
+      const int ncol = (m - s0 < 256) ? m - s0 : 256;
+      if (pass == 0) {  // MAF read line: deleted columns print '-'
+        const long long D0 = minus ? rd[3] + (m - s0 - ncol) : rd[3] + s0;
+        write_segment(a.maf_text, D0, ncol, trow, minus, 0, true, 0, lane);
+      }
+      // squeeze the columns that carry a read base (non-zero byte) into the wave's out row:
+      // lane l holds columns 4l..4l+3; its output offset is the count of kept bytes in lower
+      // lanes, from four ballots + mbcnt (no cross-lane data movement)
+      const uint32_t w = trow[lane];
+      int o = 0, total = 0;
+      bool kb[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        kb[b] = (lane * 4 + b) < ncol && ((w >> (8 * b)) & 0xffu) != 0;
+        const unsigned long long mask = __ballot(kb[b]);
+        o += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        total += __popcll(mask);
+      }
+      uint8_t *orow = reinterpret_cast<uint8_t *>(outb);
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        if (kb[b]) orow[o++] = (uint8_t)(w >> (8 * b));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int dn = s_done[j];
+      const int kind = (pass == 0) ? 0 : 1;
+      write_segment(a.read_text, rd[kind] + dn, total, outb, 0, 0, false, 0, lane);
+      if (pass == 0 && !a.is_qs)  // ERRHMM quality is all '!' (pbsim.cpp:4007-4010)
+        write_segment(a.read_text, rd[1] + dn, total, outb, 0, 1, false, 0, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) s_done[j] = dn + total;
     }
-    if (!fill) __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1431,8 +1452,7 @@ void launch_text_emit(const TextArgs &a, int64_t n_slots_max, const DeviceFlags 
   const int64_t n_tasks = a.n_reads * a.pass_num;
   if (n_tasks <= 0) return;
   hipLaunchKernelGGL(k_text_headers, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_text_rows, dim3((unsigned)(n_slots_max / 64), a.pass_num == 1 ? 4 : 6), dim3(256), 0, s, a,
-                     flags);
+  hipLaunchKernelGGL(k_text_rows, dim3((unsigned)(n_slots_max / 64), a.is_qs ? 3 : 2), dim3(256), 0, s, a, flags);
 }
 
 }  // namespace pbsim
