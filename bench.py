@@ -104,9 +104,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # PBSIM_BENCH_BACKEND=gloo + PBSIM_BENCH_ONE_GPU=1: plumbing check of the N>1 path on a 1-GPU box
+        backend = os.environ.get("PBSIM_BENCH_BACKEND", "nccl")
+        if os.environ.get("PBSIM_BENCH_ONE_GPU") == "1":
+            local = 0
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")  # where collectives run
 
     # ---- inputs resident in HBM: genome record (rank 0 generates, RCCL broadcasts) ----
     G = a.record_len
@@ -121,7 +129,12 @@ def main():
     else:
         genome = torch.empty(G, dtype=torch.uint8, device=dev)
     if world > 1:
-        dist.broadcast(genome, src=0)          # C1: reference broadcast over xGMI
+        if cdev == dev:
+            dist.broadcast(genome, src=0)      # C1: reference broadcast over xGMI (RCCL)
+        else:
+            g = genome.cpu()
+            dist.broadcast(g, src=0)
+            genome = g.to(dev)
     torch.cuda.synchronize()
 
     qs = a.workload == "qshmm10"
@@ -153,11 +166,12 @@ def main():
         pass0 = ctx.batch_walk_end()
         before = 0
         if world > 1:
-            mine = torch.tensor([pass0], dtype=torch.int64, device=dev)
+            mine = torch.tensor([pass0], dtype=torch.int64, device=cdev)
             allv = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allv, mine)        # C3: quota prefix across ranks
             before = int(sum(int(v.item()) for v in allv[:rank]))
-        # bench batches are far below the record's quota, so none is cut
+        # weak-scaling bench: every rank walks a full batch per step, so the prefix is folded to
+        # keep each batch below the record's quota (the quota cut itself is covered by the tests)
         return ctx.batch_finalize(before % max(1, quota // 4))
 
     def run(first_step, n_steps):
@@ -191,8 +205,8 @@ def main():
     dt = time.perf_counter() - t0
     walk_ms, launches, total_ms = ctx.prof_get()
 
-    tot = torch.tensor([bases, reads, ref_b, maf_c, text_b], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([bases, reads, ref_b, maf_c, text_b], dtype=torch.int64, device=cdev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tot)                   # C2: counters reduced across ranks
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

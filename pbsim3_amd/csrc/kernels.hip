@@ -547,9 +547,10 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   int ro = 0, q = 0, m = 0;
   uint32_t state = 0, tran_rv = 1;
   uint32_t acc_r = 0, acc_f = 0;
-  int nsub = 0, nins = 0, ndel = 0;
+  int nsub = 0;
   bool act = valid && L > 0;
   int group = 0;
+  const WalkLane plane = walk_lane(a.seed, read_idx, pass, 0u);
 
   // Reference window: the 8 bases under the cursor plus the next 8 in walking
   // direction, fetched ahead so a lone long read never waits on HBM; wider loads
@@ -588,7 +589,8 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     U4 W[4];
     if (mode != kModeVerbatim) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) W[j] = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 0u);
+      for (int j = 0; j < 4; j++)
+        W[j] = walk_block_fast(plane, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j));
     } else {
 #pragma unroll
       for (int j = 0; j < 4; j++) W[j] = U4{0, 0, 0, 0};
@@ -629,8 +631,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
           mod = mod ? mod : 1u;
           idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 1000u) + w.x % mod;
         }
-        const uint32_t st = lds[idx];
-        state = act ? st : state;
+        state = lds[idx];  // a finished lane keeps walking harmlessly: nothing it computes is stored
         const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + state * 32u);
         tran_rv = row[0];
         const uint32_t emis_rv = row[1], e0 = row[2], e1 = row[3];
@@ -665,13 +666,10 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
       const uint32_t b = (e == 1) ? subb : (e == 2) ? insb : nt;
       const uint32_t mr = (e == 3) ? 0u : b;  // 0 marks a deleted column; the text kernel prints '-' there
       const uint32_t mf = (e == 2) ? (uint32_t)'-' : nt;
-      acc_r |= act ? (mr << (8 * j)) : 0u;
-      acc_f |= act ? (mf << (8 * j)) : 0u;
-      const bool has = act && (e != 3);
-      q += has ? 1 : 0;
+      acc_r |= mr << (8 * j);  // columns past the lane's last one are never read back (maf_len bounds them)
+      acc_f |= mf << (8 * j);
+      q += (act && e != 3) ? 1 : 0;
       nsub += (act && e == 1) ? 1 : 0;
-      nins += (act && e == 2) ? 1 : 0;
-      ndel += (act && e == 3) ? 1 : 0;
       ro += (act && e != 2) ? 1 : 0;
       m += act ? 1 : 0;
       act = act && (ro < L) && (m < cap);
@@ -700,8 +698,8 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     a.out_len[task] = q;
     a.maf_len[task] = m;
     a.nsub[task] = nsub;
-    a.nins[task] = nins;
-    a.ndel[task] = ndel;
+    a.nins[task] = m - ro;  // every column consumes a reference base except insertions
+    a.ndel[task] = m - q;   // every column emits a read base except deletions
   }
 }
 

@@ -47,6 +47,56 @@ PB_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
   return U4{c0, c1, c2, c3};
 }
 
+// ---- the walk kernels' form of the same block -------------------------------
+// For the walk stream the counter is (event, pass<<4|sub, read, unit): only
+// `event` changes from step to step and it is wave-uniform.  Round 1 multiplies
+// M1*read (constant per lane) and M0*event (uniform -> scalar unit); round 2
+// multiplies M0*n0 (constant per lane) and M1*n2 (uniform).  So the first two of
+// the ten rounds cost two vector XORs per block instead of four 32x32->64
+// multiplies: WalkLane holds the per-lane constants, walk_block_fast() finishes.
+struct WalkLane {
+  uint32_t n1;       // lo(M1*read)
+  uint32_t b_hi;     // hi(M0*n0)
+  uint32_t b_lo;     // lo(M0*n0)
+};
+
+PB_HD WalkLane walk_lane(uint32_t seed, uint32_t read, uint32_t pass, uint32_t sub) {
+  const uint64_t a = (uint64_t)kPhiloxM1 * read;
+  const uint32_t n0 = (uint32_t)(a >> 32) ^ ((pass << 4) | sub) ^ seed;
+  const uint64_t b = (uint64_t)kPhiloxM0 * n0;
+  return WalkLane{(uint32_t)a, (uint32_t)(b >> 32), (uint32_t)b};
+}
+
+// `event` and `unit` must be wave-uniform for the scalar part to stay on the scalar unit
+PB_HD U4 walk_block_fast(const WalkLane &l, uint32_t seed, uint32_t unit, uint32_t event) {
+  // round 1, uniform half: (n2, n3) from M0*event
+  const uint64_t p = (uint64_t)kPhiloxM0 * event;
+  const uint32_t n2 = (uint32_t)(p >> 32) ^ unit ^ kStreamWalk;
+  const uint32_t n3 = (uint32_t)p;
+  // round 2 (keys bumped once)
+  const uint32_t k0 = seed + kPhiloxW0, k1 = kStreamWalk + kPhiloxW1;
+  const uint64_t q = (uint64_t)kPhiloxM1 * n2;
+  uint32_t c0 = ((uint32_t)(q >> 32) ^ k0) ^ l.n1;
+  uint32_t c1 = (uint32_t)q;
+  uint32_t c2 = (n3 ^ k1) ^ l.b_hi;
+  uint32_t c3 = l.b_lo;
+  uint32_t ka = seed + 2u * kPhiloxW0, kb = kStreamWalk + 2u * kPhiloxW1;
+#pragma unroll
+  for (int r = 2; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
+    const uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
+    const uint32_t m0 = (uint32_t)(p1 >> 32) ^ c1 ^ ka;
+    const uint32_t m2 = (uint32_t)(p0 >> 32) ^ c3 ^ kb;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = m0;
+    c2 = m2;
+    ka += kPhiloxW0;
+    kb += kPhiloxW1;
+  }
+  return U4{c0 >> 1, c1 >> 1, c2 >> 1, c3 >> 1};
+}
+
 // walk-stream block of one HMM event; words are already shifted to 31 bits
 PB_HD U4 walk_block(uint32_t seed, uint32_t unit, uint32_t read, uint32_t pass, uint32_t event, uint32_t sub) {
   U4 r = philox4x32_10(event, (pass << 4) | sub, read, unit, seed, kStreamWalk);

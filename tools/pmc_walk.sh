@@ -10,10 +10,13 @@ python3 - $out <<'PY'
 import csv,glob,collections,sys,json
 out=sys.argv[1]
 agg=collections.defaultdict(float)
+disp=collections.defaultdict(set)
 for f in glob.glob(out+"/p*/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
         if "k_walk" in r["Kernel_Name"]:
             agg[r["Counter_Name"]]+=float(r["Counter_Value"])
+            disp[r["Counter_Name"]].add(r["Dispatch_Id"])
+for k in agg: agg[k]/=max(1,len(disp[k]))   # average per launch
 d=json.loads([l for l in open(out+"/bench1.log") if l.startswith("{")][-1])
 steps=d["config"]["bases_per_step"]*1.062/64
 print("wave-steps %.3g" % steps)
