@@ -646,7 +646,8 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
     w.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
     w.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     w.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
-    launch_walk_qshmm(w, slots_max, c->qct.stride + 96 * 8 + 94 * 48 + 94 * 8, c->s().stream);
+    launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8, c->qct.all_rv_100,
+                      c->p.hp_del_bias == 1, c->s().stream);
   }
   HIP_OK(hipEventRecord(c->s().ev2, c->s().stream));
   launch_gather_pass0_scan(w.out_len, n_reads, P, c->s().d_cum.as<int64_t>(), c->s().d_scan_tmp.as<int64_t>(),

@@ -495,6 +495,7 @@ bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias
   const int ncls = h.acc_hi - h.acc_lo + 1;
   t->blob.assign((size_t)ncls * t->stride, 0);
   long end_wk = 0;  // shared like pbsim.cpp:1974
+  t->all_rv_100 = true;
   for (int a = h.acc_lo; a <= h.acc_hi; a++) {
     uint8_t *dst = t->blob.data() + (size_t)(a - h.acc_lo) * t->stride;
     uint32_t *hdr = reinterpret_cast<uint32_t *>(dst);
@@ -526,9 +527,18 @@ bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias
             &end_wk);
         tran_rv[j] = end_wk;
       }
+      if (hdr[1] != 100) t->all_rv_100 = false;
+      // states that can be visited: named by an IP entry or a TP column of this class
+      std::vector<char> reach(kStateMax + 1, 0);
+      for (int j = 1; j <= kStateMax; j++) {
+        if (m.ip[a][j] != 0) reach[j] = 1;
+        for (int k = 1; k <= kStateMax; k++)
+          if (m.tp[a][j][k] != 0) reach[k] = 1;
+      }
       for (int j = 1; j <= smax; j++) {
         rv[2 * j] = (uint16_t)tran_rv[j];
         rv[2 * j + 1] = (uint16_t)emis_rv[j];
+        if (reach[j] && (tran_rv[j] != 100 || emis_rv[j] != 100)) t->all_rv_100 = false;
       }
     } else {
       hdr[2] = 0;

@@ -95,6 +95,7 @@ bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBi
 struct QsClassTables {
   int acc_lo = 0, acc_hi = 0, smax = 0;
   uint32_t rv_off = 64, init_off = 0, tran_off = 0, emis_off = 0, freq_off = 0, stride = 0;
+  bool all_rv_100 = false;  // every init/transition/emission modulus of a reachable state is 100
   std::vector<uint8_t> blob;
   uint32_t sub_thre[kQcNum], ins_thre[kQcNum];
   uint32_t del_thr[kQcNum][kHpSlots];  // ceil(del_thre[q]*bias[hp]): x < d*b  <=>  x < ceil(d*b)

@@ -463,6 +463,113 @@ __device__ __forceinline__ void walk_priority(int lmax_wave, int mean_len) {
 }
 
 // ---------------------------------------------------------------------------
+// Per-lane reference window shared by the walk kernels: the 8 bases under the
+// cursor plus the next 8 in walking direction, fetched a group ahead so a lone
+// long read never waits on HBM.  8-byte loads because every L2->fabric request
+// moves a 64-byte sector whatever the load width (dword loads cost 16x their
+// bytes and starved the kernel).  The homopolymer window is either the hp byte
+// array (same shape) or, with kHpBits (default --hp-del-bias 1: the thresholds
+// depend on hp only through hp == 11, Q1), 32 bases of the hp==11 bit mask.
+// A cursor moves by at most 4 bases per 4-column group, hence crosses at most
+// one window boundary per group; refill() runs once per group.
+// ---------------------------------------------------------------------------
+template <bool kHpBits>
+struct RefCursor {
+  const uint64_t *lane_seq, *lane_hp;
+  const uint32_t *lane_bits;
+  int64_t p_first;
+  uint32_t pl0, cur_wl, cur_bl;
+  int wstep, rel, brel;
+  uint64_t wseq, whp, nseq, nhp;
+  uint32_t wbits, nbits;
+  bool minus, need_next, need_nbits;
+
+  __device__ __forceinline__ void init(const WalkArgs &a, int64_t off, int L, bool minus_, bool act) {
+    minus = minus_;
+    p_first = minus ? (off + L - 1) : off;
+    pl0 = (uint32_t)p_first;  // low bits are all the cursor arithmetic needs
+    wstep = minus ? -1 : 1;
+    lane_seq = reinterpret_cast<const uint64_t *>(a.ref.seq) + (p_first >> 3);
+    lane_hp = reinterpret_cast<const uint64_t *>(a.ref.hp) + (p_first >> 3);
+    lane_bits = reinterpret_cast<const uint32_t *>(a.hp11) + (p_first >> 5);
+    rel = brel = 0;
+    cur_wl = pl0 >> 3;
+    cur_bl = pl0 >> 5;
+    wseq = whp = nseq = nhp = 0;
+    wbits = nbits = 0;
+    need_next = need_nbits = false;
+    if (act) {
+      wseq = lane_seq[0];
+      const int nrel = ((p_first >> 3) + wstep < 0) ? 0 : wstep;
+      nseq = lane_seq[nrel];
+      if (kHpBits) {
+        wbits = lane_bits[0];
+        const int nb = ((p_first >> 5) + wstep < 0) ? 0 : wstep;
+        nbits = lane_bits[nb];
+      } else {
+        whp = lane_hp[0];
+        nhp = lane_hp[nrel];
+      }
+    }
+  }
+
+  // raw reference byte (forward strand, not complemented) and homopolymer class at read offset ro
+  __device__ __forceinline__ void at(int ro, bool act, uint32_t *raw, uint32_t *hp) {
+    const uint32_t pl = minus ? (pl0 - (uint32_t)ro) : (pl0 + (uint32_t)ro);
+    const bool cross = act && ((pl >> 3) != cur_wl);
+    wseq = cross ? nseq : wseq;
+    cur_wl = cross ? (pl >> 3) : cur_wl;
+    rel += cross ? wstep : 0;
+    need_next = need_next || cross;
+    const uint32_t sh = (pl & 7u) * 8u;
+    *raw = (uint32_t)(wseq >> sh) & 0xffu;
+    if (kHpBits) {
+      const bool bcross = act && ((pl >> 5) != cur_bl);
+      wbits = bcross ? nbits : wbits;
+      cur_bl = bcross ? (pl >> 5) : cur_bl;
+      brel += bcross ? wstep : 0;
+      need_nbits = need_nbits || bcross;
+      *hp = ((wbits >> (pl & 31u)) & 1u) ? 11u : 1u;
+    } else {
+      whp = cross ? nhp : whp;
+      *hp = (uint32_t)(whp >> sh) & 0xffu;
+    }
+  }
+
+  __device__ __forceinline__ void refill(bool act) {
+    if (need_next && act) {
+      const int nrel = ((p_first >> 3) + rel + wstep < 0) ? rel : rel + wstep;
+      nseq = lane_seq[nrel];
+      if (!kHpBits) nhp = lane_hp[nrel];
+      need_next = false;
+    }
+    if (kHpBits && need_nbits && act) {
+      const int nb = ((p_first >> 5) + brel + wstep < 0) ? brel : brel + wstep;
+      nbits = lane_bits[nb];
+      need_nbits = false;
+    }
+  }
+};
+
+// stages the accuracy class blob of this workgroup and the two byte LUTs behind it:
+// s_comp[0..255] identity, [256..511] revcomp's base map; s_sub[c*4+k] = substitution k
+// of base c (pbsim.cpp:5481-5484), 0 for a non-ACGT base
+__device__ __forceinline__ void stage_class(const WalkArgs &a, int cls, uint8_t *lds, uint8_t *s_comp, uint8_t *s_sub,
+                                            int tid) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(a.cls_blob + (size_t)cls * a.stride);
+  uint4 *dst = reinterpret_cast<uint4 *>(lds);
+  for (uint32_t i = tid; i < a.stride / 16; i += kWG) dst[i] = src[i];
+  const uint32_t c = (uint32_t)tid;
+  s_comp[c] = (uint8_t)c;
+  s_comp[256 + c] = (uint8_t)complement(c);
+  const uint32_t t = sub_table(c);
+  s_sub[c * 4 + 0] = (uint8_t)(t & 0xffu);
+  s_sub[c * 4 + 1] = (uint8_t)((t >> 8) & 0xffu);
+  s_sub[c * 4 + 2] = (uint8_t)((t >> 16) & 0xffu);
+  s_sub[c * 4 + 3] = 0;
+}
+
+// ---------------------------------------------------------------------------
 // K2e: ERRHMM walk.  One lane per task (read, pass); the 4 waves of a workgroup
 // share one accuracy class whose tables were staged in LDS.
 //
@@ -497,25 +604,9 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   if (a.flags->error & kErrScratchBudget) return;  // the pool cannot hold this batch: the host retries smaller
   int cls = 0;
   while (cls < a.ncls - 1 && slot0 >= a.class_start[cls + 1]) cls++;
-  {
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.cls_blob + (size_t)cls * a.stride);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (uint32_t i = tid; i < a.stride / 16; i += kWG) dst[i] = src[i];
-  }
-  // byte LUTs behind the class blob: s_comp[0..255] identity, [256..511] revcomp's
-  // base map; s_sub[c*4+k] = substitution k of base c (pbsim.cpp:5481-5484), 0 for non-ACGT
   uint8_t *s_comp = lds + a.stride;
   uint8_t *s_sub = s_comp + 512;
-  {
-    const uint32_t c = (uint32_t)tid;
-    s_comp[c] = (uint8_t)c;
-    s_comp[256 + c] = (uint8_t)complement(c);
-    const uint32_t t = sub_table(c);
-    s_sub[c * 4 + 0] = (uint8_t)(t & 0xffu);
-    s_sub[c * 4 + 1] = (uint8_t)((t >> 8) & 0xffu);
-    s_sub[c * 4 + 2] = (uint8_t)((t >> 16) & 0xffu);
-    s_sub[c * 4 + 3] = 0;
-  }
+  stage_class(a, cls, lds, s_comp, s_sub, tid);
   __syncthreads();
   const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
   const uint32_t init_rv = hdr[1], mode = hdr[2], rate_mag = hdr[3];
@@ -552,36 +643,9 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   int group = 0;
   const WalkLane plane = walk_lane(a.seed, read_idx, pass, 0u);
 
-  // Reference window: the 8 bases under the cursor plus the next 8 in walking
-  // direction, fetched ahead so a lone long read never waits on HBM; wider loads
-  // than the 1 byte a step consumes keep the L2->fabric request count down (each
-  // request moves a 64-byte sector whatever the load width).  The hp window is
-  // either the byte array (same shape) or, with kHpBits, 32 bases of the hp==11 mask.
-  const int64_t p_first = minus ? (off + L - 1) : off;
-  const uint32_t pl0 = (uint32_t)p_first;  // low bits are all the cursor arithmetic needs
-  const int wstep = minus ? -1 : 1;
   const uint32_t comp_off = minus ? 256u : 0u;
-  const uint64_t *lane_seq = reinterpret_cast<const uint64_t *>(a.ref.seq) + (p_first >> 3);
-  const uint64_t *lane_hp = reinterpret_cast<const uint64_t *>(a.ref.hp) + (p_first >> 3);
-  const uint32_t *lane_bits = reinterpret_cast<const uint32_t *>(a.hp11) + (p_first >> 5);
-  int rel = 0, brel = 0;  // current qword / mask dword, relative to the lane's first one
-  uint32_t cur_wl = pl0 >> 3, cur_bl = pl0 >> 5;
-  uint64_t wseq = 0, whp = 0, nseq = 0, nhp = 0;
-  uint32_t wbits = 0, nbits = 0;
-  bool need_next = false, need_nbits = false;
-  if (act) {
-    wseq = lane_seq[0];
-    const int nrel = ((p_first >> 3) + wstep < 0) ? 0 : wstep;
-    nseq = lane_seq[nrel];
-    if (kHpBits) {
-      wbits = lane_bits[0];
-      const int nb = ((p_first >> 5) + wstep < 0) ? 0 : wstep;
-      nbits = lane_bits[nb];
-    } else {
-      whp = lane_hp[0];
-      nhp = lane_hp[nrel];
-    }
-  }
+  RefCursor<kHpBits> cur;
+  cur.init(a, off, L, minus, act);
 
   while (__any(act)) {
     // One Philox block per MAF column; the four columns of this group are
@@ -599,26 +663,9 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     for (int j = 0; j < 4; j++) {
       const U4 w = W[j];
       // ---- reference base under the cursor
-      const uint32_t pl = minus ? (pl0 - (uint32_t)ro) : (pl0 + (uint32_t)ro);
-      const bool cross = act && ((pl >> 3) != cur_wl);  // at most one window boundary per group
-      wseq = cross ? nseq : wseq;
-      cur_wl = cross ? (pl >> 3) : cur_wl;
-      rel += cross ? wstep : 0;
-      need_next = need_next || cross;
-      const uint32_t sh = (pl & 7u) * 8u;
-      const uint32_t nt = s_comp[((uint32_t)(wseq >> sh) & 0xffu) + comp_off];
-      uint32_t hp;
-      if (kHpBits) {
-        const bool bcross = act && ((pl >> 5) != cur_bl);
-        wbits = bcross ? nbits : wbits;
-        cur_bl = bcross ? (pl >> 5) : cur_bl;
-        brel += bcross ? wstep : 0;
-        need_nbits = need_nbits || bcross;
-        hp = ((wbits >> (pl & 31u)) & 1u) ? 11u : 1u;
-      } else {
-        whp = cross ? nhp : whp;
-        hp = (uint32_t)(whp >> sh) & 0xffu;
-      }
+      uint32_t raw, hp;
+      cur.at(ro, act, &raw, &hp);
+      const uint32_t nt = s_comp[raw + comp_off];
 
       // ---- state, deletion test, emission class
       uint32_t e = 0;
@@ -678,17 +725,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
       maf_read[(size_t)group * 64] = acc_r;
       maf_ref[(size_t)group * 64] = acc_f;
     }
-    if (need_next && act) {  // refill the look-ahead window; consumed at the next boundary
-      const int nrel = ((p_first >> 3) + rel + wstep < 0) ? rel : rel + wstep;
-      nseq = lane_seq[nrel];
-      if (!kHpBits) nhp = lane_hp[nrel];
-      need_next = false;
-    }
-    if (kHpBits && need_nbits && act) {
-      const int nb = ((p_first >> 5) + brel + wstep < 0) ? brel : brel + wstep;
-      nbits = lane_bits[nb];
-      need_nbits = false;
-    }
+    cur.refill(act);
     acc_r = 0;
     acc_f = 0;
     group++;
@@ -710,6 +747,8 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
 // emits a base from sub-block 0: w.x state | w.y quality | w.z error class |
 // w.w nucleotide; sub-block 1 w.x = non-ACGT substitution.
 // ---------------------------------------------------------------------------
+// kFastRv: every init / transition / emission modulus of the class is 100.
+template <bool kFastRv, bool kHpBits>
 __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -718,18 +757,16 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   if (a.flags->error & kErrScratchBudget) return;  // the pool cannot hold this batch: the host retries smaller
   int cls = 0;
   while (cls < a.ncls - 1 && slot0 >= a.class_start[cls + 1]) cls++;
-  // LDS: [class blob | sub_thre 94 u32 | ins_thre 94 u32 | del_thr 94*12 u32 | qprob 94 f64]
-  {
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.cls_blob + (size_t)cls * a.stride);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (uint32_t i = tid; i < a.stride / 16; i += kWG) dst[i] = src[i];
-  }
-  uint32_t *s_sub = reinterpret_cast<uint32_t *>(lds + a.stride);
-  uint32_t *s_ins = s_sub + 96;
+  // LDS: [class blob | s_comp 512 | s_sub 1024 | sub_thre 96 u32 | ins_thre 96 u32 | del_thr 94*12 u32 | qprob 94 f64]
+  uint8_t *s_comp = lds + a.stride;
+  uint8_t *s_sub = s_comp + 512;
+  stage_class(a, cls, lds, s_comp, s_sub, tid);
+  uint32_t *s_subt = reinterpret_cast<uint32_t *>(s_sub + 1024);
+  uint32_t *s_ins = s_subt + 96;
   uint32_t *s_del = s_ins + 96;
   double *s_qprob = reinterpret_cast<double *>(s_del + 94 * 12);
   for (int i = tid; i < 94; i += kWG) {
-    s_sub[i] = a.sub_thre[i];
+    s_subt[i] = a.sub_thre[i];
     s_ins[i] = a.ins_thre[i];
     s_qprob[i] = a.qprob[i];
   }
@@ -765,107 +802,104 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   const int cap = 2 * L + kScratchPad;
 
   int ro = 0, q = 0, m = 0;
-  uint32_t state = 0, last_q = 0;
+  uint32_t state = 0, last_q = 0, hp_prev = 0;  // hp of the last consumed reference base; none yet -> slot 0 (Q15)
   uint32_t acc_r = 0, acc_f = 0, acc_q = 0;
-  int nsub = 0, nins = 0, ndel = 0;
+  int nsub = 0;
   double qsum = 0.0;
-  bool active = valid && L > 0;
+  bool act = valid && L > 0;
   int group = 0;
+  const uint32_t comp_off = minus ? 256u : 0u;
+  RefCursor<kHpBits> cur;
+  cur.init(a, off, L, minus, act);
+  const WalkLane lane_e = walk_lane(a.seed, read_idx, pass, 0u);  // emission blocks
+  const WalkLane lane_d = walk_lane(a.seed, read_idx, pass, 2u);  // deletion-test blocks
 
-  while (__any(active)) {
+  while (__any(act)) {
+    U4 E[4], D[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      if (active) {
-        const int64_t p = minus ? (off + L - 1 - ro) : (off + ro);
-        uint32_t nt = a.ref.seq[p];
-        if (minus) nt = complement(nt);
-        bool deleted = false;
-        if (m > 0) {
-          // hp of the previously consumed reference base; none yet -> slot 0 (Q15)
-          uint32_t hp = 0;
-          if (ro > 0) hp = a.ref.hp[minus ? (p + 1) : (p - 1)];
-          const U4 d = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 2u);
-          deleted = (d.x % 1000000u) < s_del[last_q * 12u + (hp < 12u ? hp : 11u)];
-        }
-        uint32_t mr, mf;
-        if (deleted) {  // pbsim.cpp:2272-2277
-          mr = 0;  // deleted column marker
-          mf = nt;
-          ro++;
-          ndel++;
+      const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j);
+      E[j] = walk_block_fast(lane_e, a.seed, a.unit, ev);
+      D[j] = walk_block_fast(lane_d, a.seed, a.unit, ev);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const U4 w = E[j];
+      uint32_t raw, hp;
+      cur.at(ro, act, &raw, &hp);
+      const uint32_t nt = s_comp[raw + comp_off];
+      // every column m >= 1 first takes the deletion test of the inner while (pbsim.cpp:2268-2281)
+      const bool deleted = (m > 0) && (D[j].x % 1000000u) < s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)];
+      // ---- emission (computed for every lane, used where the column is not deleted)
+      uint32_t qv, st = state;
+      if (has_model) {
+        uint32_t idx;
+        if (kFastRv) {
+          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 100u) + w.x % 100u;
         } else {
-          const U4 w = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 0u);
-          uint32_t qv;
-          if (has_model) {
-            uint32_t mod, base;
-            if (q == 0) {
-              mod = init_rv;
-              base = a.init_off;
-            } else {
-              mod = rvs[2 * state];
-              base = a.tran_off + (state - 1u) * 100u;
-            }
-            mod = mod ? mod : 1u;
-            state = lds[base + w.x % mod];
-            uint32_t emod = rvs[2 * state + 1];
-            emod = emod ? emod : 1u;
-            qv = lds[a.emis_off + (state - 1u) * 100u + w.y % emod];
-          } else {
-            qv = lds[a.freq_off + w.y % (freq_rv ? freq_rv : 1u)];
-          }
-          last_q = qv;
-          qsum += s_qprob[qv];
-          const uint32_t x = w.z % 1000000u;
-          uint32_t b = nt;
-          mf = nt;
-          if (x < s_sub[qv]) {  // pbsim.cpp:2233-2249
-            const bool acgt = (nt == 'A') | (nt == 'C') | (nt == 'G') | (nt == 'T');
-            if (acgt) {
-              b = (sub_table(nt) >> ((w.w % 3u) * 8u)) & 0xffu;
-            } else {
-              const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)m, 1u);
-              b = (kATGC >> ((v.x & 3u) * 8u)) & 0xffu;
-            }
-            nsub++;
-            ro++;
-          } else if (x < s_ins[qv]) {  // pbsim.cpp:2250-2258
-            const uint32_t k = w.w & 7u;
-            b = (k >= 4u) ? nt : ((kATGC >> (k * 8u)) & 0xffu);
-            mf = '-';
-            nins++;
-          } else {
-            ro++;
-          }
-          mr = b;
-          acc_q |= (qv + 33u) << (8 * j);
-          q++;
+          uint32_t mod = (q == 0) ? init_rv : rvs[2 * state];
+          mod = mod ? mod : 1u;
+          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 100u) + w.x % mod;
         }
-        acc_r |= mr << (8 * j);
-        acc_f |= mf << (8 * j);
-        m++;
-        if (m >= cap) {
-          atomicOr(&a.flags->error, kErrScratchOverflow);
-          ro = L;
+        st = lds[idx];
+        uint32_t eidx;
+        if (kFastRv) {
+          eidx = a.emis_off + (st - 1u) * 100u + w.y % 100u;
+        } else {
+          uint32_t emod = rvs[2 * st + 1];
+          emod = emod ? emod : 1u;
+          eidx = a.emis_off + (st - 1u) * 100u + w.y % emod;
         }
-        active = ro < L;
+        qv = lds[eidx];
+      } else {
+        qv = lds[a.freq_off + w.y % (freq_rv ? freq_rv : 1u)];
       }
+      qv = (qv < 94u) ? qv : 93u;
+      const bool emit = act && !deleted;
+      state = emit ? st : state;
+      last_q = emit ? qv : last_q;
+      qsum += emit ? s_qprob[qv] : 0.0;  // ordered double sum (pbsim.cpp:2309-2313); + 0.0 leaves it unchanged
+      const uint32_t x = w.z % 1000000u;
+      const bool is_sub = x < s_subt[qv];             // pbsim.cpp:2233-2249
+      const bool is_ins = !is_sub && x < s_ins[qv];   // pbsim.cpp:2250-2258
+      uint32_t subb = s_sub[nt * 4u + w.w % 3u];
+      if (emit && is_sub && subb == 0) {  // non-ACGT reference base: one more draw (rare)
+        const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 1u);
+        subb = (kATGC >> ((v.x & 3u) * 8u)) & 0xffu;
+      }
+      const uint32_t insb = (w.w & 4u) ? nt : ((kATGC >> ((w.w & 3u) * 8u)) & 0xffu);
+      const uint32_t b = is_sub ? subb : is_ins ? insb : nt;
+      const uint32_t mr = deleted ? 0u : b;                      // 0 marks a deleted column
+      const uint32_t mf = (!deleted && is_ins) ? (uint32_t)'-' : nt;
+      acc_r |= mr << (8 * j);
+      acc_f |= mf << (8 * j);
+      acc_q |= (deleted ? 0u : (qv + 33u)) << (8 * j);
+      const bool consumed = act && (deleted || !is_ins);
+      hp_prev = consumed ? hp : hp_prev;
+      q += emit ? 1 : 0;
+      nsub += (emit && is_sub) ? 1 : 0;
+      ro += consumed ? 1 : 0;
+      m += act ? 1 : 0;
+      act = act && (ro < L) && (m < cap);
     }
     if (valid && m > group * 4) {
       maf_read[(size_t)group * 64] = acc_r;
       maf_ref[(size_t)group * 64] = acc_f;
       qual_row[(size_t)group * 64] = acc_q;
     }
+    cur.refill(act);
     acc_r = 0;
     acc_f = 0;
     acc_q = 0;
     group++;
   }
   if (valid) {
+    if (ro < L) atomicOr(&a.flags->error, kErrScratchOverflow);
     a.out_len[task] = q;
     a.maf_len[task] = m;
     a.nsub[task] = nsub;
-    a.nins[task] = nins;
-    a.ndel[task] = ndel;
+    a.nins[task] = m - ro;
+    a.ndel[task] = m - q;
     a.qsum[task] = qsum;
   }
 }
@@ -1408,8 +1442,13 @@ void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byt
   else hipLaunchKernelGGL((k_walk_errhmm<false, false>), grid, block, lds_bytes, s, a);
 }
 
-void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_qshmm, dim3((unsigned)(n_slots_max / kWG)), dim3(kWG), lds_bytes, s, a);
+void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
+                       hipStream_t s) {
+  const dim3 grid((unsigned)(n_slots_max / kWG)), block(kWG);
+  if (fast_rv && hp_bits) hipLaunchKernelGGL((k_walk_qshmm<true, true>), grid, block, lds_bytes, s, a);
+  else if (fast_rv) hipLaunchKernelGGL((k_walk_qshmm<true, false>), grid, block, lds_bytes, s, a);
+  else if (hp_bits) hipLaunchKernelGGL((k_walk_qshmm<false, true>), grid, block, lds_bytes, s, a);
+  else hipLaunchKernelGGL((k_walk_qshmm<false, false>), grid, block, lds_bytes, s, a);
 }
 
 void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total,
