@@ -1,0 +1,123 @@
+"""Edge cases and size-independent properties on the GPU.
+
+Edge cases run the product and the oracle (keyed-Philox mode) on the same seeded
+inputs and compare bytes.  The large run is checked through properties that hold
+at any size (the oracle would take minutes there): every MAF record is
+self-consistent with its FASTQ record and with the genome."""
+import os
+
+import numpy as np
+import pytest
+
+import harness
+import product
+
+pytestmark = pytest.mark.gpu
+ONT = ["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-ONT.model"]
+QS = ["--strategy", "wgs", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model"]
+
+
+def _write_fasta(path, recs):
+    with open(path, "w") as f:
+        for i, s in enumerate(recs, 1):
+            f.write(f">r{i}\n")
+            for k in range(0, len(s), 60):
+                f.write(s[k:k + 60] + "\n")
+
+
+def _rand_seq(rng, n, alphabet="ACGT"):
+    return "".join(np.array(list(alphabet))[rng.integers(0, len(alphabet), n)])
+
+
+def _compare(args, tmp_path, scratch_mb=None):
+    outs, _ = product.run_wgs(harness.resolve(args), scratch_mb=scratch_mb)
+    want = harness.run_oracle(args, "philox", str(tmp_path))
+    for k, v in outs.items():
+        assert v == want[k], (k, len(v), len(want[k]))
+
+
+EDGE = {
+    # reads longer than the record: L >= genome.len -> offset 0, L = genome.len (pbsim.cpp:3804-3806)
+    "reads_longer_than_genome": (lambda rng: [_rand_seq(rng, 150), _rand_seq(rng, 100)],
+                                 ONT + ["--depth", "30", "--seed", "11"]),
+    # short reads down to --length-min 30 (much shorter ones make the reference index freq_accuracy[] with a negative
+    # accuracy, pbsim.cpp:4004-4005: memory corruption there, skipped here); quota truncation floors at len_min (pbsim.cpp:3797-3799)
+    "len_min_30": (lambda rng: [_rand_seq(rng, 3000)],
+                  ONT + ["--depth", "4", "--seed", "12", "--length-min", "30", "--length-mean", "60", "--length-sd", "30"]),
+    # depth below one read: the first read is already truncated
+    "quota_below_one_read": (lambda rng: [_rand_seq(rng, 20000)], ONT + ["--depth", "0.05", "--seed", "13"]),
+    # a genome of homopolymers only (hp 10/11 oscillation everywhere, Q1) and N runs
+    "homopolymers": (lambda rng: ["".join(c * n for c, n in zip("ACGTN" * 40, rng.integers(1, 30, 200)))],
+                     ONT + ["--depth", "20", "--seed", "14", "--length-mean", "300", "--length-sd", "200"]),
+    # IUPAC soup: non-ACGT substitution branch on nearly every substitution (pbsim.cpp:3947-3949)
+    "iupac": (lambda rng: [_rand_seq(rng, 5000, "ACGTRYKMSWN")],
+              ONT + ["--depth", "10", "--seed", "15", "--length-mean", "500", "--length-sd", "300"]),
+    # long id prefix and many tiny reads: MAF column padding rules (pbsim.cpp:4030-4078)
+    "id_prefix_padding": (lambda rng: [_rand_seq(rng, 1200)],
+                          ONT + ["--depth", "200", "--seed", "16", "--length-mean", "130", "--length-sd", "40",
+                                 "--id-prefix", "Sample_ABC.x"]),
+    # QSHMM: leading insertions at column 0 (Q15), classes without a model (freq2qc), 5 passes
+    "qshmm_pass5": (lambda rng: [_rand_seq(rng, 4000) + "A" * 11 + _rand_seq(rng, 500)],
+                    QS + ["--depth", "3", "--seed", "17", "--pass-num", "5", "--length-mean", "400", "--length-sd", "300",
+                          "--accuracy-mean", "0.80"]),
+    # scratch pool far too small for one default batch: the driver must shrink batches, same bytes
+    "many_small_batches": (lambda rng: [_rand_seq(rng, 600000)],
+                           ONT + ["--depth", "15", "--seed", "18", "--length-mean", "1000", "--length-sd", "700"]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EDGE))
+def test_edge_case_matches_oracle(name, tmp_path):
+    make, args = EDGE[name]
+    rng = np.random.default_rng(abs(hash(name)) % 2**31)
+    fa = tmp_path / "g.fa"
+    _write_fasta(fa, make(rng))
+    _compare(args + ["--genome", str(fa)], tmp_path, scratch_mb=8 if name == "many_small_batches" else None)
+
+
+def test_large_run_properties(tmp_path):
+    """20 Mbp x depth 5 (100 Mbases, ~11 k reads): properties that hold at any size."""
+    rng = np.random.default_rng(99)
+    genome = _rand_seq(rng, 20_000_000)
+    fa = tmp_path / "big.fa"
+    with open(fa, "w") as f:
+        f.write(">chr1\n")
+        f.write("\n".join(genome[i:i + 80] for i in range(0, len(genome), 80)))
+        f.write("\n")
+    args = harness.resolve(ONT + ["--depth", "5", "--seed", "21", "--genome", str(fa)])
+    outs, stats = product.run_wgs(args)
+    fq = outs["_0001.fq"].split(b"\n")
+    maf = outs["_0001.maf"].split(b"\n")
+    n = stats[0].res_num
+    assert len(fq) == 4 * n + 1 and len(maf) == 4 * n + 1
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    total = 0
+    gb = genome.encode()
+    for r in range(n):
+        rid, seq, plus, qual = fq[4 * r:4 * r + 4]
+        assert rid == b"@S1_%d" % (r + 1) and plus == b"+S1_%d" % (r + 1)
+        assert len(seq) == len(qual) and set(qual) <= {ord("!")}
+        a, ref_line, read_line, blank = maf[4 * r:4 * r + 4]
+        assert a == b"a" and blank == b""
+        rf = ref_line.split()
+        rd = read_line.split()
+        assert rf[0] == b"s" and rf[1] == b"ref" and rf[4] == b"+" and int(rf[5]) == len(genome)
+        start, span, ref_row = int(rf[2]), int(rf[3]), rf[6]
+        strand, read_row = rd[4], rd[6]
+        assert rd[1] == b"S1_%d" % (r + 1) and int(rd[3]) == len(seq) == int(rd[5])
+        assert strand == (b"+" if (r + 1) % 2 == 1 else b"-")
+        assert len(ref_row) == len(read_row)
+        # the reference row without gaps is the genome segment; the read row without gaps is the read
+        assert ref_row.replace(b"-", b"") == gb[start:start + span]
+        got = read_row.replace(b"-", b"")
+        if strand == b"-":
+            got = got.translate(comp)[::-1]
+        assert got == seq
+        total += len(seq)
+    assert total == stats[0].res_len_total
+    quota = int(5 * len(genome))
+    assert quota <= total < quota + 200_000
+    # error budget of the default accuracy distribution (classes 63..89, mean ~0.85)
+    err = stats[0].res_sub_rate + stats[0].res_ins_rate + stats[0].res_del_rate
+    assert 0.10 < err < 0.25 and 0.80 < stats[0].res_accuracy_mean < 0.90
+    assert abs((1 - stats[0].res_accuracy_mean) - err) < 0.02
