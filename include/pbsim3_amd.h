@@ -130,12 +130,18 @@ int pbsim_finish_hp_census(pbsim_ctx *ctx);
 int pbsim_set_transcripts(pbsim_ctx *ctx, int64_t n, const char *const *ids, const int64_t *plus_exp,
                           const int64_t *minus_exp, const uint8_t *const *seqs, const int64_t *lens);
 
+/* ---- templates (strategy templ): each FASTA record of --template is one unit that is
+ * read once, full length, '+' strand (get_templ_inf :1366, simulate_by_*_templ :5055-5103). */
+int pbsim_set_templates(pbsim_ctx *ctx, int64_t n, const char *const *ids, const uint8_t *const *seqs,
+                        const int64_t *lens);
+
 /* ---- whole-unit drivers = the reference seam --------------------------------
  * pbsim_simulate_wgs  : one FASTA record, quota loop included
  *                       (simulate_by_errhmm :3792-4080 / simulate_by_qshmm :2173-2385)
  * pbsim_simulate_trans: every transcript (simulate_by_errhmm_trans :4428-4770) */
 int pbsim_simulate_wgs(pbsim_ctx *ctx, const pbsim_sink *sink);
 int pbsim_simulate_trans(pbsim_ctx *ctx, const pbsim_sink *sink);
+int pbsim_simulate_templ(pbsim_ctx *ctx, const pbsim_sink *sink); /* simulate_by_errhmm_templ :4807 / _qshmm_templ :3055 */
 int pbsim_get_stats(pbsim_ctx *ctx, pbsim_stats *out);          /* pbsim.cpp:4082-4105, 5541-5562 */
 /* SAM header the reference's main() writes when it opens the samtools pipe for a
  * unit (pass_num > 1; pbsim.cpp:721-722 wgs, :784-785 trans/templ).  Returns the

@@ -1146,6 +1146,104 @@ static void run_trans(void) { /* pbsim.cpp:761-812 */
   close_outputs();
 }
 
+/* ------------------------------------------------------- templ strategy -- */
+/* get_templ_inf (pbsim.cpp:1366-1418) + simulate_by_{errhmm,qshmm}_templ
+ * (:4807-5392, :3055-3587): every FASTA record is one full-length template,
+ * one read each, '+' strand, offset 0; the header draws the accuracy only. */
+static long tp_num;
+static long long tp_len_total;
+
+static void templ_unit(int mode) {
+  ref_len = (long)strlen(ref_seq);
+  for (long i = 1; i <= ref_len; i++) ref_seq[i] = (char)toupper(ref_seq[i]); /* pbsim.cpp:5062-5064 (index 0 keeps its case) */
+  if (mode == 1) { /* bias pre-pass: hpfreq[v] += run length (pbsim.cpp:4995-5016) */
+    compute_hp(ref_seq, ref_len, ref_hp, 0, 1);
+    return;
+  }
+  compute_hp(ref_seq, ref_len, ref_hp, 0, 0);
+  static int rate_mag = 0;
+  g_unit = 0;
+  g_read = (uint32_t)(sim.res_num + 1);
+  int acc = (int)prob2accuracy[R_hdr(1) % accuracy_rand_value + 1];
+  long L = ref_len;
+  sim.res_num++;
+  memcpy(m_seq, ref_seq, (size_t)L);
+  memcpy(m_hp, ref_hp, (size_t)L * sizeof(short));
+  m_seq[L] = '\0';
+  if (sim.method == ME_ERR) rate_mag = errhmm_rate_mag(acc, rate_mag);
+  for (long h = 0; h < sim.pass_num; h++) {
+    g_pass = (uint32_t)h;
+    long len = (sim.method == ME_ERR) ? walk_errhmm(L, acc, rate_mag, '+') : walk_qshmm(L, acc, '+');
+    /* the MAF line names the template by its id but pads as if it were "ref" (digit_num1[0] = 3, pbsim.cpp:5290) */
+    emit_record(len, sim.method == ME_ERR ? m_newqc : m_qc, h, tr_id, 3, 1, L, '+', 0);
+  }
+}
+
+/* mode 0: stats; 1: hp census; 2: simulate.  Control flow of pbsim.cpp:5055-5362. */
+static void scan_templates(int mode) {
+  FILE *fp = fopen(sim.templ_file, "r");
+  char line[BUF_SIZE];
+  long offset = 0, seqlen = 0;
+  if (!fp) { fprintf(stderr, "ERROR: Cannot open file: %s\n", sim.templ_file); exit(255); }
+  while (1) {
+    char *rp = fgets(line, BUF_SIZE, fp);
+    if (mode != 0 && ((rp == NULL) || (line[0] == '>')) && (offset != 0)) {
+      ref_seq[offset] = '\0';
+      templ_unit(mode);
+    }
+    if (rp == NULL) break;
+    int ret = trim(line);
+    if (line[0] == '>') {
+      if (mode == 0) { tp_num++; seqlen = 0; }
+      strncpy(tr_id, line + 1, REF_ID_LEN_MAX); /* pbsim.cpp:5344-5345 */
+      tr_id[REF_ID_LEN_MAX] = '\0';
+      offset = 0;
+      while (ret != 1) {
+        if (fgets(line, BUF_SIZE, fp) == NULL) break;
+        ret = trim(line);
+      }
+    } else {
+      long n = (long)strlen(line);
+      if (mode == 0) {
+        seqlen += n;
+        tp_len_total += n;
+        if (seqlen > 1000000) die("template is too long. Max acceptable length is 1000000.");
+      } else {
+        memcpy(ref_seq + offset, line, n);
+        offset += n;
+      }
+    }
+  }
+  fclose(fp);
+}
+
+static void run_templ(void) { /* pbsim.cpp:814-866 */
+  scan_templates(0);
+  ref_seq = (char *)malloc(1000000 + 2);
+  ref_hp = (short *)malloc((1000000 + 2) * sizeof(short));
+  fprintf(stderr, ":::: Template stats ::::\n\n");
+  fprintf(stderr, "file name : %s\n", sim.templ_file);
+  fprintf(stderr, "template num. : %ld\n", tp_num);
+  fprintf(stderr, "template total length : %lld\n", tp_len_total);
+  fprintf(stderr, "\n");
+  init_sim_res();
+  open_outputs(0);
+  build_acc_table();
+  if (sim.method == ME_ERR) build_errhmm_tables(0); else build_qshmm_tables();
+  if (sim.hp_del_bias == 1) {
+    set_bias_default();
+  } else {
+    for (int i = 0; i <= 10; i++) hpfreq[i] = 0;
+    scan_templates(1);
+    normalise_bias();
+  }
+  sync_bias_alias();
+  scan_templates(2);
+  finish_stats();
+  print_simulation_stats();
+  close_outputs();
+}
+
 /* ------------------------------------------------------------------ CLI -- */
 static void set_sim_param(void) { /* pbsim.cpp:1451-1688 */
   if (!sim.set_flg[0] || !sim.set_flg[1]) die("--strategy and --method must be set.");
@@ -1249,7 +1347,7 @@ int main(int argc, char **argv) {
   if (!m_seq || !m_read || !m_maf || !m_mafref || !m_qc || !m_newqc || !m_hp) die("Cannot allocate memory.");
   if (sim.strategy == ST_WGS) run_wgs();
   else if (sim.strategy == ST_TRANS) run_trans();
-  else die("oracle: templ strategy is not restated yet (SURVEY section 8f row 2)");
+  else run_templ();
   if (want_count) fprintf(stderr, "oracle draws : %llu\n", g_draws);
   return 0;
 }

@@ -68,6 +68,9 @@ API = [
     ("pbsim_finish_hp_census", C.c_int, [C.c_void_p]),
     ("pbsim_set_transcripts", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    ("pbsim_set_templates", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_int64)]),
+    ("pbsim_simulate_templ", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
     ("pbsim_simulate_wgs", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
     ("pbsim_simulate_trans", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
     ("pbsim_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),

@@ -230,7 +230,7 @@ int main(int argc, char **argv) {
   if (!c.set_flg[0] || !c.set_flg[1]) die(": --strategy and --method must be set.");
   if (c.p.strategy == PBSIM_STRATEGY_WGS && !c.set_flg[2]) die(": for --strategy wgs, --genome must be set.");
   if (c.p.strategy == PBSIM_STRATEGY_TRANS && !c.set_flg[3]) die(": for --strategy trans, --transcript must be set.");
-  if (c.p.strategy == PBSIM_STRATEGY_TEMPL) die(": --strategy templ is not provided by the MI355X path yet (SURVEY 8f row 2)");
+  if (c.p.strategy == PBSIM_STRATEGY_TEMPL && !c.set_flg[21]) die(": for --strategy templ, --template must be set.");
   if (c.p.method == PBSIM_METHOD_QS && !c.set_flg[15]) die(": for --method qshmm, --qshmm must be set.");
   if (c.p.method == PBSIM_METHOD_ERR && !c.set_flg[16]) die(": for --method errhmm, --errhmm must be set.");
   if (c.set_flg[19]) c.p.accuracy_mean = (int)(c.p.accuracy_mean * 100) * 0.01;
@@ -286,15 +286,27 @@ int main(int argc, char **argv) {
       close_sink(c, fp_read);
       close_sink(c, fp_maf);
     }
-  } else {  // pbsim.cpp:761-812
+  } else {  // pbsim.cpp:761-812 (trans), 813-866 (templ)
+    const bool templ = c.p.strategy == PBSIM_STRATEGY_TEMPL;
     std::vector<pbsim::Transcript> tr;
     long total_exp = 0;
-    if (!pbsim::read_transcripts(c.transcript.c_str(), &tr, &total_exp, &err)) die(": %s", err.c_str());
-    fprintf(stderr, ":::: transcript stats ::::\n\n");
-    fprintf(stderr, "file name : %s\n", c.transcript.c_str());
-    fprintf(stderr, "transcript num : %ld\n", (long)tr.size());
-    fprintf(stderr, "total expression value : %ld\n", total_exp);
-    fprintf(stderr, "\n");
+    if (templ) {
+      long num = 0;
+      long long len_total = 0;
+      if (!pbsim::read_templates(c.templ.c_str(), &tr, &num, &len_total, &err)) die(": %s", err.c_str());
+      fprintf(stderr, ":::: Template stats ::::\n\n");
+      fprintf(stderr, "file name : %s\n", c.templ.c_str());
+      fprintf(stderr, "template num. : %ld\n", num);
+      fprintf(stderr, "template total length : %lld\n", len_total);
+      fprintf(stderr, "\n");
+    } else {
+      if (!pbsim::read_transcripts(c.transcript.c_str(), &tr, &total_exp, &err)) die(": %s", err.c_str());
+      fprintf(stderr, ":::: transcript stats ::::\n\n");
+      fprintf(stderr, "file name : %s\n", c.transcript.c_str());
+      fprintf(stderr, "transcript num : %ld\n", (long)tr.size());
+      fprintf(stderr, "total expression value : %ld\n", total_exp);
+      fprintf(stderr, "\n");
+    }
     std::vector<const char *> ids;
     std::vector<int64_t> plus, minus, lens;
     std::vector<const uint8_t *> seqs;
@@ -305,7 +317,8 @@ int main(int argc, char **argv) {
       seqs.push_back((const uint8_t *)t.seq.data());
       lens.push_back((int64_t)strlen(t.seq.c_str()));
     }
-    check(pbsim_set_transcripts(ctx, (int64_t)tr.size(), ids.data(), plus.data(), minus.data(), seqs.data(), lens.data()));
+    if (templ) check(pbsim_set_templates(ctx, (int64_t)tr.size(), ids.data(), seqs.data(), lens.data()));
+    else check(pbsim_set_transcripts(ctx, (int64_t)tr.size(), ids.data(), plus.data(), minus.data(), seqs.data(), lens.data()));
     FILE *fp_read, *fp_maf;
     if (c.p.pass_num == 1) {
       fp_read = open_sink(c, c.prefix + ".fq", c.prefix + ".fq.gz", false);

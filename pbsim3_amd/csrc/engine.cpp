@@ -494,9 +494,10 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   if (!c || n_reads < 1 || first_read < 1) return fail("pbsim_batch_walk: bad argument");
   NEED_DEVICE(c);
   if (c->s().b_enqueued) return fail("pbsim_batch_walk_begin: this slot still has a batch in flight (pbsim_batch_walk_end)");
-  const bool trans = c->p.strategy == PBSIM_STRATEGY_TRANS;
-  if (c->p.strategy == PBSIM_STRATEGY_TEMPL) return fail("pbsim_batch_walk: templ strategy is not provided");
-  if (!c->d_seq) return fail(trans ? "no transcripts set (pbsim_set_transcripts)" : "no reference set (pbsim_set_reference)");
+  const bool trans = c->p.strategy != PBSIM_STRATEGY_WGS;  // trans and templ share the unit machinery
+  if (!c->d_seq)
+    return fail(trans ? "no transcripts/templates set (pbsim_set_transcripts, pbsim_set_templates)"
+                      : "no reference set (pbsim_set_reference)");
   if (trans && (truncate_remaining >= 0 || first_read + n_reads - 1 > c->trans_reads))
     return fail("pbsim_batch_walk: read range outside the transcript set");
   if (truncate_remaining >= 0 && n_reads != 1) return fail("a truncated batch holds exactly one read");
@@ -558,7 +559,9 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   h.off = c->s().d_off.as<int32_t>();
   h.acc = c->s().d_acc.as<uint8_t>();
   h.read_unit = nullptr;
+  h.is_templ = 0;
   if (trans) {
+    h.is_templ = c->p.strategy == PBSIM_STRATEGY_TEMPL;
     h.read_unit = c->d_read_unit.as<int32_t>() + (first_read - 1);
     h.unit_len = c->d_unit_len.as<int64_t>();
     h.unit_rank = c->d_unit_rank.as<int32_t>();
@@ -716,7 +719,8 @@ static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
   t->id_prefix_len = (int)strlen(c->p.id_prefix);
   memcpy(t->id_prefix, c->p.id_prefix, sizeof t->id_prefix);
   t->rq_len = snprintf(t->rq_text, sizeof t->rq_text, "%f", c->p.accuracy_mean);  // pbsim.cpp:4027
-  if (c->p.strategy == PBSIM_STRATEGY_TRANS) {
+  if (c->p.strategy != PBSIM_STRATEGY_WGS) {
+    t->name_pad3 = c->p.strategy == PBSIM_STRATEGY_TEMPL;
     t->read_unit = c->d_read_unit.as<int32_t>() + (c->s().b_first - 1);
     t->read_minus = c->d_read_minus.as<uint8_t>() + (c->s().b_first - 1);
     t->unit_len = c->d_unit_len.as<int64_t>();
@@ -747,7 +751,7 @@ int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_inf
   bi.n_reads = c->s().b_n;
   bi.n_final = n_final;
   bi.len_total_after = len_total_before + cum_final;
-  if (c->p.strategy == PBSIM_STRATEGY_TRANS) {
+  if (c->p.strategy != PBSIM_STRATEGY_WGS) {
     bi.quota_reached = 0;
     bi.need_truncated_read = 0;
   } else if (c->s().b_truncated) {
@@ -1017,15 +1021,12 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
 // per-transcript hp of simulate_by_*_trans (:4428-4485): all units are concatenated
 // with '\n' separators (a byte no sequence contains, so homopolymer runs never
 // join across units) and made resident once.
-int pbsim_set_transcripts(pbsim_ctx *c, int64_t n, const char *const *ids, const int64_t *plus_exp,
-                          const int64_t *minus_exp, const uint8_t *const *seqs, const int64_t *lens) {
-  if (!c || n < 1 || !ids || !plus_exp || !minus_exp || !seqs || !lens) return fail("pbsim_set_transcripts: bad argument");
-  NEED_DEVICE(c);
-  if (c->p.strategy != PBSIM_STRATEGY_TRANS) return fail("pbsim_set_transcripts: strategy is not trans");
-  if (c->p.method == PBSIM_METHOD_ERR && c->hdr.acc_hi == 100)
-    return fail("errhmm trans with accuracy class 100 clobbers the reference's loop counter (pbsim.cpp:4533); refused");
+static int set_units(pbsim_ctx *c, int64_t n, const char *const *ids, const int64_t *plus_exp,
+                     const int64_t *minus_exp, const uint8_t *const *seqs, const int64_t *lens, bool templ) {
   HIP_OK(hipSetDevice(c->device));
-  const int keep_first = c->p.method == PBSIM_METHOD_ERR;  // SURVEY Q6 (pbsim.cpp:4457 vs 2778)
+  // errhmm trans and both templ variants upper-case seq[1..len] only (pbsim.cpp:4457, 3332, 5063);
+  // qshmm trans upper-cases seq[0..len-1] (:2778)
+  const int keep_first = templ || c->p.method == PBSIM_METHOD_ERR;
   int64_t total = 0, reads = 0, max_len = 0;
   for (int64_t u = 0; u < n; u++) {
     if (lens[u] < 1 || lens[u] > 1000000) return fail("transcript length outside 1-1000000");
@@ -1061,7 +1062,7 @@ int pbsim_set_transcripts(pbsim_ctx *c, int64_t n, const char *const *ids, const
     }
     pos += lens[u] + 1;
   }
-  // start-position buckets per rank (pbsim.cpp:4200-4224)
+  // start-position buckets per rank (pbsim.cpp:4200-4224); unused by templ
   const int rank_max = (int)ceil((float)max_len / 1000);  // pbsim.cpp:1133
   SspTables st;
   build_ssp_tables(rank_max, &st);
@@ -1105,13 +1106,37 @@ int pbsim_set_transcripts(pbsim_ctx *c, int64_t n, const char *const *ids, const
   return PBSIM_SUCCEEDED;
 }
 
+int pbsim_set_transcripts(pbsim_ctx *c, int64_t n, const char *const *ids, const int64_t *plus_exp,
+                          const int64_t *minus_exp, const uint8_t *const *seqs, const int64_t *lens) {
+  if (!c || n < 1 || !ids || !plus_exp || !minus_exp || !seqs || !lens) return fail("pbsim_set_transcripts: bad argument");
+  NEED_DEVICE(c);
+  if (c->p.strategy != PBSIM_STRATEGY_TRANS) return fail("pbsim_set_transcripts: strategy is not trans");
+  if (c->p.method == PBSIM_METHOD_ERR && c->hdr.acc_hi == 100)
+    return fail("errhmm trans with accuracy class 100 clobbers the reference's loop counter (pbsim.cpp:4533); refused");
+  return set_units(c, n, ids, plus_exp, minus_exp, seqs, lens, false);
+}
+
+// get_templ_inf (pbsim.cpp:1366-1418) + the per-template loop of simulate_by_*_templ (:5055-5103):
+// every template is one unit with exactly one '+' read over its whole length
+int pbsim_set_templates(pbsim_ctx *c, int64_t n, const char *const *ids, const uint8_t *const *seqs,
+                        const int64_t *lens) {
+  if (!c || n < 1 || !ids || !seqs || !lens) return fail("pbsim_set_templates: bad argument");
+  NEED_DEVICE(c);
+  if (c->p.strategy != PBSIM_STRATEGY_TEMPL) return fail("pbsim_set_templates: strategy is not templ");
+  std::vector<int64_t> one((size_t)n, 1), zero((size_t)n, 0);
+  return set_units(c, n, ids, one.data(), zero.data(), seqs, lens, true);
+}
+
+int pbsim_simulate_templ(pbsim_ctx *c, const pbsim_sink *sink) { return pbsim_simulate_trans(c, sink); }
+
 // simulate_by_errhmm_trans / simulate_by_qshmm_trans (pbsim.cpp:4428-4770, 2738-3017): fixed read
-// count per transcript, no quota; reads are numbered globally like sim.res_num
+// count per transcript, no quota; reads are numbered globally like sim.res_num.  The templ
+// strategy (simulate_by_*_templ) runs through the same driver.
 int pbsim_simulate_trans(pbsim_ctx *c, const pbsim_sink *sink) {
   if (!c) return fail("bad argument");
   NEED_DEVICE(c);
-  if (c->p.strategy != PBSIM_STRATEGY_TRANS) return fail("pbsim_simulate_trans: strategy is not trans");
-  if (!c->d_seq || c->trans_reads < 1) return fail("no transcripts set (pbsim_set_transcripts)");
+  if (c->p.strategy == PBSIM_STRATEGY_WGS) return fail("pbsim_simulate_trans: strategy is wgs");
+  if (!c->d_seq || c->trans_reads < 1) return fail("no transcripts/templates set");
   pbsim_reset_stats(c);
   int64_t next_read = 1, cap = batch_capacity(c);
   while (next_read <= c->trans_reads) {

@@ -53,6 +53,7 @@ struct HeaderArgs {
   int32_t *rawlen, *len, *off;
   uint8_t *acc;
   // trans (pbsim.cpp:4488-4504): per-read unit, per-unit length / rank / the 21 start offsets
+  int32_t is_templ;           // templ: one full-length '+' read per unit, accuracy draw only (pbsim.cpp:5092-5097)
   const int32_t *read_unit;   // [n_reads] (already offset to the batch)
   const int64_t *unit_len;    // [n_units]
   const int32_t *unit_rank;   // [n_units] ceil(len/1000)
@@ -137,6 +138,7 @@ struct TextArgs {
   const int32_t *read_unit;     // [n_reads] transcript index of each read (NULL for wgs)
   const int64_t *unit_len;      // [n_units]
   const char *unit_names;       // [n_units][132] NUL-terminated ids
+  int32_t name_pad3;            // templ: the name is the id but pads as "ref" (digit_num1[0] = 3, pbsim.cpp:5290)
   const uint8_t *read_minus;    // [n_reads] strand for trans (NULL for wgs)
 };
 

@@ -276,9 +276,13 @@ __global__ __launch_bounds__(256) void k_header_trans(HeaderArgs a) {
   const int rank = a.unit_rank[u];
   const uint32_t rv = (uint32_t)a.ssp_rv[rank];
   const uint32_t k = a.ssp[(size_t)rank * 1000 + w.z % (rv ? rv : 1u)];
-  const int64_t off = a.off_table[(size_t)u * 21 + k];
+  int64_t off = a.off_table[(size_t)u * 21 + k];
   if (off + L > G) L = G - off;
   if (L < 0) L = 0;
+  if (a.is_templ) {  // the whole template, no length or start draw
+    L = G;
+    off = 0;
+  }
   a.rawlen[i] = (int32_t)L;
   a.len[i] = (int32_t)L;
   a.off[i] = (int32_t)off;
@@ -996,6 +1000,7 @@ __global__ __launch_bounds__(256) void k_quota_find(const int64_t *cum, const in
 // K3: text.  Sizes per task, then one workgroup per task writes the bytes.
 // ---------------------------------------------------------------------------
 struct TaskText {
+  int name_len;   // bytes of the reference name printed on the MAF reference line
   int idl;        // strlen(id)
   int q0;         // 1 + count_digit(readnum)        (digit_num2[0], pbsim.cpp:4031)
   int r0;         // 3 ("ref") or strlen(transcript id)
@@ -1037,9 +1042,11 @@ __device__ __forceinline__ void task_text(const TextArgs &a, int64_t r, int pass
     int n = 0;
     const char *nm = a.unit_names + (size_t)u * 132;
     while (nm[n]) n++;
-    t->r0 = n;
+    t->name_len = n;
+    t->r0 = a.name_pad3 ? 3 : n;
   } else {
     t->reflen = a.ref_len;
+    t->name_len = 3;
     t->r0 = 3;
   }
   t->r1 = count_digit(t->start0);
@@ -1070,7 +1077,8 @@ __global__ __launch_bounds__(256) void k_text_sizes(TextArgs a, DeviceFlags *fla
          PB_LEN(PB_SAM_T1) + dec_len((int64_t)q - 1) + PB_LEN(PB_SAM_T2) + a.rq_len + PB_LEN(PB_SAM_T3) +
          count_digit(x.readnum) + PB_LEN(PB_SAM_T4);
   }
-  const int64_t mt = (11LL + x.w0 + x.w1 + x.w2 + x.w3 + m) + (10LL + x.idl + (x.w0 - x.q0) + x.w1 + x.w2 + x.w3 + m);
+  const int64_t mt = (11LL + (x.name_len - x.r0) + x.w0 + x.w1 + x.w2 + x.w3 + m) +
+                     (10LL + x.idl + (x.w0 - x.q0) + x.w1 + x.w2 + x.w3 + m);
   a.read_text_len[t] = rt;
   a.maf_text_len[t] = mt;
   atomicAdd((unsigned long long *)&flags->sums[3], (unsigned long long)q);
@@ -1151,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_text_headers(TextArgs a) {
   *o++ = 's';
   *o++ = ' ';
   if (a.read_unit) {
-    o = g_lit(o, a.unit_names + (size_t)a.read_unit[r] * 132, x.r0);
+    o = g_lit(o, a.unit_names + (size_t)a.read_unit[r] * 132, x.name_len);
   } else {
     *o++ = 'r';
     *o++ = 'e';

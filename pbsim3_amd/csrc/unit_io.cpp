@@ -168,4 +168,49 @@ bool read_transcripts(const char *file, std::vector<Transcript> *out, long *tota
   return true;
 }
 
+bool read_templates(const char *file, std::vector<Transcript> *out, long *num, long long *len_total, std::string *err) {
+  FILE *fp = fopen(file, "r");
+  if (!fp) {
+    *err = std::string("Cannot open file: ") + file;
+    return false;
+  }
+  std::unique_ptr<char[]> line(new char[kBuf]);
+  *num = 0;
+  *len_total = 0;
+  Transcript cur;
+  bool have = false;
+  auto flush = [&]() {
+    if (have && !cur.seq.empty()) out->push_back(cur);  // `offset != 0` (pbsim.cpp:5057)
+    cur.seq.clear();
+  };
+  while (fgets(line.get(), kBuf, fp)) {
+    bool nl = chomp(line.get());
+    if (line[0] == '>') {
+      flush();
+      (*num)++;
+      cur.id.assign(line.get() + 1, strnlen(line.get() + 1, kIdMax));
+      cur.plus = 1;
+      cur.minus = 0;
+      have = true;
+      while (!nl) {
+        if (!fgets(line.get(), kBuf, fp)) break;
+        nl = chomp(line.get());
+      }
+    } else {
+      const size_t n = strlen(line.get());
+      *len_total += (long long)n;
+      cur.seq.append(line.get(), n);
+      if (cur.seq.size() > 1000000) {
+        fclose(fp);
+        *err = "template is too long. Max acceptable length is 1000000.";
+        return false;
+      }
+      have = true;
+    }
+  }
+  flush();
+  fclose(fp);
+  return true;
+}
+
 }  // namespace pbsim

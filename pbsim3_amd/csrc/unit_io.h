@@ -28,5 +28,8 @@ struct Transcript {
   std::string seq;
 };
 bool read_transcripts(const char *file, std::vector<Transcript> *out, long *total_exp, std::string *err);
+// --template FASTA (get_templ_inf pbsim.cpp:1366-1418, the reader inside simulate_by_*_templ :5055-5362):
+// one Transcript per record with a non-empty sequence (plus=1); *num counts '>' lines, *len_total bases
+bool read_templates(const char *file, std::vector<Transcript> *out, long *num, long long *len_total, std::string *err);
 
 }  // namespace pbsim

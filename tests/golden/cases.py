@@ -46,6 +46,17 @@ CASES["trans_qshmm_rsii"] = dict(
     args=["--strategy", "trans", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model",
           "--transcript", "INPUT:tiny.transcript", "--seed", "8"])
 
+CASES["templ_errhmm_sequel"] = dict(
+    args=["--strategy", "templ", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-SEQUEL.model",
+          "--template", "INPUT:tiny.template", "--seed", "1"])
+CASES["templ_errhmm_rsii_pass3_hpbias2"] = dict(
+    args=["--strategy", "templ", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-RSII.model",
+          "--template", "INPUT:tiny.template", "--seed", "3", "--pass-num", "3", "--hp-del-bias", "2",
+          "--accuracy-mean", "0.97"])
+CASES["templ_qshmm_rsii_pass2"] = dict(
+    args=["--strategy", "templ", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model",
+          "--template", "INPUT:tiny.template", "--seed", "5", "--pass-num", "2"])
+
 # cases whose complete outputs are committed (gzip) in addition to the hashes
 FULL = ["wgs_errhmm-ont_quirk", "wgs_qshmm_rsii_pass3", "trans_errhmm_sequel"]
 
