@@ -16,7 +16,7 @@ ARCH = "gfx950"
 
 HIP_SOURCES = ["kernels.hip", "engine.cpp"]
 CXX_SOURCES = ["host_tables.cpp", "unit_io.cpp"]
-CLI_SOURCES = ["cli.cpp"]
+CLI_SOURCES = ["cli.cpp", "gzout.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("PBSIM_EXTRA_CFLAGS", "").split()
 
 
@@ -63,7 +63,7 @@ def build(force=False, verbose=False):
     cli_srcs = [os.path.join(CSRC, s) for s in CLI_SOURCES]
     if all(os.path.exists(s) for s in cli_srcs) and (force or _newer(CLI, deps + [LIB])):
         cmd = [HIPCC, "-o", CLI + ".tmp"] + COMMON + cli_srcs + \
-              ["-L" + LIB_DIR, "-lpbsim3_amd", "-Wl,-rpath,$ORIGIN/../lib"]
+              ["-L" + LIB_DIR, "-lpbsim3_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lz", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -5,7 +5,9 @@
 // the FASTA splitter, the per-record driver loop of main() (:666-759) and the
 // gzip/samtools pipes (:708-730).  Everything per read and per base happens in
 // libpbsim3_amd.so on the GPU.  Extra options: --device N, --no-gzip (write the
-// text plainly to <prefix>_NNNN.{fq,maf,sam} instead of piping into gzip/samtools).
+// text plainly to <prefix>_NNNN.{fq,maf,sam}), --gzip-threads N.  The .fq.gz/.maf.gz
+// files are written by an in-process multi-threaded gzip (gzout.h) instead of one
+// `gzip` child per file; BAM still goes through `samtools view -b` like the reference.
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,10 +16,13 @@
 #include <sys/time.h>
 #include <time.h>
 
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pbsim3_amd.h"
+#include "gzout.h"
 #include "unit_io.h"
 
 namespace {
@@ -28,6 +33,7 @@ struct Cli {
   std::string genome, transcript, templ, prefix = "sd", model, sample;
   int device = 0;
   bool no_gzip = false;
+  int gzip_threads = 0;
 };
 
 [[noreturn]] void die(const char *fmt, const char *a = "", const char *b = "") {
@@ -37,24 +43,45 @@ struct Cli {
   exit(-1);
 }
 
-FILE *open_sink(const Cli &c, const std::string &plain_name, const std::string &pipe_cmd_target, bool bam) {
-  FILE *fp;
-  if (c.no_gzip) {
-    fp = fopen(plain_name.c_str(), "w");
-  } else {
-    std::string cmd = bam ? "samtools view -b -o " + pipe_cmd_target + " -" : "gzip > " + pipe_cmd_target;
-    fp = popen(cmd.c_str(), "w");
+// one output file: plain FILE*, samtools pipe, or the in-process parallel gzip
+struct Out {
+  FILE *fp = nullptr;
+  bool pipe = false;
+  pbsim::ParallelGz gz;
+  bool use_gz = false;
+  bool write(const char *t, size_t n) { return use_gz ? gz.write(t, n) : fwrite(t, 1, n, fp) == n; }
+  void close() {
+    if (use_gz) {
+      if (!gz.close()) die(": write error on a .gz output");
+    } else if (pipe) {
+      pclose(fp);
+    } else if (fp) {
+      fclose(fp);
+    }
   }
-  if (!fp) die(": Cannot open output file: %s", c.no_gzip ? plain_name.c_str() : pipe_cmd_target.c_str());
-  return fp;
+};
+
+void open_sink(const Cli &c, Out *o, const std::string &plain_name, const std::string &target, bool bam) {
+  std::string err;
+  if (c.no_gzip) {
+    o->fp = fopen(plain_name.c_str(), "w");
+    if (!o->fp) die(": Cannot open output file: %s", plain_name.c_str());
+  } else if (bam) {  // pbsim.cpp:715-719
+    const std::string cmd = "samtools view -b -o " + target + " -";
+    o->fp = popen(cmd.c_str(), "w");
+    o->pipe = true;
+    if (!o->fp) die(": Cannot open output file: %s", target.c_str());
+  } else {
+    o->use_gz = true;
+    if (!o->gz.open(target, c.gzip_threads, &err)) die(": %s", err.c_str());
+  }
 }
 
-void close_sink(const Cli &c, FILE *fp) {
-  if (c.no_gzip) fclose(fp);
-  else pclose(fp);
-}
-
-int write_cb(void *user, const char *text, int64_t n) { return fwrite(text, 1, (size_t)n, (FILE *)user) == (size_t)n; }
+struct Two {
+  Out *r, *m;
+};
+int cb_read(void *u, const char *t, int64_t k) { return ((Two *)u)->r->write(t, (size_t)k); }
+int cb_maf(void *u, const char *t, int64_t k) { return ((Two *)u)->m->write(t, (size_t)k); }
 
 void print_sim_param(const Cli &c) {  // pbsim.cpp:5397-5465
   const pbsim_params &p = c.p;
@@ -140,7 +167,7 @@ int main(int argc, char **argv) {
       {"qshmm", 1, NULL, 0},      {"errhmm", 1, NULL, 0},        {"length-mean", 1, NULL, 0},
       {"length-sd", 1, NULL, 0},  {"accuracy-mean", 1, NULL, 0}, {"pass-num", 1, NULL, 0},
       {"template", 1, NULL, 0},   {"hp-del-bias", 1, NULL, 0},   {"device", 1, NULL, 0},
-      {"no-gzip", 0, NULL, 0},    {0, 0, 0, 0}};
+      {"no-gzip", 0, NULL, 0},    {"gzip-threads", 1, NULL, 0}, {"gzip-file", 1, NULL, 0}, {0, 0, 0, 0}};
   int opt, idx = 0;
   while ((opt = getopt_long(argc, argv, "", long_options, &idx)) != -1) {
     if (opt != 0) exit(-1);
@@ -219,6 +246,19 @@ int main(int argc, char **argv) {
       break;
     case 23: c.device = atoi(optarg); break;
     case 24: c.no_gzip = true; break;
+    case 25: c.gzip_threads = atoi(optarg); break;
+    case 26: {  // utility/self-test: gzip FILE -> FILE.gz with the parallel writer, nothing else
+      pbsim::ParallelGz gz;
+      std::string e;
+      const int th = c.gzip_threads > 0 ? c.gzip_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+      FILE *in = fopen(optarg, "rb");
+      if (!in || !gz.open(std::string(optarg) + ".gz", th, &e)) die(": Cannot open file: %s", optarg);
+      std::vector<char> buf(1 << 16);
+      size_t k;
+      while ((k = fread(buf.data(), 1, buf.size(), in)) > 0) gz.write(buf.data(), k);
+      fclose(in);
+      return gz.close() ? 0 : 255;
+    }
     default: break;
     }
   }
@@ -238,6 +278,7 @@ int main(int argc, char **argv) {
     fprintf(stderr, "ERROR: length min(%ld) is greater than max(%ld).\n", (long)c.p.len_min, (long)c.p.len_max);
     exit(-1);
   }
+  if (c.gzip_threads < 1) c.gzip_threads = (int)std::max(1u, std::thread::hardware_concurrency());
   print_sim_param(c);
 
   pbsim_ctx *ctx = pbsim_create(&c.p, c.device);
@@ -260,31 +301,27 @@ int main(int argc, char **argv) {
     for (long n = 1; n <= gi.num_seq; n++) {
       if (!pbsim::load_ref_record(c.prefix.c_str(), n, &seq, &err)) die(": %s", err.c_str());
       check(pbsim_set_reference(ctx, (const uint8_t *)seq.data(), (int64_t)seq.size(), n));
-      FILE *fp_read, *fp_maf;
+      Out o_read, o_maf;
       if (c.p.pass_num == 1) {
         snprintf(name, sizeof name, "%s_%04ld.fq", c.prefix.c_str(), n);
-        fp_read = open_sink(c, name, std::string(name) + ".gz", false);
+        open_sink(c, &o_read, name, std::string(name) + ".gz", false);
       } else {
         snprintf(name, sizeof name, "%s_%04ld", c.prefix.c_str(), n);
-        fp_read = open_sink(c, std::string(name) + ".sam", std::string(name) + ".bam", true);
+        open_sink(c, &o_read, std::string(name) + ".sam", std::string(name) + ".bam", true);
         std::vector<char> h((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
         pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
-        fwrite(h.data(), 1, h.size() - 1, fp_read);
+        o_read.write(h.data(), h.size() - 1);
       }
       snprintf(name, sizeof name, "%s_%04ld.maf", c.prefix.c_str(), n);
-      fp_maf = open_sink(c, name, std::string(name) + ".gz", false);
-      pbsim_sink sink = {NULL, write_cb, write_cb};
-      // the two callbacks need different FILE*: wrap through a tiny adapter
-      struct Two { FILE *r, *m; } two = {fp_read, fp_maf};
-      sink.user = &two;
-      sink.on_read_text = [](void *u, const char *t, int64_t k) { return write_cb(((Two *)u)->r, t, k); };
-      sink.on_maf_text = [](void *u, const char *t, int64_t k) { return write_cb(((Two *)u)->m, t, k); };
+      open_sink(c, &o_maf, name, std::string(name) + ".gz", false);
+      Two two = {&o_read, &o_maf};
+      pbsim_sink sink = {&two, cb_read, cb_maf};
       check(pbsim_simulate_wgs(ctx, &sink));
       pbsim_stats st;
       check(pbsim_get_stats(ctx, &st));
       print_simulation_stats(c, st, n);
-      close_sink(c, fp_read);
-      close_sink(c, fp_maf);
+      o_read.close();
+      o_maf.close();
     }
   } else {  // pbsim.cpp:761-812 (trans), 813-866 (templ)
     const bool templ = c.p.strategy == PBSIM_STRATEGY_TEMPL;
@@ -319,27 +356,24 @@ int main(int argc, char **argv) {
     }
     if (templ) check(pbsim_set_templates(ctx, (int64_t)tr.size(), ids.data(), seqs.data(), lens.data()));
     else check(pbsim_set_transcripts(ctx, (int64_t)tr.size(), ids.data(), plus.data(), minus.data(), seqs.data(), lens.data()));
-    FILE *fp_read, *fp_maf;
+    Out o_read, o_maf;
     if (c.p.pass_num == 1) {
-      fp_read = open_sink(c, c.prefix + ".fq", c.prefix + ".fq.gz", false);
+      open_sink(c, &o_read, c.prefix + ".fq", c.prefix + ".fq.gz", false);
     } else {
-      fp_read = open_sink(c, c.prefix + ".sam", c.prefix + ".bam", true);
+      open_sink(c, &o_read, c.prefix + ".sam", c.prefix + ".bam", true);
       std::vector<char> h((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
       pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
-      fwrite(h.data(), 1, h.size() - 1, fp_read);
+      o_read.write(h.data(), h.size() - 1);
     }
-    fp_maf = open_sink(c, c.prefix + ".maf", c.prefix + ".maf.gz", false);
-    struct Two { FILE *r, *m; } two = {fp_read, fp_maf};
-    pbsim_sink sink;
-    sink.user = &two;
-    sink.on_read_text = [](void *u, const char *t, int64_t k) { return write_cb(((Two *)u)->r, t, k); };
-    sink.on_maf_text = [](void *u, const char *t, int64_t k) { return write_cb(((Two *)u)->m, t, k); };
+    open_sink(c, &o_maf, c.prefix + ".maf", c.prefix + ".maf.gz", false);
+    Two two = {&o_read, &o_maf};
+    pbsim_sink sink = {&two, cb_read, cb_maf};
     check(pbsim_simulate_trans(ctx, &sink));
     pbsim_stats st;
     check(pbsim_get_stats(ctx, &st));
     print_simulation_stats(c, st, 0);
-    close_sink(c, fp_read);
-    close_sink(c, fp_maf);
+    o_read.close();
+    o_maf.close();
   }
   pbsim_destroy(ctx);
 

@@ -45,3 +45,16 @@ def test_cli_error_convention(tmp_path):
                         "--errhmm", "/nonexistent.model"], capture_output=True, text=True)
     assert p.returncode == 255
     assert "ERROR: Cannot open file" in p.stderr
+
+
+def test_cli_default_outputs_are_gzip(tmp_path):
+    """Without --no-gzip the CLI writes <prefix>_NNNN.fq.gz / .maf.gz itself (multi-member gzip)."""
+    import gzip
+    case = "wgs_errhmm-ont_quirk"
+    p = subprocess.run([CLI] + harness.resolve(CASES[case]["args"]) + ["--prefix", str(tmp_path / "out"), "--gzip-threads", "3"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    want = MANIFEST[f"{case}/philox"]
+    for k in ("_0001.fq", "_0002.fq", "_0001.maf", "_0002.maf"):
+        with gzip.open(str(tmp_path / ("out" + k + ".gz")), "rb") as f:
+            assert harness.sha(f.read()) == want[k]["sha256"], k
