@@ -18,6 +18,15 @@
 
 namespace pbsim {
 
+// a ^ b ^ c: one v_bitop3_b32 on gfx950 (truth table 0x96), two XORs on the host
+PB_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 constexpr uint32_t kPhiloxM0 = 0xD2511F53u;
 constexpr uint32_t kPhiloxM1 = 0xCD9E8D57u;
 constexpr uint32_t kPhiloxW0 = 0x9E3779B9u;
@@ -85,8 +94,8 @@ PB_HD U4 walk_block_fast(const WalkLane &l, uint32_t seed, uint32_t unit, uint32
   for (int r = 2; r < 10; r++) {
     const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
     const uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
-    const uint32_t m0 = (uint32_t)(p1 >> 32) ^ c1 ^ ka;
-    const uint32_t m2 = (uint32_t)(p0 >> 32) ^ c3 ^ kb;
+    const uint32_t m0 = xor3((uint32_t)(p1 >> 32), c1, ka);
+    const uint32_t m2 = xor3((uint32_t)(p0 >> 32), c3, kb);
     c1 = (uint32_t)p1;
     c3 = (uint32_t)p0;
     c0 = m0;

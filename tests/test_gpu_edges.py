@@ -121,3 +121,13 @@ def test_large_run_properties(tmp_path):
     err = stats[0].res_sub_rate + stats[0].res_ins_rate + stats[0].res_del_rate
     assert 0.10 < err < 0.25 and 0.80 < stats[0].res_accuracy_mean < 0.90
     assert abs((1 - stats[0].res_accuracy_mean) - err) < 0.02
+
+
+def test_multi_batch_quota_pipeline_matches_oracle(tmp_path):
+    """3 records x 2 Mbp x depth 12 with a 64 MiB scratch pool: ~10 pipelined batches per
+    record, the quota cut in the last one and the serial truncated tail -- bytes equal the oracle."""
+    rng = np.random.default_rng(4242)
+    fa = tmp_path / "g.fa"
+    _write_fasta(fa, [_rand_seq(rng, 2_000_000) for _ in range(3)])
+    args = ONT + ["--depth", "12", "--seed", "77", "--genome", str(fa)]
+    _compare(args, tmp_path, scratch_mb=64)
