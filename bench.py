@@ -219,7 +219,7 @@ def main():
         walk_s = walk_ms / 1e3 / max(1, launches)
         achieved = alg_bytes_launch / walk_s / 1e9 if walk_s > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01e_walk_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01f_walk_traffic.json")
         if not qs and os.path.exists(tpath):     # PMC pass of the same kernel (tools/pmc_traffic.sh), scaled per base
             tj = json.load(open(tpath))
             traffic = tj["traffic_bytes_per_launch"] / tj["bases_per_launch"] * (bases / max(1, launches))
@@ -236,7 +236,7 @@ def main():
                        "text_bytes_per_step": g_text // a.steps, "parallelism": f"read-block x{world}", "slots_in_flight": S},
             "roofline": {"bound": "hbm", "kernel": "k_walk_qshmm" if qs else "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01e_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE, raw x1024; see note there)",
+                         "traffic_source": "profiles/r01f_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE, raw x1024; see note there)",
                          "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": walk_s * 1e3,
                          "walk_share_of_step": (walk_ms / 1e3) / dt if dt > 0 else None},
         }
