@@ -147,6 +147,12 @@ int pbsim_get_stats(pbsim_ctx *ctx, pbsim_stats *out);          /* pbsim.cpp:408
  * unit (pass_num > 1; pbsim.cpp:721-722 wgs, :784-785 trans/templ).  Returns the
  * byte count (excluding the NUL), or the size needed when buf is NULL/too small. */
 int64_t pbsim_sam_header(pbsim_ctx *ctx, char *buf, int64_t cap);
+/* pass_num > 1 only: make the read sink receive BAM alignment records (SAMv1 4.2, uncompressed,
+ * one per subread, what `samtools view -b` would build from the SAM text of pbsim.cpp:4016-4027)
+ * instead of SAM text; pbsim_bam_header() gives the bytes that precede the first record.  The
+ * caller BGZF-frames the stream (the CLI does, replacing the samtools child of pbsim.cpp:716). */
+int pbsim_set_bam_output(pbsim_ctx *ctx, int on);
+int64_t pbsim_bam_header(pbsim_ctx *ctx, char *buf, int64_t cap);
 
 /* ---- batch primitives (used by the drivers above, bench.py, multi-GPU) ------
  * pbsim_batch_walk     header draw + bucketing + HMM walk of reads

@@ -75,6 +75,8 @@ API = [
     ("pbsim_simulate_trans", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
     ("pbsim_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("pbsim_sam_header", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+    ("pbsim_set_bam_output", C.c_int, [C.c_void_p, C.c_int]),
+    ("pbsim_bam_header", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("pbsim_batch_walk", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     ("pbsim_slot_count", C.c_int, []),
     ("pbsim_select_slot", C.c_int, [C.c_void_p, C.c_int]),

@@ -5,9 +5,10 @@
 // the FASTA splitter, the per-record driver loop of main() (:666-759) and the
 // gzip/samtools pipes (:708-730).  Everything per read and per base happens in
 // libpbsim3_amd.so on the GPU.  Extra options: --device N, --no-gzip (write the
-// text plainly to <prefix>_NNNN.{fq,maf,sam}), --gzip-threads N.  The .fq.gz/.maf.gz
-// files are written by an in-process multi-threaded gzip (gzout.h) instead of one
-// `gzip` child per file; BAM still goes through `samtools view -b` like the reference.
+// text plainly to <prefix>_NNNN.{fq,maf,sam}), --gzip-threads N, --samtools.  The
+// .fq.gz/.maf.gz files are written by an in-process multi-threaded gzip (gzout.h)
+// instead of one `gzip` child per file; .bam files are BGZF-framed here from BAM records
+// the GPU emits (--samtools pipes SAM text into `samtools view -b` like the reference).
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,7 +33,7 @@ struct Cli {
   pbsim_params p;
   std::string genome, transcript, templ, prefix = "sd", model, sample;
   int device = 0;
-  bool no_gzip = false;
+  bool no_gzip = false, use_samtools = false;
   int gzip_threads = 0;
 };
 
@@ -66,7 +67,10 @@ void open_sink(const Cli &c, Out *o, const std::string &plain_name, const std::s
   if (c.no_gzip) {
     o->fp = fopen(plain_name.c_str(), "w");
     if (!o->fp) die(": Cannot open output file: %s", plain_name.c_str());
-  } else if (bam) {  // pbsim.cpp:715-719
+  } else if (bam && !c.use_samtools) {  // BAM records come from the GPU; BGZF framing here
+    o->use_gz = true;
+    if (!o->gz.open(target, c.gzip_threads, &err, true)) die(": %s", err.c_str());
+  } else if (bam) {  // --samtools: the reference's pipe (pbsim.cpp:715-719)
     const std::string cmd = "samtools view -b -o " + target + " -";
     o->fp = popen(cmd.c_str(), "w");
     o->pipe = true;
@@ -74,6 +78,21 @@ void open_sink(const Cli &c, Out *o, const std::string &plain_name, const std::s
   } else {
     o->use_gz = true;
     if (!o->gz.open(target, c.gzip_threads, &err)) die(": %s", err.c_str());
+  }
+}
+
+bool native_bam(const Cli &c) { return c.p.pass_num > 1 && !c.no_gzip && !c.use_samtools; }
+
+// what main() writes when it opens the samtools pipe (pbsim.cpp:721-722), as SAM text or as the BAM header
+void write_read_header(const Cli &c, pbsim_ctx *ctx, Out *o) {
+  if (native_bam(c)) {
+    std::vector<char> h((size_t)pbsim_bam_header(ctx, NULL, 0));
+    pbsim_bam_header(ctx, h.data(), (int64_t)h.size());
+    o->write(h.data(), h.size());
+  } else {
+    std::vector<char> h((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
+    pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
+    o->write(h.data(), h.size() - 1);
   }
 }
 
@@ -167,7 +186,7 @@ int main(int argc, char **argv) {
       {"qshmm", 1, NULL, 0},      {"errhmm", 1, NULL, 0},        {"length-mean", 1, NULL, 0},
       {"length-sd", 1, NULL, 0},  {"accuracy-mean", 1, NULL, 0}, {"pass-num", 1, NULL, 0},
       {"template", 1, NULL, 0},   {"hp-del-bias", 1, NULL, 0},   {"device", 1, NULL, 0},
-      {"no-gzip", 0, NULL, 0},    {"gzip-threads", 1, NULL, 0}, {"gzip-file", 1, NULL, 0}, {0, 0, 0, 0}};
+      {"no-gzip", 0, NULL, 0},    {"gzip-threads", 1, NULL, 0}, {"gzip-file", 1, NULL, 0}, {"samtools", 0, NULL, 0}, {0, 0, 0, 0}};
   int opt, idx = 0;
   while ((opt = getopt_long(argc, argv, "", long_options, &idx)) != -1) {
     if (opt != 0) exit(-1);
@@ -247,6 +266,7 @@ int main(int argc, char **argv) {
     case 23: c.device = atoi(optarg); break;
     case 24: c.no_gzip = true; break;
     case 25: c.gzip_threads = atoi(optarg); break;
+    case 27: c.use_samtools = true; break;
     case 26: {  // utility/self-test: gzip FILE -> FILE.gz with the parallel writer, nothing else
       pbsim::ParallelGz gz;
       std::string e;
@@ -284,6 +304,7 @@ int main(int argc, char **argv) {
   pbsim_ctx *ctx = pbsim_create(&c.p, c.device);
   if (!ctx) check(0);
   check(c.p.method == PBSIM_METHOD_ERR ? pbsim_load_errhmm(ctx, c.model.c_str()) : pbsim_load_qshmm(ctx, c.model.c_str()));
+  if (native_bam(c)) check(pbsim_set_bam_output(ctx, 1));
   std::string err;
   char name[4096];
 
@@ -308,9 +329,7 @@ int main(int argc, char **argv) {
       } else {
         snprintf(name, sizeof name, "%s_%04ld", c.prefix.c_str(), n);
         open_sink(c, &o_read, std::string(name) + ".sam", std::string(name) + ".bam", true);
-        std::vector<char> h((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
-        pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
-        o_read.write(h.data(), h.size() - 1);
+        write_read_header(c, ctx, &o_read);
       }
       snprintf(name, sizeof name, "%s_%04ld.maf", c.prefix.c_str(), n);
       open_sink(c, &o_maf, name, std::string(name) + ".gz", false);
@@ -361,9 +380,7 @@ int main(int argc, char **argv) {
       open_sink(c, &o_read, c.prefix + ".fq", c.prefix + ".fq.gz", false);
     } else {
       open_sink(c, &o_read, c.prefix + ".sam", c.prefix + ".bam", true);
-      std::vector<char> h((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
-      pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
-      o_read.write(h.data(), h.size() - 1);
+      write_read_header(c, ctx, &o_read);
     }
     open_sink(c, &o_maf, c.prefix + ".maf", c.prefix + ".maf.gz", false);
     Two two = {&o_read, &o_maf};

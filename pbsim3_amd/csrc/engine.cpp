@@ -152,6 +152,7 @@ struct pbsim_ctx {
   DevBuf d_read_unit, d_read_minus, d_read_base, d_unit_len, d_unit_rank, d_unit_names, d_off_table, d_ssp, d_ssp_rv;
   int64_t scratch_budget = 0;  // bytes of wave scratch per slot
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
+  bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
 
   // per-unit statistics (pbsim.cpp:63-70, 195-196)
   int64_t res_num = 0, res_len_total = 0, res_len_min = LONG_MAX, res_len_max = 0;
@@ -719,6 +720,11 @@ static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
   t->id_prefix_len = (int)strlen(c->p.id_prefix);
   memcpy(t->id_prefix, c->p.id_prefix, sizeof t->id_prefix);
   t->rq_len = snprintf(t->rq_text, sizeof t->rq_text, "%f", c->p.accuracy_mean);  // pbsim.cpp:4027
+  t->bam = c->bam_output && c->p.pass_num > 1;
+  {
+    const float f = strtof(t->rq_text, nullptr);
+    memcpy(&t->rq_bits, &f, 4);
+  }
   if (c->p.strategy != PBSIM_STRATEGY_WGS) {
     t->name_pad3 = c->p.strategy == PBSIM_STRATEGY_TEMPL;
     t->read_unit = c->d_read_unit.as<int32_t>() + (c->s().b_first - 1);
@@ -892,6 +898,30 @@ int64_t pbsim_sam_header(pbsim_ctx *c, char *buf, int64_t cap) {  // pbsim.cpp:7
   h += "\tPM:SEQUELII\n";
   if (buf && cap > (int64_t)h.size()) memcpy(buf, h.c_str(), h.size() + 1);
   return (int64_t)h.size();
+}
+
+int pbsim_set_bam_output(pbsim_ctx *c, int on) {
+  if (!c) return fail("bad argument");
+  if (on && c->p.pass_num < 2) return fail("BAM output applies to --pass-num >= 2 (single pass writes FASTQ, pbsim.cpp:707)");
+  c->bam_output = on != 0;
+  return PBSIM_SUCCEEDED;
+}
+
+// "BAM\1" + l_text + the SAM header text + n_ref = 0 (SAMv1 section 4.2)
+int64_t pbsim_bam_header(pbsim_ctx *c, char *buf, int64_t cap) {
+  if (!c) return -1;
+  const int64_t lt = pbsim_sam_header(c, nullptr, 0);
+  const int64_t n = 4 + 4 + lt + 4;
+  if (buf && cap >= n) {
+    std::vector<char> text((size_t)lt + 1);
+    pbsim_sam_header(c, text.data(), lt + 1);
+    memcpy(buf, "BAM\1", 4);
+    const uint32_t l = (uint32_t)lt, zero = 0;
+    memcpy(buf + 4, &l, 4);
+    memcpy(buf + 8, text.data(), (size_t)lt);
+    memcpy(buf + 8 + lt, &zero, 4);
+  }
+  return n;
 }
 
 static int deliver(pbsim_ctx *c, const pbsim_sink *sink) {

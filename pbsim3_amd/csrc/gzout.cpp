@@ -1,7 +1,10 @@
 #include "gzout.h"
 
 #include <string.h>
+#include <stdint.h>
 #include <zlib.h>
+
+#include <algorithm>
 
 namespace pbsim {
 
@@ -21,11 +24,42 @@ bool deflate_member(const std::string &in, std::string *out) {
   deflateEnd(&zs);
   return ok;
 }
+// one BGZF block: gzip member with the BC subfield carrying the block size, raw deflate payload
+bool deflate_bgzf(const std::string &in, std::string *out) {
+  for (int level : {Z_DEFAULT_COMPRESSION, 0}) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out->assign(18 + deflateBound(&zs, (uLong)in.size()) + 8, '\0');
+    zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(in.data()));
+    zs.avail_in = (uInt)in.size();
+    zs.next_out = reinterpret_cast<Bytef *>(&(*out)[18]);
+    zs.avail_out = (uInt)(out->size() - 18 - 8);
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    const size_t total = 18 + clen + 8;
+    if (total > 65536) continue;  // incompressible: store
+    static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(&(*out)[0], hdr, 16);
+    (*out)[16] = (char)((total - 1) & 0xff);
+    (*out)[17] = (char)((total - 1) >> 8);
+    const uLong crc = crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef *>(in.data()), (uInt)in.size());
+    for (int i = 0; i < 4; i++) (*out)[18 + clen + i] = (char)(crc >> (8 * i));
+    for (int i = 0; i < 4; i++) (*out)[18 + clen + 4 + i] = (char)((uint32_t)in.size() >> (8 * i));
+    out->resize(total);
+    return true;
+  }
+  return false;
+}
 }  // namespace
 
 ParallelGz::~ParallelGz() { close(); }
 
-bool ParallelGz::open(const std::string &path, int threads, std::string *err) {
+bool ParallelGz::open(const std::string &path, int threads, std::string *err, bool bgzf) {
+  bgzf_ = bgzf;
+  block_ = bgzf ? 0xff00 : (1 << 20);
   fp_ = fopen(path.c_str(), "wb");
   if (!fp_) {
     *err = "Cannot open output file: " + path;
@@ -48,7 +82,7 @@ void ParallelGz::worker() {
       jobs_.pop_front();
     }
     std::string out;
-    const bool ok = deflate_member(job.in, &out);
+    const bool ok = bgzf_ ? deflate_bgzf(job.in, &out) : deflate_member(job.in, &out);
     {
       std::lock_guard<std::mutex> lk(mu_);
       if (!ok) failed_ = true;
@@ -85,18 +119,22 @@ void ParallelGz::submit() {
 bool ParallelGz::write(const char *data, size_t n) {
   if (!fp_) return false;
   while (n) {
-    const size_t take = std::min(n, kBlock - cur_.size());
+    const size_t take = std::min(n, block_ - cur_.size());
     cur_.append(data, take);
     data += take;
     n -= take;
-    if (cur_.size() >= kBlock) submit();
+    if (cur_.size() >= block_) submit();
   }
   return !failed_;
 }
 
 bool ParallelGz::close() {
   if (!fp_) return !failed_;
-  if (next_submit_ == 0 && cur_.empty()) cur_.assign("", 0), jobs_.push_back(Job{next_submit_++, std::string()}), cv_job_.notify_one();
+  if (next_submit_ == 0 && cur_.empty() && !bgzf_) {  // an empty file is still one (empty) gzip member
+    std::lock_guard<std::mutex> lk(mu_);
+    jobs_.push_back(Job{next_submit_++, std::string()});
+    cv_job_.notify_one();
+  }
   submit();
   {
     std::unique_lock<std::mutex> lk(mu_);
@@ -118,6 +156,11 @@ bool ParallelGz::close() {
   cv_job_.notify_all();
   for (auto &t : pool_) t.join();
   pool_.clear();
+  if (bgzf_) {  // the 28-byte EOF marker block
+    static const unsigned char eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
+                                          0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (fwrite(eof, 1, 28, fp_) != 28) failed_ = true;
+  }
   if (fclose(fp_) != 0) failed_ = true;
   fp_ = nullptr;
   return !failed_;

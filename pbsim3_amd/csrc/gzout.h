@@ -23,7 +23,8 @@ class ParallelGz {
  public:
   ParallelGz() = default;
   ~ParallelGz();
-  bool open(const std::string &path, int threads, std::string *err);
+  // bgzf: BGZF framing (SAMv1 section 4.1: <= 64 KiB blocks, 'BC' extra field, EOF marker) for BAM
+  bool open(const std::string &path, int threads, std::string *err, bool bgzf = false);
   bool write(const char *data, size_t n);  // false after an I/O or zlib error
   bool close();
 
@@ -43,8 +44,8 @@ class ParallelGz {
   std::string cur_;
   size_t next_submit_ = 0, next_write_ = 0;
   size_t max_pending_ = 0;
-  bool stop_ = false, failed_ = false;
-  static constexpr size_t kBlock = 1 << 20;
+  bool stop_ = false, failed_ = false, bgzf_ = false;
+  size_t block_ = 1 << 20;
 };
 
 }  // namespace pbsim

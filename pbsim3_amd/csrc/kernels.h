@@ -134,6 +134,8 @@ struct TextArgs {
   int32_t id_prefix_len;
   char rq_text[32];         // "%f" of accuracy_mean (SAM rq:f:)
   int32_t rq_len;
+  int32_t bam;              // 1: emit BAM records instead of SAM text (pass_num > 1)
+  uint32_t rq_bits;         // the float32 a SAM parser reads from rq_text
   // trans: per-read unit table
   const int32_t *read_unit;     // [n_reads] transcript index of each read (NULL for wgs)
   const int64_t *unit_len;      // [n_units]

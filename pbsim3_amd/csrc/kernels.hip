@@ -1059,6 +1059,39 @@ __device__ __forceinline__ void task_text(const TextArgs &a, int64_t r, int pass
   t->w3 = max(t->r3, t->q2);
 }
 
+// ---- BAM records (SAMv1 section 4.2) of the unaligned subreads the reference pipes into
+// `samtools view -b` (pbsim.cpp:4016-4027).  Integer tags take the smallest type that holds
+// the value, as htslib's SAM parser chooses them.
+__device__ __forceinline__ int bam_int_size(int64_t v) {
+  if (v < 0) return v >= -128 ? 1 : v >= -32768 ? 2 : 4;
+  return v < 256 ? 1 : v < 65536 ? 2 : 4;
+}
+__device__ __forceinline__ char *bam_put_int_tag(char *o, char t0, char t1, int64_t v) {
+  *o++ = t0;
+  *o++ = t1;
+  const int n = bam_int_size(v);
+  *o++ = (v < 0) ? (n == 1 ? 'c' : n == 2 ? 's' : 'i') : (n == 1 ? 'C' : n == 2 ? 'S' : 'I');
+  for (int i = 0; i < n; i++) *o++ = (char)((uint64_t)v >> (8 * i));
+  return o;
+}
+__device__ __forceinline__ char *bam_put_u32(char *o, uint32_t v) {
+  for (int i = 0; i < 4; i++) *o++ = (char)(v >> (8 * i));
+  return o;
+}
+__device__ __forceinline__ int64_t bam_record_size(int idl, int q, int64_t readnum) {
+  const int64_t tags = 4                    // cx:C
+                       + (8 + (int64_t)q)   // ip:B:C
+                       + 4                  // np:C
+                       + (8 + (int64_t)q)   // pw:B:C
+                       + 4                  // qs:C
+                       + 3 + bam_int_size((int64_t)q - 1)  // qe
+                       + 7                  // rq:f
+                       + 24                 // sn:B:f x4
+                       + 3 + bam_int_size(readnum)         // zm
+                       + 12;                // RG:Z:ffffffff
+  return 4 + 32 + (idl + 1) + (q + 1) / 2 + q + tags;
+}
+
 __global__ __launch_bounds__(256) void k_text_sizes(TextArgs a, DeviceFlags *flags) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n_tasks = a.n_reads * a.pass_num;
@@ -1069,7 +1102,9 @@ __global__ __launch_bounds__(256) void k_text_sizes(TextArgs a, DeviceFlags *fla
   TaskText x;
   task_text(a, r, pass, q, &x);
   int64_t rt;
-  if (a.pass_num == 1) {
+  if (a.bam) {
+    rt = bam_record_size(x.idl, q, x.readnum);
+  } else if (a.pass_num == 1) {
     rt = 2LL * x.idl + 2LL * q + 6;  // "@id\n" seq "\n+id\n" qual "\n"
   } else {
     // pbsim.cpp:4017-4027
@@ -1113,7 +1148,51 @@ __global__ __launch_bounds__(256) void k_text_headers(TextArgs a) {
   // ---------------- FASTQ (pbsim.cpp:4013-4014) / SAM (:4016-4027) ----------------
   char *base = a.read_text + a.read_text_off[t];
   char *o = base;
-  if (a.pass_num == 1) {
+  if (a.bam) {
+    const int64_t size = bam_record_size(idl, q, readnum);
+    o = bam_put_u32(o, (uint32_t)(size - 4));  // block_size
+    o = bam_put_u32(o, 0xffffffffu);           // refID -1
+    o = bam_put_u32(o, 0xffffffffu);           // pos -1
+    *o++ = (char)(idl + 1);                    // l_read_name
+    *o++ = (char)255;                          // mapq
+    *o++ = (char)(4680 & 0xff);                // bin of an unplaced read = reg2bin(-1, 0)
+    *o++ = (char)(4680 >> 8);
+    *o++ = 0;                                  // n_cigar_op
+    *o++ = 0;
+    *o++ = 4;                                  // flag 4
+    *o++ = 0;
+    o = bam_put_u32(o, (uint32_t)q);           // l_seq
+    o = bam_put_u32(o, 0xffffffffu);           // next_refID
+    o = bam_put_u32(o, 0xffffffffu);           // next_pos
+    o = bam_put_u32(o, 0);                     // tlen
+    o = g_lit(o, idbuf, idl);
+    *o++ = 0;
+    rd[0] = o - a.read_text;                   // packed bases, (q+1)/2 bytes
+    o += (q + 1) / 2;
+    rd[1] = o - a.read_text;                   // phred qualities
+    o += q;
+    o = bam_put_int_tag(o, 'c', 'x', 3);
+    *o++ = 'i'; *o++ = 'p'; *o++ = 'B'; *o++ = 'C';
+    o = bam_put_u32(o, (uint32_t)q);
+    rd[4] = o - a.read_text;
+    o += q;
+    o = bam_put_int_tag(o, 'n', 'p', 1);
+    *o++ = 'p'; *o++ = 'w'; *o++ = 'B'; *o++ = 'C';
+    o = bam_put_u32(o, (uint32_t)q);
+    rd[5] = o - a.read_text;
+    o += q;
+    o = bam_put_int_tag(o, 'q', 's', 0);
+    o = bam_put_int_tag(o, 'q', 'e', (int64_t)q - 1);
+    *o++ = 'r'; *o++ = 'q'; *o++ = 'f';
+    o = bam_put_u32(o, a.rq_bits);
+    *o++ = 's'; *o++ = 'n'; *o++ = 'B'; *o++ = 'f';
+    o = bam_put_u32(o, 4);
+    for (int i = 0; i < 4; i++) o = bam_put_u32(o, 0x41200000u);  // 10.0f
+    o = bam_put_int_tag(o, 'z', 'm', readnum);
+    *o++ = 'R'; *o++ = 'G'; *o++ = 'Z';
+    o = g_lit(o, "ffffffff", 8);
+    *o++ = 0;
+  } else if (a.pass_num == 1) {
     *o++ = '@';
     o = g_lit(o, idbuf, idl);
     *o++ = '\n';
@@ -1219,8 +1298,8 @@ __device__ __forceinline__ uint32_t dash_zero_bytes(uint32_t w) { return w | ((e
 
 // Writes `len` bytes at text[D0..): plus: text[D0+i] = row[i]; minus: text[D0+i] =
 // complement(row[len-1-i]).  `row` is an LDS row (dword aligned); interior bytes go out as
-// aligned dwords, the <=2 edge dwords as bytes.  fill_kind: 0 copy, 1 '!', 2 ",9" pattern
-// (phase from `rel_first`, the row byte index of D0).
+// aligned dwords, the <=2 edge dwords as bytes.  fill_kind: 0 copy, 2 ",9" pattern (phase from
+// `rel_first`, the row byte index of D0), otherwise 0x100 | b fills with the constant byte b.
 __device__ __forceinline__ void write_segment(char *text, long long D0, int len, const uint32_t *row, int minus,
                                               int fill_kind, bool dash_zero, int rel_first, int lane) {
   const long long base_al = D0 & ~3LL;
@@ -1232,8 +1311,8 @@ __device__ __forceinline__ void write_segment(char *text, long long D0, int len,
     const int i0 = a4 - d0r;  // segment byte index of this dword's first byte (may be negative at the head)
     if (a4 >= d0r && a4 + 4 <= d1r) {
       uint32_t word;
-      if (fill_kind == 1) {
-        word = 0x21212121u;
+      if (fill_kind & 0x100) {
+        word = (uint32_t)(fill_kind & 0xff) * 0x01010101u;
       } else if (fill_kind == 2) {
         word = ((rel_first + i0) & 1) ? 0x2C392C39u : 0x392C392Cu;
       } else if (!minus) {
@@ -1252,8 +1331,8 @@ __device__ __forceinline__ void write_segment(char *text, long long D0, int len,
         if (pos >= d0r && pos < d1r) {
           const int i = pos - d0r;
           uint32_t v;
-          if (fill_kind == 1) {
-            v = '!';
+          if (fill_kind & 0x100) {
+            v = (uint32_t)(fill_kind & 0xff);
           } else if (fill_kind == 2) {
             v = ((rel_first + i) & 1) ? (uint32_t)'9' : (uint32_t)',';
           } else {
@@ -1308,7 +1387,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   {
     const int j = wv * 16 + (lane & 15);
     int v = (s_task[j] >= 0) ? s_m[j] : 0;
-    if (pass == 1 && a.pass_num > 1 && 2 * s_q[j] > v && s_task[j] >= 0) v = 2 * s_q[j];
+    if (pass == 1 && a.pass_num > 1 && !a.bam && 2 * s_q[j] > v && s_task[j] >= 0) v = 2 * s_q[j];
 #pragma unroll
     for (int d = 8; d > 0; d >>= 1) {
       const int t = __shfl_xor(v, d, 64);
@@ -1348,10 +1427,14 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
           const long long D0 = minus ? rd[2] + (m - s1) : rd[2] + s0;
           write_segment(a.maf_text, D0, s1 - s0, trow, minus, 0, false, 0, lane);
         }
-        if (a.pass_num > 1 && s0 < 2 * q) {  // ",9" x len, twice (pbsim.cpp:4019-4025)
+        if (a.pass_num > 1 && !a.bam && s0 < 2 * q) {  // ",9" x len, twice (pbsim.cpp:4019-4025)
           const int s1 = (2 * q < s0 + 256) ? 2 * q : s0 + 256;
           write_segment(a.read_text, rd[4] + s0, s1 - s0, trow, 0, 2, false, s0, lane);
           write_segment(a.read_text, rd[5] + s0, s1 - s0, trow, 0, 2, false, s0, lane);
+        }
+        if (a.bam && s0 < q) {  // BAM: the ip:B:C array is len bytes of value 9
+          const int s1 = (q < s0 + 256) ? q : s0 + 256;
+          write_segment(a.read_text, rd[4] + s0, s1 - s0, trow, 0, 0x100 | 9, false, 0, lane);
         }
         continue;
       }
@@ -1382,16 +1465,49 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const int dn = s_done[j];
-      const int kind = (pass == 0) ? 0 : 1;
+      // BAM: the bases are parked as ASCII in the pw array (k_bam_finish packs them to 4 bits)
+      const int kind = (pass == 0) ? (a.bam ? 5 : 0) : 1;
       write_segment(a.read_text, rd[kind] + dn, total, outb, 0, 0, false, 0, lane);
       if (pass == 0 && !a.is_qs)  // ERRHMM quality is all '!' (pbsim.cpp:4007-4010)
-        write_segment(a.read_text, rd[1] + dn, total, outb, 0, 1, false, 0, lane);
+        write_segment(a.read_text, rd[1] + dn, total, outb, 0, 0x100 | '!', false, 0, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) s_done[j] = dn + total;
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// BAM only, after the rows: one wave per task packs the ASCII bases parked in the pw array
+// into 4-bit codes ("=ACMGRSVTWYHKDBN"), turns the qualities into phred values and fills pw with 9.
+__device__ __forceinline__ uint32_t bam_base_code(uint32_t c) {
+  switch (to_upper(c)) {  // htslib's seq_nt16_table is case-insensitive
+    case '=': return 0;  case 'A': return 1;  case 'C': return 2;  case 'M': return 3;
+    case 'G': return 4;  case 'R': return 5;  case 'S': return 6;  case 'V': return 7;
+    case 'T': return 8;  case 'W': return 9;  case 'Y': return 10; case 'H': return 11;
+    case 'K': return 12; case 'D': return 13; case 'B': return 14;
+    default: return 15;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bam_finish(TextArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= a.n_reads * a.pass_num) return;
+  const int q = a.out_len[t];
+  const int64_t *rd = a.row_dst + t * 6;
+  uint8_t *seq = reinterpret_cast<uint8_t *>(a.read_text) + rd[0];
+  uint8_t *qual = reinterpret_cast<uint8_t *>(a.read_text) + rd[1];
+  uint8_t *pw = reinterpret_cast<uint8_t *>(a.read_text) + rd[5];
+  for (int i = lane; i < (q + 1) / 2; i += 64) {
+    const uint32_t hi = bam_base_code(pw[2 * i]);
+    const uint32_t lo = (2 * i + 1 < q) ? bam_base_code(pw[2 * i + 1]) : 0u;
+    seq[i] = (uint8_t)((hi << 4) | lo);
+  }
+  for (int i = lane; i < q; i += 64) qual[i] = (uint8_t)(qual[i] - 33u);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < q; i += 64) pw[i] = 9;
 }
 
 }  // namespace
@@ -1498,6 +1614,7 @@ void launch_text_emit(const TextArgs &a, int64_t n_slots_max, const DeviceFlags 
   if (n_tasks <= 0) return;
   hipLaunchKernelGGL(k_text_headers, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_text_rows, dim3((unsigned)(n_slots_max / 64), a.is_qs ? 3 : 2), dim3(256), 0, s, a, flags);
+  if (a.bam) hipLaunchKernelGGL(k_bam_finish, dim3(blocks_for(n_tasks, 4)), dim3(256), 0, s, a);
 }
 
 }  // namespace pbsim
