@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--slots", type=int, default=2, help="batches kept in flight per GPU (engine slots)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--record-len", type=int, default=RECORD_LEN)
-    ap.add_argument("--scratch-gib", type=float, default=32.0)
+    ap.add_argument("--scratch-gib", type=float, default=48.0)
     ap.add_argument("--batch-reads", type=int, default=0, help="reads per step per GPU (0 = what the scratch pool holds)")
     ap.add_argument("--model", default="ERRHMM-ONT.model")
     ap.add_argument("--workload", default="errhmm", choices=["errhmm", "qshmm10"],
