@@ -1,0 +1,32 @@
+"""pbsim3_amd.run_multi under torchrun with two ranks (gloo, both on the test box's one GPU):
+the stitched FASTQ/MAF files equal the goldens the reference produced for the same command."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import harness
+from cases import CASES
+
+pytestmark = pytest.mark.gpu
+MANIFEST = harness.load_manifest()
+
+
+@pytest.mark.parametrize("case,batch", [("wgs_errhmm-ont_quirk", "9"), ("wgs_qshmm_rsii_pass3", "5"),
+                                        ("wgs_errhmm_ont_hpbias5", "30")])
+def test_run_multi_two_ranks(case, batch, tmp_path):
+    args = harness.resolve(CASES[case]["args"])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(30500 + os.getpid() % 1000), "-m", "pbsim3_amd.run_multi"] + args + \
+          ["--prefix", str(tmp_path / "out"), "--backend", "gloo", "--one-gpu", "--batch-reads", batch, "--scratch-mb", "256"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=harness.ROOT,
+                       env=dict(os.environ, PYTHONPATH=harness.ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    outs = harness.collect(str(tmp_path))
+    want = MANIFEST[f"{case}/philox"]
+    keys = [k for k in want if k.endswith((".fq", ".maf", ".sam"))]
+    assert keys
+    for k in keys:
+        assert harness.sha(outs[k]) == want[k]["sha256"], k
+    assert not [k for k in outs if ".rank" in k]
