@@ -146,22 +146,57 @@ __global__ __launch_bounds__(256) void k_hp_breaks(const uint8_t *seq, int64_t l
   }
 }
 
-// carry_start[t] = last break before tile t; carry_next[t] = first break after tile t
-__global__ void k_hp_carry(const int64_t *tile_first, const int64_t *tile_last, int64_t n_tiles, int64_t len,
-                           int64_t *carry_start, int64_t *carry_next) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int64_t cur = 0;
-    for (int64_t t = 0; t < n_tiles; t++) {
-      carry_start[t] = cur;
-      if (tile_last[t] >= 0) cur = tile_last[t];
+// carry_start[t] = last break before tile t (exclusive max-scan of tile_last);
+// carry_next[t] = first break after tile t (exclusive suffix min-scan of tile_first, `len` if none).
+// One workgroup of 1024: the two scans run chunk by chunk with a running carry.
+__global__ __launch_bounds__(1024) void k_hp_carry(const int64_t *tile_first, const int64_t *tile_last, int64_t n_tiles,
+                                                     int64_t len, int64_t *carry_start, int64_t *carry_next) {
+  __shared__ long long s_v[1024];
+  __shared__ long long s_carry;
+  const int tid = threadIdx.x;
+  // forward: running maximum of tile_last (-1 = no break in the tile; position 0 is always a break)
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+    const int64_t t = t0 + tid;
+    const long long v = (t < n_tiles) ? tile_last[t] : -1;
+    s_v[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const long long x = (tid >= d) ? s_v[tid - d] : -1;
+      __syncthreads();
+      if (x > s_v[tid]) s_v[tid] = x;
+      __syncthreads();
     }
+    const long long carry = s_carry;
+    const long long incl_prev = (tid > 0) ? s_v[tid - 1] : -1;  // max over the chunk's tiles before this one
+    if (t < n_tiles) carry_start[t] = (incl_prev > carry) ? incl_prev : carry;
+    __syncthreads();
+    if (tid == 1023 && s_v[1023] > s_carry) s_carry = s_v[1023];
+    __syncthreads();
   }
-  if (threadIdx.x == 64 && blockIdx.x == 0) {
-    int64_t cur = len;
-    for (int64_t t = n_tiles - 1; t >= 0; t--) {
-      carry_next[t] = cur;
-      if (tile_last[t] >= 0) cur = tile_first[t];
+  // backward: running minimum of tile_first over the tiles after t
+  if (tid == 0) s_carry = len;
+  __syncthreads();
+  const int64_t n_chunks = (n_tiles + 1023) / 1024;
+  for (int64_t c = n_chunks - 1; c >= 0; c--) {
+    const int64_t t = c * 1024 + tid;
+    const long long big = 0x7fffffffffffffffLL;
+    const long long v = (t < n_tiles && tile_last[t] >= 0) ? tile_first[t] : big;
+    s_v[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const long long x = (tid + d < 1024) ? s_v[tid + d] : big;
+      __syncthreads();
+      if (x < s_v[tid]) s_v[tid] = x;
+      __syncthreads();
     }
+    const long long carry = s_carry;
+    const long long incl_next = (tid < 1023) ? s_v[tid + 1] : big;  // min over the chunk's tiles after this one
+    if (t < n_tiles) carry_next[t] = (incl_next < carry) ? incl_next : carry;
+    __syncthreads();
+    if (tid == 0 && s_v[0] < s_carry) s_carry = s_v[0];
+    __syncthreads();
   }
 }
 
@@ -1524,7 +1559,7 @@ void launch_prepare_reference(uint8_t *seq, uint8_t *hp, uint16_t *hp11, int64_t
   if (n_tiles == 0) return;
   hipLaunchKernelGGL(k_hp_breaks, dim3((unsigned)n_tiles), dim3(256), 0, s, seq, len, keep_first_case, tile_first,
                      tile_last);
-  hipLaunchKernelGGL(k_hp_carry, dim3(1), dim3(128), 0, s, tile_first, tile_last, n_tiles, len, carry_start,
+  hipLaunchKernelGGL(k_hp_carry, dim3(1), dim3(1024), 0, s, tile_first, tile_last, n_tiles, len, carry_start,
                      carry_next);
   hipLaunchKernelGGL(k_hp_final, dim3((unsigned)n_tiles), dim3(256), 0, s, seq, hp, hp11, len, keep_first_case,
                      carry_start, carry_next, flags);

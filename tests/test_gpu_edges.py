@@ -49,6 +49,10 @@ EDGE = {
     # a genome of homopolymers only (hp 10/11 oscillation everywhere, Q1) and N runs
     "homopolymers": (lambda rng: ["".join(c * n for c, n in zip("ACGTN" * 40, rng.integers(1, 30, 200)))],
                      ONT + ["--depth", "20", "--seed", "14", "--length-mean", "300", "--length-sd", "200"]),
+    # runs spanning several 4096-base tiles of the hp kernels: 9001 x A (odd -> hp 11), 12000 x C (even -> hp 10), 10000 x N (hp 1)
+    "long_runs": (lambda rng: [_rand_seq(rng, 3000) + "A" * 9001 + _rand_seq(rng, 500) + "C" * 12000 + "G" + "N" * 10000 +
+                               _rand_seq(rng, 2500)],
+                  ONT + ["--depth", "8", "--seed", "19", "--length-mean", "2500", "--length-sd", "1500", "--hp-del-bias", "3"]),
     # IUPAC soup: non-ACGT substitution branch on nearly every substitution (pbsim.cpp:3947-3949)
     "iupac": (lambda rng: [_rand_seq(rng, 5000, "ACGTRYKMSWN")],
               ONT + ["--depth", "10", "--seed", "15", "--length-mean", "500", "--length-sd", "300"]),
