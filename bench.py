@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--workload", default="errhmm", choices=["errhmm", "qshmm10"],
                     help="errhmm = BASELINE configs[1] (headline); qshmm10 = configs[2]: QSHMM-RSII, --pass-num 10")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--whole-job", action="store_true",
+                    help="not the per-step metric: run the complete configs[1] job (4 records x --record-len, depth 20, "
+                         "quota loop + tail + statistics, text left in HBM) through pbsim_simulate_wgs and report its wall time")
     ap.add_argument("--param", action="append", default=[],
                     help="experiment only: override a pbsim_params field, e.g. --param len_sd=0 (not the headline workload)")
     a = ap.parse_args()
@@ -154,6 +157,34 @@ def main():
     torch.cuda.empty_cache()
     B = a.batch_reads or ctx.batch_capacity()
     quota = ctx.unit_quota()
+
+    if a.whole_job:
+        assert world == 1, "--whole-job is a single-GPU measurement"
+        recs = []
+        gen = torch.Generator(device=dev)
+        for r in range(4):
+            gen.manual_seed(100 + r)
+            recs.append(torch.cat([lut[torch.randint(0, 4, (min(64_000_000, G - o),), dtype=torch.uint8, device=dev,
+                                                    generator=gen).long()] for o in range(0, G, 64_000_000)]))
+        ctx.set_reference_device(recs[0].data_ptr(), G, 1)
+        ctx.simulate_wgs(collect=False)          # warm-up: pools allocated
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tot_b = tot_r = 0
+        for r in range(4):
+            ctx.set_reference_device(recs[r].data_ptr(), G, r + 1)
+            ctx.simulate_wgs(collect=False)
+            st = ctx.stats()
+            tot_b += st.res_len_total
+            tot_r += st.res_num
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "whole job wall time", "value": dt, "unit": "s", "higher_is_better": False,
+                          "bases": tot_b, "reads": tot_r, "bases_per_sec": tot_b / dt, "n_gpus": 1,
+                          "config": {"workload": f"wgs errhmm ERRHMM-ONT depth 20, 4 records x {G} bp, seed 1, "
+                                                 "quota loop + serial tail + statistics; text emitted into HBM, not copied out"}}))
+        ctx.close()
+        return
 
     S = max(1, min(a.slots, P.load().pbsim_slot_count()))
 

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <string>
 #include <vector>
@@ -953,7 +954,9 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
   if (!c->d_seq) return fail("no reference set (pbsim_set_reference)");
   pbsim_reset_stats(c);
   const int64_t quota = pbsim_unit_quota(c);
-  const double mean = std::min<double>(c->hdr.mean_len, (double)c->ref_len);
+  // expected pass-0 output bases per read: E[L] of the length table, a little less than that while nothing has
+  // been measured (deletions outweigh insertions in most models), the measured ratio afterwards
+  double mean = 0.97 * std::min<double>(c->hdr.mean_len, (double)c->ref_len);
   const int n_slots = std::max(1, std::min(kMaxSlots, c->pipeline_depth));
   int64_t cap = batch_capacity(c);
   int64_t len_total = 0, next_read = 1;
@@ -971,6 +974,9 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
     fifo.clear();
     c->cur = 0;
   };
+  const bool trace = getenv("PBSIM_TRACE") != nullptr;  // per-batch host timings on stderr
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
   int next_slot = 0;
   int64_t spec_read = 1;          // first read not yet enqueued
   double spec_total = 0;          // expected pass-0 bases once everything enqueued has finished
@@ -979,9 +985,11 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
     if (serial) {
       c->cur = 0;
       pbsim_batch_info bi;
+      const double t0 = now();
       if (!pbsim_batch_walk(c, next_read, 1, quota - len_total, nullptr)) return PBSIM_FAILED;
       if (!pbsim_batch_finalize(c, len_total, &bi)) return PBSIM_FAILED;
       if (!deliver(c, sink)) return PBSIM_FAILED;
+      if (trace) fprintf(stderr, "[pbsim trace] t=%.1f ms tail read %lld: %.1f ms\n", t0 - t_start, (long long)next_read, now() - t0);
       next_read += bi.n_final;
       len_total = bi.len_total_after;
       continue;
@@ -989,10 +997,14 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
     // keep the pipeline full with speculative batches
     while ((int)fifo.size() < n_slots) {
       const double remaining = (double)quota - spec_total;
-      int64_t n = (int64_t)(0.98 * remaining / mean);
-      if (n < 1) {
-        if (!fifo.empty()) break;
-        n = 1;
+      // split what is still expected evenly over the free slots so the batches in flight are of one size
+      // Overshoot slightly (0.5 % + 64 reads: the sum of n gamma lengths has a relative spread of ~0.8/sqrt(n)):
+      // a batch that ends past the quota costs its surplus reads, a batch that ends short costs a whole
+      // extra round trip whose duration is set by its longest read, not by its size.
+      int64_t n = (int64_t)(1.005 * remaining / mean / (double)(n_slots - (int)fifo.size())) + 64;
+      if (remaining <= 0) {
+        if (!fifo.empty()) break;  // enough is in flight to reach the quota
+        n = 64;
       }
       n = std::min(n, cap);
       c->cur = next_slot;
@@ -1009,6 +1021,7 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
     fifo.erase(fifo.begin());
     c->cur = pd.slot;
     int64_t pass0 = 0;
+    const double t0 = now();
     if (!pbsim_batch_walk_end(c, &pass0)) {
       const bool budget = g_err.rfind("scratch budget exceeded", 0) == 0 && pd.n > 1;
       const std::string keep = g_err;
@@ -1024,17 +1037,29 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
       continue;
     }
     pbsim_batch_info bi;
+    const double t1 = now();
     if (!pbsim_batch_finalize(c, len_total, &bi)) {
       drop_pending();
       return PBSIM_FAILED;
     }
+    const double t2 = now();
     if (!deliver(c, sink)) {
       drop_pending();
       return PBSIM_FAILED;
     }
+    if (trace)
+      fprintf(stderr, "[pbsim trace] t=%.1f ms batch first=%lld n=%lld final=%lld wait_walk=%.1f finalize=%.1f deliver=%.1f\n",
+              t0 - t_start, (long long)pd.first, (long long)pd.n, (long long)bi.n_final, t1 - t0, t2 - t1, now() - t2);
     next_read += bi.n_final;
     len_total = bi.len_total_after;
     spec_total += (double)pass0 - (double)pd.n * mean;  // replace the estimate by what the batch produced
+    if (pd.n >= 1000) {  // re-base the estimate (and what is still in flight) on the measured bases per read
+      const double measured = (double)pass0 / (double)pd.n;
+      double inflight = 0;
+      for (const Pending &q : fifo) inflight += (double)q.n;
+      spec_total += inflight * (measured - mean);
+      mean = measured;
+    }
     if (bi.n_final < pd.n) {  // the quota was reached inside this batch: later speculation is void
       drop_pending();
       spec_read = next_read;
