@@ -76,6 +76,42 @@ def cpu_baseline(sample_bp=4_000_000):
                       f"{bases} bases in {dt:.1f}s, gzip bypassed (cat)"}
 
 
+def bench_trans(a, torch, harness, P, local):
+    """BASELINE configs[3]: --strategy trans --method errhmm --errhmm ERRHMM-SEQUEL.model on 100 000 transcripts
+    (lengths log-uniform 300..12000, plus ~ Geometric(mean 20), minus ~ Geometric(mean 0.1), seed 1).
+    The job has a fixed read count, so the figure is the wall time of pbsim_simulate_trans with text left in HBM."""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    n = 100_000
+    lens = np.exp(rng.uniform(np.log(300), np.log(12000), n)).astype(np.int64)
+    plus = rng.geometric(1 / 21.0, n) - 1
+    minus = rng.geometric(1 / 1.1, n) - 1
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    allseq = acgt[rng.integers(0, 4, int(lens.sum()))].tobytes()
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    seqs = [allseq[offs[i]:offs[i + 1]] for i in range(n)]
+    p = P.default_params(strategy=P.STRATEGY_TRANS, method=P.METHOD_ERR, seed=1)
+    ctx = P.Context(p, local)
+    ctx.set_scratch_bytes(int(a.scratch_gib * (1 << 30)))
+    ctx.load_errhmm(harness.model_path("ERRHMM-SEQUEL.model"))
+    t0 = time.perf_counter()
+    ctx.set_transcripts(["T%d" % i for i in range(n)], [int(x) for x in plus], [int(x) for x in minus], seqs)
+    t_set = time.perf_counter() - t0
+    ctx.simulate_trans(collect=False)   # warm-up (pools)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.simulate_trans(collect=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    print(json.dumps({"metric": "whole job wall time", "value": dt, "unit": "s", "higher_is_better": False, "n_gpus": 1,
+                      "bases": st.res_len_total, "reads": st.res_num, "bases_per_sec": st.res_len_total / dt,
+                      "set_transcripts_s": t_set,
+                      "config": {"workload": "trans errhmm ERRHMM-SEQUEL, 100000 synthetic transcripts "
+                                             f"({int(lens.sum())} bp), expression plus~Geom(20) minus~Geom(0.1), seed 1"}}))
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,8 +122,9 @@ def main():
     ap.add_argument("--scratch-gib", type=float, default=48.0)
     ap.add_argument("--batch-reads", type=int, default=0, help="reads per step per GPU (0 = what the scratch pool holds)")
     ap.add_argument("--model", default="ERRHMM-ONT.model")
-    ap.add_argument("--workload", default="errhmm", choices=["errhmm", "qshmm10"],
-                    help="errhmm = BASELINE configs[1] (headline); qshmm10 = configs[2]: QSHMM-RSII, --pass-num 10")
+    ap.add_argument("--workload", default="errhmm", choices=["errhmm", "qshmm10", "trans"],
+                    help="errhmm = BASELINE configs[1] (headline); qshmm10 = configs[2]: QSHMM-RSII, --pass-num 10; "
+                         "trans = configs[3]: ERRHMM-SEQUEL on a synthetic 100k-transcript profile (whole job, wall time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--whole-job", action="store_true",
                     help="not the per-step metric: run the complete configs[1] job (4 records x --record-len, depth 20, "
@@ -140,6 +177,8 @@ def main():
             genome = g.to(dev)
     torch.cuda.synchronize()
 
+    if a.workload == "trans":
+        return bench_trans(a, torch, harness, P, local)
     qs = a.workload == "qshmm10"
     p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=1, depth=20.0,
                          pass_num=10 if qs else 1)

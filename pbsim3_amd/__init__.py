@@ -204,6 +204,33 @@ class Context:
         self.lib.pbsim_sam_header(self.h, buf, n + 1)
         return buf.raw[:n]
 
+    def set_transcripts(self, ids, plus, minus, seqs):
+        """ids: list[str]; plus/minus: expression counts; seqs: list[bytes]."""
+        n = len(ids)
+        c_ids = (C.c_char_p * n)(*[i.encode() for i in ids])
+        c_plus = (C.c_int64 * n)(*plus)
+        c_minus = (C.c_int64 * n)(*minus)
+        self._keep = [C.create_string_buffer(s, len(s)) for s in seqs]
+        c_seqs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p).value for b in self._keep])
+        c_lens = (C.c_int64 * n)(*[len(s) for s in seqs])
+        _check(self.lib.pbsim_set_transcripts(self.h, n, c_ids, c_plus, c_minus, c_seqs, c_lens))
+        self._keep = None
+
+    def simulate_trans(self, collect=True):
+        reads, mafs = [], []
+
+        def on_read(user, text, n):
+            reads.append(C.string_at(text, n))
+            return 1
+
+        def on_maf(user, text, n):
+            mafs.append(C.string_at(text, n))
+            return 1
+
+        sink = Sink(None, SINK_CB(on_read), SINK_CB(on_maf))
+        _check(self.lib.pbsim_simulate_trans(self.h, C.byref(sink) if collect else None))
+        return b"".join(reads), b"".join(mafs)
+
     def stats(self):
         s = Stats()
         _check(self.lib.pbsim_get_stats(self.h, C.byref(s)))
