@@ -153,6 +153,19 @@ int64_t pbsim_sam_header(pbsim_ctx *ctx, char *buf, int64_t cap);
  * caller BGZF-frames the stream (the CLI does, replacing the samtools child of pbsim.cpp:716). */
 int pbsim_set_bam_output(pbsim_ctx *ctx, int on);
 int64_t pbsim_bam_header(pbsim_ctx *ctx, char *buf, int64_t cap);
+/* Compression on the GPU, replacing the `gzip -c` children of pbsim.cpp:708-730 and the BGZF layer of
+ * `samtools view -b` (pbsim.cpp:716).  pbsim_set_deflate(ctx, mask): bit 0 makes the read sink, bit 1
+ * the MAF sink receive gzip members (RFC 1952) instead of text: one member per 32 KiB of text, each carrying the BGZF 'BC'
+ * extra field (SAMv1 4.1), so the concatenation is a valid multi-member .gz and, for BAM records, a
+ * valid BAM container once the caller has written a compressed header in front and the BGZF EOF marker
+ * behind.  Decompressed bytes are exactly the text the sink would have received otherwise.
+ * pbsim_batch_fetch_deflated is the batch-level primitive (after pbsim_batch_finalize; caps from
+ * pbsim_deflate_bound).  pbsim_deflate_buffer runs host bytes through the same kernels (file headers). */
+int pbsim_set_deflate(pbsim_ctx *ctx, int mask);
+int64_t pbsim_deflate_bound(int64_t text_bytes);
+int pbsim_batch_fetch_deflated(pbsim_ctx *ctx, char *read_gz, int64_t read_cap, char *maf_gz, int64_t maf_cap,
+                               int64_t *read_gz_bytes, int64_t *maf_gz_bytes);
+int pbsim_deflate_buffer(pbsim_ctx *ctx, const void *src, int64_t n, void *dst, int64_t cap, int64_t *out_bytes);
 
 /* ---- batch primitives (used by the drivers above, bench.py, multi-GPU) ------
  * pbsim_batch_walk     header draw + bucketing + HMM walk of reads

@@ -77,6 +77,11 @@ API = [
     ("pbsim_sam_header", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("pbsim_set_bam_output", C.c_int, [C.c_void_p, C.c_int]),
     ("pbsim_bam_header", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+    ("pbsim_set_deflate", C.c_int, [C.c_void_p, C.c_int]),
+    ("pbsim_deflate_bound", C.c_int64, [C.c_int64]),
+    ("pbsim_batch_fetch_deflated", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                             C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("pbsim_deflate_buffer", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     ("pbsim_batch_walk", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     ("pbsim_slot_count", C.c_int, []),
     ("pbsim_select_slot", C.c_int, [C.c_void_p, C.c_int]),
@@ -203,6 +208,19 @@ class Context:
         buf = C.create_string_buffer(n + 1)
         self.lib.pbsim_sam_header(self.h, buf, n + 1)
         return buf.raw[:n]
+
+    def set_deflate(self, mask=3):
+        """bit 0: read sink, bit 1: MAF sink receive gzip members compressed on the GPU"""
+        _check(self.lib.pbsim_set_deflate(self.h, 3 if mask is True else int(mask)))
+
+    def deflate_buffer(self, data: bytes) -> bytes:
+        """gzip members (BGZF-framed) of `data`, compressed by the GPU kernels."""
+        cap = self.lib.pbsim_deflate_bound(len(data)) + 64
+        dst = C.create_string_buffer(cap)
+        n = C.c_int64(0)
+        src = C.create_string_buffer(data, len(data)) if data else None
+        _check(self.lib.pbsim_deflate_buffer(self.h, src, len(data), dst, cap, C.byref(n)))
+        return dst.raw[:n.value]
 
     def set_transcripts(self, ids, plus, minus, seqs):
         """ids: list[str]; plus/minus: expression counts; seqs: list[bytes]."""

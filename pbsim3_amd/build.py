@@ -14,7 +14,7 @@ CLI = os.path.join(BIN_DIR, "pbsim")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["kernels.hip", "engine.cpp"]
+HIP_SOURCES = ["kernels.hip", "deflate.hip", "engine.cpp"]
 CXX_SOURCES = ["host_tables.cpp", "unit_io.cpp"]
 CLI_SOURCES = ["cli.cpp", "gzout.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("PBSIM_EXTRA_CFLAGS", "").split()

@@ -5,10 +5,11 @@
 // the FASTA splitter, the per-record driver loop of main() (:666-759) and the
 // gzip/samtools pipes (:708-730).  Everything per read and per base happens in
 // libpbsim3_amd.so on the GPU.  Extra options: --device N, --no-gzip (write the
-// text plainly to <prefix>_NNNN.{fq,maf,sam}), --gzip-threads N, --samtools.  The
-// .fq.gz/.maf.gz files are written by an in-process multi-threaded gzip (gzout.h)
-// instead of one `gzip` child per file; .bam files are BGZF-framed here from BAM records
-// the GPU emits (--samtools pipes SAM text into `samtools view -b` like the reference).
+// text plainly to <prefix>_NNNN.{fq,maf,sam}), --gzip gpu|host, --gzip-threads N,
+// --samtools.  Instead of one `gzip` child per file, the .fq.gz/.maf.gz/.bam bytes are
+// compressed on the GPU (deflate.hip: BGZF-framed gzip members, only compressed bytes cross
+// PCIe) and appended to the files here; --gzip host uses the in-process multi-threaded zlib
+// writer (gzout.h) instead; --samtools pipes SAM text into `samtools view -b` like the reference.
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -34,6 +35,7 @@ struct Cli {
   std::string genome, transcript, templ, prefix = "sd", model, sample;
   int device = 0;
   bool no_gzip = false, use_samtools = false;
+  bool gzip_on_gpu = true;  // --gzip gpu|host: where the .gz / BGZF members are produced
   int gzip_threads = 0;
 };
 
@@ -44,16 +46,29 @@ struct Cli {
   exit(-1);
 }
 
-// one output file: plain FILE*, samtools pipe, or the in-process parallel gzip
+// an empty BGZF block: the EOF marker of a BAM file (SAMv1 4.1.2), and a valid empty gzip member
+const unsigned char kBgzfEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// one output file: plain FILE*, samtools pipe, the in-process parallel gzip, or a plain FILE* that
+// receives gzip members already compressed on the GPU (pbsim_set_deflate)
 struct Out {
   FILE *fp = nullptr;
   bool pipe = false;
   pbsim::ParallelGz gz;
   bool use_gz = false;
-  bool write(const char *t, size_t n) { return use_gz ? gz.write(t, n) : fwrite(t, 1, n, fp) == n; }
+  bool members = false, bam = false;
+  size_t wrote = 0;
+  bool write(const char *t, size_t n) {
+    wrote += n;
+    return use_gz ? gz.write(t, n) : fwrite(t, 1, n, fp) == n;
+  }
   void close() {
     if (use_gz) {
       if (!gz.close()) die(": write error on a .gz output");
+    } else if (members) {
+      bool ok = true;
+      if (bam || wrote == 0) ok = fwrite(kBgzfEof, 1, sizeof kBgzfEof, fp) == sizeof kBgzfEof;
+      if (fclose(fp) != 0 || !ok) die(": write error on a compressed output");
     } else if (pipe) {
       pclose(fp);
     } else if (fp) {
@@ -67,6 +82,11 @@ void open_sink(const Cli &c, Out *o, const std::string &plain_name, const std::s
   if (c.no_gzip) {
     o->fp = fopen(plain_name.c_str(), "w");
     if (!o->fp) die(": Cannot open output file: %s", plain_name.c_str());
+  } else if (c.gzip_on_gpu && !(bam && c.use_samtools)) {  // members arrive compressed (deflate.hip)
+    o->fp = fopen(target.c_str(), "wb");
+    o->members = true;
+    o->bam = bam;
+    if (!o->fp) die(": Cannot open output file: %s", target.c_str());
   } else if (bam && !c.use_samtools) {  // BAM records come from the GPU; BGZF framing here
     o->use_gz = true;
     if (!o->gz.open(target, c.gzip_threads, &err, true)) die(": %s", err.c_str());
@@ -85,14 +105,23 @@ bool native_bam(const Cli &c) { return c.p.pass_num > 1 && !c.no_gzip && !c.use_
 
 // what main() writes when it opens the samtools pipe (pbsim.cpp:721-722), as SAM text or as the BAM header
 void write_read_header(const Cli &c, pbsim_ctx *ctx, Out *o) {
+  std::vector<char> h;
   if (native_bam(c)) {
-    std::vector<char> h((size_t)pbsim_bam_header(ctx, NULL, 0));
+    h.resize((size_t)pbsim_bam_header(ctx, NULL, 0));
     pbsim_bam_header(ctx, h.data(), (int64_t)h.size());
-    o->write(h.data(), h.size());
   } else {
-    std::vector<char> h((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
+    h.resize((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
     pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
-    o->write(h.data(), h.size() - 1);
+    h.pop_back();
+  }
+  if (o->members) {  // the header as a gzip member of its own, through the same encoder as the records
+    std::vector<char> z((size_t)pbsim_deflate_bound((int64_t)h.size()) + 64);
+    int64_t k = 0;
+    if (!pbsim_deflate_buffer(ctx, h.data(), (int64_t)h.size(), z.data(), (int64_t)z.size(), &k))
+      die(": %s", pbsim_last_error());
+    o->write(z.data(), (size_t)k);
+  } else {
+    o->write(h.data(), h.size());
   }
 }
 
@@ -157,7 +186,8 @@ void print_help() {
           "  --strategy trans --transcript TSV (id, plus, minus, sequence)\n"
           "  --method errhmm  --errhmm MODEL   |   --method qshmm --qshmm MODEL --difference-ratio (6:55:39)\n"
           "  --length-mean (9000.0) --length-sd (7000.0) --accuracy-mean (0.85) --pass-num (1) --hp-del-bias (1)\n"
-          "  --device N (0)   --no-gzip (plain .fq/.maf/.sam instead of gzip/samtools pipes)\n\n");
+          "  --device N (0)   --no-gzip (plain .fq/.maf/.sam instead of gzip/samtools pipes)\n"
+          "  --gzip gpu|host (gpu)   --gzip-threads N (host)   --samtools (pipe SAM into samtools view -b)\n\n");
 }
 
 void check(int ok) {
@@ -186,7 +216,8 @@ int main(int argc, char **argv) {
       {"qshmm", 1, NULL, 0},      {"errhmm", 1, NULL, 0},        {"length-mean", 1, NULL, 0},
       {"length-sd", 1, NULL, 0},  {"accuracy-mean", 1, NULL, 0}, {"pass-num", 1, NULL, 0},
       {"template", 1, NULL, 0},   {"hp-del-bias", 1, NULL, 0},   {"device", 1, NULL, 0},
-      {"no-gzip", 0, NULL, 0},    {"gzip-threads", 1, NULL, 0}, {"gzip-file", 1, NULL, 0}, {"samtools", 0, NULL, 0}, {0, 0, 0, 0}};
+      {"no-gzip", 0, NULL, 0},    {"gzip-threads", 1, NULL, 0}, {"gzip-file", 1, NULL, 0}, {"samtools", 0, NULL, 0},
+      {"gzip", 1, NULL, 0},       {0, 0, 0, 0}};
   int opt, idx = 0;
   while ((opt = getopt_long(argc, argv, "", long_options, &idx)) != -1) {
     if (opt != 0) exit(-1);
@@ -267,6 +298,11 @@ int main(int argc, char **argv) {
     case 24: c.no_gzip = true; break;
     case 25: c.gzip_threads = atoi(optarg); break;
     case 27: c.use_samtools = true; break;
+    case 28:
+      if (!strcmp(optarg, "gpu")) c.gzip_on_gpu = true;
+      else if (!strcmp(optarg, "host")) c.gzip_on_gpu = false;
+      else die(" (gzip: %s): gpu or host.", optarg);
+      break;
     case 26: {  // utility/self-test: gzip FILE -> FILE.gz with the parallel writer, nothing else
       pbsim::ParallelGz gz;
       std::string e;
@@ -305,6 +341,8 @@ int main(int argc, char **argv) {
   if (!ctx) check(0);
   check(c.p.method == PBSIM_METHOD_ERR ? pbsim_load_errhmm(ctx, c.model.c_str()) : pbsim_load_qshmm(ctx, c.model.c_str()));
   if (native_bam(c)) check(pbsim_set_bam_output(ctx, 1));
+  if (!c.no_gzip && c.gzip_on_gpu)  // bit 0: read sink, bit 1: MAF sink; a samtools pipe still wants SAM text
+    check(pbsim_set_deflate(ctx, (c.p.pass_num > 1 && c.use_samtools) ? 2 : 3));
   std::string err;
   char name[4096];
 

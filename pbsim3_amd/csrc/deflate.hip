@@ -1,0 +1,595 @@
+// deflate.hip -- DEFLATE on the GPU for the text the emit kernels leave in HBM.
+//
+// The reference pipes every output file through a `gzip -c` child (popen,
+// pbsim.cpp:708-730) and its BAM through `samtools view -b` (pbsim.cpp:715-719);
+// SURVEY 8(f)1 names that the true end-to-end bottleneck.  Here the FASTQ / SAM /
+// BAM / MAF bytes are compressed where they already are: one workgroup turns one
+// 32 KiB chunk of text into one BGZF-framed gzip member (RFC 1952 with the 'BC'
+// extra field of SAMv1 4.1, so the same stream is a valid .gz and a valid BAM
+// container) holding one dynamic-Huffman block (RFC 1951 3.2.7).  Only the
+// compressed bytes cross PCIe.  tests/deflate_model.py is the executable
+// specification; the GPU output is compared with it byte for byte.
+//
+//   tokens  : each thread owns 128 consecutive bytes; a byte equal to its
+//             predecessor extends a run, runs >= 3 become one distance-1 match
+//             (that is what removes the constant '!' quality line and the SAM
+//             ",9" tags), everything else is a literal.  The text has no other
+//             redundancy an LZ window would find (random bases).
+//   Huffman : LDS histogram -> rank sort -> two-queue merge -> depth limit 15 ->
+//             canonical codes; the code-length alphabet uses a fixed complete code
+//   layout  : the chunk sits in LDS padded by one dword per 32 so that the 64
+//             lanes' sequential walks over their segments hit 64 different banks;
+//             the member is assembled in LDS by ds_or on a zeroed buffer and leaves
+//             as full dwords
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace pbsim {
+
+namespace {
+
+constexpr int kChunk = DF_CHUNK;          // input bytes per member
+constexpr int kThreads = 256;
+constexpr int kSeg = kChunk / kThreads;   // 128 bytes per thread
+constexpr int kSegDw = kSeg / 4;          // 32 dwords
+constexpr int kInDw = kChunk / 4 + kChunk / 128;
+constexpr int kOutBytes = 24576;          // a Huffman member larger than this falls back to a stored block
+constexpr int kOutDw = kOutBytes / 4;
+constexpr int kSyms = 288;
+constexpr uint32_t kPoly = 0xEDB88320u;
+constexpr int kHeadBits = 18 * 8;         // BGZF header bytes in front of the deflate payload
+constexpr int kPrefixBits = 3 + 5 + 5 + 4 + 19 * 3;
+
+// fixed code for the code-length alphabet (tests/deflate_model.py CL_LEN): 0,17,18 -> 3 bits; 2,3,4,12 -> 4; rest 5
+__device__ constexpr uint8_t kClLen[19] = {3, 5, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 4, 5, 5, 5, 5, 3, 3};
+__device__ constexpr uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ uint32_t rev_bits(uint32_t code, uint32_t len) { return __brev(code) >> (32 - len); }
+
+// canonical code of code-length symbol s under kClLen, bit-reversed for the LSB-first stream
+__device__ __forceinline__ uint32_t cl_code(uint32_t s) {
+  // per length: first canonical code and the symbols in index order
+  // len 3: {0,17,18} -> 0,1,2 ; len 4: {2,3,4,12} -> 6,7,8,9 ; len 5: {1,5,6,7,8,9,10,11,13,14,15,16} -> 20..31
+  uint32_t c, l = kClLen[s];
+  if (l == 3) c = s == 0 ? 0 : s - 16;
+  else if (l == 4) c = s == 12 ? 9 : 4 + s;
+  else c = s == 1 ? 20 : s <= 11 ? 16 + s : 15 + s;
+  return rev_bits(c, l);
+}
+
+__device__ __forceinline__ uint32_t gf2_mul(uint32_t a, uint32_t b) {  // a*b mod P, reflected (bit 31 = x^0)
+  uint32_t p = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    p ^= b & (0u - ((a >> (31 - i)) & 1u));
+    b = (b >> 1) ^ (kPoly & (0u - (b & 1u)));
+  }
+  return p;
+}
+
+struct BitWriter {
+  uint32_t *out;
+  uint32_t word, nb;
+  uint64_t acc;
+  __device__ __forceinline__ void init(uint32_t *o, uint32_t bitpos) {
+    out = o;
+    word = bitpos >> 5;
+    nb = bitpos & 31;
+    acc = 0;
+  }
+  __device__ __forceinline__ void put(uint32_t v, uint32_t k) {  // k <= 32
+    acc |= (uint64_t)v << nb;
+    nb += k;
+    if (nb >= 32) {
+      atomicOr(&out[word++], (uint32_t)acc);
+      acc >>= 32;
+      nb -= 32;
+    }
+  }
+  __device__ __forceinline__ void put64(uint64_t v, uint32_t k) {
+    if (k > 32) {
+      put((uint32_t)v, 32);
+      put((uint32_t)(v >> 32), k - 32);
+    } else {
+      put((uint32_t)v, k);
+    }
+  }
+  __device__ __forceinline__ void flush() {
+    if (nb) atomicOr(&out[word], (uint32_t)acc);
+  }
+};
+
+// length 3..258 -> (symbol, extra bit count, extra value)
+__device__ __forceinline__ void length_symbol(uint32_t L, uint32_t *sym, uint32_t *eb, uint32_t *ev) {
+  const uint32_t v = L - 3;
+  if (v < 8) {
+    *sym = 257 + v;
+    *eb = 0;
+    *ev = 0;
+  } else if (L == 258) {
+    *sym = 285;
+    *eb = 0;
+    *ev = 0;
+  } else {
+    const uint32_t e = (31 - __clz(v)) - 2;
+    *sym = 261 + 4 * e + ((v >> e) & 3);
+    *eb = e;
+    *ev = v & ((1u << e) - 1);
+  }
+}
+
+// exclusive scan of one u32 per thread over the 256-thread block; *total = sum
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s_wave, uint32_t *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();  // s_wave may still be read from a previous scan
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; ++w) {
+    const uint32_t x = s_wave[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+// Walks the tokens of one thread's segment: fn_lit(byte) / fn_match(length).
+// seg = the thread's 32 dwords in the padded LDS image, prev = byte before the segment (0x100 at chunk start).
+template <class FL, class FM>
+__device__ __forceinline__ void walk_tokens(const uint32_t *seg, int nbytes, uint32_t prev, FL &&fn_lit, FM &&fn_match) {
+  uint32_t run = 0;
+  for (int j = 0; j < kSegDw; ++j) {
+    if (4 * j >= nbytes) break;
+    const uint32_t w = seg[j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (4 * j + k < nbytes) {
+        const uint32_t b = (w >> (8 * k)) & 255u;
+        if (b == prev) {
+          ++run;
+        } else {
+          if (run >= 3) fn_match(run);
+          else if (run == 2) { fn_lit(prev); fn_lit(prev); }
+          else if (run == 1) fn_lit(prev);
+          run = 0;
+          fn_lit(b);
+          prev = b;
+        }
+      }
+    }
+  }
+  if (run >= 3) fn_match(run);
+  else if (run == 2) { fn_lit(prev); fn_lit(prev); }
+  else if (run == 1) fn_lit(prev);
+}
+
+__global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__restrict__ text, int64_t n_bytes,
+                                                              uint8_t *__restrict__ slots, int32_t *__restrict__ sizes,
+                                                              const uint32_t *__restrict__ crc_table,
+                                                              const uint32_t *__restrict__ pow128, uint32_t x8rem) {
+  __shared__ uint32_t s_in[kInDw];
+  __shared__ uint32_t s_out[kOutDw];
+  __shared__ uint32_t s_hist[kSyms];
+  __shared__ uint32_t s_code[kSyms];     // reversed code | length << 16
+  __shared__ uint32_t s_sfreq[kSyms];    // frequencies in sorted order
+  __shared__ uint32_t s_w[kSyms];        // internal node weights
+  __shared__ uint16_t s_sorted[kSyms];   // symbols, ascending (freq, symbol)
+  __shared__ uint16_t s_par[kSyms];      // parent of internal node
+  __shared__ uint16_t s_leafpar[kSyms];  // parent of leaf
+  __shared__ uint16_t s_dep[kSyms];      // depth of internal node
+  __shared__ uint8_t s_len[kSyms];
+  __shared__ uint32_t s_crc[256];
+  __shared__ uint32_t s_cnt[16], s_first[16];
+  __shared__ uint32_t s_wave[kThreads / 64];
+  __shared__ uint32_t s_misc[4];         // 0 n_used, 1 any_match, 2 max symbol, 3 crc
+
+  const int tid = threadIdx.x;
+  const int64_t chunk = blockIdx.x;
+  const int64_t base = chunk * (int64_t)kChunk;
+  const int n = (int)((n_bytes - base) < (int64_t)kChunk ? (n_bytes - base) : (int64_t)kChunk);
+  const uint8_t *src = text + base;
+  uint8_t *slot = slots + chunk * (int64_t)DF_SLOT;
+
+  // ---- stage: chunk -> padded LDS image, tables, zeroed work areas
+  {
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+    for (int q = tid; q < kChunk / 16; q += kThreads) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q * 16 < n) v = src4[q];   // the text buffers carry 16 bytes of slack past their end
+      const int d = q * 4;
+      uint32_t *dst = &s_in[d + (d >> 5)];
+      dst[0] = v.x;
+      dst[1] = v.y;
+      dst[2] = v.z;
+      dst[3] = v.w;
+    }
+    for (int i = tid; i < kOutDw; i += kThreads) s_out[i] = 0;
+    for (int i = tid; i < kSyms; i += kThreads) {
+      s_hist[i] = 0;
+      s_code[i] = 0;
+      s_len[i] = 0;
+    }
+    s_crc[tid] = crc_table[tid];
+    if (tid < 16) s_cnt[tid] = 0;
+    if (tid < 4) s_misc[tid] = 0;
+  }
+  __syncthreads();
+
+  const int beg = tid * kSeg;
+  const int seg_n = n - beg < 0 ? 0 : (n - beg < kSeg ? n - beg : kSeg);
+  const uint32_t *seg = &s_in[tid * (kSegDw + 1)];
+  uint32_t prev0 = 0x100;
+  if (tid > 0 && seg_n > 0) prev0 = s_in[tid * (kSegDw + 1) - 2] >> 24;  // last byte of the previous segment
+
+  // ---- pass 1: histogram + CRC of the segment
+  {
+    bool any = false;
+    walk_tokens(
+        seg, seg_n, prev0, [&](uint32_t b) { atomicAdd(&s_hist[b], 1u); },
+        [&](uint32_t L) {
+          uint32_t s, eb, ev;
+          length_symbol(L, &s, &eb, &ev);
+          atomicAdd(&s_hist[s], 1u);
+          any = true;
+        });
+    if (any) s_misc[1] = 1;
+    uint32_t c = tid == 0 ? 0xFFFFFFFFu : 0u;
+    for (int j = 0; j < kSegDw; ++j) {
+      if (4 * j >= seg_n) break;
+      const uint32_t w = seg[j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (4 * j + k < seg_n) c = s_crc[(c ^ (w >> (8 * k))) & 255u] ^ (c >> 8);
+    }
+    // bytes after this segment = 128 * (q - tid - 1) + r for full segments, 0 for the last (partial) one
+    const int q = n >> 7, r = n & 127;
+    if (seg_n == kSeg && tid < q) {
+      c = gf2_mul(c, pow128[q - tid - 1]);
+      if (r) c = gf2_mul(c, x8rem);
+    }
+    if (seg_n == 0) c = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
+    if ((tid & 63) == 0) atomicXor(&s_misc[3], c);
+    if (tid == 0) s_hist[256] = 1;  // end of block
+  }
+  __syncthreads();
+
+  // ---- rank sort of the used symbols by (freq, symbol)
+  {
+    for (int s = tid; s < 286; s += kThreads) {
+      const uint32_t f = s_hist[s];
+      if (f) {
+        uint32_t rank = 0;
+        for (int u = 0; u < 286; ++u) {
+          const uint32_t g = s_hist[u];
+          rank += (g != 0) & ((g < f) | ((g == f) & (u < s)));
+        }
+        s_sorted[rank] = (uint16_t)s;
+        s_sfreq[rank] = f;
+        atomicAdd(&s_misc[0], 1u);
+        atomicMax(&s_misc[2], (uint32_t)s);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- Huffman depths (one lane; n_used is a few dozen for this text), limited to 15 bits
+  if (tid == 0) {
+    const int m = (int)s_misc[0];
+    if (m == 1) {
+      s_cnt[1] = 1;
+    } else {
+      int leaf = 0, root = 0;
+      for (int nxt = 0; nxt < m - 1; ++nxt) {
+        uint32_t tot = 0;
+        for (int k = 0; k < 2; ++k) {
+          const bool take_leaf = leaf < m && (root >= nxt || s_sfreq[leaf] <= s_w[root]);
+          if (take_leaf) {
+            tot += s_sfreq[leaf];
+            s_leafpar[leaf] = (uint16_t)nxt;
+            ++leaf;
+          } else {
+            tot += s_w[root];
+            s_par[root] = (uint16_t)nxt;
+            ++root;
+          }
+        }
+        s_w[nxt] = tot;
+      }
+      s_dep[m - 2] = 0;
+      for (int i = m - 3; i >= 0; --i) s_dep[i] = s_dep[s_par[i]] + 1;
+      for (int i = 0; i < m; ++i) {
+        int d = s_dep[s_leafpar[i]] + 1;
+        if (d > 15) d = 15;
+        s_cnt[d] += 1;
+      }
+      uint32_t total = 0;
+      for (int l = 1; l <= 15; ++l) total += s_cnt[l] << (15 - l);
+      while (total > (1u << 15)) {
+        s_cnt[15] -= 1;
+        for (int l = 14; l >= 1; --l)
+          if (s_cnt[l]) {
+            s_cnt[l] -= 1;
+            s_cnt[l + 1] += 2;
+            break;
+          }
+        total -= 1;
+      }
+    }
+    int i = 0;
+    for (int l = 15; l >= 1; --l)
+      for (uint32_t k = 0; k < s_cnt[l]; ++k) s_len[s_sorted[i++]] = (uint8_t)l;
+    uint32_t code = 0;
+    s_cnt[0] = 0;
+    for (int l = 1; l <= 15; ++l) {
+      code = (code + s_cnt[l - 1]) << 1;
+      s_first[l] = code;
+    }
+  }
+  __syncthreads();
+
+  // ---- canonical codes
+  for (int s = tid; s < 286; s += kThreads) {
+    const uint32_t l = s_len[s];
+    if (l) {
+      uint32_t idx = 0;
+      for (int u = 0; u < s; ++u) idx += s_len[u] == l;
+      s_code[s] = rev_bits(s_first[l] + idx, l) | (l << 16);
+    }
+  }
+  __syncthreads();
+
+  // ---- sizes: header symbols (two positions per thread) and the thread's tokens
+  const uint32_t any_match = s_misc[1];
+  const int hlit = (int)s_misc[2] + 1;   // >= 257: symbol 256 is always used
+  const int npos = hlit + 1;             // + the one distance code length
+  uint64_t hbits[2] = {0, 0};
+  uint32_t hn[2] = {0, 0};
+  for (int h = 0; h < 2; ++h) {
+    const int p = 2 * tid + h;
+    if (p >= npos) continue;
+    const uint32_t v = p < hlit ? s_len[p] : any_match;
+    if (v) {
+      hbits[h] = cl_code(v);
+      hn[h] = kClLen[v];
+    } else {
+      const uint32_t before = p == 0 ? 1u : (p - 1 < hlit ? s_len[p - 1] : any_match);
+      if (before != 0) {  // first zero of a run
+        int r = 1;
+        while (p + r < npos && (p + r < hlit ? s_len[p + r] : any_match) == 0) ++r;
+        uint64_t acc = 0;
+        uint32_t nb = 0;
+        while (r >= 11) {
+          const int t = r < 138 ? r : 138;
+          acc |= (uint64_t)(cl_code(18) | ((uint32_t)(t - 11) << 3)) << nb;
+          nb += 10;
+          r -= t;
+        }
+        if (r >= 3) {
+          acc |= (uint64_t)(cl_code(17) | ((uint32_t)(r - 3) << 3)) << nb;
+          nb += 6;
+          r = 0;
+        }
+        for (; r > 0; --r) {
+          acc |= (uint64_t)cl_code(0) << nb;
+          nb += 3;
+        }
+        hbits[h] = acc;
+        hn[h] = nb;
+      }
+    }
+  }
+  uint32_t tok_bits = 0;
+  walk_tokens(
+      seg, seg_n, prev0, [&](uint32_t b) { tok_bits += s_code[b] >> 16; },
+      [&](uint32_t L) {
+        uint32_t s, eb, ev;
+        length_symbol(L, &s, &eb, &ev);
+        tok_bits += (s_code[s] >> 16) + eb + 1;
+      });
+  uint32_t hdr_total, tok_total;
+  const uint32_t hdr_off = block_scan_excl(hn[0] + hn[1], s_wave, &hdr_total);
+  const uint32_t tok_off = block_scan_excl(tok_bits, s_wave, &tok_total);
+  const uint32_t eob_len = s_code[256] >> 16;
+  const uint32_t payload_bits = kPrefixBits + hdr_total + tok_total + eob_len;
+  const uint32_t payload_bytes = (payload_bits + 7) >> 3;
+  const bool huff = (18 + payload_bytes + 8 <= (uint32_t)kOutBytes) && (payload_bytes < (uint32_t)n + 5);
+  const uint32_t crc = s_misc[3] ^ 0xFFFFFFFFu;
+
+  if (huff) {
+    const uint32_t member = 18 + payload_bytes + 8;
+    if (tid == 0) {
+      // BGZF header: 1f 8b 08 04 | mtime 0 | xfl 0 | os ff | xlen 6 | 'B' 'C' 2 0 | bsize-1
+      s_out[0] = 0x04088b1fu;
+      s_out[1] = 0;
+      s_out[2] = 0x0006ff00u;
+      s_out[3] = 0x00024342u;
+      BitWriter bw;
+      bw.init(s_out, 16 * 8);
+      bw.put(member - 1, 16);
+      bw.put(1, 1);            // BFINAL
+      bw.put(2, 2);            // dynamic Huffman
+      bw.put(hlit - 257, 5);
+      bw.put(0, 5);            // HDIST = 1
+      bw.put(15, 4);           // HCLEN = 19
+      for (int i = 0; i < 19; ++i) bw.put(kClLen[kClOrder[i]], 3);
+      bw.flush();
+    }
+    __syncthreads();  // the plain stores above precede everybody's ds_or
+    {
+      BitWriter bw;
+      bw.init(s_out, kHeadBits + kPrefixBits + hdr_off);
+      bw.put64(hbits[0], hn[0]);
+      bw.put64(hbits[1], hn[1]);
+      bw.flush();
+    }
+    {
+      BitWriter bw;
+      bw.init(s_out, kHeadBits + kPrefixBits + hdr_total + tok_off);
+      walk_tokens(
+          seg, seg_n, prev0,
+          [&](uint32_t b) {
+            const uint32_t c = s_code[b];
+            bw.put(c & 0xFFFFu, c >> 16);
+          },
+          [&](uint32_t L) {
+            uint32_t s, eb, ev;
+            length_symbol(L, &s, &eb, &ev);
+            const uint32_t c = s_code[s];
+            // code, extra bits, then the single distance code (one 0 bit)
+            bw.put((c & 0xFFFFu) | (ev << (c >> 16)), (c >> 16) + eb + 1);
+          });
+      bw.flush();
+    }
+    if (tid == 0) {
+      BitWriter bw;
+      bw.init(s_out, kHeadBits + kPrefixBits + hdr_total + tok_total);
+      bw.put(s_code[256] & 0xFFFFu, eob_len);
+      bw.flush();
+      bw.init(s_out, (18 + payload_bytes) * 8);
+      bw.put(crc, 32);
+      bw.put((uint32_t)n, 32);
+      bw.flush();
+    }
+    __syncthreads();
+    uint32_t *dst = reinterpret_cast<uint32_t *>(slot);
+    for (uint32_t i = tid; i < (member + 3) / 4; i += kThreads) dst[i] = s_out[i];
+    if (tid == 0) sizes[chunk] = (int32_t)member;
+  } else {
+    // stored block (RFC 1951 3.2.4): incompressible input, rare for this text
+    const uint32_t member = 18 + 5 + (uint32_t)n + 8;
+    if (tid == 0) {
+      const uint8_t head[23] = {0x1f, 0x8b, 8,   4,   0,   0,
+                                0,    0,    0,   0xff, 6,  0,
+                                'B',  'C',  2,   0,   (uint8_t)((member - 1) & 255), (uint8_t)((member - 1) >> 8),
+                                1,    (uint8_t)(n & 255), (uint8_t)(n >> 8), (uint8_t)(~n & 255), (uint8_t)((~n >> 8) & 255)};
+      for (int i = 0; i < 23; ++i) slot[i] = head[i];
+      uint8_t *t = slot + 23 + n;
+      for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i));
+      for (int i = 0; i < 4; ++i) t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
+      sizes[chunk] = (int32_t)member;
+    }
+    for (int i = tid; i < n; i += kThreads) {
+      const int d = i >> 2;
+      slot[23 + i] = (uint8_t)(s_in[d + (d >> 5)] >> (8 * (i & 3)));
+    }
+  }
+}
+
+// offsets[c] = sum of sizes[< c], offsets[n] = total; n <= 8192 (one block, 8 per thread)
+__global__ __launch_bounds__(1024) void k_deflate_offsets(const int32_t *__restrict__ sizes, int n,
+                                                          int64_t *__restrict__ offsets) {
+  __shared__ uint32_t s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t v[8], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = tid * 8 + k;
+    v[k] = i < n ? (uint32_t)sizes[i] : 0u;
+    sum += v[k];
+  }
+  uint32_t inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) base += s_w[w];
+    tot += s_w[w];
+  }
+  uint32_t run = base + inc - sum;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = tid * 8 + k;
+    if (i < n) offsets[i] = run;
+    run += v[k];
+  }
+  if (tid == 0) offsets[n] = tot;
+}
+
+// dense[offsets[c] ..) = slot c's member; destinations are byte-aligned, so interior dwords are
+// rebuilt from two aligned source dwords
+__global__ __launch_bounds__(256) void k_deflate_compact(const uint8_t *__restrict__ slots,
+                                                         const int64_t *__restrict__ offsets,
+                                                         uint8_t *__restrict__ dense) {
+  const int64_t c = blockIdx.x;
+  const int64_t off = offsets[c];
+  const int size = (int)(offsets[c + 1] - off);
+  const uint8_t *src = slots + c * (int64_t)DF_SLOT;
+  uint8_t *dst = dense + off;
+  const int head = (int)((4 - (off & 3)) & 3) < size ? (int)((4 - (off & 3)) & 3) : size;
+  if ((int)threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+  const int ndw = (size - head) >> 2;
+  const uint32_t *src32 = reinterpret_cast<const uint32_t *>(src);
+  uint32_t *dst32 = reinterpret_cast<uint32_t *>(dst + head);
+  for (int i = threadIdx.x; i < ndw; i += 256) {
+    const uint32_t lo = src32[i], hi = src32[i + 1];   // head in 0..3; the slot is padded past the member
+    dst32[i] = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)head);
+  }
+  const int done = head + 4 * ndw;
+  if ((int)threadIdx.x < size - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+}
+
+uint32_t host_gf2_mul(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+  for (int i = 0; i < 32; ++i) {
+    if (a & (0x80000000u >> i)) p ^= b;
+    b = (b >> 1) ^ ((b & 1u) ? kPoly : 0u);
+  }
+  return p;
+}
+
+uint32_t host_xpow8(uint64_t nbytes) {  // x^(8 nbytes) mod P
+  uint32_t r = 0x80000000u, b = 0x00800000u;
+  while (nbytes) {
+    if (nbytes & 1) r = host_gf2_mul(r, b);
+    b = host_gf2_mul(b, b);
+    nbytes >>= 1;
+  }
+  return r;
+}
+
+}  // namespace
+
+void deflate_host_tables(uint32_t *crc_table, uint32_t *pow128) {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? kPoly : 0u);
+    crc_table[i] = c;
+  }
+  const uint32_t step = host_xpow8(128);
+  uint32_t v = 0x80000000u;
+  for (int k = 0; k < 256; ++k) {
+    pow128[k] = v;
+    v = host_gf2_mul(v, step);
+  }
+}
+
+void launch_deflate(const uint8_t *text, int64_t n_bytes, uint8_t *slots, int32_t *sizes, int64_t *offsets,
+                    uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, hipStream_t s) {
+  if (n_bytes <= 0) return;
+  const int64_t nch = (n_bytes + DF_CHUNK - 1) / DF_CHUNK;
+  const uint32_t x8rem = host_xpow8((uint64_t)(n_bytes % DF_CHUNK) & 127u);
+  hipLaunchKernelGGL(k_deflate_chunks, dim3((unsigned)nch), dim3(kThreads), 0, s, text, n_bytes, slots, sizes,
+                     d_crc_table, d_pow128, x8rem);
+  hipLaunchKernelGGL(k_deflate_offsets, dim3(1), dim3(1024), 0, s, (const int32_t *)sizes, (int)nch, offsets);
+  hipLaunchKernelGGL(k_deflate_compact, dim3((unsigned)nch), dim3(256), 0, s, (const uint8_t *)slots,
+                     (const int64_t *)offsets, dense);
+}
+
+}  // namespace pbsim

@@ -117,6 +117,8 @@ struct Slot {
   DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len, d_row_dst;
   DevBuf d_scratch, d_read_text, d_maf_text;
   HostBuf h_read_text, h_maf_text, h_stats;
+  DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];  // deflate staging, one piece of DF_PIECE_CHUNKS chunks
+  HostBuf h_df_total;
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
   bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
   int64_t b_pass0 = 0;
@@ -154,6 +156,8 @@ struct pbsim_ctx {
   int64_t scratch_budget = 0;  // bytes of wave scratch per slot
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
+  int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)
+  DevBuf d_df_tables;          // crc table [256] + x^(8*128*k) [256]
 
   // per-unit statistics (pbsim.cpp:63-70, 195-196)
   int64_t res_num = 0, res_len_total = 0, res_len_min = LONG_MAX, res_len_max = 0;
@@ -925,9 +929,116 @@ int64_t pbsim_bam_header(pbsim_ctx *c, char *buf, int64_t cap) {
   return n;
 }
 
+namespace {
+
+int ensure_deflate_tables(pbsim_ctx *c) {
+  if (c->d_df_tables.p) return PBSIM_SUCCEEDED;
+  std::vector<uint32_t> t(512);
+  deflate_host_tables(t.data(), t.data() + 256);
+  if (!upload(c->d_df_tables, t.data(), t.size() * 4, c->stream)) return PBSIM_FAILED;
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return PBSIM_SUCCEEDED;
+}
+
+// d_text[0..n) (device; 16-byte aligned with 16 bytes of slack) -> gzip members at host_dst (pinned or pageable).
+// Pieces of DF_PIECE_CHUNKS chunks; the copy of piece k overlaps the kernels of piece k+1 through the two dense buffers.
+int deflate_to_host(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, char *host_dst, int64_t cap,
+                    int64_t *out_bytes) {
+  *out_bytes = 0;
+  if (n <= 0) return PBSIM_SUCCEEDED;
+  if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
+  const int64_t piece = (int64_t)DF_PIECE_CHUNKS * DF_CHUNK;
+  const int64_t max_ch = std::min<int64_t>(DF_PIECE_CHUNKS, (n + DF_CHUNK - 1) / DF_CHUNK);
+  HIP_OK(sl.d_df_slots.ensure((size_t)max_ch * DF_SLOT));
+  HIP_OK(sl.d_df_sizes.ensure((size_t)max_ch * 4));
+  HIP_OK(sl.d_df_offsets.ensure((size_t)(max_ch + 1) * 8));
+  HIP_OK(sl.h_df_total.ensure(16));
+  const uint32_t *tab = c->d_df_tables.as<uint32_t>();
+  int64_t written = 0;
+  int k = 0;
+  for (int64_t off = 0; off < n; off += piece, k ^= 1) {
+    const int64_t len = std::min(piece, n - off);
+    const int64_t nch = (len + DF_CHUNK - 1) / DF_CHUNK;
+    HIP_OK(sl.d_df_dense[k].ensure((size_t)max_ch * DF_SLOT));
+    launch_deflate(d_text + off, len, sl.d_df_slots.as<uint8_t>(), sl.d_df_sizes.as<int32_t>(),
+                   sl.d_df_offsets.as<int64_t>(), sl.d_df_dense[k].as<uint8_t>(), tab, tab + 256, sl.stream);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(sl.h_df_total.p, sl.d_df_offsets.as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
+    HIP_OK(hipStreamSynchronize(sl.stream));  // also retires the copy of piece k-1 (same stream)
+    const int64_t total = *reinterpret_cast<int64_t *>(sl.h_df_total.p);
+    if (written + total > cap) return fail("deflate: output buffer too small");
+    HIP_OK(hipMemcpyAsync(host_dst + written, sl.d_df_dense[k].p, (size_t)total, hipMemcpyDeviceToHost, sl.stream));
+    written += total;
+  }
+  HIP_OK(hipStreamSynchronize(sl.stream));
+  *out_bytes = written;
+  return PBSIM_SUCCEEDED;
+}
+
+}  // namespace
+
+int pbsim_set_deflate(pbsim_ctx *c, int on) {
+  if (!c) return fail("bad argument");
+  c->deflate = on & 3;
+  return PBSIM_SUCCEEDED;
+}
+
+int64_t pbsim_deflate_bound(int64_t n) {
+  if (n <= 0) return 0;
+  return n + ((n + DF_CHUNK - 1) / DF_CHUNK) * 31;
+}
+
+int pbsim_batch_fetch_deflated(pbsim_ctx *c, char *read_gz, int64_t read_cap, char *maf_gz, int64_t maf_cap,
+                               int64_t *read_gz_bytes, int64_t *maf_gz_bytes) {
+  if (!c || !c->s().b_finalized) return fail("pbsim_batch_fetch_deflated: no finalized batch");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  int64_t nr = 0, nm = 0;
+  if (read_gz && !deflate_to_host(c, c->s(), c->s().d_read_text.as<uint8_t>(), c->s().b_info.read_text_bytes, read_gz,
+                                  read_cap, &nr))
+    return PBSIM_FAILED;
+  if (maf_gz && !deflate_to_host(c, c->s(), c->s().d_maf_text.as<uint8_t>(), c->s().b_info.maf_text_bytes, maf_gz,
+                                 maf_cap, &nm))
+    return PBSIM_FAILED;
+  if (read_gz_bytes) *read_gz_bytes = nr;
+  if (maf_gz_bytes) *maf_gz_bytes = nm;
+  return PBSIM_SUCCEEDED;
+}
+
+// host bytes -> gzip members through the same kernels (headers, tests)
+int pbsim_deflate_buffer(pbsim_ctx *c, const void *src, int64_t n, void *dst, int64_t cap, int64_t *out_bytes) {
+  if (!c || !out_bytes || n < 0 || (n > 0 && (!src || !dst))) return fail("pbsim_deflate_buffer: bad argument");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  *out_bytes = 0;
+  if (n == 0) return PBSIM_SUCCEEDED;
+  Slot &sl = c->slots[0];
+  DevBuf d_in;
+  HIP_OK(d_in.ensure((size_t)n + 16));
+  HIP_OK(hipMemcpyAsync(d_in.p, src, (size_t)n, hipMemcpyHostToDevice, sl.stream));
+  return deflate_to_host(c, sl, d_in.as<uint8_t>(), n, (char *)dst, cap, out_bytes);
+}
+
 static int deliver(pbsim_ctx *c, const pbsim_sink *sink) {
   const pbsim_batch_info &bi = c->s().b_info;
-  if (sink) {
+  if (sink && c->deflate) {
+    const int64_t cr = pbsim_deflate_bound(bi.read_text_bytes), cm = pbsim_deflate_bound(bi.maf_text_bytes);
+    HIP_OK(c->s().h_read_text.ensure((size_t)cr + 16));
+    HIP_OK(c->s().h_maf_text.ensure((size_t)cm + 16));
+    int64_t nr = 0, nm = 0;
+    const bool zr = c->deflate & 1, zm = c->deflate & 2;
+    if (!pbsim_batch_fetch_deflated(c, sink->on_read_text && zr ? (char *)c->s().h_read_text.p : nullptr, cr,
+                                    sink->on_maf_text && zm ? (char *)c->s().h_maf_text.p : nullptr, cm, &nr, &nm))
+      return PBSIM_FAILED;
+    if (!pbsim_batch_fetch(c, zr ? nullptr : (char *)c->s().h_read_text.p, zm ? nullptr : (char *)c->s().h_maf_text.p))
+      return PBSIM_FAILED;
+    if (!zr) nr = bi.read_text_bytes;
+    if (!zm) nm = bi.maf_text_bytes;
+    if (sink->on_read_text && nr && !sink->on_read_text(sink->user, (const char *)c->s().h_read_text.p, nr))
+      return fail("sink aborted (read text)");
+    if (sink->on_maf_text && nm && !sink->on_maf_text(sink->user, (const char *)c->s().h_maf_text.p, nm))
+      return fail("sink aborted (MAF text)");
+  } else if (sink) {
     HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
     HIP_OK(c->s().h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
     if (!pbsim_batch_fetch(c, (char *)c->s().h_read_text.p, (char *)c->s().h_maf_text.p)) return PBSIM_FAILED;

@@ -15,13 +15,15 @@ def params_from_args(argv):
     return args.parse(argv)
 
 
-def run_wgs(args, device=0, scratch_mb=None):
+def run_wgs(args, device=0, scratch_mb=None, deflate=False):
     """Returns {'_0001.fq': bytes, '_0001.maf': bytes, ...} plus per-record Stats."""
     p, a = params_from_args(args)
     outs, stats = {}, []
     with P.Context(p, device) as ctx:
         if scratch_mb:
             ctx.set_scratch_bytes(scratch_mb << 20)
+        if deflate:     # the sinks then receive gzip members compressed on the GPU
+            ctx.set_deflate(True)
         if p.method == P.METHOD_ERR:
             ctx.load_errhmm(a["--errhmm"])
         else:
@@ -35,7 +37,8 @@ def run_wgs(args, device=0, scratch_mb=None):
             ctx.set_reference(r, i)
             rt, mt = ctx.simulate_wgs()
             if p.pass_num > 1:
-                rt = ctx.sam_header() + rt  # main() writes it when opening the pipe (pbsim.cpp:721-722)
+                h = ctx.sam_header()        # main() writes it when opening the pipe (pbsim.cpp:721-722)
+                rt = (ctx.deflate_buffer(h) if deflate else h) + rt
             outs["_%04d.%s" % (i, "fq" if p.pass_num == 1 else "sam")] = rt
             outs["_%04d.maf" % i] = mt
             stats.append(ctx.stats())

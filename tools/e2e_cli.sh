@@ -12,7 +12,7 @@ open(d+"/g.fa","wb").write(b">chr1\n"+out.tobytes())
 PY
 python3 -c "import sys; sys.path.insert(0,'tests'); import harness; print(harness.model_path('ERRHMM-ONT.model'))" > $d/model.txt
 M=$(cat $d/model.txt)
-for mode in "--no-gzip" ""; do
+for mode in "--no-gzip" "" "--gzip host"; do
   t0=$(date +%s.%N)
   pbsim3_amd/bin/pbsim --strategy wgs --method errhmm --errhmm $M --genome $d/g.fa --depth 20 --seed 1 --prefix $d/out $mode 2> $d/err.txt
   t1=$(date +%s.%N)
