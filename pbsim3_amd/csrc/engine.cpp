@@ -118,7 +118,7 @@ struct Slot {
   DevBuf d_scratch, d_read_text, d_maf_text;
   HostBuf h_read_text, h_maf_text, h_stats;
   DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];  // deflate staging, one piece of DF_PIECE_CHUNKS chunks
-  HostBuf h_df_total;
+  HostBuf h_df_total, h_df_out[2];
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
   bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
   int64_t b_pass0 = 0;
@@ -929,6 +929,7 @@ int64_t pbsim_bam_header(pbsim_ctx *c, char *buf, int64_t cap) {
   return n;
 }
 
+extern "C++" {
 namespace {
 
 int ensure_deflate_tables(pbsim_ctx *c) {
@@ -940,11 +941,11 @@ int ensure_deflate_tables(pbsim_ctx *c) {
   return PBSIM_SUCCEEDED;
 }
 
-// d_text[0..n) (device; 16-byte aligned with 16 bytes of slack) -> gzip members at host_dst (pinned or pageable).
-// Pieces of DF_PIECE_CHUNKS chunks; the copy of piece k overlaps the kernels of piece k+1 through the two dense buffers.
-int deflate_to_host(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, char *host_dst, int64_t cap,
-                    int64_t *out_bytes) {
-  *out_bytes = 0;
+// d_text[0..n) (device; 16-byte aligned with 16 bytes of slack) -> gzip members, handed to `consume` piece by piece
+// (DF_PIECE_CHUNKS chunks each) from pinned staging.  While the host consumes piece k-1 (a file write, a memcpy),
+// piece k is being copied down and the GPU may already be working for another slot.
+template <class F>
+int deflate_stream(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, F &&consume) {
   if (n <= 0) return PBSIM_SUCCEEDED;
   if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
   const int64_t piece = (int64_t)DF_PIECE_CHUNKS * DF_CHUNK;
@@ -954,28 +955,43 @@ int deflate_to_host(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, ch
   HIP_OK(sl.d_df_offsets.ensure((size_t)(max_ch + 1) * 8));
   HIP_OK(sl.h_df_total.ensure(16));
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
-  int64_t written = 0;
+  int64_t pending = 0;  // bytes of the previous piece, in h_df_out[k ^ 1], copy possibly still in flight
   int k = 0;
   for (int64_t off = 0; off < n; off += piece, k ^= 1) {
     const int64_t len = std::min(piece, n - off);
     const int64_t nch = (len + DF_CHUNK - 1) / DF_CHUNK;
-    HIP_OK(sl.d_df_dense[k].ensure((size_t)max_ch * DF_SLOT));
+    HIP_OK(sl.d_df_dense[k].ensure((size_t)max_ch * DF_SLOT, true));
+    HIP_OK(sl.h_df_out[k].ensure((size_t)max_ch * DF_SLOT));
     launch_deflate(d_text + off, len, sl.d_df_slots.as<uint8_t>(), sl.d_df_sizes.as<int32_t>(),
                    sl.d_df_offsets.as<int64_t>(), sl.d_df_dense[k].as<uint8_t>(), tab, tab + 256, sl.stream);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(sl.h_df_total.p, sl.d_df_offsets.as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
     HIP_OK(hipStreamSynchronize(sl.stream));  // also retires the copy of piece k-1 (same stream)
     const int64_t total = *reinterpret_cast<int64_t *>(sl.h_df_total.p);
-    if (written + total > cap) return fail("deflate: output buffer too small");
-    HIP_OK(hipMemcpyAsync(host_dst + written, sl.d_df_dense[k].p, (size_t)total, hipMemcpyDeviceToHost, sl.stream));
-    written += total;
+    HIP_OK(hipMemcpyAsync(sl.h_df_out[k].p, sl.d_df_dense[k].p, (size_t)total, hipMemcpyDeviceToHost, sl.stream));
+    if (pending && !consume((const char *)sl.h_df_out[k ^ 1].p, pending)) return PBSIM_FAILED;
+    pending = total;
   }
   HIP_OK(hipStreamSynchronize(sl.stream));
-  *out_bytes = written;
+  if (pending && !consume((const char *)sl.h_df_out[k ^ 1].p, pending)) return PBSIM_FAILED;
   return PBSIM_SUCCEEDED;
 }
 
+int deflate_to_host(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, char *host_dst, int64_t cap,
+                    int64_t *out_bytes) {
+  int64_t written = 0;
+  const int ok = deflate_stream(c, sl, d_text, n, [&](const char *z, int64_t k) {
+    if (written + k > cap) return fail("deflate: output buffer too small");
+    memcpy(host_dst + written, z, (size_t)k);
+    written += k;
+    return PBSIM_SUCCEEDED;
+  });
+  *out_bytes = written;
+  return ok;
+}
+
 }  // namespace
+}  // extern "C++"
 
 int pbsim_set_deflate(pbsim_ctx *c, int on) {
   if (!c) return fail("bad argument");
@@ -1022,22 +1038,37 @@ int pbsim_deflate_buffer(pbsim_ctx *c, const void *src, int64_t n, void *dst, in
 static int deliver(pbsim_ctx *c, const pbsim_sink *sink) {
   const pbsim_batch_info &bi = c->s().b_info;
   if (sink && c->deflate) {
-    const int64_t cr = pbsim_deflate_bound(bi.read_text_bytes), cm = pbsim_deflate_bound(bi.maf_text_bytes);
-    HIP_OK(c->s().h_read_text.ensure((size_t)cr + 16));
-    HIP_OK(c->s().h_maf_text.ensure((size_t)cm + 16));
-    int64_t nr = 0, nm = 0;
+    // compressed sinks stream piece by piece; a sink left as text is fetched whole as before
     const bool zr = c->deflate & 1, zm = c->deflate & 2;
-    if (!pbsim_batch_fetch_deflated(c, sink->on_read_text && zr ? (char *)c->s().h_read_text.p : nullptr, cr,
-                                    sink->on_maf_text && zm ? (char *)c->s().h_maf_text.p : nullptr, cm, &nr, &nm))
+    NEED_DEVICE(c);
+    HIP_OK(hipSetDevice(c->device));
+    if (!zr) HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
+    if (!zm) HIP_OK(c->s().h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
+    if ((!zr || !zm) &&
+        !pbsim_batch_fetch(c, zr ? nullptr : (char *)c->s().h_read_text.p, zm ? nullptr : (char *)c->s().h_maf_text.p))
       return PBSIM_FAILED;
-    if (!pbsim_batch_fetch(c, zr ? nullptr : (char *)c->s().h_read_text.p, zm ? nullptr : (char *)c->s().h_maf_text.p))
-      return PBSIM_FAILED;
-    if (!zr) nr = bi.read_text_bytes;
-    if (!zm) nm = bi.maf_text_bytes;
-    if (sink->on_read_text && nr && !sink->on_read_text(sink->user, (const char *)c->s().h_read_text.p, nr))
-      return fail("sink aborted (read text)");
-    if (sink->on_maf_text && nm && !sink->on_maf_text(sink->user, (const char *)c->s().h_maf_text.p, nm))
-      return fail("sink aborted (MAF text)");
+    if (sink->on_read_text && bi.read_text_bytes) {
+      if (!zr) {
+        if (!sink->on_read_text(sink->user, (const char *)c->s().h_read_text.p, bi.read_text_bytes))
+          return fail("sink aborted (read text)");
+      } else if (!deflate_stream(c, c->s(), c->s().d_read_text.as<uint8_t>(), bi.read_text_bytes,
+                                 [&](const char *z, int64_t k) {
+                                   return sink->on_read_text(sink->user, z, k) ? PBSIM_SUCCEEDED
+                                                                               : fail("sink aborted (read text)");
+                                 }))
+        return PBSIM_FAILED;
+    }
+    if (sink->on_maf_text && bi.maf_text_bytes) {
+      if (!zm) {
+        if (!sink->on_maf_text(sink->user, (const char *)c->s().h_maf_text.p, bi.maf_text_bytes))
+          return fail("sink aborted (MAF text)");
+      } else if (!deflate_stream(c, c->s(), c->s().d_maf_text.as<uint8_t>(), bi.maf_text_bytes,
+                                 [&](const char *z, int64_t k) {
+                                   return sink->on_maf_text(sink->user, z, k) ? PBSIM_SUCCEEDED
+                                                                              : fail("sink aborted (MAF text)");
+                                 }))
+        return PBSIM_FAILED;
+    }
   } else if (sink) {
     HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
     HIP_OK(c->s().h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
