@@ -145,6 +145,10 @@ def default_params(**kw):
     return p
 
 
+# empty BGZF block: the end-of-file marker of a BAM file (SAMv1 4.1.2), also a valid empty gzip member
+BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
 class Context:
     """One GPU context (pbsim_ctx).  device=-1 gives a tables-only context that
     can build and dump host tables but refuses every compute call."""
@@ -280,6 +284,25 @@ class Context:
         m = C.create_string_buffer(max(1, info.maf_text_bytes))
         _check(self.lib.pbsim_batch_fetch(self.h, C.cast(r, C.c_void_p), C.cast(m, C.c_void_p)))
         return r.raw[:info.read_text_bytes], m.raw[:info.maf_text_bytes]
+
+    def batch_fetch_deflated(self, info):
+        """(read members, maf members): the batch's text as BGZF-framed gzip members compressed on the GPU"""
+        cr = self.lib.pbsim_deflate_bound(info.read_text_bytes) + 16
+        cm = self.lib.pbsim_deflate_bound(info.maf_text_bytes) + 16
+        r, m = C.create_string_buffer(cr), C.create_string_buffer(cm)
+        nr, nm = C.c_int64(0), C.c_int64(0)
+        _check(self.lib.pbsim_batch_fetch_deflated(self.h, C.cast(r, C.c_void_p), cr, C.cast(m, C.c_void_p), cm,
+                                                   C.byref(nr), C.byref(nm)))
+        return r.raw[:nr.value], m.raw[:nm.value]
+
+    def set_bam_output(self, on=True):
+        _check(self.lib.pbsim_set_bam_output(self.h, 1 if on else 0))
+
+    def bam_header(self):
+        n = self.lib.pbsim_bam_header(self.h, None, 0)
+        buf = C.create_string_buffer(n)
+        self.lib.pbsim_bam_header(self.h, buf, n)
+        return buf.raw[:n]
 
     def batch_account(self):
         _check(self.lib.pbsim_batch_account(self.h))

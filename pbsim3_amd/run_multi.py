@@ -8,7 +8,9 @@ Rank 0 reads the FASTA and broadcasts each record (C1); every rank walks its rea
 in read order; counters are reduced at the end of each record (C2).  The FASTQ/MAF bytes equal the
 single-GPU `pbsim --no-gzip` output; the report is the reference's stderr block.
 Extra options: --batch-reads N (reads per rank per round), --scratch-mb M, --backend nccl|gloo,
---one-gpu (all ranks on device 0: plumbing check on a single-GPU box).
+--one-gpu (all ranks on device 0: plumbing check on a single-GPU box), --gzip (every rank compresses
+its text on its GPU; gzip members are self-contained, so stitching them in read order gives valid
+<prefix>_NNNN.fq.gz / .maf.gz, and .bam for --pass-num > 1, whose decompressed bytes are the same).
 """
 import os
 import sys
@@ -18,7 +20,7 @@ import numpy as np
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    flags = {"--one-gpu": False}
+    flags = {"--one-gpu": False, "--gzip": False}
     for f in list(flags):
         if f in argv:
             argv.remove(f)
@@ -88,11 +90,15 @@ def main(argv=None):
         ctx.reset_stats()
         batch = int(a.get("--batch-reads", 0)) or max(1, ctx.batch_capacity())
         part = "%s_%04d.rank%d" % (prefix, i + 1, rank)
+        gz = flags["--gzip"]
         ext = "fq" if p.pass_num == 1 else "sam"
+        if gz and p.pass_num > 1:
+            ctx.set_bam_output(True)
+        out_ext, maf_ext = ((ext + ".gz") if p.pass_num == 1 else "bam", "maf.gz") if gz else (ext, "maf")
         index = []                                         # (first_read, bytes of read text, bytes of maf text)
         with open(part + "." + ext, "wb") as fr, open(part + ".maf", "wb") as fm:
             def on_batch(info):
-                rt, mt = ctx.batch_fetch(info)
+                rt, mt = ctx.batch_fetch_deflated(info) if gz else ctx.batch_fetch(info)
                 fr.write(rt)
                 fm.write(mt)
                 ctx.batch_account()
@@ -117,9 +123,10 @@ def main(argv=None):
                     off_r += nr
                     off_m += nm
             pieces.sort()
-            with open("%s_%04d.%s" % (prefix, i + 1, ext), "wb") as fr, open("%s_%04d.maf" % (prefix, i + 1), "wb") as fm:
+            with open("%s_%04d.%s" % (prefix, i + 1, out_ext), "wb") as fr, \
+                    open("%s_%04d.%s" % (prefix, i + 1, maf_ext), "wb") as fm:
                 if p.pass_num > 1:
-                    fr.write(ctx.sam_header())
+                    fr.write(ctx.deflate_buffer(ctx.bam_header()) if gz else ctx.sam_header())
                 files = {r: (open("%s_%04d.rank%d.%s" % (prefix, i + 1, r, ext), "rb"),
                              open("%s_%04d.rank%d.maf" % (prefix, i + 1, r), "rb")) for r in range(world)}
                 for first, r, off_r, nr, off_m, nm in pieces:
@@ -130,6 +137,11 @@ def main(argv=None):
                 for r in files:
                     files[r][0].close()
                     files[r][1].close()
+                if gz:    # BAM: the BGZF end-of-file marker; .gz: an empty member keeps an empty output a valid gzip file
+                    if p.pass_num > 1 or fr.tell() == 0:
+                        fr.write(P.BGZF_EOF)
+                    if fm.tell() == 0:
+                        fm.write(P.BGZF_EOF)
         if world > 1:
             dist.barrier()
         os.remove(part + "." + ext)

@@ -30,3 +30,35 @@ def test_run_multi_two_ranks(case, batch, tmp_path):
     for k in keys:
         assert harness.sha(outs[k]) == want[k]["sha256"], k
     assert not [k for k in outs if ".rank" in k]
+
+
+@pytest.mark.parametrize("case,batch", [("wgs_errhmm-ont_quirk", "9"), ("wgs_qshmm_rsii_pass3", "5")])
+def test_run_multi_gzip_members_stitch(case, batch, tmp_path):
+    """--gzip: every rank compresses on its GPU; the stitched members inflate to the golden bytes
+    (.bam: a BGZF container whose payload starts with the BAM header and ends with the EOF marker)"""
+    import gzip
+    args = harness.resolve(CASES[case]["args"])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(31500 + os.getpid() % 1000), "-m", "pbsim3_amd.run_multi"] + args + \
+          ["--prefix", str(tmp_path / "out"), "--backend", "gloo", "--one-gpu", "--batch-reads", batch, "--scratch-mb", "256",
+           "--gzip"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=harness.ROOT,
+                       env=dict(os.environ, PYTHONPATH=harness.ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    want = MANIFEST[f"{case}/philox"]
+    names = sorted(os.listdir(tmp_path))
+    assert not [n for n in names if ".rank" in n]
+    seen = 0
+    for n in names:
+        raw = open(tmp_path / n, "rb").read()
+        if n.endswith((".fq.gz", ".maf.gz")):
+            key = n[len("out"):-3]
+            assert harness.sha(gzip.decompress(raw)) == want[key]["sha256"], n
+            seen += 1
+        elif n.endswith(".bam"):
+            import pbsim3_amd as P
+            assert raw.endswith(P.BGZF_EOF)
+            body = gzip.decompress(raw)
+            assert body[:4] == b"BAM\x01" and b"@HD\tVN:1.5" in body[:64]
+            seen += 1
+    assert seen >= 2
