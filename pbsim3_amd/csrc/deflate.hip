@@ -23,6 +23,7 @@
 //             as full dwords
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -42,17 +43,34 @@ constexpr uint32_t kPoly = 0xEDB88320u;
 constexpr int kHeadBits = 18 * 8;         // BGZF header bytes in front of the deflate payload
 constexpr int kPrefixBits = 3 + 5 + 5 + 4 + 19 * 3;
 
-// fixed code for the code-length alphabet (tests/deflate_model.py CL_LEN): 0,17,18 -> 3 bits; 2,3,4,12 -> 4; rest 5
-__device__ constexpr uint8_t kClLen[19] = {3, 5, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 4, 5, 5, 5, 5, 3, 3};
-__device__ constexpr uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+// fixed code for the code-length alphabet (tests/deflate_model.py CL_LEN): 0,17,18 -> 3 bits; 2,3,4,12 -> 4; rest 5.
+// Everything derived from it is a compile-time constant: no table in memory on the kernel's critical path.
+constexpr int kClLenTab[19] = {3, 5, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 4, 5, 5, 5, 5, 3, 3};
+constexpr int kClOrderTab[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+constexpr uint64_t pack_cl_len() {
+  uint64_t v = 0;
+  for (int s = 0; s < 19; ++s) v |= (uint64_t)kClLenTab[s] << (3 * s);
+  return v;
+}
+constexpr uint64_t kClLenPacked = pack_cl_len();   // 3 bits per symbol
+__device__ __forceinline__ uint32_t cl_len(uint32_t s) { return (uint32_t)(kClLenPacked >> (3 * s)) & 7u; }
+// block prefix after the 18 BGZF bytes: BFINAL=1, BTYPE=2, HLIT-257 (5 bits, added at run time), HDIST-1 = 0,
+// HCLEN-4 = 15, then the 19 code-length code lengths in the order of RFC 1951 3.2.7: 74 bits
+constexpr unsigned __int128 pack_prefix() {
+  unsigned __int128 v = 1u | (2u << 1) | ((unsigned __int128)15 << 13);
+  for (int i = 0; i < 19; ++i) v |= (unsigned __int128)kClLenTab[kClOrderTab[i]] << (17 + 3 * i);
+  return v;
+}
+constexpr uint64_t kPrefixLo = (uint64_t)pack_prefix();
+constexpr uint32_t kPrefixHi = (uint32_t)(pack_prefix() >> 64);
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t code, uint32_t len) { return __brev(code) >> (32 - len); }
 
-// canonical code of code-length symbol s under kClLen, bit-reversed for the LSB-first stream
+// canonical code of code-length symbol s, bit-reversed for the LSB-first stream
 __device__ __forceinline__ uint32_t cl_code(uint32_t s) {
   // per length: first canonical code and the symbols in index order
   // len 3: {0,17,18} -> 0,1,2 ; len 4: {2,3,4,12} -> 6,7,8,9 ; len 5: {1,5,6,7,8,9,10,11,13,14,15,16} -> 20..31
-  uint32_t c, l = kClLen[s];
+  uint32_t c, l = cl_len(s);
   if (l == 3) c = s == 0 ? 0 : s - 16;
   else if (l == 4) c = s == 12 ? 9 : 4 + s;
   else c = s == 1 ? 20 : s <= 11 ? 16 + s : 15 + s;
@@ -143,57 +161,113 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s_wave
   return base + inc - v;
 }
 
-// Walks the tokens of one thread's segment: fn_lit(byte) / fn_match(length).
-// seg = the thread's 32 dwords in the padded LDS image, prev = byte before the segment (0x100 at chunk start).
-template <class FL, class FM>
-__device__ __forceinline__ void walk_tokens(const uint32_t *seg, int nbytes, uint32_t prev, FL &&fn_lit, FM &&fn_match) {
-  uint32_t run = 0;
-  for (int j = 0; j < kSegDw; ++j) {
-    if (4 * j >= nbytes) break;
-    const uint32_t w = seg[j];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (4 * j + k < nbytes) {
-        const uint32_t b = (w >> (8 * k)) & 255u;
-        if (b == prev) {
-          ++run;
-        } else {
-          if (run >= 3) fn_match(run);
-          else if (run == 2) { fn_lit(prev); fn_lit(prev); }
-          else if (run == 1) fn_lit(prev);
-          run = 0;
-          fn_lit(b);
-          prev = b;
-        }
-      }
-    }
+// 128 positions of one thread's segment as bit masks
+struct Mask128 {
+  uint64_t lo, hi;
+};
+__device__ __forceinline__ Mask128 m_and(Mask128 a, Mask128 b) { return {a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ Mask128 m_or(Mask128 a, Mask128 b) { return {a.lo | b.lo, a.hi | b.hi}; }
+__device__ __forceinline__ Mask128 m_not(Mask128 a) { return {~a.lo, ~a.hi}; }
+template <int K>
+__device__ __forceinline__ Mask128 m_shl(Mask128 a) { return {a.lo << K, (a.hi << K) | (a.lo >> (64 - K))}; }
+template <int K>
+__device__ __forceinline__ Mask128 m_shr(Mask128 a) { return {(a.lo >> K) | (a.hi << (64 - K)), a.hi >> K}; }
+__device__ __forceinline__ uint32_t m_nibble(Mask128 a, int j) {  // bits 4j..4j+3
+  return (uint32_t)((j < 16 ? a.lo >> (4 * j) : a.hi >> (4 * j - 64)) & 15u);
+}
+__device__ __forceinline__ int m_first(Mask128 a) { return a.lo ? __builtin_ctzll(a.lo) : 64 + __builtin_ctzll(a.hi); }
+__device__ __forceinline__ Mask128 m_clear(Mask128 a, int pos) {
+  if (pos < 64) a.lo &= ~(1ull << pos);
+  else a.hi &= ~(1ull << (pos - 64));
+  return a;
+}
+// number of consecutive set bits of m starting at pos (m has bit pos set)
+__device__ __forceinline__ int m_run(Mask128 m, int pos) {
+  uint64_t lo, hi;
+  if (pos == 0) {
+    lo = m.lo;
+    hi = m.hi;
+  } else if (pos < 64) {
+    lo = (m.lo >> pos) | (m.hi << (64 - pos));
+    hi = m.hi >> pos;
+  } else {
+    lo = m.hi >> (pos - 64);
+    hi = 0;
   }
-  if (run >= 3) fn_match(run);
-  else if (run == 2) { fn_lit(prev); fn_lit(prev); }
-  else if (run == 1) fn_lit(prev);
+  if (~lo) return __builtin_ctzll(~lo);
+  return ~hi ? 64 + __builtin_ctzll(~hi) : 128;
+}
+
+// Token structure of a segment (tests/deflate_model.py tokenize): a position whose byte equals its predecessor is a
+// run position; maximal groups of >= 3 run positions become one distance-1 match, every other position is a literal.
+struct SegTokens {
+  Mask128 lit;    // literal positions
+  Mask128 start;  // first position of each match
+  Mask128 cover;  // positions covered by matches
+};
+
+__device__ __forceinline__ SegTokens seg_tokens(const uint32_t *seg, int seg_n, uint32_t prev_dword, bool chunk_start) {
+  uint64_t e[2] = {0, 0};
+  uint32_t pw = prev_dword;
+#pragma unroll
+  for (int j = 0; j < kSegDw; ++j) {
+    const uint32_t w = seg[j];
+    const uint32_t d = w ^ ((w << 8) | (pw >> 24));
+    const uint32_t z = ~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d | 0x7F7F7F7Fu);  // 0x80 in every byte equal to its predecessor
+    const uint32_t nib = (((z >> 7) * 0x00204081u) >> 21) & 15u;
+    e[j >> 4] |= (uint64_t)nib << (4 * (j & 15));
+    pw = w;
+  }
+  Mask128 valid;
+  valid.lo = seg_n >= 64 ? ~0ull : (1ull << seg_n) - 1;
+  valid.hi = seg_n >= 128 ? ~0ull : seg_n > 64 ? (1ull << (seg_n - 64)) - 1 : 0ull;
+  Mask128 eq = {e[0] & valid.lo, e[1] & valid.hi};
+  if (chunk_start) eq.lo &= ~1ull;
+  const Mask128 r3 = m_and(eq, m_and(m_shr<1>(eq), m_shr<2>(eq)));
+  SegTokens t;
+  t.cover = m_or(r3, m_or(m_shl<1>(r3), m_shl<2>(r3)));
+  t.start = m_and(t.cover, m_not(m_shl<1>(t.cover)));
+  t.lit = m_and(valid, m_not(t.cover));
+  return t;
 }
 
 __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__restrict__ text, int64_t n_bytes,
                                                               uint8_t *__restrict__ slots, int32_t *__restrict__ sizes,
                                                               const uint32_t *__restrict__ crc_table,
-                                                              const uint32_t *__restrict__ pow128, uint32_t x8rem) {
+                                                              const uint32_t *__restrict__ pow128, uint32_t x8rem,
+                                                              unsigned long long *__restrict__ prof) {
   __shared__ uint32_t s_in[kInDw];
   __shared__ uint32_t s_out[kOutDw];
-  __shared__ uint32_t s_hist[kSyms];
+  __shared__ uint32_t s_hist[4 * kSyms + 64];  // four copies, by lane & 3, against same-address serialisation; + one dummy bin per lane
   __shared__ uint32_t s_code[kSyms];     // reversed code | length << 16
+  __shared__ uint32_t s_ufreq[kSyms];    // used symbols in symbol order: frequency
   __shared__ uint32_t s_sfreq[kSyms];    // frequencies in sorted order
   __shared__ uint32_t s_w[kSyms];        // internal node weights
-  __shared__ uint16_t s_sorted[kSyms];   // symbols, ascending (freq, symbol)
+  __shared__ uint16_t s_usym[kSyms];     // used symbols in symbol order
+  __shared__ uint16_t s_sorted[kSyms];   // used symbols, ascending (freq, symbol)
   __shared__ uint16_t s_par[kSyms];      // parent of internal node
   __shared__ uint16_t s_leafpar[kSyms];  // parent of leaf
   __shared__ uint16_t s_dep[kSyms];      // depth of internal node
-  __shared__ uint8_t s_len[kSyms];
-  __shared__ uint32_t s_crc[256];
+  __shared__ uint8_t s_len[kSyms];       // code length by symbol
+  __shared__ uint8_t s_ulen[kSyms];      // code length by used index
+  __shared__ uint32_t s_crc[1024];       // slice-by-4 tables
+  __shared__ uint64_t s_nz[5];           // header positions with a non-zero code length (bits >= npos set)
   __shared__ uint32_t s_cnt[16], s_first[16];
   __shared__ uint32_t s_wave[kThreads / 64];
-  __shared__ uint32_t s_misc[4];         // 0 n_used, 1 any_match, 2 max symbol, 3 crc
+  __shared__ uint32_t s_wcnt[8];
+  __shared__ uint32_t s_misc[4];         // 0 n_used, 1 any_match, 3 crc
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long t_prev = prof ? wall_clock64() : 0;
+  int phase = 0;
+  auto mark = [&]() {   // PBSIM_DEFLATE_PROF: per-phase time of lane 0, summed over chunks (100 MHz ticks)
+    if (prof && tid == 0) {
+      const unsigned long long t = wall_clock64();
+      atomicAdd(&prof[phase], t - t_prev);
+      t_prev = t;
+    }
+    ++phase;
+  };
   const int64_t chunk = blockIdx.x;
   const int64_t base = chunk * (int64_t)kChunk;
   const int n = (int)((n_bytes - base) < (int64_t)kChunk ? (n_bytes - base) : (int64_t)kChunk);
@@ -215,41 +289,55 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
     }
     for (int i = tid; i < kOutDw; i += kThreads) s_out[i] = 0;
     for (int i = tid; i < kSyms; i += kThreads) {
-      s_hist[i] = 0;
       s_code[i] = 0;
       s_len[i] = 0;
     }
-    s_crc[tid] = crc_table[tid];
+    for (int i = tid; i < 4 * kSyms + 64; i += kThreads) s_hist[i] = 0;
+    for (int i = tid; i < 1024; i += kThreads) s_crc[i] = crc_table[i];
     if (tid < 16) s_cnt[tid] = 0;
     if (tid < 4) s_misc[tid] = 0;
   }
   __syncthreads();
+  mark();  // 0 stage
 
   const int beg = tid * kSeg;
   const int seg_n = n - beg < 0 ? 0 : (n - beg < kSeg ? n - beg : kSeg);
   const uint32_t *seg = &s_in[tid * (kSegDw + 1)];
-  uint32_t prev0 = 0x100;
-  if (tid > 0 && seg_n > 0) prev0 = s_in[tid * (kSegDw + 1) - 2] >> 24;  // last byte of the previous segment
+  const SegTokens tk = seg_tokens(seg, seg_n, tid ? s_in[tid * (kSegDw + 1) - 2] : 0u, tid == 0);
+  const int seg_dw = (seg_n + 3) >> 2;
 
   // ---- pass 1: histogram + CRC of the segment
   {
-    bool any = false;
-    walk_tokens(
-        seg, seg_n, prev0, [&](uint32_t b) { atomicAdd(&s_hist[b], 1u); },
-        [&](uint32_t L) {
-          uint32_t s, eb, ev;
-          length_symbol(L, &s, &eb, &ev);
-          atomicAdd(&s_hist[s], 1u);
-          any = true;
-        });
-    if (any) s_misc[1] = 1;
-    uint32_t c = tid == 0 ? 0xFFFFFFFFu : 0u;
-    for (int j = 0; j < kSegDw; ++j) {
-      if (4 * j >= seg_n) break;
+    uint32_t *hist = &s_hist[(lane & 3) * kSyms];
+    const uint32_t copy = (lane & 3) * kSyms, dummy = 4 * kSyms + lane;   // non-literal positions count into the lane's dummy bin
+#pragma unroll 2
+    for (int j = 0; j < seg_dw; ++j) {
+      const uint32_t nl = m_nibble(tk.lit, j);
+      if (nl == 0) continue;
       const uint32_t w = seg[j];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (4 * j + k < seg_n) c = s_crc[(c ^ (w >> (8 * k))) & 255u] ^ (c >> 8);
+        atomicAdd(&s_hist[((nl >> k) & 1u) ? copy + ((w >> (8 * k)) & 255u) : dummy], 1u);
+    }
+    Mask128 st = tk.start;
+    if (st.lo | st.hi) s_misc[1] = 1;
+    while (st.lo | st.hi) {
+      const int pos = m_first(st);
+      st = m_clear(st, pos);
+      uint32_t s, eb, ev;
+      length_symbol((uint32_t)m_run(tk.cover, pos), &s, &eb, &ev);
+      atomicAdd(&hist[s], 1u);
+    }
+    uint32_t c = tid == 0 ? 0xFFFFFFFFu : 0u;
+    const int full = seg_n >> 2;
+#pragma unroll 4
+    for (int j = 0; j < full; ++j) {
+      const uint32_t x = c ^ seg[j];
+      c = s_crc[768 + (x & 255u)] ^ s_crc[512 + ((x >> 8) & 255u)] ^ s_crc[256 + ((x >> 16) & 255u)] ^ s_crc[x >> 24];
+    }
+    if (seg_n & 3) {
+      const uint32_t w = seg[full];
+      for (int k = 0; k < (seg_n & 3); ++k) c = s_crc[(c ^ (w >> (8 * k))) & 255u] ^ (c >> 8);
     }
     // bytes after this segment = 128 * (q - tid - 1) + r for full segments, 0 for the last (partial) one
     const int q = n >> 7, r = n & 127;
@@ -260,33 +348,59 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
     if (seg_n == 0) c = 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
-    if ((tid & 63) == 0) atomicXor(&s_misc[3], c);
+    if (lane == 0) atomicXor(&s_misc[3], c);
     if (tid == 0) s_hist[256] = 1;  // end of block
   }
   __syncthreads();
+  mark();  // 1 histogram + crc
 
-  // ---- rank sort of the used symbols by (freq, symbol)
+  // ---- used symbols in symbol order, then rank sort by (freq, symbol)
   {
-    for (int s = tid; s < 286; s += kThreads) {
-      const uint32_t f = s_hist[s];
-      if (f) {
-        uint32_t rank = 0;
-        for (int u = 0; u < 286; ++u) {
-          const uint32_t g = s_hist[u];
-          rank += (g != 0) & ((g < f) | ((g == f) & (u < s)));
-        }
-        s_sorted[rank] = (uint16_t)s;
-        s_sfreq[rank] = f;
-        atomicAdd(&s_misc[0], 1u);
-        atomicMax(&s_misc[2], (uint32_t)s);
+    uint32_t f[2], pre[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int s = tid + h * kThreads;
+      f[h] = s < 286 ? s_hist[s] + s_hist[kSyms + s] + s_hist[2 * kSyms + s] + s_hist[3 * kSyms + s] : 0u;
+      const uint64_t b = __ballot(f[h] != 0);
+      pre[h] = (uint32_t)__popcll(b & ((1ull << lane) - 1));
+      if (lane == 0) s_wcnt[h * 4 + wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t x = s_wcnt[i];
+      if (i < wave) pre[0] += x;
+      if (i < 4 + wave) pre[1] += x;
+      m += x;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (f[h]) {
+        s_usym[pre[h]] = (uint16_t)(tid + h * kThreads);
+        s_ufreq[pre[h]] = f[h];
       }
+    if (tid == 0) s_misc[0] = m;
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += kThreads) {
+      const uint32_t fi = s_ufreq[i];
+      uint32_t rank = 0;
+#pragma unroll 4
+      for (uint32_t u = 0; u < m; ++u) {
+        const uint32_t g = s_ufreq[u];
+        rank += (g < fi) | ((g == fi) & (u < i));
+      }
+      s_sorted[rank] = s_usym[i];
+      s_sfreq[rank] = fi;
     }
   }
   __syncthreads();
+  mark();  // 2 sort
 
   // ---- Huffman depths (one lane; n_used is a few dozen for this text), limited to 15 bits
+  const int m_used = (int)s_misc[0];
   if (tid == 0) {
-    const int m = (int)s_misc[0];
+    const int m = m_used;
     if (m == 1) {
       s_cnt[1] = 1;
     } else {
@@ -338,66 +452,100 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
     }
   }
   __syncthreads();
+  mark();  // 3 huffman build
 
-  // ---- canonical codes
-  for (int s = tid; s < 286; s += kThreads) {
-    const uint32_t l = s_len[s];
-    if (l) {
-      uint32_t idx = 0;
-      for (int u = 0; u < s; ++u) idx += s_len[u] == l;
-      s_code[s] = rev_bits(s_first[l] + idx, l) | (l << 16);
+  // ---- canonical codes: index among the used symbols of the same length, in symbol order
+  for (int i = tid; i < m_used; i += kThreads) s_ulen[i] = s_len[s_usym[i]];
+  __syncthreads();
+  for (int i = tid; i < m_used; i += kThreads) {
+    const uint32_t l = s_ulen[i];
+    uint32_t idx = 0;
+#pragma unroll 4
+    for (int u = 0; u < i; ++u) idx += s_ulen[u] == l;
+    s_code[s_usym[i]] = rev_bits(s_first[l] + idx, l) | (l << 16);
+  }
+  const uint32_t any_match = s_misc[1];
+  const int hlit = (int)s_usym[m_used - 1] + 1;   // >= 257: symbol 256 is always used
+  const int npos = hlit + 1;                       // + the one distance code length
+  {  // non-zero mask of the header's code length sequence
+    const int p0 = tid;
+    const uint32_t v0 = p0 < hlit ? s_len[p0] : (p0 == hlit ? any_match : 1u);
+    const uint64_t b0 = __ballot(v0 != 0);
+    if (lane == 0) s_nz[wave] = b0;
+    if (wave == 0) {
+      const int p1 = 256 + lane;
+      const uint32_t v1 = p1 < hlit ? s_len[p1] : (p1 == hlit ? any_match : 1u);
+      const uint64_t b1 = __ballot(v1 != 0);
+      if (lane == 0) s_nz[4] = b1;
     }
   }
   __syncthreads();
+  mark();  // 4 canonical codes
 
   // ---- sizes: header symbols (two positions per thread) and the thread's tokens
-  const uint32_t any_match = s_misc[1];
-  const int hlit = (int)s_misc[2] + 1;   // >= 257: symbol 256 is always used
-  const int npos = hlit + 1;             // + the one distance code length
   uint64_t hbits[2] = {0, 0};
   uint32_t hn[2] = {0, 0};
+#pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int p = 2 * tid + h;
     if (p >= npos) continue;
     const uint32_t v = p < hlit ? s_len[p] : any_match;
     if (v) {
       hbits[h] = cl_code(v);
-      hn[h] = kClLen[v];
-    } else {
-      const uint32_t before = p == 0 ? 1u : (p - 1 < hlit ? s_len[p - 1] : any_match);
-      if (before != 0) {  // first zero of a run
-        int r = 1;
-        while (p + r < npos && (p + r < hlit ? s_len[p + r] : any_match) == 0) ++r;
-        uint64_t acc = 0;
-        uint32_t nb = 0;
-        while (r >= 11) {
-          const int t = r < 138 ? r : 138;
-          acc |= (uint64_t)(cl_code(18) | ((uint32_t)(t - 11) << 3)) << nb;
-          nb += 10;
-          r -= t;
-        }
-        if (r >= 3) {
-          acc |= (uint64_t)(cl_code(17) | ((uint32_t)(r - 3) << 3)) << nb;
-          nb += 6;
-          r = 0;
-        }
-        for (; r > 0; --r) {
-          acc |= (uint64_t)cl_code(0) << nb;
-          nb += 3;
-        }
-        hbits[h] = acc;
-        hn[h] = nb;
+      hn[h] = cl_len(v);
+    } else if (p == 0 || ((s_nz[(p - 1) >> 6] >> ((p - 1) & 63)) & 1ull)) {  // first zero of a run
+      // run length = distance to the next non-zero position (bits >= npos are set)
+      int wi = p >> 6;
+      uint64_t bits = s_nz[wi] >> (p & 63);   // bit 0 (position p) is clear
+      int r;
+      if (bits) {
+        r = __builtin_ctzll(bits);
+      } else {
+        r = 64 - (p & 63);
+        for (++wi; s_nz[wi] == 0; ++wi) r += 64;
+        r += __builtin_ctzll(s_nz[wi]);
       }
+      uint64_t acc = 0;
+      uint32_t nb = 0;
+      while (r >= 11) {
+        const int t = r < 138 ? r : 138;
+        acc |= (uint64_t)(cl_code(18) | ((uint32_t)(t - 11) << 3)) << nb;
+        nb += 10;
+        r -= t;
+      }
+      if (r >= 3) {
+        acc |= (uint64_t)(cl_code(17) | ((uint32_t)(r - 3) << 3)) << nb;
+        nb += 6;
+        r = 0;
+      }
+      for (; r > 0; --r) {
+        acc |= (uint64_t)cl_code(0) << nb;
+        nb += 3;
+      }
+      hbits[h] = acc;
+      hn[h] = nb;
     }
   }
   uint32_t tok_bits = 0;
-  walk_tokens(
-      seg, seg_n, prev0, [&](uint32_t b) { tok_bits += s_code[b] >> 16; },
-      [&](uint32_t L) {
-        uint32_t s, eb, ev;
-        length_symbol(L, &s, &eb, &ev);
-        tok_bits += (s_code[s] >> 16) + eb + 1;
-      });
+  {
+#pragma unroll 2
+    for (int j = 0; j < seg_dw; ++j) {
+      const uint32_t nl = m_nibble(tk.lit, j);
+      if (nl == 0) continue;
+      const uint32_t w = seg[j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)   // s_code[287] is never assigned: zero length for non-literal positions
+        tok_bits += s_code[((nl >> k) & 1u) ? (w >> (8 * k)) & 255u : 287u] >> 16;
+    }
+    Mask128 st = tk.start;
+    while (st.lo | st.hi) {
+      const int pos = m_first(st);
+      st = m_clear(st, pos);
+      uint32_t s, eb, ev;
+      length_symbol((uint32_t)m_run(tk.cover, pos), &s, &eb, &ev);
+      tok_bits += (s_code[s] >> 16) + eb + 1;
+    }
+  }
   uint32_t hdr_total, tok_total;
   const uint32_t hdr_off = block_scan_excl(hn[0] + hn[1], s_wave, &hdr_total);
   const uint32_t tok_off = block_scan_excl(tok_bits, s_wave, &tok_total);
@@ -406,6 +554,7 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
   const uint32_t payload_bytes = (payload_bits + 7) >> 3;
   const bool huff = (18 + payload_bytes + 8 <= (uint32_t)kOutBytes) && (payload_bytes < (uint32_t)n + 5);
   const uint32_t crc = s_misc[3] ^ 0xFFFFFFFFu;
+  mark();  // 5 sizes + scans
 
   if (huff) {
     const uint32_t member = 18 + payload_bytes + 8;
@@ -418,15 +567,12 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       BitWriter bw;
       bw.init(s_out, 16 * 8);
       bw.put(member - 1, 16);
-      bw.put(1, 1);            // BFINAL
-      bw.put(2, 2);            // dynamic Huffman
-      bw.put(hlit - 257, 5);
-      bw.put(0, 5);            // HDIST = 1
-      bw.put(15, 4);           // HCLEN = 19
-      for (int i = 0; i < 19; ++i) bw.put(kClLen[kClOrder[i]], 3);
+      bw.put64(kPrefixLo | ((uint64_t)(hlit - 257) << 3), 64);
+      bw.put(kPrefixHi, kPrefixBits - 64);
       bw.flush();
     }
     __syncthreads();  // the plain stores above precede everybody's ds_or
+    mark();  // 6 prefix
     {
       BitWriter bw;
       bw.init(s_out, kHeadBits + kPrefixBits + hdr_off);
@@ -434,24 +580,46 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       bw.put64(hbits[1], hn[1]);
       bw.flush();
     }
+    mark();  // 7 header symbols
     {
       BitWriter bw;
       bw.init(s_out, kHeadBits + kPrefixBits + hdr_total + tok_off);
-      walk_tokens(
-          seg, seg_n, prev0,
-          [&](uint32_t b) {
-            const uint32_t c = s_code[b];
-            bw.put(c & 0xFFFFu, c >> 16);
-          },
-          [&](uint32_t L) {
-            uint32_t s, eb, ev;
-            length_symbol(L, &s, &eb, &ev);
-            const uint32_t c = s_code[s];
-            // code, extra bits, then the single distance code (one 0 bit)
-            bw.put((c & 0xFFFFu) | (ev << (c >> 16)), (c >> 16) + eb + 1);
-          });
+      // (code size matters here: the loop must stay resident in the instruction cache, so the rare
+      // match path is a rolled loop and nothing is unrolled across dwords)
+#pragma unroll 2
+      for (int j = 0; j < seg_dw; ++j) {
+        const uint32_t nl = m_nibble(tk.lit, j), ns = m_nibble(tk.start, j);
+        if ((nl | ns) == 0) continue;   // inside a match
+        const uint32_t w = seg[j];
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = s_code[((nl >> k) & 1u) ? (w >> (8 * k)) & 255u : 287u];   // [287] == 0
+        if (ns == 0) {
+          // literals only: two codes (<= 30 bits) per accumulator step, no per-byte branches
+#pragma unroll
+          for (int k = 0; k < 4; k += 2) {
+            const uint32_t l0 = c[k] >> 16;
+            bw.put((c[k] & 0xFFFFu) | ((c[k + 1] & 0xFFFFu) << l0), l0 + (c[k + 1] >> 16));
+          }
+        } else {
+#pragma unroll 1
+          for (int k = 0; k < 4; ++k) {
+            if ((nl >> k) & 1u) {
+              const uint32_t ck = s_code[(w >> (8 * k)) & 255u];
+              bw.put(ck & 0xFFFFu, ck >> 16);
+            } else if ((ns >> k) & 1u) {
+              uint32_t sy, eb, ev;
+              length_symbol((uint32_t)m_run(tk.cover, 4 * j + k), &sy, &eb, &ev);
+              const uint32_t cm = s_code[sy];
+              // code, extra bits, then the single distance code (one 0 bit)
+              bw.put((cm & 0xFFFFu) | (ev << (cm >> 16)), (cm >> 16) + eb + 1);
+            }
+          }
+        }
+      }
       bw.flush();
     }
+    mark();  // 8 tokens (lane 0's own)
     if (tid == 0) {
       BitWriter bw;
       bw.init(s_out, kHeadBits + kPrefixBits + hdr_total + tok_total);
@@ -463,9 +631,11 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       bw.flush();
     }
     __syncthreads();
+    mark();  // 9 trailer + barrier
     uint32_t *dst = reinterpret_cast<uint32_t *>(slot);
     for (uint32_t i = tid; i < (member + 3) / 4; i += kThreads) dst[i] = s_out[i];
     if (tid == 0) sizes[chunk] = (int32_t)member;
+    mark();  // 10 store
   } else {
     // stored block (RFC 1951 3.2.4): incompressible input, rare for this text
     const uint32_t member = 18 + 5 + (uint32_t)n + 8;
@@ -572,6 +742,11 @@ void deflate_host_tables(uint32_t *crc_table, uint32_t *pow128) {
     for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? kPoly : 0u);
     crc_table[i] = c;
   }
+  for (int t = 1; t < 4; ++t)   // slice-by-4: table t advances a byte t positions further
+    for (uint32_t i = 0; i < 256; ++i) {
+      const uint32_t c = crc_table[(t - 1) * 256 + i];
+      crc_table[t * 256 + i] = (c >> 8) ^ crc_table[c & 255u];
+    }
   const uint32_t step = host_xpow8(128);
   uint32_t v = 0x80000000u;
   for (int k = 0; k < 256; ++k) {
@@ -581,12 +756,13 @@ void deflate_host_tables(uint32_t *crc_table, uint32_t *pow128) {
 }
 
 void launch_deflate(const uint8_t *text, int64_t n_bytes, uint8_t *slots, int32_t *sizes, int64_t *offsets,
-                    uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, hipStream_t s) {
+                    uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, hipStream_t s,
+                    unsigned long long *d_prof) {
   if (n_bytes <= 0) return;
   const int64_t nch = (n_bytes + DF_CHUNK - 1) / DF_CHUNK;
   const uint32_t x8rem = host_xpow8((uint64_t)(n_bytes % DF_CHUNK) & 127u);
   hipLaunchKernelGGL(k_deflate_chunks, dim3((unsigned)nch), dim3(kThreads), 0, s, text, n_bytes, slots, sizes,
-                     d_crc_table, d_pow128, x8rem);
+                     d_crc_table, d_pow128, x8rem, d_prof);
   hipLaunchKernelGGL(k_deflate_offsets, dim3(1), dim3(1024), 0, s, (const int32_t *)sizes, (int)nch, offsets);
   hipLaunchKernelGGL(k_deflate_compact, dim3((unsigned)nch), dim3(256), 0, s, (const uint8_t *)slots,
                      (const int64_t *)offsets, dense);

@@ -157,7 +157,8 @@ struct pbsim_ctx {
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
   int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)
-  DevBuf d_df_tables;          // crc table [256] + x^(8*128*k) [256]
+  DevBuf d_df_tables;          // crc slice-by-4 tables [4][256] + x^(8*128*k) [256]
+  DevBuf d_df_prof;
 
   // per-unit statistics (pbsim.cpp:63-70, 195-196)
   int64_t res_num = 0, res_len_total = 0, res_len_min = LONG_MAX, res_len_max = 0;
@@ -934,8 +935,8 @@ namespace {
 
 int ensure_deflate_tables(pbsim_ctx *c) {
   if (c->d_df_tables.p) return PBSIM_SUCCEEDED;
-  std::vector<uint32_t> t(512);
-  deflate_host_tables(t.data(), t.data() + 256);
+  std::vector<uint32_t> t(1024 + 256);
+  deflate_host_tables(t.data(), t.data() + 1024);
   if (!upload(c->d_df_tables, t.data(), t.size() * 4, c->stream)) return PBSIM_FAILED;
   HIP_OK(hipStreamSynchronize(c->stream));
   return PBSIM_SUCCEEDED;
@@ -955,6 +956,12 @@ int deflate_stream(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, F &
   HIP_OK(sl.d_df_offsets.ensure((size_t)(max_ch + 1) * 8));
   HIP_OK(sl.h_df_total.ensure(16));
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
+  unsigned long long *d_prof = nullptr;
+  if (getenv("PBSIM_DEFLATE_PROF")) {
+    HIP_OK(c->d_df_prof.ensure(128));
+    HIP_OK(hipMemsetAsync(c->d_df_prof.p, 0, 128, sl.stream));
+    d_prof = c->d_df_prof.as<unsigned long long>();
+  }
   int64_t pending = 0;  // bytes of the previous piece, in h_df_out[k ^ 1], copy possibly still in flight
   int k = 0;
   for (int64_t off = 0; off < n; off += piece, k ^= 1) {
@@ -963,7 +970,7 @@ int deflate_stream(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, F &
     HIP_OK(sl.d_df_dense[k].ensure((size_t)max_ch * DF_SLOT, true));
     HIP_OK(sl.h_df_out[k].ensure((size_t)max_ch * DF_SLOT));
     launch_deflate(d_text + off, len, sl.d_df_slots.as<uint8_t>(), sl.d_df_sizes.as<int32_t>(),
-                   sl.d_df_offsets.as<int64_t>(), sl.d_df_dense[k].as<uint8_t>(), tab, tab + 256, sl.stream);
+                   sl.d_df_offsets.as<int64_t>(), sl.d_df_dense[k].as<uint8_t>(), tab, tab + 1024, sl.stream, d_prof);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(sl.h_df_total.p, sl.d_df_offsets.as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
     HIP_OK(hipStreamSynchronize(sl.stream));  // also retires the copy of piece k-1 (same stream)
@@ -973,6 +980,16 @@ int deflate_stream(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, F &
     pending = total;
   }
   HIP_OK(hipStreamSynchronize(sl.stream));
+  if (d_prof) {
+    unsigned long long t[16];
+    HIP_OK(hipMemcpy(t, d_prof, 128, hipMemcpyDeviceToHost));
+    const double nch = (double)((n + DF_CHUNK - 1) / DF_CHUNK);
+    static const char *names[11] = {"stage", "hist+crc", "sort", "build", "codes", "sizes", "prefix", "hdrsyms", "tokens",
+                                    "trailer", "store"};
+    fprintf(stderr, "[deflate prof] %.0f chunks; us per chunk (lane 0):", nch);
+    for (int i = 0; i < 11; ++i) fprintf(stderr, " %s %.1f", names[i], t[i] / nch / 100);
+    fprintf(stderr, "\n");
+  }
   if (pending && !consume((const char *)sl.h_df_out[k ^ 1].p, pending)) return PBSIM_FAILED;
   return PBSIM_SUCCEEDED;
 }

@@ -170,10 +170,11 @@ void launch_text_emit(const TextArgs &a, int64_t n_slots_max, const DeviceFlags 
 #define DF_CHUNK 32768
 #define DF_SLOT (DF_CHUNK + 64)          // per-chunk staging stride (a stored member is DF_CHUNK + 31 bytes)
 #define DF_PIECE_CHUNKS 8192             // chunks per launch (k_deflate_offsets scans them in one block)
-void deflate_host_tables(uint32_t *crc_table /*256*/, uint32_t *pow128 /*256*/);
+void deflate_host_tables(uint32_t *crc_table /*4 x 256, slice-by-4*/, uint32_t *pow128 /*256*/);
 // text (16-byte aligned, 16 bytes of readable slack) -> dense[0 .. offsets[nch]);  nch = ceil(n_bytes / DF_CHUNK) <= DF_PIECE_CHUNKS;
 // slots: nch * DF_SLOT bytes, sizes: nch, offsets: nch + 1, dense: nch * DF_SLOT bytes worst case
 void launch_deflate(const uint8_t *text, int64_t n_bytes, uint8_t *slots, int32_t *sizes, int64_t *offsets,
-                    uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, hipStream_t s);
+                    uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, hipStream_t s,
+                    unsigned long long *d_prof = nullptr /* PBSIM_DEFLATE_PROF: 8 per-phase tick sums */);
 
 }  // namespace pbsim
