@@ -43,7 +43,7 @@
 #define TR_RANK_MAX 1000
 
 enum { ST_WGS = 1, ST_TRANS = 2, ST_TEMPL = 3 };
-enum { ME_QS = 1, ME_ERR = 2 };
+enum { ME_QS = 1, ME_ERR = 2, ME_SAM = 3, ME_SAM_REUSE = 4, ME_SAM_STORE = 5 }; /* pbsim.cpp:37-41 */
 enum { RNG_GLIBC = 0, RNG_PHILOX = 1 };
 
 /* ---------------------------------------------------------------- state -- */
@@ -57,6 +57,8 @@ static struct {
   long sub_ratio, ins_ratio, del_ratio;
   double sub_rate, ins_rate, del_rate;
   const char *prefix, *id_prefix, *genome_file, *transcript_file, *templ_file, *model_file;
+  const char *sample_file, *profile_id;
+  double accuracy_min, accuracy_max; /* sampling filter, pbsim.cpp:1622-1634 */
   int pass_num;
   double hp_del_bias;
   /* results (pbsim.cpp:63-70) */
@@ -790,26 +792,282 @@ static void print_sim_param(void) { /* pbsim.cpp:5397-5465 */
   fprintf(stderr, ":::: Simulation parameters :::\n\n");
   fprintf(stderr, "strategy : %s\n", sim.strategy == ST_WGS ? "wgs" : sim.strategy == ST_TRANS ? "trans" : "templ");
   if (sim.method == ME_QS) fprintf(stderr, "method : qshmm\nqshmm : %s\n", sim.model_file);
-  else fprintf(stderr, "method : errhmm\nerrhmm : %s\n", sim.model_file);
+  else if (sim.method == ME_ERR) fprintf(stderr, "method : errhmm\nerrhmm : %s\n", sim.model_file);
+  else fprintf(stderr, "method : sample\n");
   if (sim.strategy == ST_WGS) fprintf(stderr, "genome : %s\n", sim.genome_file);
   else if (sim.strategy == ST_TRANS) fprintf(stderr, "transcript : %s\n", sim.transcript_file);
   else fprintf(stderr, "template : %s\n", sim.templ_file);
   fprintf(stderr, "prefix : %s\n", sim.prefix);
   fprintf(stderr, "id-prefix : %s\n", sim.id_prefix);
   if (sim.strategy == ST_WGS) fprintf(stderr, "depth : %lf\n", sim.depth);
-  if (sim.strategy != ST_TEMPL) {
+  if (sim.strategy == ST_TEMPL) {
+  } else if (sim.method == ME_QS || sim.method == ME_ERR) {
     fprintf(stderr, "length-mean : %f\n", sim.len_mean);
     fprintf(stderr, "length-sd : %f\n", sim.len_sd);
+    fprintf(stderr, "length-min : %ld\n", sim.len_min);
+    fprintf(stderr, "length-max : %ld\n", sim.len_max);
+  } else {
+    fprintf(stderr, "length-mean : (sample FASTQ)\nlength-sd : (sample FASTQ)\n");
     fprintf(stderr, "length-min : %ld\n", sim.len_min);
     fprintf(stderr, "length-max : %ld\n", sim.len_max);
   }
   if (sim.method != ME_ERR)
     fprintf(stderr, "difference-ratio : %ld:%ld:%ld\n", sim.sub_ratio, sim.ins_ratio, sim.del_ratio);
   fprintf(stderr, "seed : %d\n", sim.seed);
-  fprintf(stderr, "accuracy-mean : %f\n", sim.accuracy_mean);
+  if (sim.method == ME_QS || sim.method == ME_ERR) {
+    fprintf(stderr, "accuracy-mean : %f\n", sim.accuracy_mean);
+  } else { /* glibc prints "(null)" for the option that was not given */
+    fprintf(stderr, "sample : %s\n", sim.sample_file ? sim.sample_file : "(null)");
+    fprintf(stderr, "sample-profile-id : %s\n", sim.profile_id ? sim.profile_id : "(null)");
+    fprintf(stderr, "accuracy-mean : (sample FASTQ)\naccuracy-sd : (sample FASTQ)\n");
+    fprintf(stderr, "accuracy-min : %f\n", sim.accuracy_min);
+    fprintf(stderr, "accuracy-max : %f\n", sim.accuracy_max);
+  }
   fprintf(stderr, "pass_num : %d\n", sim.pass_num);
   fprintf(stderr, "hp-del-bias : %f\n", sim.hp_del_bias);
   fprintf(stderr, "\n");
+}
+
+/* ------------------------------------------------------ sampling method -- */
+/* pbsim.cpp:120-137 (sample_t), 1155-1330 (get_sample_inf), 1336-1360 (print_sample_stats),
+ * 1694-1949 (simulate_by_sample).  Only the quality strings of the sample FASTQ are used. */
+static struct {
+  long num, len_min, len_max;
+  long long len_total;
+  long num_filtered, len_min_filtered, len_max_filtered;
+  long long len_total_filtered;
+  double len_mean_filtered, len_sd_filtered, accuracy_mean_filtered, accuracy_sd_filtered;
+} sample;
+static FILE *fp_filtered, *fp_stats;
+static char profile_fq[4096], profile_stats[4096];
+
+static void get_sample_inf(void) { /* pbsim.cpp:1155-1330 */
+  char line[BUF_SIZE];
+  for (long i = 0; i <= sim.len_max; i++) freq_len[i] = 0;
+  for (long i = 0; i <= 100000; i++) freq_accuracy[i] = 0;
+  memset(&sample, 0, sizeof sample);
+  sample.len_min = sample.len_min_filtered = LONG_MAX;
+  if (sim.method == ME_SAM_REUSE) { /* the stored stats file, "key\tvalue" lines (:1185-1210) */
+    while (fgets(line, BUF_SIZE, fp_stats) != NULL) {
+      trim(line);
+      char *item = strtok(line, "\t"), *val = strtok(NULL, "\t");
+      if (strcmp(item, "num") == 0) sample.num_filtered = atol(val);
+      else if (strcmp(item, "len_total") == 0) sample.len_total_filtered = atol(val);
+      else if (strcmp(item, "len_min") == 0) sample.len_min_filtered = atol(val);
+      else if (strcmp(item, "len_max") == 0) sample.len_max_filtered = atol(val);
+      else if (strcmp(item, "len_mean") == 0) sample.len_mean_filtered = atof(val);
+      else if (strcmp(item, "len_sd") == 0) sample.len_sd_filtered = atof(val);
+      else if (strcmp(item, "accuracy_mean") == 0) sample.accuracy_mean_filtered = atof(val);
+      else if (strcmp(item, "accuracy_sd") == 0) sample.accuracy_sd_filtered = atof(val);
+    }
+    return;
+  }
+  FILE *fp = fopen(sim.sample_file, "r");
+  if (!fp) { fprintf(stderr, "ERROR: Cannot open file: %s\n", sim.sample_file); exit(255); }
+  char *qc_tmp = malloc(FASTQ_LEN_MAX + BUF_SIZE);
+  double acc_total = 0;
+  long len = 0;
+  int line_num = 0;
+  qc_tmp[0] = '\0';
+  /* records are counted by line feeds: the 4th one closes a read; a line longer than the buffer arrives in
+   * chunks without a line feed, of which only those of the quality line (line_num == 3) are kept (:1216-1283) */
+  while (fgets(line, BUF_SIZE, fp) != NULL) {
+    if (trim(line) == 1) {
+      if (++line_num < 4) continue;
+      len += (long)strlen(line);
+      if (len > FASTQ_LEN_MAX) { fprintf(stderr, "ERROR: fastq is too long. Max acceptable length is %d.\n", FASTQ_LEN_MAX); exit(255); }
+      sample.num++;
+      sample.len_total += len;
+      if (len > sample.len_max) sample.len_max = len;
+      if (len < sample.len_min) sample.len_min = len;
+      if (len >= sim.len_min && len <= sim.len_max) {
+        strcat(qc_tmp, line);
+        double prob = 0.0;
+        for (long i = 0; i < len; i++) prob += qc_prob[(int)qc_tmp[i] - 33];
+        const double accuracy = 1.0 - (prob / len);
+        if (accuracy >= sim.accuracy_min && accuracy <= sim.accuracy_max) {
+          acc_total += accuracy;
+          sample.num_filtered++;
+          sample.len_total_filtered += len;
+          freq_len[len]++;
+          freq_accuracy[(int)(accuracy * 100000 + 0.5)]++;
+          fprintf(fp_filtered, "%s\n", qc_tmp);
+          if (len > sample.len_max_filtered) sample.len_max_filtered = len;
+          if (len < sample.len_min_filtered) sample.len_min_filtered = len;
+        }
+      }
+      line_num = 0;
+      qc_tmp[0] = '\0';
+      len = 0;
+    } else if (line_num == 3) {
+      len += (long)strlen(line);
+      if (len > FASTQ_LEN_MAX) { fprintf(stderr, "ERROR: fastq is too long. Max acceptable length is %d.\n", FASTQ_LEN_MAX); exit(255); }
+      strcat(qc_tmp, line);
+    }
+  }
+  fclose(fp);
+  free(qc_tmp);
+  if (sample.num_filtered < 1) die("there is no sample in the valid range of length and accuracy.");
+  sample.len_mean_filtered = (double)sample.len_total_filtered / sample.num_filtered;
+  sample.accuracy_mean_filtered = acc_total / sample.num_filtered;
+  double variance = 0.0;
+  for (long i = 0; i <= sim.len_max; i++)
+    if (freq_len[i] > 0) variance += pow((sample.len_mean_filtered - i), 2) * freq_len[i];
+  sample.len_sd_filtered = sqrt(variance / sample.num_filtered);
+  variance = 0.0;
+  for (long i = 0; i <= 100000; i++)
+    if (freq_accuracy[i] > 0) variance += pow((sample.accuracy_mean_filtered - i * 0.00001), 2) * freq_accuracy[i];
+  sample.accuracy_sd_filtered = sqrt(variance / sample.num_filtered);
+  if (sim.method == ME_SAM_STORE) { /* :1317-1326 */
+    fprintf(fp_stats, "num\t%ld\nlen_total\t%lld\nlen_min\t%ld\nlen_max\t%ld\n", sample.num_filtered,
+            sample.len_total_filtered, sample.len_min_filtered, sample.len_max_filtered);
+    fprintf(fp_stats, "len_mean\t%f\nlen_sd\t%f\naccuracy_mean\t%f\naccuracy_sd\t%f\n", sample.len_mean_filtered,
+            sample.len_sd_filtered, sample.accuracy_mean_filtered, sample.accuracy_sd_filtered);
+  }
+}
+
+static void print_sample_stats(void) { /* pbsim.cpp:1336-1360 */
+  fprintf(stderr, ":::: sample reads stats ::::\n\n");
+  if (sim.method == ME_SAM_REUSE) {
+    fprintf(stderr, "file name : %s\n", profile_fq);
+  } else {
+    fprintf(stderr, "file name : %s\n", sim.sample_file);
+    fprintf(stderr, "\n:: all reads ::\n");
+    fprintf(stderr, "read num. : %ld\n", sample.num);
+    fprintf(stderr, "read total length : %lld\n", sample.len_total);
+    fprintf(stderr, "read min length : %ld\n", sample.len_min);
+    fprintf(stderr, "read max length : %ld\n", sample.len_max);
+  }
+  fprintf(stderr, "\n:: filtered reads ::\n");
+  fprintf(stderr, "read num. : %ld\n", sample.num_filtered);
+  fprintf(stderr, "read total length : %lld\n", sample.len_total_filtered);
+  fprintf(stderr, "read min length : %ld\n", sample.len_min_filtered);
+  fprintf(stderr, "read max length : %ld\n", sample.len_max_filtered);
+  fprintf(stderr, "read length mean (SD) : %f (%f)\n", sample.len_mean_filtered, sample.len_sd_filtered);
+  fprintf(stderr, "read accuracy mean (SD) : %f (%f)\n", sample.accuracy_mean_filtered, sample.accuracy_sd_filtered);
+  fprintf(stderr, "\n");
+}
+
+static void open_sample_profile(void) { /* pbsim.cpp:580-617 */
+  if (sim.method == ME_SAM) {
+    if (!(fp_filtered = tmpfile())) die("Cannot open temporary file");
+  } else {
+    const char *mode = sim.method == ME_SAM_STORE ? "w+" : "r";
+    if (!(fp_filtered = fopen(profile_fq, mode)) || !(fp_stats = fopen(profile_stats, mode)))
+      die("Cannot open sample_profile");
+  }
+  get_sample_inf();
+  print_sample_stats();
+}
+
+/* One record under the sampling method (pbsim.cpp:1694-1949).  Every filtered quality string is used
+ * sample_num (or sample_num + 1) times per sweep over the profile; the string is cut to the length of the read it
+ * just produced (:1834), so the copies of one string form a chain of non-increasing lengths. */
+static void simulate_sample_record(void) {
+  const long long len_quota = (long long)(sim.depth * ref_len);
+  long long len_total = 0;
+  for (long i = 0; i <= sim.len_max; i++) freq_len[i] = 0;
+  for (long i = 0; i <= 100000; i++) freq_accuracy[i] = 0;
+  long sample_num = (long)(len_quota / sample.len_total_filtered);
+  const long sample_residue = (long)(len_quota % sample.len_total_filtered);
+  long sample_interval = 1;
+  if (sample_residue != 0) {
+    sample_interval = (long)((double)(sample.len_total_filtered / sample_residue) * 2 + 0.5); /* integer quotient first */
+    if (sample_interval > (long)(sample.num_filtered * 0.5)) sample_interval = (long)(sample.num_filtered * 0.5);
+  }
+  g_unit = (uint32_t)ref_num;
+  g_pass = 0;
+  while (len_total < len_quota) {
+    rewind(fp_filtered);
+    g_read = (uint32_t)(sim.res_num + 1);
+    long sample_value = R_hdr(3) % sample.num_filtered; /* :1732 */
+    while (fgets(m_qc, (int)(sample.len_max_filtered + 2), fp_filtered) != NULL) {
+      if (len_total >= len_quota) break;
+      trim(m_qc);
+      const long num = (sample_value % sample_interval == 0) ? sample_num + 1 : sample_num;
+      sample_value++;
+      for (long i = 0; i < num; i++) {
+        if (len_total >= len_quota) break;
+        long L = (long)strlen(m_qc), offset;
+        g_read = (uint32_t)(sim.res_num + 1);
+        if (L >= ref_len) {
+          offset = 0;
+          L = ref_len;
+        } else {
+          offset = R_hdr(2) % (ref_len - L + 1);
+        }
+        sim.res_num++;
+        for (long j = 0; j < L; j++) {
+          m_seq[j] = ref_seq[offset + j];
+          m_hp[j] = ref_hp[offset + j];
+        }
+        m_seq[L] = '\0';
+        char strand = '+';
+        if (sim.res_num % 2 != 1) {
+          strand = '-';
+          revcomp(m_seq);
+          revshort(m_hp, L);
+        }
+        long ref_offset = 0, read_offset = 0, maf_offset = 0;
+        while (ref_offset < L && read_offset < L) { /* :1777-1832 */
+          const char nt = m_seq[ref_offset];
+          int qv = (int)m_qc[read_offset] - 33;
+          g_event = (uint32_t)maf_offset;
+          long rand_value = R_walk(0, 2) % 1000000;
+          if (rand_value < sub_thre[qv]) {
+            int need_n;
+            sim.res_sub_num++;
+            char b = sub_nt(nt, R_walk(0, 3) % 3, &need_n);
+            if (need_n) b = "ATGC"[R_walk(1, 0) % 4];
+            m_read[read_offset] = b;
+            m_mafref[maf_offset] = nt;
+            ref_offset++;
+          } else if (rand_value < ins_thre[qv]) {
+            sim.res_ins_num++;
+            const long index = R_walk(0, 3) % 8;
+            m_read[read_offset] = (index >= 4) ? nt : "ATGC"[index];
+            m_mafref[maf_offset] = '-';
+          } else {
+            m_read[read_offset] = nt;
+            m_mafref[maf_offset] = nt;
+            ref_offset++;
+          }
+          m_maf[maf_offset] = m_read[read_offset];
+          maf_offset++;
+          read_offset++;
+          while (ref_offset < L && read_offset < L) {
+            /* mut.hp[-1] when no reference base has been consumed yet: observed 0 (see walk_qshmm, Q15) */
+            const int hp = (ref_offset > 0) ? m_hp[ref_offset - 1] : 0;
+            g_event = (uint32_t)maf_offset;
+            rand_value = R_walk(2, 0) % 1000000;
+            qv = (int)m_qc[read_offset - 1] - 33;
+            if (!(rand_value < del_thre[qv] * hp_bias[hp])) break;
+            sim.res_del_num++;
+            m_maf[maf_offset] = '-';
+            m_mafref[maf_offset] = m_seq[ref_offset];
+            maf_offset++;
+            ref_offset++;
+          }
+        }
+        m_qc[read_offset] = '\0'; /* the chain: the next copy of this string is this much shorter */
+        m_read[read_offset] = '\0';
+        m_maf[maf_offset] = '\0';
+        m_mafref[maf_offset] = '\0';
+        if (strand == '-') {
+          revcomp(m_maf);
+          revcomp(m_mafref);
+        }
+        const long len = (long)strlen(m_read);
+        len_total += len;
+        double prob = 0.0;
+        for (long j = 0; j < len; j++) prob += qc_prob[(int)m_qc[j] - 33];
+        account(len, 1.0 - (prob / len));
+        emit_record(len, m_qc, 0, "ref", 3, offset + 1, offset + ref_offset, strand, 1);
+      }
+    }
+    sample_num = 0;
+  }
+  finish_stats();
 }
 
 /* --------------------------------------------------------- WGS strategy -- */
@@ -994,16 +1252,23 @@ static void run_wgs(void) { /* pbsim.cpp:667-759 */
     for (ref_num = 1; ref_num <= ref_num_seq; ref_num++) get_genome_seq();
     normalise_bias();
   }
-  build_len_table();
-  build_acc_table();
-  if (sim.method == ME_ERR) build_errhmm_tables(1); else build_qshmm_tables();
+  const int sampling = sim.method >= ME_SAM;
+  if (!sampling) {
+    build_len_table();
+    build_acc_table();
+    if (sim.method == ME_ERR) build_errhmm_tables(1); else build_qshmm_tables();
+  }
   for (ref_num = 1; ref_num <= ref_num_seq; ref_num++) {
     get_genome_seq();
     init_sim_res();
     open_outputs(1);
-    simulate_wgs_record();
+    if (sampling) simulate_sample_record(); else simulate_wgs_record();
     print_simulation_stats();
     close_outputs();
+  }
+  if (sim.method == ME_SAM_STORE || sim.method == ME_SAM_REUSE) { /* pbsim.cpp:756-759 */
+    fclose(fp_filtered);
+    fclose(fp_stats);
   }
 }
 
@@ -1247,6 +1512,7 @@ static void run_templ(void) { /* pbsim.cpp:814-866 */
 /* ------------------------------------------------------------------ CLI -- */
 static void set_sim_param(void) { /* pbsim.cpp:1451-1688 */
   if (!sim.set_flg[0] || !sim.set_flg[1]) die("--strategy and --method must be set.");
+  if (sim.strategy != ST_WGS && sim.method == ME_SAM) die("sampling-based simulation is possible only for wgs strategy.");
   if (sim.strategy == ST_WGS && !sim.set_flg[2]) die("for --strategy wgs, --genome must be set.");
   if (sim.strategy == ST_TRANS && !sim.set_flg[3]) die("for --strategy trans, --transcript must be set.");
   if (sim.strategy == ST_TEMPL && !sim.set_flg[21]) die("for --strategy templ, --template must be set.");
@@ -1260,6 +1526,30 @@ static void set_sim_param(void) { /* pbsim.cpp:1451-1688 */
   sim.sub_rate = (double)sim.sub_ratio / sum;
   sim.ins_rate = (double)sim.ins_ratio / sum;
   sim.del_rate = (double)sim.del_ratio / sum;
+  if (sim.method == ME_SAM) { /* pbsim.cpp:1567-1620 */
+    if (sim.set_flg[11]) {
+      if (sim.set_flg[12]) sim.method = ME_SAM_STORE;
+    } else if (sim.set_flg[12]) {
+      sim.method = ME_SAM_REUSE;
+    } else {
+      die("for --method sample, --sample (and/or --sample-profile-id) must be set.");
+    }
+  }
+  if (sim.set_flg[12]) {
+    snprintf(profile_fq, sizeof profile_fq, "sample_profile_%s.fastq", sim.profile_id);
+    snprintf(profile_stats, sizeof profile_stats, "sample_profile_%s.stats", sim.profile_id);
+  }
+  if (sim.method == ME_SAM_STORE || sim.method == ME_SAM_REUSE) {
+    const char *names[2] = {profile_fq, profile_stats};
+    for (int k = 0; k < 2; k++) {
+      FILE *fp = fopen(names[k], "r");
+      if (fp && sim.method == ME_SAM_STORE) { fprintf(stderr, "ERROR: %s exists.\n", names[k]); exit(255); }
+      if (!fp && sim.method == ME_SAM_REUSE) { fprintf(stderr, "ERROR: %s does not exist.\n", names[k]); exit(255); }
+      if (fp) fclose(fp);
+    }
+  }
+  sim.accuracy_min = sim.set_flg[13] ? (int)(sim.accuracy_min * 100) * 0.01 : 0.75;
+  sim.accuracy_max = sim.set_flg[14] ? (int)(sim.accuracy_max * 100) * 0.01 : 1.0;
   if (sim.method == ME_QS && !sim.set_flg[15]) die("for --method qshmm, --qshmm must be set.");
   if (sim.method == ME_ERR && !sim.set_flg[16]) die("for --method errhmm, --errhmm must be set.");
   if (!sim.set_flg[17]) sim.len_mean = 9000;
@@ -1271,6 +1561,7 @@ static void set_sim_param(void) { /* pbsim.cpp:1451-1688 */
     exit(255);
   }
   if (!sim.set_flg[20]) sim.pass_num = 1;
+  if (sim.pass_num > 1 && sim.method >= ME_SAM) die("sampling-based simulation supports only single-pass.");
   if (!sim.set_flg[22]) sim.hp_del_bias = 1;
 }
 
@@ -1299,7 +1590,8 @@ int main(int argc, char **argv) {
     case 1:
       if (strncmp(optarg, "qshmm", 5) == 0) sim.method = ME_QS;
       else if (strncmp(optarg, "errhmm", 6) == 0) sim.method = ME_ERR;
-      else die("oracle: method must be qshmm or errhmm (sampling method is out of scope)");
+      else if (strncmp(optarg, "sample", 6) == 0) sim.method = ME_SAM;
+      else die("method: Acceptable value: qshmm, errhmm, sample.");
       break;
     case 2: sim.genome_file = optarg; break;
     case 3: sim.transcript_file = optarg; break;
@@ -1320,6 +1612,10 @@ int main(int argc, char **argv) {
       break;
     }
     case 10: sim.seed = (unsigned int)atoi(optarg); break;
+    case 11: sim.sample_file = optarg; break;
+    case 12: sim.profile_id = optarg; break;
+    case 13: sim.accuracy_min = atof(optarg); if (sim.accuracy_min < 0.0 || sim.accuracy_min > 1.0) die("accuracy-min: Acceptable range is 0.0-1.0."); break;
+    case 14: sim.accuracy_max = atof(optarg); if (sim.accuracy_max < 0.0 || sim.accuracy_max > 1.0) die("accuracy-max: Acceptable range is 0.0-1.0."); break;
     case 15: case 16: sim.model_file = optarg; break;
     case 17: sim.len_mean = atof(optarg); if (sim.len_mean < 1 || sim.len_mean > FASTQ_LEN_MAX) die("length-mean: Acceptable range is 1-1000000."); break;
     case 18: sim.len_sd = atof(optarg); if (sim.len_sd < 0 || sim.len_sd > FASTQ_LEN_MAX) die("length-sd: Acceptable range is 0-1000000."); break;
@@ -1340,7 +1636,8 @@ int main(int argc, char **argv) {
   print_sim_param();
   srand(sim.seed); /* pbsim.cpp:543 */
   init_common_tables();
-  if (sim.method == ME_QS) set_qshmm(); else set_errhmm();
+  if (sim.method >= ME_SAM) open_sample_profile(); /* pbsim.cpp:580-617, before the models */
+  if (sim.method == ME_QS) set_qshmm(); else if (sim.method == ME_ERR) set_errhmm();
   size_t cap = (size_t)sim.len_max * 2 + 1; /* pbsim.cpp:5488-5531 */
   m_seq = malloc(cap); m_read = malloc(cap); m_maf = malloc(cap); m_mafref = malloc(cap);
   m_qc = malloc(cap); m_newqc = malloc(cap); m_hp = malloc(cap * sizeof(short));

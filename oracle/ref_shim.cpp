@@ -54,9 +54,12 @@ static const site_t SITES[] = {
   {5172,K_WALK,0,0},{5175,K_WALK,0,0},{5179,K_WALK,0,1},{5184,K_WALK,0,2},{5186,K_WALK,0,2},
   {5191,K_WALK,1,0},
   {5208,K_WALK,0,3},{5218,K_WALK,1,2},{5228,K_WALK,0,3},
-  /* simulate_by_sample: not keyed (sampling method is out of scope) */
-  {1732,K_SERIAL,0,0},{1758,K_SERIAL,0,0},{1782,K_SERIAL,0,0},{1785,K_SERIAL,0,0},
-  {1795,K_SERIAL,0,0},{1802,K_SERIAL,0,0},{1820,K_SERIAL,0,0},
+  /* simulate_by_sample                   pbsim.cpp:1732-1820
+   * 1732 is the per-round `sample_value`: header slot 3 of the round's first read (res_num+1);
+   * 1758 the read's offset (header slot 2); the walk uses the QSHMM slots (error class z, nucleotide w,
+   * sub-block 1 for a non-ACGT substitution, sub-block 2 for the deletion test of a column) */
+  {1732,K_HDR,0,3},{1758,K_HDR,0,2},{1782,K_WALK,0,2},{1785,K_WALK,0,3},
+  {1795,K_WALK,1,0},{1802,K_WALK,0,3},{1820,K_WALK,2,0},
 };
 #define NSITES ((int)(sizeof(SITES)/sizeof(SITES[0])))
 

@@ -57,6 +57,24 @@ CASES["templ_qshmm_rsii_pass2"] = dict(
     args=["--strategy", "templ", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model",
           "--template", "INPUT:tiny.template", "--seed", "5", "--pass-num", "2"])
 
+# ---- sampling method (pbsim.cpp:1694-1949): quality strings come from a FASTQ, tests/golden/make_sample_fastq.py
+SAMPLE = ["--strategy", "wgs", "--method", "sample"]
+CASES["wgs_sample_plain"] = dict(     # 4 copies per string + a second sweep; default ratio 6:55:39
+    args=SAMPLE + ["--sample", "INPUT:sample.fastq", "--genome", "INPUT:plain.fa", "--depth", "3", "--seed", "1"])
+CASES["wgs_sample_quirk"] = dict(     # strings longer than the record (clipped to it), quota below the profile's total
+    args=SAMPLE + ["--sample", "INPUT:sample.fastq", "--genome", "INPUT:quirk.fa", "--depth", "5", "--seed", "2"])
+CASES["wgs_sample_delheavy"] = dict(  # deletions outnumber insertions: every copy is shorter than the one before
+    args=SAMPLE + ["--sample", "INPUT:sample.fastq", "--genome", "INPUT:plain.fa", "--depth", "2.5", "--seed", "3",
+                   "--difference-ratio", "10:30:60", "--hp-del-bias", "3", "--accuracy-min", "0.8",
+                   "--length-min", "150", "--length-max", "5000"])
+CASES["wgs_sample_store"] = dict(     # --sample + --sample-profile-id: the filtered profile is written out
+    args=SAMPLE + ["--sample", "INPUT:sample.fastq", "--sample-profile-id", "g1", "--genome", "INPUT:quirk.fa",
+                   "--depth", "2", "--seed", "4", "--accuracy-max", "0.99"])
+CASES["wgs_sample_reuse"] = dict(     # --sample-profile-id alone: the stored profile is read back
+    setup=SAMPLE + ["--sample", "INPUT:sample.fastq", "--sample-profile-id", "g1", "--genome", "INPUT:quirk.fa",
+                    "--depth", "1", "--seed", "4", "--accuracy-max", "0.99"],
+    args=SAMPLE + ["--sample-profile-id", "g1", "--genome", "INPUT:plain.fa", "--depth", "2", "--seed", "5"])
+
 # cases whose complete outputs are committed (gzip) in addition to the hashes
 FULL = ["wgs_errhmm-ont_quirk", "wgs_qshmm_rsii_pass3", "trans_errhmm_sequel"]
 

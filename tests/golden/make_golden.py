@@ -28,65 +28,13 @@ from cases import CASES, FULL, MODES  # noqa: E402
 REF_DATA = "/root/reference/data"
 
 
-def strip_report(err: str) -> str:
-    """Drop run-dependent lines: file paths, prefix, wall/CPU time."""
-    keep = []
-    for line in err.splitlines():
-        if line.startswith((":::: System utilization", "CPU time(s)", "Elapsed time(s)")):
-            continue
-        if line.split(" : ")[0] in ("prefix", "genome", "transcript", "errhmm", "qshmm", "file name", "template"):
-            continue
-        keep.append(line)
-    return "\n".join(keep).rstrip("\n") + "\n"
-
-
-def resolve(args, inputs_dir, model_dir):
-    out = []
-    for a in args:
-        if a.startswith("MODEL:"):
-            out.append(os.path.join(model_dir, a[6:]))
-        elif a.startswith("INPUT:"):
-            out.append(os.path.join(inputs_dir, a[6:]))
-        else:
-            out.append(a)
-    return out
-
-
-def make_stubs(d):
-    os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "gzip"), "w") as f:
-        f.write("#!/bin/sh\nexec cat\n")
-    with open(os.path.join(d, "samtools"), "w") as f:
-        f.write('#!/bin/sh\nexec cat > "$4"\n')
-    for n in ("gzip", "samtools"):
-        os.chmod(os.path.join(d, n), 0o755)
-
-
-def canonical_outputs(workdir, prefix):
-    """name -> bytes, with reference file names mapped to plain-text names."""
-    res = {}
-    for fn in sorted(os.listdir(workdir)):
-        if not fn.startswith(prefix):
-            continue
-        key = fn[len(prefix):]
-        key = key.replace(".fq.gz", ".fq").replace(".maf.gz", ".maf").replace(".bam", ".sam")
-        with open(os.path.join(workdir, fn), "rb") as f:
-            res[key] = f.read()
-    return res
+sys.path.insert(0, os.path.dirname(HERE))
+import harness  # noqa: E402  (same canonicalisation as the tests)
 
 
 def run_reference(case, mode, workdir):
-    exe = os.path.join(ROOT, "oracle", "_ref", "pbsim_ref" if mode == "glibc" else "pbsim_ref_philox")
-    args = resolve(CASES[case]["args"], os.path.join(HERE, "inputs"), REF_DATA)
-    seed = args[args.index("--seed") + 1]
-    stubs = os.path.join(workdir, "stubs")
-    make_stubs(stubs)
-    env = dict(os.environ, PATH=stubs + ":" + os.environ["PATH"], PBSHIM_SEED=seed, PBSHIM_MODE="philox")
-    p = subprocess.run([exe] + args + ["--prefix", os.path.join(workdir, "out")], env=env,
-                       capture_output=True, text=True, check=True)
-    outs = canonical_outputs(workdir, "out")
-    outs[".stderr"] = strip_report(p.stderr).encode()
-    return outs
+    # the six model files of the cases are committed under tests/golden/models (copies of /root/reference/data)
+    return harness.run_reference(CASES[case]["args"], mode, workdir, case=CASES[case])
 
 
 def main():

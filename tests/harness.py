@@ -44,7 +44,7 @@ def strip_report(err: str) -> str:
     for line in err.splitlines():
         if line.startswith((":::: System utilization", "CPU time(s)", "Elapsed time(s)", "oracle draws")):
             continue
-        if line.split(" : ")[0] in ("prefix", "genome", "transcript", "errhmm", "qshmm", "file name", "template"):
+        if line.split(" : ")[0] in ("prefix", "genome", "transcript", "errhmm", "qshmm", "file name", "template", "sample"):
             continue
         keep.append(line)
     return "\n".join(keep).rstrip("\n") + "\n"
@@ -65,6 +65,9 @@ def resolve(args):
 def collect(workdir, prefix="out"):
     res = {}
     for fn in sorted(os.listdir(workdir)):
+        if fn.startswith("sample_profile_"):     # --sample-profile-id writes into the working directory (pbsim.cpp:1590)
+            with open(os.path.join(workdir, fn), "rb") as f:
+                res[".profile_" + fn.rsplit(".", 1)[1]] = f.read()
         if fn.startswith(prefix) and os.path.isfile(os.path.join(workdir, fn)):
             key = fn[len(prefix):]
             key = key.replace(".fq.gz", ".fq").replace(".maf.gz", ".maf").replace(".bam", ".sam")
@@ -73,10 +76,21 @@ def collect(workdir, prefix="out"):
     return res
 
 
-def run_oracle(args, mode, workdir, extra=()):
+def run_setup(exe_and_flags, case, workdir, env=None):
+    """A case may name a command that must have run before it in the same directory (a stored sample profile)."""
+    if case and case.get("setup"):
+        subprocess.run(exe_and_flags[:1] + resolve(case["setup"]) + ["--prefix", os.path.join(workdir, "setup")] +
+                       exe_and_flags[1:], capture_output=True, text=True, check=True, cwd=workdir, env=env)
+        for fn in os.listdir(workdir):
+            if fn.startswith("setup"):
+                os.remove(os.path.join(workdir, fn))
+
+
+def run_oracle(args, mode, workdir, extra=(), case=None):
     build_oracle()
+    run_setup([ORACLE, "--rng", mode], case, workdir)
     p = subprocess.run([ORACLE] + resolve(args) + ["--prefix", os.path.join(workdir, "out"), "--rng", mode] + list(extra),
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, cwd=workdir)
     if p.returncode != 0:
         raise RuntimeError(f"oracle failed ({p.returncode}): {p.stderr[-2000:]}")
     outs = collect(workdir)
@@ -94,15 +108,16 @@ def make_stubs(d):
         os.chmod(os.path.join(d, n), 0o755)
 
 
-def run_reference(args, mode, workdir):
+def run_reference(args, mode, workdir, case=None):
     exe = REF_GLIBC if mode == "glibc" else REF_PHILOX
     args = resolve(args)
     seed = args[args.index("--seed") + 1]
     stubs = os.path.join(workdir, "stubs")
     make_stubs(stubs)
     env = dict(os.environ, PATH=stubs + ":" + os.environ["PATH"], PBSHIM_SEED=seed, PBSHIM_MODE="philox")
+    run_setup([exe], case, workdir, env)
     p = subprocess.run([exe] + args + ["--prefix", os.path.join(workdir, "out")], env=env,
-                       capture_output=True, text=True, check=True)
+                       capture_output=True, text=True, check=True, cwd=workdir)
     outs = collect(workdir)
     outs[".stderr"] = strip_report(p.stderr).encode()
     return outs

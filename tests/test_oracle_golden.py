@@ -16,7 +16,7 @@ MANIFEST = harness.load_manifest()
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_oracle_matches_reference_golden(case, mode, tmp_path):
-    outs = harness.run_oracle(CASES[case]["args"], mode, str(tmp_path))
+    outs = harness.run_oracle(CASES[case]["args"], mode, str(tmp_path), case=CASES[case])
     want = MANIFEST[f"{case}/{mode}"]
     assert sorted(outs) == sorted(want), (sorted(outs), sorted(want))
     for k, v in outs.items():
