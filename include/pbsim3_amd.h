@@ -37,6 +37,7 @@ extern "C" {
 #define PBSIM_STRATEGY_TEMPL 3 /* pbsim.cpp:36 */
 #define PBSIM_METHOD_QS 1      /* pbsim.cpp:37 */
 #define PBSIM_METHOD_ERR 2     /* pbsim.cpp:38 */
+#define PBSIM_METHOD_SAMPLE 3  /* pbsim.cpp:39 (METHOD_SAM; the store/reuse variants :40-41 are file handling of the caller) */
 
 /* Validated simulation parameters = the fields of `struct sim_t`
  * (pbsim.cpp:51-77) that the hot path reads.  pbsim_params_default() applies
@@ -143,6 +144,13 @@ int pbsim_simulate_wgs(pbsim_ctx *ctx, const pbsim_sink *sink);
 int pbsim_simulate_trans(pbsim_ctx *ctx, const pbsim_sink *sink);
 int pbsim_simulate_templ(pbsim_ctx *ctx, const pbsim_sink *sink); /* simulate_by_errhmm_templ :4807 / _qshmm_templ :3055 */
 int pbsim_get_stats(pbsim_ctx *ctx, pbsim_stats *out);          /* pbsim.cpp:4082-4105, 5541-5562 */
+/* Sampling method (--method sample, wgs only, single pass).  pbsim_set_sample_profile hands over what
+ * get_sample_inf (pbsim.cpp:1155-1330) leaves in its filtered profile: the quality strings that passed the
+ * length / accuracy filter, in file order (the caller parses the FASTQ, keeps the statistics and the
+ * sample_profile_<ID> files).  pbsim_simulate_sample = simulate_by_sample (pbsim.cpp:1694-1949) for the
+ * current reference record. */
+int pbsim_set_sample_profile(pbsim_ctx *ctx, int64_t n, const uint8_t *const *quals, const int64_t *lens);
+int pbsim_simulate_sample(pbsim_ctx *ctx, const pbsim_sink *sink);
 /* SAM header the reference's main() writes when it opens the samtools pipe for a
  * unit (pass_num > 1; pbsim.cpp:721-722 wgs, :784-785 trans/templ).  Returns the
  * byte count (excluding the NUL), or the size needed when buf is NULL/too small. */

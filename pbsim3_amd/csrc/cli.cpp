@@ -32,7 +32,9 @@ namespace {
 struct Cli {
   int set_flg[32] = {0};
   pbsim_params p;
-  std::string genome, transcript, templ, prefix = "sd", model, sample;
+  std::string genome, transcript, templ, prefix = "sd", model, sample, profile_id;
+  bool sam_store = false, sam_reuse = false;  // METHOD_SAM_STORE / METHOD_SAM_REUSE (pbsim.cpp:40-41, 1567-1580)
+  double accuracy_min = 0.75, accuracy_max = 1.0;
   int device = 0;
   bool no_gzip = false, use_samtools = false;
   bool gzip_on_gpu = true;  // --gzip gpu|host: where the .gz / BGZF members are produced
@@ -136,8 +138,10 @@ void print_sim_param(const Cli &c) {  // pbsim.cpp:5397-5465
   fprintf(stderr, ":::: Simulation parameters :::\n\n");
   fprintf(stderr, "strategy : %s\n",
           p.strategy == PBSIM_STRATEGY_WGS ? "wgs" : p.strategy == PBSIM_STRATEGY_TRANS ? "trans" : "templ");
+  const bool sampling = p.method == PBSIM_METHOD_SAMPLE;
   if (p.method == PBSIM_METHOD_QS) fprintf(stderr, "method : qshmm\nqshmm : %s\n", c.model.c_str());
-  else fprintf(stderr, "method : errhmm\nerrhmm : %s\n", c.model.c_str());
+  else if (p.method == PBSIM_METHOD_ERR) fprintf(stderr, "method : errhmm\nerrhmm : %s\n", c.model.c_str());
+  else fprintf(stderr, "method : sample\n");
   if (p.strategy == PBSIM_STRATEGY_WGS) fprintf(stderr, "genome : %s\n", c.genome.c_str());
   else if (p.strategy == PBSIM_STRATEGY_TRANS) fprintf(stderr, "transcript : %s\n", c.transcript.c_str());
   else fprintf(stderr, "template : %s\n", c.templ.c_str());
@@ -145,15 +149,27 @@ void print_sim_param(const Cli &c) {  // pbsim.cpp:5397-5465
   fprintf(stderr, "id-prefix : %s\n", p.id_prefix);
   if (p.strategy == PBSIM_STRATEGY_WGS) fprintf(stderr, "depth : %lf\n", p.depth);
   if (p.strategy != PBSIM_STRATEGY_TEMPL) {
-    fprintf(stderr, "length-mean : %f\n", p.len_mean);
-    fprintf(stderr, "length-sd : %f\n", p.len_sd);
+    if (sampling) {
+      fprintf(stderr, "length-mean : (sample FASTQ)\nlength-sd : (sample FASTQ)\n");
+    } else {
+      fprintf(stderr, "length-mean : %f\n", p.len_mean);
+      fprintf(stderr, "length-sd : %f\n", p.len_sd);
+    }
     fprintf(stderr, "length-min : %ld\n", (long)p.len_min);
     fprintf(stderr, "length-max : %ld\n", (long)p.len_max);
   }
   if (p.method != PBSIM_METHOD_ERR)
     fprintf(stderr, "difference-ratio : %ld:%ld:%ld\n", (long)p.sub_ratio, (long)p.ins_ratio, (long)p.del_ratio);
   fprintf(stderr, "seed : %d\n", p.seed);
-  fprintf(stderr, "accuracy-mean : %f\n", p.accuracy_mean);
+  if (sampling) {  // pbsim.cpp:5453-5460; an option that was not given prints as glibc's "(null)"
+    fprintf(stderr, "sample : %s\n", c.set_flg[11] ? c.sample.c_str() : "(null)");
+    fprintf(stderr, "sample-profile-id : %s\n", c.set_flg[12] ? c.profile_id.c_str() : "(null)");
+    fprintf(stderr, "accuracy-mean : (sample FASTQ)\naccuracy-sd : (sample FASTQ)\n");
+    fprintf(stderr, "accuracy-min : %f\n", c.accuracy_min);
+    fprintf(stderr, "accuracy-max : %f\n", c.accuracy_max);
+  } else {
+    fprintf(stderr, "accuracy-mean : %f\n", p.accuracy_mean);
+  }
   fprintf(stderr, "pass_num : %d\n", p.pass_num);
   fprintf(stderr, "hp-del-bias : %f\n", p.hp_del_bias);
   fprintf(stderr, "\n");
@@ -232,7 +248,7 @@ int main(int argc, char **argv) {
     case 1:
       if (!strncmp(optarg, "qshmm", 5)) c.p.method = PBSIM_METHOD_QS;
       else if (!strncmp(optarg, "errhmm", 6)) c.p.method = PBSIM_METHOD_ERR;
-      else if (!strncmp(optarg, "sample", 6)) die(": --method sample is not provided by the MI355X path (SURVEY 2 row 19)");
+      else if (!strncmp(optarg, "sample", 6)) c.p.method = PBSIM_METHOD_SAMPLE;
       else die(" (method: %s): Acceptable value: qshmm, errhmm, sample.", optarg);
       break;
     case 2: c.genome = optarg; break;
@@ -270,6 +286,15 @@ int main(int argc, char **argv) {
     }
     case 10: c.p.seed = (unsigned int)atoi(optarg); break;
     case 11: c.sample = optarg; break;
+    case 12: c.profile_id = optarg; break;
+    case 13:
+      c.accuracy_min = atof(optarg);
+      if (c.accuracy_min < 0.0 || c.accuracy_min > 1.0) die(" (accuracy-min: %s): Acceptable range is 0.0-1.0.", optarg);
+      break;
+    case 14:
+      c.accuracy_max = atof(optarg);
+      if (c.accuracy_max < 0.0 || c.accuracy_max > 1.0) die(" (accuracy-max: %s): Acceptable range is 0.0-1.0.", optarg);
+      break;
     case 15: case 16: c.model = optarg; break;
     case 17:
       c.p.len_mean = atof(optarg);
@@ -327,6 +352,23 @@ int main(int argc, char **argv) {
   if (c.p.strategy == PBSIM_STRATEGY_WGS && !c.set_flg[2]) die(": for --strategy wgs, --genome must be set.");
   if (c.p.strategy == PBSIM_STRATEGY_TRANS && !c.set_flg[3]) die(": for --strategy trans, --transcript must be set.");
   if (c.p.strategy == PBSIM_STRATEGY_TEMPL && !c.set_flg[21]) die(": for --strategy templ, --template must be set.");
+  const bool sampling = c.p.method == PBSIM_METHOD_SAMPLE;
+  const std::string profile_fq = "sample_profile_" + c.profile_id + ".fastq",
+                    profile_stats = "sample_profile_" + c.profile_id + ".stats";
+  if (sampling) {  // pbsim.cpp:1461-1464, 1567-1634
+    if (c.p.strategy != PBSIM_STRATEGY_WGS) die(": sampling-based simulation is possible only for wgs strategy.");
+    if (c.set_flg[11]) c.sam_store = c.set_flg[12] != 0;
+    else if (c.set_flg[12]) c.sam_reuse = true;
+    else die(": for --method sample, --sample (and/or --sample-profile-id) must be set.");
+    for (const std::string &f : {profile_fq, profile_stats}) {
+      FILE *fp = (c.sam_store || c.sam_reuse) ? fopen(f.c_str(), "r") : NULL;
+      if (fp) fclose(fp);
+      if (c.sam_store && fp) die(": %s exists.", f.c_str());
+      if (c.sam_reuse && !fp) die(": %s does not exist.", f.c_str());
+    }
+  }
+  c.accuracy_min = c.set_flg[13] ? (int)(c.accuracy_min * 100) * 0.01 : 0.75;
+  c.accuracy_max = c.set_flg[14] ? (int)(c.accuracy_max * 100) * 0.01 : 1.0;
   if (c.p.method == PBSIM_METHOD_QS && !c.set_flg[15]) die(": for --method qshmm, --qshmm must be set.");
   if (c.p.method == PBSIM_METHOD_ERR && !c.set_flg[16]) die(": for --method errhmm, --errhmm must be set.");
   if (c.set_flg[19]) c.p.accuracy_mean = (int)(c.p.accuracy_mean * 100) * 0.01;
@@ -334,12 +376,55 @@ int main(int argc, char **argv) {
     fprintf(stderr, "ERROR: length min(%ld) is greater than max(%ld).\n", (long)c.p.len_min, (long)c.p.len_max);
     exit(-1);
   }
+  if (c.p.pass_num > 1 && sampling) die(": sampling-based simulation supports only single-pass.");
   if (c.gzip_threads < 1) c.gzip_threads = (int)std::max(1u, std::thread::hardware_concurrency());
   print_sim_param(c);
 
+  pbsim::SampleProfile prof;
+  if (sampling) {  // pbsim.cpp:580-617: read (or re-read) the profile, print its statistics
+    std::string e;
+    if (c.sam_reuse) {
+      if (!pbsim::read_sample_profile(profile_fq, profile_stats, &prof, &e)) die(": %s", e.c_str());
+    } else {
+      if (!pbsim::read_sample_fastq(c.sample.c_str(), (long)c.p.len_min, (long)c.p.len_max, c.accuracy_min,
+                                    c.accuracy_max, &prof, &e))
+        die(": %s", e.c_str());
+      if (c.sam_store && !pbsim::write_sample_profile(profile_fq, profile_stats, prof, &e)) die(": %s", e.c_str());
+    }
+    fprintf(stderr, ":::: sample reads stats ::::\n\n");  // print_sample_stats, pbsim.cpp:1336-1360
+    if (c.sam_reuse) {
+      fprintf(stderr, "file name : %s\n", profile_fq.c_str());
+    } else {
+      fprintf(stderr, "file name : %s\n", c.sample.c_str());
+      fprintf(stderr, "\n:: all reads ::\n");
+      fprintf(stderr, "read num. : %ld\n", prof.num);
+      fprintf(stderr, "read total length : %lld\n", prof.len_total);
+      fprintf(stderr, "read min length : %ld\n", prof.len_min);
+      fprintf(stderr, "read max length : %ld\n", prof.len_max);
+    }
+    fprintf(stderr, "\n:: filtered reads ::\n");
+    fprintf(stderr, "read num. : %ld\n", prof.num_filtered);
+    fprintf(stderr, "read total length : %lld\n", prof.len_total_filtered);
+    fprintf(stderr, "read min length : %ld\n", prof.len_min_filtered);
+    fprintf(stderr, "read max length : %ld\n", prof.len_max_filtered);
+    fprintf(stderr, "read length mean (SD) : %f (%f)\n", prof.len_mean_filtered, prof.len_sd_filtered);
+    fprintf(stderr, "read accuracy mean (SD) : %f (%f)\n", prof.accuracy_mean_filtered, prof.accuracy_sd_filtered);
+    fprintf(stderr, "\n");
+  }
+
   pbsim_ctx *ctx = pbsim_create(&c.p, c.device);
   if (!ctx) check(0);
-  check(c.p.method == PBSIM_METHOD_ERR ? pbsim_load_errhmm(ctx, c.model.c_str()) : pbsim_load_qshmm(ctx, c.model.c_str()));
+  if (sampling) {
+    std::vector<const uint8_t *> qp;
+    std::vector<int64_t> ql;
+    for (const std::string &q : prof.quals) {
+      qp.push_back((const uint8_t *)q.data());
+      ql.push_back((int64_t)q.size());
+    }
+    check(pbsim_set_sample_profile(ctx, (int64_t)qp.size(), qp.data(), ql.data()));
+  } else {
+    check(c.p.method == PBSIM_METHOD_ERR ? pbsim_load_errhmm(ctx, c.model.c_str()) : pbsim_load_qshmm(ctx, c.model.c_str()));
+  }
   if (native_bam(c)) check(pbsim_set_bam_output(ctx, 1));
   if (!c.no_gzip && c.gzip_on_gpu)  // bit 0: read sink, bit 1: MAF sink; a samtools pipe still wants SAM text
     check(pbsim_set_deflate(ctx, (c.p.pass_num > 1 && c.use_samtools) ? 2 : 3));
@@ -373,7 +458,7 @@ int main(int argc, char **argv) {
       open_sink(c, &o_maf, name, std::string(name) + ".gz", false);
       Two two = {&o_read, &o_maf};
       pbsim_sink sink = {&two, cb_read, cb_maf};
-      check(pbsim_simulate_wgs(ctx, &sink));
+      check(sampling ? pbsim_simulate_sample(ctx, &sink) : pbsim_simulate_wgs(ctx, &sink));
       pbsim_stats st;
       check(pbsim_get_stats(ctx, &st));
       print_simulation_stats(c, st, n);

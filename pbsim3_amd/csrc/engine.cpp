@@ -153,6 +153,11 @@ struct pbsim_ctx {
   // trans units (pbsim_set_transcripts)
   int64_t n_units = 0, trans_reads = 0;
   DevBuf d_read_unit, d_read_minus, d_read_base, d_unit_len, d_unit_rank, d_unit_names, d_off_table, d_ssp, d_ssp_rv;
+  // sampling method (pbsim_set_sample_profile): filtered quality strings, padded to 8 bytes each
+  DevBuf d_sq, d_sq_line_len, d_sq_line_qoff, d_sq_vbase;
+  std::vector<int32_t> sq_len;
+  std::vector<int64_t> sq_off;
+  int64_t sq_total = 0;        // sample.len_total_filtered
   int64_t scratch_budget = 0;  // bytes of wave scratch per slot
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
@@ -173,7 +178,8 @@ struct pbsim_ctx {
 
 namespace {
 
-int regions_of(const pbsim_ctx *c) { return c->p.method == PBSIM_METHOD_QS ? 3 : 2; }
+bool has_quality_row(const pbsim_ctx *c) { return c->p.method == PBSIM_METHOD_QS || c->p.method == PBSIM_METHOD_SAMPLE; }
+int regions_of(const pbsim_ctx *c) { return has_quality_row(c) ? 3 : 2; }
 int ncls_of(const pbsim_ctx *c) { return c->hdr.acc_hi - c->hdr.acc_lo + 1; }
 
 int upload(DevBuf &b, const void *src, size_t n, hipStream_t s) {
@@ -195,7 +201,15 @@ int ensure_header_tables(pbsim_ctx *c) {
 int ensure_class_tables(pbsim_ctx *c) {
   if (!c->class_tables_dirty) return PBSIM_SUCCEEDED;
   std::string e;
-  if (c->p.method == PBSIM_METHOD_ERR) {
+  if (c->p.method == PBSIM_METHOD_SAMPLE) {  // no model: only qc[].prob and set_mut's thresholds
+    build_mut_tables(c->p, c->bias, &c->qct);
+    std::vector<uint8_t> t(94 * 4 * 2 + 94 * 12 * 4 + 94 * 8);
+    memcpy(t.data(), c->qct.sub_thre, 94 * 4);
+    memcpy(t.data() + 94 * 4, c->qct.ins_thre, 94 * 4);
+    memcpy(t.data() + 94 * 8, c->qct.del_thr, 94 * 12 * 4);
+    memcpy(t.data() + 94 * 8 + 94 * 48, c->qct.qprob, 94 * 8);
+    if (!upload(c->d_qs_tabs, t.data(), t.size(), c->stream)) return PBSIM_FAILED;
+  } else if (c->p.method == PBSIM_METHOD_ERR) {
     if (!c->err) return fail("no ERRHMM model loaded (pbsim_load_errhmm)");
     const bool wgs = c->p.strategy == PBSIM_STRATEGY_WGS;
     if (!build_err_class_tables(*c->err, c->hdr, c->bias, wgs, &c->ect, &e)) return fail(e);
@@ -301,8 +315,17 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
     fail("pbsim_create: params is NULL");
     return nullptr;
   }
-  if (p->strategy < 1 || p->strategy > 3 || (p->method != PBSIM_METHOD_QS && p->method != PBSIM_METHOD_ERR)) {
+  if (p->strategy < 1 || p->strategy > 3 ||
+      (p->method != PBSIM_METHOD_QS && p->method != PBSIM_METHOD_ERR && p->method != PBSIM_METHOD_SAMPLE)) {
     fail("--strategy and --method must be set.");
+    return nullptr;
+  }
+  if (p->method == PBSIM_METHOD_SAMPLE && p->strategy != PBSIM_STRATEGY_WGS) {  // pbsim.cpp:1461-1464
+    fail("sampling-based simulation is possible only for wgs strategy.");
+    return nullptr;
+  }
+  if (p->method == PBSIM_METHOD_SAMPLE && p->pass_num > 1) {  // pbsim.cpp:1675-1680
+    fail("sampling-based simulation supports only single-pass.");
     return nullptr;
   }
   if (p->len_min > p->len_max || p->len_min < 1 || p->len_max > 1000000) {
@@ -501,6 +524,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   if (!c || n_reads < 1 || first_read < 1) return fail("pbsim_batch_walk: bad argument");
   NEED_DEVICE(c);
   if (c->s().b_enqueued) return fail("pbsim_batch_walk_begin: this slot still has a batch in flight (pbsim_batch_walk_end)");
+  if (c->p.method == PBSIM_METHOD_SAMPLE) return fail("the sampling method runs through pbsim_simulate_sample");
   const bool trans = c->p.strategy != PBSIM_STRATEGY_WGS;  // trans and templ share the unit machinery
   if (!c->d_seq)
     return fail(trans ? "no transcripts/templates set (pbsim_set_transcripts, pbsim_set_templates)"
@@ -706,7 +730,7 @@ static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
   t->n_reads = n_emit;
   t->pass_num = c->p.pass_num;
   t->is_wgs = c->p.strategy == PBSIM_STRATEGY_WGS;
-  t->is_qs = c->p.method == PBSIM_METHOD_QS;
+  t->is_qs = has_quality_row(c);
   t->unit = (uint32_t)c->unit;
   t->ref_len = c->ref_len;
   t->len = c->s().d_len.as<int32_t>();
@@ -747,7 +771,9 @@ int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_inf
   DeviceFlags *flags = c->s().d_flags.as<DeviceFlags>();
   const int64_t quota = pbsim_unit_quota(c);
   const int P = c->p.pass_num;
-  launch_quota_cut(c->s().d_cum.as<int64_t>(), c->s().d_rawlen.as<int32_t>(), c->s().b_n, len_total_before, quota,
+  // the sampling method never truncates a read: it only stops before the first read that starts at or past the quota
+  launch_quota_cut(c->s().d_cum.as<int64_t>(),
+                   c->p.method == PBSIM_METHOD_SAMPLE ? nullptr : c->s().d_rawlen.as<int32_t>(), c->s().b_n, len_total_before, quota,
                    c->s().b_truncated ? 1 : 0, flags, c->s().stream);
   DeviceFlags f;
   if (!read_flags(c, &f)) return PBSIM_FAILED;
@@ -837,7 +863,7 @@ int pbsim_batch_account(pbsim_ctx *c) {
   HIP_OK(hipMemcpyAsync(ns, c->s().d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
   HIP_OK(hipMemcpyAsync(ni, c->s().d_nins.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
   HIP_OK(hipMemcpyAsync(nd, c->s().d_ndel.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
-  if (c->p.method == PBSIM_METHOD_QS)
+  if (has_quality_row(c))
     HIP_OK(hipMemcpyAsync(qs, c->s().d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, c->s().stream));
   HIP_OK(hipStreamSynchronize(c->s().stream));
   c->res_num += c->s().b_info.n_final;
@@ -851,7 +877,7 @@ int pbsim_batch_account(pbsim_ctx *c) {
     c->res_ins += ni[t];
     c->res_del += nd[t];
     double value;
-    if (c->p.method == PBSIM_METHOD_QS) value = 1.0 - (qs[t] / len);
+    if (has_quality_row(c)) value = 1.0 - (qs[t] / len);
     else value = 1.0 - ((double)((long)ns[t] + ni[t] + nd[t]) / len);
     c->accuracy_total += value;
     const double w = value * 100000 + 0.5;
@@ -1339,6 +1365,215 @@ int pbsim_set_templates(pbsim_ctx *c, int64_t n, const char *const *ids, const u
   if (c->p.strategy != PBSIM_STRATEGY_TEMPL) return fail("pbsim_set_templates: strategy is not templ");
   std::vector<int64_t> one((size_t)n, 1), zero((size_t)n, 0);
   return set_units(c, n, ids, one.data(), zero.data(), seqs, lens, true);
+}
+
+// get_sample_inf's product (pbsim.cpp:1155-1330): the quality strings that passed the length and accuracy
+// filter, in file order.  Parsing, filtering, the statistics and the stored-profile files are the caller's.
+int pbsim_set_sample_profile(pbsim_ctx *c, int64_t n, const uint8_t *const *quals, const int64_t *lens) {
+  if (!c || n < 1 || !quals || !lens) return fail("pbsim_set_sample_profile: bad argument");
+  NEED_DEVICE(c);
+  if (c->p.method != PBSIM_METHOD_SAMPLE) return fail("pbsim_set_sample_profile: method is not sample");
+  if (n > 0x7fffffffLL) return fail("too many sample reads");
+  HIP_OK(hipSetDevice(c->device));
+  c->sq_len.resize((size_t)n);
+  c->sq_off.resize((size_t)n);
+  int64_t total = 0, bytes = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (lens[i] < 1 || lens[i] > 1000000) return fail("sample read length outside 1-1000000");
+    c->sq_len[(size_t)i] = (int32_t)lens[i];
+    c->sq_off[(size_t)i] = bytes;
+    total += lens[i];
+    bytes += (lens[i] + 7) & ~7LL;
+  }
+  std::vector<uint8_t> pool((size_t)bytes + 8, 0);
+  for (int64_t i = 0; i < n; i++) memcpy(pool.data() + c->sq_off[(size_t)i], quals[i], (size_t)lens[i]);
+  if (!upload(c->d_sq, pool.data(), pool.size(), c->stream)) return PBSIM_FAILED;
+  HIP_OK(hipStreamSynchronize(c->stream));
+  c->sq_total = total;
+  return PBSIM_SUCCEEDED;
+}
+
+// simulate_by_sample (pbsim.cpp:1694-1949) for the current record.  Each sweep over the profile uses string s
+// `sample_num` or `sample_num + 1` times ((sample_value + s) % sample_interval == 0), reads are numbered in that
+// order, and a read is made as long as len_total < quota at its start.  A chunk = a run of consecutive strings
+// with all their copies; its strings walk in parallel, one lane each (k_walk_sample), and everything after the walk
+// (prefix in read order, the cut, text, statistics) is the ordinary batch machinery.
+int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
+  if (!c) return fail("bad argument");
+  NEED_DEVICE(c);
+  if (c->p.method != PBSIM_METHOD_SAMPLE) return fail("pbsim_simulate_sample: method is not sample");
+  if (!c->d_seq) return fail("no reference set (pbsim_set_reference)");
+  if (c->sq_len.empty()) return fail("no sample profile set (pbsim_set_sample_profile)");
+  HIP_OK(hipSetDevice(c->device));
+  if (!ensure_class_tables(c)) return PBSIM_FAILED;
+  pbsim_reset_stats(c);
+  c->cur = 0;
+  Slot &sl = c->s();
+  const int64_t quota = pbsim_unit_quota(c), F = (int64_t)c->sq_len.size(), G = c->ref_len;
+  int64_t sample_num = quota / c->sq_total;            // :1718-1728
+  const int64_t residue = quota % c->sq_total;
+  int64_t interval = 1;
+  if (residue != 0) {
+    interval = (int64_t)((double)(c->sq_total / residue) * 2 + 0.5);
+    if (interval > (int64_t)(F * 0.5)) interval = (int64_t)(F * 0.5);
+  }
+  if (interval < 1) return fail("sample profile holds a single read: the reference divides by zero here (pbsim.cpp:1741)");
+  int64_t len_total = 0, res = 0;
+  bool done = false;
+  std::vector<int32_t> h_len, h_vbase, h_cap, h_tos, h_sot;
+  std::vector<int64_t> h_qoff, h_woff;
+  while (len_total < quota && !done) {
+    const int64_t sv = (int64_t)(header_block(c->p.seed, (uint32_t)c->unit, (uint32_t)(res + 1)).w % (uint32_t)F);  // :1732
+    int64_t line = 0;
+    while (line < F && len_total < quota && !done) {
+      // ---- lay the chunk out: strings with at least one copy, 64 per wave, one virtual wave per copy
+      h_len.clear(); h_qoff.clear(); h_vbase.assign(1, 0); h_cap.clear(); h_woff.clear(); h_tos.clear(); h_sot.clear();
+      int64_t need = 0, n_tasks = 0;
+      while (line < F) {
+        // next wave: up to 64 strings that have copies in this sweep
+        int64_t probe = line, cnt = 0, kmax = 0, lmax = 0, tasks_w = 0;
+        int64_t idx[64], num[64];
+        while (probe < F && cnt < 64) {
+          const int64_t k = sample_num + (((sv + probe) % interval == 0) ? 1 : 0);
+          if (k > 0) {
+            idx[cnt] = probe;
+            num[cnt] = k;
+            kmax = std::max(kmax, k);
+            lmax = std::max<int64_t>(lmax, std::min<int64_t>(c->sq_len[(size_t)probe], G));
+            tasks_w += k;
+            cnt++;
+          }
+          probe++;
+        }
+        if (cnt == 0) {
+          line = probe;
+          break;
+        }
+        const int64_t cap_dw = (2 * lmax + kScratchPad + 3) / 4;
+        const int64_t bytes_w = kmax * cap_dw * 256 * 3;
+        if (!h_len.empty() && (need + bytes_w > c->scratch_budget || n_tasks + tasks_w > 0x3fffffff ||
+                               (int64_t)h_cap.size() + kmax > 0x1ffffff))
+          break;  // chunk full: this wave opens the next one
+        if (bytes_w > c->scratch_budget)
+          return fail("scratch pool too small for one wave of sample strings and their copies (pbsim_set_scratch_bytes)");
+        const int32_t v0 = (int32_t)h_cap.size();
+        for (int64_t k = 0; k < kmax; k++) {
+          h_cap.push_back((int32_t)cap_dw);
+          h_woff.push_back(need + k * cap_dw * 256 * 3);
+        }
+        h_tos.resize(h_tos.size() + (size_t)kmax * 64, -1);
+        for (int64_t e = 0; e < cnt; e++) {
+          h_len.push_back(c->sq_len[(size_t)idx[e]]);
+          h_qoff.push_back(c->sq_off[(size_t)idx[e]]);
+          for (int64_t k = 0; k < num[e]; k++) {
+            const int64_t slot = ((int64_t)v0 + k) * 64 + e;
+            h_tos[(size_t)slot] = (int32_t)n_tasks;
+            h_sot.push_back((int32_t)slot);
+            n_tasks++;
+          }
+        }
+        while (h_len.size() % 64 != 0) {  // the kernel indexes strings as wave * 64 + lane: pad a short wave
+          h_len.push_back(0);
+          h_qoff.push_back(0);
+        }
+        h_vbase.push_back((int32_t)h_cap.size());
+        need += bytes_w;
+        line = probe;
+      }
+      if (n_tasks == 0) continue;
+      const int64_t n_lines = (int64_t)h_len.size(), n_lw = (int64_t)h_vbase.size() - 1, V = (int64_t)h_cap.size();
+      if (res + n_tasks > 0xfffffff0LL) return fail("read index exceeds 32 bits");
+      // ---- device state of the batch
+      HIP_OK(sl.d_flags.ensure(sizeof(DeviceFlags)));
+      HIP_OK(sl.d_len.ensure(n_tasks * 4));
+      HIP_OK(sl.d_off.ensure(n_tasks * 4));
+      HIP_OK(sl.d_task_of_slot.ensure(V * 64 * 4));
+      HIP_OK(sl.d_slot_of_task.ensure(n_tasks * 4));
+      HIP_OK(sl.d_wave_cap.ensure(V * 4));
+      HIP_OK(sl.d_wave_off.ensure(V * 8));
+      HIP_OK(sl.d_out_len.ensure(n_tasks * 4));
+      HIP_OK(sl.d_maf_len.ensure(n_tasks * 4));
+      HIP_OK(sl.d_nsub.ensure(n_tasks * 4));
+      HIP_OK(sl.d_nins.ensure(n_tasks * 4));
+      HIP_OK(sl.d_ndel.ensure(n_tasks * 4));
+      HIP_OK(sl.d_qsum.ensure(n_tasks * 8));
+      HIP_OK(sl.d_cum.ensure((n_tasks + 1) * 8));
+      HIP_OK(sl.d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
+      HIP_OK(sl.d_scratch.ensure((size_t)c->scratch_budget, true));
+      HIP_OK(c->d_sq_line_len.ensure(n_lines * 4));
+      HIP_OK(c->d_sq_line_qoff.ensure(n_lines * 8));
+      HIP_OK(c->d_sq_vbase.ensure((n_lw + 1) * 4));
+      DeviceFlags f0;
+      memset(&f0, 0, sizeof f0);
+      f0.total_slots = V * 64;
+      f0.n_final = n_tasks;
+      HIP_OK(hipMemcpyAsync(sl.d_flags.p, &f0, sizeof f0, hipMemcpyHostToDevice, sl.stream));
+      HIP_OK(hipMemcpyAsync(c->d_sq_line_len.p, h_len.data(), n_lines * 4, hipMemcpyHostToDevice, sl.stream));
+      HIP_OK(hipMemcpyAsync(c->d_sq_line_qoff.p, h_qoff.data(), n_lines * 8, hipMemcpyHostToDevice, sl.stream));
+      HIP_OK(hipMemcpyAsync(c->d_sq_vbase.p, h_vbase.data(), (n_lw + 1) * 4, hipMemcpyHostToDevice, sl.stream));
+      HIP_OK(hipMemcpyAsync(sl.d_task_of_slot.p, h_tos.data(), V * 64 * 4, hipMemcpyHostToDevice, sl.stream));
+      HIP_OK(hipMemcpyAsync(sl.d_slot_of_task.p, h_sot.data(), n_tasks * 4, hipMemcpyHostToDevice, sl.stream));
+      HIP_OK(hipMemcpyAsync(sl.d_wave_cap.p, h_cap.data(), V * 4, hipMemcpyHostToDevice, sl.stream));
+      HIP_OK(hipMemcpyAsync(sl.d_wave_off.p, h_woff.data(), V * 8, hipMemcpyHostToDevice, sl.stream));
+      DeviceFlags *flags = sl.d_flags.as<DeviceFlags>();
+      SampleArgs a;
+      memset(&a, 0, sizeof a);
+      a.seed = c->p.seed;
+      a.unit = (uint32_t)c->unit;
+      a.first_read = res + 1;
+      a.n_lines = (int32_t)n_lines;
+      a.n_line_waves = (int32_t)n_lw;
+      a.ref.seq = c->d_seq;
+      a.ref.hp = c->d_hp.as<uint8_t>();
+      a.ref.len = G;
+      a.hp11 = c->d_hp11.as<uint16_t>();
+      a.quals = c->d_sq.as<uint8_t>();
+      a.line_qoff = c->d_sq_line_qoff.as<int64_t>();
+      a.line_len = c->d_sq_line_len.as<int32_t>();
+      a.vbase = c->d_sq_vbase.as<int32_t>();
+      a.task_of_slot = sl.d_task_of_slot.as<int32_t>();
+      a.wave_cap = sl.d_wave_cap.as<int32_t>();
+      a.wave_off = sl.d_wave_off.as<int64_t>();
+      a.scratch = sl.d_scratch.as<uint8_t>();
+      a.span = sl.d_len.as<int32_t>();
+      a.off = sl.d_off.as<int32_t>();
+      a.out_len = sl.d_out_len.as<int32_t>();
+      a.maf_len = sl.d_maf_len.as<int32_t>();
+      a.nsub = sl.d_nsub.as<int32_t>();
+      a.nins = sl.d_nins.as<int32_t>();
+      a.ndel = sl.d_ndel.as<int32_t>();
+      a.qsum = sl.d_qsum.as<double>();
+      const uint8_t *t = c->d_qs_tabs.as<uint8_t>();
+      a.sub_thre = reinterpret_cast<const uint32_t *>(t);
+      a.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
+      a.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
+      a.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
+      a.flags = flags;
+      launch_walk_sample(a, c->p.hp_del_bias == 1, sl.stream);
+      launch_gather_pass0_scan(a.out_len, n_tasks, 1, sl.d_cum.as<int64_t>(), sl.d_scan_tmp.as<int64_t>(),
+                               &flags->sums[0], sl.stream);
+      HIP_OK(hipGetLastError());
+      DeviceFlags f;
+      if (!read_flags(c, &f)) return PBSIM_FAILED;
+      if (f.error & kErrScratchOverflow) return fail("a sampled read produced more MAF columns than its scratch holds");
+      sl.b_first = res + 1;
+      sl.b_n = n_tasks;
+      sl.b_slots_max = V * 64;
+      sl.b_truncated = false;
+      sl.b_enqueued = false;
+      sl.b_walked = true;
+      sl.b_finalized = false;
+      sl.b_pass0 = f.sums[0];
+      pbsim_batch_info bi;
+      if (!pbsim_batch_finalize(c, len_total, &bi)) return PBSIM_FAILED;
+      if (!deliver(c, sink)) return PBSIM_FAILED;
+      len_total = bi.len_total_after;
+      res += bi.n_final;
+      if (bi.n_final < n_tasks) done = true;  // the quota was reached inside this chunk (:1735, :1749)
+    }
+    sample_num = 0;  // :1922
+  }
+  return PBSIM_SUCCEEDED;
 }
 
 int pbsim_simulate_templ(pbsim_ctx *c, const pbsim_sink *sink) { return pbsim_simulate_trans(c, sink); }

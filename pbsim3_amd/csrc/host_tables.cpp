@@ -425,6 +425,31 @@ bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBi
   return true;
 }
 
+// qc[].prob (pbsim.cpp:546-549) and set_mut's thresholds (:5474-5479), shared by the QSHMM and sampling walks
+void build_mut_tables(const pbsim_params &p, const HpBias &b, QsClassTables *t) {
+  for (int q = 0; q < kQcNum; q++) t->qprob[q] = pow(10, (double)q / -10);
+  const long sum = (long)(p.sub_ratio + p.ins_ratio + p.del_ratio);
+  const double sub_rate = (double)p.sub_ratio / sum, ins_rate = (double)p.ins_ratio / sum,
+               del_rate = (double)p.del_ratio / sum;
+  for (int q = 0; q < kQcNum; q++) {
+    const double pr = t->qprob[q];
+    t->sub_thre[q] = (uint32_t)(int)((pr * sub_rate) * 1000000 + 0.5);
+    t->ins_thre[q] = (uint32_t)(int)((pr * (sub_rate + ins_rate)) * 1000000 + 0.5);
+    const long del = (long)(int)((pr * del_rate) / (1 + pr * del_rate) * 1000000 + 0.5);
+    for (int hp = 0; hp < kHpSlots; hp++) {
+      // `rand_value < del_thre * bias[hp]` (pbsim.cpp:2272, 1821), rand_value integral
+      // hp==0 (Q15) reads hp_del_bias[0] = the bits of hpfreq[11]: a positive
+      // denormal once any hp==11 base has been counted, else 0.0
+      double v;
+      if (hp == 0) v = (b.hp11_seen && del > 0) ? 4.9406564584124654e-324 : 0.0;
+      else v = (double)del * b.bias[hp];
+      double c = ceil(v);
+      if (c > 4294967295.0) c = 4294967295.0;
+      t->del_thr[q][hp] = (uint32_t)c;
+    }
+  }
+}
+
 bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias &b, const pbsim_params &p,
                            QsClassTables *t, std::string *err) {
   (void)err;
@@ -450,26 +475,7 @@ bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias
       }
     }
   }
-  const long sum = (long)(p.sub_ratio + p.ins_ratio + p.del_ratio);
-  const double sub_rate = (double)p.sub_ratio / sum, ins_rate = (double)p.ins_ratio / sum,
-               del_rate = (double)p.del_ratio / sum;
-  for (int q = 0; q < kQcNum; q++) {
-    const double pr = t->qprob[q];
-    t->sub_thre[q] = (uint32_t)(int)((pr * sub_rate) * 1000000 + 0.5);
-    t->ins_thre[q] = (uint32_t)(int)((pr * (sub_rate + ins_rate)) * 1000000 + 0.5);
-    const long del = (long)(int)((pr * del_rate) / (1 + pr * del_rate) * 1000000 + 0.5);
-    for (int hp = 0; hp < kHpSlots; hp++) {
-      // `rand_value < del_thre * bias[hp]` (pbsim.cpp:2272), rand_value integral
-      // hp==0 (Q15) reads hp_del_bias[0] = the bits of hpfreq[11]: a positive
-      // denormal once any hp==11 base has been counted, else 0.0
-      double v;
-      if (hp == 0) v = (b.hp11_seen && del > 0) ? 4.9406564584124654e-324 : 0.0;
-      else v = (double)del * b.bias[hp];
-      double c = ceil(v);
-      if (c > 4294967295.0) c = 4294967295.0;
-      t->del_thr[q][hp] = (uint32_t)c;
-    }
-  }
+  build_mut_tables(p, b, t);
 
   // ---- per class
   t->acc_lo = h.acc_lo;

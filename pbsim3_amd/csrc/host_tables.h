@@ -103,5 +103,7 @@ struct QsClassTables {
 };
 bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias &b, const pbsim_params &p,
                            QsClassTables *t, std::string *err);
+// fills qprob / sub_thre / ins_thre / del_thr only (the sampling method has no model)
+void build_mut_tables(const pbsim_params &p, const HpBias &b, QsClassTables *t);
 
 }  // namespace pbsim

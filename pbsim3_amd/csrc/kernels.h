@@ -111,6 +111,30 @@ struct WalkArgs {
   DeviceFlags *flags;
 };
 
+// sampling method: one lane per filtered quality string of the chunk, copies walked in sequence
+struct SampleArgs {
+  uint32_t seed, unit;
+  int64_t first_read;         // read index of task 0
+  int32_t n_lines;            // strings in this chunk
+  int32_t n_line_waves;       // ceil(n_lines / 64)
+  RefView ref;
+  const uint16_t *hp11;
+  const uint8_t *quals;       // filtered quality strings, each padded to a multiple of 8 bytes
+  const int64_t *line_qoff;   // [n_lines] byte offset of the string
+  const int32_t *line_len;    // [n_lines]
+  const int32_t *vbase;       // [n_line_waves + 1] first virtual wave (= scratch/text slot wave) of each string wave
+  const int32_t *task_of_slot;
+  const int32_t *wave_cap;
+  const int64_t *wave_off;
+  uint8_t *scratch;
+  int32_t *span, *off;        // per task: reference bases consumed, start offset in the record
+  int32_t *out_len, *maf_len, *nsub, *nins, *ndel;
+  double *qsum;
+  const uint32_t *sub_thre, *ins_thre, *del_thr;  // [94], [94], [94*12]
+  const double *qprob;                           // [94]
+  DeviceFlags *flags;
+};
+
 struct TextArgs {
   int64_t first_read;
   int64_t n_reads;          // reads to emit (n_final)
@@ -155,6 +179,7 @@ void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byt
                         hipStream_t s);
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
                        hipStream_t s);
+void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s);
 // exclusive scan of int64 (in-place allowed: out may equal in); tmp needs (n/1024+2) int64
 void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total, hipStream_t s);
 // cum[r] = pass-0 output bases of reads < r (exclusive scan), *total = their sum

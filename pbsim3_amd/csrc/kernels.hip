@@ -524,13 +524,16 @@ struct RefCursor {
   bool minus, need_next, need_nbits;
 
   __device__ __forceinline__ void init(const WalkArgs &a, int64_t off, int L, bool minus_, bool act) {
+    init(a.ref, a.hp11, off, L, minus_, act);
+  }
+  __device__ __forceinline__ void init(const RefView &ref, const uint16_t *hp11, int64_t off, int L, bool minus_, bool act) {
     minus = minus_;
     p_first = minus ? (off + L - 1) : off;
     pl0 = (uint32_t)p_first;  // low bits are all the cursor arithmetic needs
     wstep = minus ? -1 : 1;
-    lane_seq = reinterpret_cast<const uint64_t *>(a.ref.seq) + (p_first >> 3);
-    lane_hp = reinterpret_cast<const uint64_t *>(a.ref.hp) + (p_first >> 3);
-    lane_bits = reinterpret_cast<const uint32_t *>(a.hp11) + (p_first >> 5);
+    lane_seq = reinterpret_cast<const uint64_t *>(ref.seq) + (p_first >> 3);
+    lane_hp = reinterpret_cast<const uint64_t *>(ref.hp) + (p_first >> 3);
+    lane_bits = reinterpret_cast<const uint32_t *>(hp11) + (p_first >> 5);
     rel = brel = 0;
     cur_wl = pl0 >> 3;
     cur_bl = pl0 >> 5;
@@ -944,6 +947,158 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// K2s: the sampling method's walk (pbsim.cpp:1749-1834).  The quality string comes
+// from a sample FASTQ instead of an HMM; every filtered string is used for several
+// reads in a row and is cut to the length of the read it has just produced
+// (`mut.qc[read_offset] = '\0'`, :1834), so the copies of one string form a chain.
+// One lane per STRING: the lane walks its copies one after the other (the strings
+// of a chunk run in parallel, the chain inside a string is the reference's own
+// serial dependence).  Copy k of the 64 strings of wave w lands in "virtual wave"
+// vbase[w] + k of the scratch pool, so the text kernels see ordinary tasks.
+//
+//   column m:  m >= 1 -> deletion test  D.x % 1e6 < del_thr[qc[q-1]][hp(last consumed base)]   (:1816-1831)
+//              else      error class    E.z % 1e6 vs sub_thre / ins_thre of qc[q]                (:1779-1810)
+//   ends when the reference window OR the quality string is used up                              (:1776)
+// ---------------------------------------------------------------------------
+template <bool kHpBits>
+__global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
+  __shared__ uint8_t s_comp[512];
+  __shared__ uint8_t s_sub[1024];
+  __shared__ uint32_t s_subt[96], s_ins[96], s_del[94 * 12];
+  __shared__ double s_qprob[94];
+  const int tid = threadIdx.x;
+  {
+    const uint32_t c = (uint32_t)tid;
+    s_comp[c] = (uint8_t)c;
+    s_comp[256 + c] = (uint8_t)complement(c);
+    const uint32_t t = sub_table(c);
+    s_sub[c * 4 + 0] = (uint8_t)(t & 0xffu);
+    s_sub[c * 4 + 1] = (uint8_t)((t >> 8) & 0xffu);
+    s_sub[c * 4 + 2] = (uint8_t)((t >> 16) & 0xffu);
+    s_sub[c * 4 + 3] = 0;
+    for (int i = tid; i < 94; i += kWG) {
+      s_subt[i] = a.sub_thre[i];
+      s_ins[i] = a.ins_thre[i];
+      s_qprob[i] = a.qprob[i];
+    }
+    for (int i = tid; i < 94 * 12; i += kWG) s_del[i] = a.del_thr[i];
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const int lw = (int)blockIdx.x * (kWG / 64) + (tid >> 6);
+  if (lw >= a.n_line_waves) return;
+  const int line = lw * 64 + lane;
+  const bool has_line = line < a.n_lines;
+  int Lcur = has_line ? a.line_len[line] : 0;
+  const uint64_t *qsrc = reinterpret_cast<const uint64_t *>(a.quals + (has_line ? a.line_qoff[line] : 0));
+  const int v0 = a.vbase[lw], K = a.vbase[lw + 1] - v0;
+  const int64_t G = a.ref.len;
+
+  for (int k = 0; k < K; ++k) {
+    const int64_t wave = v0 + k;
+    const int task = a.task_of_slot[wave * 64 + lane];
+    const bool valid = task >= 0;
+    const uint32_t read_idx = (uint32_t)(a.first_read + (valid ? task : 0));
+    int L = Lcur;
+    int64_t off = 0;
+    if (valid) {  // pbsim.cpp:1753-1759
+      if ((int64_t)L >= G) L = (int)G;
+      else off = (int64_t)(header_block(a.seed, a.unit, read_idx).z % (uint32_t)(G - L + 1));
+    }
+    const bool minus = (read_idx & 1u) == 0;  // :1767-1773
+    const int cap_dw = a.wave_cap[wave];
+    uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
+    uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
+    uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;
+    const int cap = cap_dw * 4;
+
+    int ro = 0, q = 0, m = 0, nsub = 0, group = 0;
+    uint32_t last_q = 0, hp_prev = 0;  // no reference base consumed yet: mut.hp[-1], observed 0 (Q15)
+    uint32_t acc_r = 0, acc_f = 0, acc_q = 0;
+    double qsum = 0.0;
+    bool act = valid && L > 0;
+    const uint32_t comp_off = minus ? 256u : 0u;
+    RefCursor<kHpBits> cur;
+    cur.init(a.ref, a.hp11, off, L, minus, act);
+    const WalkLane lane_e = walk_lane(a.seed, read_idx, 0u, 0u);
+    const WalkLane lane_d = walk_lane(a.seed, read_idx, 0u, 2u);
+    uint64_t qwin = act ? qsrc[0] : 0;
+    int qwin_idx = 0;
+
+    while (__any(act)) {
+      U4 E[4], D[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j);
+        E[j] = walk_block_fast(lane_e, a.seed, a.unit, ev);
+        D[j] = walk_block_fast(lane_d, a.seed, a.unit, ev);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const U4 w = E[j];
+        uint32_t raw, hp;
+        cur.at(ro, act, &raw, &hp);
+        const uint32_t nt = s_comp[raw + comp_off];
+        const bool deleted = (m > 0) && (D[j].x % 1000000u) < s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)];
+        if (act && (q >> 3) != qwin_idx) {  // next 8 quality characters of the string
+          qwin_idx = q >> 3;
+          qwin = qsrc[qwin_idx];
+        }
+        uint32_t qv = (uint32_t)(qwin >> ((q & 7) * 8)) & 0xffu;
+        qv = (qv >= 33u && qv < 127u) ? qv - 33u : 0u;
+        const bool emit = act && !deleted;
+        last_q = emit ? qv : last_q;
+        qsum += emit ? s_qprob[qv] : 0.0;  // ordered sum, pbsim.cpp:1857-1860
+        const uint32_t x = w.z % 1000000u;
+        const bool is_sub = x < s_subt[qv];
+        const bool is_ins = !is_sub && x < s_ins[qv];
+        uint32_t subb = s_sub[nt * 4u + w.w % 3u];
+        if (emit && is_sub && subb == 0) {  // non-ACGT reference base (:1794-1796)
+          const U4 v = walk_block(a.seed, a.unit, read_idx, 0u, (uint32_t)(group * 4 + j), 1u);
+          subb = (kATGC >> ((v.x & 3u) * 8u)) & 0xffu;
+        }
+        const uint32_t insb = (w.w & 4u) ? nt : ((kATGC >> ((w.w & 3u) * 8u)) & 0xffu);
+        const uint32_t b = is_sub ? subb : is_ins ? insb : nt;
+        const uint32_t mr = deleted ? 0u : b;
+        const uint32_t mf = (!deleted && is_ins) ? (uint32_t)'-' : nt;
+        acc_r |= mr << (8 * j);
+        acc_f |= mf << (8 * j);
+        acc_q |= (deleted ? 0u : (qv + 33u)) << (8 * j);
+        const bool consumed = act && (deleted || !is_ins);
+        hp_prev = consumed ? hp : hp_prev;
+        q += emit ? 1 : 0;
+        nsub += (emit && is_sub) ? 1 : 0;
+        ro += consumed ? 1 : 0;
+        m += act ? 1 : 0;
+        act = act && (ro < L) && (q < L) && (m < cap);
+      }
+      if (valid && m > group * 4) {
+        maf_read[(size_t)group * 64] = acc_r;
+        maf_ref[(size_t)group * 64] = acc_f;
+        qual_row[(size_t)group * 64] = acc_q;
+      }
+      cur.refill(act);
+      acc_r = 0;
+      acc_f = 0;
+      acc_q = 0;
+      group++;
+    }
+    if (valid) {
+      if (ro < L && q < L) atomicOr(&a.flags->error, kErrScratchOverflow);
+      a.span[task] = ro;          // seq_right - seq_left + 1 = ref_offset (:1846-1847)
+      a.off[task] = (int32_t)off;
+      a.out_len[task] = q;
+      a.maf_len[task] = m;
+      a.nsub[task] = nsub;
+      a.nins[task] = m - ro;
+      a.ndel[task] = m - q;
+      a.qsum[task] = qsum;
+      Lcur = q;                   // the string is cut to this read's length (:1834)
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // exclusive scan of int64 (3 phases)
 // ---------------------------------------------------------------------------
 constexpr int kScanTile = 2048;  // 256 threads x 8
@@ -1028,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_quota_find(const int64_t *cum, const in
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n_reads) return;
   const int64_t t = before + cum[r];
-  if (!(t < quota) || (t + rawlen[r] > quota)) atomicMin((long long *)&flags->n_final, (long long)r);
+  if (!(t < quota) || (rawlen && t + rawlen[r] > quota)) atomicMin((long long *)&flags->n_final, (long long)r);
 }
 
 // ---------------------------------------------------------------------------
@@ -1608,6 +1763,13 @@ void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byte
   else if (fast_rv) hipLaunchKernelGGL((k_walk_qshmm<true, false>), grid, block, lds_bytes, s, a);
   else if (hp_bits) hipLaunchKernelGGL((k_walk_qshmm<false, true>), grid, block, lds_bytes, s, a);
   else hipLaunchKernelGGL((k_walk_qshmm<false, false>), grid, block, lds_bytes, s, a);
+}
+
+void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s) {
+  if (a.n_line_waves <= 0) return;
+  const dim3 grid((unsigned)((a.n_line_waves + kWG / 64 - 1) / (kWG / 64))), block(kWG);
+  if (hp_bits) hipLaunchKernelGGL((k_walk_sample<true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_walk_sample<false>), grid, block, 0, s, a);
 }
 
 void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total,

@@ -1,9 +1,12 @@
 #include "unit_io.h"
 
+#include <limits.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <memory>
 
 namespace pbsim {
@@ -210,6 +213,158 @@ bool read_templates(const char *file, std::vector<Transcript> *out, long *num, l
   }
   flush();
   fclose(fp);
+  return true;
+}
+
+bool read_sample_fastq(const char *file, long len_min, long len_max, double acc_min, double acc_max, SampleProfile *out,
+                       std::string *err) {
+  FILE *fp = fopen(file, "r");
+  if (!fp) {
+    *err = std::string("Cannot open file: ") + file;
+    return false;
+  }
+  double qprob[94];
+  for (int q = 0; q < 94; q++) qprob[q] = pow(10, (double)q / -10);  // pbsim.cpp:546-549
+  std::vector<long> freq_len((size_t)len_max + 1, 0), freq_acc(100001, 0);
+  std::unique_ptr<char[]> line(new char[kBuf]);
+  SampleProfile &s = *out;
+  s = SampleProfile();
+  s.len_min = s.len_min_filtered = LONG_MAX;
+  std::string qc;
+  double acc_total = 0.0;
+  int line_num = 0;
+  // a record ends with its 4th line feed; a line longer than the buffer arrives in chunks without one, and only the
+  // chunks of the 4th (quality) line are kept (pbsim.cpp:1216-1283)
+  while (fgets(line.get(), kBuf, fp)) {
+    const bool nl = chomp(line.get());
+    if (!nl) {
+      if (line_num == 3) {
+        qc += line.get();
+        if ((long)qc.size() > 1000000) {
+          fclose(fp);
+          *err = "fastq is too long. Max acceptable length is 1000000.";
+          return false;
+        }
+      }
+      continue;
+    }
+    if (++line_num < 4) continue;
+    const size_t tail = strlen(line.get());
+    const long len = (long)(qc.size() + tail);
+    if (len > 1000000) {
+      fclose(fp);
+      *err = "fastq is too long. Max acceptable length is 1000000.";
+      return false;
+    }
+    s.num++;
+    s.len_total += len;
+    if (s.num > 100000000L) {
+      fclose(fp);
+      *err = "fastq is too many. Max acceptable number is 100000000.";
+      return false;
+    }
+    s.len_max = std::max(s.len_max, len);
+    s.len_min = std::min(s.len_min, len);
+    if (len >= len_min && len <= len_max) {
+      qc.append(line.get(), tail);
+      double prob = 0.0;
+      for (long i = 0; i < len; i++) {
+        const int q = (int)(unsigned char)qc[(size_t)i] - 33;
+        prob += qprob[q < 0 ? 0 : q > 93 ? 93 : q];
+      }
+      const double accuracy = 1.0 - (prob / len);
+      if (accuracy >= acc_min && accuracy <= acc_max) {
+        acc_total += accuracy;
+        s.num_filtered++;
+        s.len_total_filtered += len;
+        freq_len[(size_t)len]++;
+        freq_acc[(size_t)(int)(accuracy * 100000 + 0.5)]++;
+        s.quals.push_back(qc);
+        s.len_max_filtered = std::max(s.len_max_filtered, len);
+        s.len_min_filtered = std::min(s.len_min_filtered, len);
+      }
+    }
+    line_num = 0;
+    qc.clear();
+  }
+  fclose(fp);
+  if (s.num_filtered < 1) {
+    *err = "there is no sample in the valid range of length and accuracy.";
+    return false;
+  }
+  s.len_mean_filtered = (double)s.len_total_filtered / s.num_filtered;
+  s.accuracy_mean_filtered = acc_total / s.num_filtered;
+  double variance = 0.0;
+  for (long i = 0; i <= len_max; i++)
+    if (freq_len[(size_t)i] > 0) variance += pow((s.len_mean_filtered - i), 2) * freq_len[(size_t)i];
+  s.len_sd_filtered = sqrt(variance / s.num_filtered);
+  variance = 0.0;
+  for (long i = 0; i <= 100000; i++)
+    if (freq_acc[(size_t)i] > 0) variance += pow((s.accuracy_mean_filtered - i * 0.00001), 2) * freq_acc[(size_t)i];
+  s.accuracy_sd_filtered = sqrt(variance / s.num_filtered);
+  return true;
+}
+
+bool write_sample_profile(const std::string &fq, const std::string &stats, const SampleProfile &p, std::string *err) {
+  FILE *f = fopen(fq.c_str(), "w"), *g = fopen(stats.c_str(), "w");
+  if (!f || !g) {
+    if (f) fclose(f);
+    if (g) fclose(g);
+    *err = "Cannot open sample_profile";
+    return false;
+  }
+  for (const std::string &q : p.quals) fprintf(f, "%s\n", q.c_str());
+  fprintf(g, "num\t%ld\nlen_total\t%lld\nlen_min\t%ld\nlen_max\t%ld\n", p.num_filtered, p.len_total_filtered,
+          p.len_min_filtered, p.len_max_filtered);
+  fprintf(g, "len_mean\t%f\nlen_sd\t%f\naccuracy_mean\t%f\naccuracy_sd\t%f\n", p.len_mean_filtered, p.len_sd_filtered,
+          p.accuracy_mean_filtered, p.accuracy_sd_filtered);
+  const bool ok = fclose(f) == 0;
+  return (fclose(g) == 0) && ok;
+}
+
+bool read_sample_profile(const std::string &fq, const std::string &stats, SampleProfile *out, std::string *err) {
+  FILE *f = fopen(fq.c_str(), "r"), *g = fopen(stats.c_str(), "r");
+  if (!f || !g) {
+    if (f) fclose(f);
+    if (g) fclose(g);
+    *err = "Cannot open sample_profile";
+    return false;
+  }
+  SampleProfile &s = *out;
+  s = SampleProfile();
+  std::unique_ptr<char[]> line(new char[kBuf]);
+  while (fgets(line.get(), kBuf, g)) {  // pbsim.cpp:1185-1210
+    chomp(line.get());
+    char *tab = strchr(line.get(), '\t');
+    if (!tab) continue;
+    *tab = '\0';
+    const char *item = line.get(), *val = tab + 1;
+    if (!strcmp(item, "num")) s.num_filtered = atol(val);
+    else if (!strcmp(item, "len_total")) s.len_total_filtered = atol(val);
+    else if (!strcmp(item, "len_min")) s.len_min_filtered = atol(val);
+    else if (!strcmp(item, "len_max")) s.len_max_filtered = atol(val);
+    else if (!strcmp(item, "len_mean")) s.len_mean_filtered = atof(val);
+    else if (!strcmp(item, "len_sd")) s.len_sd_filtered = atof(val);
+    else if (!strcmp(item, "accuracy_mean")) s.accuracy_mean_filtered = atof(val);
+    else if (!strcmp(item, "accuracy_sd")) s.accuracy_sd_filtered = atof(val);
+  }
+  fclose(g);
+  // simulate_by_sample reads the strings with fgets(len_max_filtered + 2) (pbsim.cpp:1733): one string per line
+  std::string cur;
+  while (fgets(line.get(), kBuf, f)) {
+    const bool nl = chomp(line.get());
+    cur += line.get();
+    if (nl) {
+      s.quals.push_back(cur);
+      cur.clear();
+    }
+  }
+  if (!cur.empty()) s.quals.push_back(cur);
+  fclose(f);
+  if (s.quals.empty() || s.len_total_filtered < 1) {
+    *err = "sample_profile is empty";
+    return false;
+  }
   return true;
 }
 

@@ -32,4 +32,22 @@ bool read_transcripts(const char *file, std::vector<Transcript> *out, long *tota
 // one Transcript per record with a non-empty sequence (plus=1); *num counts '>' lines, *len_total bases
 bool read_templates(const char *file, std::vector<Transcript> *out, long *num, long long *len_total, std::string *err);
 
+// Sampling method: the filtered profile of get_sample_inf (pbsim.cpp:1155-1330).  `quals` are the quality strings
+// that passed --length-min/max and --accuracy-min/max, in file order; the statistics are the ones
+// print_sample_stats prints (:1336-1360) and the stored profile's .stats file holds (:1317-1326).
+struct SampleProfile {
+  long num = 0, len_min = 0, len_max = 0;
+  long long len_total = 0;
+  long num_filtered = 0, len_min_filtered = 0, len_max_filtered = 0;
+  long long len_total_filtered = 0;
+  double len_mean_filtered = 0, len_sd_filtered = 0, accuracy_mean_filtered = 0, accuracy_sd_filtered = 0;
+  std::vector<std::string> quals;
+};
+// parse + filter a FASTQ (line-feed counting and BUF_SIZE chunking as in the reference)
+bool read_sample_fastq(const char *file, long len_min, long len_max, double acc_min, double acc_max, SampleProfile *out,
+                       std::string *err);
+// sample_profile_<ID>.fastq (one quality string per line) + .stats ("key<TAB>value" lines)
+bool write_sample_profile(const std::string &fq, const std::string &stats, const SampleProfile &p, std::string *err);
+bool read_sample_profile(const std::string &fq, const std::string &stats, SampleProfile *out, std::string *err);
+
 }  // namespace pbsim

@@ -15,11 +15,12 @@ CLI = os.path.join(harness.ROOT, "pbsim3_amd", "bin", "pbsim")
 pytestmark = pytest.mark.gpu
 
 
-def run_cli(args, workdir):
+def run_cli(args, workdir, case=None):
     import pbsim3_amd.build as b
     b.build()
+    harness.run_setup([CLI, "--no-gzip"], case, workdir)
     p = subprocess.run([CLI] + harness.resolve(args) + ["--prefix", os.path.join(workdir, "out"), "--no-gzip"],
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, cwd=workdir)
     assert p.returncode == 0, p.stderr[-2000:]
     outs = harness.collect(workdir)
     outs[".stderr"] = harness.strip_report(p.stderr).encode()
@@ -28,12 +29,12 @@ def run_cli(args, workdir):
 
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_cli_matches_reference_golden(case, tmp_path):
-    outs = run_cli(CASES[case]["args"], str(tmp_path))
+    outs = run_cli(CASES[case]["args"], str(tmp_path), CASES[case])
     want = MANIFEST[f"{case}/philox"]
     assert sorted(outs) == sorted(want), (sorted(outs), sorted(want))
     for k, v in outs.items():
         if harness.sha(v) != want[k]["sha256"]:
-            ref = harness.run_oracle(CASES[case]["args"], "philox", str(tmp_path / "o"))[k] if (tmp_path / "o").mkdir() is None else b""
+            ref = harness.run_oracle(CASES[case]["args"], "philox", str(tmp_path / "o"), case=CASES[case])[k] if (tmp_path / "o").mkdir() is None else b""
             n = next((i for i, (x, y) in enumerate(zip(v, ref)) if x != y), min(len(v), len(ref)))
             raise AssertionError(f"{case}{k}: differs at byte {n} (sizes {len(v)} vs {len(ref)}):\n"
                                  f"  got  {v[max(0, n - 80):n + 60]!r}\n  want {ref[max(0, n - 80):n + 60]!r}")
