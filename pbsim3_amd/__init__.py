@@ -12,7 +12,7 @@ import os
 from . import build as _build
 
 STRATEGY_WGS, STRATEGY_TRANS, STRATEGY_TEMPL = 1, 2, 3
-METHOD_QS, METHOD_ERR = 1, 2
+METHOD_QS, METHOD_ERR, METHOD_SAMPLE = 1, 2, 3
 
 
 class Params(C.Structure):
@@ -77,6 +77,8 @@ API = [
     ("pbsim_sam_header", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("pbsim_set_bam_output", C.c_int, [C.c_void_p, C.c_int]),
     ("pbsim_bam_header", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+    ("pbsim_set_sample_profile", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    ("pbsim_simulate_sample", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
     ("pbsim_set_deflate", C.c_int, [C.c_void_p, C.c_int]),
     ("pbsim_deflate_bound", C.c_int64, [C.c_int64]),
     ("pbsim_batch_fetch_deflated", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -212,6 +214,32 @@ class Context:
         buf = C.create_string_buffer(n + 1)
         self.lib.pbsim_sam_header(self.h, buf, n + 1)
         return buf.raw[:n]
+
+    def set_sample_profile(self, quals):
+        """quals: list[bytes], the filtered quality strings in file order (pbsim3_amd.args.read_sample_fastq)"""
+        n = len(quals)
+        keep = [C.create_string_buffer(q, len(q)) for q in quals]
+        ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p).value for b in keep])
+        lens = (C.c_int64 * n)(*[len(q) for q in quals])
+        _check(self.lib.pbsim_set_sample_profile(self.h, n, ptrs, lens))
+
+    def simulate_sample(self, collect=True):
+        return self._simulate(self.lib.pbsim_simulate_sample, collect)
+
+    def _simulate(self, fn, collect):
+        reads, mafs = [], []
+
+        def on_read(user, text, n):
+            reads.append(C.string_at(text, n))
+            return 1
+
+        def on_maf(user, text, n):
+            mafs.append(C.string_at(text, n))
+            return 1
+
+        sink = Sink(None, SINK_CB(on_read), SINK_CB(on_maf))
+        _check(fn(self.h, C.byref(sink) if collect else None))
+        return b"".join(reads), b"".join(mafs)
 
     def set_deflate(self, mask=3):
         """bit 0: read sink, bit 1: MAF sink receive gzip members compressed on the GPU"""

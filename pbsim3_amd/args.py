@@ -8,7 +8,7 @@ def parse(argv):
     a = dict(zip(argv[::2], argv[1::2]))
     kw = {}
     kw["strategy"] = {"wgs": 1, "trans": 2, "templ": 3}[a["--strategy"][:5] if a["--strategy"].startswith("t") else "wgs"]
-    kw["method"] = {"qshmm": 1, "errhmm": 2}[a["--method"]]
+    kw["method"] = {"qshmm": 1, "errhmm": 2, "sample": 3}[a["--method"]]
     if "--seed" in a:
         kw["seed"] = int(a["--seed"])
     if "--depth" in a:
@@ -49,3 +49,22 @@ def read_fasta(path):
             elif cur is not None:
                 cur.append(line)
     return [b"".join(r) for r in recs], ids
+
+
+def read_sample_fastq(path, len_min=100, len_max=1000000, acc_min=0.75, acc_max=1.0):
+    """The filtered quality strings of get_sample_inf (pbsim.cpp:1216-1283) for a well-formed 4-line FASTQ:
+    length within [len_min, len_max], accuracy 1 - mean(10^(-Q/10)) within [acc_min, acc_max], file order."""
+    out = []
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    for i in range(3, len(lines), 4):
+        q = lines[i]
+        if not (len_min <= len(q) <= len_max):
+            continue
+        prob = 0.0
+        for ch in q:                      # same summation order as the reference
+            prob += 10 ** ((ch - 33) / -10)
+        acc = 1.0 - prob / len(q)
+        if acc_min <= acc <= acc_max:
+            out.append(q)
+    return out

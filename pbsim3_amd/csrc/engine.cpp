@@ -1422,65 +1422,102 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
   bool done = false;
   std::vector<int32_t> h_len, h_vbase, h_cap, h_tos, h_sot;
   std::vector<int64_t> h_qoff, h_woff;
+  struct Ent {
+    int64_t line, num;  // string index, copies to make in this chunk
+    int32_t len;        // its current length (shorter than the file's once a chain is carried over)
+  };
+  std::vector<Ent> cand;
+  std::vector<int32_t> order;
+  // a string whose copies do not fit one chunk continues in the next one: copies done so far, current length
+  int64_t carry_line = -1, carry_done = 0;
+  int32_t carry_len = 0;
   while (len_total < quota && !done) {
     const int64_t sv = (int64_t)(header_block(c->p.seed, (uint32_t)c->unit, (uint32_t)(res + 1)).w % (uint32_t)F);  // :1732
     int64_t line = 0;
     while (line < F && len_total < quota && !done) {
-      // ---- lay the chunk out: strings with at least one copy, 64 per wave, one virtual wave per copy
-      h_len.clear(); h_qoff.clear(); h_vbase.assign(1, 0); h_cap.clear(); h_woff.clear(); h_tos.clear(); h_sot.clear();
-      int64_t need = 0, n_tasks = 0;
-      while (line < F) {
-        // next wave: up to 64 strings that have copies in this sweep
-        int64_t probe = line, cnt = 0, kmax = 0, lmax = 0, tasks_w = 0;
-        int64_t idx[64], num[64];
-        while (probe < F && cnt < 64) {
-          const int64_t k = sample_num + (((sv + probe) % interval == 0) ? 1 : 0);
-          if (k > 0) {
-            idx[cnt] = probe;
-            num[cnt] = k;
-            kmax = std::max(kmax, k);
-            lmax = std::max<int64_t>(lmax, std::min<int64_t>(c->sq_len[(size_t)probe], G));
-            tasks_w += k;
-            cnt++;
-          }
-          probe++;
+      // ---- candidates: consecutive strings (file order = read order) that have copies in this sweep
+      cand.clear();
+      int64_t probe = line;
+      while (probe < F && cand.size() < (size_t)1 << 18) {
+        int64_t k = sample_num + (((sv + probe) % interval == 0) ? 1 : 0);
+        int32_t len = c->sq_len[(size_t)probe];
+        if (probe == carry_line) {
+          k -= carry_done;
+          len = carry_len;
         }
-        if (cnt == 0) {
-          line = probe;
-          break;
-        }
-        const int64_t cap_dw = (2 * lmax + kScratchPad + 3) / 4;
-        const int64_t bytes_w = kmax * cap_dw * 256 * 3;
-        if (!h_len.empty() && (need + bytes_w > c->scratch_budget || n_tasks + tasks_w > 0x3fffffff ||
-                               (int64_t)h_cap.size() + kmax > 0x1ffffff))
-          break;  // chunk full: this wave opens the next one
-        if (bytes_w > c->scratch_budget)
-          return fail("scratch pool too small for one wave of sample strings and their copies (pbsim_set_scratch_bytes)");
-        const int32_t v0 = (int32_t)h_cap.size();
-        for (int64_t k = 0; k < kmax; k++) {
-          h_cap.push_back((int32_t)cap_dw);
-          h_woff.push_back(need + k * cap_dw * 256 * 3);
-        }
-        h_tos.resize(h_tos.size() + (size_t)kmax * 64, -1);
-        for (int64_t e = 0; e < cnt; e++) {
-          h_len.push_back(c->sq_len[(size_t)idx[e]]);
-          h_qoff.push_back(c->sq_off[(size_t)idx[e]]);
-          for (int64_t k = 0; k < num[e]; k++) {
-            const int64_t slot = ((int64_t)v0 + k) * 64 + e;
-            h_tos[(size_t)slot] = (int32_t)n_tasks;
-            h_sot.push_back((int32_t)slot);
-            n_tasks++;
-          }
-        }
-        while (h_len.size() % 64 != 0) {  // the kernel indexes strings as wave * 64 + lane: pad a short wave
-          h_len.push_back(0);
-          h_qoff.push_back(0);
-        }
-        h_vbase.push_back((int32_t)h_cap.size());
-        need += bytes_w;
-        line = probe;
+        if (k > 0) cand.push_back(Ent{probe, k, len});
+        probe++;
       }
-      if (n_tasks == 0) continue;
+      if (cand.empty()) {
+        line = probe;
+        continue;
+      }
+      // ---- lay the chunk out.  Reads stay in file order; LANES are dealt by length (the longest strings share a
+      // wave), one virtual wave of scratch per copy.  Shrink the chunk until it fits the pool.
+      size_t n_c = cand.size();
+      int64_t need = 0, n_tasks = 0;
+      for (;;) {
+        order.resize(n_c);
+        for (size_t i = 0; i < n_c; i++) order[i] = (int32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cand[(size_t)x].len > cand[(size_t)y].len; });
+        h_vbase.assign(1, 0);
+        h_cap.clear();
+        h_woff.clear();
+        need = 0;
+        n_tasks = 0;
+        for (size_t w0 = 0; w0 < n_c; w0 += 64) {
+          int64_t kmax = 0, lmax = 0;
+          for (size_t i = w0; i < std::min(n_c, w0 + 64); i++) {
+            const Ent &e = cand[(size_t)order[i]];
+            kmax = std::max(kmax, e.num);
+            lmax = std::max<int64_t>(lmax, std::min<int64_t>(e.len, G));
+            n_tasks += e.num;
+          }
+          const int64_t cap_dw = (2 * lmax + kScratchPad + 3) / 4;
+          for (int64_t k = 0; k < kmax; k++) {
+            h_cap.push_back((int32_t)cap_dw);
+            h_woff.push_back(need);
+            need += cap_dw * 256 * 3;
+          }
+          h_vbase.push_back((int32_t)h_cap.size());
+        }
+        if (need <= c->scratch_budget && n_tasks <= 0x3fffffff && h_cap.size() <= 0x1ffffff) break;
+        if (n_c > 1) {
+          n_c = (n_c + 1) / 2;
+          continue;
+        }
+        // one string alone: make as many of its copies as fit, the chain continues in the next chunk
+        const int64_t per_copy = need / cand[0].num;
+        const int64_t kfit = c->scratch_budget / std::max<int64_t>(per_copy, 1);
+        if (kfit < 1) return fail("scratch pool too small for a single sampled read (pbsim_set_scratch_bytes)");
+        cand[0].num = std::min(cand[0].num, kfit);
+      }
+      h_len.assign(((n_c + 63) / 64) * 64, 0);
+      h_qoff.assign(h_len.size(), 0);
+      h_tos.assign(h_cap.size() * 64, -1);
+      h_sot.resize((size_t)n_tasks);
+      {
+        std::vector<int32_t> pos_of(n_c);
+        for (size_t i = 0; i < n_c; i++) pos_of[(size_t)order[i]] = (int32_t)i;
+        int64_t t = 0;
+        for (size_t e = 0; e < n_c; e++) {  // tasks in file order, lanes in length order
+          const size_t pos = (size_t)pos_of[e];
+          h_len[pos] = cand[e].len;
+          h_qoff[pos] = c->sq_off[(size_t)cand[e].line];
+          const int64_t v0 = h_vbase[pos / 64];
+          for (int64_t k = 0; k < cand[e].num; k++) {
+            const int64_t slot = (v0 + k) * 64 + (int64_t)(pos % 64);
+            h_tos[(size_t)slot] = (int32_t)t;
+            h_sot[(size_t)t] = (int32_t)slot;
+            t++;
+          }
+        }
+      }
+      // where this chunk leaves the sweep: past its last string, unless that string still has copies to make
+      const Ent last = cand[n_c - 1];
+      const int64_t last_total = sample_num + (((sv + last.line) % interval == 0) ? 1 : 0);
+      const int64_t last_done = (last.line == carry_line ? carry_done : 0) + last.num;
+      const bool last_unfinished = last_done < last_total;
       const int64_t n_lines = (int64_t)h_len.size(), n_lw = (int64_t)h_vbase.size() - 1, V = (int64_t)h_cap.size();
       if (res + n_tasks > 0xfffffff0LL) return fail("read index exceeds 32 bits");
       // ---- device state of the batch
@@ -1570,8 +1607,19 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
       len_total = bi.len_total_after;
       res += bi.n_final;
       if (bi.n_final < n_tasks) done = true;  // the quota was reached inside this chunk (:1735, :1749)
+      if (last_unfinished && !done) {
+        carry_line = last.line;
+        carry_done = last_done;
+        HIP_OK(hipMemcpy(&carry_len, sl.d_out_len.as<int32_t>() + (n_tasks - 1), 4, hipMemcpyDeviceToHost));
+        line = last.line;
+      } else {
+        carry_line = -1;
+        carry_done = 0;
+        line = last.line + 1;
+      }
     }
     sample_num = 0;  // :1922
+    carry_line = -1;
   }
   return PBSIM_SUCCEEDED;
 }

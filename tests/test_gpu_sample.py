@@ -1,0 +1,94 @@
+"""The sampling method (--method sample, pbsim.cpp:1694-1949) through the C ABI against the oracle on the same seeded
+inputs: chunking under a small scratch pool (chunks must not change a byte), chains of copies, strings longer than the
+record, deletion-heavy ratios (every copy shorter than the last), --hp-del-bias, many sweeps over a tiny profile."""
+import os
+import random
+
+import pytest
+
+import harness
+import pbsim3_amd as P
+from pbsim3_amd import args as A
+
+pytestmark = pytest.mark.gpu
+INPUTS = os.path.join(harness.GOLDEN, "inputs")
+
+
+def run_product(argv, scratch_mb=None):
+    p, a = A.parse(argv)
+    quals = A.read_sample_fastq(a["--sample"], p.len_min, p.len_max,
+                                int(float(a.get("--accuracy-min", 0.75)) * 100) * 0.01 if "--accuracy-min" in a else 0.75,
+                                int(float(a.get("--accuracy-max", 1.0)) * 100) * 0.01 if "--accuracy-max" in a else 1.0)
+    outs = {}
+    with P.Context(p, 0) as ctx:
+        if scratch_mb:
+            ctx.set_scratch_bytes(scratch_mb << 20)
+        ctx.set_sample_profile(quals)
+        recs = A.read_fasta(a["--genome"])[0]
+        if p.hp_del_bias != 1:
+            for r in recs:
+                ctx.add_hp_census(r)
+            ctx.finish_hp_census()
+        for i, r in enumerate(recs, 1):
+            ctx.set_reference(r, i)
+            rt, mt = ctx.simulate_sample()
+            outs["_%04d.fq" % i] = rt
+            outs["_%04d.maf" % i] = mt
+    return outs
+
+
+def check(argv, tmp_path, scratch_mb=None):
+    want = harness.run_oracle(argv, "philox", str(tmp_path))
+    got = run_product(harness.resolve(argv), scratch_mb)
+    for k, v in got.items():
+        if v != want[k]:
+            n = next((i for i, (x, y) in enumerate(zip(v, want[k])) if x != y), min(len(v), len(want[k])))
+            raise AssertionError(f"{k}: differs at byte {n} (sizes {len(v)} vs {len(want[k])}):\n"
+                                 f"  got  {v[max(0, n - 80):n + 60]!r}\n  want {want[k][max(0, n - 80):n + 60]!r}")
+    return got
+
+
+BASE = ["--strategy", "wgs", "--method", "sample", "--sample", "INPUT:sample.fastq"]
+
+
+@pytest.mark.parametrize("scratch_mb", [8, 24, 96])
+def test_chunking_does_not_change_bytes(tmp_path, scratch_mb):
+    check(BASE + ["--genome", "INPUT:plain.fa", "--depth", "3", "--seed", "11"], tmp_path, scratch_mb)
+
+
+def test_many_copies_per_string(tmp_path):
+    """depth 40 on a 200 kbp record: ~60 copies per string, deletion-heavy so that every copy shrinks"""
+    check(BASE + ["--genome", "INPUT:plain.fa", "--depth", "40", "--seed", "12", "--difference-ratio", "5:15:80"], tmp_path, 24)
+
+
+def test_insertion_heavy_stops_on_the_quality_string(tmp_path):
+    """ins >> del: the read ends when the quality string is used up, ref span < string length (pbsim.cpp:1776, 1847)"""
+    check(BASE + ["--genome", "INPUT:quirk.fa", "--depth", "6", "--seed", "13", "--difference-ratio", "5:90:5",
+                  "--hp-del-bias", "4"], tmp_path)
+
+
+def test_tiny_profile_many_sweeps(tmp_path):
+    """4 short strings against a quota of 30x: one long chain per string, then residue sweeps"""
+    r = random.Random(3)
+    fq = tmp_path / "tiny.fastq"
+    with open(fq, "w") as f:
+        for i, n in enumerate([300, 450, 800, 1200]):
+            q = "".join(chr(33 + r.randint(8, 30)) for _ in range(n))
+            f.write("@r%d\n%s\n+\n%s\n" % (i, "A" * n, q))
+    argv = ["--strategy", "wgs", "--method", "sample", "--sample", str(fq), "--genome", "INPUT:quirk.fa",
+            "--depth", "30", "--seed", "14"]
+    check(argv, tmp_path, 16)
+
+
+def test_high_quality_profile(tmp_path):
+    """Q40 strings: a handful of errors per read, deletion/insertion balance decides each chain link"""
+    r = random.Random(4)
+    fq = tmp_path / "hifi.fastq"
+    with open(fq, "w") as f:
+        for i in range(40):
+            n = r.randint(500, 4000)
+            q = "".join(chr(33 + r.randint(35, 45)) for _ in range(n))
+            f.write("@h%d\n%s\n+\n%s\n" % (i, "C" * n, q))
+    argv = ["--strategy", "wgs", "--method", "sample", "--sample", str(fq), "--genome", "INPUT:plain.fa",
+            "--depth", "8", "--seed", "15", "--difference-ratio", "20:30:50"]
+    check(argv, tmp_path)
