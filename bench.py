@@ -76,6 +76,40 @@ def cpu_baseline(sample_bp=4_000_000):
                       f"{bases} bases in {dt:.1f}s, gzip bypassed (cat)"}
 
 
+def bench_sample(a, torch, harness, P, local):
+    """Sampling method at scale: 200 000 synthetic quality strings (lengths gamma mean 9 000 / sd 7 000
+    clipped to 100..60 000, per-read quality level Q8..Q30 with jitter), a 100 Mbp record, depth 20 -> 2.0 Gbases.
+    Whole job, text left in HBM; the chains make this path latency-bound (one lane per string)."""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    n = 200_000
+    k = (9000.0 / 7000.0) ** 2
+    lens = np.clip(rng.gamma(k, 9000.0 / k, n), 100, 60000).astype(np.int64)
+    level = rng.integers(8, 31, n)
+    quals = []
+    for i in range(n):
+        q = np.clip(level[i] + rng.integers(-5, 6, int(lens[i])), 0, 93).astype(np.uint8) + 33
+        quals.append(q.tobytes())
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 100_000_000)].tobytes()
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_SAMPLE, seed=1, depth=float(dict(kv.split("=") for kv in a.param).get("depth", 20)))
+    ctx = P.Context(p, local)
+    ctx.set_scratch_bytes(int(a.scratch_gib * (1 << 30)))
+    ctx.set_sample_profile(quals)
+    ctx.set_reference(genome, 1)
+    ctx.simulate_sample(collect=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.simulate_sample(collect=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    print(json.dumps({"metric": "whole job wall time", "value": dt, "unit": "s", "higher_is_better": False, "n_gpus": 1,
+                      "bases": st.res_len_total, "reads": st.res_num, "bases_per_sec": st.res_len_total / dt,
+                      "config": {"workload": f"wgs sample, {n} synthetic quality strings ({int(lens.sum())} bases), "
+                                             f"100 Mbp record, depth {p.depth}, seed 1"}}))
+    ctx.close()
+
+
 def bench_trans(a, torch, harness, P, local):
     """BASELINE configs[3]: --strategy trans --method errhmm --errhmm ERRHMM-SEQUEL.model on 100 000 transcripts
     (lengths log-uniform 300..12000, plus ~ Geometric(mean 20), minus ~ Geometric(mean 0.1), seed 1).
@@ -122,7 +156,7 @@ def main():
     ap.add_argument("--scratch-gib", type=float, default=48.0)
     ap.add_argument("--batch-reads", type=int, default=0, help="reads per step per GPU (0 = what the scratch pool holds)")
     ap.add_argument("--model", default="ERRHMM-ONT.model")
-    ap.add_argument("--workload", default="errhmm", choices=["errhmm", "qshmm10", "trans"],
+    ap.add_argument("--workload", default="errhmm", choices=["errhmm", "qshmm10", "trans", "sample"],
                     help="errhmm = BASELINE configs[1] (headline); qshmm10 = configs[2]: QSHMM-RSII, --pass-num 10; "
                          "trans = configs[3]: ERRHMM-SEQUEL on a synthetic 100k-transcript profile (whole job, wall time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,6 +211,8 @@ def main():
             genome = g.to(dev)
     torch.cuda.synchronize()
 
+    if a.workload == "sample":
+        return bench_sample(a, torch, harness, P, local)
     if a.workload == "trans":
         return bench_trans(a, torch, harness, P, local)
     qs = a.workload == "qshmm10"
