@@ -657,17 +657,17 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
   }
 }
 
-// offsets[c] = sum of sizes[< c], offsets[n] = total; n <= 8192 (one block, 8 per thread)
-__global__ __launch_bounds__(1024) void k_deflate_offsets(const int32_t *__restrict__ sizes, int n,
-                                                          int64_t *__restrict__ offsets) {
-  __shared__ uint32_t s_w[16];
+// offsets[c] = sum of sizes[< c], offsets[n] = total; n <= 8192 (one block of 256 -- a workgroup of the walk kernel's
+// footprint gets a CU at once, a 1024-thread block waits behind concurrent walks -- 32 per thread)
+__global__ __launch_bounds__(256) void k_deflate_offsets(const int32_t *__restrict__ sizes, int n,
+                                                         int64_t *__restrict__ offsets) {
+  __shared__ uint32_t s_w[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t v[8], sum = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = tid * 8 + k;
-    v[k] = i < n ? (uint32_t)sizes[i] : 0u;
-    sum += v[k];
+  constexpr int kPer = DF_PIECE_CHUNKS / 256;
+  uint32_t sum = 0;
+  for (int k = 0; k < kPer; ++k) {
+    const int i = tid * kPer + k;
+    sum += i < n ? (uint32_t)sizes[i] : 0u;
   }
   uint32_t inc = sum;
 #pragma unroll
@@ -678,16 +678,17 @@ __global__ __launch_bounds__(1024) void k_deflate_offsets(const int32_t *__restr
   if (lane == 63) s_w[wave] = inc;
   __syncthreads();
   uint32_t base = 0, tot = 0;
-  for (int w = 0; w < 16; ++w) {
+  for (int w = 0; w < 4; ++w) {
     if (w < wave) base += s_w[w];
     tot += s_w[w];
   }
   uint32_t run = base + inc - sum;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = tid * 8 + k;
-    if (i < n) offsets[i] = run;
-    run += v[k];
+  for (int k = 0; k < kPer; ++k) {
+    const int i = tid * kPer + k;
+    if (i < n) {
+      offsets[i] = run;
+      run += (uint32_t)sizes[i];
+    }
   }
   if (tid == 0) offsets[n] = tot;
 }
@@ -763,7 +764,7 @@ void launch_deflate(const uint8_t *text, int64_t n_bytes, uint8_t *slots, int32_
   const uint32_t x8rem = host_xpow8((uint64_t)(n_bytes % DF_CHUNK) & 127u);
   hipLaunchKernelGGL(k_deflate_chunks, dim3((unsigned)nch), dim3(kThreads), 0, s, text, n_bytes, slots, sizes,
                      d_crc_table, d_pow128, x8rem, d_prof);
-  hipLaunchKernelGGL(k_deflate_offsets, dim3(1), dim3(1024), 0, s, (const int32_t *)sizes, (int)nch, offsets);
+  hipLaunchKernelGGL(k_deflate_offsets, dim3(1), dim3(256), 0, s, (const int32_t *)sizes, (int)nch, offsets);
   hipLaunchKernelGGL(k_deflate_compact, dim3((unsigned)nch), dim3(256), 0, s, (const uint8_t *)slots,
                      (const int64_t *)offsets, dense);
 }

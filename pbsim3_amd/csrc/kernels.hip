@@ -26,6 +26,7 @@ namespace pbsim {
 
 namespace {
 
+constexpr int kScanBlock = 256;  // single-workgroup scan kernels
 constexpr uint32_t kATGC = 0x43475441u;  // "ATGC" little-endian (mut.ins_nt / sub_nt_n, pbsim.cpp:5485-5486)
 
 __device__ __forceinline__ uint32_t to_upper(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
@@ -339,15 +340,16 @@ __global__ __launch_bounds__(256) void k_sort_hist(SortArgs a) {
   atomicAdd(&a.hist[sort_bin(a.acc[r], a.acc_lo, a.len[r])], a.pass_num);
 }
 
-// one workgroup of 1024: per class an exclusive scan over its kLenBuckets bins;
+// One workgroup of kScanBlock = 256 threads (one wave per SIMD, the footprint of a walk workgroup: a 1024-thread
+// block needs 16 free wave slots on ONE CU at once and starves for tens of ms behind the other slot's walk): per class an exclusive scan over its kLenBuckets bins;
 // class starts are rounded up to the walk workgroup size
-__global__ __launch_bounds__(1024) void k_sort_scan(SortArgs a) {
-  __shared__ int s_part[1024];
+__global__ __launch_bounds__(kScanBlock) void k_sort_scan(SortArgs a) {
+  __shared__ int s_part[kScanBlock];
   __shared__ int s_base;
   const int tid = threadIdx.x;
   if (tid == 0) s_base = 0;
   __syncthreads();
-  constexpr int kPer = kLenBuckets / 1024;
+  constexpr int kPer = kLenBuckets / kScanBlock;
   for (int c = 0; c < a.ncls; c++) {
     int v[kPer], sum = 0;
     for (int k = 0; k < kPer; k++) {
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(1024) void k_sort_scan(SortArgs a) {
     }
     s_part[tid] = sum;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < kScanBlock; d <<= 1) {
       const int t = (tid >= d) ? s_part[tid - d] : 0;
       __syncthreads();
       s_part[tid] += t;
@@ -369,9 +371,9 @@ __global__ __launch_bounds__(1024) void k_sort_scan(SortArgs a) {
       run += v[k];
     }
     __syncthreads();
-    if (tid == 1023) {
+    if (tid == kScanBlock - 1) {
       a.class_start[c] = base;
-      s_base = (base + s_part[1023] + kWG - 1) / kWG * kWG;
+      s_base = (base + s_part[kScanBlock - 1] + kWG - 1) / kWG * kWG;
     }
     __syncthreads();
   }
@@ -411,27 +413,37 @@ __global__ __launch_bounds__(256) void k_wave_cap(SortArgs a) {
   a.wave_cap[w] = (lmax < 0) ? 0 : (2 * lmax + kScratchPad + 3) / 4;
 }
 
-__global__ __launch_bounds__(1024) void k_wave_scan(SortArgs a) {
-  __shared__ long long s_part[1024];
+__global__ __launch_bounds__(kScanBlock) void k_wave_scan(SortArgs a) {
+  __shared__ long long s_part[kScanBlock];
   __shared__ long long s_base;
   const int tid = threadIdx.x;
   const int64_t n_waves = a.n_slots_max / 64;
   if (tid == 0) s_base = 0;
   __syncthreads();
-  for (int64_t w0 = 0; w0 < n_waves; w0 += 1024) {
-    const int64_t w = w0 + tid;
-    const long long bytes = (w < n_waves) ? (long long)a.wave_cap[w] * 256LL * a.regions : 0;
-    s_part[tid] = bytes;
+  constexpr int kPer = 8;
+  for (int64_t w0 = 0; w0 < n_waves; w0 += kScanBlock * kPer) {
+    long long v[kPer], sum = 0;
+    for (int k = 0; k < kPer; k++) {
+      const int64_t w = w0 + (int64_t)tid * kPer + k;
+      v[k] = (w < n_waves) ? (long long)a.wave_cap[w] * 256LL * a.regions : 0;
+      sum += v[k];
+    }
+    s_part[tid] = sum;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < kScanBlock; d <<= 1) {
       const long long t = (tid >= d) ? s_part[tid - d] : 0;
       __syncthreads();
       s_part[tid] += t;
       __syncthreads();
     }
-    if (w < n_waves) a.wave_off[w] = s_base + s_part[tid] - bytes;
+    long long run = s_base + s_part[tid] - sum;
+    for (int k = 0; k < kPer; k++) {
+      const int64_t w = w0 + (int64_t)tid * kPer + k;
+      if (w < n_waves) a.wave_off[w] = run;
+      run += v[k];
+    }
     __syncthreads();
-    if (tid == 1023) s_base += s_part[1023];
+    if (tid == kScanBlock - 1) s_base += s_part[kScanBlock - 1];
     __syncthreads();
   }
   if (tid == 0) {
@@ -456,18 +468,18 @@ __global__ __launch_bounds__(256) void k_wg_hist(SortArgs a, int32_t *wg_hist) {
   atomicAdd(&wg_hist[key], 1);
 }
 
-__global__ __launch_bounds__(1024) void k_wg_scan(int32_t *wg_hist, int32_t *wg_start) {
-  __shared__ int s_part[1024];
+__global__ __launch_bounds__(kScanBlock) void k_wg_scan(int32_t *wg_hist, int32_t *wg_start) {
+  __shared__ int s_part[kScanBlock];
   __shared__ int s_base;
   const int tid = threadIdx.x;
   if (tid == 0) s_base = 0;
   __syncthreads();
-  for (int i0 = 0; i0 < kLenBuckets + 1; i0 += 1024) {
+  for (int i0 = 0; i0 < kLenBuckets + 1; i0 += kScanBlock) {
     const int i = i0 + tid;
     const int v = (i < kLenBuckets + 1) ? wg_hist[i] : 0;
     s_part[tid] = v;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < kScanBlock; d <<= 1) {
       const int t = (tid >= d) ? s_part[tid - d] : 0;
       __syncthreads();
       s_part[tid] += t;
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(1024) void k_wg_scan(int32_t *wg_hist, int32_t *wg_
     }
     if (i < kLenBuckets + 1) wg_start[i] = s_base + s_part[tid] - v;
     __syncthreads();
-    if (tid == 1023) s_base += s_part[1023];
+    if (tid == kScanBlock - 1) s_base += s_part[kScanBlock - 1];
     __syncthreads();
   }
 }
@@ -1118,18 +1130,18 @@ __global__ __launch_bounds__(256) void k_scan_sums(const int64_t *in, int64_t n,
   if (threadIdx.x == 0) sums[blockIdx.x] = s[0];
 }
 
-__global__ __launch_bounds__(1024) void k_scan_single(int64_t *sums, int64_t n, int64_t *total) {
-  __shared__ long long s_part[1024];
+__global__ __launch_bounds__(kScanBlock) void k_scan_single(int64_t *sums, int64_t n, int64_t *total) {
+  __shared__ long long s_part[kScanBlock];
   __shared__ long long s_base;
   const int tid = threadIdx.x;
   if (tid == 0) s_base = 0;
   __syncthreads();
-  for (int64_t i0 = 0; i0 < n; i0 += 1024) {
+  for (int64_t i0 = 0; i0 < n; i0 += kScanBlock) {
     const int64_t i = i0 + tid;
     const long long v = (i < n) ? sums[i] : 0;
     s_part[tid] = v;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < kScanBlock; d <<= 1) {
       const long long t = (tid >= d) ? s_part[tid - d] : 0;
       __syncthreads();
       s_part[tid] += t;
@@ -1137,7 +1149,7 @@ __global__ __launch_bounds__(1024) void k_scan_single(int64_t *sums, int64_t n, 
     }
     if (i < n) sums[i] = s_base + s_part[tid] - v;
     __syncthreads();
-    if (tid == 1023) s_base += s_part[1023];
+    if (tid == kScanBlock - 1) s_base += s_part[kScanBlock - 1];
     __syncthreads();
   }
   if (tid == 0 && total) *total = s_base;
@@ -1472,82 +1484,72 @@ __global__ __launch_bounds__(256) void k_text_headers(TextArgs a) {
   *o++ = '\n';
 }
 
-// ---- big rows: one workgroup per (scratch wave, row kind).  A 64-task x 256-column
-// tile is read as coalesced 256-byte lines of the wave-transposed scratch, turned
-// through LDS, and written as aligned dwords into each task's text position.
-//   kind 0 read bases  = MAF read row with the deleted columns (byte 0) squeezed out
-//   kind 1 qualities   = quality row squeezed the same way (QSHMM), '!' fill for ERRHMM
-//                        (pbsim.cpp:4007-4010)
-//   kind 2 MAF reference row | 3 MAF read row (0 -> '-'); '-' strand rows are
-//          reverse-complemented back to forward orientation (pbsim.cpp:3981-3984)
-//   kind 4,5 the two ",9" x len SAM tag fills (pbsim.cpp:4019-4025)
-constexpr int kTileStride = 65;  // dwords per task row in LDS (64 + 1 pad: conflict-free turn)
+// ---- big rows: one workgroup per (scratch wave, pass).  A 64-task x 256-column tile is read as
+// coalesced 256-byte lines of the wave-transposed scratch, turned through LDS (one row per task)
+// and leaves as ALIGNED dwords, 64 lanes x 4 bytes = one 256-byte store per task and tile.
+// A task's destination is not dword aligned with its columns; instead of patching edges in every
+// tile, the row keeps the last dword of the previous tile in front of the new one (carry) and
+// every tile writes whole destination dwords; only a row's first and last <= 3 bytes go out as
+// bytes.  '-' strand rows are reverse-complemented on the way (pbsim.cpp:3981-3984): the same
+// columns, destination dwords descending, bytes swapped and complemented.
+//   pass 0  MAF read row -> MAF read line (0 prints as '-') AND, with the deleted columns (byte 0)
+//           squeezed out, the read bases (FASTQ / SAM sequence; BAM: parked in the pw array)
+//   pass 1  MAF reference row -> MAF reference line
+//   pass 2  QSHMM quality row, squeezed the same way -> quality line
+// Constant fills ('!' qualities, SAM ",9" tags, BAM ip array) are k_text_fill's.
+constexpr int kTileStride = 65;  // dwords per task row in LDS: [carry dword | 64 tile dwords]; 65 = 1 mod 64 banks
 
 // zero bytes (deleted columns) of a MAF read row print as '-'
 __device__ __forceinline__ uint32_t dash_zero_bytes(uint32_t w) { return w | ((eq_bytes(w, 0u) >> 7) * 0x2Du); }
 
-// Writes `len` bytes at text[D0..): plus: text[D0+i] = row[i]; minus: text[D0+i] =
-// complement(row[len-1-i]).  `row` is an LDS row (dword aligned); interior bytes go out as
-// aligned dwords, the <=2 edge dwords as bytes.  fill_kind: 0 copy, 2 ",9" pattern (phase from
-// `rel_first`, the row byte index of D0), otherwise 0x100 | b fills with the constant byte b.
-__device__ __forceinline__ void write_segment(char *text, long long D0, int len, const uint32_t *row, int minus,
-                                              int fill_kind, bool dash_zero, int rel_first, int lane) {
-  const long long base_al = D0 & ~3LL;
-  const int d0r = (int)(D0 - base_al);  // 0..3
-  const int d1r = d0r + len;
-  char *out = text + base_al;
+// One MAF line of one task for the tile of columns [256 t, 256 t + 256): `row` = [carry | tile] in LDS.
+// D = byte offset of the line in `text`, m = its length (columns), minus = reverse-complement.
+__device__ __forceinline__ void write_maf_tile(char *text, long long D, int m, int t, const uint32_t *row, int minus,
+                                               bool dash_zero, int lane) {
+  // h = bytes in front of the first whole destination dword (walking direction), written as bytes by tile 0
+  int h = minus ? (int)((D + m) & 3) : (int)((4 - (D & 3)) & 3);
+  h = h < m ? h : m;
+  const int cons = (t == 0) ? h : 256 * t - ((4 - h) & 3);  // columns already written before this tile
+  const int avail = (m < 256 * (t + 1)) ? m : 256 * (t + 1);
   const uint8_t *row8 = reinterpret_cast<const uint8_t *>(row);
-  for (int a4 = lane * 4; a4 < d1r; a4 += 256) {
-    const int i0 = a4 - d0r;  // segment byte index of this dword's first byte (may be negative at the head)
-    if (a4 >= d0r && a4 + 4 <= d1r) {
-      uint32_t word;
-      if (fill_kind & 0x100) {
-        word = (uint32_t)(fill_kind & 0xff) * 0x01010101u;
-      } else if (fill_kind == 2) {
-        word = ((rel_first + i0) & 1) ? 0x2C392C39u : 0x392C392Cu;
-      } else if (!minus) {
-        word = __builtin_amdgcn_alignbyte(row[(i0 >> 2) + 1], row[i0 >> 2], (uint32_t)(i0 & 3));
-      } else {
-        const int sb = len - 1 - i0 - 3;  // lowest of the four source bytes
-        const uint32_t w = __builtin_amdgcn_alignbyte(row[(sb >> 2) + 1], row[sb >> 2], (uint32_t)(sb & 3));
-        word = complement4(__builtin_bswap32(w));
-      }
-      if (dash_zero) word = dash_zero_bytes(word);
-      *reinterpret_cast<uint32_t *>(out + a4) = word;
+  const int b0 = 4 + cons - 256 * t;  // byte index of column `cons` in the row buffer (>= 1)
+  if (t == 0 && lane < h) {
+    uint32_t v = row8[4 + lane];
+    if (minus) v = complement(v);
+    if (dash_zero && v == 0) v = '-';
+    text[minus ? D + m - 1 - lane : D + lane] = (char)v;
+  }
+  const int n_dw = (avail - cons) >> 2;
+  if (lane < n_dw) {
+    const int b = b0 + 4 * lane;
+    uint32_t w = __builtin_amdgcn_alignbyte(row[(b >> 2) + 1], row[b >> 2], (uint32_t)(b & 3));
+    long long dst;
+    if (minus) {
+      w = complement4(__builtin_bswap32(w));
+      dst = D + m - cons - 4 * lane - 4;
     } else {
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int pos = a4 + b;
-        if (pos >= d0r && pos < d1r) {
-          const int i = pos - d0r;
-          uint32_t v;
-          if (fill_kind & 0x100) {
-            v = (uint32_t)(fill_kind & 0xff);
-          } else if (fill_kind == 2) {
-            v = ((rel_first + i) & 1) ? (uint32_t)'9' : (uint32_t)',';
-          } else {
-            v = row8[minus ? (len - 1 - i) : i];
-            if (minus) v = complement(v);
-            if (dash_zero && v == 0) v = '-';
-          }
-          out[pos] = (char)v;
-        }
-      }
+      dst = D + cons + 4 * lane;
+    }
+    if (dash_zero) w = dash_zero_bytes(w);
+    *reinterpret_cast<uint32_t *>(text + dst) = w;
+  }
+  if (avail == m) {  // the row ends in this tile: its last <= 3 columns
+    const int r = (m - cons) & 3, c0 = m - r;
+    if (lane < r && cons <= c0) {
+      uint32_t v = row8[4 + (c0 - 256 * t) + lane];
+      if (minus) v = complement(v);
+      if (dash_zero && v == 0) v = '-';
+      text[minus ? D + m - 1 - (c0 + lane) : D + c0 + lane] = (char)v;
     }
   }
 }
 
-// One workgroup = one scratch wave (64 tasks); each of its 4 waves owns 16 tasks and
-// runs on its own (no workgroup barrier in the tile loop).  blockIdx.y selects the pass:
-//   pass 0  MAF read row of the scratch -> MAF read line (kind 3) AND, squeezed, the read
-//           bases (kind 0); for ERRHMM also the '!' quality fill (kind 1)
-//   pass 1  MAF reference row -> MAF reference line (kind 2); SAM ",9" fills (kinds 4, 5)
-//   pass 2  QSHMM quality row, squeezed -> qualities (kind 1)
 __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags *flags) {
-  __shared__ uint32_t s_tile[64 * kTileStride];
-  __shared__ uint32_t s_out[4 * kTileStride];  // one squeezed row per wave
+  __shared__ uint32_t s_tile[64 * kTileStride + 2];  // + the dword an aligned alignbyte of the last row reads past it
+  __shared__ uint32_t s_out[4 * 66];  // one squeezed row per wave: [pending | <= 256 kept bytes]
   __shared__ int s_q[64], s_m[64], s_task[64], s_done[64];
   __shared__ int s_minus[64];
+  __shared__ uint32_t s_pend[64];     // squeezed bytes of a task that do not fill a destination dword yet
   const int64_t wave = blockIdx.x;
   const int pass = blockIdx.y;
   if (wave * 64 >= flags->total_slots) return;
@@ -1570,14 +1572,15 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     s_task[tid] = tk;
     s_done[tid] = 0;
     s_minus[tid] = minus;
+    s_pend[tid] = 0;
   }
+  for (int i = tid; i < 64; i += 256) s_tile[i * kTileStride] = 0;
   __syncthreads();
   // extent of this wave's 16 tasks
   int mmax = 0;
   {
     const int j = wv * 16 + (lane & 15);
     int v = (s_task[j] >= 0) ? s_m[j] : 0;
-    if (pass == 1 && a.pass_num > 1 && !a.bam && 2 * s_q[j] > v && s_task[j] >= 0) v = 2 * s_q[j];
 #pragma unroll
     for (int d = 8; d > 0; d >>= 1) {
       const int t = __shfl_xor(v, d, 64);
@@ -1587,19 +1590,25 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   }
   if (mmax == 0) return;
   const int cap_dw = a.wave_cap[wave];
-  const int region_idx = (pass == 0) ? 0 : (pass == 1) ? 1 : 2;
   const uint32_t *region =
-      reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave] + (size_t)region_idx * cap_dw * 256);
+      reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave] + (size_t)pass * cap_dw * 256);
   uint32_t *tile = s_tile + wv * 16 * kTileStride;
-  uint32_t *outb = s_out + wv * kTileStride;
-  const int lt = lane & 15, lc = lane >> 4;  // load role: task-in-wave, chunk-in-quad
+  uint32_t *outb = s_out + wv * 66;
+  uint8_t *orow = reinterpret_cast<uint8_t *>(outb);
+  const int lt = lane & 15, lc = lane >> 4;  // load role: task-in-wave, which quarter of the tile's dwords
 
-  for (int s0 = 0; s0 < mmax; s0 += 256) {
+  for (int s0 = 0, t = 0; s0 < mmax; s0 += 256, ++t) {
     const int c0 = s0 >> 2;
+    // carry: the previous tile's last dword moves in front (lanes 0..15, one task row each)
+    if (lane < 16 && t > 0) tile[lane * kTileStride] = tile[lane * kTileStride + 64];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll 4
-    for (int c = 0; c < 64; c += 4) {
-      const int cc = c0 + c + lc;
-      tile[lt * kTileStride + c + lc] = (cc < cap_dw) ? region[(size_t)cc * 64 + wv * 16 + lt] : 0u;
+    for (int c = 0; c < 16; ++c) {  // lane (lt, lc) loads dword c + 16 lc of task lt: banks lt + c + 16 lc, all different
+      const int col = c + 16 * lc;
+      const int cc = c0 + col;
+      tile[lt * kTileStride + 1 + col] = (cc < cap_dw) ? region[(size_t)cc * 64 + wv * 16 + lt] : 0u;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1608,37 +1617,25 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
       const int j = wv * 16 + i;
       const int task = s_task[j];
       if (task < 0) continue;
-      const int m = s_m[j], q = s_q[j], minus = s_minus[j];
+      const int m = s_m[j], minus = s_minus[j];
+      if (s0 >= m) continue;
       const int64_t *rd = a.row_dst + (int64_t)task * 6;
       const uint32_t *trow = tile + i * kTileStride;
       if (pass == 1) {
-        if (s0 < m) {  // MAF reference line
-          const int s1 = (m < s0 + 256) ? m : s0 + 256;
-          const long long D0 = minus ? rd[2] + (m - s1) : rd[2] + s0;
-          write_segment(a.maf_text, D0, s1 - s0, trow, minus, 0, false, 0, lane);
-        }
-        if (a.pass_num > 1 && !a.bam && s0 < 2 * q) {  // ",9" x len, twice (pbsim.cpp:4019-4025)
-          const int s1 = (2 * q < s0 + 256) ? 2 * q : s0 + 256;
-          write_segment(a.read_text, rd[4] + s0, s1 - s0, trow, 0, 2, false, s0, lane);
-          write_segment(a.read_text, rd[5] + s0, s1 - s0, trow, 0, 2, false, s0, lane);
-        }
-        if (a.bam && s0 < q) {  // BAM: the ip:B:C array is len bytes of value 9
-          const int s1 = (q < s0 + 256) ? q : s0 + 256;
-          write_segment(a.read_text, rd[4] + s0, s1 - s0, trow, 0, 0x100 | 9, false, 0, lane);
-        }
+        write_maf_tile(a.maf_text, rd[2], m, t, trow, minus, false, lane);
         continue;
       }
-      if (s0 >= m) continue;
+      if (pass == 0) write_maf_tile(a.maf_text, rd[3], m, t, trow, minus, true, lane);
+      // ---- squeeze the columns that carry a read base (non-zero byte): lane l holds columns 4l..4l+3 of the
+      // tile; its output offset is the count of kept bytes in lower lanes (ballots + mbcnt).  The wave's out
+      // row starts with the task's pending bytes so that the row is destination-dword aligned.
       const int ncol = (m - s0 < 256) ? m - s0 : 256;
-      if (pass == 0) {  // MAF read line: deleted columns print '-'
-        const long long D0 = minus ? rd[3] + (m - s0 - ncol) : rd[3] + s0;
-        write_segment(a.maf_text, D0, ncol, trow, minus, 0, true, 0, lane);
-      }
-      // squeeze the columns that carry a read base (non-zero byte) into the wave's out row:
-      // lane l holds columns 4l..4l+3; its output offset is the count of kept bytes in lower
-      // lanes, from four ballots + mbcnt (no cross-lane data movement)
-      const uint32_t w = trow[lane];
-      int o = 0, total = 0;
+      const int dn = s_done[j];
+      // BAM: the bases are parked as ASCII in the pw array (k_bam_finish packs them to 4 bits)
+      const long long D = rd[(pass == 0) ? (a.bam ? 5 : 0) : 1];
+      const int p = (int)((D + dn) & 3);  // bytes of the destination dword in front of this window's first byte
+      const uint32_t w = trow[1 + lane];
+      int o = p, total = 0;
       bool kb[4];
 #pragma unroll
       for (int b = 0; b < 4; b++) {
@@ -1647,24 +1644,74 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
         o += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         total += __popcll(mask);
       }
-      uint8_t *orow = reinterpret_cast<uint8_t *>(outb);
+      if (lane == 0) outb[0] = s_pend[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int b = 0; b < 4; b++)
         if (kb[b]) orow[o++] = (uint8_t)(w >> (8 * b));
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const int dn = s_done[j];
-      // BAM: the bases are parked as ASCII in the pw array (k_bam_finish packs them to 4 bits)
-      const int kind = (pass == 0) ? (a.bam ? 5 : 0) : 1;
-      write_segment(a.read_text, rd[kind] + dn, total, outb, 0, 0, false, 0, lane);
-      if (pass == 0 && !a.is_qs)  // ERRHMM quality is all '!' (pbsim.cpp:4007-4010)
-        write_segment(a.read_text, rd[1] + dn, total, outb, 0, 0x100 | '!', false, 0, lane);
+      const int have = p + total;              // row bytes: [0, p) belong to earlier windows (or to the text in front)
+      const bool last = s0 + 256 >= m;
+      const int n_dw = have >> 2;
+      char *dst = a.read_text + (D + dn - p);  // dword aligned
+      const int foreign = (p > dn) ? p - dn : 0;  // leading bytes of dword 0 that belong to the text in front of the row
+      if (lane < n_dw) {
+        if (lane == 0 && foreign) {
+          for (int b = foreign; b < 4; b++) dst[b] = (char)orow[b];
+        } else {
+          reinterpret_cast<uint32_t *>(dst)[lane] = outb[lane];
+        }
+      }
+      const int rem = have & 3;
+      if (last) {
+        const int lo = (n_dw == 0) ? foreign : 0;  // a row that ends inside its first dword
+        if (lane >= lo && lane < rem) dst[4 * n_dw + lane] = (char)orow[4 * n_dw + lane];
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (lane == 0) s_done[j] = dn + total;
+      if (lane == 0) {
+        s_done[j] = dn + total;
+        s_pend[j] = outb[n_dw];
+      }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Constant stretches of the read text, streamed with 16-byte stores (no turn through LDS needed):
+//   ERRHMM quality line: out_len x '!' (pbsim.cpp:4007-4010);  SAM ip / pw tags: out_len x ",9" each
+//   (pbsim.cpp:4019-4025);  BAM ip array: out_len bytes of value 9.  One wave per task.
+__device__ __forceinline__ void fill_run(char *dst, int64_t n, uint32_t even_byte, uint32_t odd_byte, int lane) {
+  // byte i of the run is even_byte for even i, odd_byte for odd i
+  const int64_t head = min(n, (int64_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15));
+  if (lane < head) dst[lane] = (char)((lane & 1) ? odd_byte : even_byte);
+  const uint32_t lo = (head & 1) ? odd_byte : even_byte, hi = (head & 1) ? even_byte : odd_byte;
+  const uint32_t w = lo | (hi << 8) | (lo << 16) | (hi << 24);
+  const int64_t n16 = (n - head) >> 4;
+  uint4 *d16 = reinterpret_cast<uint4 *>(dst + head);
+  const uint4 v = make_uint4(w, w, w, w);
+  for (int64_t i = lane; i < n16; i += 64) d16[i] = v;
+  const int64_t done = head + (n16 << 4);
+  if (lane < n - done) dst[done + lane] = (char)(((done + lane) & 1) ? odd_byte : even_byte);
+}
+
+__global__ __launch_bounds__(256) void k_text_fill(TextArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= a.n_reads * a.pass_num) return;
+  const int64_t q = a.out_len[t];
+  const int64_t *rd = a.row_dst + t * 6;
+  if (!a.is_qs) fill_run(a.read_text + rd[1], q, '!', '!', lane);
+  if (a.pass_num > 1) {
+    if (a.bam) {
+      fill_run(a.read_text + rd[4], q, 9, 9, lane);
+    } else {
+      fill_run(a.read_text + rd[4], 2 * q, ',', '9', lane);
+      fill_run(a.read_text + rd[5], 2 * q, ',', '9', lane);
+    }
   }
 }
 
@@ -1736,14 +1783,14 @@ void launch_task_sort(const SortArgs &a, hipStream_t s) {
   (void)hipMemsetAsync(a.bin_cursor, 0, nbins * sizeof(int32_t), s);
   (void)hipMemsetAsync(a.task_of_slot, 0xff, (size_t)a.n_slots_max * sizeof(int32_t), s);
   hipLaunchKernelGGL(k_sort_hist, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(kScanBlock), 0, s, a);
   hipLaunchKernelGGL(k_sort_scatter, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_wave_cap, dim3(blocks_for(a.n_slots_max / 64, 256)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_wave_scan, dim3(1), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(k_wave_scan, dim3(1), dim3(kScanBlock), 0, s, a);
   const int64_t n_wg = a.n_slots_max / kWG;
   (void)hipMemsetAsync(a.wg_hist, 0, (kLenBuckets + 1) * sizeof(int32_t), s);
   hipLaunchKernelGGL(k_wg_hist, dim3(blocks_for(n_wg, 256)), dim3(256), 0, s, a, a.wg_hist);
-  hipLaunchKernelGGL(k_wg_scan, dim3(1), dim3(1024), 0, s, a.wg_hist, a.wg_start);
+  hipLaunchKernelGGL(k_wg_scan, dim3(1), dim3(kScanBlock), 0, s, a.wg_hist, a.wg_start);
   hipLaunchKernelGGL(k_wg_scatter, dim3(blocks_for(n_wg, 256)), dim3(256), 0, s, a, a.wg_start, a.wg_order);
 }
 
@@ -1780,7 +1827,7 @@ void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64
   }
   const unsigned nb = blocks_for(n, kScanTile);
   hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, s, in, n, tmp);
-  hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, s, tmp, (int64_t)nb, total);
+  hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(kScanBlock), 0, s, tmp, (int64_t)nb, total);
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, out, n, (const int64_t *)tmp);
 }
 
@@ -1810,6 +1857,7 @@ void launch_text_emit(const TextArgs &a, int64_t n_slots_max, const DeviceFlags 
   const int64_t n_tasks = a.n_reads * a.pass_num;
   if (n_tasks <= 0) return;
   hipLaunchKernelGGL(k_text_headers, dim3(blocks_for(n_tasks, 256)), dim3(256), 0, s, a);
+  if (!a.is_qs || a.pass_num > 1) hipLaunchKernelGGL(k_text_fill, dim3(blocks_for(n_tasks, 4)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_text_rows, dim3((unsigned)(n_slots_max / 64), a.is_qs ? 3 : 2), dim3(256), 0, s, a, flags);
   if (a.bam) hipLaunchKernelGGL(k_bam_finish, dim3(blocks_for(n_tasks, 4)), dim3(256), 0, s, a);
 }

@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage (GPU box): tools/timeline.sh OUTDIR [bench args] -- kernel timeline (start, duration, queue) of the last 2 bench steps
+out=$1; shift
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/$out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $R/$out -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/$out/bench.json 2> $R/$out/err.txt
+cd $R
+python3 - $out <<'PY'
+import csv,glob,sys
+f=glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True)[0]
+rows=[r for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+t_end=max(int(r["End_Timestamp"]) for r in rows)
+sel=[r for r in rows if int(r["Start_Timestamp"])>t_end-260e6]
+t0=int(sel[0]["Start_Timestamp"])
+for r in sel:
+    d=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
+    if d<0.15: continue
+    name=r["Kernel_Name"].split("(")[0].split("::")[-1][:28]
+    print("%8.2f ms  +%7.2f ms  q%-3s %s" % ((int(r["Start_Timestamp"])-t0)/1e6, d, r.get("Queue_Id","?"), name))
+PY
