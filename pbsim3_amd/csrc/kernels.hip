@@ -1485,71 +1485,103 @@ __global__ __launch_bounds__(256) void k_text_headers(TextArgs a) {
 }
 
 // ---- big rows: one workgroup per (scratch wave, pass).  A 64-task x 256-column tile is read as
-// coalesced 256-byte lines of the wave-transposed scratch, turned through LDS (one row per task)
-// and leaves as ALIGNED dwords, 64 lanes x 4 bytes = one 256-byte store per task and tile.
-// A task's destination is not dword aligned with its columns; instead of patching edges in every
-// tile, the row keeps the last dword of the previous tile in front of the new one (carry) and
-// every tile writes whole destination dwords; only a row's first and last <= 3 bytes go out as
-// bytes.  '-' strand rows are reverse-complemented on the way (pbsim.cpp:3981-3984): the same
-// columns, destination dwords descending, bytes swapped and complemented.
+// coalesced 256-byte lines of the wave-transposed scratch and turned through LDS (one row per
+// task).  Each of the 4 waves owns 16 tasks and serves FOUR of them per step: 16 lanes per task,
+// one 16-byte chunk per lane, so a 256-column window of a task leaves as 16 aligned 16-byte
+// stores.  A task's destination is not 16-byte aligned with its columns; instead of patching
+// edges in every tile, the row keeps the last 16 bytes of the previous tile in front of the new
+// one (carry) and every tile writes whole destination chunks; only a row's first and last
+// <= 15 bytes go out as bytes.  '-' strand rows are reverse-complemented on the way
+// (pbsim.cpp:3981-3984): same columns, destination chunks descending, bytes swapped + complemented.
 //   pass 0  MAF read row -> MAF read line (0 prints as '-') AND, with the deleted columns (byte 0)
 //           squeezed out, the read bases (FASTQ / SAM sequence; BAM: parked in the pw array)
 //   pass 1  MAF reference row -> MAF reference line
 //   pass 2  QSHMM quality row, squeezed the same way -> quality line
 // Constant fills ('!' qualities, SAM ",9" tags, BAM ip array) are k_text_fill's.
-constexpr int kTileStride = 65;  // dwords per task row in LDS: [carry dword | 64 tile dwords]; 65 = 1 mod 64 banks
+constexpr int kTileStride = 69;  // dwords per task row in LDS: [16 carry bytes | 256 tile bytes] + 1 (5 mod 64: conflict-free turn)
+constexpr int kOutStride = 73;   // squeezed row: [<= 15 pending bytes | <= 256 kept bytes], 16-byte chunks
 
 // zero bytes (deleted columns) of a MAF read row print as '-'
 __device__ __forceinline__ uint32_t dash_zero_bytes(uint32_t w) { return w | ((eq_bytes(w, 0u) >> 7) * 0x2Du); }
 
-// One MAF line of one task for the tile of columns [256 t, 256 t + 256): `row` = [carry | tile] in LDS.
-// D = byte offset of the line in `text`, m = its length (columns), minus = reverse-complement.
+// LDS hand-off between the lanes of ONE wave (its tile rows and out rows are private to it): the LDS pipeline
+// executes a wave's ds operations in order, so only the compiler has to be kept from reordering them.  A
+// workgroup-scope fence here would also wait for the wave's outstanding global stores (vmcnt) at every step.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// inclusive prefix sum over the 16 lanes of a DPP row
+__device__ __forceinline__ int row16_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  return x;
+}
+
+// One MAF line of one task for the tile of columns [256 t, 256 t + 256), served by the 16 lanes `sub` of a group.
+// `row` = [carry | tile] in LDS; D = byte offset of the line in `text`, m = its length, minus = reverse-complement.
 __device__ __forceinline__ void write_maf_tile(char *text, long long D, int m, int t, const uint32_t *row, int minus,
-                                               bool dash_zero, int lane) {
-  // h = bytes in front of the first whole destination dword (walking direction), written as bytes by tile 0
-  int h = minus ? (int)((D + m) & 3) : (int)((4 - (D & 3)) & 3);
+                                               bool dash_zero, int sub) {
+  // h = bytes in front of the first whole destination chunk (in walking direction), written as bytes by tile 0
+  int h = minus ? (int)((D + m) & 15) : (int)((16 - (D & 15)) & 15);
   h = h < m ? h : m;
-  const int cons = (t == 0) ? h : 256 * t - ((4 - h) & 3);  // columns already written before this tile
+  const int cons = (t == 0) ? h : 256 * t - ((16 - h) & 15);  // columns already written before this tile
   const int avail = (m < 256 * (t + 1)) ? m : 256 * (t + 1);
   const uint8_t *row8 = reinterpret_cast<const uint8_t *>(row);
-  const int b0 = 4 + cons - 256 * t;  // byte index of column `cons` in the row buffer (>= 1)
-  if (t == 0 && lane < h) {
-    uint32_t v = row8[4 + lane];
+  if (t == 0 && sub < h) {
+    uint32_t v = row8[16 + sub];
     if (minus) v = complement(v);
     if (dash_zero && v == 0) v = '-';
-    text[minus ? D + m - 1 - lane : D + lane] = (char)v;
+    text[minus ? D + m - 1 - sub : D + sub] = (char)v;
   }
-  const int n_dw = (avail - cons) >> 2;
-  if (lane < n_dw) {
-    const int b = b0 + 4 * lane;
-    uint32_t w = __builtin_amdgcn_alignbyte(row[(b >> 2) + 1], row[b >> 2], (uint32_t)(b & 3));
+  const int n_ch = (avail - cons) >> 4;
+  if (sub < n_ch) {
+    const int b = 16 + cons - 256 * t + 16 * sub;  // byte index of the chunk's first column in the row buffer (>= 1)
+    const uint32_t *src = row + (b >> 2);
+    const uint32_t sh = (uint32_t)(b & 3);
+    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4];
+    uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+             w2 = __builtin_amdgcn_alignbyte(d3, d2, sh), w3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
     long long dst;
     if (minus) {
-      w = complement4(__builtin_bswap32(w));
-      dst = D + m - cons - 4 * lane - 4;
+      const uint32_t r0 = complement4(__builtin_bswap32(w3)), r1 = complement4(__builtin_bswap32(w2)),
+                     r2 = complement4(__builtin_bswap32(w1)), r3 = complement4(__builtin_bswap32(w0));
+      w0 = r0;
+      w1 = r1;
+      w2 = r2;
+      w3 = r3;
+      dst = D + m - cons - 16 * sub - 16;
     } else {
-      dst = D + cons + 4 * lane;
+      dst = D + cons + 16 * sub;
     }
-    if (dash_zero) w = dash_zero_bytes(w);
-    *reinterpret_cast<uint32_t *>(text + dst) = w;
+    if (dash_zero) {
+      w0 = dash_zero_bytes(w0);
+      w1 = dash_zero_bytes(w1);
+      w2 = dash_zero_bytes(w2);
+      w3 = dash_zero_bytes(w3);
+    }
+    *reinterpret_cast<uint4 *>(text + dst) = make_uint4(w0, w1, w2, w3);
   }
-  if (avail == m) {  // the row ends in this tile: its last <= 3 columns
-    const int r = (m - cons) & 3, c0 = m - r;
-    if (lane < r && cons <= c0) {
-      uint32_t v = row8[4 + (c0 - 256 * t) + lane];
+  if (avail == m) {  // the row ends in this tile: its last <= 15 columns
+    const int r = (m - cons) & 15, c0 = m - r;
+    if (sub < r) {
+      uint32_t v = row8[16 + (c0 - 256 * t) + sub];
       if (minus) v = complement(v);
       if (dash_zero && v == 0) v = '-';
-      text[minus ? D + m - 1 - (c0 + lane) : D + c0 + lane] = (char)v;
+      text[minus ? D + m - 1 - (c0 + sub) : D + c0 + sub] = (char)v;
     }
   }
 }
 
 __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags *flags) {
-  __shared__ uint32_t s_tile[64 * kTileStride + 2];  // + the dword an aligned alignbyte of the last row reads past it
-  __shared__ uint32_t s_out[4 * 66];  // one squeezed row per wave: [pending | <= 256 kept bytes]
+  __shared__ uint32_t s_tile[64 * kTileStride + 4];  // + the dwords an aligned alignbyte of the last row reads past it
+  __shared__ uint32_t s_out[16 * kOutStride];        // one squeezed row per (wave, group)
+  __shared__ uint32_t s_pend[64 * 4];                // squeezed bytes of a task that do not fill a 16-byte chunk yet
   __shared__ int s_q[64], s_m[64], s_task[64], s_done[64];
   __shared__ int s_minus[64];
-  __shared__ uint32_t s_pend[64];     // squeezed bytes of a task that do not fill a destination dword yet
   const int64_t wave = blockIdx.x;
   const int pass = blockIdx.y;
   if (wave * 64 >= flags->total_slots) return;
@@ -1572,9 +1604,8 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     s_task[tid] = tk;
     s_done[tid] = 0;
     s_minus[tid] = minus;
-    s_pend[tid] = 0;
   }
-  for (int i = tid; i < 64; i += 256) s_tile[i * kTileStride] = 0;
+  s_pend[tid] = 0;
   __syncthreads();
   // extent of this wave's 16 tasks
   int mmax = 0;
@@ -1593,91 +1624,98 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   const uint32_t *region =
       reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave] + (size_t)pass * cap_dw * 256);
   uint32_t *tile = s_tile + wv * 16 * kTileStride;
-  uint32_t *outb = s_out + wv * 66;
-  uint8_t *orow = reinterpret_cast<uint8_t *>(outb);
   const int lt = lane & 15, lc = lane >> 4;  // load role: task-in-wave, which quarter of the tile's dwords
+  const int g = lane >> 4, sub = lane & 15;  // serve role: task group, 16-byte chunk
+  uint32_t *outb = s_out + (wv * 4 + g) * kOutStride;
+  uint8_t *orow = reinterpret_cast<uint8_t *>(outb);
 
   for (int s0 = 0, t = 0; s0 < mmax; s0 += 256, ++t) {
     const int c0 = s0 >> 2;
-    // carry: the previous tile's last dword moves in front (lanes 0..15, one task row each)
-    if (lane < 16 && t > 0) tile[lane * kTileStride] = tile[lane * kTileStride + 64];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // carry: the previous tile's last 16 bytes move in front (lane = task row x dword)
+    if (t > 0) tile[lt * kTileStride + lc] = tile[lt * kTileStride + 64 + lc];
+    wave_lds_sync();
 #pragma unroll 4
-    for (int c = 0; c < 16; ++c) {  // lane (lt, lc) loads dword c + 16 lc of task lt: banks lt + c + 16 lc, all different
+    for (int c = 0; c < 16; ++c) {  // lane (lt, lc) loads dword c + 16 lc of task lt: banks 5 lt + c + 16 lc, all different
       const int col = c + 16 * lc;
       const int cc = c0 + col;
-      tile[lt * kTileStride + 1 + col] = (cc < cap_dw) ? region[(size_t)cc * 64 + wv * 16 + lt] : 0u;
+      tile[lt * kTileStride + 4 + col] = (cc < cap_dw) ? region[(size_t)cc * 64 + wv * 16 + lt] : 0u;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int i = 0; i < 16; i++) {
-      const int j = wv * 16 + i;
+    wave_lds_sync();
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+      const int i = it * 4 + g, j = wv * 16 + i;
       const int task = s_task[j];
-      if (task < 0) continue;
       const int m = s_m[j], minus = s_minus[j];
-      if (s0 >= m) continue;
-      const int64_t *rd = a.row_dst + (int64_t)task * 6;
+      const bool act = task >= 0 && s0 < m;
+      const int64_t *rd = a.row_dst + (int64_t)(act ? task : 0) * 6;
       const uint32_t *trow = tile + i * kTileStride;
       if (pass == 1) {
-        write_maf_tile(a.maf_text, rd[2], m, t, trow, minus, false, lane);
+        if (act) write_maf_tile(a.maf_text, rd[2], m, t, trow, minus, false, sub);
         continue;
       }
-      if (pass == 0) write_maf_tile(a.maf_text, rd[3], m, t, trow, minus, true, lane);
-      // ---- squeeze the columns that carry a read base (non-zero byte): lane l holds columns 4l..4l+3 of the
-      // tile; its output offset is the count of kept bytes in lower lanes (ballots + mbcnt).  The wave's out
-      // row starts with the task's pending bytes so that the row is destination-dword aligned.
-      const int ncol = (m - s0 < 256) ? m - s0 : 256;
+      if (pass == 0 && act) write_maf_tile(a.maf_text, rd[3], m, t, trow, minus, true, sub);
+      // ---- squeeze the columns that carry a read base (non-zero byte): lane `sub` holds columns 16 sub .. 16 sub + 15
+      // of the window; its output offset is the count of kept bytes in the lower lanes of its row of 16 (DPP scan).
+      // The out row starts with the task's pending bytes, so that it is destination-chunk aligned.
+      const int ncol = act ? ((m - s0 < 256) ? m - s0 : 256) : 0;
       const int dn = s_done[j];
       // BAM: the bases are parked as ASCII in the pw array (k_bam_finish packs them to 4 bits)
-      const long long D = rd[(pass == 0) ? (a.bam ? 5 : 0) : 1];
-      const int p = (int)((D + dn) & 3);  // bytes of the destination dword in front of this window's first byte
-      const uint32_t w = trow[1 + lane];
-      int o = p, total = 0;
-      bool kb[4];
+      const long long D = act ? rd[(pass == 0) ? (a.bam ? 5 : 0) : 1] : 0;
+      const int p = (int)((D + dn) & 15);  // bytes of the destination chunk in front of this window's first byte
+      uint32_t w[4];
+      uint32_t keep = 0;
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        kb[b] = (lane * 4 + b) < ncol && ((w >> (8 * b)) & 0xffu) != 0;
-        const unsigned long long mask = __ballot(kb[b]);
-        o += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        total += __popcll(mask);
+      for (int k = 0; k < 4; k++) {
+        w[k] = trow[4 + 4 * sub + k];
+        const uint32_t nz = ~eq_bytes(w[k], 0u) & 0x80808080u;          // 0x80 per non-zero byte
+        keep |= ((((nz >> 7) * 0x00204081u) >> 21) & 15u) << (4 * k);    // -> 4 bits
       }
-      if (lane == 0) outb[0] = s_pend[j];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+      const int nv = ncol - 16 * sub;  // valid columns of this lane
+      keep &= (nv >= 16) ? 0xffffu : (nv > 0 ? (1u << nv) - 1u : 0u);
+      const int cnt = __popc(keep);
+      const int incl = row16_scan(cnt);
+      const int total = __shfl(incl, (lane & 48) | 15, 64);
+      if (sub < 4) outb[sub] = s_pend[j * 4 + sub];
+      wave_lds_sync();
+      {
+        int o = p + incl - cnt;
 #pragma unroll
-      for (int b = 0; b < 4; b++)
-        if (kb[b]) orow[o++] = (uint8_t)(w >> (8 * b));
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            if ((keep >> (4 * k + b)) & 1u) orow[o++] = (uint8_t)(w[k] >> (8 * b));
+      }
+      wave_lds_sync();
       const int have = p + total;              // row bytes: [0, p) belong to earlier windows (or to the text in front)
       const bool last = s0 + 256 >= m;
-      const int n_dw = have >> 2;
-      char *dst = a.read_text + (D + dn - p);  // dword aligned
-      const int foreign = (p > dn) ? p - dn : 0;  // leading bytes of dword 0 that belong to the text in front of the row
-      if (lane < n_dw) {
-        if (lane == 0 && foreign) {
-          for (int b = foreign; b < 4; b++) dst[b] = (char)orow[b];
+      const int n_ch = have >> 4;
+      char *dst = a.read_text + (D + dn - p);  // 16-byte aligned
+      const int foreign = (p > dn) ? p - dn : 0;  // leading bytes of chunk 0 that belong to the text in front of the row
+      if (act && sub < n_ch) {
+        const uint32_t *src = outb + 4 * sub;
+        if (sub == 0 && foreign) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (4 * k >= foreign) {
+              reinterpret_cast<uint32_t *>(dst)[k] = src[k];
+            } else if (4 * k + 4 > foreign) {
+              for (int b = foreign; b < 4 * k + 4; b++) dst[b] = (char)orow[b];
+            }
+          }
         } else {
-          reinterpret_cast<uint32_t *>(dst)[lane] = outb[lane];
+          reinterpret_cast<uint4 *>(dst)[sub] = make_uint4(src[0], src[1], src[2], src[3]);
         }
       }
-      const int rem = have & 3;
-      if (last) {
-        const int lo = (n_dw == 0) ? foreign : 0;  // a row that ends inside its first dword
-        if (lane >= lo && lane < rem) dst[4 * n_dw + lane] = (char)orow[4 * n_dw + lane];
+      const int rem = have & 15;
+      if (act && last) {
+        const int lo = (n_ch == 0) ? foreign : 0;  // a row that ends inside its first chunk
+        if (sub >= lo && sub < rem) dst[16 * n_ch + sub] = (char)orow[16 * n_ch + sub];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) {
-        s_done[j] = dn + total;
-        s_pend[j] = outb[n_dw];
-      }
+      wave_lds_sync();
+      if (act && sub < 4) s_pend[j * 4 + sub] = outb[4 * n_ch + sub];
+      if (act && sub == 0) s_done[j] = dn + total;
+      wave_lds_sync();
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
