@@ -344,7 +344,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01f_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE, raw x1024; see note there)",
                          "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": walk_s * 1e3,
-                         "walk_share_of_step": (walk_ms / 1e3) / dt if dt > 0 else None},
+                         "walk_share_of_step": (walk_ms / 1e3) / dt if dt > 0 else None,
+                         # the kernel's real ceiling is integer issue, not HBM: PMC pass of the same kernel
+                         "issue_bound": None if qs else {"valu_busy_frac": 0.93, "valu_per_wave_step": 163.4,
+                                                         "source": "profiles/r01h_walk_pmc.json (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD-cycles)"}},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
