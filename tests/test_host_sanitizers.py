@@ -1,0 +1,46 @@
+"""Host-side C++ of the product (FASTA / transcript / template / sample-FASTQ readers, model parsers, integer table
+builders) under AddressSanitizer + UBSan on the CPU.  GPU sanitizers are not available on the pool; these are the
+parts of the library that touch untrusted input files."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import harness
+
+CSRC = os.path.join(harness.ROOT, "pbsim3_amd", "csrc")
+HERE = os.path.join(harness.ROOT, "tests", "asan")
+FLAGS = ["-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+         "-I" + CSRC, "-I" + os.path.join(harness.ROOT, "include")]
+MODELS = ["ERRHMM-RSII.model", "ERRHMM-SEQUEL.model", "ERRHMM-ONT.model", "ERRHMM-ONT-HQ.model", "QSHMM-RSII.model",
+          "QSHMM-ONT.model"]
+
+
+def build(tmp_path, driver, source):
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / driver)
+    p = subprocess.run(["g++"] + FLAGS + [os.path.join(HERE, driver + ".cpp"), os.path.join(CSRC, source), "-o", exe],
+                       capture_output=True, text=True)
+    if p.returncode != 0 and "sanitize" in p.stderr:
+        pytest.skip("no sanitizer runtime")
+    assert p.returncode == 0, p.stderr[-2000:]
+    return exe
+
+
+def test_parsers_under_asan(tmp_path):
+    exe = build(tmp_path, "parsers_driver", "unit_io.cpp")
+    i = os.path.join(harness.GOLDEN, "inputs")
+    p = subprocess.run([exe, i + "/sample.fastq", i + "/quirk.fa", i + "/tiny.transcript", i + "/tiny.template", str(tmp_path)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert "num 153 filt 124 tot 133973" in p.stdout and "same=1" in p.stdout
+    assert "rec 1 len 17104" in p.stdout and "tr 12 exp 45" in p.stdout
+
+
+def test_table_builders_under_asan(tmp_path):
+    exe = build(tmp_path, "tables_driver", "host_tables.cpp")
+    p = subprocess.run([exe] + [harness.model_path(m) for m in MODELS], capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert p.stdout.count(" ok stride ") == len(MODELS)
