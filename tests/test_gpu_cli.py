@@ -59,3 +59,18 @@ def test_cli_default_outputs_are_gzip(tmp_path):
     for k in ("_0001.fq", "_0002.fq", "_0001.maf", "_0002.maf"):
         with gzip.open(str(tmp_path / ("out" + k + ".gz")), "rb") as f:
             assert harness.sha(f.read()) == want[k]["sha256"], k
+
+
+@pytest.mark.parametrize("mode", [["--gzip", "host", "--gzip-threads", "2"], []])
+def test_cli_sample_method_compressed(tmp_path, mode):
+    """--method sample through the default (GPU) and the host compressors: the members inflate to the golden bytes"""
+    import gzip
+    case = "wgs_sample_quirk"
+    p = subprocess.run([CLI] + harness.resolve(CASES[case]["args"]) + ["--prefix", str(tmp_path / "out")] + mode,
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    want = MANIFEST[f"{case}/philox"]
+    for k in ("_0001.fq", "_0002.fq", "_0001.maf", "_0002.maf"):
+        with gzip.open(str(tmp_path / ("out" + k + ".gz")), "rb") as f:
+            assert harness.sha(f.read()) == want[k]["sha256"], k
+    assert harness.sha(harness.strip_report(p.stderr).encode()) == want[".stderr"]["sha256"]
