@@ -664,6 +664,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   if (c->p.method == PBSIM_METHOD_ERR) {
     w.stride = c->ect.stride;
     w.rows_off = c->ect.rows_off;
+    w.emis_off = c->ect.emis_off;
     w.init_off = c->ect.init_off;
     w.tran_off = c->ect.tran_off;
     launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->p.hp_del_bias == 1,

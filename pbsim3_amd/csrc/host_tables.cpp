@@ -289,6 +289,17 @@ void hp_census_weighted(const uint8_t *seq, int64_t len, int64_t weight, int kee
   }
 }
 
+// x % d for x < 2^31, 2 <= d <= 65535 as  x - (mulhi(x, magic) >> shift) * d :
+// shift = floor(log2(d - 1)), magic = ceil(2^(32 + shift) / d) < 2^32; the error term magic*d - 2^(32+shift) < d <= 2^(shift+1)
+// times x < 2^31 stays below 2^(32+shift), so the quotient is exact.
+void emission_magic(uint32_t d, uint32_t *magic, uint32_t *shift) {
+  uint32_t s = 0;
+  while ((2u << s) <= d - 1) s++;
+  const unsigned __int128 num = (unsigned __int128)1 << (32 + s);
+  *magic = (uint32_t)((num + d - 1) / d);
+  *shift = s;
+}
+
 bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBias &b, bool emis_skip_le,
                             ErrClassTables *t, std::string *err) {
   t->acc_lo = h.acc_lo;
@@ -304,7 +315,8 @@ bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBi
   }
   t->smax = smax;
   t->rows_off = 64;
-  t->init_off = t->rows_off + 32u * (uint32_t)(smax + 1);
+  t->emis_off = t->rows_off + 32u * (uint32_t)(smax + 1);
+  t->init_off = t->emis_off + 16u * (uint32_t)(smax + 1);
   t->tran_off = t->init_off + 1008u;
   t->stride = (t->tran_off + 1000u * (uint32_t)smax + 15u) & ~15u;
   const int ncls = h.acc_hi - h.acc_lo + 1;
@@ -409,6 +421,29 @@ bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBi
       row[1] = (uint16_t)r.emis_rv[j];
       row[2] = (uint16_t)e0;
       row[3] = (uint16_t)e1;
+      {
+        // Emission class without a division: e = (r >= E0') + (r >= E1') with r = z % d by multiply-high
+        // (emission_magic()).  emis_rv == 0 (pbsim.cpp:3865: `rand() % 3`) is d = 3 with thresholds 1, 2;
+        // emis_rv == 1 (the index is always 1) is a constant class, also carried by d = 3.
+        uint32_t d = (uint32_t)r.emis_rv[j], t0 = (uint32_t)e0, t1 = (uint32_t)e1;
+        if (d == 0) {
+          d = 3;
+          t0 = 1;
+          t1 = 2;
+        } else if (d == 1) {
+          const int c = (1 > e0) + (1 > e1);
+          d = 3;
+          t0 = (c >= 1) ? 0 : 3;
+          t1 = (c >= 2) ? 0 : 3;
+        }
+        uint32_t magic, shift;
+        emission_magic(d, &magic, &shift);
+        uint8_t *er = dst + t->emis_off + 16u * (uint32_t)j;
+        const uint32_t w1 = shift | (d << 16), w2 = t0 | (t1 << 16);
+        memcpy(er, &magic, 4);
+        memcpy(er + 4, &w1, 4);
+        memcpy(er + 8, &w2, 4);
+      }
       for (int hp = 0; hp < kHpSlots; hp++) {
         // `index <= emis2del * bias[hp]` (pbsim.cpp:3862) with integral index
         // == `index <= floor(emis2del*bias[hp])`

@@ -79,7 +79,7 @@ void hp_census_weighted(const uint8_t *seq, int64_t len, int64_t weight, int kee
 // collapsed, so that e = (i > E0) + (i > E1) equals the expanded emis2err[i].
 struct ErrClassTables {
   int acc_lo = 0, acc_hi = 0, smax = 0;
-  uint32_t rows_off = 64, init_off = 0, tran_off = 0, stride = 0;
+  uint32_t rows_off = 64, emis_off = 0, init_off = 0, tran_off = 0, stride = 0;  // emis_off: 16 B per state {magic, shift | d << 16, E0' | E1' << 16}
   bool all_rv_1000 = false;  // every reachable modulus == 1000 (fast-path eligibility)
   std::vector<uint8_t> blob; // (acc_hi-acc_lo+1) * stride
 };
@@ -104,6 +104,7 @@ struct QsClassTables {
 bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias &b, const pbsim_params &p,
                            QsClassTables *t, std::string *err);
 // fills qprob / sub_thre / ins_thre / del_thr only (the sampling method has no model)
+void emission_magic(uint32_t d, uint32_t *magic, uint32_t *shift);
 void build_mut_tables(const pbsim_params &p, const HpBias &b, QsClassTables *t);
 
 }  // namespace pbsim

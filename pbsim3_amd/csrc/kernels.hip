@@ -734,20 +734,16 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
         }
         state = lds[idx];  // a finished lane keeps walking harmlessly: nothing it computes is stored
         const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + state * 32u);
-        tran_rv = row[0];
-        const uint32_t emis_rv = row[1], e0 = row[2], e1 = row[3];
+        if (!kFastRv) tran_rv = row[0];
         const uint32_t thr = row[4 + (hp < 12u ? hp : 11u)];
         const bool del = (w.y % 1000u + 1u) <= thr;
-        const uint32_t i1000 = w.z % 1000u + 1u;
-        e = (uint32_t)(i1000 > e0) + (uint32_t)(i1000 > e1);
-        if (!del && emis_rv != 1000u) {  // near-pure-deletion states (rare)
-          if (emis_rv == 0) {
-            e = w.z % 3u;
-          } else {
-            const uint32_t i = w.z % emis_rv + 1u;
-            e = (uint32_t)(i > e0) + (uint32_t)(i > e1);
-          }
-        }
+        // emission class: the modulus differs from state to state (emis_rv = round(1000 * (1 - P(del)))), so
+        // `z % emis_rv` is a multiply-high with the state's magic number (host_tables.cpp emission_magic)
+        const uint2 em = *reinterpret_cast<const uint2 *>(lds + a.emis_off + state * 16u);
+        const uint32_t ee = *reinterpret_cast<const uint32_t *>(lds + a.emis_off + state * 16u + 8u);
+        const uint32_t quo = __umulhi(w.z, em.x) >> (em.y & 0xffffu);
+        const uint32_t rem = w.z - quo * (em.y >> 16);
+        e = (uint32_t)(rem >= (ee & 0xffffu)) + (uint32_t)(rem >= (ee >> 16));
         e = del ? 3u : e;
       }
       uint32_t subb = s_sub[nt * 4u + w.w % 3u];  // 0 for a non-ACGT reference base

@@ -29,5 +29,23 @@ int main(int argc, char **argv) {
       printf("%s ok stride %u\n", f.c_str(), t.stride);
     }
   }
-  return 0;
+  // emission_magic: x % d by multiply-high must be exact for every 31-bit x (checked at the multiples of d around
+  // 2^31, at small x and along a stride)
+  long bad = 0;
+  for (uint32_t d = 2; d <= 1000; d++) {
+    uint32_t magic, shift;
+    emission_magic(d, &magic, &shift);
+    auto chk = [&](uint64_t x) {
+      if (x >= (1ull << 31)) return;
+      const uint32_t q = (uint32_t)(((uint64_t)(uint32_t)x * magic) >> 32) >> shift;
+      if ((uint32_t)x - q * d != (uint32_t)x % d) bad++;
+    };
+    for (uint64_t x = 0; x < 4096; x++) chk(x);
+    for (uint64_t k = 0; k < 3000; k++) { chk((1ull << 31) - 1 - k); }
+    const uint64_t top = ((1ull << 31) - 1) / d * d;
+    for (int k = -3; k <= 3; k++) { chk(top + k); chk(top / 2 + k); chk(top - d + k); }
+    for (uint64_t x = 12345; x < (1ull << 31); x += 7919u * 131u) chk(x);
+  }
+  printf("emission_magic bad %ld\n", bad);
+  return bad != 0;
 }

@@ -122,7 +122,11 @@ def test_errhmm_class_tables_are_well_formed(model):
         assert acc == 63 + c and mode in (0, 1, 2)
         assert init_rv == 1000
         rows = np.frombuffer(b[64:64 + 32 * (smax + 1)], dtype=np.uint16).reshape(smax + 1, 16)
-        init = np.frombuffer(b[64 + 32 * (smax + 1):64 + 32 * (smax + 1) + 1000], dtype=np.uint8)
+        # emission rows: 16 B per state {magic u32, shift u16, d u16, E0' u16, E1' u16, pad}: z % d by multiply-high
+        emis_off = 64 + 32 * (smax + 1)
+        em = np.frombuffer(b[emis_off:emis_off + 16 * (smax + 1)], dtype=np.uint32).reshape(smax + 1, 4)
+        init_off = emis_off + 16 * (smax + 1)
+        init = np.frombuffer(b[init_off:init_off + 1000], dtype=np.uint8)
         assert init.min() >= 1 and init.max() <= smax
         assert (np.diff(init.astype(int)) >= 0).all()
         for j in range(1, smax + 1):
@@ -130,6 +134,17 @@ def test_errhmm_class_tables_are_well_formed(model):
             if tran_rv == 0:
                 continue
             assert tran_rv == 1000 and 0 <= emis_rv <= 1000 and e0 <= e1 <= emis_rv
+            magic, shift, d = int(em[j][0]), int(em[j][1]) & 0xffff, int(em[j][1]) >> 16
+            t0, t1 = int(em[j][2]) & 0xffff, int(em[j][2]) >> 16
+            if emis_rv >= 2:
+                assert (d, t0, t1) == (emis_rv, e0, e1)
+            else:                                  # emis_rv 0: rand() % 3; emis_rv 1: constant class
+                assert d == 3
+            for z in (0, 1, d - 1, d, 999, 1000, 123456789, 2 ** 31 - 1, (2 ** 31 - 1) // d * d, (2 ** 31 - 1) // d * d - 1):
+                assert z - ((z * magic >> 32) >> shift) * d == z % d
+                r = z % d
+                want = z % 3 if emis_rv == 0 else ((z % emis_rv + 1 > e0) + (z % emis_rv + 1 > e1))
+                assert (r >= t0) + (r >= t1) == want
             assert rows[j][4 + 11] == 0           # Q1: hp 11 -> bias 0.0 -> no HMM deletion
             assert rows[j][4 + 1] == rows[j][4 + 10]  # default --hp-del-bias 1
     ctx.close()

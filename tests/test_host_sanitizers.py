@@ -44,3 +44,4 @@ def test_table_builders_under_asan(tmp_path):
     p = subprocess.run([exe] + [harness.model_path(m) for m in MODELS], capture_output=True, text=True)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert p.stdout.count(" ok stride ") == len(MODELS)
+    assert "emission_magic bad 0" in p.stdout
