@@ -573,24 +573,26 @@ struct RefCursor {
     const bool cross = act && ((pl >> 3) != cur_wl);
     wseq = cross ? nseq : wseq;
     cur_wl = cross ? (pl >> 3) : cur_wl;
-    rel += cross ? wstep : 0;
     need_next = need_next || cross;
-    const uint32_t sh = (pl & 7u) * 8u;
-    *raw = (uint32_t)(wseq >> sh) & 0xffu;
+    // byte (pl & 7) of the window: one v_perm_b32 (selector 0x0c = constant zero for the upper bytes)
+    const uint32_t sel = (pl & 7u) | 0x0c0c0c00u;
+    *raw = __builtin_amdgcn_perm((uint32_t)(wseq >> 32), (uint32_t)wseq, sel);
     if (kHpBits) {
       const bool bcross = act && ((pl >> 5) != cur_bl);
       wbits = bcross ? nbits : wbits;
       cur_bl = bcross ? (pl >> 5) : cur_bl;
-      brel += bcross ? wstep : 0;
       need_nbits = need_nbits || bcross;
       *hp = ((wbits >> (pl & 31u)) & 1u) ? 11u : 1u;
     } else {
       whp = cross ? nhp : whp;
-      *hp = (uint32_t)(whp >> sh) & 0xffu;
+      *hp = __builtin_amdgcn_perm((uint32_t)(whp >> 32), (uint32_t)whp, sel);
     }
   }
 
   __device__ __forceinline__ void refill(bool act) {
+    // windows walked so far, from the cursor's current window index (kept per step) instead of per-step counters
+    rel = (int)cur_wl - (int)(pl0 >> 3);
+    brel = (int)cur_bl - (int)(pl0 >> 5);
     if (need_next && act) {
       const int nrel = ((p_first >> 3) + rel + wstep < 0) ? rel : rel + wstep;
       nseq = lane_seq[nrel];
