@@ -346,8 +346,8 @@ def main():
                          "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": walk_s * 1e3,
                          "walk_share_of_step": (walk_ms / 1e3) / dt if dt > 0 else None,
                          # the kernel's real ceiling is integer issue, not HBM: PMC pass of the same kernel
-                         "issue_bound": None if qs else {"valu_busy_frac": 0.93, "valu_per_wave_step": 163.4,
-                                                         "source": "profiles/r01h_walk_pmc.json (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD-cycles)"}},
+                         "issue_bound": None if qs else {"valu_busy_frac": 0.886, "valu_per_wave_step": 135.5,
+                                                         "source": "profiles/r01i_walk_pmc.json (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD-cycles)"}},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
