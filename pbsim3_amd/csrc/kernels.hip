@@ -685,9 +685,11 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     // strand: wgs by parity of the read number (pbsim.cpp:3820-3826, Q9); trans by expression (:4516-4522)
     minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
   }
-  const int cap_dw = a.wave_cap[wave];
+  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);  // wave-uniform: keeps row offsets scalar
   walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
-  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
+  const int64_t woff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.wave_off[wave] >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wave_off[wave]);
+  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + woff) + lane;
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
   const int cap = 2 * L + kScratchPad;
 
@@ -846,9 +848,11 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
     // strand: wgs by parity of the read number (pbsim.cpp:3820-3826, Q9); trans by expression (:4516-4522)
     minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
   }
-  const int cap_dw = a.wave_cap[wave];
+  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);  // wave-uniform: keeps row offsets scalar
   walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
-  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
+  const int64_t woff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.wave_off[wave] >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wave_off[wave]);
+  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + woff) + lane;
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
   uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;  // quality per MAF column (0 in deleted columns)
   const int cap = 2 * L + kScratchPad;
@@ -1016,8 +1020,10 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
       else off = (int64_t)(header_block(a.seed, a.unit, read_idx).z % (uint32_t)(G - L + 1));
     }
     const bool minus = (read_idx & 1u) == 0;  // :1767-1773
-    const int cap_dw = a.wave_cap[wave];
-    uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + lane;
+    const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);  // wave-uniform: keeps row offsets scalar
+    const int64_t woff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.wave_off[wave] >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wave_off[wave]);
+  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + woff) + lane;
     uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
     uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;
     const int cap = cap_dw * 4;
@@ -1618,7 +1624,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     mmax = __shfl(v, 0, 64);
   }
   if (mmax == 0) return;
-  const int cap_dw = a.wave_cap[wave];
+  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);  // wave-uniform: keeps row offsets scalar
   const uint32_t *region =
       reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave] + (size_t)pass * cap_dw * 256);
   uint32_t *tile = s_tile + wv * 16 * kTileStride;
