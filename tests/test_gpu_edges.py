@@ -135,3 +135,37 @@ def test_multi_batch_quota_pipeline_matches_oracle(tmp_path):
     _write_fasta(fa, [_rand_seq(rng, 2_000_000) for _ in range(3)])
     args = ONT + ["--depth", "12", "--seed", "77", "--genome", str(fa)]
     _compare(args, tmp_path, scratch_mb=64)
+
+
+def test_full_size_record_is_invariant_under_batching():
+    """BASELINE configs[1] size (one 750 Mbp record x depth 20 = 15 Gbases, 1.7 M reads): the same reads whatever
+    the batch partition -- a 10 GiB and a 40 GiB scratch pool cut the record into different batches, yet every counter,
+    the quota-cut read count and the ordered double sum behind the mean accuracy are identical.  Property test: no oracle
+    can walk 15 Gbases in seconds."""
+    import torch
+    import pbsim3_amd as P
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    idx = torch.randint(0, 4, (750_000_000,), device="cuda", dtype=torch.uint8, generator=g)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    genome = torch.empty_like(idx)
+    for lo in range(0, idx.numel(), 1 << 27):      # gather in pieces: index tensors are 8 bytes per element
+        genome[lo:lo + (1 << 27)] = lut[idx[lo:lo + (1 << 27)].long()]
+    del idx
+    results = []
+    for gib in (10, 40):
+        p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=20.0)
+        with P.Context(p, 0) as ctx:
+            ctx.set_scratch_bytes(gib << 30)
+            ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+            ctx.set_reference_device(genome.data_ptr(), genome.numel(), 1)
+            ctx.simulate_wgs(collect=False)
+            st = ctx.stats()
+            results.append((st.res_num, st.res_len_total, st.res_len_min, st.res_len_max, st.res_sub_num,
+                            st.res_ins_num, st.res_del_num, round(st.res_accuracy_mean, 12)))
+        torch.cuda.synchronize()
+    assert results[0] == results[1], results
+    n, total = results[0][0], results[0][1]
+    assert 15_000_000_000 <= total < 15_000_000_000 + 1_000_000 and 1_500_000 < n < 1_900_000
+    sub, ins, dele = (results[0][k] / total for k in (4, 5, 6))
+    assert 0.02 < sub + ins + dele < 0.2
