@@ -36,7 +36,7 @@ constexpr int kThreads = 256;
 constexpr int kSeg = kChunk / kThreads;   // 128 bytes per thread
 constexpr int kSegDw = kSeg / 4;          // 32 dwords
 constexpr int kInDw = kChunk / 4 + kChunk / 128;
-constexpr int kOutBytes = 24576;          // a Huffman member larger than this falls back to a stored block
+constexpr int kOutBytes = 33024;          // member capacity of the LDS image (it is reused as the output buffer)
 constexpr int kOutDw = kOutBytes / 4;
 constexpr int kSyms = 288;
 constexpr uint32_t kPoly = 0xEDB88320u;
@@ -206,7 +206,8 @@ struct SegTokens {
   Mask128 cover;  // positions covered by matches
 };
 
-__device__ __forceinline__ SegTokens seg_tokens(const uint32_t *seg, int seg_n, uint32_t prev_dword, bool chunk_start) {
+__device__ __forceinline__ SegTokens seg_tokens(const uint32_t (&seg)[kSegDw], int seg_n, uint32_t prev_dword,
+                                                bool chunk_start) {
   uint64_t e[2] = {0, 0};
   uint32_t pw = prev_dword;
 #pragma unroll
@@ -236,8 +237,11 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
                                                               const uint32_t *__restrict__ crc_table,
                                                               const uint32_t *__restrict__ pow128, uint32_t x8rem,
                                                               unsigned long long *__restrict__ prof) {
+  // The chunk's LDS image lives only until every thread holds its 128 bytes in registers; the same memory is then
+  // the (zeroed) output buffer the member is assembled in.  49 KB per workgroup = three workgroups per CU.
   __shared__ uint32_t s_in[kInDw];
-  __shared__ uint32_t s_out[kOutDw];
+  static_assert(kOutDw <= kInDw, "the output image must fit the input image");
+  uint32_t *const s_out = s_in;
   __shared__ uint32_t s_hist[4 * kSyms + 64];  // four copies, by lane & 3, against same-address serialisation; + one dummy bin per lane
   __shared__ uint32_t s_code[kSyms];     // reversed code | length << 16
   __shared__ uint32_t s_ufreq[kSyms];    // used symbols in symbol order: frequency
@@ -287,7 +291,6 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       dst[2] = v.z;
       dst[3] = v.w;
     }
-    for (int i = tid; i < kOutDw; i += kThreads) s_out[i] = 0;
     for (int i = tid; i < kSyms; i += kThreads) {
       s_code[i] = 0;
       s_len[i] = 0;
@@ -302,18 +305,22 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
 
   const int beg = tid * kSeg;
   const int seg_n = n - beg < 0 ? 0 : (n - beg < kSeg ? n - beg : kSeg);
-  const uint32_t *seg = &s_in[tid * (kSegDw + 1)];
-  const SegTokens tk = seg_tokens(seg, seg_n, tid ? s_in[tid * (kSegDw + 1) - 2] : 0u, tid == 0);
-  const int seg_dw = (seg_n + 3) >> 2;
+  uint32_t seg[kSegDw];  // the thread's segment, in registers from here on (every loop over it is fully unrolled)
+#pragma unroll
+  for (int j = 0; j < kSegDw; ++j) seg[j] = s_in[tid * (kSegDw + 1) + j];
+  const uint32_t prev_dw = tid ? s_in[tid * (kSegDw + 1) - 2] : 0u;
+  __syncthreads();
+  for (int i = tid; i < kInDw; i += kThreads) s_in[i] = 0;  // now the output buffer (visible after the next barrier)
+  const SegTokens tk = seg_tokens(seg, seg_n, prev_dw, tid == 0);
 
   // ---- pass 1: histogram + CRC of the segment
   {
     uint32_t *hist = &s_hist[(lane & 3) * kSyms];
     const uint32_t copy = (lane & 3) * kSyms, dummy = 4 * kSyms + lane;   // non-literal positions count into the lane's dummy bin
-#pragma unroll 2
-    for (int j = 0; j < seg_dw; ++j) {
+#pragma unroll
+    for (int j = 0; j < kSegDw; ++j) {
       const uint32_t nl = m_nibble(tk.lit, j);
-      if (nl == 0) continue;
+      if (nl == 0) continue;   // also true beyond the segment's end
       const uint32_t w = seg[j];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -330,14 +337,14 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
     }
     uint32_t c = tid == 0 ? 0xFFFFFFFFu : 0u;
     const int full = seg_n >> 2;
-#pragma unroll 4
-    for (int j = 0; j < full; ++j) {
-      const uint32_t x = c ^ seg[j];
-      c = s_crc[768 + (x & 255u)] ^ s_crc[512 + ((x >> 8) & 255u)] ^ s_crc[256 + ((x >> 16) & 255u)] ^ s_crc[x >> 24];
-    }
-    if (seg_n & 3) {
-      const uint32_t w = seg[full];
-      for (int k = 0; k < (seg_n & 3); ++k) c = s_crc[(c ^ (w >> (8 * k))) & 255u] ^ (c >> 8);
+#pragma unroll
+    for (int j = 0; j < kSegDw; ++j) {
+      if (j < full) {
+        const uint32_t x = c ^ seg[j];
+        c = s_crc[768 + (x & 255u)] ^ s_crc[512 + ((x >> 8) & 255u)] ^ s_crc[256 + ((x >> 16) & 255u)] ^ s_crc[x >> 24];
+      } else if (j == full) {
+        for (int k = 0; k < (seg_n & 3); ++k) c = s_crc[(c ^ (seg[j] >> (8 * k))) & 255u] ^ (c >> 8);
+      }
     }
     // bytes after this segment = 128 * (q - tid - 1) + r for full segments, 0 for the last (partial) one
     const int q = n >> 7, r = n & 127;
@@ -528,8 +535,8 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
   }
   uint32_t tok_bits = 0;
   {
-#pragma unroll 2
-    for (int j = 0; j < seg_dw; ++j) {
+#pragma unroll
+    for (int j = 0; j < kSegDw; ++j) {
       const uint32_t nl = m_nibble(tk.lit, j);
       if (nl == 0) continue;
       const uint32_t w = seg[j];
@@ -584,10 +591,9 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
     {
       BitWriter bw;
       bw.init(s_out, kHeadBits + kPrefixBits + hdr_total + tok_off);
-      // (code size matters here: the loop must stay resident in the instruction cache, so the rare
-      // match path is a rolled loop and nothing is unrolled across dwords)
-#pragma unroll 2
-      for (int j = 0; j < seg_dw; ++j) {
+      // (the rare match path stays a rolled loop: the unrolled literal path is what has to fit the instruction cache)
+#pragma unroll
+      for (int j = 0; j < kSegDw; ++j) {
         const uint32_t nl = m_nibble(tk.lit, j), ns = m_nibble(tk.start, j);
         if ((nl | ns) == 0) continue;   // inside a match
         const uint32_t w = seg[j];
@@ -650,10 +656,11 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       for (int i = 0; i < 4; ++i) t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
       sizes[chunk] = (int32_t)member;
     }
-    for (int i = tid; i < n; i += kThreads) {
-      const int d = i >> 2;
-      slot[23 + i] = (uint8_t)(s_in[d + (d >> 5)] >> (8 * (i & 3)));
-    }
+#pragma unroll
+    for (int j = 0; j < kSegDw; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (4 * j + k < seg_n) slot[23 + beg + 4 * j + k] = (uint8_t)(seg[j] >> (8 * k));
   }
 }
 
