@@ -119,6 +119,8 @@ struct Slot {
   HostBuf h_read_text, h_maf_text, h_stats;
   DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];  // deflate staging, one piece of DF_PIECE_CHUNKS chunks
   HostBuf h_df_total, h_df_out[2];
+  hipStream_t copy_stream = nullptr;   // D2H of compressed pieces
+  hipEvent_t ev_df[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
   bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
   int64_t b_pass0 = 0;
@@ -394,6 +396,11 @@ void pbsim_destroy(pbsim_ctx *c) {
     if (sl.ev2) (void)hipEventDestroy(sl.ev2);
     if (sl.ev3) (void)hipEventDestroy(sl.ev3);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    if (sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);
+    for (int i = 0; i < 2; i++) {
+      if (sl.ev_df[i]) (void)hipEventDestroy(sl.ev_df[i]);
+      if (sl.ev_cp[i]) (void)hipEventDestroy(sl.ev_cp[i]);
+    }
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -989,24 +996,41 @@ int deflate_stream(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, F &
     HIP_OK(hipMemsetAsync(c->d_df_prof.p, 0, 128, sl.stream));
     d_prof = c->d_df_prof.as<unsigned long long>();
   }
+  // Copies run on their own stream: the D2H of piece k-1 overlaps the kernels of piece k (and the host's consume()).
+  if (!sl.copy_stream) {
+    HIP_OK(hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      HIP_OK(hipEventCreateWithFlags(&sl.ev_df[i], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&sl.ev_cp[i], hipEventDisableTiming));
+    }
+  }
   int64_t pending = 0;  // bytes of the previous piece, in h_df_out[k ^ 1], copy possibly still in flight
+  bool used[2] = {false, false};
   int k = 0;
   for (int64_t off = 0; off < n; off += piece, k ^= 1) {
     const int64_t len = std::min(piece, n - off);
     const int64_t nch = (len + DF_CHUNK - 1) / DF_CHUNK;
     HIP_OK(sl.d_df_dense[k].ensure((size_t)max_ch * DF_SLOT, true));
     HIP_OK(sl.h_df_out[k].ensure((size_t)max_ch * DF_SLOT));
+    if (used[k]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[k], 0));  // piece k-2 has left this dense buffer
     launch_deflate(d_text + off, len, sl.d_df_slots.as<uint8_t>(), sl.d_df_sizes.as<int32_t>(),
                    sl.d_df_offsets.as<int64_t>(), sl.d_df_dense[k].as<uint8_t>(), tab, tab + 1024, sl.stream, d_prof);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(sl.h_df_total.p, sl.d_df_offsets.as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
-    HIP_OK(hipStreamSynchronize(sl.stream));  // also retires the copy of piece k-1 (same stream)
+    HIP_OK(hipEventRecord(sl.ev_df[k], sl.stream));
+    HIP_OK(hipStreamSynchronize(sl.stream));
     const int64_t total = *reinterpret_cast<int64_t *>(sl.h_df_total.p);
-    HIP_OK(hipMemcpyAsync(sl.h_df_out[k].p, sl.d_df_dense[k].p, (size_t)total, hipMemcpyDeviceToHost, sl.stream));
-    if (pending && !consume((const char *)sl.h_df_out[k ^ 1].p, pending)) return PBSIM_FAILED;
+    HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[k], 0));
+    HIP_OK(hipMemcpyAsync(sl.h_df_out[k].p, sl.d_df_dense[k].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
+    HIP_OK(hipEventRecord(sl.ev_cp[k], sl.copy_stream));
+    used[k] = true;
+    if (pending) {
+      HIP_OK(hipEventSynchronize(sl.ev_cp[k ^ 1]));
+      if (!consume((const char *)sl.h_df_out[k ^ 1].p, pending)) return PBSIM_FAILED;
+    }
     pending = total;
   }
-  HIP_OK(hipStreamSynchronize(sl.stream));
+  HIP_OK(hipStreamSynchronize(sl.copy_stream));
   if (d_prof) {
     unsigned long long t[16];
     HIP_OK(hipMemcpy(t, d_prof, 128, hipMemcpyDeviceToHost));

@@ -14,5 +14,6 @@ python3 bench.py --workload qshmm10 --no-cpu-baseline > $out/bench_qshmm10.json 
 python3 bench.py --workload trans > $out/bench_trans.json 2>/dev/null
 python3 bench.py --workload sample > $out/bench_sample.json 2>/dev/null
 python3 bench.py --whole-job --no-cpu-baseline > $out/bench_whole_job.json 2>/dev/null
+python3 bench.py --whole-job --deflate --no-cpu-baseline > $out/bench_whole_job_deflate.json 2>/dev/null
 rm -rf $out/prof
 tail -c 1500 $out/bench_n1.json; echo; head -5 $out/kernel_stats.csv | cut -c1-200
