@@ -242,19 +242,23 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
   __shared__ uint32_t s_in[kInDw];
   static_assert(kOutDw <= kInDw, "the output image must fit the input image");
   uint32_t *const s_out = s_in;
-  __shared__ uint32_t s_hist[4 * kSyms + 64];  // four copies, by lane & 3, against same-address serialisation; + one dummy bin per lane
+  __shared__ uint32_t s_hist[3 * kSyms + 64];  // three copies, by lane % 3, against same-address serialisation; + one dummy bin per lane
   __shared__ uint32_t s_code[kSyms];     // reversed code | length << 16
-  __shared__ uint32_t s_ufreq[kSyms];    // used symbols in symbol order: frequency
-  __shared__ uint32_t s_sfreq[kSyms];    // frequencies in sorted order
-  __shared__ uint32_t s_w[kSyms];        // internal node weights
-  __shared__ uint16_t s_usym[kSyms];     // used symbols in symbol order
-  __shared__ uint16_t s_sorted[kSyms];   // used symbols, ascending (freq, symbol)
-  __shared__ uint16_t s_par[kSyms];      // parent of internal node
-  __shared__ uint16_t s_leafpar[kSyms];  // parent of leaf
-  __shared__ uint16_t s_dep[kSyms];      // depth of internal node
   __shared__ uint8_t s_len[kSyms];       // code length by symbol
-  __shared__ uint8_t s_ulen[kSyms];      // code length by used index
-  __shared__ uint32_t s_crc[1024];       // slice-by-4 tables
+  // Between the register load and the emission the image is free: the CRC tables and the Huffman construction's
+  // work arrays live in its first 2 680 dwords and are zeroed again before the first bit is written.  39.6 KB of
+  // LDS per workgroup = four workgroups per CU.
+  uint32_t *const s_crc = s_in;                 // [1024] slice-by-4 tables
+  uint32_t *const s_ufreq = s_in + 1024;        // [288] used symbols in symbol order: frequency
+  uint32_t *const s_sfreq = s_in + 1312;        // [288] frequencies in sorted order
+  uint32_t *const s_w = s_in + 1600;            // [288] internal node weights
+  uint16_t *const s_usym = reinterpret_cast<uint16_t *>(s_in + 1888);     // [288] used symbols in symbol order
+  uint16_t *const s_sorted = reinterpret_cast<uint16_t *>(s_in + 2032);   // [288] used symbols, ascending (freq, symbol)
+  uint16_t *const s_par = reinterpret_cast<uint16_t *>(s_in + 2176);      // [288] parent of internal node
+  uint16_t *const s_leafpar = reinterpret_cast<uint16_t *>(s_in + 2320);  // [288] parent of leaf
+  uint16_t *const s_dep = reinterpret_cast<uint16_t *>(s_in + 2464);      // [288] depth of internal node
+  uint8_t *const s_ulen = reinterpret_cast<uint8_t *>(s_in + 2608);       // [288] code length by used index
+  constexpr int kWorkDw = 2680;
   __shared__ uint64_t s_nz[5];           // header positions with a non-zero code length (bits >= npos set)
   __shared__ uint32_t s_cnt[16], s_first[16];
   __shared__ uint32_t s_wave[kThreads / 64];
@@ -295,8 +299,7 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       s_code[i] = 0;
       s_len[i] = 0;
     }
-    for (int i = tid; i < 4 * kSyms + 64; i += kThreads) s_hist[i] = 0;
-    for (int i = tid; i < 1024; i += kThreads) s_crc[i] = crc_table[i];
+    for (int i = tid; i < 3 * kSyms + 64; i += kThreads) s_hist[i] = 0;
     if (tid < 16) s_cnt[tid] = 0;
     if (tid < 4) s_misc[tid] = 0;
   }
@@ -310,13 +313,14 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
   for (int j = 0; j < kSegDw; ++j) seg[j] = s_in[tid * (kSegDw + 1) + j];
   const uint32_t prev_dw = tid ? s_in[tid * (kSegDw + 1) - 2] : 0u;
   __syncthreads();
-  for (int i = tid; i < kInDw; i += kThreads) s_in[i] = 0;  // now the output buffer (visible after the next barrier)
+  for (int i = tid; i < kInDw; i += kThreads) s_in[i] = (i < 1024) ? crc_table[i] : 0u;  // work area, then output buffer
+  __syncthreads();
   const SegTokens tk = seg_tokens(seg, seg_n, prev_dw, tid == 0);
 
   // ---- pass 1: histogram + CRC of the segment
   {
-    uint32_t *hist = &s_hist[(lane & 3) * kSyms];
-    const uint32_t copy = (lane & 3) * kSyms, dummy = 4 * kSyms + lane;   // non-literal positions count into the lane's dummy bin
+    const uint32_t copy = (uint32_t)(lane % 3) * kSyms, dummy = 3 * kSyms + lane;   // non-literal positions count into the lane's dummy bin
+    uint32_t *hist = &s_hist[copy];
 #pragma unroll
     for (int j = 0; j < kSegDw; ++j) {
       const uint32_t nl = m_nibble(tk.lit, j);
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int s = tid + h * kThreads;
-      f[h] = s < 286 ? s_hist[s] + s_hist[kSyms + s] + s_hist[2 * kSyms + s] + s_hist[3 * kSyms + s] : 0u;
+      f[h] = s < 286 ? s_hist[s] + s_hist[kSyms + s] + s_hist[2 * kSyms + s] : 0u;
       const uint64_t b = __ballot(f[h] != 0);
       pre[h] = (uint32_t)__popcll(b & ((1ull << lane) - 1));
       if (lane == 0) s_wcnt[h * 4 + wave] = (uint32_t)__popcll(b);
@@ -565,6 +569,9 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
 
   if (huff) {
     const uint32_t member = 18 + payload_bytes + 8;
+    __syncthreads();  // everybody is done with the work arrays
+    for (int i = tid; i < kWorkDw; i += kThreads) s_in[i] = 0;
+    __syncthreads();
     if (tid == 0) {
       // BGZF header: 1f 8b 08 04 | mtime 0 | xfl 0 | os ff | xlen 6 | 'B' 'C' 2 0 | bsize-1
       s_out[0] = 0x04088b1fu;
