@@ -78,16 +78,22 @@ def cpu_baseline(sample_bp=4_000_000):
         bases = count("out")
         # the same job once per host core, concurrently (distinct seeds and prefixes): what the box's CPU can do at best
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncopy = min(ncpu, 64)                # bounded: every copy writes ~85 MB of text into the temp dir
         procs = []
         t1 = time.time()
-        for k in range(ncpu):
+        for k in range(ncopy):
             a2 = list(cmd)
             a2[a2.index("--seed") + 1] = str(100 + k)
+            a2[a2.index("--depth") + 1] = "5"
             a2[a2.index("--prefix") + 1] = os.path.join(td, "all%d" % k)
             procs.append(subprocess.Popen(a2, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
-        ok = all(q.wait() == 0 for q in procs)
+        rcs = [q.wait() for q in procs]
         dt_all = time.time() - t1
-        all_cores = {"value": count("all") / dt_all, "cores": ncpu, "note": f"{ncpu} concurrent copies of the sample job"} if ok else None
+        if all(rc == 0 for rc in rcs):
+            all_cores = {"value": count("all") / dt_all, "cores": ncopy,
+                         "note": f"{ncopy} concurrent copies of the sample job at depth 5 on the box's {ncpu} host cores"}
+        else:
+            all_cores = {"value": None, "cores": ncopy, "note": f"{sum(rc != 0 for rc in rcs)} of {ncopy} copies failed"}
     return {"value": bases / dt, "unit": "bases/s", "cores": 1, "kind": "reference" if ref else "port",
             "sample": f"{sample_bp // 1_000_000} Mbp uniform genome x depth 20, ERRHMM-ONT, seed 1, "
                       f"{bases} bases in {dt:.1f}s, gzip bypassed (cat)",
