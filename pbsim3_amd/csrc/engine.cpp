@@ -161,6 +161,7 @@ struct pbsim_ctx {
   std::vector<int64_t> sq_off;
   int64_t sq_total = 0;        // sample.len_total_filtered
   int64_t scratch_budget = 0;  // bytes of wave scratch per slot
+  bool scratch_auto = true;    // sized per record by pbsim_simulate_wgs unless PBSIM_SCRATCH_MB / pbsim_set_scratch_bytes said otherwise
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
   int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)
@@ -380,6 +381,7 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
   }
   const char *mb = getenv("PBSIM_SCRATCH_MB");
   c->scratch_budget = (mb && atoll(mb) > 0) ? atoll(mb) * (1LL << 20) : (8LL << 30);
+  c->scratch_auto = !(mb && atoll(mb) > 0);
   const char *pd = getenv("PBSIM_PIPELINE_DEPTH");
   if (pd && atoi(pd) >= 1) c->pipeline_depth = std::min(kMaxSlots, atoi(pd));
   return c.release();
@@ -429,6 +431,7 @@ int pbsim_load_qshmm(pbsim_ctx *c, const char *path) {
 int pbsim_set_scratch_bytes(pbsim_ctx *c, int64_t bytes) {
   if (!c || bytes < (1 << 20)) return fail("pbsim_set_scratch_bytes: bad argument");
   c->scratch_budget = bytes;
+  c->scratch_auto = false;
   return PBSIM_SUCCEEDED;
 }
 
@@ -1168,6 +1171,17 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
   // been measured (deletions outweigh insertions in most models), the measured ratio afterwards
   double mean = 0.97 * std::min<double>(c->hdr.mean_len, (double)c->ref_len);
   const int n_slots = std::max(1, std::min(kMaxSlots, c->pipeline_depth));
+  if (c->scratch_auto) {
+    // Nobody chose a pool size: a record wants to run as two batches (one per slot) -- a batch's walk lasts at least
+    // as long as its longest read, so many small batches waste the GPU on their tails -- up to a share of the free HBM
+    // (the text buffers need about as much again).
+    size_t free_b = 0, total_b = 0;
+    HIP_OK(hipMemGetInfo(&free_b, &total_b));
+    const double want = (double)quota * c->p.pass_num * 1.07 * regions_of(c) * 1.3 / n_slots + (64 << 20);
+    const double share = std::min(48.0 * (1LL << 30), 0.15 * (double)(free_b + c->s().d_scratch.bytes * n_slots));
+    const int64_t auto_b = (int64_t)std::max(256.0 * (1 << 20), std::min(want, share));
+    if (auto_b > c->scratch_budget || c->scratch_budget > 2 * auto_b) c->scratch_budget = auto_b;
+  }
   int64_t cap = batch_capacity(c);
   int64_t len_total = 0, next_read = 1;
   struct Pending {
