@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage (GPU box): tools/e2e_cli.sh GENOME_BP  -- end-to-end wall time of the pbsim CLI (FASTA on disk -> files on disk)
+# usage (GPU box): tools/e2e_cli.sh GENOME_BP [MODES]  -- end-to-end wall time of the pbsim CLI (FASTA on disk -> files on disk)
+# MODES: comma list of plain,gpu,host (default all three; host = zlib on the CPU threads, minutes at 1 Gbp)
 n=${1:-100000000}
 d=$(mktemp -d /dev/shm/pbsim_e2e.XXXX)
 python3 - $n $d <<'PY'
@@ -12,7 +13,9 @@ open(d+"/g.fa","wb").write(b">chr1\n"+out.tobytes())
 PY
 python3 -c "import sys; sys.path.insert(0,'tests'); import harness; print(harness.model_path('ERRHMM-ONT.model'))" > $d/model.txt
 M=$(cat $d/model.txt)
-for mode in "--no-gzip" "" "--gzip host"; do
+modes=${2:-plain,gpu,host}
+for m in ${modes//,/ }; do
+  case $m in plain) mode="--no-gzip";; gpu) mode="";; host) mode="--gzip host";; esac
   t0=$(date +%s.%N)
   pbsim3_amd/bin/pbsim --strategy wgs --method errhmm --errhmm $M --genome $d/g.fa --depth 20 --seed 1 --prefix $d/out $mode 2> $d/err.txt
   t1=$(date +%s.%N)
