@@ -83,11 +83,6 @@ __device__ __forceinline__ int dec_len(int64_t v) { return v < 0 ? 1 + count_dig
 #define PB_SAM_T4 "\tRG:Z:ffffffff\n"
 #define PB_LEN(s) ((int)sizeof(s) - 1)
 
-__device__ __forceinline__ int put_lit(char *dst, const char *lit, int n) {
-  for (int i = 0; i < n; i++) dst[i] = lit[i];
-  return n;
-}
-
 __device__ __forceinline__ int put_dec(char *dst, int64_t v) {
   int neg = 0;
   if (v < 0) {
