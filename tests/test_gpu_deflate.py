@@ -97,3 +97,28 @@ def test_simulation_sinks_deflated(case):
         g = packed[k]
         assert gzip.decompress(g) == v, k
         assert len(g) < 0.5 * len(v)
+
+
+def test_randomized_buffers(ctx):
+    """60 random buffers: sizes around the chunk / segment seams, alphabets from 1 to 256 symbols, geometric run
+    lengths, skewed symbol frequencies.  Every stream must inflate to its input; the small ones must equal the model."""
+    r = random.Random(2026)
+    seams = [1, 2, 3, 4, 5, 127, 128, 129, 255, 256, 257, 4095, 32767, 32768, 32769, 65535, 65536, 65537]
+    for it in range(60):
+        n = r.choice(seams) if it < len(seams) else r.randint(1, 150000)
+        k = r.choice([1, 2, 4, 5, 16, 64, 256])
+        alphabet = bytes(r.sample(range(256), k))
+        weights = [r.random() ** r.choice([1, 4, 12]) + 1e-9 for _ in alphabet]
+        run_p = r.choice([0.0, 0.3, 0.9, 0.99])
+        out = bytearray()
+        while len(out) < n:
+            b = r.choices(alphabet, weights)[0]
+            run = 1
+            while r.random() < run_p and run < 2000:
+                run += 1
+            out.extend(bytes([b]) * run)
+        data = bytes(out[:n])
+        got = ctx.deflate_buffer(data)
+        assert gzip.decompress(got) == data, (it, n, k, run_p)
+        if n <= 70000:
+            assert got == deflate_model.compress(data), (it, n, k, run_p)
