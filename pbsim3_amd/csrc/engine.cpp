@@ -1313,7 +1313,7 @@ static int set_units(pbsim_ctx *c, int64_t n, const char *const *ids, const int6
     reads += (int64_t)(int)(plus_exp[u] + minus_exp[u]);  // `int read_num` (pbsim.cpp:4149)
     max_len = std::max(max_len, lens[u]);
   }
-  if (reads < 1) return fail("transcript set has no expression");
+  // zero total expression is legal: the reference simply simulates nothing and prints its report (with NaN means)
   if (reads > 0x7fffff00LL) return fail("too many reads");
   std::vector<uint8_t> cat((size_t)total);
   std::vector<int64_t> ubase(n), ulen(n);
@@ -1366,9 +1366,11 @@ static int set_units(pbsim_ctx *c, int64_t n, const char *const *ids, const int6
   HIP_OK(hipMemsetAsync(c->d_seq_own.as<uint8_t>() + total, 0, 64, c->stream));
   int64_t census[kHpSlots] = {0};
   if (!prepare_reference(c, c->d_seq_own.as<uint8_t>(), total, keep_first, census)) return PBSIM_FAILED;
-  if (!upload(c->d_read_unit, runit.data(), runit.size() * 4, c->stream)) return PBSIM_FAILED;
-  if (!upload(c->d_read_base, rbase.data(), rbase.size() * 8, c->stream)) return PBSIM_FAILED;
-  if (!upload(c->d_read_minus, rminus.data(), rminus.size(), c->stream)) return PBSIM_FAILED;
+  if (reads > 0) {
+    if (!upload(c->d_read_unit, runit.data(), runit.size() * 4, c->stream)) return PBSIM_FAILED;
+    if (!upload(c->d_read_base, rbase.data(), rbase.size() * 8, c->stream)) return PBSIM_FAILED;
+    if (!upload(c->d_read_minus, rminus.data(), rminus.size(), c->stream)) return PBSIM_FAILED;
+  }
   if (!upload(c->d_unit_len, ulen.data(), ulen.size() * 8, c->stream)) return PBSIM_FAILED;
   if (!upload(c->d_unit_rank, urank.data(), urank.size() * 4, c->stream)) return PBSIM_FAILED;
   if (!upload(c->d_unit_names, names.data(), names.size(), c->stream)) return PBSIM_FAILED;
@@ -1672,7 +1674,7 @@ int pbsim_simulate_trans(pbsim_ctx *c, const pbsim_sink *sink) {
   if (!c) return fail("bad argument");
   NEED_DEVICE(c);
   if (c->p.strategy == PBSIM_STRATEGY_WGS) return fail("pbsim_simulate_trans: strategy is wgs");
-  if (!c->d_seq || c->trans_reads < 1) return fail("no transcripts/templates set");
+  if (!c->d_seq || c->n_units < 1) return fail("no transcripts/templates set");
   pbsim_reset_stats(c);
   int64_t next_read = 1, cap = batch_capacity(c);
   while (next_read <= c->trans_reads) {

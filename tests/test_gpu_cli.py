@@ -74,3 +74,19 @@ def test_cli_sample_method_compressed(tmp_path, mode):
         with gzip.open(str(tmp_path / ("out" + k + ".gz")), "rb") as f:
             assert harness.sha(f.read()) == want[k]["sha256"], k
     assert harness.sha(harness.strip_report(p.stderr).encode()) == want[".stderr"]["sha256"]
+
+
+def test_cli_transcripts_without_expression(tmp_path):
+    """plus = minus = 0 everywhere: the reference simulates nothing and still prints its report (NaN means)"""
+    tsv = tmp_path / "t.tsv"
+    tsv.write_text("T0\t0\t0\t" + "ACGT" * 40 + "\nT1\t0\t0\t" + "GGCATTA" * 30 + "\n")
+    args = ["--strategy", "trans", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-SEQUEL.model", "--transcript", str(tsv),
+            "--seed", "1"]
+    (tmp_path / "o").mkdir()
+    (tmp_path / "p").mkdir()
+    want = harness.run_oracle(args, "philox", str(tmp_path / "o"))
+    outs = run_cli(args, str(tmp_path / "p"))
+    assert sorted(outs) == sorted(want)
+    for k in want:
+        assert outs[k] == want[k], k
+    assert b"nan" in outs[".stderr"] and outs[".fq"] == b""
