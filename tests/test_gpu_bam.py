@@ -106,27 +106,31 @@ def test_native_bam_equals_golden_sam(case, tmp_path):
     sams = sorted(k for k in gold if k.endswith(".sam"))
     assert sams
     for k in sams:
-        bam = (tmp_path / ("out" + k[:-4] + ".bam")).read_bytes()
-        text, recs = parse_bam(bgzf_decompress(bam))
-        lines = gold[k].decode().split("\n")
-        hdr = [l for l in lines if l.startswith("@")]
-        body = [l for l in lines if l and not l.startswith("@")]
-        assert text.decode() == "\n".join(hdr) + "\n"
-        assert len(recs) == len(body)
-        for r, line in zip(recs, body):
-            f = line.split("\t")
-            # 4-bit codes carry no case (a lower-case first base survives in SAM text only, Q6)
-            assert (r["name"], r["flag"], r["mapq"], r["seq"], r["qual"]) == (f[0], int(f[1]), int(f[4]), f[9].upper(), f[10])
-            assert [t[0] for t in r["tags"]] == [x[:2] for x in f[11:]]
-            for (tag, kind, v, typ), x in zip(r["tags"], f[11:]):
-                val = x[5:]
-                if kind == "i":
-                    assert v == int(val) and typ == smallest(int(val)), (tag, v, typ)
-                elif kind == "f":
-                    assert v == np.float32(float(val))
-                elif kind == "Z":
-                    assert v == val
-                elif kind == "B:C":
-                    assert x[5:7] == "C," and v == [int(y) for y in val.split(",")[1:]]
-                else:
-                    assert v == [float(y) for y in val.split(",")[1:]]
+        compare_bam_with_sam((tmp_path / ("out" + k[:-4] + ".bam")).read_bytes(), gold[k])
+
+
+def compare_bam_with_sam(bam, sam_text):
+    """every header byte, field and tag of the BAM container against the SAM text of the same run"""
+    text, recs = parse_bam(bgzf_decompress(bam))
+    lines = sam_text.decode().split("\n")
+    hdr = [l for l in lines if l.startswith("@")]
+    body = [l for l in lines if l and not l.startswith("@")]
+    assert text.decode() == "\n".join(hdr) + "\n"
+    assert len(recs) == len(body)
+    for r, line in zip(recs, body):
+        f = line.split("\t")
+        # 4-bit codes carry no case (a lower-case first base survives in SAM text only, Q6)
+        assert (r["name"], r["flag"], r["mapq"], r["seq"], r["qual"]) == (f[0], int(f[1]), int(f[4]), f[9].upper(), f[10])
+        assert [t[0] for t in r["tags"]] == [x[:2] for x in f[11:]]
+        for (tag, kind, v, typ), x in zip(r["tags"], f[11:]):
+            val = x[5:]
+            if kind == "i":
+                assert v == int(val) and typ == smallest(int(val)), (tag, v, typ)
+            elif kind == "f":
+                assert v == np.float32(float(val))
+            elif kind == "Z":
+                assert v == val
+            elif kind == "B:C":
+                assert x[5:7] == "C," and v == [int(y) for y in val.split(",")[1:]]
+            else:
+                assert v == [float(y) for y in val.split(",")[1:]]
