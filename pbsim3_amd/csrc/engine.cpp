@@ -119,6 +119,8 @@ struct Slot {
   HostBuf h_read_text, h_maf_text, h_stats;
   DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];  // deflate staging, one piece of DF_PIECE_CHUNKS chunks
   HostBuf h_df_total, h_df_out[2];
+  hipStream_t walk_stream = nullptr;   // low priority: the walk kernel only
+  hipEvent_t ev_prep = nullptr;        // header + sort done (walk_stream waits for it)
   hipStream_t copy_stream = nullptr;   // D2H of compressed pieces
   hipEvent_t ev_df[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
@@ -369,11 +371,18 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
     fail("cannot initialise the HIP device/stream");
     return nullptr;
   }
+  // The long walk kernel goes to a LOW priority stream of its slot, everything short (header, sort, scans, text
+  // emission) to a HIGH priority one: workgroups of an older kernel are otherwise dispatched before those of a
+  // younger one, and the other slot's half-millisecond kernels waited 15-20 ms behind a walk's pending workgroups.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   for (Slot &sl : c->slots) {
-    if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&sl.walk_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
       fail("cannot create a HIP stream");
       return nullptr;
     }
+    (void)hipEventCreateWithFlags(&sl.ev_prep, hipEventDisableTiming);
     (void)hipEventCreate(&sl.ev0);
     (void)hipEventCreate(&sl.ev1);
     (void)hipEventCreate(&sl.ev2);
@@ -399,6 +408,8 @@ void pbsim_destroy(pbsim_ctx *c) {
     if (sl.ev3) (void)hipEventDestroy(sl.ev3);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
     if (sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);
+    if (sl.walk_stream) (void)hipStreamDestroy(sl.walk_stream);
+    if (sl.ev_prep) (void)hipEventDestroy(sl.ev_prep);
     for (int i = 0; i < 2; i++) {
       if (sl.ev_df[i]) (void)hipEventDestroy(sl.ev_df[i]);
       if (sl.ev_cp[i]) (void)hipEventDestroy(sl.ev_cp[i]);
@@ -670,15 +681,17 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   w.ndel = c->s().d_ndel.as<int32_t>();
   w.qsum = c->s().d_qsum.as<double>();
   w.flags = flags;
-  HIP_OK(hipEventRecord(c->s().ev1, c->s().stream));
+  hipStream_t ws = c->s().walk_stream;
+  HIP_OK(hipEventRecord(c->s().ev_prep, c->s().stream));
+  HIP_OK(hipStreamWaitEvent(ws, c->s().ev_prep, 0));
+  HIP_OK(hipEventRecord(c->s().ev1, ws));
   if (c->p.method == PBSIM_METHOD_ERR) {
     w.stride = c->ect.stride;
     w.rows_off = c->ect.rows_off;
     w.emis_off = c->ect.emis_off;
     w.init_off = c->ect.init_off;
     w.tran_off = c->ect.tran_off;
-    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->p.hp_del_bias == 1,
-                       c->s().stream);
+    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->p.hp_del_bias == 1, ws);
   } else {
     w.stride = c->qct.stride;
     w.rv_off = c->qct.rv_off;
@@ -692,9 +705,10 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
     w.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     w.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
     launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8, c->qct.all_rv_100,
-                      c->p.hp_del_bias == 1, c->s().stream);
+                      c->p.hp_del_bias == 1, ws);
   }
-  HIP_OK(hipEventRecord(c->s().ev2, c->s().stream));
+  HIP_OK(hipEventRecord(c->s().ev2, ws));
+  HIP_OK(hipStreamWaitEvent(c->s().stream, c->s().ev2, 0));
   launch_gather_pass0_scan(w.out_len, n_reads, P, c->s().d_cum.as<int64_t>(), c->s().d_scan_tmp.as<int64_t>(),
                            &flags->sums[0], c->s().stream);
   HIP_OK(hipEventRecord(c->s().ev3, c->s().stream));

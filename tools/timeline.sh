@@ -17,6 +17,6 @@ t0=int(sel[0]["Start_Timestamp"])
 for r in sel:
     d=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
     if d<0.15: continue
-    name=r["Kernel_Name"].split("(")[0].split("::")[-1][:28]
+    name=r["Kernel_Name"].replace("void ","").replace("pbsim::(anonymous namespace)::","").split("(")[0][:28]
     print("%8.2f ms  +%7.2f ms  q%-3s %s" % ((int(r["Start_Timestamp"])-t0)/1e6, d, r.get("Queue_Id","?"), name))
 PY
