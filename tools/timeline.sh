@@ -12,7 +12,7 @@ f=glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True)[0]
 rows=[r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 t_end=max(int(r["End_Timestamp"]) for r in rows)
-sel=[r for r in rows if int(r["Start_Timestamp"])>t_end-260e6]
+sel=[r for r in rows if t_end-330e6 < int(r["Start_Timestamp"]) < t_end-130e6]
 t0=int(sel[0]["Start_Timestamp"])
 for r in sel:
     d=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
