@@ -789,13 +789,13 @@ static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
   }
 }
 
-int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *info) {
+// First half of pbsim_batch_finalize: the quota cut (which reads of the batch are final, len_total behind them).
+static int finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out) {
   if (!c || !c->s().b_walked) return fail("pbsim_batch_finalize: no walked batch");
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
   DeviceFlags *flags = c->s().d_flags.as<DeviceFlags>();
   const int64_t quota = pbsim_unit_quota(c);
-  const int P = c->p.pass_num;
   // the sampling method never truncates a read: it only stops before the first read that starts at or past the quota
   launch_quota_cut(c->s().d_cum.as<int64_t>(),
                    c->p.method == PBSIM_METHOD_SAMPLE ? nullptr : c->s().d_rawlen.as<int32_t>(), c->s().b_n, len_total_before, quota,
@@ -824,6 +824,18 @@ int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_inf
     bi.quota_reached = (n_final < c->s().b_n) || (bi.len_total_after >= quota);
     bi.need_truncated_read = (n_final < c->s().b_n) && (bi.len_total_after < quota);
   }
+  c->s().b_info = bi;
+  *out = bi;
+  return PBSIM_SUCCEEDED;
+}
+
+// Second half: text sizes, their scans, and the text itself into the slot's device buffers.
+static int finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
+  DeviceFlags *flags = c->s().d_flags.as<DeviceFlags>();
+  DeviceFlags f;
+  pbsim_batch_info bi = c->s().b_info;
+  const int P = c->p.pass_num;
+  const int64_t n_final = bi.n_final;
   const int64_t n_tasks = n_final * P;
   if (n_tasks > 0) {
     HIP_OK(c->s().d_rt_len.ensure(n_tasks * 8));
@@ -855,6 +867,12 @@ int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_inf
   c->s().b_finalized = true;
   if (info) *info = bi;
   return PBSIM_SUCCEEDED;
+}
+
+int pbsim_batch_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *info) {
+  pbsim_batch_info bi;
+  if (!finalize_cut(c, len_total_before, &bi)) return PBSIM_FAILED;
+  return finalize_text(c, info);
 }
 
 int pbsim_batch_fetch(pbsim_ctx *c, char *read_text, char *maf_text) {
@@ -1219,12 +1237,19 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
   int64_t spec_read = 1;          // first read not yet enqueued
   double spec_total = 0;          // expected pass-0 bases once everything enqueued has finished
   bool serial = false;
+  int tail_slot = -1;             // slot on which the first truncated read was started ahead of time (-1: none)
   while (len_total < quota) {
     if (serial) {
-      c->cur = 0;
       pbsim_batch_info bi;
       const double t0 = now();
-      if (!pbsim_batch_walk(c, next_read, 1, quota - len_total, nullptr)) return PBSIM_FAILED;
+      if (tail_slot >= 0) {       // begun while the last bulk batch's text was being emitted
+        c->cur = tail_slot;
+        tail_slot = -1;
+        if (!pbsim_batch_walk_end(c, nullptr)) return PBSIM_FAILED;
+      } else {
+        c->cur = 0;
+        if (!pbsim_batch_walk(c, next_read, 1, quota - len_total, nullptr)) return PBSIM_FAILED;
+      }
       if (!pbsim_batch_finalize(c, len_total, &bi)) return PBSIM_FAILED;
       if (!deliver(c, sink)) return PBSIM_FAILED;
       if (trace) fprintf(stderr, "[pbsim trace] t=%.1f ms tail read %lld: %.1f ms\n", t0 - t_start, (long long)next_read, now() - t0);
@@ -1276,7 +1301,19 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
     }
     pbsim_batch_info bi;
     const double t1 = now();
-    if (!pbsim_batch_finalize(c, len_total, &bi)) {
+    if (!finalize_cut(c, len_total, &bi)) {
+      drop_pending();
+      return PBSIM_FAILED;
+    }
+    if (fifo.empty() && n_slots > 1 && bi.n_final < pd.n && bi.need_truncated_read) {
+      // The quota falls inside this batch and the next read will be a truncated one (pbsim.cpp:3795-3800).  A lone
+      // read walks for up to ~20 ms: start it on the free slot now, beside this batch's text emission.
+      tail_slot = (pd.slot + 1) % n_slots;
+      c->cur = tail_slot;
+      if (!pbsim_batch_walk_begin(c, next_read + bi.n_final, 1, quota - bi.len_total_after)) tail_slot = -1;
+      c->cur = pd.slot;
+    }
+    if (!finalize_text(c, &bi)) {
       drop_pending();
       return PBSIM_FAILED;
     }
