@@ -9,5 +9,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 
+# PyTorch-ROCm bundles its own copies of libamdhip64 / libhsa-runtime64; libpbsim3_amd.so links the system ones.  Both
+# can live in one process only if torch's copies are loaded FIRST (the other order leaves torch without a device:
+# "no ROCm-capable device is detected").  Some GPU tests use torch after the product, so fix the load order here.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
