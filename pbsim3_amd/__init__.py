@@ -110,11 +110,34 @@ def lib_path():
     return _build.LIB
 
 
+def _torch_runtime_first():
+    """PyTorch-ROCm wheels bundle their own libhsa-runtime64 / libamdhip64; this library links the system copies.  The two
+    coexist in one process only when torch's are mapped first, so if torch is installed but not imported yet, map its two
+    runtime libraries now (no `import torch`): a later `import torch` in the same process then still finds its device.
+    PBSIM_TORCH_COMPAT=0 skips this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("PBSIM_TORCH_COMPAT", "1") == "0":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if not spec or not spec.origin:
+            return
+        libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:       # best effort: the product itself does not depend on it
+        pass
+
+
 def load(build_if_missing=True):
     """Loads libpbsim3_amd.so (building it in-tree with hipcc when absent)."""
     global _lib
     if _lib is not None:
         return _lib
+    _torch_runtime_first()
     if not os.path.exists(_build.LIB):
         if not build_if_missing:
             raise RuntimeError("libpbsim3_amd.so is not built (python -m pbsim3_amd.build)")
