@@ -169,3 +169,32 @@ def test_full_size_record_is_invariant_under_batching():
     assert 15_000_000_000 <= total < 15_000_000_000 + 1_000_000 and 1_500_000 < n < 1_900_000
     sub, ins, dele = (results[0][k] / total for k in (4, 5, 6))
     assert 0.02 < sub + ins + dele < 0.2
+
+
+def test_two_contexts_alive_at_once(tmp_path):
+    """Two contexts in one process (different seeds and methods), used alternately record by record: each produces what it
+    produces alone.  Nothing in the library is process-global except the last-error string."""
+    import pbsim3_amd as P
+    from pbsim3_amd import args as A
+    SHORT = ["--length-mean", "1200", "--length-sd", "900"]
+    recs = A.read_fasta(os.path.join(harness.GOLDEN, "inputs", "quirk.fa"))[0]
+    a_args = harness.resolve(["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-ONT.model",
+                              "--genome", "INPUT:quirk.fa", "--depth", "4", "--seed", "31"] + SHORT)
+    b_args = harness.resolve(["--strategy", "wgs", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model",
+                              "--genome", "INPUT:quirk.fa", "--depth", "3", "--seed", "32", "--pass-num", "2"] + SHORT)
+    alone_a, _ = product.run_wgs(a_args)
+    alone_b, _ = product.run_wgs(b_args)
+    pa, _ = A.parse(a_args)
+    pb, _ = A.parse(b_args)
+    got_a, got_b = {}, {}
+    with P.Context(pa, 0) as ca, P.Context(pb, 0) as cb:
+        ca.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+        cb.load_qshmm(harness.model_path("QSHMM-RSII.model"))
+        for i, r in enumerate(recs, 1):
+            ca.set_reference(r, i)
+            cb.set_reference(r, i)
+            rt_b, mt_b = cb.simulate_wgs()
+            rt_a, mt_a = ca.simulate_wgs()
+            got_a["_%04d.fq" % i], got_a["_%04d.maf" % i] = rt_a, mt_a
+            got_b["_%04d.sam" % i], got_b["_%04d.maf" % i] = cb.sam_header() + rt_b, mt_b
+    assert got_a == alone_a and got_b == alone_b
