@@ -1727,19 +1727,61 @@ int pbsim_simulate_trans(pbsim_ctx *c, const pbsim_sink *sink) {
   if (c->p.strategy == PBSIM_STRATEGY_WGS) return fail("pbsim_simulate_trans: strategy is wgs");
   if (!c->d_seq || c->n_units < 1) return fail("no transcripts/templates set");
   pbsim_reset_stats(c);
-  int64_t next_read = 1, cap = batch_capacity(c);
-  while (next_read <= c->trans_reads) {
-    const int64_t n = std::min(cap, c->trans_reads - next_read + 1);
-    if (!pbsim_batch_walk(c, next_read, n, -1, nullptr)) {
-      if (g_err.rfind("scratch budget exceeded", 0) == 0 && n > 1) {
-        cap = std::max<int64_t>(1, n / 2);
-        continue;
+  // No quota here: every read is final, so the batches simply pipeline over the slots (the walk of one beside the text
+  // emission of the other).  At least ~four batches, so that there is something to overlap.
+  const int n_slots = std::max(1, std::min(kMaxSlots, c->pipeline_depth));
+  const int64_t R = c->trans_reads;
+  int64_t cap = batch_capacity(c);
+  struct Pending {
+    int slot;
+    int64_t first, n;
+  };
+  std::vector<Pending> fifo;
+  auto drop_pending = [&]() {
+    for (const Pending &pd : fifo) {
+      c->cur = pd.slot;
+      (void)hipStreamSynchronize(c->s().stream);
+      c->s().b_enqueued = false;
+    }
+    fifo.clear();
+    c->cur = 0;
+  };
+  int64_t next_begin = 1, next_read = 1;
+  int next_slot = 0;
+  while (next_read <= R) {
+    while ((int)fifo.size() < n_slots && next_begin <= R) {
+      const int64_t part = std::max<int64_t>(65536, (R + 2 * n_slots - 1) / (2 * n_slots));
+      const int64_t n = std::min(std::min(cap, part), R - next_begin + 1);
+      c->cur = next_slot;
+      if (!pbsim_batch_walk_begin(c, next_begin, n, -1)) {
+        drop_pending();
+        return PBSIM_FAILED;
       }
-      return PBSIM_FAILED;
+      fifo.push_back(Pending{next_slot, next_begin, n});
+      next_slot = (next_slot + 1) % n_slots;
+      next_begin += n;
+    }
+    const Pending pd = fifo.front();
+    fifo.erase(fifo.begin());
+    c->cur = pd.slot;
+    if (!pbsim_batch_walk_end(c, nullptr)) {
+      const bool budget = g_err.rfind("scratch budget exceeded", 0) == 0 && pd.n > 1;
+      const std::string keep = g_err;
+      drop_pending();
+      if (!budget) {
+        g_err = keep;
+        return PBSIM_FAILED;
+      }
+      cap = std::max<int64_t>(1, pd.n / 2);  // retry from this batch with smaller ones
+      next_begin = pd.first;
+      next_slot = 0;
+      continue;
     }
     pbsim_batch_info bi;
-    if (!pbsim_batch_finalize(c, 0, &bi)) return PBSIM_FAILED;
-    if (!deliver(c, sink)) return PBSIM_FAILED;
+    if (!pbsim_batch_finalize(c, 0, &bi) || !deliver(c, sink)) {
+      drop_pending();
+      return PBSIM_FAILED;
+    }
     next_read += bi.n_final;
   }
   return PBSIM_SUCCEEDED;
