@@ -1728,7 +1728,7 @@ int pbsim_simulate_trans(pbsim_ctx *c, const pbsim_sink *sink) {
   if (!c->d_seq || c->n_units < 1) return fail("no transcripts/templates set");
   pbsim_reset_stats(c);
   // No quota here: every read is final, so the batches simply pipeline over the slots (the walk of one beside the text
-  // emission of the other).  At least ~four batches, so that there is something to overlap.
+  // emission of the other): one batch per slot when everything fits (small batches waste the GPU on their tails).
   const int n_slots = std::max(1, std::min(kMaxSlots, c->pipeline_depth));
   const int64_t R = c->trans_reads;
   int64_t cap = batch_capacity(c);
@@ -1750,7 +1750,7 @@ int pbsim_simulate_trans(pbsim_ctx *c, const pbsim_sink *sink) {
   int next_slot = 0;
   while (next_read <= R) {
     while ((int)fifo.size() < n_slots && next_begin <= R) {
-      const int64_t part = std::max<int64_t>(65536, (R + 2 * n_slots - 1) / (2 * n_slots));
+      const int64_t part = std::max<int64_t>(65536, (R + n_slots - 1) / n_slots);
       const int64_t n = std::min(std::min(cap, part), R - next_begin + 1);
       c->cur = next_slot;
       if (!pbsim_batch_walk_begin(c, next_begin, n, -1)) {
