@@ -377,8 +377,13 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   for (Slot &sl : c->slots) {
-    if (hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
-        hipStreamCreateWithPriority(&sl.walk_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
+    if (hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio_greatest) != hipSuccess)
+      sl.stream = nullptr;
+    if (hipStreamCreateWithPriority(&sl.walk_stream, hipStreamNonBlocking, prio_least) != hipSuccess)
+      sl.walk_stream = nullptr;
+    // no priorities on this runtime: plain streams still give the right answers, only the overlap is worse
+    if ((!sl.stream && hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) ||
+        (!sl.walk_stream && hipStreamCreateWithFlags(&sl.walk_stream, hipStreamNonBlocking) != hipSuccess)) {
       fail("cannot create a HIP stream");
       return nullptr;
     }
