@@ -1498,7 +1498,7 @@ __global__ __launch_bounds__(256) void k_text_headers(TextArgs a) {
 //   pass 2  QSHMM quality row, squeezed the same way -> quality line
 // Constant fills ('!' qualities, SAM ",9" tags, BAM ip array) are k_text_fill's.
 constexpr int kTileStride = 69;  // dwords per task row in LDS: [16 carry bytes | 256 tile bytes] + 1 (5 mod 64: conflict-free turn)
-constexpr int kOutStride = 73;   // squeezed row: [<= 15 pending bytes | <= 256 kept bytes], 16-byte chunks
+constexpr int kOutStride = 76;   // squeezed row: [<= 15 pending bytes | <= 256 kept bytes] + the dword an OR may spill into; 16-byte aligned
 
 // zero bytes (deleted columns) of a MAF read row print as '-'
 __device__ __forceinline__ uint32_t dash_zero_bytes(uint32_t w) { return w | ((eq_bytes(w, 0u) >> 7) * 0x2Du); }
@@ -1542,25 +1542,38 @@ __device__ __forceinline__ void write_maf_tile(char *text, long long D, int m, i
     const uint32_t *src = row + (b >> 2);
     const uint32_t sh = (uint32_t)(b & 3);
     const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4];
-    uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
-             w2 = __builtin_amdgcn_alignbyte(d3, d2, sh), w3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-    long long dst;
-    if (minus) {
-      const uint32_t r0 = complement4(__builtin_bswap32(w3)), r1 = complement4(__builtin_bswap32(w2)),
-                     r2 = complement4(__builtin_bswap32(w1)), r3 = complement4(__builtin_bswap32(w0));
-      w0 = r0;
-      w1 = r1;
-      w2 = r2;
-      w3 = r3;
-      dst = D + m - cons - 16 * sub - 16;
-    } else {
-      dst = D + cons + 16 * sub;
-    }
-    if (dash_zero) {
-      w0 = dash_zero_bytes(w0);
-      w1 = dash_zero_bytes(w1);
-      w2 = dash_zero_bytes(w2);
-      w3 = dash_zero_bytes(w3);
+    const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                   a2 = __builtin_amdgcn_alignbyte(d3, d2, sh), a3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    // the line's bytes in destination order: '-' strand = descending columns
+    const uint32_t rev = minus ? 0x00010203u : 0x03020100u;
+    const uint32_t x0 = __builtin_amdgcn_perm(0u, minus ? a3 : a0, rev), x1 = __builtin_amdgcn_perm(0u, minus ? a2 : a1, rev),
+                   x2 = __builtin_amdgcn_perm(0u, minus ? a1 : a2, rev), x3 = __builtin_amdgcn_perm(0u, minus ? a0 : a3, rev);
+    const long long dst = minus ? D + m - cons - 16 * sub - 16 : D + cons + 16 * sub;
+    // Byte map (complement on the '-' strand, 0 -> '-' on the read line) as ONE v_perm_b32 per dword: the low three bits
+    // of the bytes a row normally holds are distinct (0 -> 0, 'A' -> 1, 'C' -> 3, 'T' -> 4, '-' -> 5, 'N' -> 6, 'G' -> 7), so
+    // they select from an 8-byte table.  Mapping the result back through the inverse table returns the input exactly for
+    // the bytes of that set and never for any other byte (IUPAC codes of the reference): those chunks take the SWAR path.
+    const uint32_t f_lo = (minus ? 0x47025400u : 0x43024100u) | (dash_zero ? 0x2Du : 0u);  // [0] [1] [2] [3]
+    const uint32_t f_hi = minus ? 0x434E2D41u : 0x474E2D54u;                              // [4] [5] [6] [7]
+    const uint32_t b_lo = minus ? 0x47025400u : 0x43024100u;
+    const uint32_t b_hi = (minus ? 0x434E0041u : 0x474E0054u) | (dash_zero ? 0u : 0x2D00u);
+    uint32_t w0 = __builtin_amdgcn_perm(f_hi, f_lo, x0 & 0x07070707u), w1 = __builtin_amdgcn_perm(f_hi, f_lo, x1 & 0x07070707u),
+             w2 = __builtin_amdgcn_perm(f_hi, f_lo, x2 & 0x07070707u), w3 = __builtin_amdgcn_perm(f_hi, f_lo, x3 & 0x07070707u);
+    const uint32_t bad = (__builtin_amdgcn_perm(b_hi, b_lo, w0 & 0x07070707u) ^ x0) |
+                         (__builtin_amdgcn_perm(b_hi, b_lo, w1 & 0x07070707u) ^ x1) |
+                         (__builtin_amdgcn_perm(b_hi, b_lo, w2 & 0x07070707u) ^ x2) |
+                         (__builtin_amdgcn_perm(b_hi, b_lo, w3 & 0x07070707u) ^ x3);
+    if (__builtin_expect(bad != 0, 0)) {
+      w0 = minus ? complement4(x0) : x0;
+      w1 = minus ? complement4(x1) : x1;
+      w2 = minus ? complement4(x2) : x2;
+      w3 = minus ? complement4(x3) : x3;
+      if (dash_zero) {
+        w0 = dash_zero_bytes(w0);
+        w1 = dash_zero_bytes(w1);
+        w2 = dash_zero_bytes(w2);
+        w3 = dash_zero_bytes(w3);
+      }
     }
     *reinterpret_cast<uint4 *>(text + dst) = make_uint4(w0, w1, w2, w3);
   }
@@ -1577,7 +1590,8 @@ __device__ __forceinline__ void write_maf_tile(char *text, long long D, int m, i
 
 __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags *flags) {
   __shared__ uint32_t s_tile[64 * kTileStride + 4];  // + the dwords an aligned alignbyte of the last row reads past it
-  __shared__ uint32_t s_out[16 * kOutStride];        // one squeezed row per (wave, group)
+  __shared__ __attribute__((aligned(16))) uint32_t s_out[16 * kOutStride];  // one squeezed row per (wave, group)
+  __shared__ uint32_t s_sel[16];                     // v_perm selectors that move the kept bytes of a dword to its low end
   __shared__ uint32_t s_pend[64 * 4];                // squeezed bytes of a task that do not fill a 16-byte chunk yet
   __shared__ int s_q[64], s_m[64], s_task[64], s_done[64];
   __shared__ int s_minus[64];
@@ -1605,6 +1619,15 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     s_minus[tid] = minus;
   }
   s_pend[tid] = 0;
+  if (tid < 16) {
+    uint32_t sel = 0x0c0c0c0cu, n = 0;  // 0x0c selects a zero byte
+    for (uint32_t b = 0; b < 4; b++)
+      if ((tid >> b) & 1) {
+        sel = (sel & ~(0xffu << (8 * n))) | (b << (8 * n));
+        n++;
+      }
+    s_sel[tid] = sel;
+  }
   __syncthreads();
   // extent of this wave's 16 tasks
   int mmax = 0;
@@ -1674,15 +1697,22 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
       const int cnt = __popc(keep);
       const int incl = row16_scan(cnt);
       const int total = __shfl(incl, (lane & 48) | 15, 64);
+      // the out row: pending bytes in front, zeros behind; every lane ORs its kept bytes in, one dword of <= 4 at a time
+      // (compacted by a v_perm_b32, shifted to its byte offset: two ds_or_b32, the second one usually of zero)
+      reinterpret_cast<uint4 *>(outb)[1 + sub] = make_uint4(0u, 0u, 0u, 0u);
+      if (sub < 2) reinterpret_cast<uint4 *>(outb)[17 + sub] = make_uint4(0u, 0u, 0u, 0u);
       if (sub < 4) outb[sub] = s_pend[j * 4 + sub];
       wave_lds_sync();
       {
-        int o = p + incl - cnt;
+        const int o = p + incl - cnt;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-          for (int b = 0; b < 4; b++)
-            if ((keep >> (4 * k + b)) & 1u) orow[o++] = (uint8_t)(w[k] >> (8 * b));
+        for (int k = 0; k < 4; k++) {
+          const uint32_t v = __builtin_amdgcn_perm(0u, w[k], s_sel[(keep >> (4 * k)) & 15u]);
+          const int off = o + __popc(keep & ((1u << (4 * k)) - 1u));
+          const unsigned long long sv = (unsigned long long)v << (8 * (off & 3));
+          atomicOr(&outb[off >> 2], (uint32_t)sv);
+          atomicOr(&outb[(off >> 2) + 1], (uint32_t)(sv >> 32));
+        }
       }
       wave_lds_sync();
       const int have = p + total;              // row bytes: [0, p) belong to earlier windows (or to the text in front)
@@ -1702,7 +1732,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
             }
           }
         } else {
-          reinterpret_cast<uint4 *>(dst)[sub] = make_uint4(src[0], src[1], src[2], src[3]);
+          reinterpret_cast<uint4 *>(dst)[sub] = reinterpret_cast<const uint4 *>(outb)[sub];
         }
       }
       const int rem = have & 15;
