@@ -31,6 +31,26 @@ constexpr uint32_t kATGC = 0x43475441u;  // "ATGC" little-endian (mut.ins_nt / s
 
 __device__ __forceinline__ uint32_t to_upper(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
 
+// The per-column scratch rows are written once by a walk and read once by the text emission: streaming (nontemporal)
+// accesses keep them from evicting the reference lines the walk's gathers re-use from L2.
+#ifndef PBSIM_NT
+#define PBSIM_NT 1
+#endif
+__device__ __forceinline__ void scratch_store(uint32_t *p, uint32_t v) {
+#if PBSIM_NT & 1
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ uint32_t scratch_load(const uint32_t *p) {
+#if PBSIM_NT & 2
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 // revcomp()'s base map (pbsim.cpp:5853-5863): A<->T, G<->C, everything else unchanged
 __device__ __forceinline__ uint32_t complement(uint32_t c) {
   uint32_t r = c;
@@ -771,8 +791,8 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
       act = act && (ro < L) && (m < cap);
     }
     if (valid && m > group * 4) {
-      maf_read[(size_t)group * 64] = acc_r;
-      maf_ref[(size_t)group * 64] = acc_f;
+      scratch_store(&maf_read[(size_t)group * 64], acc_r);
+      scratch_store(&maf_ref[(size_t)group * 64], acc_f);
     }
     cur.refill(act);
     acc_r = 0;
@@ -934,9 +954,9 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
       act = act && (ro < L) && (m < cap);
     }
     if (valid && m > group * 4) {
-      maf_read[(size_t)group * 64] = acc_r;
-      maf_ref[(size_t)group * 64] = acc_f;
-      qual_row[(size_t)group * 64] = acc_q;
+      scratch_store(&maf_read[(size_t)group * 64], acc_r);
+      scratch_store(&maf_ref[(size_t)group * 64], acc_f);
+      scratch_store(&qual_row[(size_t)group * 64], acc_q);
     }
     cur.refill(act);
     acc_r = 0;
@@ -1084,9 +1104,9 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
         act = act && (ro < L) && (q < L) && (m < cap);
       }
       if (valid && m > group * 4) {
-        maf_read[(size_t)group * 64] = acc_r;
-        maf_ref[(size_t)group * 64] = acc_f;
-        qual_row[(size_t)group * 64] = acc_q;
+        scratch_store(&maf_read[(size_t)group * 64], acc_r);
+        scratch_store(&maf_ref[(size_t)group * 64], acc_f);
+        scratch_store(&qual_row[(size_t)group * 64], acc_q);
       }
       cur.refill(act);
       acc_r = 0;
@@ -1660,7 +1680,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     for (int c = 0; c < 16; ++c) {  // lane (lt, lc) loads dword c + 16 lc of task lt: banks 5 lt + c + 16 lc, all different
       const int col = c + 16 * lc;
       const int cc = c0 + col;
-      tile[lt * kTileStride + 4 + col] = (cc < cap_dw) ? region[(size_t)cc * 64 + wv * 16 + lt] : 0u;
+      tile[lt * kTileStride + 4 + col] = (cc < cap_dw) ? scratch_load(&region[(size_t)cc * 64 + wv * 16 + lt]) : 0u;
     }
     wave_lds_sync();
 #pragma unroll 1
