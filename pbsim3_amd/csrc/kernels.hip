@@ -1615,6 +1615,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   __shared__ uint32_t s_pend[64 * 4];                // squeezed bytes of a task that do not fill a 16-byte chunk yet
   __shared__ int s_q[64], s_m[64], s_task[64], s_done[64];
   __shared__ int s_minus[64];
+  __shared__ long long s_dmaf[64], s_dsq[64];       // destination offsets of the task's MAF line / squeezed line
   const int64_t wave = blockIdx.x;
   const int pass = blockIdx.y;
   if (wave * 64 >= flags->total_slots) return;
@@ -1622,6 +1623,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   if (tid < 64) {
     const int task = a.task_of_slot[wave * 64 + tid];
     int q = 0, m = 0, minus = 0, tk = -1;
+    long long dmaf = 0, dsq = 0;
     if (task >= 0) {
       const int64_t r = task / a.pass_num;
       if (r < a.n_reads) {
@@ -1630,6 +1632,10 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
         m = a.maf_len[task];
         q = a.out_len[task];
         tk = task;
+        const int64_t *rd = a.row_dst + (int64_t)task * 6;
+        dmaf = rd[(pass == 1) ? 2 : 3];
+        // BAM: the bases are parked as ASCII in the pw array (k_bam_finish packs them to 4 bits)
+        dsq = rd[(pass == 0) ? (a.bam ? 5 : 0) : 1];
       }
     }
     s_q[tid] = q;
@@ -1637,6 +1643,8 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     s_task[tid] = tk;
     s_done[tid] = 0;
     s_minus[tid] = minus;
+    s_dmaf[tid] = dmaf;
+    s_dsq[tid] = dsq;
   }
   s_pend[tid] = 0;
   if (tid < 16) {
@@ -1671,38 +1679,43 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   uint32_t *outb = s_out + (wv * 4 + g) * kOutStride;
   uint8_t *orow = reinterpret_cast<uint8_t *>(outb);
 
+  // lane (lt, lc) loads dword c + 16 lc of task lt (LDS banks 5 lt + c + 16 lc: all different); the loads of the NEXT
+  // tile are issued before this tile is served, so their latency hides behind the four serving steps
+  uint32_t pre[16];
+  const uint32_t *lane_src = region + wv * 16 + lt + (size_t)(16 * lc) * 64;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) pre[c] = (c + 16 * lc < cap_dw) ? scratch_load(lane_src + (size_t)c * 64) : 0u;
   for (int s0 = 0, t = 0; s0 < mmax; s0 += 256, ++t) {
-    const int c0 = s0 >> 2;
     // carry: the previous tile's last 16 bytes move in front (lane = task row x dword)
     if (t > 0) tile[lt * kTileStride + lc] = tile[lt * kTileStride + 64 + lc];
     wave_lds_sync();
-#pragma unroll 4
-    for (int c = 0; c < 16; ++c) {  // lane (lt, lc) loads dword c + 16 lc of task lt: banks 5 lt + c + 16 lc, all different
-      const int col = c + 16 * lc;
-      const int cc = c0 + col;
-      tile[lt * kTileStride + 4 + col] = (cc < cap_dw) ? scratch_load(&region[(size_t)cc * 64 + wv * 16 + lt]) : 0u;
-    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) tile[lt * kTileStride + 4 + c + 16 * lc] = pre[c];
     wave_lds_sync();
+    if (s0 + 256 < mmax) {
+      const int c1 = (s0 + 256) >> 2;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        pre[c] = (c1 + c + 16 * lc < cap_dw) ? scratch_load(lane_src + (size_t)(c1 + c) * 64) : 0u;
+    }
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {
       const int i = it * 4 + g, j = wv * 16 + i;
       const int task = s_task[j];
       const int m = s_m[j], minus = s_minus[j];
       const bool act = task >= 0 && s0 < m;
-      const int64_t *rd = a.row_dst + (int64_t)(act ? task : 0) * 6;
       const uint32_t *trow = tile + i * kTileStride;
       if (pass == 1) {
-        if (act) write_maf_tile(a.maf_text, rd[2], m, t, trow, minus, false, sub);
+        if (act) write_maf_tile(a.maf_text, s_dmaf[j], m, t, trow, minus, false, sub);
         continue;
       }
-      if (pass == 0 && act) write_maf_tile(a.maf_text, rd[3], m, t, trow, minus, true, sub);
+      if (pass == 0 && act) write_maf_tile(a.maf_text, s_dmaf[j], m, t, trow, minus, true, sub);
       // ---- squeeze the columns that carry a read base (non-zero byte): lane `sub` holds columns 16 sub .. 16 sub + 15
       // of the window; its output offset is the count of kept bytes in the lower lanes of its row of 16 (DPP scan).
       // The out row starts with the task's pending bytes, so that it is destination-chunk aligned.
       const int ncol = act ? ((m - s0 < 256) ? m - s0 : 256) : 0;
       const int dn = s_done[j];
-      // BAM: the bases are parked as ASCII in the pw array (k_bam_finish packs them to 4 bits)
-      const long long D = act ? rd[(pass == 0) ? (a.bam ? 5 : 0) : 1] : 0;
+      const long long D = s_dsq[j];
       const int p = (int)((D + dn) & 15);  // bytes of the destination chunk in front of this window's first byte
       uint32_t w[4];
       uint32_t keep = 0;
