@@ -148,7 +148,8 @@ struct pbsim_ctx {
 
   DevBuf d_prob2len, d_prob2acc, d_cls, d_qs_tabs;
   // reference
-  DevBuf d_seq_own, d_hp, d_hp11, d_tiles, d_ref_flags;
+  DevBuf d_seq_own, d_hp, d_tiles, d_ref_flags;
+  bool seq_hp_flag = false;  // bit 7 of the prepared sequence bytes carries hp == 11 (k_hp_final)
   const uint8_t *d_seq = nullptr;
   int64_t ref_len = 0;
   int64_t unit = 0;
@@ -246,20 +247,19 @@ int read_flags(pbsim_ctx *c, DeviceFlags *f) {
 int prepare_reference(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int keep_first_case, int64_t census_out[kHpSlots]) {
   const int64_t n_tiles = (len + kHpTile - 1) / kHpTile;
   HIP_OK(c->d_hp.ensure((size_t)len + 64));
-  HIP_OK(c->d_hp11.ensure((size_t)len / 8 + 64));
-  HIP_OK(hipMemsetAsync(c->d_hp11.p, 0, (size_t)len / 8 + 64, c->stream));
   HIP_OK(c->d_tiles.ensure((size_t)(n_tiles + 1) * 4 * sizeof(int64_t)));
   HIP_OK(c->d_ref_flags.ensure(sizeof(DeviceFlags)));
   HIP_OK(hipMemsetAsync(c->d_ref_flags.p, 0, sizeof(DeviceFlags), c->stream));
   HIP_OK(hipMemsetAsync(c->d_hp.as<uint8_t>() + len, 0, 64, c->stream));
   int64_t *t = c->d_tiles.as<int64_t>();
-  launch_prepare_reference(d_seq, c->d_hp.as<uint8_t>(), c->d_hp11.as<uint16_t>(), len, t, t + (n_tiles + 1), t + 2 * (n_tiles + 1),
+  launch_prepare_reference(d_seq, c->d_hp.as<uint8_t>(), c->p.hp_del_bias == 1, len, t, t + (n_tiles + 1), t + 2 * (n_tiles + 1),
                            t + 3 * (n_tiles + 1), keep_first_case, c->d_ref_flags.as<DeviceFlags>(), c->stream);
   HIP_OK(hipGetLastError());
   DeviceFlags f;
   HIP_OK(hipMemcpyAsync(&f, c->d_ref_flags.p, sizeof f, hipMemcpyDeviceToHost, c->stream));
   HIP_OK(hipStreamSynchronize(c->stream));
   for (int i = 0; i < kHpSlots; i++) census_out[i] += (int64_t)f.hpfreq[i];
+  c->seq_hp_flag = c->p.hp_del_bias == 1 && !f.high_bytes;
   return PBSIM_SUCCEEDED;
 }
 
@@ -663,7 +663,6 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   w.ncls = ncls;
   w.ref.seq = c->d_seq;
   w.ref.hp = c->d_hp.as<uint8_t>();
-  w.hp11 = c->d_hp11.as<uint16_t>();
   w.ref.len = c->ref_len;
   w.len = h.len;
   w.off = h.off;
@@ -696,7 +695,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
     w.emis_off = c->ect.emis_off;
     w.init_off = c->ect.init_off;
     w.tran_off = c->ect.tran_off;
-    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->p.hp_del_bias == 1, ws);
+    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->seq_hp_flag, ws);
   } else {
     w.stride = c->qct.stride;
     w.rv_off = c->qct.rv_off;
@@ -710,7 +709,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
     w.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     w.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
     launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8, c->qct.all_rv_100,
-                      c->p.hp_del_bias == 1, ws);
+                      c->seq_hp_flag, ws);
   }
   HIP_OK(hipEventRecord(c->s().ev2, ws));
   HIP_OK(hipStreamWaitEvent(c->s().stream, c->s().ev2, 0));
@@ -1660,7 +1659,6 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
       a.ref.seq = c->d_seq;
       a.ref.hp = c->d_hp.as<uint8_t>();
       a.ref.len = G;
-      a.hp11 = c->d_hp11.as<uint16_t>();
       a.quals = c->d_sq.as<uint8_t>();
       a.line_qoff = c->d_sq_line_qoff.as<int64_t>();
       a.line_len = c->d_sq_line_len.as<int32_t>();
@@ -1683,7 +1681,7 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
       a.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
       a.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
       a.flags = flags;
-      launch_walk_sample(a, c->p.hp_del_bias == 1, sl.stream);
+      launch_walk_sample(a, c->seq_hp_flag, sl.stream);
       launch_gather_pass0_scan(a.out_len, n_tasks, 1, sl.d_cum.as<int64_t>(), sl.d_scan_tmp.as<int64_t>(),
                                &flags->sums[0], sl.stream);
       HIP_OK(hipGetLastError());

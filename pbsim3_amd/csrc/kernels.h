@@ -23,7 +23,7 @@ enum : uint32_t {
 
 struct DeviceFlags {
   uint32_t error;
-  uint32_t pad;
+  uint32_t high_bytes;    // k_hp_breaks: the unit holds bytes >= 0x80 (no room for the hp == 11 flag in bit 7)
   int64_t n_final;        // quota cut (reads)
   int64_t total_slots;    // slots after class alignment
   int64_t scratch_need;   // bytes the batch needs
@@ -33,7 +33,7 @@ struct DeviceFlags {
 };
 
 struct RefView {
-  const uint8_t *seq;  // upper-cased, padded to a multiple of 16 bytes
+  const uint8_t *seq;  // upper-cased, padded to a multiple of 16 bytes; bit 7 = hp == 11 when the unit was prepared with flag_hp11
   const uint8_t *hp;   // homopolymer length per base, 1..11
   int64_t len;
 };
@@ -90,7 +90,6 @@ struct WalkArgs {
   int32_t pass_num;
   int32_t ncls;
   RefView ref;
-  const uint16_t *hp11;      // 1 bit per base: hp == 11
   const int32_t *len, *off;
   const int64_t *read_base;  // trans: offset of the read's unit inside the concatenated reference (NULL: 0)
   const uint8_t *read_minus; // trans: strand per read (NULL: wgs parity rule)
@@ -118,7 +117,6 @@ struct SampleArgs {
   int32_t n_lines;            // strings in this chunk
   int32_t n_line_waves;       // ceil(n_lines / 64)
   RefView ref;
-  const uint16_t *hp11;
   const uint8_t *quals;       // filtered quality strings, each padded to a multiple of 8 bytes
   const int64_t *line_qoff;   // [n_lines] byte offset of the string
   const int32_t *line_len;    // [n_lines]
@@ -169,7 +167,7 @@ struct TextArgs {
 };
 
 // ---- launches (all asynchronous on `s`) ------------------------------------
-void launch_prepare_reference(uint8_t *seq, uint8_t *hp, uint16_t *hp11, int64_t len, int64_t *tile_first, int64_t *tile_last,
+void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int flag_hp11, int64_t len, int64_t *tile_first, int64_t *tile_last,
                               int64_t *carry_start, int64_t *carry_next, int keep_first_case, DeviceFlags *flags,
                               hipStream_t s);
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s);

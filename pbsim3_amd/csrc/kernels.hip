@@ -122,14 +122,15 @@ __device__ __forceinline__ int put_dec(char *dst, int64_t v) {
 // ---------------------------------------------------------------------------
 // K0: upper-case + homopolymer length.  A "break" at i starts a new run.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ref_char(const uint8_t *seq, int64_t i, int keep_first_case) {
-  const uint32_t c = seq[i];
+// `strip` = 0x7f once bit 7 of a byte may already carry another tile's hp == 11 flag (k_hp_final), else 0xff
+__device__ __forceinline__ uint32_t ref_char(const uint8_t *seq, int64_t i, int keep_first_case, uint32_t strip = 0xffu) {
+  const uint32_t c = seq[i] & strip;
   if (keep_first_case && (i == 0 || seq[i - 1] == '\n')) return c;
   return to_upper(c);
 }
 
 __global__ __launch_bounds__(256) void k_hp_breaks(const uint8_t *seq, int64_t len, int keep_first_case,
-                                                     int64_t *tile_first, int64_t *tile_last) {
+                                                     int64_t *tile_first, int64_t *tile_last, DeviceFlags *flags) {
   __shared__ long long s_first, s_last;
   if (threadIdx.x == 0) {
     s_first = 0x7fffffffffffffffLL;
@@ -138,12 +139,14 @@ __global__ __launch_bounds__(256) void k_hp_breaks(const uint8_t *seq, int64_t l
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kHpTile + (int64_t)threadIdx.x * 16;
   long long first = 0x7fffffffffffffffLL, last = -1;
+  uint32_t high = 0;
   if (base < len) {
     uint32_t prev = (base > 0) ? ref_char(seq, base - 1, keep_first_case) : 0x100u;
     for (int k = 0; k < 16; k++) {
       const int64_t i = base + k;
       if (i >= len) break;
       const uint32_t c = ref_char(seq, i, keep_first_case);
+      high |= c;
       if (c != prev) {
         if (first > i) first = i;
         last = i;
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(256) void k_hp_breaks(const uint8_t *seq, int64_t l
       prev = c;
     }
   }
+  if (high & 0x80u) flags->high_bytes = 1;  // non-ASCII input: bit 7 cannot carry the hp == 11 flag
   if (last >= 0) {
     atomicMin(&s_first, first);
     atomicMax(&s_last, last);
@@ -216,7 +220,10 @@ __global__ __launch_bounds__(1024) void k_hp_carry(const int64_t *tile_first, co
   }
 }
 
-__global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, uint16_t *hp11, int64_t len,
+// flag_hp11: --hp-del-bias 1 (default), where the deletion threshold depends on hp only through hp == 11 (Q1): the
+// flag goes into bit 7 of the sequence byte itself (unless the input holds non-ASCII bytes), so that the walks need
+// no second gather for it.  Other tiles rewrite their bytes concurrently: neighbours are read with the bit stripped.
+__global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int flag_hp11, int64_t len,
                                                     int keep_first_case, const int64_t *carry_start,
                                                     const int64_t *carry_next, DeviceFlags *flags) {
   __shared__ long long s_last[256], s_first[256];
@@ -224,16 +231,18 @@ __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, uin
   const int tid = threadIdx.x;
   if (tid < 12) s_hist[tid] = 0;
   const int64_t base = (int64_t)blockIdx.x * kHpTile + (int64_t)tid * 16;
+  const bool flag = flag_hp11 && !flags->high_bytes;
+  const uint32_t strip = flag ? 0x7fu : 0xffu;
   uint32_t c[16];
   bool brk[16];
   long long first = 0x7fffffffffffffffLL, last = -1;
   int n = 0;
   if (base < len) {
-    uint32_t prev = (base > 0) ? ref_char(seq, base - 1, keep_first_case) : 0x100u;
+    uint32_t prev = (base > 0) ? ref_char(seq, base - 1, keep_first_case, strip) : 0x100u;
     for (int k = 0; k < 16; k++) {
       const int64_t i = base + k;
       if (i >= len) break;
-      c[k] = ref_char(seq, i, keep_first_case);
+      c[k] = ref_char(seq, i, keep_first_case, strip);
       brk[k] = (c[k] != prev);
       if (brk[k]) {
         if (first > i) first = i;
@@ -268,18 +277,15 @@ __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, uin
       next_start[k] = nxt;
       if (brk[k]) nxt = base + k;
     }
-    uint32_t bits11 = 0;
     for (int k = 0; k < n; k++) {
       const long long run = next_start[k] - start[k];
       // nnum++ ; if (nnum > 11) nnum = 10  (pbsim.cpp:1045-1048): 11,13,.. -> 11 ; 12,14,.. -> 10
       uint32_t v = (run <= 11) ? (uint32_t)run : ((run & 1) ? 11u : 10u);
       if (c[k] == 'N') v = 1;  // pbsim.cpp:1050-1054
       hp[base + k] = (uint8_t)v;
-      seq[base + k] = (uint8_t)c[k];
-      bits11 |= (v == 11u) ? (1u << k) : 0u;
+      seq[base + k] = (uint8_t)(c[k] | ((flag && v == 11u) ? 0x80u : 0u));
       if (c[k] != '\n') atomicAdd(&s_hist[v], 1u);
     }
-    hp11[base >> 4] = (uint16_t)bits11;  // one bit per base: hp == 11 (the only class the default bias treats apart, Q1)
   }
   __syncthreads();
   if (tid < 12 && s_hist[tid]) atomicAdd(&flags->hpfreq[tid], (unsigned long long)s_hist[tid]);
@@ -533,56 +539,49 @@ __device__ __forceinline__ void walk_priority(int lmax_wave, int mean_len) {
 // cursor plus the next 8 in walking direction, fetched a group ahead so a lone
 // long read never waits on HBM.  8-byte loads because every L2->fabric request
 // moves a 64-byte sector whatever the load width (dword loads cost 16x their
-// bytes and starved the kernel).  The homopolymer window is either the hp byte
-// array (same shape) or, with kHpBits (default --hp-del-bias 1: the thresholds
-// depend on hp only through hp == 11, Q1), 32 bases of the hp==11 bit mask.
+// bytes and starved the kernel).  The homopolymer class comes from the hp byte
+// array (a second window of the same shape) or, with kHpBits (default
+// --hp-del-bias 1: the thresholds depend on hp only through hp == 11, Q1), from
+// bit 7 of the sequence byte itself (k_hp_final put it there): no second gather.
 // A cursor moves by at most 4 bases per 4-column group, hence crosses at most
 // one window boundary per group; refill() runs once per group.
 // ---------------------------------------------------------------------------
 template <bool kHpBits>
 struct RefCursor {
   const uint64_t *lane_seq, *lane_hp;
-  const uint32_t *lane_bits;
   int64_t p_first;
-  uint32_t pl0, cur_wl, cur_bl;
-  int wstep, rel, brel;
+  uint32_t pl0, cur_wl;
+  int wstep, rel;
   uint64_t wseq, whp, nseq, nhp;
-  uint32_t wbits, nbits;
-  bool minus, need_next, need_nbits;
+  bool minus, need_next;
 
   __device__ __forceinline__ void init(const WalkArgs &a, int64_t off, int L, bool minus_, bool act) {
-    init(a.ref, a.hp11, off, L, minus_, act);
+    init(a.ref, off, L, minus_, act);
   }
-  __device__ __forceinline__ void init(const RefView &ref, const uint16_t *hp11, int64_t off, int L, bool minus_, bool act) {
+  __device__ __forceinline__ void init(const RefView &ref, int64_t off, int L, bool minus_, bool act) {
     minus = minus_;
     p_first = minus ? (off + L - 1) : off;
     pl0 = (uint32_t)p_first;  // low bits are all the cursor arithmetic needs
     wstep = minus ? -1 : 1;
     lane_seq = reinterpret_cast<const uint64_t *>(ref.seq) + (p_first >> 3);
     lane_hp = reinterpret_cast<const uint64_t *>(ref.hp) + (p_first >> 3);
-    lane_bits = reinterpret_cast<const uint32_t *>(hp11) + (p_first >> 5);
-    rel = brel = 0;
+    rel = 0;
     cur_wl = pl0 >> 3;
-    cur_bl = pl0 >> 5;
     wseq = whp = nseq = nhp = 0;
-    wbits = nbits = 0;
-    need_next = need_nbits = false;
+    need_next = false;
     if (act) {
       wseq = lane_seq[0];
       const int nrel = ((p_first >> 3) + wstep < 0) ? 0 : wstep;
       nseq = lane_seq[nrel];
-      if (kHpBits) {
-        wbits = lane_bits[0];
-        const int nb = ((p_first >> 5) + wstep < 0) ? 0 : wstep;
-        nbits = lane_bits[nb];
-      } else {
+      if (!kHpBits) {
         whp = lane_hp[0];
         nhp = lane_hp[nrel];
       }
     }
   }
 
-  // raw reference byte (forward strand, not complemented) and homopolymer class at read offset ro
+  // raw reference byte (forward strand, not complemented; with kHpBits bit 7 is the hp == 11 flag, which the s_comp
+  // table drops) and homopolymer class at read offset ro
   __device__ __forceinline__ void at(int ro, bool act, uint32_t *raw, uint32_t *hp) {
     const uint32_t pl = minus ? (pl0 - (uint32_t)ro) : (pl0 + (uint32_t)ro);
     const bool cross = act && ((pl >> 3) != cur_wl);
@@ -593,11 +592,7 @@ struct RefCursor {
     const uint32_t sel = (pl & 7u) | 0x0c0c0c00u;
     *raw = __builtin_amdgcn_perm((uint32_t)(wseq >> 32), (uint32_t)wseq, sel);
     if (kHpBits) {
-      const bool bcross = act && ((pl >> 5) != cur_bl);
-      wbits = bcross ? nbits : wbits;
-      cur_bl = bcross ? (pl >> 5) : cur_bl;
-      need_nbits = need_nbits || bcross;
-      *hp = ((wbits >> (pl & 31u)) & 1u) ? 11u : 1u;
+      *hp = (*raw & 0x80u) ? 11u : 1u;
     } else {
       whp = cross ? nhp : whp;
       *hp = __builtin_amdgcn_perm((uint32_t)(whp >> 32), (uint32_t)whp, sel);
@@ -607,17 +602,11 @@ struct RefCursor {
   __device__ __forceinline__ void refill(bool act) {
     // windows walked so far, from the cursor's current window index (kept per step) instead of per-step counters
     rel = (int)cur_wl - (int)(pl0 >> 3);
-    brel = (int)cur_bl - (int)(pl0 >> 5);
     if (need_next && act) {
       const int nrel = ((p_first >> 3) + rel + wstep < 0) ? rel : rel + wstep;
       nseq = lane_seq[nrel];
       if (!kHpBits) nhp = lane_hp[nrel];
       need_next = false;
-    }
-    if (kHpBits && need_nbits && act) {
-      const int nb = ((p_first >> 5) + brel + wstep < 0) ? brel : brel + wstep;
-      nbits = lane_bits[nb];
-      need_nbits = false;
     }
   }
 };
@@ -626,13 +615,14 @@ struct RefCursor {
 // s_comp[0..255] identity, [256..511] revcomp's base map; s_sub[c*4+k] = substitution k
 // of base c (pbsim.cpp:5481-5484), 0 for a non-ACGT base
 __device__ __forceinline__ void stage_class(const WalkArgs &a, int cls, uint8_t *lds, uint8_t *s_comp, uint8_t *s_sub,
-                                            int tid) {
+                                            int tid, bool hp_flag) {
   const uint4 *src = reinterpret_cast<const uint4 *>(a.cls_blob + (size_t)cls * a.stride);
   uint4 *dst = reinterpret_cast<uint4 *>(lds);
   for (uint32_t i = tid; i < a.stride / 16; i += kWG) dst[i] = src[i];
   const uint32_t c = (uint32_t)tid;
-  s_comp[c] = (uint8_t)c;
-  s_comp[256 + c] = (uint8_t)complement(c);
+  const uint32_t base = hp_flag ? (c & 0x7fu) : c;  // bit 7 of a sequence byte is the hp == 11 flag, not part of the base
+  s_comp[c] = (uint8_t)base;
+  s_comp[256 + c] = (uint8_t)complement(base);
   const uint32_t t = sub_table(c);
   s_sub[c * 4 + 0] = (uint8_t)(t & 0xffu);
   s_sub[c * 4 + 1] = (uint8_t)((t >> 8) & 0xffu);
@@ -677,7 +667,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   while (cls < a.ncls - 1 && slot0 >= a.class_start[cls + 1]) cls++;
   uint8_t *s_comp = lds + a.stride;
   uint8_t *s_sub = s_comp + 512;
-  stage_class(a, cls, lds, s_comp, s_sub, tid);
+  stage_class(a, cls, lds, s_comp, s_sub, tid, kHpBits);
   __syncthreads();
   const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
   const uint32_t init_rv = hdr[1], mode = hdr[2], rate_mag = hdr[3];
@@ -829,7 +819,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   // LDS: [class blob | s_comp 512 | s_sub 1024 | sub_thre 96 u32 | ins_thre 96 u32 | del_thr 94*12 u32 | qprob 94 f64]
   uint8_t *s_comp = lds + a.stride;
   uint8_t *s_sub = s_comp + 512;
-  stage_class(a, cls, lds, s_comp, s_sub, tid);
+  stage_class(a, cls, lds, s_comp, s_sub, tid, kHpBits);
   uint32_t *s_subt = reinterpret_cast<uint32_t *>(s_sub + 1024);
   uint32_t *s_ins = s_subt + 96;
   uint32_t *s_del = s_ins + 96;
@@ -998,8 +988,9 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
   const int tid = threadIdx.x;
   {
     const uint32_t c = (uint32_t)tid;
-    s_comp[c] = (uint8_t)c;
-    s_comp[256 + c] = (uint8_t)complement(c);
+    const uint32_t base = kHpBits ? (c & 0x7fu) : c;  // bit 7 of a sequence byte is the hp == 11 flag (RefCursor)
+    s_comp[c] = (uint8_t)base;
+    s_comp[256 + c] = (uint8_t)complement(base);
     const uint32_t t = sub_table(c);
     s_sub[c * 4 + 0] = (uint8_t)(t & 0xffu);
     s_sub[c * 4 + 1] = (uint8_t)((t >> 8) & 0xffu);
@@ -1050,7 +1041,7 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
     bool act = valid && L > 0;
     const uint32_t comp_off = minus ? 256u : 0u;
     RefCursor<kHpBits> cur;
-    cur.init(a.ref, a.hp11, off, L, minus, act);
+    cur.init(a.ref, off, L, minus, act);
     const WalkLane lane_e = walk_lane(a.seed, read_idx, 0u, 0u);
     const WalkLane lane_d = walk_lane(a.seed, read_idx, 0u, 2u);
     uint64_t qwin = act ? qsrc[0] : 0;
@@ -1854,16 +1845,16 @@ __global__ __launch_bounds__(256) void k_bam_finish(TextArgs a) {
 // ---------------------------------------------------------------------------
 static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-void launch_prepare_reference(uint8_t *seq, uint8_t *hp, uint16_t *hp11, int64_t len, int64_t *tile_first, int64_t *tile_last,
+void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int flag_hp11, int64_t len, int64_t *tile_first, int64_t *tile_last,
                               int64_t *carry_start, int64_t *carry_next, int keep_first_case, DeviceFlags *flags,
                               hipStream_t s) {
   const int64_t n_tiles = (len + kHpTile - 1) / kHpTile;
   if (n_tiles == 0) return;
   hipLaunchKernelGGL(k_hp_breaks, dim3((unsigned)n_tiles), dim3(256), 0, s, seq, len, keep_first_case, tile_first,
-                     tile_last);
+                     tile_last, flags);
   hipLaunchKernelGGL(k_hp_carry, dim3(1), dim3(1024), 0, s, tile_first, tile_last, n_tiles, len, carry_start,
                      carry_next);
-  hipLaunchKernelGGL(k_hp_final, dim3((unsigned)n_tiles), dim3(256), 0, s, seq, hp, hp11, len, keep_first_case,
+  hipLaunchKernelGGL(k_hp_final, dim3((unsigned)n_tiles), dim3(256), 0, s, seq, hp, flag_hp11, len, keep_first_case,
                      carry_start, carry_next, flags);
 }
 

@@ -18,7 +18,7 @@ QS = ["--strategy", "wgs", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.mod
 
 
 def _write_fasta(path, recs):
-    with open(path, "w") as f:
+    with open(path, "w", encoding="latin-1") as f:
         for i, s in enumerate(recs, 1):
             f.write(f">r{i}\n")
             for k in range(0, len(s), 60):
@@ -64,6 +64,11 @@ EDGE = {
     "qshmm_pass5": (lambda rng: [_rand_seq(rng, 4000) + "A" * 11 + _rand_seq(rng, 500)],
                     QS + ["--depth", "3", "--seed", "17", "--pass-num", "5", "--length-mean", "400", "--length-sd", "300",
                           "--accuracy-mean", "0.80"]),
+    # bytes >= 0x80 in the record (runs of them too: hp 11 of a non-ASCII byte): bit 7 of the sequence bytes cannot
+    # carry the hp == 11 flag, the walks must fall back to the hp byte array (k_hp_breaks high_bytes)
+    "non_ascii_bytes": (lambda rng: [_rand_seq(rng, 1500) + "\xc4" * 13 + _rand_seq(rng, 700, "ACGT\x80\xe9") + "A" * 11 +
+                                     _rand_seq(rng, 1500) + "\xff" * 12 + _rand_seq(rng, 300)],
+                        ONT + ["--depth", "25", "--seed", "21", "--length-mean", "400", "--length-sd", "250"]),
     # scratch pool far too small for one default batch: the driver must shrink batches, same bytes
     "many_small_batches": (lambda rng: [_rand_seq(rng, 600000)],
                            ONT + ["--depth", "15", "--seed", "18", "--length-mean", "1000", "--length-sd", "700"]),
