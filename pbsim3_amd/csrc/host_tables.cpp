@@ -317,7 +317,7 @@ bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBi
   t->rows_off = 64;
   t->emis_off = t->rows_off + 32u * (uint32_t)(smax + 1);
   t->init_off = t->emis_off + 16u * (uint32_t)(smax + 1);
-  t->tran_off = t->init_off + 1008u;
+  t->tran_off = t->init_off + 1000u;  // contiguous: the initial-state table is row 0 of the transition table (k_walk_errhmm)
   t->stride = (t->tran_off + 1000u * (uint32_t)smax + 15u) & ~15u;
   const int ncls = h.acc_hi - h.acc_lo + 1;
   t->blob.assign((size_t)ncls * t->stride, 0);
@@ -451,6 +451,12 @@ bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBi
         if (v > 65535.0) v = 65535.0;
         row[4 + hp] = (uint16_t)v;
       }
+      {
+        // the two thresholds the default --hp-del-bias 1 can reach (hp != 11 | hp == 11, Q1) ride in the emission row, so
+        // that the walk gets everything a step needs of its state with one 16-byte LDS read
+        const uint32_t w3 = (uint32_t)row[4 + 1] | ((uint32_t)row[4 + 11] << 16);
+        memcpy(dst + t->emis_off + 16u * (uint32_t)j + 12, &w3, 4);
+      }
       if (j <= m.state_max[mc]) {
         if (r.tran_rv[j] != 1000) t->all_rv_1000 = false;
       }
@@ -529,7 +535,7 @@ bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias
   t->smax = smax;
   t->rv_off = 64;
   t->init_off = (t->rv_off + 4u * (uint32_t)(smax + 1) + 15u) & ~15u;
-  t->tran_off = t->init_off + 112u;
+  t->tran_off = t->init_off + 100u;  // contiguous: the initial-state table is row 0 of the transition table (k_walk_qshmm)
   t->emis_off = t->tran_off + 100u * (uint32_t)smax;
   t->freq_off = (t->emis_off + 100u * (uint32_t)smax + 15u) & ~15u;
   t->stride = (t->freq_off + 1000u + 15u) & ~15u;

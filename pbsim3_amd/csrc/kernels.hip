@@ -527,7 +527,14 @@ __global__ __launch_bounds__(256) void k_wg_scatter(SortArgs a, int32_t *wg_star
 }
 
 // waves that carry the longest reads are the kernel's critical path: raise them
+#ifndef PBSIM_WALK_PRIO
+#define PBSIM_WALK_PRIO 1
+#endif
+#ifndef PBSIM_TEXT_PRIO
+#define PBSIM_TEXT_PRIO 3
+#endif
 __device__ __forceinline__ void walk_priority(int lmax_wave, int mean_len) {
+  if (!PBSIM_WALK_PRIO) return;
   const int r = lmax_wave / (2 * (mean_len > 0 ? mean_len : 1));
   if (r >= 3) __builtin_amdgcn_s_setprio(3);
   else if (r == 2) __builtin_amdgcn_s_setprio(2);
@@ -735,7 +742,8 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
       if (mode != kModeVerbatim) {
         uint32_t idx;
         if (kFastRv) {
-          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 1000u) + w.x % 1000u;
+          // the initial-state table sits right in front of the transition rows (host_tables.cpp): it is row 0
+          idx = a.init_off + __umul24((q == 0) ? 0u : state, 1000u) + w.x % 1000u;
         } else {
           uint32_t mod = (q == 0) ? init_rv : tran_rv;  // Q2: re-initialise while nothing has been emitted
           mod = mod ? mod : 1u;
@@ -744,15 +752,15 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
         state = lds[idx];  // a finished lane keeps walking harmlessly: nothing it computes is stored
         const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + state * 32u);
         if (!kFastRv) tran_rv = row[0];
-        const uint32_t thr = row[4 + (hp < 12u ? hp : 11u)];
-        const bool del = (w.y % 1000u + 1u) <= thr;
         // emission class: the modulus differs from state to state (emis_rv = round(1000 * (1 - P(del)))), so
-        // `z % emis_rv` is a multiply-high with the state's magic number (host_tables.cpp emission_magic)
-        const uint2 em = *reinterpret_cast<const uint2 *>(lds + a.emis_off + state * 16u);
-        const uint32_t ee = *reinterpret_cast<const uint32_t *>(lds + a.emis_off + state * 16u + 8u);
+        // `z % emis_rv` is a multiply-high with the state's magic number (host_tables.cpp emission_magic).  The row's
+        // last dword holds the deletion thresholds of hp != 11 | hp == 11: one 16-byte read serves the whole step.
+        const uint4 em = *reinterpret_cast<const uint4 *>(lds + a.emis_off + state * 16u);
+        const uint32_t thr = kHpBits ? __builtin_amdgcn_ubfe(em.w, (raw >> 3) & 16u, 16u) : row[4 + (hp < 12u ? hp : 11u)];
+        const bool del = (w.y % 1000u + 1u) <= thr;
         const uint32_t quo = __umulhi(w.z, em.x) >> (em.y & 0xffffu);
         const uint32_t rem = w.z - quo * (em.y >> 16);
-        e = (uint32_t)(rem >= (ee & 0xffffu)) + (uint32_t)(rem >= (ee >> 16));
+        e = (uint32_t)(rem >= (em.z & 0xffffu)) + (uint32_t)(rem >= (em.z >> 16));
         e = del ? 3u : e;
       }
       uint32_t subb = s_sub[nt * 4u + w.w % 3u];  // 0 for a non-ACGT reference base
@@ -896,7 +904,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
       if (has_model) {
         uint32_t idx;
         if (kFastRv) {
-          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 100u) + w.x % 100u;
+          idx = a.init_off + __umul24((q == 0) ? 0u : state, 100u) + w.x % 100u;  // init table = row 0 (host_tables.cpp)
         } else {
           uint32_t mod = (q == 0) ? init_rv : rvs[2 * state];
           mod = mod ? mod : 1u;
@@ -1609,6 +1617,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   __shared__ long long s_dmaf[64], s_dsq[64];       // destination offsets of the task's MAF line / squeezed line
   const int64_t wave = blockIdx.x;
   const int pass = blockIdx.y;
+  if (PBSIM_TEXT_PRIO) __builtin_amdgcn_s_setprio(PBSIM_TEXT_PRIO);
   if (wave * 64 >= flags->total_slots) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid < 64) {
@@ -1790,6 +1799,7 @@ __device__ __forceinline__ void fill_run(char *dst, int64_t n, uint32_t even_byt
 }
 
 __global__ __launch_bounds__(256) void k_text_fill(TextArgs a) {
+  if (PBSIM_TEXT_PRIO) __builtin_amdgcn_s_setprio(PBSIM_TEXT_PRIO);
   const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (t >= a.n_reads * a.pass_num) return;

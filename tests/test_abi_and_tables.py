@@ -122,11 +122,14 @@ def test_errhmm_class_tables_are_well_formed(model):
         assert acc == 63 + c and mode in (0, 1, 2)
         assert init_rv == 1000
         rows = np.frombuffer(b[64:64 + 32 * (smax + 1)], dtype=np.uint16).reshape(smax + 1, 16)
-        # emission rows: 16 B per state {magic u32, shift u16, d u16, E0' u16, E1' u16, pad}: z % d by multiply-high
+        # emission rows: 16 B per state {magic u32, shift u16, d u16, E0' u16, E1' u16, del_thr[hp 1] u16, del_thr[hp 11] u16}:
+        # z % d by multiply-high, and the two deletion thresholds the default bias can reach
         emis_off = 64 + 32 * (smax + 1)
         em = np.frombuffer(b[emis_off:emis_off + 16 * (smax + 1)], dtype=np.uint32).reshape(smax + 1, 4)
         init_off = emis_off + 16 * (smax + 1)
         init = np.frombuffer(b[init_off:init_off + 1000], dtype=np.uint8)
+        # the transition rows follow the initial-state table without a gap (the walk indexes it as row 0)
+        assert stride == (init_off + 1000 + 1000 * smax + 15) // 16 * 16
         assert init.min() >= 1 and init.max() <= smax
         assert (np.diff(init.astype(int)) >= 0).all()
         for j in range(1, smax + 1):
@@ -146,6 +149,7 @@ def test_errhmm_class_tables_are_well_formed(model):
                 want = z % 3 if emis_rv == 0 else ((z % emis_rv + 1 > e0) + (z % emis_rv + 1 > e1))
                 assert (r >= t0) + (r >= t1) == want
             assert rows[j][4 + 11] == 0           # Q1: hp 11 -> bias 0.0 -> no HMM deletion
+            assert int(em[j][3]) == int(rows[j][4 + 1]) | (int(rows[j][4 + 11]) << 16)
             assert rows[j][4 + 1] == rows[j][4 + 10]  # default --hp-del-bias 1
     ctx.close()
 
