@@ -106,6 +106,10 @@ constexpr int kMaxSlots = 4;
 // Everything one in-flight batch owns.  Several slots (each with its own stream)
 // let the walk of batch k+1 fill the GPU while the longest reads of batch k
 // are still draining and while batch k's text is being emitted.
+// k_text_rows prefetches whole 256-column tiles without bounds checks: up to two tiles (2 x 64 dwords x 256 B) past the
+// last wave's last row
+constexpr size_t kScratchSlack = 64u << 10;
+
 struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -593,7 +597,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   HIP_OK(c->s().d_qsum.ensure(n_tasks * 8));
   HIP_OK(c->s().d_cum.ensure((n_reads + 1) * 8));
   HIP_OK(c->s().d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
-  HIP_OK(c->s().d_scratch.ensure((size_t)c->scratch_budget, true));
+  HIP_OK(c->s().d_scratch.ensure((size_t)c->scratch_budget + kScratchSlack, true));
 
   HIP_OK(hipEventRecord(c->s().ev0, c->s().stream));
   HIP_OK(hipMemsetAsync(c->s().d_flags.p, 0, sizeof(DeviceFlags), c->s().stream));
@@ -1632,7 +1636,7 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
       HIP_OK(sl.d_qsum.ensure(n_tasks * 8));
       HIP_OK(sl.d_cum.ensure((n_tasks + 1) * 8));
       HIP_OK(sl.d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
-      HIP_OK(sl.d_scratch.ensure((size_t)c->scratch_budget, true));
+      HIP_OK(sl.d_scratch.ensure((size_t)c->scratch_budget + kScratchSlack, true));
       HIP_OK(c->d_sq_line_len.ensure(n_lines * 4));
       HIP_OK(c->d_sq_line_qoff.ensure(n_lines * 8));
       HIP_OK(c->d_sq_vbase.ensure((n_lw + 1) * 4));

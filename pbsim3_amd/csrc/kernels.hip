@@ -1681,10 +1681,11 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
 
   // lane (lt, lc) loads dword c + 16 lc of task lt (LDS banks 5 lt + c + 16 lc: all different); the loads of the NEXT
   // tile are issued before this tile is served, so their latency hides behind the four serving steps
+  // (no bounds checks: columns past a row's end are never used, and the pool ends with kScratchSlack bytes of slack)
   uint32_t pre[16];
   const uint32_t *lane_src = region + wv * 16 + lt + (size_t)(16 * lc) * 64;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) pre[c] = (c + 16 * lc < cap_dw) ? scratch_load(lane_src + (size_t)c * 64) : 0u;
+  for (int c = 0; c < 16; ++c) pre[c] = scratch_load(lane_src + (size_t)c * 64);
   for (int s0 = 0, t = 0; s0 < mmax; s0 += 256, ++t) {
     // carry: the previous tile's last 16 bytes move in front (lane = task row x dword)
     if (t > 0) tile[lt * kTileStride + lc] = tile[lt * kTileStride + 64 + lc];
@@ -1695,8 +1696,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     if (s0 + 256 < mmax) {
       const int c1 = (s0 + 256) >> 2;
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
-        pre[c] = (c1 + c + 16 * lc < cap_dw) ? scratch_load(lane_src + (size_t)(c1 + c) * 64) : 0u;
+      for (int c = 0; c < 16; ++c) pre[c] = scratch_load(lane_src + (size_t)(c1 + c) * 64);
     }
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {
