@@ -579,9 +579,9 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   HIP_OK(c->s().d_len.ensure(n_reads * 4));
   HIP_OK(c->s().d_off.ensure(n_reads * 4));
   HIP_OK(c->s().d_acc.ensure(n_reads));
-  HIP_OK(c->s().d_hist.ensure(nbins * 4));
+  HIP_OK(c->s().d_hist.ensure(nbins * kBinPad * 4));
   HIP_OK(c->s().d_bin_start.ensure(nbins * 4));
-  HIP_OK(c->s().d_bin_cursor.ensure(nbins * 4));
+  HIP_OK(c->s().d_bin_cursor.ensure(nbins * kBinPad * 4));
   HIP_OK(c->s().d_class_start.ensure((ncls + 1) * 4));
   HIP_OK(c->s().d_task_of_slot.ensure(slots_max * 4));
   HIP_OK(c->s().d_slot_of_task.ensure(n_tasks * 4));

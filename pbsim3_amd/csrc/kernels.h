@@ -10,6 +10,11 @@ namespace pbsim {
 
 constexpr int kWG = 256;            // threads per workgroup of the walk kernels (4 waves)
 constexpr int kLenBuckets = 4096;   // length buckets per accuracy class in the task sort
+#ifndef PBSIM_BIN_PAD
+#define PBSIM_BIN_PAD 16
+#endif
+constexpr int kBinPad = PBSIM_BIN_PAD;  // int32 slots per counter of the sort's histogram / cursors: one counter per 64-byte line,
+                                      // neighbouring (hot) length buckets do not share a line that 8 XCDs fight over
 constexpr int kLenShift = 8;        // bucket = len >> 8  (len_max 1e6 -> 3907 buckets)
 constexpr int kScratchPad = 64;     // per-task slack: cap = 2*L + kScratchPad columns (pbsim.cpp:5488 uses 2*len_max+1)
 constexpr int kMaxClasses = 64;
@@ -68,9 +73,9 @@ struct SortArgs {
   int32_t acc_lo, ncls;
   const int32_t *len;
   const uint8_t *acc;
-  int32_t *hist;        // [ncls*kLenBuckets]
+  int32_t *hist;        // [ncls*kLenBuckets*kBinPad]
   int32_t *bin_start;   // [ncls*kLenBuckets]
-  int32_t *bin_cursor;  // [ncls*kLenBuckets]
+  int32_t *bin_cursor;  // [ncls*kLenBuckets*kBinPad]
   int32_t *class_start; // [ncls+1], multiples of kWG
   int32_t *task_of_slot;
   int32_t *slot_of_task;

@@ -358,7 +358,7 @@ __device__ __forceinline__ int sort_bin(int acc, int acc_lo, int len) {
 __global__ __launch_bounds__(256) void k_sort_hist(SortArgs a) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= a.n_reads) return;
-  atomicAdd(&a.hist[sort_bin(a.acc[r], a.acc_lo, a.len[r])], a.pass_num);
+  atomicAdd(&a.hist[(size_t)sort_bin(a.acc[r], a.acc_lo, a.len[r]) * kBinPad], a.pass_num);
 }
 
 // One workgroup of kScanBlock = 256 threads (one wave per SIMD, the footprint of a walk workgroup: a 1024-thread
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kScanBlock) void k_sort_scan(SortArgs a) {
   for (int c = 0; c < a.ncls; c++) {
     int v[kPer], sum = 0;
     for (int k = 0; k < kPer; k++) {
-      v[k] = a.hist[c * kLenBuckets + tid * kPer + k];
+      v[k] = a.hist[(size_t)(c * kLenBuckets + tid * kPer + k) * kBinPad];
       sum += v[k];
     }
     s_part[tid] = sum;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= a.n_reads) return;
   const int bin = sort_bin(a.acc[r], a.acc_lo, a.len[r]);
-  const int slot = a.bin_start[bin] + atomicAdd(&a.bin_cursor[bin], a.pass_num);
+  const int slot = a.bin_start[bin] + atomicAdd(&a.bin_cursor[(size_t)bin * kBinPad], a.pass_num);
   for (int h = 0; h < a.pass_num; h++) {
     const int task = (int)(r * a.pass_num + h);
     a.task_of_slot[slot + h] = task;
@@ -1313,32 +1313,38 @@ __device__ __forceinline__ int64_t bam_record_size(int idl, int q, int64_t readn
 }
 
 __global__ __launch_bounds__(256) void k_text_sizes(TextArgs a, DeviceFlags *flags) {
+  __shared__ unsigned long long s_sum[3];  // one global atomic per workgroup and counter: all tasks hit the same line
+  if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+  __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n_tasks = a.n_reads * a.pass_num;
-  if (t >= n_tasks) return;
-  const int64_t r = t / a.pass_num;
-  const int pass = (int)(t - r * a.pass_num);
-  const int q = a.out_len[t], m = a.maf_len[t];
-  TaskText x;
-  task_text(a, r, pass, q, &x);
-  int64_t rt;
-  if (a.bam) {
-    rt = bam_record_size(x.idl, q, x.readnum);
-  } else if (a.pass_num == 1) {
-    rt = 2LL * x.idl + 2LL * q + 6;  // "@id\n" seq "\n+id\n" qual "\n"
-  } else {
-    // pbsim.cpp:4017-4027
-    rt = (int64_t)x.idl + PB_LEN(PB_SAM_MID) + q + 1 + q + PB_LEN(PB_SAM_IP) + 2LL * q + PB_LEN(PB_SAM_PW) + 2LL * q +
-         PB_LEN(PB_SAM_T1) + dec_len((int64_t)q - 1) + PB_LEN(PB_SAM_T2) + a.rq_len + PB_LEN(PB_SAM_T3) +
-         count_digit(x.readnum) + PB_LEN(PB_SAM_T4);
+  if (t < n_tasks) {
+    const int64_t r = t / a.pass_num;
+    const int pass = (int)(t - r * a.pass_num);
+    const int q = a.out_len[t], m = a.maf_len[t];
+    TaskText x;
+    task_text(a, r, pass, q, &x);
+    int64_t rt;
+    if (a.bam) {
+      rt = bam_record_size(x.idl, q, x.readnum);
+    } else if (a.pass_num == 1) {
+      rt = 2LL * x.idl + 2LL * q + 6;  // "@id\n" seq "\n+id\n" qual "\n"
+    } else {
+      // pbsim.cpp:4017-4027
+      rt = (int64_t)x.idl + PB_LEN(PB_SAM_MID) + q + 1 + q + PB_LEN(PB_SAM_IP) + 2LL * q + PB_LEN(PB_SAM_PW) + 2LL * q +
+           PB_LEN(PB_SAM_T1) + dec_len((int64_t)q - 1) + PB_LEN(PB_SAM_T2) + a.rq_len + PB_LEN(PB_SAM_T3) +
+           count_digit(x.readnum) + PB_LEN(PB_SAM_T4);
+    }
+    const int64_t mt = (11LL + (x.name_len - x.r0) + x.w0 + x.w1 + x.w2 + x.w3 + m) +
+                       (10LL + x.idl + (x.w0 - x.q0) + x.w1 + x.w2 + x.w3 + m);
+    a.read_text_len[t] = rt;
+    a.maf_text_len[t] = mt;
+    atomicAdd(&s_sum[0], (unsigned long long)q);
+    atomicAdd(&s_sum[1], (unsigned long long)a.len[r]);
+    atomicAdd(&s_sum[2], (unsigned long long)m);
   }
-  const int64_t mt = (11LL + (x.name_len - x.r0) + x.w0 + x.w1 + x.w2 + x.w3 + m) +
-                     (10LL + x.idl + (x.w0 - x.q0) + x.w1 + x.w2 + x.w3 + m);
-  a.read_text_len[t] = rt;
-  a.maf_text_len[t] = mt;
-  atomicAdd((unsigned long long *)&flags->sums[3], (unsigned long long)q);
-  atomicAdd((unsigned long long *)&flags->sums[4], (unsigned long long)a.len[r]);
-  atomicAdd((unsigned long long *)&flags->sums[5], (unsigned long long)m);
+  __syncthreads();
+  if (threadIdx.x < 3) atomicAdd((unsigned long long *)&flags->sums[3 + threadIdx.x], s_sum[threadIdx.x]);
 }
 
 // ---- small pieces: one thread per task writes every header/separator and
@@ -1880,8 +1886,8 @@ void launch_header_trans(const HeaderArgs &a, hipStream_t s) {
 
 void launch_task_sort(const SortArgs &a, hipStream_t s) {
   const size_t nbins = (size_t)a.ncls * kLenBuckets;
-  (void)hipMemsetAsync(a.hist, 0, nbins * sizeof(int32_t), s);
-  (void)hipMemsetAsync(a.bin_cursor, 0, nbins * sizeof(int32_t), s);
+  (void)hipMemsetAsync(a.hist, 0, nbins * kBinPad * sizeof(int32_t), s);
+  (void)hipMemsetAsync(a.bin_cursor, 0, nbins * kBinPad * sizeof(int32_t), s);
   (void)hipMemsetAsync(a.task_of_slot, 0xff, (size_t)a.n_slots_max * sizeof(int32_t), s);
   hipLaunchKernelGGL(k_sort_hist, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(kScanBlock), 0, s, a);
