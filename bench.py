@@ -170,6 +170,19 @@ def bench_trans(a, torch, harness, P, local):
     ctx.close()
 
 
+def issue_bound(columns_per_launch, walk_s):
+    """The walk's real ceiling is integer issue, not HBM: figures of the PMC pass of the same kernel (tools/pmc_kernel.sh)."""
+    path = os.path.join(ROOT, "profiles", "r01x_walk_pmc.json")
+    if not os.path.exists(path):
+        return None
+    pj = json.load(open(path))
+    valu = pj["per_wave_step"]["valu"]          # VALU instructions per wave-step = per lane and MAF column
+    return {"valu_busy_frac": pj["valu_busy_fraction"], "valu_per_wave_step": valu,
+            "int_lane_ops_per_sec": valu * columns_per_launch / walk_s if walk_s > 0 else None,
+            "lds_table_hit_rate": 1.0,          # every HMM table read is an LDS read (4 per column)
+            "source": "profiles/r01x_walk_pmc.json (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD-cycles)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -372,7 +385,7 @@ def main():
         walk_s = walk_ms / 1e3 / max(1, launches)
         achieved = alg_bytes_launch / walk_s / 1e9 if walk_s > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01o_walk_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01x_walk_traffic.json")
         if not qs and os.path.exists(tpath):     # PMC pass of the same kernel (tools/pmc_traffic.sh), scaled per base
             tj = json.load(open(tpath))
             traffic = tj["traffic_bytes_per_launch"] / tj["bases_per_launch"] * (bases / max(1, launches))
@@ -389,15 +402,11 @@ def main():
                        "text_bytes_per_step": g_text // a.steps, "parallelism": f"read-block x{world}", "slots_in_flight": S},
             "roofline": {"bound": "hbm", "kernel": "k_walk_qshmm" if qs else "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01o_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE, raw x1024; see note there)",
+                         "traffic_source": "profiles/r01x_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE, raw x1024; see note there)",
                          "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": walk_s * 1e3,
                          "walk_share_of_step": (walk_ms / 1e3) / dt if dt > 0 else None,
                          # the kernel's real ceiling is integer issue, not HBM: PMC pass of the same kernel
-                         "issue_bound": None if qs else {"valu_busy_frac": 0.886, "valu_per_wave_step": 135.5,
-                                                         # 135.5 VALU instructions per wave-step = per lane and MAF column
-                                                         "int_lane_ops_per_sec": 135.5 * (maf_c / max(1, launches)) / walk_s if walk_s > 0 else None,
-                                                         "lds_table_hit_rate": 1.0,   # every HMM table read is an LDS read (5 per column)
-                                                         "source": "profiles/r01i_walk_pmc.json (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD-cycles)"}},
+                         "issue_bound": None if qs else issue_bound(maf_c / max(1, launches), walk_s)},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
