@@ -27,6 +27,19 @@ namespace pbsim {
 namespace {
 
 constexpr int kScanBlock = 256;  // single-workgroup scan kernels
+
+// Wave priorities (s_setprio).  The walk of one slot shares the GPU with every other kernel of the other slot; its waves
+// live for milliseconds, the others' for microseconds.  Without a raised priority the short kernels' waves rarely get to
+// issue on a SIMD they share with walk waves (k_text_headers: 0.5 ms alone, 13 ms beside a QSHMM walk).
+#ifndef PBSIM_WALK_PRIO
+#define PBSIM_WALK_PRIO 1   // waves that carry the longest reads raise themselves (walk_priority)
+#endif
+#ifndef PBSIM_TEXT_PRIO
+#define PBSIM_TEXT_PRIO 3   // every kernel that is not a walk
+#endif
+__device__ __forceinline__ void short_kernel_priority() {
+  if (PBSIM_TEXT_PRIO) __builtin_amdgcn_s_setprio(PBSIM_TEXT_PRIO);
+}
 constexpr uint32_t kATGC = 0x43475441u;  // "ATGC" little-endian (mut.ins_nt / sub_nt_n, pbsim.cpp:5485-5486)
 
 __device__ __forceinline__ uint32_t to_upper(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int
 // K1: read header (WGS).  pbsim.cpp:3793-3813 (= 2174-2194)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_header_wgs(HeaderArgs a) {
+  short_kernel_priority();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_reads) return;
   const uint32_t read = (uint32_t)(a.first_read + i);
@@ -322,6 +336,7 @@ __global__ __launch_bounds__(256) void k_header_wgs(HeaderArgs a) {
 // K1t: read header (trans).  pbsim.cpp:4488-4504 (= 2809-2825): no quota, start
 // position from the rank's bucket table, length clipped to the transcript end.
 __global__ __launch_bounds__(256) void k_header_trans(HeaderArgs a) {
+  short_kernel_priority();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_reads) return;
   const uint32_t read = (uint32_t)(a.first_read + i);
@@ -356,6 +371,7 @@ __device__ __forceinline__ int sort_bin(int acc, int acc_lo, int len) {
 }
 
 __global__ __launch_bounds__(256) void k_sort_hist(SortArgs a) {
+  short_kernel_priority();
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= a.n_reads) return;
   atomicAdd(&a.hist[(size_t)sort_bin(a.acc[r], a.acc_lo, a.len[r]) * kBinPad], a.pass_num);
@@ -365,6 +381,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(SortArgs a) {
 // block needs 16 free wave slots on ONE CU at once and starves for tens of ms behind the other slot's walk): per class an exclusive scan over its kLenBuckets bins;
 // class starts are rounded up to the walk workgroup size
 __global__ __launch_bounds__(kScanBlock) void k_sort_scan(SortArgs a) {
+  short_kernel_priority();
   __shared__ int s_part[kScanBlock];
   __shared__ int s_base;
   const int tid = threadIdx.x;
@@ -405,6 +422,7 @@ __global__ __launch_bounds__(kScanBlock) void k_sort_scan(SortArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a) {
+  short_kernel_priority();
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= a.n_reads) return;
   const int bin = sort_bin(a.acc[r], a.acc_lo, a.len[r]);
@@ -418,6 +436,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a) {
 
 // per wave: scratch columns needed = 2*Lmax + pad (in dwords per lane)
 __global__ __launch_bounds__(256) void k_wave_cap(SortArgs a) {
+  short_kernel_priority();
   const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n_waves = a.n_slots_max / 64;
   if (w >= n_waves) return;
@@ -435,6 +454,7 @@ __global__ __launch_bounds__(256) void k_wave_cap(SortArgs a) {
 }
 
 __global__ __launch_bounds__(kScanBlock) void k_wave_scan(SortArgs a) {
+  short_kernel_priority();
   __shared__ long long s_part[kScanBlock];
   __shared__ long long s_base;
   const int tid = threadIdx.x;
@@ -477,6 +497,7 @@ __global__ __launch_bounds__(kScanBlock) void k_wave_scan(SortArgs a) {
 // ends when its longest read ends, so workgroups holding long reads go first
 // (and their waves run at raised priority, see walk_priority()).
 __global__ __launch_bounds__(256) void k_wg_hist(SortArgs a, int32_t *wg_hist) {
+  short_kernel_priority();
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= a.n_slots_max / kWG) return;
   const int task = a.task_of_slot[g * kWG];
@@ -490,6 +511,7 @@ __global__ __launch_bounds__(256) void k_wg_hist(SortArgs a, int32_t *wg_hist) {
 }
 
 __global__ __launch_bounds__(kScanBlock) void k_wg_scan(int32_t *wg_hist, int32_t *wg_start) {
+  short_kernel_priority();
   __shared__ int s_part[kScanBlock];
   __shared__ int s_base;
   const int tid = threadIdx.x;
@@ -514,6 +536,7 @@ __global__ __launch_bounds__(kScanBlock) void k_wg_scan(int32_t *wg_hist, int32_
 }
 
 __global__ __launch_bounds__(256) void k_wg_scatter(SortArgs a, int32_t *wg_start, int32_t *wg_order) {
+  short_kernel_priority();
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= a.n_slots_max / kWG) return;
   const int task = a.task_of_slot[g * kWG];
@@ -527,12 +550,6 @@ __global__ __launch_bounds__(256) void k_wg_scatter(SortArgs a, int32_t *wg_star
 }
 
 // waves that carry the longest reads are the kernel's critical path: raise them
-#ifndef PBSIM_WALK_PRIO
-#define PBSIM_WALK_PRIO 1
-#endif
-#ifndef PBSIM_TEXT_PRIO
-#define PBSIM_TEXT_PRIO 3
-#endif
 __device__ __forceinline__ void walk_priority(int lmax_wave, int mean_len) {
   if (!PBSIM_WALK_PRIO) return;
   const int r = lmax_wave / (2 * (mean_len > 0 ? mean_len : 1));
@@ -1134,6 +1151,7 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
 constexpr int kScanTile = 2048;  // 256 threads x 8
 
 __global__ __launch_bounds__(256) void k_scan_sums(const int64_t *in, int64_t n, int64_t *sums) {
+  short_kernel_priority();
   __shared__ long long s[256];
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 8;
   long long t = 0;
@@ -1149,6 +1167,7 @@ __global__ __launch_bounds__(256) void k_scan_sums(const int64_t *in, int64_t n,
 }
 
 __global__ __launch_bounds__(kScanBlock) void k_scan_single(int64_t *sums, int64_t n, int64_t *total) {
+  short_kernel_priority();
   __shared__ long long s_part[kScanBlock];
   __shared__ long long s_base;
   const int tid = threadIdx.x;
@@ -1174,6 +1193,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_single(int64_t *sums, int64
 }
 
 __global__ __launch_bounds__(256) void k_scan_apply(const int64_t *in, int64_t *out, int64_t n, const int64_t *sums) {
+  short_kernel_priority();
   __shared__ long long s[256];
   const int tid = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)tid * 8;
@@ -1202,6 +1222,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int64_t *in, int64_t *
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gather_pass0(const int32_t *out_len, int64_t n_reads, int32_t pass_num,
                                                         int64_t *cum) {
+  short_kernel_priority();
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r < n_reads) cum[r] = out_len[r * pass_num];
 }
@@ -1210,6 +1231,7 @@ __global__ void k_quota_init(DeviceFlags *flags, int64_t n_reads) { flags->n_fin
 
 __global__ __launch_bounds__(256) void k_quota_find(const int64_t *cum, const int32_t *rawlen, int64_t n_reads,
                                                       int64_t before, int64_t quota, DeviceFlags *flags) {
+  short_kernel_priority();
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n_reads) return;
   const int64_t t = before + cum[r];
@@ -1313,6 +1335,7 @@ __device__ __forceinline__ int64_t bam_record_size(int idl, int q, int64_t readn
 }
 
 __global__ __launch_bounds__(256) void k_text_sizes(TextArgs a, DeviceFlags *flags) {
+  short_kernel_priority();
   __shared__ unsigned long long s_sum[3];  // one global atomic per workgroup and counter: all tasks hit the same line
   if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
   __syncthreads();
@@ -1359,6 +1382,7 @@ __device__ __forceinline__ char *g_pad(char *o, int n) {
 }
 
 __global__ __launch_bounds__(256) void k_text_headers(TextArgs a) {
+  short_kernel_priority();
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n_tasks = a.n_reads * a.pass_num;
   if (t >= n_tasks) return;
@@ -1623,7 +1647,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   __shared__ long long s_dmaf[64], s_dsq[64];       // destination offsets of the task's MAF line / squeezed line
   const int64_t wave = blockIdx.x;
   const int pass = blockIdx.y;
-  if (PBSIM_TEXT_PRIO) __builtin_amdgcn_s_setprio(PBSIM_TEXT_PRIO);
+  short_kernel_priority();
   if (wave * 64 >= flags->total_slots) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid < 64) {
@@ -1805,7 +1829,7 @@ __device__ __forceinline__ void fill_run(char *dst, int64_t n, uint32_t even_byt
 }
 
 __global__ __launch_bounds__(256) void k_text_fill(TextArgs a) {
-  if (PBSIM_TEXT_PRIO) __builtin_amdgcn_s_setprio(PBSIM_TEXT_PRIO);
+  short_kernel_priority();
   const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (t >= a.n_reads * a.pass_num) return;
@@ -1835,6 +1859,7 @@ __device__ __forceinline__ uint32_t bam_base_code(uint32_t c) {
 }
 
 __global__ __launch_bounds__(256) void k_bam_finish(TextArgs a) {
+  short_kernel_priority();
   const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (t >= a.n_reads * a.pass_num) return;
