@@ -143,6 +143,19 @@ int pbsim_set_templates(pbsim_ctx *ctx, int64_t n, const char *const *ids, const
 int pbsim_simulate_wgs(pbsim_ctx *ctx, const pbsim_sink *sink);
 int pbsim_simulate_trans(pbsim_ctx *ctx, const pbsim_sink *sink);
 int pbsim_simulate_templ(pbsim_ctx *ctx, const pbsim_sink *sink); /* simulate_by_errhmm_templ :4807 / _qshmm_templ :3055 */
+/* Read-block shard of a unit set (multi-GPU front-end, one rank per GPU): reads first_read .. first_read + n_reads - 1 of
+ * the global numbering sim.res_num of simulate_by_*_trans / _templ (pbsim.cpp:4516-4522 assigns reads to transcripts in
+ * file order).  Every byte of a read depends only on (seed, read, pass, event), so the shards of all ranks concatenated
+ * in read order are the bytes pbsim_simulate_trans delivers; the statistics cover the shard only (the caller sums them).
+ * pbsim_unit_reads: reads of the whole set (sum of the expression values, or the number of templates). */
+int pbsim_simulate_units_range(pbsim_ctx *ctx, int64_t first_read, int64_t n_reads, const pbsim_sink *sink);
+int64_t pbsim_unit_reads(pbsim_ctx *ctx);
+/* Host-side readers of the reference's unit files for callers above the ABI that are not C++: parse `path` like
+ * simulate_by_*_trans does its --transcript file (pbsim.cpp:4428-4485; get_transcript_inf :1075) resp. get_templ_inf its
+ * --template FASTA (:1366) and hand the units over (pbsim_set_transcripts / pbsim_set_templates).
+ * stats[0] = units, stats[1] = total expression value (trans) resp. total template length (templ). */
+int pbsim_load_transcript_file(pbsim_ctx *ctx, const char *path, int64_t stats[2]);
+int pbsim_load_template_file(pbsim_ctx *ctx, const char *path, int64_t stats[2]);
 int pbsim_get_stats(pbsim_ctx *ctx, pbsim_stats *out);          /* pbsim.cpp:4082-4105, 5541-5562 */
 /* Sampling method (--method sample, wgs only, single pass).  pbsim_set_sample_profile hands over what
  * get_sample_inf (pbsim.cpp:1155-1330) leaves in its filtered profile: the quality strings that passed the

@@ -71,6 +71,10 @@ API = [
     ("pbsim_set_templates", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_int64)]),
     ("pbsim_simulate_templ", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
+    ("pbsim_simulate_units_range", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(Sink)]),
+    ("pbsim_unit_reads", C.c_int64, [C.c_void_p]),
+    ("pbsim_load_transcript_file", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    ("pbsim_load_template_file", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     ("pbsim_simulate_wgs", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
     ("pbsim_simulate_trans", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
     ("pbsim_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
@@ -288,6 +292,37 @@ class Context:
         c_lens = (C.c_int64 * n)(*[len(s) for s in seqs])
         _check(self.lib.pbsim_set_transcripts(self.h, n, c_ids, c_plus, c_minus, c_seqs, c_lens))
         self._keep = None
+
+    def load_transcript_file(self, path):
+        """--transcript file -> units; returns (transcripts, total expression value)"""
+        st = (C.c_int64 * 2)()
+        _check(self.lib.pbsim_load_transcript_file(self.h, os.fsencode(path), st))
+        return st[0], st[1]
+
+    def load_template_file(self, path):
+        """--template FASTA -> units; returns (templates, total length)"""
+        st = (C.c_int64 * 2)()
+        _check(self.lib.pbsim_load_template_file(self.h, os.fsencode(path), st))
+        return st[0], st[1]
+
+    def unit_reads(self):
+        return self.lib.pbsim_unit_reads(self.h)
+
+    def simulate_units_range(self, first_read, n_reads):
+        """reads first_read .. first_read + n_reads - 1 of the unit set (one rank's shard); returns (read text, maf text)"""
+        reads, mafs = [], []
+
+        def on_read(user, text, n):
+            reads.append(C.string_at(text, n))
+            return 1
+
+        def on_maf(user, text, n):
+            mafs.append(C.string_at(text, n))
+            return 1
+
+        sink = Sink(None, SINK_CB(on_read), SINK_CB(on_maf))
+        _check(self.lib.pbsim_simulate_units_range(self.h, first_read, n_reads, C.byref(sink)))
+        return b"".join(reads), b"".join(mafs)
 
     def simulate_trans(self, collect=True):
         reads, mafs = [], []

@@ -24,6 +24,7 @@
 #include "../../include/pbsim3_amd.h"
 #include "host_tables.h"
 #include "kernels.h"
+#include "unit_io.h"
 #include "philox.h"
 
 namespace {
@@ -1730,14 +1731,50 @@ int pbsim_simulate_templ(pbsim_ctx *c, const pbsim_sink *sink) { return pbsim_si
 // strategy (simulate_by_*_templ) runs through the same driver.
 int pbsim_simulate_trans(pbsim_ctx *c, const pbsim_sink *sink) {
   if (!c) return fail("bad argument");
+  return pbsim_simulate_units_range(c, 1, c->trans_reads, sink);
+}
+
+int64_t pbsim_unit_reads(pbsim_ctx *c) { return c ? c->trans_reads : -1; }
+
+static int load_unit_file(pbsim_ctx *c, const char *path, int64_t stats[2], bool templ) {
+  if (!c || !path) return fail("bad argument");
+  std::vector<Transcript> tr;
+  std::string err;
+  long a = 0;
+  long long b = 0;
+  if (templ ? !read_templates(path, &tr, &a, &b, &err) : !read_transcripts(path, &tr, &a, &err)) return fail(err);
+  std::vector<const char *> ids;
+  std::vector<int64_t> plus, minus, lens;
+  std::vector<const uint8_t *> seqs;
+  for (auto &t : tr) {
+    ids.push_back(t.id.c_str());
+    plus.push_back(t.plus);
+    minus.push_back(t.minus);
+    seqs.push_back((const uint8_t *)t.seq.data());
+    lens.push_back((int64_t)strlen(t.seq.c_str()));
+  }
+  if (stats) {
+    stats[0] = templ ? (int64_t)a : (int64_t)tr.size();
+    stats[1] = templ ? (int64_t)b : (int64_t)a;
+  }
+  return templ ? pbsim_set_templates(c, (int64_t)tr.size(), ids.data(), seqs.data(), lens.data())
+               : pbsim_set_transcripts(c, (int64_t)tr.size(), ids.data(), plus.data(), minus.data(), seqs.data(), lens.data());
+}
+int pbsim_load_transcript_file(pbsim_ctx *c, const char *path, int64_t stats[2]) { return load_unit_file(c, path, stats, false); }
+int pbsim_load_template_file(pbsim_ctx *c, const char *path, int64_t stats[2]) { return load_unit_file(c, path, stats, true); }
+
+int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads, const pbsim_sink *sink) {
+  if (!c) return fail("bad argument");
   NEED_DEVICE(c);
   if (c->p.strategy == PBSIM_STRATEGY_WGS) return fail("pbsim_simulate_trans: strategy is wgs");
   if (!c->d_seq || c->n_units < 1) return fail("no transcripts/templates set");
+  if (first_read < 1 || n_reads < 0 || first_read - 1 + n_reads > c->trans_reads)
+    return fail("pbsim_simulate_units_range: reads outside 1 .. pbsim_unit_reads()");
   pbsim_reset_stats(c);
   // No quota here: every read is final, so the batches simply pipeline over the slots (the walk of one beside the text
   // emission of the other): one batch per slot when everything fits (small batches waste the GPU on their tails).
   const int n_slots = std::max(1, std::min(kMaxSlots, c->pipeline_depth));
-  const int64_t R = c->trans_reads;
+  const int64_t R = first_read - 1 + n_reads;  // last read of the range
   int64_t cap = batch_capacity(c);
   struct Pending {
     int slot;
@@ -1753,11 +1790,11 @@ int pbsim_simulate_trans(pbsim_ctx *c, const pbsim_sink *sink) {
     fifo.clear();
     c->cur = 0;
   };
-  int64_t next_begin = 1, next_read = 1;
+  int64_t next_begin = first_read, next_read = first_read;
   int next_slot = 0;
   while (next_read <= R) {
     while ((int)fifo.size() < n_slots && next_begin <= R) {
-      const int64_t part = std::max<int64_t>(65536, (R + n_slots - 1) / n_slots);
+      const int64_t part = std::max<int64_t>(65536, (n_reads + n_slots - 1) / n_slots);
       const int64_t n = std::min(std::min(cap, part), R - next_begin + 1);
       c->cur = next_slot;
       if (!pbsim_batch_walk_begin(c, next_begin, n, -1)) {

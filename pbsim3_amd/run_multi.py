@@ -1,4 +1,4 @@
-"""Multi-GPU front-end for the wgs strategy: one process per GPU under torchrun,
+"""Multi-GPU front-end (wgs: quota loop sharded by read block; trans / templ: read blocks of the unit set): one process per GPU under torchrun,
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         -m pbsim3_amd.run_multi --strategy wgs --method errhmm --errhmm M --genome G.fa --prefix out [...]
@@ -33,8 +33,6 @@ def main(argv=None):
     from pbsim3_amd import multi
 
     p, a = A.parse(argv)
-    if p.strategy != P.STRATEGY_WGS:
-        raise SystemExit("ERROR: run_multi shards the wgs strategy (trans/templ: use the pbsim CLI)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if flags["--one-gpu"] else int(os.environ.get("LOCAL_RANK", "0"))
@@ -56,6 +54,12 @@ def main(argv=None):
         if world > 1:
             dist.broadcast(t, src=0)
         return [int(x) for x in t.tolist()]
+
+    if p.strategy != P.STRATEGY_WGS:
+        run_units(p, a, flags, P, torch, dist, comm, rank, world, local, cdev, prefix)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     recs = []
     if rank == 0:
@@ -171,6 +175,84 @@ def main(argv=None):
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_units(p, a, flags, P, torch, dist, comm, rank, world, local, cdev, prefix):
+    """trans / templ strategies: no quota, every read of the unit set is final (simulate_by_*_trans pbsim.cpp:4428-4770,
+    simulate_by_*_templ :4807-5392), so rank r simply takes the r-th contiguous block of the global read numbering.
+    Every rank parses the unit file itself (one node, one file system); text is stitched in rank order."""
+    templ = p.strategy == P.STRATEGY_TEMPL
+    ctx = P.Context(p, local)
+    if "--scratch-mb" in a:
+        ctx.set_scratch_bytes(int(a["--scratch-mb"]) << 20)
+    (ctx.load_errhmm if p.method == P.METHOD_ERR else ctx.load_qshmm)(a["--errhmm" if p.method == P.METHOD_ERR else "--qshmm"])
+    n_units, total = ctx.load_template_file(a["--template"]) if templ else ctx.load_transcript_file(a["--transcript"])
+    if rank == 0:
+        if templ:
+            sys.stderr.write(":::: Template stats ::::\n\nfile name : %s\ntemplate num. : %d\ntemplate total length : %d\n\n"
+                             % (a["--template"], n_units, total))
+        else:
+            sys.stderr.write(":::: transcript stats ::::\n\nfile name : %s\ntranscript num : %d\ntotal expression value : %d\n\n"
+                             % (a["--transcript"], n_units, total))
+    R = ctx.unit_reads()
+    per = (R + world - 1) // world
+    first = 1 + rank * per
+    n = max(0, min(per, R - first + 1))
+    gz = flags["--gzip"]
+    ext = "fq" if p.pass_num == 1 else "sam"
+    if gz:
+        ctx.set_deflate(3)
+        if p.pass_num > 1:
+            ctx.set_bam_output(True)
+    rt, mt = ctx.simulate_units_range(first, n) if n > 0 else (b"", b"")
+    part = "%s.rank%d" % (prefix, rank)
+    with open(part + "." + ext, "wb") as f:
+        f.write(rt)
+    with open(part + ".maf", "wb") as f:
+        f.write(mt)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        out_ext, maf_ext = ((ext + ".gz") if p.pass_num == 1 else "bam", "maf.gz") if gz else (ext, "maf")
+        with open(prefix + "." + out_ext, "wb") as fr, open(prefix + "." + maf_ext, "wb") as fm:
+            if p.pass_num > 1:
+                fr.write(ctx.deflate_buffer(ctx.bam_header()) if gz else ctx.sam_header())
+            for r in range(world):
+                with open("%s.rank%d.%s" % (prefix, r, ext), "rb") as f:
+                    fr.write(f.read())
+                with open("%s.rank%d.maf" % (prefix, r), "rb") as f:
+                    fm.write(f.read())
+            if gz:
+                if p.pass_num > 1 or fr.tell() == 0:
+                    fr.write(P.BGZF_EOF)
+                if fm.tell() == 0:
+                    fm.write(P.BGZF_EOF)
+    if world > 1:
+        dist.barrier()
+    os.remove(part + "." + ext)
+    os.remove(part + ".maf")
+    # ---- C2: counters
+    st = ctx.stats() if n > 0 else None
+    ints = torch.tensor([st.res_num, st.res_len_total, st.res_sub_num, st.res_ins_num, st.res_del_num] if st else [0] * 5,
+                        dtype=torch.int64, device=cdev)
+    acc = torch.tensor([st.res_accuracy_mean * st.res_pass_num if st and st.res_num else 0.0], dtype=torch.float64, device=cdev)
+    mn = torch.tensor([st.res_len_min if st and st.res_num else 2**62], dtype=torch.int64, device=cdev)
+    mx = torch.tensor([st.res_len_max if st else 0], dtype=torch.int64, device=cdev)
+    if world > 1:
+        dist.all_reduce(ints)
+        dist.all_reduce(acc)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        nr, tot, ns, ni, nd = (int(x) for x in ints.tolist())
+        passes = max(1, nr * p.pass_num)
+        sys.stderr.write(":::: Simulation stats ::::\n\nread num. : %d\n" % nr)
+        sys.stderr.write("read length mean : %f\n" % (tot / passes))
+        sys.stderr.write("read length min : %d\nread length max : %d\n" % (int(mn.item()) if nr else 0, int(mx.item())))
+        sys.stderr.write("read accuracy mean : %f\n" % (float(acc.item()) / passes))
+        sys.stderr.write("substitution rate. : %f\ninsertion rate. : %f\ndeletion rate. : %f\n\n"
+                         % ((ns / tot, ni / tot, nd / tot) if tot else (0.0, 0.0, 0.0)))
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -32,6 +32,31 @@ def test_run_multi_two_ranks(case, batch, tmp_path):
     assert not [k for k in outs if ".rank" in k]
 
 
+@pytest.mark.parametrize("case", ["trans_errhmm_sequel", "trans_errhmm_ont_hpbias4", "trans_qshmm_rsii", "templ_errhmm_sequel",
+                                  "templ_errhmm_rsii_pass3_hpbias2", "templ_qshmm_rsii_pass2"])
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_run_multi_unit_strategies(case, ranks, tmp_path):
+    """trans / templ: every rank simulates one contiguous block of the unit set's reads (pbsim_simulate_units_range);
+    the blocks stitched in rank order are the golden bytes"""
+    args = harness.resolve(CASES[case]["args"])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(32500 + os.getpid() % 1000), "-m", "pbsim3_amd.run_multi"] + args + \
+          ["--prefix", str(tmp_path / "out"), "--backend", "gloo", "--one-gpu", "--scratch-mb", "256"]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=harness.ROOT,
+                       env=dict(os.environ, PYTHONPATH=harness.ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    outs = harness.collect(str(tmp_path))
+    want = MANIFEST[f"{case}/philox"]
+    keys = [k for k in want if k.endswith((".fq", ".maf", ".sam"))]
+    assert keys
+    for k in keys:
+        assert harness.sha(outs[k]) == want[k]["sha256"], k
+    assert not [k for k in outs if ".rank" in k]
+    n_reads = outs[".fq"].count(b"\n") // 4 if ".fq" in outs else None
+    if n_reads is not None:
+        assert ("read num. : %d" % n_reads) in p.stderr
+
+
 @pytest.mark.parametrize("case,batch", [("wgs_errhmm-ont_quirk", "9"), ("wgs_qshmm_rsii_pass3", "5")])
 def test_run_multi_gzip_members_stitch(case, batch, tmp_path):
     """--gzip: every rank compresses on its GPU; the stitched members inflate to the golden bytes
