@@ -64,3 +64,35 @@ def test_two_ranks_reproduce_single_context(batch):
         assert res[0][rec][0] == res[1][rec][0] == stats[rec].res_num
         assert fq == want["_%04d.fq" % (rec + 1)]
         assert maf == want["_%04d.maf" % (rec + 1)]
+
+
+def test_unit_range_shards_concatenate_to_the_whole(tmp_path):
+    """pbsim_simulate_units_range: any partition of 1 .. pbsim_unit_reads() into contiguous blocks gives, concatenated,
+    the bytes of pbsim_simulate_trans; the shard statistics add up; bad ranges are refused"""
+    import pbsim3_amd as P
+    from pbsim3_amd import args as A
+    argv = harness.resolve(CASES["trans_errhmm_sequel"]["args"])
+    p, a = A.parse(argv)
+    with P.Context(p, 0) as ctx:
+        ctx.load_errhmm(a["--errhmm"])
+        n_units, total = ctx.load_transcript_file(a["--transcript"])
+        R = ctx.unit_reads()
+        assert n_units > 0 and R == total
+        whole = ctx.simulate_trans()
+        st = ctx.stats()
+        for cuts in ([0, R], [0, 1, R], [0, R // 3, R // 3, 2 * R // 3, R - 1, R]):
+            rt = mt = b""
+            n = bases = 0
+            for lo, hi in zip(cuts, cuts[1:]):
+                r, m = ctx.simulate_units_range(lo + 1, hi - lo)
+                rt += r
+                mt += m
+                if hi > lo:
+                    s = ctx.stats()
+                    n += s.res_num
+                    bases += s.res_len_total
+            assert (rt, mt) == whole
+            assert (n, bases) == (st.res_num, st.res_len_total)
+        for first, cnt in ((0, 1), (1, R + 1), (R + 1, 1), (1, -1)):
+            with pytest.raises(P.PbsimError):
+                ctx.simulate_units_range(first, cnt)
