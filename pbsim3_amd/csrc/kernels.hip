@@ -85,6 +85,16 @@ __device__ __forceinline__ uint32_t complement4(uint32_t w) {
   return w ^ (at * 0x15u) ^ (cg * 0x04u);                          // 'A'^'T' = 0x15, 'C'^'G' = 0x04
 }
 
+// w % 3 of a 31-bit draw: 3 q == -q (mod 4) and the remainder is below 4, so w - 3 q == (w + q) & 3
+__device__ __forceinline__ uint32_t mod3(uint32_t w) { return (w + __umulhi(w, 0x55555556u)) & 3u; }
+
+// inserted base (mut.ins_nt, pbsim.cpp:5485): "ATGC"[w % 8] for w % 8 < 4, else a copy of the reference base --
+// one byte select from the eight bytes {nt nt nt nt | C G T A}
+__device__ __forceinline__ uint32_t ins_base(uint32_t w, uint32_t nt) {
+  const uint32_t nt4 = __builtin_amdgcn_perm(0u, nt, 0u);  // byte 0 in all four bytes
+  return __builtin_amdgcn_perm(nt4, kATGC, (w & 7u) | 0x0c0c0c00u);
+}
+
 // mut.sub_nt_{a,t,g,c} (pbsim.cpp:5481-5484) packed little-endian
 __device__ __forceinline__ uint32_t sub_table(uint32_t nt) {
   uint32_t t = 0;
@@ -574,7 +584,7 @@ template <bool kHpBits>
 struct RefCursor {
   const uint64_t *lane_seq, *lane_hp;
   int64_t p_first;
-  uint32_t pl0, cur_wl;
+  uint32_t pl0, pl0s, smask, cur_wl;
   int wstep, rel;
   uint64_t wseq, whp, nseq, nhp;
   bool minus, need_next;
@@ -586,6 +596,8 @@ struct RefCursor {
     minus = minus_;
     p_first = minus ? (off + L - 1) : off;
     pl0 = (uint32_t)p_first;  // low bits are all the cursor arithmetic needs
+    smask = minus ? 0xffffffffu : 0u;  // pl0 -+ ro as ONE v_xad_u32: (ro ^ smask) + (pl0 - smask)
+    pl0s = pl0 - smask;
     wstep = minus ? -1 : 1;
     lane_seq = reinterpret_cast<const uint64_t *>(ref.seq) + (p_first >> 3);
     lane_hp = reinterpret_cast<const uint64_t *>(ref.hp) + (p_first >> 3);
@@ -607,7 +619,7 @@ struct RefCursor {
   // raw reference byte (forward strand, not complemented; with kHpBits bit 7 is the hp == 11 flag, which the s_comp
   // table drops) and homopolymer class at read offset ro
   __device__ __forceinline__ void at(int ro, bool act, uint32_t *raw, uint32_t *hp) {
-    const uint32_t pl = minus ? (pl0 - (uint32_t)ro) : (pl0 + (uint32_t)ro);
+    const uint32_t pl = ((uint32_t)ro ^ smask) + pl0s;
     const bool cross = act && ((pl >> 3) != cur_wl);
     wseq = cross ? nseq : wseq;
     cur_wl = cross ? (pl >> 3) : cur_wl;
@@ -780,7 +792,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
         e = (uint32_t)(rem >= (em.z & 0xffffu)) + (uint32_t)(rem >= (em.z >> 16));
         e = del ? 3u : e;
       }
-      uint32_t subb = s_sub[nt * 4u + w.w % 3u];  // 0 for a non-ACGT reference base
+      uint32_t subb = s_sub[nt * 4u + mod3(w.w)];  // 0 for a non-ACGT reference base
       const bool need1 =
           act && ((mode == kModeBelow && e == 0) || (mode == kModeAbove && e != 0) || (subb == 0 && e == 1));
       if (need1) {
@@ -793,12 +805,12 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
         if (subb == 0) subb = (kATGC >> ((v.z & 3u) * 8u)) & 0xffu;
       }
       // ---- emit
-      const uint32_t insb = (w.w & 4u) ? nt : ((kATGC >> ((w.w & 3u) * 8u)) & 0xffu);
-      const uint32_t b = (e == 1) ? subb : (e == 2) ? insb : nt;
-      const uint32_t mr = (e == 3) ? 0u : b;  // 0 marks a deleted column; the text kernel prints '-' there
+      // the read row's byte is byte e of {nt, substituted, inserted, 0}: 0 marks a deleted column (the text kernel prints
+      // '-' there).  One v_perm_b32 selects it and drops it into byte j of the accumulator.
+      const uint32_t cand = nt | (subb << 8) | (ins_base(w.w, nt) << 16);
+      acc_r = __builtin_amdgcn_perm(cand, acc_r, (0x03020100u & ~(0xffu << (8 * j))) + ((4u + e) << (8 * j)));
       const uint32_t mf = (e == 2) ? (uint32_t)'-' : nt;
-      acc_r |= mr << (8 * j);  // columns past the lane's last one are never read back (maf_len bounds them)
-      acc_f |= mf << (8 * j);
+      acc_f |= mf << (8 * j);  // columns past the lane's last one are never read back (maf_len bounds them)
       q += (act && e != 3) ? 1 : 0;
       nsub += (act && e == 1) ? 1 : 0;
       ro += (act && e != 2) ? 1 : 0;
