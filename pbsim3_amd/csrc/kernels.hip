@@ -148,8 +148,24 @@ __device__ __forceinline__ int put_dec(char *dst, int64_t v) {
 // `strip` = 0x7f once bit 7 of a byte may already carry another tile's hp == 11 flag (k_hp_final), else 0xff
 __device__ __forceinline__ uint32_t ref_char(const uint8_t *seq, int64_t i, int keep_first_case, uint32_t strip = 0xffu) {
   const uint32_t c = seq[i] & strip;
-  if (keep_first_case && (i == 0 || seq[i - 1] == '\n')) return c;
+  if (keep_first_case && (i == 0 || (seq[i - 1] & strip) == '\n')) return c;
   return to_upper(c);
+}
+
+// The 16 characters base .. base + 15 as ref_char() gives them, from ONE 16-byte load (base is a multiple of 16, the
+// buffer ends with 64 bytes of padding); *prev = the character in front of the chunk (0x100 in front of the unit).
+__device__ __forceinline__ void ref_chunk(const uint8_t *seq, int64_t base, int keep_first_case, uint32_t strip, uint32_t c[16],
+                                          uint32_t *prev) {
+  const uint4 v = *reinterpret_cast<const uint4 *>(seq + base);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t before = (base > 0) ? (uint32_t)(seq[base - 1] & strip) : (uint32_t)'\n';  // the start of the unit is a line start
+  *prev = (base > 0) ? ref_char(seq, base - 1, keep_first_case, strip) : 0x100u;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const uint32_t raw = ((w[k >> 2] >> (8 * (k & 3))) & 0xffu) & strip;
+    c[k] = (keep_first_case && before == '\n') ? raw : to_upper(raw);
+    before = raw;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_hp_breaks(const uint8_t *seq, int64_t len, int keep_first_case,
@@ -164,11 +180,13 @@ __global__ __launch_bounds__(256) void k_hp_breaks(const uint8_t *seq, int64_t l
   long long first = 0x7fffffffffffffffLL, last = -1;
   uint32_t high = 0;
   if (base < len) {
-    uint32_t prev = (base > 0) ? ref_char(seq, base - 1, keep_first_case) : 0x100u;
+    uint32_t cc[16], prev;
+    ref_chunk(seq, base, keep_first_case, 0xffu, cc, &prev);
+#pragma unroll
     for (int k = 0; k < 16; k++) {
       const int64_t i = base + k;
       if (i >= len) break;
-      const uint32_t c = ref_char(seq, i, keep_first_case);
+      const uint32_t c = cc[k];
       high |= c;
       if (c != prev) {
         if (first > i) first = i;
@@ -261,11 +279,12 @@ __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int
   long long first = 0x7fffffffffffffffLL, last = -1;
   int n = 0;
   if (base < len) {
-    uint32_t prev = (base > 0) ? ref_char(seq, base - 1, keep_first_case, strip) : 0x100u;
+    uint32_t prev;
+    ref_chunk(seq, base, keep_first_case, strip, c, &prev);
+#pragma unroll
     for (int k = 0; k < 16; k++) {
       const int64_t i = base + k;
       if (i >= len) break;
-      c[k] = ref_char(seq, i, keep_first_case, strip);
       brk[k] = (c[k] != prev);
       if (brk[k]) {
         if (first > i) first = i;
@@ -300,14 +319,26 @@ __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int
       next_start[k] = nxt;
       if (brk[k]) nxt = base + k;
     }
-    for (int k = 0; k < n; k++) {
+    uint32_t so[4] = {0, 0, 0, 0}, ho[4] = {0, 0, 0, 0};  // the 16 sequence / hp bytes, packed
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k >= n) break;
       const long long run = next_start[k] - start[k];
       // nnum++ ; if (nnum > 11) nnum = 10  (pbsim.cpp:1045-1048): 11,13,.. -> 11 ; 12,14,.. -> 10
       uint32_t v = (run <= 11) ? (uint32_t)run : ((run & 1) ? 11u : 10u);
       if (c[k] == 'N') v = 1;  // pbsim.cpp:1050-1054
-      hp[base + k] = (uint8_t)v;
-      seq[base + k] = (uint8_t)(c[k] | ((flag && v == 11u) ? 0x80u : 0u));
+      ho[k >> 2] |= v << (8 * (k & 3));
+      so[k >> 2] |= (c[k] | ((flag && v == 11u) ? 0x80u : 0u)) << (8 * (k & 3));
       if (c[k] != '\n') atomicAdd(&s_hist[v], 1u);
+    }
+    if (n == 16) {
+      *reinterpret_cast<uint4 *>(seq + base) = make_uint4(so[0], so[1], so[2], so[3]);
+      if (!flag) *reinterpret_cast<uint4 *>(hp + base) = make_uint4(ho[0], ho[1], ho[2], ho[3]);  // the flag replaces the array
+    } else {
+      for (int k = 0; k < n; k++) {
+        seq[base + k] = (uint8_t)(so[k >> 2] >> (8 * (k & 3)));
+        if (!flag) hp[base + k] = (uint8_t)(ho[k >> 2] >> (8 * (k & 3)));
+      }
     }
   }
   __syncthreads();
