@@ -119,6 +119,12 @@ int pbsim_load_qshmm(pbsim_ctx *ctx, const char *path);         /* set_qshmm  :5
  * (1-based).  The _device form takes a pointer already in this GPU's HBM. */
 int pbsim_set_reference(pbsim_ctx *ctx, const uint8_t *seq, int64_t len, int64_t record_index);
 int pbsim_set_reference_device(pbsim_ctx *ctx, const void *seq_device, int64_t len, int64_t record_index);
+/* Optional: hand the NEXT record over early.  Its upload and preparation (toupper + homopolymer lengths, get_genome_seq
+ * pbsim.cpp:1014-1065) run on a stream of their own beside the simulation of the current record; the next
+ * pbsim_set_reference* call with the same pointer and length adopts the result instead of doing the work again (any other
+ * call drops it).  The bytes must not change in between.  wgs only. */
+int pbsim_prefetch_reference(pbsim_ctx *ctx, const uint8_t *seq, int64_t len);
+int pbsim_prefetch_reference_device(pbsim_ctx *ctx, const void *seq_device, int64_t len);
 /* --hp-del-bias != 1 needs the homopolymer census of ALL records first
  * (pbsim.cpp:677-696): call once per record, then pbsim_finish_hp_census(). */
 int pbsim_add_hp_census(pbsim_ctx *ctx, const uint8_t *seq, int64_t len);

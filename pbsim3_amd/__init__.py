@@ -71,6 +71,8 @@ API = [
     ("pbsim_set_templates", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_int64)]),
     ("pbsim_simulate_templ", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
+    ("pbsim_prefetch_reference", C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    ("pbsim_prefetch_reference_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("pbsim_simulate_units_range", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(Sink)]),
     ("pbsim_unit_reads", C.c_int64, [C.c_void_p]),
     ("pbsim_load_transcript_file", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
@@ -212,6 +214,10 @@ class Context:
 
     def set_reference_device(self, ptr: int, length: int, record_index: int):
         _check(self.lib.pbsim_set_reference_device(self.h, C.c_void_p(ptr), length, record_index))
+
+    def prefetch_reference_device(self, ptr: int, length: int):
+        """upload + prepare the NEXT record beside the current simulation; set_reference_device(ptr, length, ...) adopts it"""
+        _check(self.lib.pbsim_prefetch_reference_device(self.h, C.c_void_p(ptr), length))
 
     def add_hp_census(self, seq: bytes):
         buf = C.create_string_buffer(seq, len(seq))

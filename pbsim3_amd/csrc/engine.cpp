@@ -154,6 +154,11 @@ struct pbsim_ctx {
   DevBuf d_prob2len, d_prob2acc, d_cls, d_qs_tabs;
   // reference
   DevBuf d_seq_own, d_hp, d_tiles, d_ref_flags;
+  // the NEXT record, uploaded and prepared beside the current record's simulation (pbsim_prefetch_reference*)
+  DevBuf d_seq_next, d_hp_next, d_tiles_next, d_ref_flags_next;
+  hipStream_t prefetch_stream = nullptr;
+  const void *pf_src = nullptr;
+  int64_t pf_len = 0;
   bool seq_hp_flag = false;  // bit 7 of the prepared sequence bytes carries hp == 11 (k_hp_final)
   const uint8_t *d_seq = nullptr;
   int64_t ref_len = 0;
@@ -248,24 +253,33 @@ int read_flags(pbsim_ctx *c, DeviceFlags *f) {
   return PBSIM_SUCCEEDED;
 }
 
-// upper-case + homopolymer lengths on the GPU; adds the unit's hp census to `census_out`
-int prepare_reference(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int keep_first_case, int64_t census_out[kHpSlots]) {
+// upper-case + homopolymer lengths on the GPU: enqueue on `stream` ...
+static int enqueue_prepare(pbsim_ctx *c, uint8_t *d_seq, DevBuf &hp, DevBuf &tiles, DevBuf &flags, int64_t len, int keep_first_case,
+                           hipStream_t stream) {
   const int64_t n_tiles = (len + kHpTile - 1) / kHpTile;
-  HIP_OK(c->d_hp.ensure((size_t)len + 64));
-  HIP_OK(c->d_tiles.ensure((size_t)(n_tiles + 1) * 4 * sizeof(int64_t)));
-  HIP_OK(c->d_ref_flags.ensure(sizeof(DeviceFlags)));
-  HIP_OK(hipMemsetAsync(c->d_ref_flags.p, 0, sizeof(DeviceFlags), c->stream));
-  HIP_OK(hipMemsetAsync(c->d_hp.as<uint8_t>() + len, 0, 64, c->stream));
-  int64_t *t = c->d_tiles.as<int64_t>();
-  launch_prepare_reference(d_seq, c->d_hp.as<uint8_t>(), c->p.hp_del_bias == 1, len, t, t + (n_tiles + 1), t + 2 * (n_tiles + 1),
-                           t + 3 * (n_tiles + 1), keep_first_case, c->d_ref_flags.as<DeviceFlags>(), c->stream);
+  HIP_OK(hp.ensure((size_t)len + 64));
+  HIP_OK(tiles.ensure((size_t)(n_tiles + 1) * 4 * sizeof(int64_t)));
+  HIP_OK(flags.ensure(sizeof(DeviceFlags)));
+  HIP_OK(hipMemsetAsync(flags.p, 0, sizeof(DeviceFlags), stream));
+  HIP_OK(hipMemsetAsync(hp.as<uint8_t>() + len, 0, 64, stream));
+  int64_t *t = tiles.as<int64_t>();
+  launch_prepare_reference(d_seq, hp.as<uint8_t>(), c->p.hp_del_bias == 1, len, t, t + (n_tiles + 1), t + 2 * (n_tiles + 1),
+                           t + 3 * (n_tiles + 1), keep_first_case, flags.as<DeviceFlags>(), stream);
   HIP_OK(hipGetLastError());
+  return PBSIM_SUCCEEDED;
+}
+// ... and collect: adds the unit's hp census to `census_out`, notes whether the sequence bytes carry the hp == 11 flag
+static int finish_prepare(pbsim_ctx *c, DevBuf &flags, hipStream_t stream, int64_t census_out[kHpSlots]) {
   DeviceFlags f;
-  HIP_OK(hipMemcpyAsync(&f, c->d_ref_flags.p, sizeof f, hipMemcpyDeviceToHost, c->stream));
-  HIP_OK(hipStreamSynchronize(c->stream));
+  HIP_OK(hipMemcpyAsync(&f, flags.p, sizeof f, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
   for (int i = 0; i < kHpSlots; i++) census_out[i] += (int64_t)f.hpfreq[i];
   c->seq_hp_flag = c->p.hp_del_bias == 1 && !f.high_bytes;
   return PBSIM_SUCCEEDED;
+}
+int prepare_reference(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int keep_first_case, int64_t census_out[kHpSlots]) {
+  if (!enqueue_prepare(c, d_seq, c->d_hp, c->d_tiles, c->d_ref_flags, len, keep_first_case, c->stream)) return PBSIM_FAILED;
+  return finish_prepare(c, c->d_ref_flags, c->stream, census_out);
 }
 
 void note_hp11(pbsim_ctx *c, const int64_t census[kHpSlots]) {
@@ -425,6 +439,7 @@ void pbsim_destroy(pbsim_ctx *c) {
       if (sl.ev_cp[i]) (void)hipEventDestroy(sl.ev_cp[i]);
     }
   }
+  if (c->prefetch_stream) (void)hipStreamDestroy(c->prefetch_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -480,13 +495,55 @@ int pbsim_finish_hp_census(pbsim_ctx *c) {
   return PBSIM_SUCCEEDED;
 }
 
-static int set_reference_common(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int64_t record_index) {
+// pbsim_prefetch_reference*: upload + prepare the NEXT record on a stream of its own while the current one is simulated; the
+// following pbsim_set_reference* call with the same pointer and length adopts it instead of doing the work again
+static int prefetch_reference(pbsim_ctx *c, const void *seq, int64_t len, hipMemcpyKind kind) {
+  if (!c || !seq) return fail("pbsim_prefetch_reference: bad argument");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  if (len < 1 || len > 1000000000LL) return fail("pbsim_prefetch_reference: bad length");
+  if (c->p.strategy != PBSIM_STRATEGY_WGS) return fail("pbsim_prefetch_reference: strategy is not wgs");
+  if (!c->prefetch_stream) HIP_OK(hipStreamCreateWithFlags(&c->prefetch_stream, hipStreamNonBlocking));
+  c->pf_src = nullptr;
+  HIP_OK(hipStreamSynchronize(c->prefetch_stream));  // an earlier prefetch that was never adopted
+  HIP_OK(c->d_seq_next.ensure((size_t)len + 64));
+  HIP_OK(hipMemcpyAsync(c->d_seq_next.p, seq, (size_t)len, kind, c->prefetch_stream));
+  HIP_OK(hipMemsetAsync(c->d_seq_next.as<uint8_t>() + len, 0, 64, c->prefetch_stream));
+  if (!enqueue_prepare(c, c->d_seq_next.as<uint8_t>(), c->d_hp_next, c->d_tiles_next, c->d_ref_flags_next, len, 0, c->prefetch_stream))
+    return PBSIM_FAILED;
+  c->pf_src = seq;
+  c->pf_len = len;
+  return PBSIM_SUCCEEDED;
+}
+int pbsim_prefetch_reference(pbsim_ctx *c, const uint8_t *seq, int64_t len) {
+  return prefetch_reference(c, seq, len, hipMemcpyHostToDevice);
+}
+int pbsim_prefetch_reference_device(pbsim_ctx *c, const void *seq_device, int64_t len) {
+  return prefetch_reference(c, seq_device, len, hipMemcpyDeviceToDevice);
+}
+static bool take_prefetch(pbsim_ctx *c, const void *seq, int64_t len) {
+  const bool hit = c->pf_src && c->pf_src == seq && c->pf_len == len;
+  c->pf_src = nullptr;
+  return hit;
+}
+
+// `prefetched`: the record is already in d_seq_next / d_hp_next, its preparation enqueued on the prefetch stream
+static int set_reference_common(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int64_t record_index, bool prefetched = false) {
   if (len < 1) return fail("Reference is too short.");
   if (len > 1000000000LL) return fail("Reference is too long. Acceptable length <= 1000000000.");
   if (c->p.hp_del_bias != 1 && !c->census_done)
     return fail("--hp-del-bias != 1 needs pbsim_add_hp_census() for every record and pbsim_finish_hp_census() first");
   int64_t census[kHpSlots] = {0};
-  if (!prepare_reference(c, d_seq, len, 0, census)) return PBSIM_FAILED;
+  if (prefetched) {
+    if (!finish_prepare(c, c->d_ref_flags_next, c->prefetch_stream, census)) return PBSIM_FAILED;
+    std::swap(c->d_seq_own.p, c->d_seq_next.p);
+    std::swap(c->d_seq_own.bytes, c->d_seq_next.bytes);
+    std::swap(c->d_hp.p, c->d_hp_next.p);
+    std::swap(c->d_hp.bytes, c->d_hp_next.bytes);
+    d_seq = c->d_seq_own.as<uint8_t>();
+  } else if (!prepare_reference(c, d_seq, len, 0, census)) {
+    return PBSIM_FAILED;
+  }
   note_hp11(c, census);
   c->d_seq = d_seq;
   c->ref_len = len;
@@ -500,6 +557,7 @@ int pbsim_set_reference(pbsim_ctx *c, const uint8_t *seq, int64_t len, int64_t r
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
   if (len < 1) return fail("Reference is too short.");
+  if (take_prefetch(c, seq, len)) return set_reference_common(c, nullptr, len, record_index, true);
   HIP_OK(c->d_seq_own.ensure((size_t)len + 64));
   HIP_OK(hipMemcpyAsync(c->d_seq_own.p, seq, (size_t)len, hipMemcpyHostToDevice, c->stream));
   HIP_OK(hipMemsetAsync(c->d_seq_own.as<uint8_t>() + len, 0, 64, c->stream));
@@ -511,6 +569,7 @@ int pbsim_set_reference_device(pbsim_ctx *c, const void *seq_device, int64_t len
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
   if (len < 1) return fail("Reference is too short.");
+  if (take_prefetch(c, seq_device, len)) return set_reference_common(c, nullptr, len, record_index, true);
   // the kernels read whole dwords and upper-case in place: keep an owned, padded copy
   HIP_OK(c->d_seq_own.ensure((size_t)len + 64));
   HIP_OK(hipMemcpyAsync(c->d_seq_own.p, seq_device, (size_t)len, hipMemcpyDeviceToDevice, c->stream));

@@ -203,3 +203,35 @@ def test_two_contexts_alive_at_once(tmp_path):
             got_a["_%04d.fq" % i], got_a["_%04d.maf" % i] = rt_a, mt_a
             got_b["_%04d.sam" % i], got_b["_%04d.maf" % i] = cb.sam_header() + rt_b, mt_b
     assert got_a == alone_a and got_b == alone_b
+
+
+def test_prefetched_reference_is_adopted_and_changes_nothing():
+    """pbsim_prefetch_reference_device: the next record is uploaded and prepared beside the current simulation; the
+    bytes of every record equal a run without prefetch, also when a prefetch is dropped (other pointer) or unused"""
+    import torch
+    import pbsim3_amd as P
+    from pbsim3_amd import args as A
+    argv = harness.resolve(ONT + ["--genome", "INPUT:quirk.fa", "--depth", "6", "--seed", "31"])
+    p, a = A.parse(argv)
+    recs = A.read_fasta(a["--genome"])[0]
+    rng = np.random.default_rng(5)
+    recs = recs + [_rand_seq(rng, 30000).encode() + b"A" * 13 + _rand_seq(rng, 9000).encode()]
+    dev = [torch.frombuffer(bytearray(r), dtype=torch.uint8).cuda() for r in recs]
+    decoy = torch.zeros(1000, dtype=torch.uint8, device="cuda") + 65
+
+    def run(mode):
+        outs = []
+        with P.Context(p, 0) as ctx:
+            ctx.load_errhmm(a["--errhmm"])
+            for i, t in enumerate(dev):
+                ctx.set_reference_device(t.data_ptr(), t.numel(), i + 1)
+                if mode == "prefetch" and i + 1 < len(dev):
+                    ctx.prefetch_reference_device(dev[i + 1].data_ptr(), dev[i + 1].numel())
+                if mode == "decoy":
+                    ctx.prefetch_reference_device(decoy.data_ptr(), decoy.numel())
+                outs.append(ctx.simulate_wgs())
+        return outs
+
+    plain = run("none")
+    assert run("prefetch") == plain
+    assert run("decoy") == plain
