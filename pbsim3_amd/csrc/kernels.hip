@@ -267,28 +267,31 @@ __global__ __launch_bounds__(1024) void k_hp_carry(const int64_t *tile_first, co
 __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int flag_hp11, int64_t len,
                                                     int keep_first_case, const int64_t *carry_start,
                                                     const int64_t *carry_next, DeviceFlags *flags) {
-  __shared__ long long s_last[256], s_first[256];
+  // positions inside the tile as int32 offsets from the tile's first base (-1 / kNone: no break)
+  constexpr int kNone = 0x7fffffff;
+  __shared__ int s_last[256], s_first[256];
   __shared__ unsigned int s_hist[12];
   const int tid = threadIdx.x;
   if (tid < 12) s_hist[tid] = 0;
-  const int64_t base = (int64_t)blockIdx.x * kHpTile + (int64_t)tid * 16;
+  const int64_t tile0 = (int64_t)blockIdx.x * kHpTile;
+  const int tb = tid * 16;  // this thread's first base, relative to the tile
+  const int64_t base = tile0 + tb;
   const bool flag = flag_hp11 && !flags->high_bytes;
   const uint32_t strip = flag ? 0x7fu : 0xffu;
   uint32_t c[16];
   bool brk[16];
-  long long first = 0x7fffffffffffffffLL, last = -1;
+  int first = kNone, last = -1;
   int n = 0;
   if (base < len) {
     uint32_t prev;
     ref_chunk(seq, base, keep_first_case, strip, c, &prev);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const int64_t i = base + k;
-      if (i >= len) break;
+      if (base + k >= len) break;
       brk[k] = (c[k] != prev);
       if (brk[k]) {
-        if (first > i) first = i;
-        last = i;
+        if (first == kNone) first = tb + k;
+        last = tb + k;
       }
       prev = c[k];
       n = k + 1;
@@ -299,37 +302,45 @@ __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int
   __syncthreads();
   // inclusive max-scan of s_last / inclusive suffix min-scan of s_first
   for (int d = 1; d < 256; d <<= 1) {
-    const long long a = (tid >= d) ? s_last[tid - d] : -1;
-    const long long b = (tid + d < 256) ? s_first[tid + d] : 0x7fffffffffffffffLL;
+    const int a = (tid >= d) ? s_last[tid - d] : -1;
+    const int b = (tid + d < 256) ? s_first[tid + d] : kNone;
     __syncthreads();
     if (a > s_last[tid]) s_last[tid] = a;
     if (b < s_first[tid]) s_first[tid] = b;
     __syncthreads();
   }
   if (n > 0) {
-    long long cur_start = (tid > 0 && s_last[tid - 1] >= 0) ? s_last[tid - 1] : carry_start[blockIdx.x];
-    long long nxt = (tid < 255 && s_first[tid + 1] != 0x7fffffffffffffffLL) ? s_first[tid + 1]
-                                                                            : carry_next[blockIdx.x];
-    long long start[16], next_start[16];
-    for (int k = 0; k < n; k++) {
-      if (brk[k]) cur_start = base + k;
+    // run boundaries relative to THIS THREAD's first base: a run is at most 10^9 long, so int32 holds every difference
+    const int64_t cs = (tid > 0 && s_last[tid - 1] >= 0) ? tile0 + s_last[tid - 1] : carry_start[blockIdx.x];
+    const int64_t nx = (tid < 255 && s_first[tid + 1] != kNone) ? tile0 + s_first[tid + 1] : carry_next[blockIdx.x];
+    int cur_start = (int)(cs - base), nxt = (int)(nx - base);
+    int start[16], next_start[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k < n && brk[k]) cur_start = k;
       start[k] = cur_start;
     }
-    for (int k = n - 1; k >= 0; k--) {
+#pragma unroll
+    for (int k = 15; k >= 0; k--) {
       next_start[k] = nxt;
-      if (brk[k]) nxt = base + k;
+      if (k < n && brk[k]) nxt = k;
     }
     uint32_t so[4] = {0, 0, 0, 0}, ho[4] = {0, 0, 0, 0};  // the 16 sequence / hp bytes, packed
+    unsigned long long census = 0;                        // 12 counters of 5 bits (<= 16 bases each)
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       if (k >= n) break;
-      const long long run = next_start[k] - start[k];
+      const int run = next_start[k] - start[k];
       // nnum++ ; if (nnum > 11) nnum = 10  (pbsim.cpp:1045-1048): 11,13,.. -> 11 ; 12,14,.. -> 10
       uint32_t v = (run <= 11) ? (uint32_t)run : ((run & 1) ? 11u : 10u);
       if (c[k] == 'N') v = 1;  // pbsim.cpp:1050-1054
       ho[k >> 2] |= v << (8 * (k & 3));
       so[k >> 2] |= (c[k] | ((flag && v == 11u) ? 0x80u : 0u)) << (8 * (k & 3));
-      if (c[k] != '\n') atomicAdd(&s_hist[v], 1u);
+      if (c[k] != '\n') census += 1ull << (5 * v);
+    }
+    for (int v = 0; v < 12; v++) {  // one LDS atomic per class this thread saw (a per-base atomic serialised on hp 1)
+      const unsigned int cnt = (unsigned int)(census >> (5 * v)) & 31u;
+      if (cnt) atomicAdd(&s_hist[v], cnt);
     }
     if (n == 16) {
       *reinterpret_cast<uint4 *>(seq + base) = make_uint4(so[0], so[1], so[2], so[3]);
