@@ -235,3 +235,16 @@ def test_prefetched_reference_is_adopted_and_changes_nothing():
     plain = run("none")
     assert run("prefetch") == plain
     assert run("decoy") == plain
+
+    # the host-pointer variant (pbsim_prefetch_reference): same pointer and length at pbsim_set_reference adopt the copy
+    import ctypes as C
+    bufs = [C.create_string_buffer(r, len(r)) for r in recs]
+    outs = []
+    with P.Context(p, 0) as ctx:
+        ctx.load_errhmm(a["--errhmm"])
+        for i, b in enumerate(bufs):
+            P._check(ctx.lib.pbsim_set_reference(ctx.h, C.cast(b, C.c_void_p), len(recs[i]), i + 1))
+            if i + 1 < len(bufs):
+                P._check(ctx.lib.pbsim_prefetch_reference(ctx.h, C.cast(bufs[i + 1], C.c_char_p), len(recs[i + 1])))
+            outs.append(ctx.simulate_wgs())
+    assert outs == plain
