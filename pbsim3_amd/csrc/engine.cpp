@@ -110,6 +110,7 @@ constexpr int kMaxSlots = 4;
 // k_text_rows prefetches whole 256-column tiles without bounds checks: up to two tiles (2 x 64 dwords x 256 B) past the
 // last wave's last row
 constexpr size_t kScratchSlack = 64u << 10;
+constexpr double kSinkBatchBases = 2.5e9;  // pbsim_simulate_wgs: expected bases per batch when the text goes to a sink
 
 struct Slot {
   hipStream_t stream = nullptr;
@@ -1277,7 +1278,11 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
     // (the text buffers need about as much again).
     size_t free_b = 0, total_b = 0;
     HIP_OK(hipMemGetInfo(&free_b, &total_b));
-    const double want = (double)quota * c->p.pass_num * 1.07 * regions_of(c) * 1.3 / n_slots + (64 << 20);
+    // With a sink the text leaves the GPU batch by batch (PCIe, host writes: ~0.15 s per Gbase), which hides any tail of
+    // the walks, while the first hipMalloc of a 25-GB text buffer costs 0.8 s: batches of ~2.5 Gbases there.
+    double batch_bases = (double)quota * c->p.pass_num / n_slots;
+    if (sink && (sink->on_read_text || sink->on_maf_text)) batch_bases = std::min(batch_bases, kSinkBatchBases);
+    const double want = batch_bases * 1.07 * regions_of(c) * 1.3 + (64 << 20);
     const double share = std::min(48.0 * (1LL << 30), 0.15 * (double)(free_b + c->s().d_scratch.bytes * n_slots));
     const int64_t auto_b = (int64_t)std::max(256.0 * (1 << 20), std::min(want, share));
     if (auto_b > c->scratch_budget || c->scratch_budget > 2 * auto_b) c->scratch_budget = auto_b;
