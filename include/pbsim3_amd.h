@@ -186,6 +186,8 @@ int64_t pbsim_bam_header(pbsim_ctx *ctx, char *buf, int64_t cap);
  * extra field (SAMv1 4.1), so the concatenation is a valid multi-member .gz and, for BAM records, a
  * valid BAM container once the caller has written a compressed header in front and the BGZF EOF marker
  * behind.  Decompressed bytes are exactly the text the sink would have received otherwise.
+ * Bit 2 (with bits 0 and 1): the two sinks are independent -- on_read_text is then called from a second host thread
+ * while on_maf_text runs on the caller's (two files are written side by side; never one callback concurrently with itself).
  * pbsim_batch_fetch_deflated is the batch-level primitive (after pbsim_batch_finalize; caps from
  * pbsim_deflate_bound).  pbsim_deflate_buffer runs host bytes through the same kernels (file headers). */
 int pbsim_set_deflate(pbsim_ctx *ctx, int mask);

@@ -426,8 +426,11 @@ int main(int argc, char **argv) {
     check(c.p.method == PBSIM_METHOD_ERR ? pbsim_load_errhmm(ctx, c.model.c_str()) : pbsim_load_qshmm(ctx, c.model.c_str()));
   }
   if (native_bam(c)) check(pbsim_set_bam_output(ctx, 1));
-  if (!c.no_gzip && c.gzip_on_gpu)  // bit 0: read sink, bit 1: MAF sink; a samtools pipe still wants SAM text
-    check(pbsim_set_deflate(ctx, (c.p.pass_num > 1 && c.use_samtools) ? 2 : 3));
+  if (!c.no_gzip && c.gzip_on_gpu) {  // bit 0: read sink, bit 1: MAF sink; a samtools pipe still wants SAM text
+    // bit 2: the read file and the MAF file are written by two host threads (each Out is touched by one of them only)
+    const char *one = getenv("PBSIM_CLI_ONE_WRITER");  // measurement knob: both files from the calling thread
+    check(pbsim_set_deflate(ctx, (c.p.pass_num > 1 && c.use_samtools) ? 2 : (one && *one == '1') ? 3 : 7));
+  }
   std::string err;
   char name[4096];
 

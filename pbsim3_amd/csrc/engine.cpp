@@ -19,6 +19,7 @@
 #include <chrono>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pbsim3_amd.h"
@@ -112,6 +113,17 @@ constexpr int kMaxSlots = 4;
 constexpr size_t kScratchSlack = 64u << 10;
 constexpr double kSinkBatchBases = 2.5e9;  // pbsim_simulate_wgs: expected bases per batch when the text goes to a sink
 
+// One deflate pipeline: staging for one piece of DF_PIECE_CHUNKS chunks, double-buffered dense output + pinned copies, its
+// own streams.  A slot owns two, so that its read text and its MAF text can be compressed, copied and handed to their
+// sinks side by side (pbsim_set_deflate bit 2).
+struct DfLane {
+  DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];
+  HostBuf h_df_total, h_df_out[2];
+  hipStream_t stream = nullptr;        // kernels of this lane
+  hipStream_t copy_stream = nullptr;   // D2H of compressed pieces
+  hipEvent_t ev_df[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
+};
+
 struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -123,12 +135,9 @@ struct Slot {
   DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len, d_row_dst;
   DevBuf d_scratch, d_read_text, d_maf_text;
   HostBuf h_read_text, h_maf_text, h_stats;
-  DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];  // deflate staging, one piece of DF_PIECE_CHUNKS chunks
-  HostBuf h_df_total, h_df_out[2];
+  DfLane df[2];                        // deflate staging: [0] read text (or any single stream), [1] MAF text beside it
   hipStream_t walk_stream = nullptr;   // low priority: the walk kernel only
   hipEvent_t ev_prep = nullptr;        // header + sort done (walk_stream waits for it)
-  hipStream_t copy_stream = nullptr;   // D2H of compressed pieces
-  hipEvent_t ev_df[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
   bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
   int64_t b_pass0 = 0;
@@ -179,6 +188,7 @@ struct pbsim_ctx {
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
   int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)
+  bool deflate_parallel = false;  // pbsim_set_deflate bit 2: the two sinks are served from two host threads
   DevBuf d_df_tables;          // crc slice-by-4 tables [4][256] + x^(8*128*k) [256]
   DevBuf d_df_prof;
 
@@ -432,13 +442,16 @@ void pbsim_destroy(pbsim_ctx *c) {
     if (sl.ev2) (void)hipEventDestroy(sl.ev2);
     if (sl.ev3) (void)hipEventDestroy(sl.ev3);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
-    if (sl.copy_stream) (void)hipStreamDestroy(sl.copy_stream);
+    for (DfLane &L : sl.df) {
+      if (L.stream) (void)hipStreamDestroy(L.stream);
+      if (L.copy_stream) (void)hipStreamDestroy(L.copy_stream);
+      for (int i = 0; i < 2; i++) {
+        if (L.ev_df[i]) (void)hipEventDestroy(L.ev_df[i]);
+        if (L.ev_cp[i]) (void)hipEventDestroy(L.ev_cp[i]);
+      }
+    }
     if (sl.walk_stream) (void)hipStreamDestroy(sl.walk_stream);
     if (sl.ev_prep) (void)hipEventDestroy(sl.ev_prep);
-    for (int i = 0; i < 2; i++) {
-      if (sl.ev_df[i]) (void)hipEventDestroy(sl.ev_df[i]);
-      if (sl.ev_cp[i]) (void)hipEventDestroy(sl.ev_cp[i]);
-    }
   }
   if (c->prefetch_stream) (void)hipStreamDestroy(c->prefetch_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1084,7 +1097,7 @@ int ensure_deflate_tables(pbsim_ctx *c) {
 // (DF_PIECE_CHUNKS chunks each) from pinned staging.  While the host consumes piece k-1 (a file write, a memcpy),
 // piece k is being copied down and the GPU may already be working for another slot.
 template <class F>
-int deflate_stream(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, F &&consume) {
+int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F &&consume) {
   if (n <= 0) return PBSIM_SUCCEEDED;
   if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
   const int64_t piece = (int64_t)DF_PIECE_CHUNKS * DF_CHUNK;
@@ -1094,6 +1107,7 @@ int deflate_stream(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, F &
   HIP_OK(sl.d_df_offsets.ensure((size_t)(max_ch + 1) * 8));
   HIP_OK(sl.h_df_total.ensure(16));
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
+  if (!sl.stream) HIP_OK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
   unsigned long long *d_prof = nullptr;
   if (getenv("PBSIM_DEFLATE_PROF")) {
     HIP_OK(c->d_df_prof.ensure(128));
@@ -1149,7 +1163,7 @@ int deflate_stream(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, F &
   return PBSIM_SUCCEEDED;
 }
 
-int deflate_to_host(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, char *host_dst, int64_t cap,
+int deflate_to_host(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, char *host_dst, int64_t cap,
                     int64_t *out_bytes) {
   int64_t written = 0;
   const int ok = deflate_stream(c, sl, d_text, n, [&](const char *z, int64_t k) {
@@ -1168,6 +1182,7 @@ int deflate_to_host(pbsim_ctx *c, Slot &sl, const uint8_t *d_text, int64_t n, ch
 int pbsim_set_deflate(pbsim_ctx *c, int on) {
   if (!c) return fail("bad argument");
   c->deflate = on & 3;
+  c->deflate_parallel = (on & 4) != 0;
   return PBSIM_SUCCEEDED;
 }
 
@@ -1182,10 +1197,10 @@ int pbsim_batch_fetch_deflated(pbsim_ctx *c, char *read_gz, int64_t read_cap, ch
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
   int64_t nr = 0, nm = 0;
-  if (read_gz && !deflate_to_host(c, c->s(), c->s().d_read_text.as<uint8_t>(), c->s().b_info.read_text_bytes, read_gz,
+  if (read_gz && !deflate_to_host(c, c->s().df[0], c->s().d_read_text.as<uint8_t>(), c->s().b_info.read_text_bytes, read_gz,
                                   read_cap, &nr))
     return PBSIM_FAILED;
-  if (maf_gz && !deflate_to_host(c, c->s(), c->s().d_maf_text.as<uint8_t>(), c->s().b_info.maf_text_bytes, maf_gz,
+  if (maf_gz && !deflate_to_host(c, c->s().df[0], c->s().d_maf_text.as<uint8_t>(), c->s().b_info.maf_text_bytes, maf_gz,
                                  maf_cap, &nm))
     return PBSIM_FAILED;
   if (read_gz_bytes) *read_gz_bytes = nr;
@@ -1204,7 +1219,8 @@ int pbsim_deflate_buffer(pbsim_ctx *c, const void *src, int64_t n, void *dst, in
   DevBuf d_in;
   HIP_OK(d_in.ensure((size_t)n + 16));
   HIP_OK(hipMemcpyAsync(d_in.p, src, (size_t)n, hipMemcpyHostToDevice, sl.stream));
-  return deflate_to_host(c, sl, d_in.as<uint8_t>(), n, (char *)dst, cap, out_bytes);
+  HIP_OK(hipStreamSynchronize(sl.stream));  // the lane's kernels run on its own stream
+  return deflate_to_host(c, sl.df[0], d_in.as<uint8_t>(), n, (char *)dst, cap, out_bytes);
 }
 
 static int deliver(pbsim_ctx *c, const pbsim_sink *sink) {
@@ -1219,27 +1235,43 @@ static int deliver(pbsim_ctx *c, const pbsim_sink *sink) {
     if ((!zr || !zm) &&
         !pbsim_batch_fetch(c, zr ? nullptr : (char *)c->s().h_read_text.p, zm ? nullptr : (char *)c->s().h_maf_text.p))
       return PBSIM_FAILED;
-    if (sink->on_read_text && bi.read_text_bytes) {
-      if (!zr) {
-        if (!sink->on_read_text(sink->user, (const char *)c->s().h_read_text.p, bi.read_text_bytes))
-          return fail("sink aborted (read text)");
-      } else if (!deflate_stream(c, c->s(), c->s().d_read_text.as<uint8_t>(), bi.read_text_bytes,
-                                 [&](const char *z, int64_t k) {
-                                   return sink->on_read_text(sink->user, z, k) ? PBSIM_SUCCEEDED
-                                                                               : fail("sink aborted (read text)");
-                                 }))
-        return PBSIM_FAILED;
-    }
-    if (sink->on_maf_text && bi.maf_text_bytes) {
-      if (!zm) {
-        if (!sink->on_maf_text(sink->user, (const char *)c->s().h_maf_text.p, bi.maf_text_bytes))
-          return fail("sink aborted (MAF text)");
-      } else if (!deflate_stream(c, c->s(), c->s().d_maf_text.as<uint8_t>(), bi.maf_text_bytes,
-                                 [&](const char *z, int64_t k) {
-                                   return sink->on_maf_text(sink->user, z, k) ? PBSIM_SUCCEEDED
-                                                                              : fail("sink aborted (MAF text)");
-                                 }))
-        return PBSIM_FAILED;
+    Slot &sl = c->s();
+    auto send_read = [&]() -> int {
+      if (!(sink->on_read_text && bi.read_text_bytes)) return PBSIM_SUCCEEDED;
+      if (!zr)
+        return sink->on_read_text(sink->user, (const char *)sl.h_read_text.p, bi.read_text_bytes) ? PBSIM_SUCCEEDED
+                                                                                                 : fail("sink aborted (read text)");
+      return deflate_stream(c, sl.df[0], sl.d_read_text.as<uint8_t>(), bi.read_text_bytes, [&](const char *z, int64_t k) {
+        return sink->on_read_text(sink->user, z, k) ? PBSIM_SUCCEEDED : fail("sink aborted (read text)");
+      });
+    };
+    auto send_maf = [&]() -> int {
+      if (!(sink->on_maf_text && bi.maf_text_bytes)) return PBSIM_SUCCEEDED;
+      if (!zm)
+        return sink->on_maf_text(sink->user, (const char *)sl.h_maf_text.p, bi.maf_text_bytes) ? PBSIM_SUCCEEDED
+                                                                                              : fail("sink aborted (MAF text)");
+      return deflate_stream(c, sl.df[1], sl.d_maf_text.as<uint8_t>(), bi.maf_text_bytes, [&](const char *z, int64_t k) {
+        return sink->on_maf_text(sink->user, z, k) ? PBSIM_SUCCEEDED : fail("sink aborted (MAF text)");
+      });
+    };
+    if (c->deflate_parallel && zr && zm && bi.read_text_bytes && bi.maf_text_bytes) {
+      // the two sinks are independent files: the read text goes through its lane on a second host thread while this one
+      // drives the MAF lane (a file's writers would serialise on its inode, two files do not)
+      if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
+      int ok_read = PBSIM_SUCCEEDED;
+      std::string err_read;
+      std::thread t([&]() {
+        (void)hipSetDevice(c->device);
+        ok_read = send_read();
+        if (!ok_read) err_read = g_err;  // the error string is thread local
+      });
+      const int ok_maf = send_maf();
+      t.join();
+      if (!ok_read) return fail(err_read);
+      if (!ok_maf) return PBSIM_FAILED;
+    } else {
+      if (!send_read()) return PBSIM_FAILED;
+      if (!send_maf()) return PBSIM_FAILED;
     }
   } else if (sink) {
     HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
