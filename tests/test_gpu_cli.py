@@ -90,3 +90,26 @@ def test_cli_transcripts_without_expression(tmp_path):
     for k in want:
         assert outs[k] == want[k], k
     assert b"nan" in outs[".stderr"] and outs[".fq"] == b""
+
+
+@pytest.mark.parametrize("case", ["wgs_qshmm_rsii_pass3", "trans_errhmm_sequel", "templ_qshmm_rsii_pass2", "wgs_errhmm_ont_hpbias5"])
+@pytest.mark.parametrize("one_writer", ["0", "1"])
+def test_cli_gpu_members_from_one_and_two_writer_threads(tmp_path, case, one_writer):
+    """Default CLI mode (members compressed on the GPU): with two writer threads (pbsim_set_deflate bit 2) and with one,
+    .fq.gz / .maf.gz inflate to the golden text and the .bam is a BGZF container that ends with the EOF marker."""
+    import gzip
+    import pbsim3_amd as P
+    p = subprocess.run([CLI] + harness.resolve(CASES[case]["args"]) + ["--prefix", str(tmp_path / "out")], capture_output=True,
+                       text=True, env=dict(os.environ, PBSIM_CLI_ONE_WRITER=one_writer))
+    assert p.returncode == 0, p.stderr[-2000:]
+    want = MANIFEST[f"{case}/philox"]
+    seen = 0
+    for n in sorted(os.listdir(tmp_path)):
+        raw = open(tmp_path / n, "rb").read()
+        if n.endswith((".fq.gz", ".maf.gz")):
+            assert harness.sha(gzip.decompress(raw)) == want[n[len("out"):-3]]["sha256"], n
+            seen += 1
+        elif n.endswith(".bam"):
+            assert raw.endswith(P.BGZF_EOF) and gzip.decompress(raw)[:4] == b"BAM\x01", n
+            seen += 1
+    assert seen >= 2
