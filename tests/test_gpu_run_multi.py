@@ -32,9 +32,9 @@ def test_run_multi_two_ranks(case, batch, tmp_path):
     assert not [k for k in outs if ".rank" in k]
 
 
-@pytest.mark.parametrize("case", ["trans_errhmm_sequel", "trans_errhmm_ont_hpbias4", "trans_qshmm_rsii", "templ_errhmm_sequel",
-                                  "templ_errhmm_rsii_pass3_hpbias2", "templ_qshmm_rsii_pass2"])
-@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("case,ranks", [("trans_errhmm_sequel", 2), ("trans_errhmm_ont_hpbias4", 3), ("trans_qshmm_rsii", 2),
+                                        ("templ_errhmm_sequel", 2), ("templ_errhmm_rsii_pass3_hpbias2", 2),
+                                        ("templ_qshmm_rsii_pass2", 3)])
 def test_run_multi_unit_strategies(case, ranks, tmp_path):
     """trans / templ: every rank simulates one contiguous block of the unit set's reads (pbsim_simulate_units_range);
     the blocks stitched in rank order are the golden bytes"""
