@@ -284,7 +284,7 @@ def main():
         gz_bytes = [0]
         if a.deflate:                            # sinks that only count: the members are already in pinned host memory
             import ctypes as C
-            ctx.set_deflate(3)
+            ctx.set_deflate(int(os.environ.get("PBSIM_BENCH_DEFLATE_MASK", "7")))   # bit 2: the two sinks from two host threads
 
             def count(user, text, n):
                 gz_bytes[0] += n
