@@ -78,8 +78,22 @@ static long sub_thre[94], ins_thre[94], del_thre[94]; /* pbsim.cpp:5474-5479 */
 static double e_ip[ACC_MAX + 1][STATE_MAX + 1], e_ep[ACC_MAX + 1][STATE_MAX + 1][4],
     e_tp[ACC_MAX + 1][STATE_MAX + 1][STATE_MAX + 1];
 static int e_exist[ACC_MAX + 1], e_state_max[ACC_MAX + 1], e_acc_min, e_acc_max;
-static double q_ip[ACC_MAX + 1][STATE_MAX + 1], q_ep[ACC_MAX + 1][STATE_MAX + 1][94],
-    q_tp[ACC_MAX + 1][STATE_MAX + 1][STATE_MAX + 1];
+/* struct qshmm_t (pbsim.cpp:160-166) lays ip[101][51], ep[101][51][94], tp[101][51][51] out back to back, and set_qshmm
+ * indexes them with whatever state / column numbers the file holds.  QSHMM-ONT-HQ.model has classes with up to 56 states
+ * (SURVEY Q7): in the compiled reference a state above STATE_MAX simply lands STATE_MAX+1 slots further on in the same
+ * block (the next state's row, the next class, the next member).  That is deterministic, and it is what the goldens
+ * `wgs_qshmm_onthq*` were produced with, so the block is restated as ONE flat array with the reference's strides and no
+ * per-dimension check; only a write past the end of tp[] (it would hit exist_hmm[]) is refused. */
+#define Q_IP_N ((ACC_MAX + 1) * (STATE_MAX + 1))
+#define Q_EP_N ((ACC_MAX + 1) * (STATE_MAX + 1) * 94)
+#define Q_TP_N ((ACC_MAX + 1) * (STATE_MAX + 1) * (STATE_MAX + 1))
+static double q_block[Q_IP_N + Q_EP_N + Q_TP_N];
+#define Q_IP_AT(a, s) ((long)(a) * (STATE_MAX + 1) + (s))
+#define Q_EP_AT(a, s, k) (Q_IP_N + ((long)(a) * (STATE_MAX + 1) + (s)) * 94 + (k))
+#define Q_TP_AT(a, s, k) (Q_IP_N + Q_EP_N + ((long)(a) * (STATE_MAX + 1) + (s)) * (STATE_MAX + 1) + (k))
+#define q_ip(a, s) q_block[Q_IP_AT(a, s)]
+#define q_ep(a, s, k) q_block[Q_EP_AT(a, s, k)]
+#define q_tp(a, s, k) q_block[Q_TP_AT(a, s, k)]
 static int q_exist[ACC_MAX + 1];
 
 /* lookup tables (expanded, as the reference builds them) */
@@ -211,6 +225,12 @@ static void set_errhmm(void) { /* pbsim.cpp:5640-5714 */
   fclose(fp);
 }
 
+static void q_store(long at, double v) {
+  if (at < 0 || at >= (long)(Q_IP_N + Q_EP_N + Q_TP_N))
+    die("oracle: QSHMM model writes past qshmm.tp[] (the reference would overwrite exist_hmm[])");
+  q_block[at] = v;
+}
+
 static void set_qshmm(void) { /* pbsim.cpp:5570-5634 */
   FILE *fp = fopen(sim.model_file, "r");
   char line[BUF_SIZE], *tp;
@@ -219,25 +239,22 @@ static void set_qshmm(void) { /* pbsim.cpp:5570-5634 */
     trim(line);
     tp = strtok(line, " ");
     int accuracy = atoi(tp);
+    if (accuracy < 0 || accuracy > ACC_MAX) die("oracle: QSHMM accuracy class outside 0-100");
     q_exist[accuracy] = 1;
     tp = strtok(NULL, " ");
     if (strcmp(tp, "IP") == 0) {
       int state = atoi(strtok(NULL, " "));
-      q_ip[accuracy][state] = atof(strtok(NULL, " "));
+      q_store(Q_IP_AT(accuracy, state), atof(strtok(NULL, " ")));
     } else if (strcmp(tp, "EP") == 0) {
       int state = atoi(strtok(NULL, " "));
       int num = 0;
-      /* Q7: states > STATE_MAX overflow the reference's rows; refuse instead. */
-      if (state > STATE_MAX) die("oracle: QSHMM state > STATE_MAX (reference UB, SURVEY Q7)");
-      while ((tp = strtok(NULL, " ")) != NULL) q_ep[accuracy][state][num++] = atof(tp);
+      while ((tp = strtok(NULL, " ")) != NULL) q_store(Q_EP_AT(accuracy, state, num++), atof(tp));
     } else if (strcmp(tp, "TP") == 0) {
       int state = atoi(strtok(NULL, " "));
       int num = 0;
-      if (state > STATE_MAX) die("oracle: QSHMM state > STATE_MAX (reference UB, SURVEY Q7)");
       while ((tp = strtok(NULL, " ")) != NULL) {
         num++;
-        if (num > STATE_MAX) die("oracle: QSHMM state > STATE_MAX (reference UB, SURVEY Q7)");
-        q_tp[accuracy][state][num] = atof(tp);
+        q_store(Q_TP_AT(accuracy, state, num), atof(tp));
       }
     }
   }
@@ -378,8 +395,8 @@ static void build_qshmm_tables(void) {
       start_wk = 1;
       double tot = 0.0;
       for (j = 1; j <= STATE_MAX; j++) {
-        if (q_ip[i][j] == 0) continue;
-        tot += q_ip[i][j];
+        if (q_ip(i, j) == 0) continue;
+        tot += q_ip(i, j);
         end_wk = (int)(tot * 100 + 0.5);
         if (end_wk > 100) end_wk = 100;
         for (k = start_wk; k <= end_wk; k++) init2state[i][k] = (unsigned char)j;
@@ -391,8 +408,8 @@ static void build_qshmm_tables(void) {
         start_wk = 1;
         tot = 0.0;
         for (k = 0; k <= 93; k++) {
-          if (q_ep[i][j][k] == 0) continue;
-          tot += q_ep[i][j][k];
+          if (q_ep(i, j, k) == 0) continue;
+          tot += q_ep(i, j, k);
           end_wk = (int)(tot * 100 + 0.5);
           if (end_wk > 100) end_wk = 100;
           for (l = start_wk; l <= end_wk; l++) emis2err[i][j][l] = (unsigned char)k; /* emis2qc */
@@ -405,8 +422,8 @@ static void build_qshmm_tables(void) {
         start_wk = 1;
         tot = 0.0;
         for (k = 1; k <= STATE_MAX; k++) {
-          if (q_tp[i][j][k] == 0) continue;
-          tot += q_tp[i][j][k];
+          if (q_tp(i, j, k) == 0) continue;
+          tot += q_tp(i, j, k);
           end_wk = (int)(tot * 100 + 0.5);
           if (end_wk > 100) end_wk = 100;
           for (l = start_wk; l <= end_wk; l++) tran2state[i][j][l] = (unsigned char)k;
@@ -1310,14 +1327,16 @@ static void simulate_trans_unit(void) { /* pbsim.cpp:4453-4769 (errhmm), 2774-30
       revshort(m_hp, L);
     }
     if (sim.method == ME_ERR) rate_mag = errhmm_rate_mag(acc, rate_mag);
-    if (sim.method == ME_ERR && acc == 100)
-      die("oracle: errhmm trans with accuracy class 100 clobbers the reference's loop counter (SURVEY Q5)");
     for (long h = 0; h < sim.pass_num; h++) {
       g_pass = (uint32_t)h;
       long len = (sim.method == ME_ERR) ? walk_errhmm(L, acc, rate_mag, strand) : walk_qshmm(L, acc, strand);
       emit_record(len, sim.method == ME_ERR ? m_newqc : m_qc, h, tr_id, (int)strlen(tr_id), seq_left, seq_right,
                   strand, 0);
     }
+    /* Q5: the verbatim copy of an accuracy-100 read, `for (i=0; i<mut.len; i++)` (pbsim.cpp:4533), runs on the SAME `i` as
+     * the per-transcript read loop (pbsim.cpp:4487): behind such a read the loop continues at i = mut.len + 1, so a
+     * transcript makes fewer (or, with mut.len < i, repeated) reads than its expression value says. */
+    if (sim.method == ME_ERR && acc == 100) i = L > 0 ? L : 0;
   }
   rate_mag_persist = rate_mag;
 }

@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 BIN_DIR = os.path.join(HERE, "bin")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libpbsim3_amd.so")
 CLI = os.path.join(BIN_DIR, "pbsim")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -47,14 +48,26 @@ def _assert_gfx950(path):
 def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(BIN_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
     deps = _deps()
+    headers = [d for d in deps if d.endswith(".h")]
     if force or _newer(LIB, deps):
-        # NB: no `-x` flags -- hipcc drops --offload-arch when it sees one and
-        # silently builds for its default target instead of gfx950
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", LIB + ".tmp"] + COMMON
+        # one object per source (kernels.hip alone takes most of a minute), relinked when any of them changed.
+        # NB: no `-x` flags -- hipcc drops --offload-arch when it sees one and silently builds for its default target
+        objs = []
         for s in HIP_SOURCES + CXX_SOURCES:
-            if os.path.exists(os.path.join(CSRC, s)):
-                cmd.append(os.path.join(CSRC, s))
+            src = os.path.join(CSRC, s)
+            if not os.path.exists(src):
+                continue
+            obj = os.path.join(OBJ_DIR, s + ".o")
+            objs.append(obj)
+            if force or _newer(obj, [src] + headers):
+                cmd = [HIPCC, f"--offload-arch={ARCH}", "-c", "-o", obj + ".tmp"] + COMMON + [src]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.run(cmd, check=True)
+                os.replace(obj + ".tmp", obj)
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", LIB + ".tmp"] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

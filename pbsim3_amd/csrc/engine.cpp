@@ -1471,13 +1471,29 @@ static int set_units(pbsim_ctx *c, int64_t n, const char *const *ids, const int6
   }
   // zero total expression is legal: the reference simply simulates nothing and prints its report (with NaN means)
   if (reads > 0x7fffff00LL) return fail("too many reads");
+  // start-position buckets per rank (pbsim.cpp:4200-4224); unused by templ
+  const int rank_max = (int)ceil((float)max_len / 1000);  // pbsim.cpp:1133
+  SspTables st;
+  build_ssp_tables(rank_max, &st);
+  std::vector<uint8_t> ssp((size_t)(rank_max + 1) * 1000, 0);
+  for (int k = 1; k <= rank_max; k++)
+    for (int i = 1; i <= 1000; i++) ssp[(size_t)k * 1000 + (i - 1)] = (uint8_t)(st.value[(size_t)k * 1001 + i] / 5);
+  // in simulate_by_errhmm_trans the verbatim copy of an accuracy-100 read, `for (i=0; i<mut.len; i++)`
+  // (pbsim.cpp:4533), runs on the same `i` as the per-transcript read loop (:4487), which therefore continues at
+  // i = mut.len + 1 behind such a read.  Which reads a transcript makes then depends on the header draws of the reads
+  // before it -- a serial chain, but over header draws only (one Philox block and three table lookups per read, the
+  // arithmetic of k_header_trans), so the host walks it once here and the kernels see an ordinary read -> unit map.
+  const bool q5 = !templ && c->p.method == PBSIM_METHOD_ERR && c->hdr.acc_hi == 100;
   std::vector<uint8_t> cat((size_t)total);
   std::vector<int64_t> ubase(n), ulen(n);
-  std::vector<int32_t> urank(n), offt((size_t)n * 21), runit((size_t)reads);
-  std::vector<int64_t> rbase((size_t)reads);
-  std::vector<uint8_t> rminus((size_t)reads);
+  std::vector<int32_t> urank(n), offt((size_t)n * 21), runit;
+  std::vector<int64_t> rbase;
+  std::vector<uint8_t> rminus;
+  runit.reserve((size_t)reads);
+  rbase.reserve((size_t)reads);
+  rminus.reserve((size_t)reads);
   std::vector<char> names((size_t)n * 132, 0);
-  int64_t pos = 0, r = 0;
+  int64_t pos = 0;
   for (int64_t u = 0; u < n; u++) {
     memcpy(cat.data() + pos, seqs[u], (size_t)lens[u]);
     cat[pos + lens[u]] = '\n';
@@ -1490,20 +1506,28 @@ static int set_units(pbsim_ctx *c, int64_t n, const char *const *ids, const int6
     }
     strncpy(&names[(size_t)u * 132], ids[u], 128);
     const int64_t rn = (int64_t)(int)(plus_exp[u] + minus_exp[u]);
-    for (int64_t i = 1; i <= rn; i++, r++) {
-      runit[r] = (int32_t)u;
-      rbase[r] = pos;
-      rminus[r] = (i > plus_exp[u]) ? 1 : 0;  // pbsim.cpp:4516-4522
+    for (int64_t i = 1; i <= rn; i++) {
+      if (q5) {
+        if ((int64_t)runit.size() >= 0x7fffff00LL) return fail("too many reads");
+        const U4 w = header_block(c->p.seed, 0u, (uint32_t)(runit.size() + 1));
+        int64_t L = c->hdr.prob2len[(size_t)(w.x % (uint32_t)c->hdr.len_rv) + 1];
+        const int acc = c->hdr.prob2acc[(size_t)(w.y % (uint32_t)c->hdr.acc_rv) + 1];
+        const uint32_t rv = (uint32_t)st.rv[(size_t)urank[u]];
+        const int64_t off = offt[(size_t)u * 21 + ssp[(size_t)urank[u] * 1000 + w.z % (rv ? rv : 1u)]];
+        if (off + L > lens[u]) L = lens[u] - off;
+        runit.push_back((int32_t)u);
+        rbase.push_back(pos);
+        rminus.push_back((i > plus_exp[u]) ? 1 : 0);
+        if (acc == 100) i = std::max<int64_t>(L, 0);  // the clobbered counter; the loop's i++ follows
+        continue;
+      }
+      runit.push_back((int32_t)u);
+      rbase.push_back(pos);
+      rminus.push_back((i > plus_exp[u]) ? 1 : 0);  // pbsim.cpp:4516-4522
     }
     pos += lens[u] + 1;
   }
-  // start-position buckets per rank (pbsim.cpp:4200-4224); unused by templ
-  const int rank_max = (int)ceil((float)max_len / 1000);  // pbsim.cpp:1133
-  SspTables st;
-  build_ssp_tables(rank_max, &st);
-  std::vector<uint8_t> ssp((size_t)(rank_max + 1) * 1000, 0);
-  for (int k = 1; k <= rank_max; k++)
-    for (int i = 1; i <= 1000; i++) ssp[(size_t)k * 1000 + (i - 1)] = (uint8_t)(st.value[(size_t)k * 1001 + i] / 5);
+  reads = (int64_t)runit.size();
 
   // hp-del-bias census weighted by expression (pbsim.cpp:4352-4426)
   hp_bias_default(&c->bias);
@@ -1548,8 +1572,6 @@ int pbsim_set_transcripts(pbsim_ctx *c, int64_t n, const char *const *ids, const
   if (!c || n < 1 || !ids || !plus_exp || !minus_exp || !seqs || !lens) return fail("pbsim_set_transcripts: bad argument");
   NEED_DEVICE(c);
   if (c->p.strategy != PBSIM_STRATEGY_TRANS) return fail("pbsim_set_transcripts: strategy is not trans");
-  if (c->p.method == PBSIM_METHOD_ERR && c->hdr.acc_hi == 100)
-    return fail("errhmm trans with accuracy class 100 clobbers the reference's loop counter (pbsim.cpp:4533); refused");
   return set_units(c, n, ids, plus_exp, minus_exp, seqs, lens, false);
 }
 

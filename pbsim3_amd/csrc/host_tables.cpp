@@ -131,6 +131,15 @@ bool parse_qshmm(const char *path, QsModel *m, std::string *err) {
   memset(m, 0, sizeof(*m));
   std::unique_ptr<char[]> line(new char[kLineMax]);
   bool ok = true;
+  // the reference's unchecked `qshmm.xx[accuracy][state][num] = atof(tp)` on the flat block (see QsModel)
+  auto store = [&](long at, double v) {
+    if (at < 0 || at >= QsModel::kIpN + QsModel::kEpN + QsModel::kTpN) {
+      *err = "QSHMM model writes past qshmm.tp[] (the reference would overwrite exist_hmm[] here)";
+      return false;
+    }
+    m->blk[at] = v;
+    return true;
+  };
   while (ok && fgets(line.get(), kLineMax, fp)) {
     chomp(line.get());
     int acc;
@@ -146,36 +155,20 @@ bool parse_qshmm(const char *path, QsModel *m, std::string *err) {
       break;
     }
     const int state = atoi(st);
-    // QSHMM-ONT-HQ.model has 56 states and overruns the reference's
-    // [STATE_MAX+1] rows (undefined behaviour there); refuse loudly instead.
-    if (state < 0 || state > kStateMax) {
-      *err = "model state exceeds STATE_MAX (50); the reference overruns its tables on this file (undefined behaviour)";
+    if (state < 0) {
+      *err = "negative model state";
       ok = false;
       break;
     }
     if (!strcmp(kind, "IP")) {
       const char *v = strtok(NULL, " ");
-      m->ip[acc][state] = v ? atof(v) : 0.0;
+      ok = store(QsModel::ip_at(acc, state), v ? atof(v) : 0.0);
     } else if (!strcmp(kind, "EP")) {
       int n = 0;
-      for (char *v = strtok(NULL, " "); v; v = strtok(NULL, " ")) {
-        if (n >= kQcNum) {
-          *err = "QSHMM EP row has more than 94 columns";
-          ok = false;
-          break;
-        }
-        m->ep[acc][state][n++] = atof(v);
-      }
+      for (char *v = strtok(NULL, " "); v && ok; v = strtok(NULL, " ")) ok = store(QsModel::ep_at(acc, state, n++), atof(v));
     } else if (!strcmp(kind, "TP")) {
       int n = 0;
-      for (char *v = strtok(NULL, " "); v; v = strtok(NULL, " ")) {
-        if (++n > kStateMax) {
-          *err = "model state exceeds STATE_MAX (50); the reference overruns its tables on this file (undefined behaviour)";
-          ok = false;
-          break;
-        }
-        m->tp[acc][state][n] = atof(v);
-      }
+      for (char *v = strtok(NULL, " "); v && ok; v = strtok(NULL, " ")) ok = store(QsModel::tp_at(acc, state, ++n), atof(v));
     }
   }
   fclose(fp);
@@ -525,11 +518,11 @@ bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias
   for (int a = 0; a <= kAccMax; a++) {
     if (!m.exist[a]) continue;
     for (int j = 1; j <= kStateMax; j++) {
-      if (m.ip[a][j] != 0) smax = std::max(smax, j);
+      if (m.ip(a, j) != 0) smax = std::max(smax, j);
       for (int k = 1; k <= kStateMax; k++)
-        if (m.tp[a][j][k] != 0) smax = std::max(smax, std::max(j, k));
+        if (m.tp(a, j, k) != 0) smax = std::max(smax, std::max(j, k));
       for (int k = 0; k < kQcNum; k++)
-        if (m.ep[a][j][k] != 0) smax = std::max(smax, j);
+        if (m.ep(a, j, k) != 0) smax = std::max(smax, j);
     }
   }
   t->smax = smax;
@@ -551,14 +544,14 @@ bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias
     if (m.exist[a] == 1) {
       hdr[2] = 1;
       expand_cdf(
-          100, 1, kStateMax, [&](int j) { return m.ip[a][j]; }, [&](int j) { return m.ip[a][j] == 0; },
+          100, 1, kStateMax, [&](int j) { return m.ip(a, j); }, [&](int j) { return m.ip(a, j) == 0; },
           [&](long s, int j) { dst[t->init_off + (s - 1)] = (uint8_t)j; }, &end_wk);
       hdr[1] = (uint32_t)end_wk;
       uint16_t *rv = reinterpret_cast<uint16_t *>(dst + t->rv_off);
       std::vector<long> emis_rv(kStateMax + 1, 0), tran_rv(kStateMax + 1, 0);
       for (int j = 1; j <= kStateMax; j++) {
         expand_cdf(
-            100, 0, kQcNum - 1, [&](int k) { return m.ep[a][j][k]; }, [&](int k) { return m.ep[a][j][k] == 0; },
+            100, 0, kQcNum - 1, [&](int k) { return m.ep(a, j, k); }, [&](int k) { return m.ep(a, j, k) == 0; },
             [&](long s, int k) {
               if (j <= smax) dst[t->emis_off + 100u * (uint32_t)(j - 1) + (s - 1)] = (uint8_t)k;
             },
@@ -567,7 +560,7 @@ bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias
       }
       for (int j = 1; j <= kStateMax; j++) {
         expand_cdf(
-            100, 1, kStateMax, [&](int k) { return m.tp[a][j][k]; }, [&](int k) { return m.tp[a][j][k] == 0; },
+            100, 1, kStateMax, [&](int k) { return m.tp(a, j, k); }, [&](int k) { return m.tp(a, j, k) == 0; },
             [&](long s, int k) {
               if (j <= smax) dst[t->tran_off + 100u * (uint32_t)(j - 1) + (s - 1)] = (uint8_t)k;
             },
@@ -578,9 +571,9 @@ bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias
       // states that can be visited: named by an IP entry or a TP column of this class
       std::vector<char> reach(kStateMax + 1, 0);
       for (int j = 1; j <= kStateMax; j++) {
-        if (m.ip[a][j] != 0) reach[j] = 1;
+        if (m.ip(a, j) != 0) reach[j] = 1;
         for (int k = 1; k <= kStateMax; k++)
-          if (m.tp[a][j][k] != 0) reach[k] = 1;
+          if (m.tp(a, j, k) != 0) reach[k] = 1;
       }
       for (int j = 1; j <= smax; j++) {
         rv[2 * j] = (uint16_t)tran_rv[j];

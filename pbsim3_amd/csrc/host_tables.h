@@ -30,11 +30,24 @@ struct ErrModel {  // struct errhmm_t, pbsim.cpp:169-178
   int acc_min, acc_max;
 };
 
-struct QsModel {  // struct qshmm_t, pbsim.cpp:160-166
-  double ip[kAccMax + 1][kStateMax + 1];
-  double ep[kAccMax + 1][kStateMax + 1][kQcNum];
-  double tp[kAccMax + 1][kStateMax + 1][kStateMax + 1];
+// struct qshmm_t, pbsim.cpp:160-166: ip[101][51], ep[101][51][94], tp[101][51][51] back to back.  set_qshmm (:5570-5634)
+// indexes them with whatever state / column numbers the file holds, and QSHMM-ONT-HQ.model has classes with up to 56
+// states: in the compiled reference such an entry lands STATE_MAX+1 slots further on in the same block (the
+// next state's row, the next class, the next member) where a later line overwrites it or nobody reads it.  Pinned, not
+// refused: the block is ONE flat array with the reference's strides, written without a per-dimension check (only a write
+// past the end of tp[] is an error), and read through ip()/ep()/tp() with in-range indices like the table loops do.
+struct QsModel {
+  static constexpr long kIpN = (long)(kAccMax + 1) * (kStateMax + 1);
+  static constexpr long kEpN = kIpN * kQcNum;
+  static constexpr long kTpN = kIpN * (kStateMax + 1);
+  double blk[kIpN + kEpN + kTpN];
   int exist[kAccMax + 1];
+  static long ip_at(long a, long j) { return a * (kStateMax + 1) + j; }
+  static long ep_at(long a, long j, long k) { return kIpN + (a * (kStateMax + 1) + j) * kQcNum + k; }
+  static long tp_at(long a, long j, long k) { return kIpN + kEpN + (a * (kStateMax + 1) + j) * (kStateMax + 1) + k; }
+  double ip(int a, int j) const { return blk[ip_at(a, j)]; }
+  double ep(int a, int j, int k) const { return blk[ep_at(a, j, k)]; }
+  double tp(int a, int j, int k) const { return blk[tp_at(a, j, k)]; }
 };
 
 bool parse_errhmm(const char *path, ErrModel *m, std::string *err);

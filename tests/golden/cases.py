@@ -46,6 +46,24 @@ CASES["trans_qshmm_rsii"] = dict(
     args=["--strategy", "trans", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model",
           "--transcript", "INPUT:tiny.transcript", "--seed", "8"])
 
+# SURVEY Q7, pinned: QSHMM-ONT-HQ.model has classes with 52 and 56 states; the compiled reference writes states > STATE_MAX
+# into the neighbouring rows of its flat tables and loops over 50 states (pbsim.cpp:160-166, 5606-5626, 2073, 2124)
+CASES["wgs_qshmm_onthq_acc95"] = dict(
+    args=["--strategy", "wgs", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-ONT-HQ.model",
+          "--genome", "INPUT:quirk.fa", "--depth", "5", "--seed", "11", "--accuracy-mean", "0.95"] + SHORT)
+CASES["wgs_qshmm_onthq_pass2_hpbias2"] = dict(
+    args=["--strategy", "wgs", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-ONT-HQ.model",
+          "--genome", "INPUT:quirk.fa", "--depth", "3", "--seed", "12", "--accuracy-mean", "0.97", "--pass-num", "2",
+          "--hp-del-bias", "2"] + SHORT)
+# SURVEY Q5, pinned: errhmm trans with accuracy class 100 in range -- the verbatim copy (pbsim.cpp:4533) clobbers the
+# per-transcript read counter (:4487), so fewer reads than the expression values are made
+CASES["trans_errhmm_rsii_acc98"] = dict(
+    args=["--strategy", "trans", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-RSII.model",
+          "--transcript", "INPUT:tiny.transcript", "--seed", "3", "--accuracy-mean", "0.98"])
+CASES["trans_errhmm_sequel_acc99_pass2"] = dict(
+    args=["--strategy", "trans", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-SEQUEL.model",
+          "--transcript", "INPUT:tiny.transcript", "--seed", "14", "--accuracy-mean", "0.99", "--pass-num", "2"] + SHORT)
+
 CASES["templ_errhmm_sequel"] = dict(
     args=["--strategy", "templ", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-SEQUEL.model",
           "--template", "INPUT:tiny.template", "--seed", "1"])

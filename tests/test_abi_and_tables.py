@@ -154,11 +154,25 @@ def test_errhmm_class_tables_are_well_formed(model):
     ctx.close()
 
 
-def test_model_with_too_many_states_is_refused(tmp_path):
-    """a QSHMM with > STATE_MAX states overruns the reference's arrays."""
+def test_qshmm_states_above_state_max_follow_the_reference_layout(tmp_path):
+    """SURVEY Q7, pinned: a QSHMM entry with state > STATE_MAX lands 51 slots further on in the reference's flat
+    ip|ep|tp block (pbsim.cpp:160-166, 5606-5626).  `80 IP 52 x` is ip[81][1]: invisible to class 80, the initial state of
+    class 81.  Only a write past the end of tp[] (class 100, it would hit exist_hmm[]) is refused."""
+    ep = " ".join(["0"] * 20 + ["1.0"] + ["0"] * 70)
+    base = "81 EP 1 %s\n81 TP 1 1.0\n80 IP 1 1.0\n80 EP 1 %s\n80 TP 1 1.0\n" % (ep, ep)
+    a, b = tmp_path / "a.model", tmp_path / "b.model"
+    a.write_text(base + "81 IP 1 1.0\n")
+    b.write_text(base + "80 IP 52 1.0\n")            # ip[80][52] == ip[81][1]
+    blobs = []
+    for f in (a, b):
+        ctx = P.Context(P.default_params(method=P.METHOD_QS), -1)
+        ctx.load_qshmm(str(f))
+        blobs.append(ctx.dump_table(2))
+        ctx.close()
+    assert blobs[0] == blobs[1]
     bad = tmp_path / "bad.model"
-    bad.write_text("80 IP 56 1.0\n")
+    bad.write_text("100 TP 56 " + " ".join(["0.1"] * 56) + "\n")
     ctx = P.Context(P.default_params(method=P.METHOD_QS), -1)
-    with pytest.raises(P.PbsimError, match="STATE_MAX"):
+    with pytest.raises(P.PbsimError, match="past qshmm.tp"):
         ctx.load_qshmm(str(bad))
     ctx.close()
