@@ -231,6 +231,95 @@ int64_t pbsim_batch_capacity(pbsim_ctx *ctx);
 /* scratch pool per slot in bytes (default: PBSIM_SCRATCH_MB env or 8 GiB) */
 int pbsim_set_scratch_bytes(pbsim_ctx *ctx, int64_t bytes);
 
+/* ---- the whole job on one or several GPUs -------------------------------------
+ * main() runs its records one after the other (pbsim.cpp:667-759).  Here ALL records of the genome are made resident in
+ * HBM (288 GB holds any genome the reference can read: 3 bytes per base there, 2 here) and ONE pipeline of read batches
+ * runs across them: batches of record n+1 start as soon as record n has enough reads in flight, so the tail of a record
+ * (its last text emission, its truncated last reads, pbsim.cpp:3795-3800) hides behind the next record's walks.
+ *
+ * Several GPUs: one context per GPU ("rank"), every rank holds every record (C1: the caller broadcasts them) and runs
+ * the same job; a round of the pipeline gives rank r the r-th block of the round's reads.  The ranks only exchange
+ * integers through the caller's pbsim_comm: per round the blocks' pass-0 bases (C3, places every rank's quota prefix) and
+ * their cut / text sizes (every rank learns the byte range of its text inside the record's stream), per record the
+ * statistics (C2: counters, min/max, the two histograms; the order-dependent accuracy sum is folded in read order).  The
+ * concatenation of all ranks' text in offset order is byte for byte what one GPU delivers, and so are the statistics.
+ *
+ * pbsim_comm: blocking collectives over the `world` ranks, called by every rank in the same order (the job is
+ * deterministic in the gathered values, so the ranks stay in lockstep by construction).  torch.distributed (backend nccl
+ * = RCCL), RCCL itself, MPI or -- for several contexts inside one process -- a host barrier all fit. */
+#define PBSIM_OP_SUM 0
+#define PBSIM_OP_MIN 1
+#define PBSIM_OP_MAX 2
+typedef struct pbsim_comm {
+  void *user;
+  int32_t rank, world;
+  /* every rank contributes n values; recv holds world * n, rank-major */
+  int (*all_gather_i64)(void *user, const int64_t *send, int64_t n, int64_t *recv);
+  /* element-wise reduction over the ranks, in place; op = PBSIM_OP_* */
+  int (*all_reduce_i64)(void *user, int64_t *buf, int64_t n, int32_t op);
+  /* optional (C1): `bytes` bytes at `ptr` (device memory of this rank's GPU when on_device, else host memory) of rank
+   * `root` to every rank.  NULL: the caller has every rank load the records itself. */
+  int (*broadcast)(void *user, void *ptr, int64_t bytes, int32_t root, int32_t on_device);
+} pbsim_comm;
+
+/* Receiver of a job's output.  Text arrives as (record, bytes, offset): `offset` is the position of the piece inside the
+ * record's read stream resp. MAF stream (what the reference writes into <prefix>_NNNN.fq|sam / .maf after any header the
+ * caller puts in front), so every rank can pwrite() its pieces into the final file; on one GPU the offsets simply run up.
+ * on_record_done is called on EVERY rank, in record order, with the statistics of the whole record (identical on all
+ * ranks) and the total size of its two streams.  Return 0 to abort. */
+typedef struct pbsim_record_sink {
+  void *user;
+  int (*on_read_text)(void *user, int64_t record, const char *text, int64_t bytes, int64_t offset);
+  int (*on_maf_text)(void *user, int64_t record, const char *text, int64_t bytes, int64_t offset);
+  int (*on_record_done)(void *user, int64_t record, const pbsim_stats *stats, int64_t read_bytes, int64_t maf_bytes);
+} pbsim_record_sink;
+
+/* Records are numbered 1.. in the order they are added (genome.num).  The bytes are uploaded and prepared (toupper +
+ * homopolymer lengths, pbsim.cpp:1014-1065) asynchronously; pbsim_job_run simulates every record added since the last
+ * pbsim_job_clear.  --hp-del-bias != 1 needs no separate census pass here: the census of all resident records is known
+ * before the first walk (pbsim.cpp:677-696).  wgs, methods errhmm / qshmm. */
+int pbsim_job_add_record(pbsim_ctx *ctx, const uint8_t *seq, int64_t len);
+int pbsim_job_add_record_device(pbsim_ctx *ctx, const void *seq_device, int64_t len);
+/* C1 in one call: rank `root` passes the record (the others may pass NULL); with comm->broadcast the bytes travel GPU to
+ * GPU, without it every rank must pass them. */
+int pbsim_job_add_record_comm(pbsim_ctx *ctx, const uint8_t *seq, int64_t len, const pbsim_comm *comm, int32_t root);
+int64_t pbsim_job_records(pbsim_ctx *ctx);
+/* drops the records; the next one added is record `first_record` (a genome larger than HBM runs as several jobs whose
+ * numbering continues; --hp-del-bias != 1 then needs pbsim_add_hp_census / pbsim_finish_hp_census over ALL records first).
+ * pbsim_job_clear = pbsim_job_begin(ctx, 1). */
+int pbsim_job_begin(pbsim_ctx *ctx, int64_t first_record);
+int pbsim_job_clear(pbsim_ctx *ctx);
+/* comm == NULL: this GPU alone.  sink may be NULL (text stays in HBM: measurements) and so may any of its callbacks. */
+int pbsim_job_run(pbsim_ctx *ctx, const pbsim_comm *comm, const pbsim_record_sink *sink);
+/* SAM / BAM header of record `record` of the job (pbsim_sam_header / pbsim_bam_header are those of the current unit) */
+int64_t pbsim_job_sam_header(pbsim_ctx *ctx, int64_t record, char *buf, int64_t cap);
+int64_t pbsim_job_bam_header(pbsim_ctx *ctx, int64_t record, char *buf, int64_t cap);
+/* what the last pbsim_job_run did, for bench.py: [0] reads walked (speculation included), [1] reads delivered,
+ * [2] rounds, [3] bases delivered (all passes), [4] wall microseconds, [5] microseconds this rank waited in collectives */
+int pbsim_job_counters(pbsim_ctx *ctx, int64_t out[8]);
+
+/* Statistics primitives for callers that shard a unit set over several contexts themselves (trans / templ:
+ * pbsim_simulate_units_range per rank): keep the per-task accuracy values while accounting (before simulating), then
+ * merge -- afterwards pbsim_get_stats on every rank reports the whole unit set exactly as one GPU would
+ * (pbsim.cpp:4082-4105, the order-dependent sum of :4003 included).  pbsim_stats_add_tasks accounts tasks given as plain
+ * arrays (device-free; tests of the merge). */
+int pbsim_stats_keep_values(pbsim_ctx *ctx, int on);
+int pbsim_stats_merge(pbsim_ctx *ctx, const pbsim_comm *comm);
+int pbsim_stats_add_tasks(pbsim_ctx *ctx, int64_t first_task, int64_t n, const int32_t *out_len, const int32_t *nsub,
+                          const int32_t *nins, const int32_t *ndel, const double *qsum);
+/* the ":::: Simulation stats ::::" block of print_simulation_stats (pbsim.cpp:5541-5564); unit = genome.num (wgs).
+ * Returns the byte count (excluding the NUL), or the size needed when buf is NULL / too small. */
+int64_t pbsim_format_stats(const pbsim_params *p, const pbsim_stats *s, int64_t unit, char *buf, int64_t cap);
+
+/* ---- the command line as a library call ------------------------------------------
+ * Everything `pbsim` does for one rank: the reference's options (pbsim.cpp:257-282) and set_sim_param validation
+ * (:1451-1688), the stderr report blocks, the <prefix>_NNNN.ref files, the output files.  comm == NULL: this GPU alone.
+ * With a communicator every rank calls it with the same argv; rank 0 prints the report and creates the files, every rank
+ * writes its own byte ranges of them.  The `pbsim` binary calls this from one host thread per GPU of --devices (host
+ * barrier or RCCL communicator); pbsim3_amd/run_multi.py calls it from one process per GPU under torchrun
+ * (torch.distributed).  Returns the process exit status (0, or 255 like the reference's exit(-1)). */
+int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int device);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------
  * Accumulated HIP-event time of the walk kernel launches since the last reset,
  * measured on the engine's own stream, and the number of launches. */

@@ -53,8 +53,45 @@ class Sink(C.Structure):
     _fields_ = [("user", C.c_void_p), ("on_read_text", SINK_CB), ("on_maf_text", SINK_CB)]
 
 
+OP_SUM, OP_MIN, OP_MAX = 0, 1, 2
+GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64))
+REDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_int32)
+BCAST_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
+
+
+class Comm(C.Structure):
+    """pbsim_comm: blocking collectives over the ranks of a job (one context per GPU)."""
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32),
+                ("all_gather_i64", GATHER_CB), ("all_reduce_i64", REDUCE_CB), ("broadcast", BCAST_CB)]
+
+
+REC_TEXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_char), C.c_int64, C.c_int64)
+REC_DONE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_int64, C.c_int64)
+
+
+class RecordSink(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("on_read_text", REC_TEXT_CB), ("on_maf_text", REC_TEXT_CB),
+                ("on_record_done", REC_DONE_CB)]
+
+
 # every symbol include/pbsim3_amd.h declares: (name, restype, argtypes)
 API = [
+    ("pbsim_job_add_record", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("pbsim_job_add_record_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("pbsim_job_add_record_comm", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Comm), C.c_int32]),
+    ("pbsim_job_records", C.c_int64, [C.c_void_p]),
+    ("pbsim_job_begin", C.c_int, [C.c_void_p, C.c_int64]),
+    ("pbsim_job_clear", C.c_int, [C.c_void_p]),
+    ("pbsim_job_run", C.c_int, [C.c_void_p, C.POINTER(Comm), C.POINTER(RecordSink)]),
+    ("pbsim_job_sam_header", C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
+    ("pbsim_job_bam_header", C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
+    ("pbsim_job_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ("pbsim_stats_keep_values", C.c_int, [C.c_void_p, C.c_int]),
+    ("pbsim_stats_merge", C.c_int, [C.c_void_p, C.POINTER(Comm)]),
+    ("pbsim_stats_add_tasks", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    ("pbsim_format_stats", C.c_int64, [C.POINTER(Params), C.POINTER(Stats), C.c_int64, C.c_char_p, C.c_int64]),
+    ("pbsim_cli_main", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(Comm), C.c_int]),
     ("pbsim_params_default", None, [C.POINTER(Params)]),
     ("pbsim_create", C.c_void_p, [C.POINTER(Params), C.c_int]),
     ("pbsim_destroy", None, [C.c_void_p]),
@@ -178,6 +215,83 @@ def default_params(**kw):
 
 # empty BGZF block: the end-of-file marker of a BAM file (SAMv1 4.1.2), also a valid empty gzip member
 BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
+def make_comm(rank, world, all_gather, all_reduce, broadcast=None):
+    """pbsim_comm from Python callables:
+         all_gather(list[int]) -> list[list[int]] (rank-major), all_reduce(list[int], op) -> list[int],
+         broadcast(ptr:int, nbytes:int, root:int, on_device:bool) -> None (optional, C1).
+    The returned Comm keeps the ctypes trampolines alive (comm._keep)."""
+    def _g(user, send, n, recv):
+        try:
+            out = all_gather([send[i] for i in range(n)])
+            k = 0
+            for row in out:
+                for v in row:
+                    recv[k] = v
+                    k += 1
+            return 1
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 0
+
+    def _r(user, buf, n, op):
+        try:
+            import numpy as np
+            a = np.ctypeslib.as_array(buf, shape=(n,)) if n else None
+            if n:
+                a[:] = all_reduce(a, op)
+            return 1
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 0
+
+    def _b(user, ptr, nbytes, root, on_device):
+        try:
+            broadcast(ptr, nbytes, root, bool(on_device))
+            return 1
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 0
+
+    cbs = (GATHER_CB(_g), REDUCE_CB(_r), BCAST_CB(_b) if broadcast else BCAST_CB())
+    comm = Comm(None, rank, world, *cbs)
+    comm._keep = cbs
+    return comm
+
+
+def torch_comm(dist, device):
+    """pbsim_comm over torch.distributed (backend nccl = RCCL on the GPUs, gloo on the CPU): the job's integer collectives
+    (C3 all_gather, C2 all_reduce).  `device`: the torch device the collectives run on (this rank's GPU for nccl, cpu for
+    gloo).  No broadcast callback: a caller that holds the records as torch tensors broadcasts them itself (C1,
+    dist.broadcast) and hands every rank its copy (pbsim_job_add_record_device); pbsim_cli_main has every rank read the
+    <prefix>_NNNN.ref files instead."""
+    import numpy as np
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def all_gather(vals):
+        t = torch.tensor(vals, dtype=torch.int64, device=device)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.tolist() for o in out]
+
+    def all_reduce(arr, op):
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+        dist.all_reduce(t, op={OP_SUM: dist.ReduceOp.SUM, OP_MIN: dist.ReduceOp.MIN, OP_MAX: dist.ReduceOp.MAX}[op])
+        return t.cpu().numpy()
+
+    return make_comm(rank, world, all_gather, all_reduce, None)
+
+
+def cli_main(argv, comm=None, device=-1):
+    """pbsim_cli_main: the whole command line for this rank (argv without the program name)."""
+    args = [b"pbsim"] + [os.fsencode(a) for a in argv]
+    arr = (C.c_char_p * (len(args) + 1))(*args, None)
+    return load().pbsim_cli_main(len(args), arr, C.byref(comm) if comm is not None else None, device)
 
 
 class Context:
@@ -395,6 +509,77 @@ class Context:
         buf = C.create_string_buffer(n)
         self.lib.pbsim_bam_header(self.h, buf, n)
         return buf.raw[:n]
+
+    # ---- the whole job (pbsim_job_*)
+    def job_begin(self, first_record=1):
+        _check(self.lib.pbsim_job_begin(self.h, first_record))
+
+    def job_add_record(self, seq: bytes):
+        buf = C.create_string_buffer(seq, len(seq))
+        _check(self.lib.pbsim_job_add_record(self.h, C.cast(buf, C.c_void_p), len(seq)))
+
+    def job_add_record_device(self, ptr: int, length: int):
+        _check(self.lib.pbsim_job_add_record_device(self.h, C.c_void_p(ptr), length))
+
+    def job_run(self, comm=None, collect=True, on_done=None):
+        """Runs every record of the job.  collect: returns {record: [read bytes, maf bytes]} assembled from the positional
+        pieces this rank received (holes stay zero: other ranks' ranges), plus {record: (Stats, read_bytes, maf_bytes)}."""
+        pieces, done = {}, {}
+
+        def put(which, rec, text, n, off):
+            pieces.setdefault(rec, [[], []])[which].append((off, C.string_at(text, n)))
+            return 1
+
+        def fin(user, rec, st, rb, mb):
+            s = Stats()
+            C.memmove(C.byref(s), st, C.sizeof(Stats))
+            done[rec] = (s, rb, mb)
+            if on_done:
+                on_done(rec, s, rb, mb)
+            return 1
+
+        cbs = (REC_TEXT_CB(lambda u, r, t, n, o: put(0, r, t, n, o)), REC_TEXT_CB(lambda u, r, t, n, o: put(1, r, t, n, o)),
+               REC_DONE_CB(fin))
+        sink = RecordSink(None, *cbs) if collect else RecordSink(None, REC_TEXT_CB(), REC_TEXT_CB(), cbs[2])
+        _check(self.lib.pbsim_job_run(self.h, C.byref(comm) if comm is not None else None, C.byref(sink)))
+        out = {}
+        for rec, (s, rb, mb) in done.items():
+            bufs = [bytearray(rb), bytearray(mb)]
+            for which in (0, 1):
+                for off, data in pieces.get(rec, [[], []])[which]:
+                    bufs[which][off:off + len(data)] = data
+            out[rec] = bufs
+        return out, done
+
+    def job_counters(self):
+        a = (C.c_int64 * 8)()
+        _check(self.lib.pbsim_job_counters(self.h, a))
+        return dict(reads_walked=a[0], reads_delivered=a[1], rounds=a[2], bases=a[3], wall_us=a[4], comm_us=a[5])
+
+    def job_sam_header(self, record):
+        n = self.lib.pbsim_job_sam_header(self.h, record, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.lib.pbsim_job_sam_header(self.h, record, buf, n + 1)
+        return buf.raw[:n]
+
+    def stats_keep_values(self, on=True):
+        _check(self.lib.pbsim_stats_keep_values(self.h, 1 if on else 0))
+
+    def stats_merge(self, comm):
+        _check(self.lib.pbsim_stats_merge(self.h, C.byref(comm)))
+
+    def stats_add_tasks(self, first_task, out_len, nsub, nins, ndel, qsum=None):
+        import numpy as np
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (out_len, nsub, nins, ndel)]
+        q = np.ascontiguousarray(qsum, dtype=np.float64) if qsum is not None else None
+        p32 = C.POINTER(C.c_int32)
+        _check(self.lib.pbsim_stats_add_tasks(self.h, first_task, len(a[0]), *[x.ctypes.data_as(p32) for x in a],
+                                              q.ctypes.data_as(C.POINTER(C.c_double)) if q is not None else None))
+
+    def format_stats(self, stats, unit=0):
+        buf = C.create_string_buffer(2048)
+        n = self.lib.pbsim_format_stats(C.byref(self.params), C.byref(stats), unit, buf, 2048)
+        return buf.raw[:n].decode()
 
     def batch_account(self):
         _check(self.lib.pbsim_batch_account(self.h))

@@ -15,9 +15,9 @@ CLI = os.path.join(BIN_DIR, "pbsim")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["kernels.hip", "deflate.hip", "engine.cpp"]
-CXX_SOURCES = ["host_tables.cpp", "unit_io.cpp"]
-CLI_SOURCES = ["cli.cpp", "gzout.cpp"]
+HIP_SOURCES = ["kernels.hip", "deflate.hip", "engine.cpp", "job.cpp"]
+CXX_SOURCES = ["host_tables.cpp", "unit_io.cpp", "stats.cpp", "cli.cpp", "gzout.cpp"]
+CLI_SOURCES = ["main.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("PBSIM_EXTRA_CFLAGS", "").split()
 
 
@@ -67,7 +67,7 @@ def build(force=False, verbose=False):
                     print(" ".join(cmd))
                 subprocess.run(cmd, check=True)
                 os.replace(obj + ".tmp", obj)
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", LIB + ".tmp"] + objs
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", LIB + ".tmp"] + objs + ["-lz", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
@@ -76,7 +76,7 @@ def build(force=False, verbose=False):
     cli_srcs = [os.path.join(CSRC, s) for s in CLI_SOURCES]
     if all(os.path.exists(s) for s in cli_srcs) and (force or _newer(CLI, deps + [LIB])):
         cmd = [HIPCC, "-o", CLI + ".tmp"] + COMMON + cli_srcs + \
-              ["-L" + LIB_DIR, "-lpbsim3_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lz", "-lpthread"]
+              ["-L" + LIB_DIR, "-lpbsim3_amd", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -1,15 +1,17 @@
-// cli.cpp -- `pbsim`: the reference's command line (23 long options,
-// pbsim.cpp:257-282) in front of the C ABI of include/pbsim3_amd.h.  This is
-// INTEGRATION.md written out: option parsing and validation (pbsim.cpp:286-530,
-// set_sim_param :1451-1688), the stderr report blocks (:5397-5465, :5541-5564),
-// the FASTA splitter, the per-record driver loop of main() (:666-759) and the
-// gzip/samtools pipes (:708-730).  Everything per read and per base happens in
-// libpbsim3_amd.so on the GPU.  Extra options: --device N, --no-gzip (write the
-// text plainly to <prefix>_NNNN.{fq,maf,sam}), --gzip gpu|host, --gzip-threads N,
-// --samtools.  Instead of one `gzip` child per file, the .fq.gz/.maf.gz/.bam bytes are
-// compressed on the GPU (deflate.hip: BGZF-framed gzip members, only compressed bytes cross
-// PCIe) and appended to the files here; --gzip host uses the in-process multi-threaded zlib
-// writer (gzout.h) instead; --samtools pipes SAM text into `samtools view -b` like the reference.
+// cli.cpp -- the reference's command line (23 long options, pbsim.cpp:257-282) in front of the C ABI of
+// include/pbsim3_amd.h, as a library call: pbsim_cli_main().  This is INTEGRATION.md written out: option parsing and
+// validation (pbsim.cpp:286-530, set_sim_param :1451-1688), the stderr report blocks (:5397-5465, :5541-5564), the FASTA
+// splitter, the record loop of main() (:666-759) and the gzip/samtools pipes (:708-730).  Everything per read and per
+// base happens on the GPU.  Extra options: --device N, --devices a,b,.. (one rank per GPU, see main.cpp), --no-gzip (write
+// the text plainly to <prefix>_NNNN.{fq,maf,sam}), --gzip gpu|host, --gzip-threads N, --samtools.  Instead of one `gzip`
+// child per file, the .fq.gz/.maf.gz/.bam bytes are compressed on the GPU (deflate.hip: BGZF-framed gzip members, only
+// compressed bytes cross PCIe) and written here; --gzip host uses the in-process multi-threaded zlib writer (gzout.h);
+// --samtools pipes SAM text into `samtools view -b` like the reference.
+//
+// wgs (errhmm / qshmm) runs as ONE job over all records (pbsim_job_run): the records are resident in HBM, and on several
+// ranks every rank pwrite()s its own byte ranges of the final files.  Rank 0 alone prints and creates files.
+#include <fcntl.h>
+#include <unistd.h>
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,6 +21,8 @@
 #include <time.h>
 
 #include <algorithm>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,11 +45,18 @@ struct Cli {
   int gzip_threads = 0;
 };
 
+// the reference's exit(-1).  Other ranks of the process may be inside HIP calls on their own threads: leave without running
+// static destructors under them (everything buffered is flushed first)
+[[noreturn]] void quit(int status) {
+  fflush(NULL);
+  _exit(status & 255);
+}
+
 [[noreturn]] void die(const char *fmt, const char *a = "", const char *b = "") {
   fprintf(stderr, "ERROR");
   fprintf(stderr, fmt, a, b);
   fprintf(stderr, "\n");
-  exit(-1);
+  quit(-1);
 }
 
 // an empty BGZF block: the EOF marker of a BAM file (SAMv1 4.1.2), and a valid empty gzip member
@@ -106,14 +117,15 @@ void open_sink(const Cli &c, Out *o, const std::string &plain_name, const std::s
 bool native_bam(const Cli &c) { return c.p.pass_num > 1 && !c.no_gzip && !c.use_samtools; }
 
 // what main() writes when it opens the samtools pipe (pbsim.cpp:721-722), as SAM text or as the BAM header
-void write_read_header(const Cli &c, pbsim_ctx *ctx, Out *o) {
+// (`record`: genome.num for wgs -- the PU tag carries it; 0 for trans / templ)
+void write_read_header(const Cli &c, pbsim_ctx *ctx, Out *o, int64_t record) {
   std::vector<char> h;
   if (native_bam(c)) {
-    h.resize((size_t)pbsim_bam_header(ctx, NULL, 0));
-    pbsim_bam_header(ctx, h.data(), (int64_t)h.size());
+    h.resize((size_t)pbsim_job_bam_header(ctx, record, NULL, 0));
+    pbsim_job_bam_header(ctx, record, h.data(), (int64_t)h.size());
   } else {
-    h.resize((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
-    pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
+    h.resize((size_t)pbsim_job_sam_header(ctx, record, NULL, 0) + 1);
+    pbsim_job_sam_header(ctx, record, h.data(), (int64_t)h.size());
     h.pop_back();
   }
   if (o->members) {  // the header as a gzip member of its own, through the same encoder as the records
@@ -202,23 +214,19 @@ void print_help() {
           "  --strategy trans --transcript TSV (id, plus, minus, sequence)\n"
           "  --method errhmm  --errhmm MODEL   |   --method qshmm --qshmm MODEL --difference-ratio (6:55:39)\n"
           "  --length-mean (9000.0) --length-sd (7000.0) --accuracy-mean (0.85) --pass-num (1) --hp-del-bias (1)\n"
-          "  --device N (0)   --no-gzip (plain .fq/.maf/.sam instead of gzip/samtools pipes)\n"
+          "  --device N (0)   --devices a,b,.. (one rank per GPU)   --no-gzip (plain .fq/.maf/.sam instead of gzip/samtools pipes)\n"
           "  --gzip gpu|host (gpu)   --gzip-threads N (host)   --samtools (pipe SAM into samtools view -b)\n\n");
 }
 
 void check(int ok) {
   if (!ok) {
     fprintf(stderr, "ERROR: %s\n", pbsim_last_error());
-    exit(-1);
+    quit(-1);
   }
 }
 
-}  // namespace
-
-int main(int argc, char **argv) {
-  struct timeval tv0;
-  gettimeofday(&tv0, NULL);
-  Cli c;
+// options + set_sim_param (pbsim.cpp:286-530, 1451-1688); exits like the reference on a bad value
+void parse_args(int argc, char **argv, Cli &c) {
   pbsim_params_default(&c.p);
   c.p.strategy = 0;
   c.p.method = 0;
@@ -233,10 +241,11 @@ int main(int argc, char **argv) {
       {"length-sd", 1, NULL, 0},  {"accuracy-mean", 1, NULL, 0}, {"pass-num", 1, NULL, 0},
       {"template", 1, NULL, 0},   {"hp-del-bias", 1, NULL, 0},   {"device", 1, NULL, 0},
       {"no-gzip", 0, NULL, 0},    {"gzip-threads", 1, NULL, 0}, {"gzip-file", 1, NULL, 0}, {"samtools", 0, NULL, 0},
-      {"gzip", 1, NULL, 0},       {0, 0, 0, 0}};
+      {"gzip", 1, NULL, 0},       {"devices", 1, NULL, 0},      {"comm", 1, NULL, 0},          {0, 0, 0, 0}};
+  optind = 0;  // glibc: a full re-initialisation (this function runs once per rank)
   int opt, idx = 0;
   while ((opt = getopt_long(argc, argv, "", long_options, &idx)) != -1) {
-    if (opt != 0) exit(-1);
+    if (opt != 0) quit(-1);
     c.set_flg[idx] = 1;
     switch (idx) {
     case 0:
@@ -328,6 +337,7 @@ int main(int argc, char **argv) {
       else if (!strcmp(optarg, "host")) c.gzip_on_gpu = false;
       else die(" (gzip: %s): gpu or host.", optarg);
       break;
+    case 29: case 30: break;  // --devices / --comm: main.cpp (one rank per GPU); a rank itself runs on `device`
     case 26: {  // utility/self-test: gzip FILE -> FILE.gz with the parallel writer, nothing else
       pbsim::ParallelGz gz;
       std::string e;
@@ -338,14 +348,14 @@ int main(int argc, char **argv) {
       size_t k;
       while ((k = fread(buf.data(), 1, buf.size(), in)) > 0) gz.write(buf.data(), k);
       fclose(in);
-      return gz.close() ? 0 : 255;
+      quit(gz.close() ? 0 : 255);
     }
     default: break;
     }
   }
   if (argc == 1) {
     print_help();
-    exit(-1);
+    quit(-1);
   }
   // ---- set_sim_param (pbsim.cpp:1451-1688)
   if (!c.set_flg[0] || !c.set_flg[1]) die(": --strategy and --method must be set.");
@@ -374,11 +384,199 @@ int main(int argc, char **argv) {
   if (c.set_flg[19]) c.p.accuracy_mean = (int)(c.p.accuracy_mean * 100) * 0.01;
   if (c.p.len_min > c.p.len_max) {
     fprintf(stderr, "ERROR: length min(%ld) is greater than max(%ld).\n", (long)c.p.len_min, (long)c.p.len_max);
-    exit(-1);
+    quit(-1);
   }
   if (c.p.pass_num > 1 && sampling) die(": sampling-based simulation supports only single-pass.");
   if (c.gzip_threads < 1) c.gzip_threads = (int)std::max(1u, std::thread::hardware_concurrency());
-  print_sim_param(c);
+}
+
+// ---- output files ------------------------------------------------------------------------------------------------------
+// A positional file: every rank opens the same path and pwrite()s its own byte ranges (rank 0 creates / truncates it first).
+struct PosFile {
+  int fd = -1;
+  std::string path;
+  int64_t base = 0;  // bytes rank 0 puts in front of the record stream (SAM / BAM header)
+  void create(const std::string &p) {
+    path = p;
+    fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) die(": Cannot open output file: %s", p.c_str());
+  }
+  void attach(const std::string &p) {
+    path = p;
+    fd = ::open(p.c_str(), O_WRONLY);
+    if (fd < 0) die(": Cannot open output file: %s", p.c_str());
+  }
+  bool write_at(const char *t, int64_t n, int64_t off) {
+    while (n > 0) {
+      const ssize_t k = ::pwrite(fd, t, (size_t)n, (off_t)off);
+      if (k <= 0) return false;
+      t += k;
+      n -= k;
+      off += k;
+    }
+    return true;
+  }
+  void close_checked() {
+    if (fd >= 0 && ::close(fd) != 0) die(": write error on %s", path.c_str());
+    fd = -1;
+  }
+};
+
+// what a rank needs per output stream of one wgs record
+struct Stream {
+  PosFile pos;      // --no-gzip and --gzip gpu: positional
+  Out seq;          // --gzip host, --samtools: one sequential consumer (a single rank only)
+  bool positional = false;
+  int64_t expect = 0;  // sequential: the next offset
+  bool write(const char *t, int64_t n, int64_t off) {
+    if (positional) return pos.write_at(t, n, pos.base + off);
+    if (off != expect) return false;  // a sequential consumer on a single rank: offsets simply run up
+    expect += n;
+    return seq.write(t, (size_t)n);
+  }
+};
+
+struct RecFiles {
+  Stream read, maf;
+};
+
+struct JobFiles {
+  const Cli *cli = nullptr;
+  pbsim_ctx *ctx = nullptr;
+  const pbsim_comm *comm = nullptr;
+  int64_t first = 1;
+  std::vector<std::unique_ptr<RecFiles>> recs;
+  RecFiles &of(int64_t record) { return *recs[(size_t)(record - first)]; }
+};
+
+bool positional_mode(const Cli &c, bool bam) { return c.no_gzip || (c.gzip_on_gpu && !(bam && c.use_samtools)); }
+
+void barrier(const pbsim_comm *comm) {
+  if (!comm || comm->world <= 1) return;
+  int64_t x = 0;
+  if (!comm->all_reduce_i64(comm->user, &x, 1, PBSIM_OP_SUM)) die(": communicator failed");
+}
+
+std::string read_name(const Cli &c, long n) {
+  char name[4096];
+  snprintf(name, sizeof name, "%s_%04ld", c.prefix.c_str(), n);
+  if (c.p.pass_num == 1) return std::string(name) + (c.no_gzip ? ".fq" : ".fq.gz");
+  return std::string(name) + (c.no_gzip ? ".sam" : ".bam");
+}
+std::string maf_name(const Cli &c, long n) {
+  char name[4096];
+  snprintf(name, sizeof name, "%s_%04ld.maf", c.prefix.c_str(), n);
+  return std::string(name) + (c.no_gzip ? "" : ".gz");
+}
+
+// header bytes in front of the read stream (pbsim.cpp:721-722): SAM text, or the BAM header as a gzip member of its own
+std::vector<char> read_header_bytes(const Cli &c, pbsim_ctx *ctx, int64_t record) {
+  std::vector<char> h;
+  if (c.p.pass_num == 1) return h;
+  if (native_bam(c)) {
+    h.resize((size_t)pbsim_job_bam_header(ctx, record, NULL, 0));
+    pbsim_job_bam_header(ctx, record, h.data(), (int64_t)h.size());
+  } else {
+    h.resize((size_t)pbsim_job_sam_header(ctx, record, NULL, 0) + 1);
+    pbsim_job_sam_header(ctx, record, h.data(), (int64_t)h.size());
+    h.pop_back();
+  }
+  if (!c.no_gzip && c.gzip_on_gpu && !c.use_samtools) {
+    std::vector<char> z((size_t)pbsim_deflate_bound((int64_t)h.size()) + 64);
+    int64_t k = 0;
+    if (!pbsim_deflate_buffer(ctx, h.data(), (int64_t)h.size(), z.data(), (int64_t)z.size(), &k)) die(": %s", pbsim_last_error());
+    z.resize((size_t)k);
+    return z;
+  }
+  return h;
+}
+
+// opens the two outputs of record n on this rank (rank 0 creates, the others attach after a barrier -- see open_job_files)
+void open_record(JobFiles &jf, long n, bool creator) {
+  const Cli &c = *jf.cli;
+  RecFiles &rf = jf.of(n);
+  const bool bam = c.p.pass_num > 1;
+  rf.read.positional = positional_mode(c, bam);
+  rf.maf.positional = positional_mode(c, false);
+  if (rf.read.positional) {
+    const std::vector<char> h = read_header_bytes(c, jf.ctx, n);
+    rf.read.pos.base = (int64_t)h.size();
+    if (creator) {
+      rf.read.pos.create(read_name(c, n));
+      if (!h.empty() && !rf.read.pos.write_at(h.data(), (int64_t)h.size(), 0)) die(": write error on %s", rf.read.pos.path.c_str());
+    } else {
+      rf.read.pos.attach(read_name(c, n));
+    }
+  } else if (creator) {  // sequential consumers exist on a single rank only
+    char name[4096];
+    snprintf(name, sizeof name, "%s_%04ld", c.prefix.c_str(), n);
+    if (bam) {
+      open_sink(c, &rf.read.seq, std::string(name) + ".sam", std::string(name) + ".bam", true);
+      write_read_header(c, jf.ctx, &rf.read.seq, n);
+    } else {
+      open_sink(c, &rf.read.seq, std::string(name) + ".fq", std::string(name) + ".fq.gz", false);
+    }
+  }
+  if (rf.maf.positional) {
+    if (creator) rf.maf.pos.create(maf_name(c, n));
+    else rf.maf.pos.attach(maf_name(c, n));
+  } else if (creator) {
+    char name[4096];
+    snprintf(name, sizeof name, "%s_%04ld.maf", c.prefix.c_str(), n);
+    open_sink(c, &rf.maf.seq, name, std::string(name) + ".gz", false);
+  }
+}
+
+int job_read(void *u, int64_t record, const char *t, int64_t k, int64_t off) { return ((JobFiles *)u)->of(record).read.write(t, k, off); }
+int job_maf(void *u, int64_t record, const char *t, int64_t k, int64_t off) { return ((JobFiles *)u)->of(record).maf.write(t, k, off); }
+int job_done(void *u, int64_t record, const pbsim_stats *st, int64_t read_bytes, int64_t maf_bytes) {
+  JobFiles &jf = *(JobFiles *)u;
+  const Cli &c = *jf.cli;
+  RecFiles &rf = jf.of(record);
+  const bool rank0 = !jf.comm || jf.comm->rank == 0;
+  if (rank0) print_simulation_stats(c, *st, (long)record);
+  for (int which = 0; which < 2; which++) {
+    Stream &s = which == 0 ? rf.read : rf.maf;
+    const int64_t bytes = which == 0 ? read_bytes : maf_bytes;
+    if (s.positional) {
+      // compressed streams end with the BGZF EOF marker when they are BAM, or when they would otherwise be empty files
+      const bool members = !c.no_gzip;
+      const bool bam = which == 0 && c.p.pass_num > 1;
+      if (rank0 && members && (bam || s.pos.base + bytes == 0) &&
+          !s.pos.write_at((const char *)kBgzfEof, sizeof kBgzfEof, s.pos.base + bytes))
+        return 0;
+      s.pos.close_checked();
+    } else if (rank0) {
+      s.seq.close();
+    }
+  }
+  return 1;
+}
+
+}  // namespace
+
+extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int device) {
+  struct timeval tv0;
+  gettimeofday(&tv0, NULL);
+  Cli c;
+  {
+    // getopt_long keeps its state in globals: the ranks of one process (main.cpp: one thread per GPU) parse one after the other
+    static std::mutex parse_mu;
+    std::lock_guard<std::mutex> lock(parse_mu);
+    parse_args(argc, argv, c);
+  }
+  if (device >= 0) c.device = device;
+  const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+  const bool rank0 = rank == 0;
+  const bool sampling = c.p.method == PBSIM_METHOD_SAMPLE;
+  const std::string profile_fq = "sample_profile_" + c.profile_id + ".fastq",
+                    profile_stats = "sample_profile_" + c.profile_id + ".stats";
+  if (world > 1) {
+    if (sampling) die(": --method sample runs on one GPU (its chains of copies are serial per sampled read).");
+    if (!c.no_gzip && (!c.gzip_on_gpu || c.use_samtools))
+      die(": several GPUs write their own byte ranges of the outputs: use --gzip gpu (default) or --no-gzip.");
+  }
+  if (rank0) print_sim_param(c);
 
   pbsim::SampleProfile prof;
   if (sampling) {  // pbsim.cpp:580-617: read (or re-read) the profile, print its statistics
@@ -434,7 +632,68 @@ int main(int argc, char **argv) {
   std::string err;
   char name[4096];
 
-  if (c.p.strategy == PBSIM_STRATEGY_WGS) {  // pbsim.cpp:667-759
+  if (c.p.strategy == PBSIM_STRATEGY_WGS && !sampling && !(c.p.pass_num > 1 && c.use_samtools && !c.no_gzip && c.gzip_on_gpu)) {
+    // ---- pbsim.cpp:667-759 as one job: rank 0 splits the FASTA into <prefix>_NNNN.ref (and prints the reference stats),
+    // every rank loads the records (C1: broadcast GPU to GPU when the communicator can, else from the .ref files),
+    // groups of records that fit the GPU's memory run as one pipeline each
+    pbsim::GenomeInfo gi;
+    if (rank0 && !pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
+    if (world > 1) {
+      int64_t nrec = rank0 ? gi.num_seq : 0;
+      if (!comm->all_reduce_i64(comm->user, &nrec, 1, PBSIM_OP_SUM)) die(": communicator failed");
+      gi.num_seq = (long)nrec;
+      std::vector<int64_t> lens((size_t)nrec, 0);
+      if (rank0) for (long i = 0; i < gi.num_seq; i++) lens[(size_t)i] = gi.len[(size_t)i];
+      if (nrec && !comm->all_reduce_i64(comm->user, lens.data(), nrec, PBSIM_OP_SUM)) die(": communicator failed");
+      gi.len.assign(lens.begin(), lens.end());
+    }
+    // records per job: what leaves most of the HBM to the batches (2 bytes per base resident: sequence + homopolymer lengths)
+    const char *gb = getenv("PBSIM_JOB_REF_GB");
+    const double ref_budget = (gb && atof(gb) > 0 ? atof(gb) : 64.0) * (double)(1LL << 30) / 2.0;
+    std::vector<std::pair<long, long>> groups;  // [first, last] record numbers
+    for (long n = 1; n <= gi.num_seq;) {
+      long m = n;
+      double sum = (double)gi.len[(size_t)n - 1];
+      while (m + 1 <= gi.num_seq && sum + (double)gi.len[(size_t)m] <= ref_budget) sum += (double)gi.len[(size_t)m++];
+      groups.emplace_back(n, m);
+      n = m + 1;
+    }
+    std::string seq;
+    const bool bcast = world > 1 && comm->broadcast != NULL;
+    auto load = [&](long n) -> const uint8_t * {
+      if (bcast && !rank0) return NULL;
+      if (!pbsim::load_ref_record(c.prefix.c_str(), n, &seq, &err)) die(": %s", err.c_str());
+      return (const uint8_t *)seq.data();
+    };
+    if (!bcast) barrier(comm);  // the .ref files are complete before anybody else reads them
+    if (c.p.hp_del_bias != 1 && groups.size() > 1) {  // pbsim.cpp:677-696: the census covers ALL records before the first read
+      for (long n = 1; n <= gi.num_seq; n++) {
+        if (!pbsim::load_ref_record(c.prefix.c_str(), n, &seq, &err)) die(": %s", err.c_str());
+        check(pbsim_add_hp_census(ctx, (const uint8_t *)seq.data(), (int64_t)seq.size()));
+      }
+      check(pbsim_finish_hp_census(ctx));
+    }
+    for (const auto &g : groups) {
+      check(pbsim_job_begin(ctx, g.first));
+      for (long n = g.first; n <= g.second; n++) {
+        const uint8_t *p = load(n);
+        check(pbsim_job_add_record_comm(ctx, p, (int64_t)gi.len[(size_t)n - 1], comm, 0));
+      }
+      JobFiles jf;
+      jf.cli = &c;
+      jf.ctx = ctx;
+      jf.comm = comm;
+      jf.first = g.first;
+      for (long n = g.first; n <= g.second; n++) jf.recs.emplace_back(new RecFiles);
+      if (rank0) for (long n = g.first; n <= g.second; n++) open_record(jf, n, true);
+      barrier(comm);  // the files exist
+      if (!rank0) for (long n = g.first; n <= g.second; n++) open_record(jf, n, false);
+      pbsim_record_sink sink = {&jf, job_read, job_maf, job_done};
+      check(pbsim_job_run(ctx, comm, &sink));
+    }
+    check(pbsim_job_begin(ctx, 1));
+  } else if (c.p.strategy == PBSIM_STRATEGY_WGS) {  // the sampling method, or SAM text into a samtools pipe: record by record
+    if (world > 1) die(": this combination of options runs on one GPU.");
     pbsim::GenomeInfo gi;
     if (!pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
     std::string seq;
@@ -455,7 +714,7 @@ int main(int argc, char **argv) {
       } else {
         snprintf(name, sizeof name, "%s_%04ld", c.prefix.c_str(), n);
         open_sink(c, &o_read, std::string(name) + ".sam", std::string(name) + ".bam", true);
-        write_read_header(c, ctx, &o_read);
+        write_read_header(c, ctx, &o_read, n);
       }
       snprintf(name, sizeof name, "%s_%04ld.maf", c.prefix.c_str(), n);
       open_sink(c, &o_maf, name, std::string(name) + ".gz", false);
@@ -476,18 +735,22 @@ int main(int argc, char **argv) {
       long num = 0;
       long long len_total = 0;
       if (!pbsim::read_templates(c.templ.c_str(), &tr, &num, &len_total, &err)) die(": %s", err.c_str());
-      fprintf(stderr, ":::: Template stats ::::\n\n");
-      fprintf(stderr, "file name : %s\n", c.templ.c_str());
-      fprintf(stderr, "template num. : %ld\n", num);
-      fprintf(stderr, "template total length : %lld\n", len_total);
-      fprintf(stderr, "\n");
+      if (rank0) {
+        fprintf(stderr, ":::: Template stats ::::\n\n");
+        fprintf(stderr, "file name : %s\n", c.templ.c_str());
+        fprintf(stderr, "template num. : %ld\n", num);
+        fprintf(stderr, "template total length : %lld\n", len_total);
+        fprintf(stderr, "\n");
+      }
     } else {
       if (!pbsim::read_transcripts(c.transcript.c_str(), &tr, &total_exp, &err)) die(": %s", err.c_str());
-      fprintf(stderr, ":::: transcript stats ::::\n\n");
-      fprintf(stderr, "file name : %s\n", c.transcript.c_str());
-      fprintf(stderr, "transcript num : %ld\n", (long)tr.size());
-      fprintf(stderr, "total expression value : %ld\n", total_exp);
-      fprintf(stderr, "\n");
+      if (rank0) {
+        fprintf(stderr, ":::: transcript stats ::::\n\n");
+        fprintf(stderr, "file name : %s\n", c.transcript.c_str());
+        fprintf(stderr, "transcript num : %ld\n", (long)tr.size());
+        fprintf(stderr, "total expression value : %ld\n", total_exp);
+        fprintf(stderr, "\n");
+      }
     }
     std::vector<const char *> ids;
     std::vector<int64_t> plus, minus, lens;
@@ -501,31 +764,104 @@ int main(int argc, char **argv) {
     }
     if (templ) check(pbsim_set_templates(ctx, (int64_t)tr.size(), ids.data(), seqs.data(), lens.data()));
     else check(pbsim_set_transcripts(ctx, (int64_t)tr.size(), ids.data(), plus.data(), minus.data(), seqs.data(), lens.data()));
-    Out o_read, o_maf;
-    if (c.p.pass_num == 1) {
-      open_sink(c, &o_read, c.prefix + ".fq", c.prefix + ".fq.gz", false);
+    if (world == 1) {
+      Out o_read, o_maf;
+      if (c.p.pass_num == 1) {
+        open_sink(c, &o_read, c.prefix + ".fq", c.prefix + ".fq.gz", false);
+      } else {
+        open_sink(c, &o_read, c.prefix + ".sam", c.prefix + ".bam", true);
+        write_read_header(c, ctx, &o_read, 0);
+      }
+      open_sink(c, &o_maf, c.prefix + ".maf", c.prefix + ".maf.gz", false);
+      Two two = {&o_read, &o_maf};
+      pbsim_sink sink = {&two, cb_read, cb_maf};
+      check(pbsim_simulate_trans(ctx, &sink));
+      pbsim_stats st;
+      check(pbsim_get_stats(ctx, &st));
+      print_simulation_stats(c, st, 0);
+      o_read.close();
+      o_maf.close();
     } else {
-      open_sink(c, &o_read, c.prefix + ".sam", c.prefix + ".bam", true);
-      write_read_header(c, ctx, &o_read);
+      // No quota here: rank r takes the r-th contiguous block of the unit set's read numbering (pbsim.cpp:4516-4522 assigns
+      // reads to transcripts in file order), keeps its bytes, learns its offsets from the other ranks' sizes and writes them.
+      const int64_t R = pbsim_unit_reads(ctx), per = (R + world - 1) / world;
+      const int64_t first = 1 + (int64_t)rank * per, n = std::max<int64_t>(0, std::min(per, R - first + 1));
+      std::string buf_r, buf_m;
+      struct Keep {
+        std::string *r, *m;
+      } keep = {&buf_r, &buf_m};
+      pbsim_sink sink = {&keep,
+                         [](void *u, const char *t, int64_t k) { ((Keep *)u)->r->append(t, (size_t)k); return 1; },
+                         [](void *u, const char *t, int64_t k) { ((Keep *)u)->m->append(t, (size_t)k); return 1; }};
+      check(pbsim_stats_keep_values(ctx, 1));
+      check(pbsim_simulate_units_range(ctx, first, n, &sink));
+      check(pbsim_stats_merge(ctx, comm));
+      const bool bam = c.p.pass_num > 1;
+      const std::string rname = c.prefix + (c.p.pass_num == 1 ? (c.no_gzip ? ".fq" : ".fq.gz") : (c.no_gzip ? ".sam" : ".bam"));
+      const std::string mname = c.prefix + (c.no_gzip ? ".maf" : ".maf.gz");
+      std::vector<char> h;
+      if (bam) {
+        if (native_bam(c)) {
+          h.resize((size_t)pbsim_bam_header(ctx, NULL, 0));
+          pbsim_bam_header(ctx, h.data(), (int64_t)h.size());
+          std::vector<char> z((size_t)pbsim_deflate_bound((int64_t)h.size()) + 64);
+          int64_t k = 0;
+          check(pbsim_deflate_buffer(ctx, h.data(), (int64_t)h.size(), z.data(), (int64_t)z.size(), &k));
+          z.resize((size_t)k);
+          h.swap(z);
+        } else {
+          h.resize((size_t)pbsim_sam_header(ctx, NULL, 0) + 1);
+          pbsim_sam_header(ctx, h.data(), (int64_t)h.size());
+          h.pop_back();
+        }
+      }
+      const int64_t mine[2] = {(int64_t)buf_r.size(), (int64_t)buf_m.size()};
+      std::vector<int64_t> all((size_t)world * 2);
+      if (!comm->all_gather_i64(comm->user, mine, 2, all.data())) die(": communicator failed");
+      int64_t at_r = (int64_t)h.size(), at_m = 0, tot_r = (int64_t)h.size(), tot_m = 0;
+      for (int q = 0; q < world; q++) {
+        if (q < rank) {
+          at_r += all[(size_t)q * 2];
+          at_m += all[(size_t)q * 2 + 1];
+        }
+        tot_r += all[(size_t)q * 2];
+        tot_m += all[(size_t)q * 2 + 1];
+      }
+      PosFile fr, fm;
+      if (rank0) {
+        fr.create(rname);
+        fm.create(mname);
+        if (!h.empty() && !fr.write_at(h.data(), (int64_t)h.size(), 0)) die(": write error on %s", rname.c_str());
+        if (!c.no_gzip) {  // BAM: the BGZF end-of-file marker; .gz: an empty member keeps an empty output a valid gzip file
+          if ((bam || tot_r == 0) && !fr.write_at((const char *)kBgzfEof, sizeof kBgzfEof, tot_r)) die(": write error on %s", rname.c_str());
+          if (tot_m == 0 && !fm.write_at((const char *)kBgzfEof, sizeof kBgzfEof, 0)) die(": write error on %s", mname.c_str());
+        }
+      }
+      barrier(comm);
+      if (!rank0) {
+        fr.attach(rname);
+        fm.attach(mname);
+      }
+      if (!fr.write_at(buf_r.data(), (int64_t)buf_r.size(), at_r) || !fm.write_at(buf_m.data(), (int64_t)buf_m.size(), at_m))
+        die(": write error on %s", rname.c_str());
+      fr.close_checked();
+      fm.close_checked();
+      pbsim_stats st;
+      check(pbsim_get_stats(ctx, &st));
+      if (rank0) print_simulation_stats(c, st, 0);
     }
-    open_sink(c, &o_maf, c.prefix + ".maf", c.prefix + ".maf.gz", false);
-    Two two = {&o_read, &o_maf};
-    pbsim_sink sink = {&two, cb_read, cb_maf};
-    check(pbsim_simulate_trans(ctx, &sink));
-    pbsim_stats st;
-    check(pbsim_get_stats(ctx, &st));
-    print_simulation_stats(c, st, 0);
-    o_read.close();
-    o_maf.close();
   }
   pbsim_destroy(ctx);
+  barrier(comm);
 
-  struct rusage ru;
-  getrusage(RUSAGE_SELF, &ru);
-  struct timeval tv1;
-  gettimeofday(&tv1, NULL);
-  fprintf(stderr, ":::: System utilization ::::\n\n");
-  fprintf(stderr, "CPU time(s) : %ld\n", (long)ru.ru_utime.tv_sec);
-  fprintf(stderr, "Elapsed time(s) : %ld\n", (long)(tv1.tv_sec - tv0.tv_sec));
+  if (rank0) {
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    struct timeval tv1;
+    gettimeofday(&tv1, NULL);
+    fprintf(stderr, ":::: System utilization ::::\n\n");
+    fprintf(stderr, "CPU time(s) : %ld\n", (long)ru.ru_utime.tv_sec);
+    fprintf(stderr, "Elapsed time(s) : %ld\n", (long)(tv1.tv_sec - tv0.tv_sec));
+  }
   return 0;
 }

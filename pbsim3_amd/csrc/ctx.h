@@ -1,0 +1,290 @@
+// ctx.h -- the context behind the C ABI (pbsim_ctx), shared by engine.cpp (batch primitives, per-unit drivers) and
+// job.cpp (the job-level pipeline over records and ranks).  Internal: nothing here is part of include/pbsim3_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pbsim3_amd.h"
+#include "host_tables.h"
+#include "kernels.h"
+
+namespace pbsim {
+extern thread_local std::string g_err;  // pbsim_last_error() of the calling thread
+int fail(const std::string &m);         // sets g_err, returns PBSIM_FAILED
+}  // namespace pbsim
+
+
+#define NEED_DEVICE(c)                                                                      \
+  do {                                                                                      \
+    if ((c)->device < 0 || !(c)->stream)                                                    \
+      return fail("this context has no HIP device: the gfx950 product path has no CPU fallback"); \
+  } while (0)
+
+#define HIP_OK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);       \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t ensure(size_t n, bool exact = false) {
+    if (n <= bytes) return hipSuccess;
+    release();
+    size_t want = exact ? n : n + n / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return e;
+    }
+    bytes = want;
+    return hipSuccess;
+  }
+  template <class T>
+  T *as() const {
+    return reinterpret_cast<T *>(p);
+  }
+};
+
+struct HostBuf {  // pinned staging
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~HostBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+    size_t want = n + n / 8 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return e;
+    }
+    bytes = want;
+    return hipSuccess;
+  }
+};
+
+using namespace pbsim;
+
+constexpr int kMaxSlots = 6;
+
+// Everything one in-flight batch owns.  Several slots (each with its own stream)
+// let the walk of batch k+1 fill the GPU while the longest reads of batch k
+// are still draining and while batch k's text is being emitted.
+// k_text_rows prefetches whole 256-column tiles without bounds checks: up to two tiles (2 x 64 dwords x 256 B) past the
+// last wave's last row
+constexpr size_t kScratchSlack = 64u << 10;
+constexpr double kSinkBatchBases = 2.5e9;  // pbsim_simulate_wgs: expected bases per batch when the text goes to a sink
+
+// One deflate pipeline: staging for one piece of DF_PIECE_CHUNKS chunks, double-buffered dense output + pinned copies, its
+// own streams.  A slot owns two, so that its read text and its MAF text can be compressed, copied and handed to their
+// sinks side by side (pbsim_set_deflate bit 2).
+struct DfLane {
+  DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];
+  HostBuf h_df_total, h_df_out[2];
+  hipStream_t stream = nullptr;        // kernels of this lane
+  hipStream_t copy_stream = nullptr;   // D2H of compressed pieces
+  hipEvent_t ev_df[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
+  // Pinned arena that holds ALL compressed pieces of one batch (job.cpp, several ranks): a rank learns where its bytes go in
+  // the record's stream only after every rank has compressed its block, so the pieces wait here, D2H-copied straight in.
+  std::vector<std::unique_ptr<HostBuf>> arena_blocks;
+  size_t arena_block = 0, arena_used = 0;
+  std::vector<std::pair<const char *, int64_t>> arena_segs;
+  void arena_reset() {
+    arena_block = arena_used = 0;
+    arena_segs.clear();
+  }
+  char *arena_reserve(int64_t n) {
+    const size_t kBlock = 256u << 20;
+    for (;; arena_block++, arena_used = 0) {
+      if (arena_block == arena_blocks.size()) {
+        arena_blocks.emplace_back(new HostBuf);
+        if (arena_blocks.back()->ensure(std::max(kBlock, (size_t)n)) != hipSuccess) return nullptr;
+      }
+      HostBuf &b = *arena_blocks[arena_block];
+      if (arena_used + (size_t)n <= b.bytes) {
+        char *p = (char *)b.p + arena_used;
+        arena_used += ((size_t)n + 63) & ~(size_t)63;
+        arena_segs.emplace_back(p, n);
+        return p;
+      }
+    }
+  }
+};
+
+// The reference a batch reads: a FASTA record (wgs) or the concatenated unit set (trans / templ), prepared in HBM.
+// A slot keeps the descriptor of the batch it holds, so batches of different records can be in flight side by side.
+struct RefDesc {
+  const uint8_t *seq = nullptr;  // upper-cased bases (bit 7 = hp == 11 when hp_flag)
+  const uint8_t *hp = nullptr;   // homopolymer length per base
+  int64_t len = 0;
+  int64_t unit = 0;              // genome.num (wgs, 1-based) or 0
+  bool hp_flag = false;
+  bool hp11 = false;             // a base with hp == 11 has been counted up to and including this record (Q15)
+};
+
+// Statistics of one unit (pbsim.cpp:63-70 `sim.res_*`, :195-196 the two histograms), accumulated per finished task in read
+// order.  `accuracy_total` (pbsim.cpp:4003) is an order-dependent double sum: when the tasks of a unit are spread over several
+// ranks each rank keeps the per-task values of its blocks (keep_values) and the merge folds them in read order on every
+// rank, so the merged mean is bit-identical to one GPU's (stats.cpp: stats_merge).
+struct StatsAcc {
+  int64_t res_num = 0, res_len_total = 0, res_len_min = LONG_MAX, res_len_max = 0;
+  int64_t res_sub = 0, res_ins = 0, res_del = 0;
+  double accuracy_total = 0.0;
+  std::vector<int64_t> freq_len, freq_acc;  // [2*len_max+2], [100001]; sized on first use
+  bool keep_values = false;
+  struct Block {
+    int64_t first_task;  // global 0-based task index ((read-1)*pass_num + pass) of values[0]
+    std::vector<double> values;
+  };
+  std::vector<Block> blocks;
+  void reset() {
+    res_num = res_len_total = res_len_max = 0;
+    res_len_min = LONG_MAX;
+    res_sub = res_ins = res_del = 0;
+    accuracy_total = 0.0;
+    std::fill(freq_len.begin(), freq_len.end(), 0);
+    std::fill(freq_acc.begin(), freq_acc.end(), 0);
+    blocks.clear();
+  }
+};
+
+struct Slot {
+  RefDesc ref;                         // of the batch in this slot
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  DevBuf d_flags;
+  DevBuf d_rawlen, d_len, d_off, d_acc;
+  DevBuf d_hist, d_bin_start, d_bin_cursor, d_class_start;
+  DevBuf d_task_of_slot, d_slot_of_task, d_wave_cap, d_wave_off, d_wg_tmp, d_wg_order;
+  DevBuf d_out_len, d_maf_len, d_nsub, d_nins, d_ndel, d_qsum;
+  DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len, d_row_dst;
+  DevBuf d_scratch, d_read_text, d_maf_text;
+  HostBuf h_read_text, h_maf_text, h_stats;
+  DfLane df[2];                        // deflate staging: [0] read text (or any single stream), [1] MAF text beside it
+  hipStream_t walk_stream = nullptr;   // low priority: the walk kernel only
+  hipEvent_t ev_prep = nullptr;        // header + sort done (walk_stream waits for it)
+  int64_t b_first = 0, b_n = 0, b_slots_max = 0;
+  bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
+  int64_t b_pass0 = 0;
+  pbsim_batch_info b_info;
+};
+
+// One record of a job (pbsim_job_add_record): resident in HBM for the whole job
+struct JobRecord {
+  DevBuf seq, hp, tiles, flags;
+  int64_t len = 0;
+  RefDesc ref;
+};
+
+struct pbsim_ctx {
+  pbsim_params p;
+  int device = 0;
+  hipStream_t stream = nullptr;  // reference preparation and table uploads
+  Slot slots[kMaxSlots];
+  int cur = 0;
+  Slot &s() { return slots[cur]; }
+
+  std::unique_ptr<ErrModel> err;
+  std::unique_ptr<QsModel> qs;
+  HeaderTables hdr;
+  HpBias bias;
+  ErrClassTables ect;
+  QsClassTables qct;
+  bool class_tables_dirty = true;
+  bool header_uploaded = false;
+
+  DevBuf d_prob2len, d_prob2acc, d_cls;
+  DevBuf d_qs_tabs_v[2];         // set_mut thresholds + qprob; [1]: the variant once an hp == 11 base has been counted (Q15)
+  bool qs_tabs_ready[2] = {false, false};
+  // reference
+  DevBuf d_seq_own, d_hp, d_tiles, d_ref_flags;
+  // the NEXT record, uploaded and prepared beside the current record's simulation (pbsim_prefetch_reference*)
+  DevBuf d_seq_next, d_hp_next, d_tiles_next, d_ref_flags_next;
+  hipStream_t prefetch_stream = nullptr;
+  const void *pf_src = nullptr;
+  int64_t pf_len = 0;
+  bool seq_hp_flag = false;  // bit 7 of the prepared sequence bytes carries hp == 11 (k_hp_final)
+  const uint8_t *d_seq = nullptr;
+  int64_t ref_len = 0;
+  int64_t unit = 0;
+  int64_t census[kHpSlots] = {0};
+  bool census_done = false;
+  // trans units (pbsim_set_transcripts)
+  int64_t n_units = 0, trans_reads = 0;
+  DevBuf d_read_unit, d_read_minus, d_read_base, d_unit_len, d_unit_rank, d_unit_names, d_off_table, d_ssp, d_ssp_rv;
+  // sampling method (pbsim_set_sample_profile): filtered quality strings, padded to 8 bytes each
+  DevBuf d_sq, d_sq_line_len, d_sq_line_qoff, d_sq_vbase;
+  std::vector<int32_t> sq_len;
+  std::vector<int64_t> sq_off;
+  int64_t sq_total = 0;        // sample.len_total_filtered
+  int64_t scratch_budget = 0;  // bytes of wave scratch per slot
+  bool scratch_auto = true;    // sized per record by pbsim_simulate_wgs unless PBSIM_SCRATCH_MB / pbsim_set_scratch_bytes said otherwise
+  int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
+  bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
+  int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)
+  bool deflate_parallel = false;  // pbsim_set_deflate bit 2: the two sinks are served from two host threads
+  DevBuf d_df_tables;          // crc slice-by-4 tables [4][256] + x^(8*128*k) [256]
+  DevBuf d_df_prof;
+
+  // per-unit statistics (pbsim.cpp:63-70, 195-196)
+  StatsAcc st;                   // of the current unit (pbsim_batch_account / pbsim_get_stats)
+  std::vector<std::unique_ptr<JobRecord>> job_records;  // pbsim_job_add_record (job.cpp)
+  int64_t job_counters[8] = {0};
+  int64_t job_first_unit = 1;    // genome.num of the job's first record (pbsim_job_begin)
+
+  // profiling
+  double prof_walk_ms = 0, prof_total_ms = 0;
+  int64_t prof_walk_launches = 0;
+};
+
+// ---- internals shared by engine.cpp and job.cpp ---------------------------------------------------------------------
+namespace pbsim {
+RefDesc current_ref(const pbsim_ctx *c);
+int64_t quota_of(const pbsim_ctx *c, int64_t ref_len);  // (long long)(depth * len), pbsim.cpp:705
+int walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining);
+int64_t batch_capacity_for(const pbsim_ctx *c, int64_t ref_len);  // reads one batch is sized to (scratch budget)
+// the two halves of pbsim_batch_finalize on the selected slot: the quota cut, then text sizes + scans + text emission
+int finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out);
+int finalize_text(pbsim_ctx *c, pbsim_batch_info *info);
+std::string sam_header_text(const pbsim_ctx *c, int64_t unit);
+// pbsim.cpp:3986-4005 / 2293-2316 for the n_final reads of the selected slot's finalized batch, into `st`
+int account_slot(pbsim_ctx *c, StatsAcc *st);
+// one finished task (pbsim.cpp:3986-4005): lengths, error counts, the accuracy value and its histogram bin
+void stats_add_task(StatsAcc *st, int64_t len_max, bool quality, long len, long nsub, long nins, long ndel, double qsum,
+                    std::vector<double> *values);
+// pbsim.cpp:4082-4105, 5541-5562: means, SDs, rates
+void stats_finish(const StatsAcc &st, const pbsim_params &p, int64_t ref_len, pbsim_stats *o);
+// sums the accumulators of all ranks into every rank's `st` (counters, min/max, histograms, accuracy_total in read order);
+// extra[0..n_extra) are summed along (byte totals of a record's streams)
+int stats_merge(StatsAcc *st, const pbsim_params &p, const pbsim_comm *comm, int64_t *extra, int n_extra);
+// d_text[0..n) (device) -> BGZF-framed gzip members, handed to `consume` piece by piece from pinned staging (deflate.hip)
+// `place` (optional): pinned host memory for a piece of the given size instead of the lane's staging (a batch-wide arena)
+int deflate_pieces(pbsim_ctx *c, DfLane &lane, const uint8_t *d_text, int64_t n,
+                   const std::function<int(const char *, int64_t)> &consume,
+                   const std::function<char *(int64_t)> *place = nullptr);
+int ensure_deflate_ready(pbsim_ctx *c);  // CRC / shift tables of deflate.hip resident (call before using lanes from threads)
+// upper-case + homopolymer pass of a record (k_hp_*) enqueued on `stream`; flags receives the census (DeviceFlags)
+int prepare_enqueue(pbsim_ctx *c, uint8_t *d_seq, DevBuf &hp, DevBuf &tiles, DevBuf &flags, int64_t len, hipStream_t stream);
+int ensure_tables(pbsim_ctx *c, bool hp11);  // header + class tables (+ the set_mut variant) resident
+inline bool has_quality(const pbsim_ctx *c) { return c->p.method == PBSIM_METHOD_QS || c->p.method == PBSIM_METHOD_SAMPLE; }
+}  // namespace pbsim

@@ -17,191 +17,23 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
-#include "../../include/pbsim3_amd.h"
-#include "host_tables.h"
-#include "kernels.h"
+#include "ctx.h"
 #include "unit_io.h"
 #include "philox.h"
 
-namespace {
-
+namespace pbsim {
 thread_local std::string g_err;
-
 int fail(const std::string &m) {
   g_err = m;
   return PBSIM_FAILED;
 }
-
-#define NEED_DEVICE(c)                                                                      \
-  do {                                                                                      \
-    if ((c)->device < 0 || !(c)->stream)                                                    \
-      return fail("this context has no HIP device: the gfx950 product path has no CPU fallback"); \
-  } while (0)
-
-#define HIP_OK(expr)                                                                        \
-  do {                                                                                      \
-    hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
-      return fail(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);       \
-  } while (0)
-
-struct DevBuf {
-  void *p = nullptr;
-  size_t bytes = 0;
-  ~DevBuf() { release(); }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
-  }
-  hipError_t ensure(size_t n, bool exact = false) {
-    if (n <= bytes) return hipSuccess;
-    release();
-    size_t want = exact ? n : n + n / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) {
-      p = nullptr;
-      return e;
-    }
-    bytes = want;
-    return hipSuccess;
-  }
-  template <class T>
-  T *as() const {
-    return reinterpret_cast<T *>(p);
-  }
-};
-
-struct HostBuf {  // pinned staging
-  void *p = nullptr;
-  size_t bytes = 0;
-  ~HostBuf() {
-    if (p) (void)hipHostFree(p);
-  }
-  hipError_t ensure(size_t n) {
-    if (n <= bytes) return hipSuccess;
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    bytes = 0;
-    size_t want = n + n / 8 + 4096;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-    if (e != hipSuccess) {
-      p = nullptr;
-      return e;
-    }
-    bytes = want;
-    return hipSuccess;
-  }
-};
-
-}  // namespace
-
-using namespace pbsim;
-
-constexpr int kMaxSlots = 4;
-
-// Everything one in-flight batch owns.  Several slots (each with its own stream)
-// let the walk of batch k+1 fill the GPU while the longest reads of batch k
-// are still draining and while batch k's text is being emitted.
-// k_text_rows prefetches whole 256-column tiles without bounds checks: up to two tiles (2 x 64 dwords x 256 B) past the
-// last wave's last row
-constexpr size_t kScratchSlack = 64u << 10;
-constexpr double kSinkBatchBases = 2.5e9;  // pbsim_simulate_wgs: expected bases per batch when the text goes to a sink
-
-// One deflate pipeline: staging for one piece of DF_PIECE_CHUNKS chunks, double-buffered dense output + pinned copies, its
-// own streams.  A slot owns two, so that its read text and its MAF text can be compressed, copied and handed to their
-// sinks side by side (pbsim_set_deflate bit 2).
-struct DfLane {
-  DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];
-  HostBuf h_df_total, h_df_out[2];
-  hipStream_t stream = nullptr;        // kernels of this lane
-  hipStream_t copy_stream = nullptr;   // D2H of compressed pieces
-  hipEvent_t ev_df[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
-};
-
-struct Slot {
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-  DevBuf d_flags;
-  DevBuf d_rawlen, d_len, d_off, d_acc;
-  DevBuf d_hist, d_bin_start, d_bin_cursor, d_class_start;
-  DevBuf d_task_of_slot, d_slot_of_task, d_wave_cap, d_wave_off, d_wg_tmp, d_wg_order;
-  DevBuf d_out_len, d_maf_len, d_nsub, d_nins, d_ndel, d_qsum;
-  DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len, d_row_dst;
-  DevBuf d_scratch, d_read_text, d_maf_text;
-  HostBuf h_read_text, h_maf_text, h_stats;
-  DfLane df[2];                        // deflate staging: [0] read text (or any single stream), [1] MAF text beside it
-  hipStream_t walk_stream = nullptr;   // low priority: the walk kernel only
-  hipEvent_t ev_prep = nullptr;        // header + sort done (walk_stream waits for it)
-  int64_t b_first = 0, b_n = 0, b_slots_max = 0;
-  bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
-  int64_t b_pass0 = 0;
-  pbsim_batch_info b_info;
-};
-
-struct pbsim_ctx {
-  pbsim_params p;
-  int device = 0;
-  hipStream_t stream = nullptr;  // reference preparation and table uploads
-  Slot slots[kMaxSlots];
-  int cur = 0;
-  Slot &s() { return slots[cur]; }
-
-  std::unique_ptr<ErrModel> err;
-  std::unique_ptr<QsModel> qs;
-  HeaderTables hdr;
-  HpBias bias;
-  ErrClassTables ect;
-  QsClassTables qct;
-  bool class_tables_dirty = true;
-  bool header_uploaded = false;
-
-  DevBuf d_prob2len, d_prob2acc, d_cls, d_qs_tabs;
-  // reference
-  DevBuf d_seq_own, d_hp, d_tiles, d_ref_flags;
-  // the NEXT record, uploaded and prepared beside the current record's simulation (pbsim_prefetch_reference*)
-  DevBuf d_seq_next, d_hp_next, d_tiles_next, d_ref_flags_next;
-  hipStream_t prefetch_stream = nullptr;
-  const void *pf_src = nullptr;
-  int64_t pf_len = 0;
-  bool seq_hp_flag = false;  // bit 7 of the prepared sequence bytes carries hp == 11 (k_hp_final)
-  const uint8_t *d_seq = nullptr;
-  int64_t ref_len = 0;
-  int64_t unit = 0;
-  int64_t census[kHpSlots] = {0};
-  bool census_done = false;
-  // trans units (pbsim_set_transcripts)
-  int64_t n_units = 0, trans_reads = 0;
-  DevBuf d_read_unit, d_read_minus, d_read_base, d_unit_len, d_unit_rank, d_unit_names, d_off_table, d_ssp, d_ssp_rv;
-  // sampling method (pbsim_set_sample_profile): filtered quality strings, padded to 8 bytes each
-  DevBuf d_sq, d_sq_line_len, d_sq_line_qoff, d_sq_vbase;
-  std::vector<int32_t> sq_len;
-  std::vector<int64_t> sq_off;
-  int64_t sq_total = 0;        // sample.len_total_filtered
-  int64_t scratch_budget = 0;  // bytes of wave scratch per slot
-  bool scratch_auto = true;    // sized per record by pbsim_simulate_wgs unless PBSIM_SCRATCH_MB / pbsim_set_scratch_bytes said otherwise
-  int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
-  bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
-  int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)
-  bool deflate_parallel = false;  // pbsim_set_deflate bit 2: the two sinks are served from two host threads
-  DevBuf d_df_tables;          // crc slice-by-4 tables [4][256] + x^(8*128*k) [256]
-  DevBuf d_df_prof;
-
-  // per-unit statistics (pbsim.cpp:63-70, 195-196)
-  int64_t res_num = 0, res_len_total = 0, res_len_min = LONG_MAX, res_len_max = 0;
-  int64_t res_sub = 0, res_ins = 0, res_del = 0;
-  double accuracy_total = 0.0;
-  std::vector<int64_t> freq_len, freq_acc;
-
-  // profiling
-  double prof_walk_ms = 0, prof_total_ms = 0;
-  int64_t prof_walk_launches = 0;
-};
+}  // namespace pbsim
 
 namespace {
 
@@ -225,17 +57,30 @@ int ensure_header_tables(pbsim_ctx *c) {
   return PBSIM_SUCCEEDED;
 }
 
+// [sub 94 u32 | ins 94 u32 | del 94*12 u32 | qprob 94 f64]: qc[].prob and set_mut's thresholds.  Only del_thr[q][0] depends on
+// whether an hp == 11 base has been counted yet (Q15), so both variants can be resident and a batch picks its record's.
+int ensure_qs_tabs(pbsim_ctx *c, bool hp11) {
+  if (c->qs_tabs_ready[hp11]) return PBSIM_SUCCEEDED;
+  HpBias b = c->bias;
+  b.hp11_seen = hp11;
+  QsClassTables q;
+  build_mut_tables(c->p, b, &q);
+  std::vector<uint8_t> t(94 * 4 * 2 + 94 * 12 * 4 + 94 * 8);
+  memcpy(t.data(), q.sub_thre, 94 * 4);
+  memcpy(t.data() + 94 * 4, q.ins_thre, 94 * 4);
+  memcpy(t.data() + 94 * 8, q.del_thr, 94 * 12 * 4);
+  memcpy(t.data() + 94 * 8 + 94 * 48, q.qprob, 94 * 8);
+  if (!upload(c->d_qs_tabs_v[hp11], t.data(), t.size(), c->stream)) return PBSIM_FAILED;
+  HIP_OK(hipStreamSynchronize(c->stream));
+  c->qs_tabs_ready[hp11] = true;
+  return PBSIM_SUCCEEDED;
+}
+
 int ensure_class_tables(pbsim_ctx *c) {
   if (!c->class_tables_dirty) return PBSIM_SUCCEEDED;
   std::string e;
+  c->qs_tabs_ready[0] = c->qs_tabs_ready[1] = false;  // the bias may have changed
   if (c->p.method == PBSIM_METHOD_SAMPLE) {  // no model: only qc[].prob and set_mut's thresholds
-    build_mut_tables(c->p, c->bias, &c->qct);
-    std::vector<uint8_t> t(94 * 4 * 2 + 94 * 12 * 4 + 94 * 8);
-    memcpy(t.data(), c->qct.sub_thre, 94 * 4);
-    memcpy(t.data() + 94 * 4, c->qct.ins_thre, 94 * 4);
-    memcpy(t.data() + 94 * 8, c->qct.del_thr, 94 * 12 * 4);
-    memcpy(t.data() + 94 * 8 + 94 * 48, c->qct.qprob, 94 * 8);
-    if (!upload(c->d_qs_tabs, t.data(), t.size(), c->stream)) return PBSIM_FAILED;
   } else if (c->p.method == PBSIM_METHOD_ERR) {
     if (!c->err) return fail("no ERRHMM model loaded (pbsim_load_errhmm)");
     const bool wgs = c->p.strategy == PBSIM_STRATEGY_WGS;
@@ -245,13 +90,6 @@ int ensure_class_tables(pbsim_ctx *c) {
     if (!c->qs) return fail("no QSHMM model loaded (pbsim_load_qshmm)");
     if (!build_qs_class_tables(*c->qs, c->hdr, c->bias, c->p, &c->qct, &e)) return fail(e);
     if (!upload(c->d_cls, c->qct.blob.data(), c->qct.blob.size(), c->stream)) return PBSIM_FAILED;
-    // [sub 94 u32 | ins 94 u32 | del 94*12 u32 | qprob 94 f64]
-    std::vector<uint8_t> t(94 * 4 * 2 + 94 * 12 * 4 + 94 * 8);
-    memcpy(t.data(), c->qct.sub_thre, 94 * 4);
-    memcpy(t.data() + 94 * 4, c->qct.ins_thre, 94 * 4);
-    memcpy(t.data() + 94 * 8, c->qct.del_thr, 94 * 12 * 4);
-    memcpy(t.data() + 94 * 8 + 94 * 48, c->qct.qprob, 94 * 8);
-    if (!upload(c->d_qs_tabs, t.data(), t.size(), c->stream)) return PBSIM_FAILED;
   }
   HIP_OK(hipStreamSynchronize(c->stream));
   c->class_tables_dirty = false;
@@ -297,21 +135,22 @@ void note_hp11(pbsim_ctx *c, const int64_t census[kHpSlots]) {
   // hpfreq[11]++ in get_genome_seq (pbsim.cpp:1058) lands in hp_del_bias[0]:
   // from then on the Q15 deletion test can fire when the draw is exactly 0
   if (census[11] > 0 && !c->bias.hp11_seen) {
-    c->bias.hp11_seen = true;
-    if (c->p.method == PBSIM_METHOD_QS) c->class_tables_dirty = true;
+    c->bias.hp11_seen = true;  // batches pick the matching set_mut table variant through RefDesc::hp11 (ensure_qs_tabs)
   }
 }
 
-int64_t batch_capacity(const pbsim_ctx *c) {
-  const double mean = std::min<double>(c->hdr.mean_len, (double)std::max<int64_t>(c->ref_len, 1));
+int64_t batch_capacity(const pbsim_ctx *c) { return batch_capacity_for(c, c->ref_len); }
+
+}  // namespace
+
+int64_t pbsim::batch_capacity_for(const pbsim_ctx *c, int64_t ref_len) {
+  const double mean = std::min<double>(c->hdr.mean_len, (double)std::max<int64_t>(ref_len, 1));
   const double per_task = (double)regions_of(c) * (2.0 * mean + kScratchPad) * 1.12 + 64.0;
   int64_t n = (int64_t)((double)c->scratch_budget / (per_task * c->p.pass_num));
   n = std::max<int64_t>(n, 1);
   n = std::min<int64_t>(n, (int64_t)(0x7fffff00 / std::max(1, c->p.pass_num)));
   return n;
 }
-
-}  // namespace
 
 extern "C" {
 
@@ -384,8 +223,6 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
     return nullptr;
   }
   hp_bias_default(&c->bias);
-  c->freq_len.assign((size_t)c->p.len_max * 2 + 2, 0);
-  c->freq_acc.assign(100001, 0);
   if (device == -1) return c.release();  // tables-only context: every compute entry point refuses
   int n = 0;
   hipError_t he = hipGetDeviceCount(&n);
@@ -566,6 +403,18 @@ static int set_reference_common(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int64
   return PBSIM_SUCCEEDED;
 }
 
+// descriptor of the context's current unit (what pbsim_batch_walk_begin hands to the slot)
+extern "C++" RefDesc pbsim::current_ref(const pbsim_ctx *c) {
+  RefDesc r;
+  r.seq = c->d_seq;
+  r.hp = c->d_hp.as<uint8_t>();
+  r.len = c->ref_len;
+  r.unit = c->unit;
+  r.hp_flag = c->seq_hp_flag;
+  r.hp11 = c->bias.hp11_seen;
+  return r;
+}
+
 int pbsim_set_reference(pbsim_ctx *c, const uint8_t *seq, int64_t len, int64_t record_index) {
   if (!c || !seq) return fail("pbsim_set_reference: bad argument");
   NEED_DEVICE(c);
@@ -591,22 +440,16 @@ int pbsim_set_reference_device(pbsim_ctx *c, const void *seq_device, int64_t len
   return set_reference_common(c, c->d_seq_own.as<uint8_t>(), len, record_index);
 }
 
-int64_t pbsim_unit_quota(pbsim_ctx *c) {  // pbsim.cpp:705
-  return c ? (int64_t)(long long)(c->p.depth * (double)c->ref_len) : 0;
+extern "C++" int64_t pbsim::quota_of(const pbsim_ctx *c, int64_t ref_len) {  // pbsim.cpp:705
+  return (int64_t)(long long)(c->p.depth * (double)ref_len);
 }
+int64_t pbsim_unit_quota(pbsim_ctx *c) { return c ? quota_of(c, c->ref_len) : 0; }
 
 int64_t pbsim_batch_capacity(pbsim_ctx *c) { return c ? batch_capacity(c) : 0; }
 
 int pbsim_reset_stats(pbsim_ctx *c) {  // init_sim_res, pbsim.cpp:1437-1445 + 3626-3631
   if (!c) return fail("bad argument");
-  c->res_num = 0;
-  c->res_len_total = 0;
-  c->res_len_min = LONG_MAX;
-  c->res_len_max = 0;
-  c->res_sub = c->res_ins = c->res_del = 0;
-  c->accuracy_total = 0.0;
-  std::fill(c->freq_len.begin(), c->freq_len.end(), 0);
-  std::fill(c->freq_acc.begin(), c->freq_acc.end(), 0);
+  c->st.reset();
   return PBSIM_SUCCEEDED;
 }
 
@@ -617,7 +460,7 @@ int pbsim_batch_walk(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t 
 }
 
 int pbsim_select_slot(pbsim_ctx *c, int slot) {
-  if (!c || slot < 0 || slot >= kMaxSlots) return fail("pbsim_select_slot: slot out of range (0-3)");
+  if (!c || slot < 0 || slot >= kMaxSlots) return fail("pbsim_select_slot: slot out of range");
   c->cur = slot;
   return PBSIM_SUCCEEDED;
 }
@@ -625,20 +468,29 @@ int pbsim_select_slot(pbsim_ctx *c, int slot) {
 int pbsim_slot_count(void) { return kMaxSlots; }
 
 int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, int64_t truncate_remaining) {
+  if (!c) return fail("pbsim_batch_walk: bad argument");
+  if (!c->d_seq)
+    return fail(c->p.strategy != PBSIM_STRATEGY_WGS ? "no transcripts/templates set (pbsim_set_transcripts, pbsim_set_templates)"
+                                                    : "no reference set (pbsim_set_reference)");
+  return walk_begin(c, current_ref(c), first_read, n_reads, truncate_remaining);
+}
+
+// header draw -> bucketing -> walk -> pass-0 prefix of reads [first_read, first_read + n_reads) of `ref`, on the selected slot
+extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining) {
   if (!c || n_reads < 1 || first_read < 1) return fail("pbsim_batch_walk: bad argument");
   NEED_DEVICE(c);
   if (c->s().b_enqueued) return fail("pbsim_batch_walk_begin: this slot still has a batch in flight (pbsim_batch_walk_end)");
   if (c->p.method == PBSIM_METHOD_SAMPLE) return fail("the sampling method runs through pbsim_simulate_sample");
   const bool trans = c->p.strategy != PBSIM_STRATEGY_WGS;  // trans and templ share the unit machinery
-  if (!c->d_seq)
-    return fail(trans ? "no transcripts/templates set (pbsim_set_transcripts, pbsim_set_templates)"
-                      : "no reference set (pbsim_set_reference)");
+  if (!ref.seq) return fail("no reference set (pbsim_set_reference)");
   if (trans && (truncate_remaining >= 0 || first_read + n_reads - 1 > c->trans_reads))
     return fail("pbsim_batch_walk: read range outside the transcript set");
   if (truncate_remaining >= 0 && n_reads != 1) return fail("a truncated batch holds exactly one read");
   if (first_read + n_reads > 0xffffffffLL) return fail("read index exceeds 32 bits");
   HIP_OK(hipSetDevice(c->device));
   if (!ensure_header_tables(c) || !ensure_class_tables(c)) return PBSIM_FAILED;
+  if (c->p.method == PBSIM_METHOD_QS && !ensure_qs_tabs(c, ref.hp11)) return PBSIM_FAILED;
+  c->s().ref = ref;
   const int P = c->p.pass_num;
   const int ncls = ncls_of(c);
   if (ncls > kMaxClasses) return fail("too many accuracy classes");
@@ -679,14 +531,14 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
 
   HeaderArgs h;
   h.seed = c->p.seed;
-  h.unit = (uint32_t)c->unit;
+  h.unit = (uint32_t)ref.unit;
   h.first_read = first_read;
   h.n_reads = n_reads;
   h.prob2len = c->d_prob2len.as<int32_t>();
   h.len_rv = c->hdr.len_rv;
   h.prob2acc = c->d_prob2acc.as<uint8_t>();
   h.acc_rv = c->hdr.acc_rv;
-  h.ref_len = c->ref_len;
+  h.ref_len = ref.len;
   h.len_min = c->p.len_min;
   h.truncate_remaining = truncate_remaining;
   h.rawlen = c->s().d_rawlen.as<int32_t>();
@@ -735,13 +587,13 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   WalkArgs w;
   memset(&w, 0, sizeof w);
   w.seed = c->p.seed;
-  w.unit = trans ? 0u : (uint32_t)c->unit;
+  w.unit = trans ? 0u : (uint32_t)ref.unit;
   w.first_read = first_read;
   w.pass_num = P;
   w.ncls = ncls;
-  w.ref.seq = c->d_seq;
-  w.ref.hp = c->d_hp.as<uint8_t>();
-  w.ref.len = c->ref_len;
+  w.ref.seq = ref.seq;
+  w.ref.hp = ref.hp;
+  w.ref.len = ref.len;
   w.len = h.len;
   w.off = h.off;
   if (trans) {
@@ -773,7 +625,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
     w.emis_off = c->ect.emis_off;
     w.init_off = c->ect.init_off;
     w.tran_off = c->ect.tran_off;
-    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, c->seq_hp_flag, ws);
+    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws);
   } else {
     w.stride = c->qct.stride;
     w.rv_off = c->qct.rv_off;
@@ -781,13 +633,13 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
     w.tran_off = c->qct.tran_off;
     w.emis_off = c->qct.emis_off;
     w.freq_off = c->qct.freq_off;
-    const uint8_t *t = c->d_qs_tabs.as<uint8_t>();
+    const uint8_t *t = c->d_qs_tabs_v[ref.hp11].as<uint8_t>();
     w.sub_thre = reinterpret_cast<const uint32_t *>(t);
     w.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
     w.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     w.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
     launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8, c->qct.all_rv_100,
-                      c->seq_hp_flag, ws);
+                      ref.hp_flag, ws);
   }
   HIP_OK(hipEventRecord(c->s().ev2, ws));
   HIP_OK(hipStreamWaitEvent(c->s().stream, c->s().ev2, 0));
@@ -838,8 +690,8 @@ static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
   t->pass_num = c->p.pass_num;
   t->is_wgs = c->p.strategy == PBSIM_STRATEGY_WGS;
   t->is_qs = has_quality_row(c);
-  t->unit = (uint32_t)c->unit;
-  t->ref_len = c->ref_len;
+  t->unit = (uint32_t)c->s().ref.unit;
+  t->ref_len = c->s().ref.len;
   t->len = c->s().d_len.as<int32_t>();
   t->off = c->s().d_off.as<int32_t>();
   t->out_len = c->s().d_out_len.as<int32_t>();
@@ -872,12 +724,12 @@ static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
 }
 
 // First half of pbsim_batch_finalize: the quota cut (which reads of the batch are final, len_total behind them).
-static int finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out) {
+extern "C++" int pbsim::finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out) {
   if (!c || !c->s().b_walked) return fail("pbsim_batch_finalize: no walked batch");
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
   DeviceFlags *flags = c->s().d_flags.as<DeviceFlags>();
-  const int64_t quota = pbsim_unit_quota(c);
+  const int64_t quota = quota_of(c, c->s().ref.len);
   // the sampling method never truncates a read: it only stops before the first read that starts at or past the quota
   launch_quota_cut(c->s().d_cum.as<int64_t>(),
                    c->p.method == PBSIM_METHOD_SAMPLE ? nullptr : c->s().d_rawlen.as<int32_t>(), c->s().b_n, len_total_before, quota,
@@ -912,7 +764,7 @@ static int finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info
 }
 
 // Second half: text sizes, their scans, and the text itself into the slot's device buffers.
-static int finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
+extern "C++" int pbsim::finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
   DeviceFlags *flags = c->s().d_flags.as<DeviceFlags>();
   DeviceFlags f;
   pbsim_batch_info bi = c->s().b_info;
@@ -973,7 +825,7 @@ int pbsim_batch_fetch(pbsim_ctx *c, char *read_text, char *maf_text) {
 
 // pbsim.cpp:3986-4005 (errhmm) / 2293-2316 (qshmm), applied in read order so the
 // order-dependent double sum `accuracy_total` matches the CPU bit for bit
-int pbsim_batch_account(pbsim_ctx *c) {
+extern "C++" int pbsim::account_slot(pbsim_ctx *c, StatsAcc *st) {
   if (!c || !c->s().b_finalized) return fail("pbsim_batch_account: no finalized batch");
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
@@ -988,71 +840,41 @@ int pbsim_batch_account(pbsim_ctx *c) {
   HIP_OK(hipMemcpyAsync(ns, c->s().d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
   HIP_OK(hipMemcpyAsync(ni, c->s().d_nins.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
   HIP_OK(hipMemcpyAsync(nd, c->s().d_ndel.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
-  if (has_quality_row(c))
-    HIP_OK(hipMemcpyAsync(qs, c->s().d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, c->s().stream));
+  const bool quality = has_quality_row(c);
+  if (quality) HIP_OK(hipMemcpyAsync(qs, c->s().d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, c->s().stream));
   HIP_OK(hipStreamSynchronize(c->s().stream));
-  c->res_num += c->s().b_info.n_final;
-  for (int64_t t = 0; t < n_tasks; t++) {
-    const long len = ol[t];
-    c->res_len_total += len;
-    if ((size_t)len < c->freq_len.size()) c->freq_len[len]++;
-    if (len > c->res_len_max) c->res_len_max = len;
-    if (len < c->res_len_min) c->res_len_min = len;
-    c->res_sub += ns[t];
-    c->res_ins += ni[t];
-    c->res_del += nd[t];
-    double value;
-    if (has_quality_row(c)) value = 1.0 - (qs[t] / len);
-    else value = 1.0 - ((double)((long)ns[t] + ni[t] + nd[t]) / len);
-    c->accuracy_total += value;
-    const double w = value * 100000 + 0.5;
-    if (w >= 0 && w < 100001) c->freq_acc[(int)w]++;
+  st->res_num += c->s().b_info.n_final;
+  std::vector<double> *values = nullptr;
+  if (st->keep_values) {
+    st->blocks.emplace_back();
+    st->blocks.back().first_task = (c->s().b_first - 1) * P;
+    values = &st->blocks.back().values;
+    values->reserve((size_t)n_tasks);
   }
+  for (int64_t t = 0; t < n_tasks; t++) stats_add_task(st, c->p.len_max, quality, ol[t], ns[t], ni[t], nd[t], quality ? qs[t] : 0.0, values);
   return PBSIM_SUCCEEDED;
 }
+
+int pbsim_batch_account(pbsim_ctx *c) { return c ? account_slot(c, &c->st) : fail("pbsim_batch_account: bad argument"); }
 
 int pbsim_get_stats(pbsim_ctx *c, pbsim_stats *o) {  // pbsim.cpp:4082-4105, 5541-5562
   if (!c || !o) return fail("pbsim_get_stats: bad argument");
-  memset(o, 0, sizeof *o);
-  o->res_num = c->res_num;
-  o->res_pass_num = c->res_num * c->p.pass_num;
-  o->res_len_total = c->res_len_total;
-  o->res_len_min = c->res_len_min;
-  o->res_len_max = c->res_len_max;
-  o->res_sub_num = c->res_sub;
-  o->res_ins_num = c->res_ins;
-  o->res_del_num = c->res_del;
-  o->res_len_mean = (double)c->res_len_total / o->res_pass_num;
-  o->res_accuracy_mean = c->accuracy_total / o->res_pass_num;
-  if (o->res_pass_num == 1) {
-    o->res_len_sd = 0.0;
-    o->res_accuracy_sd = 0.0;
-  } else {
-    double variance = 0.0;
-    for (long i = 0; i <= (long)c->p.len_max; i++)
-      if (c->freq_len[i] > 0) variance += pow((o->res_len_mean - i), 2) * c->freq_len[i];
-    o->res_len_sd = sqrt(variance / o->res_pass_num);
-    variance = 0.0;
-    for (long i = 0; i <= 100000; i++)
-      if (c->freq_acc[i] > 0) variance += pow((o->res_accuracy_mean - i * 0.00001), 2) * c->freq_acc[i];
-    o->res_accuracy_sd = sqrt(variance / o->res_pass_num);
-  }
-  if (c->p.strategy == PBSIM_STRATEGY_WGS && c->ref_len > 0)
-    o->res_depth = (double)c->res_len_total / c->ref_len / c->p.pass_num;
-  o->res_sub_rate = (double)c->res_sub / c->res_len_total;
-  o->res_ins_rate = (double)c->res_ins / c->res_len_total;
-  o->res_del_rate = (double)c->res_del / c->res_len_total;
+  stats_finish(c->st, c->p, c->p.strategy == PBSIM_STRATEGY_WGS ? c->ref_len : 0, o);
   return PBSIM_SUCCEEDED;
 }
 
-int64_t pbsim_sam_header(pbsim_ctx *c, char *buf, int64_t cap) {  // pbsim.cpp:721-722, 784-785
-  if (!c) return -1;
+extern "C++" std::string pbsim::sam_header_text(const pbsim_ctx *c, int64_t unit) {  // pbsim.cpp:721-722, 784-785
   std::string h = "@HD\tVN:1.5\tSO:unknown\tpb:3.0.7\n";
   h += "@RG\tID:ffffffff\tPL:PACBIO\tDS:READTYPE=SUBREAD;Ipd:CodecV1=ip;PulseWidth:CodecV1=pw;"
        "BINDINGKIT=101-789-500;SEQUENCINGKIT=101-826-100;BASECALLERVERSION=5.0.0;FRAMERATEHZ=100.000000\tPU:";
   h += c->p.id_prefix;
-  if (c->p.strategy == PBSIM_STRATEGY_WGS) h += std::to_string((long)c->unit);
+  if (c->p.strategy == PBSIM_STRATEGY_WGS) h += std::to_string((long)unit);
   h += "\tPM:SEQUELII\n";
+  return h;
+}
+int64_t pbsim_sam_header(pbsim_ctx *c, char *buf, int64_t cap) {
+  if (!c) return -1;
+  const std::string h = sam_header_text(c, c->unit);
   if (buf && cap > (int64_t)h.size()) memcpy(buf, h.c_str(), h.size() + 1);
   return (int64_t)h.size();
 }
@@ -1096,8 +918,11 @@ int ensure_deflate_tables(pbsim_ctx *c) {
 // d_text[0..n) (device; 16-byte aligned with 16 bytes of slack) -> gzip members, handed to `consume` piece by piece
 // (DF_PIECE_CHUNKS chunks each) from pinned staging.  While the host consumes piece k-1 (a file write, a memcpy),
 // piece k is being copied down and the GPU may already be working for another slot.
+// `place` (optional): where a piece of `total` compressed bytes shall be copied to (pinned host memory of the caller's, e.g.
+// an arena that keeps a whole batch) instead of the lane's double-buffered staging.
 template <class F>
-int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F &&consume) {
+int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F &&consume,
+                   const std::function<char *(int64_t)> *place = nullptr) {
   if (n <= 0) return PBSIM_SUCCEEDED;
   if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
   const int64_t piece = (int64_t)DF_PIECE_CHUNKS * DF_CHUNK;
@@ -1123,13 +948,14 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     }
   }
   int64_t pending = 0;  // bytes of the previous piece, in h_df_out[k ^ 1], copy possibly still in flight
+  const char *pending_ptr = nullptr;
   bool used[2] = {false, false};
   int k = 0;
   for (int64_t off = 0; off < n; off += piece, k ^= 1) {
     const int64_t len = std::min(piece, n - off);
     const int64_t nch = (len + DF_CHUNK - 1) / DF_CHUNK;
     HIP_OK(sl.d_df_dense[k].ensure((size_t)max_ch * DF_SLOT, true));
-    HIP_OK(sl.h_df_out[k].ensure((size_t)max_ch * DF_SLOT));
+    if (!place) HIP_OK(sl.h_df_out[k].ensure((size_t)max_ch * DF_SLOT));
     if (used[k]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[k], 0));  // piece k-2 has left this dense buffer
     launch_deflate(d_text + off, len, sl.d_df_slots.as<uint8_t>(), sl.d_df_sizes.as<int32_t>(),
                    sl.d_df_offsets.as<int64_t>(), sl.d_df_dense[k].as<uint8_t>(), tab, tab + 1024, sl.stream, d_prof);
@@ -1139,14 +965,17 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     HIP_OK(hipStreamSynchronize(sl.stream));
     const int64_t total = *reinterpret_cast<int64_t *>(sl.h_df_total.p);
     HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[k], 0));
-    HIP_OK(hipMemcpyAsync(sl.h_df_out[k].p, sl.d_df_dense[k].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
+    char *dst = place ? (*place)(total) : (char *)sl.h_df_out[k].p;
+    if (!dst) return fail("deflate: no room for a compressed piece");
+    HIP_OK(hipMemcpyAsync(dst, sl.d_df_dense[k].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
     HIP_OK(hipEventRecord(sl.ev_cp[k], sl.copy_stream));
     used[k] = true;
     if (pending) {
       HIP_OK(hipEventSynchronize(sl.ev_cp[k ^ 1]));
-      if (!consume((const char *)sl.h_df_out[k ^ 1].p, pending)) return PBSIM_FAILED;
+      if (!consume(pending_ptr, pending)) return PBSIM_FAILED;
     }
     pending = total;
+    pending_ptr = dst;
   }
   HIP_OK(hipStreamSynchronize(sl.copy_stream));
   if (d_prof) {
@@ -1159,7 +988,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     for (int i = 0; i < 11; ++i) fprintf(stderr, " %s %.1f", names[i], t[i] / nch / 100);
     fprintf(stderr, "\n");
   }
-  if (pending && !consume((const char *)sl.h_df_out[k ^ 1].p, pending)) return PBSIM_FAILED;
+  if (pending && !consume(pending_ptr, pending)) return PBSIM_FAILED;
   return PBSIM_SUCCEEDED;
 }
 
@@ -1178,6 +1007,22 @@ int deflate_to_host(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, 
 
 }  // namespace
 }  // extern "C++"
+
+extern "C++" int pbsim::deflate_pieces(pbsim_ctx *c, DfLane &lane, const uint8_t *d_text, int64_t n,
+                                       const std::function<int(const char *, int64_t)> &consume,
+                                       const std::function<char *(int64_t)> *place) {
+  return deflate_stream(c, lane, d_text, n, consume, place);
+}
+extern "C++" int pbsim::prepare_enqueue(pbsim_ctx *c, uint8_t *d_seq, DevBuf &hp, DevBuf &tiles, DevBuf &flags, int64_t len,
+                                        hipStream_t stream) {
+  return enqueue_prepare(c, d_seq, hp, tiles, flags, len, 0, stream);
+}
+extern "C++" int pbsim::ensure_tables(pbsim_ctx *c, bool hp11) {
+  if (!ensure_header_tables(c) || !ensure_class_tables(c)) return PBSIM_FAILED;
+  if (c->p.method == PBSIM_METHOD_QS && !ensure_qs_tabs(c, hp11)) return PBSIM_FAILED;
+  return PBSIM_SUCCEEDED;
+}
+extern "C++" int pbsim::ensure_deflate_ready(pbsim_ctx *c) { return ensure_deflate_tables(c); }
 
 int pbsim_set_deflate(pbsim_ctx *c, int on) {
   if (!c) return fail("bad argument");
@@ -1624,10 +1469,11 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
   if (!c->d_seq) return fail("no reference set (pbsim_set_reference)");
   if (c->sq_len.empty()) return fail("no sample profile set (pbsim_set_sample_profile)");
   HIP_OK(hipSetDevice(c->device));
-  if (!ensure_class_tables(c)) return PBSIM_FAILED;
+  if (!ensure_class_tables(c) || !ensure_qs_tabs(c, c->bias.hp11_seen)) return PBSIM_FAILED;
   pbsim_reset_stats(c);
   c->cur = 0;
   Slot &sl = c->s();
+  sl.ref = current_ref(c);
   const int64_t quota = pbsim_unit_quota(c), F = (int64_t)c->sq_len.size(), G = c->ref_len;
   int64_t sample_num = quota / c->sq_total;            // :1718-1728
   const int64_t residue = quota % c->sq_total;
@@ -1798,7 +1644,7 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
       a.nins = sl.d_nins.as<int32_t>();
       a.ndel = sl.d_ndel.as<int32_t>();
       a.qsum = sl.d_qsum.as<double>();
-      const uint8_t *t = c->d_qs_tabs.as<uint8_t>();
+      const uint8_t *t = c->d_qs_tabs_v[c->bias.hp11_seen].as<uint8_t>();
       a.sub_thre = reinterpret_cast<const uint32_t *>(t);
       a.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
       a.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);

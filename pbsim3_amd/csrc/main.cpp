@@ -1,0 +1,82 @@
+// main.cpp -- the `pbsim` binary: the reference's command line on one or several MI355X.
+//   pbsim ... [--device N]            one GPU: pbsim_cli_main on the calling thread
+//   pbsim ... --devices 0,1,2,3       one rank per listed GPU, one host thread each (a GPU may be listed more than once:
+//                                     several contexts on one device, the plumbing check of a single-GPU box);
+//                                     --comm host (default): host barrier + GPU-to-GPU peer copies (thread_comm.h)
+//                                     --comm rccl: RCCL communicator over xGMI for C1 / C2 / C3 (rccl_comm.h; distinct GPUs)
+// Every rank runs the same pbsim_cli_main(argv): the job is deterministic in the values the ranks exchange, so they stay
+// in lockstep; rank 0 prints the report and creates the files, every rank writes its own byte ranges.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pbsim3_amd.h"
+#include "rccl_comm.h"
+#include "thread_comm.h"
+
+int main(int argc, char **argv) {
+  std::vector<int> devices;
+  std::string comm_kind = "host";
+  for (int i = 1; i < argc; i++) {
+    const char *a = argv[i];
+    const char *v = NULL;
+    if (!strncmp(a, "--devices=", 10)) v = a + 10;
+    else if (!strcmp(a, "--devices") && i + 1 < argc) v = argv[i + 1];
+    if (v) {
+      devices.clear();
+      for (const char *p = v; *p;) {
+        char *e = NULL;
+        const long d = strtol(p, &e, 10);
+        if (e == p || d < 0) {
+          fprintf(stderr, "ERROR (devices: %s): a comma-separated list of GPU indices.\n", v);
+          return 255;
+        }
+        devices.push_back((int)d);
+        p = (*e == ',') ? e + 1 : e;
+        if (*e && *e != ',') {
+          fprintf(stderr, "ERROR (devices: %s): a comma-separated list of GPU indices.\n", v);
+          return 255;
+        }
+      }
+    }
+    if (!strncmp(a, "--comm=", 7)) comm_kind = a + 7;
+    else if (!strcmp(a, "--comm") && i + 1 < argc) comm_kind = argv[i + 1];
+  }
+  if (comm_kind != "host" && comm_kind != "rccl") {
+    fprintf(stderr, "ERROR (comm: %s): host or rccl.\n", comm_kind.c_str());
+    return 255;
+  }
+  if (devices.empty()) return pbsim_cli_main(argc, argv, NULL, -1) & 255;
+
+  const int world = (int)devices.size();
+  pbsim::ThreadCommShared shared(devices);
+  std::vector<pbsim::ThreadCommRank> ranks((size_t)world);
+  std::vector<pbsim_comm> comms((size_t)world);
+  std::vector<pbsim::RcclRank> rccl((size_t)world);
+  for (int r = 0; r < world; r++) {
+    ranks[(size_t)r] = pbsim::ThreadCommRank{&shared, r};
+    comms[(size_t)r] = pbsim::thread_comm(&ranks[(size_t)r]);
+  }
+  if (comm_kind == "rccl") {
+    std::string err;
+    if (!pbsim::rccl_init_all(devices, &rccl, &err)) {
+      fprintf(stderr, "ERROR: --comm rccl: %s\n", err.c_str());
+      return 255;
+    }
+    for (int r = 0; r < world; r++) comms[(size_t)r] = pbsim::rccl_comm(&rccl[(size_t)r]);
+  }
+  std::vector<int> rc((size_t)world, 0);
+  std::vector<std::thread> th;
+  for (int r = 1; r < world; r++)
+    th.emplace_back([&, r]() { rc[(size_t)r] = pbsim_cli_main(argc, argv, &comms[(size_t)r], devices[(size_t)r]); });
+  rc[0] = pbsim_cli_main(argc, argv, &comms[0], devices[0]);
+  for (std::thread &t : th) t.join();
+  if (comm_kind == "rccl") pbsim::rccl_destroy_all(&rccl);
+  for (int r = 0; r < world; r++)
+    if (rc[(size_t)r]) return rc[(size_t)r] & 255;
+  return 0;
+}

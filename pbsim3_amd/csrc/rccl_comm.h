@@ -1,0 +1,162 @@
+// rccl_comm.h -- pbsim_comm over RCCL (xGMI) for the ranks of one process, one host thread per GPU: ncclBroadcast carries
+// a record from the loading rank's GPU to all others (C1), ncclAllGather the per-round integers (C3), ncclAllReduce the
+// statistics (C2) -- the three collectives SURVEY 8(e) names.  librccl is opened at run time (dlopen), so the binary has no
+// link-time dependency on it and a box without it still runs --comm host.  RCCL refuses two ranks on one device: distinct
+// GPUs only (a single-GPU box can run --devices 0 --comm rccl, a communicator of one).
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pbsim3_amd.h"
+
+namespace pbsim {
+
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool load(std::string *err) {
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      *err = "cannot open librccl.so";
+      return false;
+    }
+#define PBSIM_RCCL_SYM(field, sym)                                \
+  field = reinterpret_cast<decltype(field)>(dlsym(lib, sym));     \
+  if (!field) {                                                   \
+    *err = std::string("librccl lacks ") + sym;                   \
+    return false;                                                 \
+  }
+    PBSIM_RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    PBSIM_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    PBSIM_RCCL_SYM(Broadcast, "ncclBroadcast")
+    PBSIM_RCCL_SYM(AllReduce, "ncclAllReduce")
+    PBSIM_RCCL_SYM(AllGather, "ncclAllGather")
+    PBSIM_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef PBSIM_RCCL_SYM
+    return true;
+  }
+};
+
+struct RcclRank {
+  RcclApi *api = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t stream = nullptr;
+  void *d_send = nullptr, *d_recv = nullptr;  // staging for the integer collectives
+  size_t cap = 0;
+  bool ensure(size_t bytes_send, size_t bytes_recv) {
+    if (hipSetDevice(device) != hipSuccess) return false;
+    if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return false;
+    const size_t need = bytes_send > bytes_recv ? bytes_send : bytes_recv;
+    if (need <= cap) return true;
+    if (d_send) (void)hipFree(d_send);
+    if (d_recv) (void)hipFree(d_recv);
+    cap = need + need / 4 + 4096;
+    return hipMalloc(&d_send, cap) == hipSuccess && hipMalloc(&d_recv, cap) == hipSuccess;
+  }
+};
+
+inline int rccl_all_gather(void *user, const int64_t *send, int64_t n, int64_t *recv) {
+  RcclRank *r = (RcclRank *)user;
+  if (!r->ensure((size_t)n * 8, (size_t)n * 8 * (size_t)r->world)) return 0;
+  if (hipMemcpyAsync(r->d_send, send, (size_t)n * 8, hipMemcpyHostToDevice, r->stream) != hipSuccess) return 0;
+  if (r->api->AllGather(r->d_send, r->d_recv, (size_t)n, ncclInt64, r->comm, r->stream) != ncclSuccess) return 0;  // C3
+  if (hipMemcpyAsync(recv, r->d_recv, (size_t)n * 8 * (size_t)r->world, hipMemcpyDeviceToHost, r->stream) != hipSuccess) return 0;
+  return hipStreamSynchronize(r->stream) == hipSuccess;
+}
+
+inline int rccl_all_reduce(void *user, int64_t *buf, int64_t n, int32_t op) {
+  RcclRank *r = (RcclRank *)user;
+  if (n == 0) return 1;
+  if (!r->ensure((size_t)n * 8, (size_t)n * 8)) return 0;
+  const ncclRedOp_t rop = op == PBSIM_OP_SUM ? ncclSum : op == PBSIM_OP_MIN ? ncclMin : ncclMax;
+  if (hipMemcpyAsync(r->d_send, buf, (size_t)n * 8, hipMemcpyHostToDevice, r->stream) != hipSuccess) return 0;
+  if (r->api->AllReduce(r->d_send, r->d_recv, (size_t)n, ncclInt64, rop, r->comm, r->stream) != ncclSuccess) return 0;  // C2
+  if (hipMemcpyAsync(buf, r->d_recv, (size_t)n * 8, hipMemcpyDeviceToHost, r->stream) != hipSuccess) return 0;
+  return hipStreamSynchronize(r->stream) == hipSuccess;
+}
+
+inline int rccl_broadcast(void *user, void *p, int64_t bytes, int32_t root, int32_t on_device) {
+  RcclRank *r = (RcclRank *)user;
+  if (hipSetDevice(r->device) != hipSuccess) return 0;
+  if (!r->stream && hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return 0;
+  void *d = p;
+  if (!on_device) {
+    if (!r->ensure((size_t)bytes, (size_t)bytes)) return 0;
+    d = r->d_send;
+    if (r->rank == root && hipMemcpyAsync(d, p, (size_t)bytes, hipMemcpyHostToDevice, r->stream) != hipSuccess) return 0;
+  }
+  if (r->api->Broadcast(d, d, (size_t)bytes, ncclUint8, root, r->comm, r->stream) != ncclSuccess) return 0;  // C1
+  if (!on_device && r->rank != root && hipMemcpyAsync(p, d, (size_t)bytes, hipMemcpyDeviceToHost, r->stream) != hipSuccess) return 0;
+  return hipStreamSynchronize(r->stream) == hipSuccess;
+}
+
+inline RcclApi &rccl_api() {
+  static RcclApi api;
+  return api;
+}
+
+inline bool rccl_init_all(const std::vector<int> &devices, std::vector<RcclRank> *ranks, std::string *err) {
+  RcclApi &api = rccl_api();
+  if (!api.lib && !api.load(err)) return false;
+  for (size_t i = 0; i < devices.size(); i++)
+    for (size_t j = i + 1; j < devices.size(); j++)
+      if (devices[i] == devices[j]) {
+        *err = "RCCL takes one rank per GPU; list every device once (or use --comm host)";
+        return false;
+      }
+  std::vector<ncclComm_t> comms(devices.size());
+  const ncclResult_t rc = api.CommInitAll(comms.data(), (int)devices.size(), devices.data());
+  if (rc != ncclSuccess) {
+    *err = std::string("ncclCommInitAll: ") + api.GetErrorString(rc);
+    return false;
+  }
+  ranks->resize(devices.size());
+  for (size_t i = 0; i < devices.size(); i++) {
+    RcclRank &r = (*ranks)[i];
+    r.api = &api;
+    r.comm = comms[i];
+    r.rank = (int)i;
+    r.world = (int)devices.size();
+    r.device = devices[i];
+  }
+  return true;
+}
+
+inline void rccl_destroy_all(std::vector<RcclRank> *ranks) {
+  for (RcclRank &r : *ranks) {
+    (void)hipSetDevice(r.device);
+    if (r.stream) (void)hipStreamSynchronize(r.stream);
+    if (r.comm) (void)r.api->CommDestroy(r.comm);
+    if (r.d_send) (void)hipFree(r.d_send);
+    if (r.d_recv) (void)hipFree(r.d_recv);
+    if (r.stream) (void)hipStreamDestroy(r.stream);
+    r.comm = nullptr;
+  }
+}
+
+inline pbsim_comm rccl_comm(RcclRank *r) {
+  pbsim_comm c;
+  c.user = r;
+  c.rank = r->rank;
+  c.world = r->world;
+  c.all_gather_i64 = rccl_all_gather;
+  c.all_reduce_i64 = rccl_all_reduce;
+  c.broadcast = rccl_broadcast;
+  return c;
+}
+
+}  // namespace pbsim

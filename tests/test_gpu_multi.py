@@ -1,98 +1,107 @@
-"""Multi-rank invariance on real hardware: two processes (gloo rendezvous, both on
-the one GPU of the test box) shard a record by read block through
-pbsim3_amd.multi; the concatenated FASTQ/MAF must equal the single-context run
-byte for byte (N-GPU output == 1-GPU output)."""
+"""Multi-rank invariance on real hardware: `pbsim --devices 0,0,..` runs one rank per listed device (here: several
+contexts on the one GPU of the test box, host-barrier communicator) through the job pipeline of csrc/job.cpp.  Every
+output file AND the stderr report must equal what the reference produced for the same command line (golden manifest,
+keyed-Philox mode) -- N-GPU output == 1-GPU output == reference, byte for byte."""
+import gzip
 import os
-import sys
+import subprocess
 
 import pytest
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 import harness
-import product
 from cases import CASES
 
 pytestmark = pytest.mark.gpu
+MANIFEST = harness.load_manifest()
+CLI = os.path.join(harness.ROOT, "pbsim3_amd", "bin", "pbsim")
 
 
-def _worker(rank, world, port, args, batch, q):
-    sys.path.insert(0, harness.ROOT)
+def run_devices(args, workdir, ranks, scratch_mb=None, extra=("--no-gzip",), case=None, env=None):
+    import pbsim3_amd.build as b
+    b.build()
+    e = dict(os.environ)
+    if scratch_mb:
+        e["PBSIM_SCRATCH_MB"] = str(scratch_mb)
+    e.update(env or {})
+    if case:
+        harness.run_setup([CLI, "--no-gzip"], case, workdir)
+    p = subprocess.run([CLI] + harness.resolve(args) + ["--prefix", os.path.join(workdir, "out"), "--devices",
+                                                        ",".join(["0"] * ranks)] + list(extra),
+                       capture_output=True, text=True, cwd=workdir, env=e)
+    assert p.returncode == 0, p.stderr[-6000:]
+    outs = harness.collect(workdir)
+    outs[".stderr"] = harness.strip_report(p.stderr).encode()
+    return outs
+
+
+def check_against_golden(outs, case):
+    want = MANIFEST[f"{case}/philox"]
+    assert sorted(outs) == sorted(want), (sorted(outs), sorted(want))
+    for k, v in outs.items():
+        assert harness.sha(v) == want[k]["sha256"], (case, k, v[-600:] if k == ".stderr" else len(v))
+
+
+WGS = sorted(c for c in CASES if c.startswith("wgs_") and "sample" not in c)
+
+
+@pytest.mark.parametrize("case", WGS)
+def test_two_ranks_every_wgs_golden(case, tmp_path):
+    check_against_golden(run_devices(CASES[case]["args"], str(tmp_path), 2), case)
+
+
+@pytest.mark.parametrize("case,ranks,scratch_mb", [
+    ("wgs_errhmm-ont_quirk", 3, 3), ("wgs_errhmm-ont_quirk", 8, 4), ("wgs_errhmm-ont-hq_quirk", 4, 3),
+    ("wgs_errhmm_rsii_default", 4, 24), ("wgs_qshmm_rsii_pass3", 5, 4), ("wgs_errhmm_ont_hpbias5", 2, 3),
+    ("wgs_qshmm_onthq_pass2_hpbias2", 3, 4), ("wgs_errhmm_sequel_pass3", 8, 3)])
+def test_many_ranks_many_rounds(case, ranks, scratch_mb, tmp_path):
+    """a scratch pool of a few MB per slot forces tens of rounds per record: cuts inside any rank's block, top-up rounds,
+    tails on any rank, records overlapping in the pipeline"""
+    check_against_golden(run_devices(CASES[case]["args"], str(tmp_path), ranks, scratch_mb), case)
+
+
+@pytest.mark.parametrize("case,ranks", [("trans_errhmm_sequel", 2), ("trans_errhmm_ont_hpbias4", 3), ("trans_qshmm_rsii", 4),
+                                        ("trans_errhmm_rsii_acc98", 3), ("trans_errhmm_sequel_acc99_pass2", 2),
+                                        ("templ_errhmm_sequel", 2), ("templ_errhmm_rsii_pass3_hpbias2", 4),
+                                        ("templ_qshmm_rsii_pass2", 3)])
+def test_unit_strategies(case, ranks, tmp_path):
+    """trans / templ: rank r takes the r-th block of the unit set's read numbering (pbsim_simulate_units_range); statistics
+    merged with pbsim_stats_merge; files written by byte range"""
+    check_against_golden(run_devices(CASES[case]["args"], str(tmp_path), ranks), case)
+
+
+@pytest.mark.parametrize("case,ranks,scratch_mb", [("wgs_errhmm-ont_quirk", 3, 3), ("wgs_qshmm_rsii_pass3", 2, 4),
+                                                   ("trans_errhmm_sequel", 3, None), ("templ_qshmm_rsii_pass2", 2, None)])
+def test_compressed_outputs_by_byte_range(case, ranks, scratch_mb, tmp_path):
+    """default --gzip gpu: every rank compresses its blocks on the GPU and pwrite()s the members at the offsets the ranks
+    agreed on; the files must be valid multi-member gzip / BGZF whose payload is the golden text"""
     import pbsim3_amd as P
-    from pbsim3_amd import multi
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    p, a = product.params_from_args(args)
-    out = []
-    with P.Context(p, 0) as ctx:
-        ctx.set_scratch_bytes(256 << 20)
-        ctx.load_errhmm(a["--errhmm"])
-        recs = product.read_fasta(a["--genome"])
-        for i, r in enumerate(recs, 1):
-            ctx.set_reference(r, i)
-            kept = []
-
-            def on_batch(info):
-                rt, mt = ctx.batch_fetch(info)
-                kept.append((info.first_read, rt, mt))
-
-            reads, total = multi.simulate_record_sharded(ctx, multi.TorchComm(dist), batch, on_batch)
-            out.append((reads, total, kept))
-    q.put((rank, out))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("batch", [7, 40])
-def test_two_ranks_reproduce_single_context(batch):
-    case = "wgs_errhmm-ont_quirk"
-    args = harness.resolve(CASES[case]["args"])
-    want, stats = product.run_wgs(args)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() + batch) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, args, batch, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-    for rec in range(len(stats)):
-        pieces = sorted(res[0][rec][2] + res[1][rec][2])
-        fq = b"".join(x[1] for x in pieces)
-        maf = b"".join(x[2] for x in pieces)
-        assert res[0][rec][0] == res[1][rec][0] == stats[rec].res_num
-        assert fq == want["_%04d.fq" % (rec + 1)]
-        assert maf == want["_%04d.maf" % (rec + 1)]
+    import test_gpu_bam
+    work = tmp_path / "w"
+    work.mkdir()
+    outs = run_devices(CASES[case]["args"], str(work), ranks, scratch_mb, extra=())
+    want = MANIFEST[f"{case}/philox"]
+    gold = None
+    seen = 0
+    for n in sorted(os.listdir(work)):
+        raw = open(work / n, "rb").read()
+        if n.endswith((".fq.gz", ".maf.gz")):
+            assert harness.sha(gzip.decompress(raw)) == want[n[len("out"):-3]]["sha256"], n
+            seen += 1
+        elif n.endswith(".bam"):
+            assert raw.endswith(P.BGZF_EOF)
+            if gold is None:
+                (tmp_path / "g").mkdir()
+                gold = harness.run_oracle(CASES[case]["args"], "philox", str(tmp_path / "g"))
+            test_gpu_bam.compare_bam_with_sam(raw, gold[n[len("out"):-4] + ".sam"])
+            seen += 1
+    assert seen >= 2
+    assert harness.sha(outs[".stderr"]) == want[".stderr"]["sha256"]
 
 
-def test_unit_range_shards_concatenate_to_the_whole(tmp_path):
-    """pbsim_simulate_units_range: any partition of 1 .. pbsim_unit_reads() into contiguous blocks gives, concatenated,
-    the bytes of pbsim_simulate_trans; the shard statistics add up; bad ranges are refused"""
-    import pbsim3_amd as P
-    from pbsim3_amd import args as A
-    argv = harness.resolve(CASES["trans_errhmm_sequel"]["args"])
-    p, a = A.parse(argv)
-    with P.Context(p, 0) as ctx:
-        ctx.load_errhmm(a["--errhmm"])
-        n_units, total = ctx.load_transcript_file(a["--transcript"])
-        R = ctx.unit_reads()
-        assert n_units > 0 and R == total
-        whole = ctx.simulate_trans()
-        st = ctx.stats()
-        for cuts in ([0, R], [0, 1, R], [0, R // 3, R // 3, 2 * R // 3, R - 1, R]):
-            rt = mt = b""
-            n = bases = 0
-            for lo, hi in zip(cuts, cuts[1:]):
-                r, m = ctx.simulate_units_range(lo + 1, hi - lo)
-                rt += r
-                mt += m
-                if hi > lo:
-                    s = ctx.stats()
-                    n += s.res_num
-                    bases += s.res_len_total
-            assert (rt, mt) == whole
-            assert (n, bases) == (st.res_num, st.res_len_total)
-        for first, cnt in ((0, 1), (1, R + 1), (R + 1, 1), (1, -1)):
-            with pytest.raises(P.PbsimError):
-                ctx.simulate_units_range(first, cnt)
+def test_failure_on_one_rank_stops_the_job(tmp_path):
+    """a model file that does not exist: every rank fails alike, status 255, nothing hangs"""
+    p = subprocess.run([CLI, "--strategy", "wgs", "--method", "errhmm", "--errhmm", "/nonexistent.model", "--genome",
+                        os.path.join(harness.GOLDEN, "inputs", "quirk.fa"), "--prefix", str(tmp_path / "o"), "--devices", "0,0"],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 255
+    assert "ERROR" in p.stderr
