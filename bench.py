@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py -- simulated bases/s of the HIP hot path on MI355X.
+"""bench.py -- simulated bases/s of the HIP hot path on MI355X: the whole BASELINE job, on 1..N GPUs.
 
-Workload (BASELINE.json configs[1]): --strategy wgs --method errhmm --errhmm
-ERRHMM-ONT.model, default length/accuracy parameters, on a synthetic uniform
-ACGT genome resident in HBM.  One "step" = one batch of reads through the whole
-path: header draw -> (class,length) bucketing -> ERRHMM walk -> quota scan ->
-FASTQ + MAF text emitted into HBM buffers.  Inputs are resident before the timed
-region; outputs stay in HBM (PCIe-inclusive rate: DESIGN.md).
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): --strategy wgs --method errhmm --errhmm
+ERRHMM-ONT.model --depth 20, default length / accuracy parameters, on a synthetic 3 Gbp genome = 4 records x 750 Mbp of
+uniform ACGT, all resident in HBM before the timed region.  One "step" = one complete run of the job through
+pbsim_job_run: header draws, (class, length) bucketing, ERRHMM walks, the quota rule with its truncated tail reads, FASTQ +
+MAF text emitted on the GPU, per-record statistics -- AND the delivery of the output: FASTQ + MAF are compressed on the GPU
+(BGZF-framed gzip members, deflate.hip) and copied into pinned host memory, where a sink receives them ("incl.
+batch D2H"; what the CLI does for .fq.gz / .maf.gz except the file writes).  `value` = bases of the job / wall time of a
+step.  Sub-fields give the same job with the text left in HBM (whole_job_hbm) and the steady-state batch pipeline on one
+record (steady_state_hbm).
 
-N > 1 (torchrun, one rank per GPU): rank 0's genome is broadcast over RCCL,
-reads shard by contiguous read-index block per rank, the pass-0 base counts are
-all-gathered to place each rank's quota prefix, and the statistics counters are
-all-reduced.  Weak scaling: every rank walks a full batch per step.
+--gpus N (torchrun, one rank per GPU): the SAME job, strong scaling.  Rank 0 generates the records, RCCL broadcasts them
+(C1), every round of the pipeline is sharded by read block over the ranks, the ranks exchange only integers (C3 all-gather
+per round, C2 all-reduce per record) through torch.distributed (backend nccl = RCCL over xGMI); every rank delivers its
+own blocks to its own host memory.
 """
 import argparse
 import json
@@ -19,6 +22,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,15 +32,46 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 RECORD_LEN = 750_000_000     # one of the 4 records of the 3 Gbp genome (<= REF_SEQ_LEN_MAX, pbsim.cpp:24)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PCIE_PEAK_GBS = 63.0         # Gen5 x16, one direction
+
+WORKLOADS = {
+    # name: (method, model, depth, pass_num, description)
+    "errhmm": ("errhmm", "ERRHMM-ONT.model", 20.0, 1, "BASELINE configs[1]: wgs errhmm ERRHMM-ONT depth 20"),
+    "onthq60": ("errhmm", "ERRHMM-ONT-HQ.model", 60.0, 1, "BASELINE configs[4]: wgs errhmm ERRHMM-ONT-HQ depth 60"),
+    "qshmm10": ("qshmm", "QSHMM-RSII.model", 20.0, 10, "BASELINE configs[2]: wgs qshmm QSHMM-RSII depth 20 pass-num 10 (BAM records)"),
+}
+
+def physical_cores():
+    """(physical cores, logical CPUs) this process may run on"""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return min(len(seen), logical), logical
+    except OSError:
+        pass
+    return logical, logical
 
 
-def cpu_baseline(sample_bp=4_000_000):
-    """Reference pbsim (oracle/_ref/pbsim_ref, compiled from /root/reference in the
-    build container) or, if absent, the C oracle in glibc mode, timed single-threaded
-    on a bounded sample of the same workload with compression bypassed."""
+def cpu_baseline(model="ERRHMM-ONT.model", depth=20, sample_bp=4_000_000):
+    """The reference itself (oracle/_ref/pbsim_ref, compiled from /root/reference in the build container; else the C
+    restatement in glibc mode) timed on the GPU box's host cores on a bounded sample of the same workload, compression
+    bypassed: one core; the keyed-Philox build on one core (the stream the GPU output is bit-identical to); and one copy per
+    physical core, concurrently.  A reported baseline, not the target."""
     import numpy as np
     import harness
     ref = harness.REF_GLIBC if os.path.exists(harness.REF_GLIBC) else None
+    ref_philox = harness.REF_PHILOX if os.path.exists(harness.REF_PHILOX) else None
     if ref is None:
         harness.build_oracle()
     with tempfile.TemporaryDirectory() as td:
@@ -46,57 +81,68 @@ def cpu_baseline(sample_bp=4_000_000):
         with open(fa, "wb") as f:
             f.write(b">chr1\n")
             lines = seq.reshape(-1, 80)
-            out = np.concatenate([lines, np.full((lines.shape[0], 1), 10, np.uint8)], axis=1)
-            f.write(out.tobytes())
-        model = harness.model_path("ERRHMM-ONT.model")
-        args = ["--strategy", "wgs", "--method", "errhmm", "--errhmm", model, "--genome", fa,
-                "--depth", "20", "--seed", "1", "--prefix", os.path.join(td, "out")]
-        env = dict(os.environ)
-        if ref:
-            stubs = os.path.join(td, "stubs")
-            harness.make_stubs(stubs)
+            f.write(np.concatenate([lines, np.full((lines.shape[0], 1), 10, np.uint8)], axis=1).tobytes())
+        mpath = harness.model_path(model)
+
+        def command(exe, prefix, seed, dep, philox=False):
+            args = ["--strategy", "wgs", "--method", "errhmm", "--errhmm", mpath, "--genome", fa,
+                    "--depth", str(dep), "--seed", str(seed), "--prefix", os.path.join(td, prefix)]
+            if exe in (ref, ref_philox):
+                return [exe] + args
+            return [harness.ORACLE] + args + ["--rng", "philox" if philox else "glibc"]
+
+        def env_for(seed, null_out):
+            env = dict(os.environ, PBSHIM_SEED=str(seed), PBSHIM_MODE="philox")
+            stubs = os.path.join(td, "stubs_null" if null_out else "stubs")
+            if not os.path.exists(stubs):
+                harness.make_stubs(stubs)
+                if null_out:      # the text is produced and piped, then dropped: no 100 MB files per copy
+                    for n in ("gzip", "samtools"):
+                        with open(os.path.join(stubs, n), "w") as f:
+                            f.write("#!/bin/sh\nexec cat > /dev/null\n")
             env["PATH"] = stubs + ":" + env["PATH"]
-            cmd = [ref] + args
-        else:
-            cmd = [harness.ORACLE] + args + ["--rng", "glibc"]
-        t0 = time.time()
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True)
-        dt = time.time() - t0
-        if p.returncode != 0:
+            return env
+
+        def bases_of_report(err):
+            """sum over records of read num x mean length (printed with 6 decimals: exact below a million reads)"""
+            n = tot = 0
+            for line in err.splitlines():
+                if line.startswith("read num. :"):
+                    n = int(line.split(":")[1])
+                elif line.startswith("read length mean (SD) :"):
+                    tot += round(n * float(line.split(":")[1].split("(")[0]))
+            return tot
+
+        def one(exe, philox=False):
+            t0 = time.time()
+            p = subprocess.run(command(exe, "one", 1, depth, philox), env=env_for(1, True), capture_output=True, text=True)
+            dt = time.time() - t0
+            return (bases_of_report(p.stderr) / dt, dt) if p.returncode == 0 else (None, dt)
+
+        exe = ref or harness.ORACLE
+        v1, dt1 = one(exe)
+        if v1 is None:
             return None
-
-        def count(prefix):
-            n = 0
-            for fn in os.listdir(td):
-                if fn.startswith(prefix) and (fn.endswith(".fq") or fn.endswith(".fq.gz")):
-                    with open(os.path.join(td, fn), "rb") as f:
-                        for i, line in enumerate(f):
-                            if i % 4 == 1:
-                                n += len(line) - 1
-            return n
-
-        bases = count("out")
-        # the same job once per host core, concurrently (distinct seeds and prefixes): what the box's CPU can do at best
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        ncopy = min(ncpu, 64)                # bounded: every copy writes ~85 MB of text into the temp dir
-        procs = []
+        vp, dtp = one(ref_philox or harness.ORACLE, philox=True)
+        phys, logical = physical_cores()
+        ncopy = min(phys, 256)
+        per_copy_depth = max(2, min(depth, 5))
         t1 = time.time()
-        for k in range(ncopy):
-            a2 = list(cmd)
-            a2[a2.index("--seed") + 1] = str(100 + k)
-            a2[a2.index("--depth") + 1] = "5"
-            a2[a2.index("--prefix") + 1] = os.path.join(td, "all%d" % k)
-            procs.append(subprocess.Popen(a2, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
-        rcs = [q.wait() for q in procs]
+        procs = [subprocess.Popen(command(exe, "all%d" % k, 100 + k, per_copy_depth), env=env_for(100 + k, True),
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True) for k in range(ncopy)]
+        outs = [q.communicate()[1] for q in procs]
         dt_all = time.time() - t1
-        if all(rc == 0 for rc in rcs):
-            all_cores = {"value": count("all") / dt_all, "cores": ncopy,
-                         "note": f"{ncopy} concurrent copies of the sample job at depth 5 on the box's {ncpu} host cores"}
+        if all(q.returncode == 0 for q in procs):
+            all_cores = {"value": sum(bases_of_report(o) for o in outs) / dt_all, "cores": ncopy,
+                         "note": f"{ncopy} concurrent copies (one per physical core; {logical} logical CPUs) of the sample job at "
+                                 f"depth {per_copy_depth}, distinct seeds, {dt_all:.1f}s"}
         else:
-            all_cores = {"value": None, "cores": ncopy, "note": f"{sum(rc != 0 for rc in rcs)} of {ncopy} copies failed"}
-    return {"value": bases / dt, "unit": "bases/s", "cores": 1, "kind": "reference" if ref else "port",
-            "sample": f"{sample_bp // 1_000_000} Mbp uniform genome x depth 20, ERRHMM-ONT, seed 1, "
-                      f"{bases} bases in {dt:.1f}s, gzip bypassed (cat)",
+            all_cores = {"value": None, "cores": ncopy, "note": "some copies failed"}
+    return {"value": v1, "unit": "bases/s", "cores": 1, "kind": "reference" if ref else "port",
+            "sample": f"{sample_bp // 1_000_000} Mbp uniform genome x depth {depth}, {model[:-6]}, seed 1, {dt1:.1f}s, "
+                      "text piped into `cat > /dev/null` instead of gzip",
+            "philox_mode": {"value": vp, "cores": 1, "kind": "reference + oracle/ref_shim.h" if ref_philox else "port",
+                            "note": f"same job on the keyed Philox stream (the one the GPU output is bit-identical to), {dtp:.1f}s"},
             "all_cores": all_cores}
 
 
@@ -183,30 +229,107 @@ def issue_bound(columns_per_launch, walk_s):
             "source": "profiles/r01x_walk_pmc.json (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD-cycles)"}
 
 
+def make_records(torch, dist, dev, cdev, rank, world, n_rec, G):
+    """uniform ACGT records, generated on rank 0's GPU (seed 100 + r) and broadcast over RCCL (C1)"""
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    recs = []
+    for r in range(n_rec):
+        if rank == 0:
+            gen.manual_seed(100 + r)
+            t = torch.cat([lut[torch.randint(0, 4, (min(64_000_000, G - o),), dtype=torch.uint8, device=dev, generator=gen).long()]
+                           for o in range(0, G, 64_000_000)])
+        else:
+            t = torch.empty(G, dtype=torch.uint8, device=dev)
+        if world > 1:
+            if cdev == dev:
+                dist.broadcast(t, src=0)
+            else:                                # gloo plumbing check: through host memory
+                h = t.cpu()
+                dist.broadcast(h, src=0)
+                t = h.to(dev)
+        recs.append(t)
+    torch.cuda.synchronize()
+    return recs
+
+
+class CountingSink:
+    """receives the members in pinned host memory and only counts them (one counter per sink: the two arrive from two threads)"""
+
+    def __init__(self, P, C):
+        self.read_bytes = self.maf_bytes = 0
+        self.stats = {}
+        self._cbs = (P.REC_TEXT_CB(self._read), P.REC_TEXT_CB(self._maf), P.REC_DONE_CB(self._done))
+        self.sink = P.RecordSink(None, *self._cbs)
+        self.P, self.C = P, C
+
+    def _read(self, user, rec, text, n, off):
+        self.read_bytes += n
+        return 1
+
+    def _maf(self, user, rec, text, n, off):
+        self.maf_bytes += n
+        return 1
+
+    def _done(self, user, rec, st, rb, mb):
+        s = self.P.Stats()
+        self.C.memmove(self.C.byref(s), st, self.C.sizeof(self.P.Stats))
+        self.stats[rec] = (s.res_num, s.res_len_total, rb, mb)
+        return 1
+
+
+def steady_state(a, torch, harness, P, local, model, genome_ptr, G):
+    """the batch pipeline alone: two slots, one record, full batches, no quota cut, text left in HBM (the round-1 headline)"""
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=20.0)
+    ctx = P.Context(p, local)
+    ctx.set_scratch_bytes(int(a.scratch_gib * (1 << 30)))
+    ctx.load_errhmm(harness.model_path(model))
+    ctx.set_reference_device(genome_ptr, G, 1)
+    B, S = ctx.batch_capacity(), 2
+
+    def run(first_step, n_steps):
+        infos, pending, nxt = [], [], first_step
+        while len(infos) < n_steps:
+            while len(pending) < S and nxt < first_step + n_steps:
+                ctx.select_slot(nxt % S)
+                ctx.batch_walk_begin(1 + nxt * B, B)
+                pending.append(nxt)
+                nxt += 1
+            i = pending.pop(0)
+            ctx.select_slot(i % S)
+            ctx.batch_walk_end()
+            infos.append(ctx.batch_finalize(0))
+        return infos
+    run(0, S)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    infos = run(S, 4)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return {"value": sum(i.bases for i in infos) / dt, "unit": "bases/s", "steps": 4, "reads_per_step": B,
+            "note": "two batches in flight on one record, every read final (no quota cut), FASTQ + MAF text left in HBM"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--slots", type=int, default=2, help="batches kept in flight per GPU (engine slots)")
+    ap.add_argument("--steps", type=int, default=3, help="timed runs of the whole job")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--record-len", type=int, default=RECORD_LEN)
-    ap.add_argument("--scratch-gib", type=float, default=48.0)
-    ap.add_argument("--batch-reads", type=int, default=0, help="reads per step per GPU (0 = what the scratch pool holds)")
-    ap.add_argument("--model", default="ERRHMM-ONT.model")
-    ap.add_argument("--workload", default="errhmm", choices=["errhmm", "qshmm10", "trans", "sample"],
-                    help="errhmm = BASELINE configs[1] (headline); qshmm10 = configs[2]: QSHMM-RSII, --pass-num 10; "
-                         "trans = configs[3]: ERRHMM-SEQUEL on a synthetic 100k-transcript profile (whole job, wall time)")
+    ap.add_argument("--records", type=int, default=4)
+    ap.add_argument("--scratch-gib", type=float, default=48.0, help="steady-state sub-measurement only")
+    ap.add_argument("--workload", default="errhmm", choices=sorted(WORKLOADS) + ["trans", "sample"],
+                    help="errhmm = BASELINE configs[1] (headline); onthq60 = configs[4]; qshmm10 = configs[2]; "
+                         "trans = configs[3] (whole job, wall time); sample = the sampling method")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--whole-job", action="store_true",
-                    help="not the per-step metric: run the complete configs[1] job (4 records x --record-len, depth 20, "
-                         "quota loop + tail + statistics, text left in HBM) through pbsim_simulate_wgs and report its wall time")
-    ap.add_argument("--deflate", action="store_true",
-                    help="with --whole-job: compress FASTQ + MAF on the GPU (pbsim_set_deflate) and copy the members to pinned "
-                         "host memory -- everything the CLI does for .fq.gz/.maf.gz except the file writes")
+    ap.add_argument("--no-extras", action="store_true", help="skip the whole_job_hbm / steady_state_hbm sub-measurements")
+    ap.add_argument("--hbm-only", action="store_true", help="experiment: leave the text in HBM in the timed runs too")
     ap.add_argument("--param", action="append", default=[],
                     help="experiment only: override a pbsim_params field, e.g. --param len_sd=0 (not the headline workload)")
     a = ap.parse_args()
 
+    import ctypes as C
     import torch
     import harness
     import pbsim3_amd as P
@@ -223,6 +346,7 @@ def main():
         if os.environ.get("PBSIM_BENCH_ONE_GPU") == "1":
             local = 0
         if backend == "nccl":
+            torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
@@ -230,195 +354,150 @@ def main():
     dev = torch.device("cuda", local)
     cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")  # where collectives run
 
-    # ---- inputs resident in HBM: genome record (rank 0 generates, RCCL broadcasts) ----
-    G = a.record_len
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    if rank == 0:
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(1)
-        genome = lut[torch.randint(0, 4, (G,), dtype=torch.uint8, device=dev, generator=gen).long()] \
-            if G <= 64_000_000 else torch.cat([
-                lut[torch.randint(0, 4, (min(64_000_000, G - o),), dtype=torch.uint8, device=dev, generator=gen).long()]
-                for o in range(0, G, 64_000_000)])
-    else:
-        genome = torch.empty(G, dtype=torch.uint8, device=dev)
-    if world > 1:
-        if cdev == dev:
-            dist.broadcast(genome, src=0)      # C1: reference broadcast over xGMI (RCCL)
-        else:
-            g = genome.cpu()
-            dist.broadcast(g, src=0)
-            genome = g.to(dev)
-    torch.cuda.synchronize()
-
     if a.workload == "sample":
         return bench_sample(a, torch, harness, P, local)
     if a.workload == "trans":
         return bench_trans(a, torch, harness, P, local)
-    qs = a.workload == "qshmm10"
-    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=1, depth=20.0,
-                         pass_num=10 if qs else 1)
+    method, model, depth, pass_num, desc = WORKLOADS[a.workload]
+    qs = method == "qshmm"
+    G, NR = a.record_len, a.records
+
+    recs = make_records(torch, dist, dev, cdev, rank, world, NR, G)
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=1, depth=depth, pass_num=pass_num)
     for kv in a.param:
         k, v = kv.split("=")
         setattr(p, k, type(getattr(p, k))(float(v)))
     ctx = P.Context(p, local)
-    ctx.set_scratch_bytes(int(a.scratch_gib * (1 << 30)))
-    if qs:
-        ctx.load_qshmm(harness.model_path("QSHMM-RSII.model"))
-    else:
-        ctx.load_errhmm(harness.model_path(a.model))
-    ctx.set_reference_device(genome.data_ptr(), G, 1)
-    del genome
-    torch.cuda.empty_cache()
-    B = a.batch_reads or ctx.batch_capacity()
-    quota = ctx.unit_quota()
+    (ctx.load_qshmm if qs else ctx.load_errhmm)(harness.model_path(model))
+    if pass_num > 1:
+        ctx.set_bam_output(True)
+    for t in recs:
+        ctx.job_add_record_device(t.data_ptr(), G)
+    comm = P.torch_comm(dist, cdev) if world > 1 else None
+    cref = C.byref(comm) if comm is not None else None
 
-    if a.whole_job:
-        assert world == 1, "--whole-job is a single-GPU measurement"
-        recs = []
-        gen = torch.Generator(device=dev)
-        for r in range(4):
-            gen.manual_seed(100 + r)
-            recs.append(torch.cat([lut[torch.randint(0, 4, (min(64_000_000, G - o),), dtype=torch.uint8, device=dev,
-                                                    generator=gen).long()] for o in range(0, G, 64_000_000)]))
-        gz_bytes = [0]
-        if a.deflate:                            # sinks that only count: the members are already in pinned host memory
-            import ctypes as C
-            ctx.set_deflate(int(os.environ.get("PBSIM_BENCH_DEFLATE_MASK", "7")))   # bit 2: the two sinks from two host threads
+    def run_job(deliver):
+        sink = CountingSink(P, C)
+        ctx.set_deflate(7 if deliver else 0)    # bits 0/1: both sinks receive gzip members; bit 2: served from two host threads
+        if not deliver:
+            sink.sink = P.RecordSink(None, P.REC_TEXT_CB(), P.REC_TEXT_CB(), sink._cbs[2])
+        P._check(ctx.lib.pbsim_job_run(ctx.h, cref, C.byref(sink.sink)))
+        return sink
 
-            def count(user, text, n):
-                gz_bytes[0] += n
-                return 1
-            cb = P.SINK_CB(count)
-            sink = P.Sink(None, cb, cb)
-
-            def run_record():
-                P._check(ctx.lib.pbsim_simulate_wgs(ctx.h, C.byref(sink)))
-        else:
-            def run_record():
-                ctx.simulate_wgs(collect=False)
-        ctx.set_reference_device(recs[0].data_ptr(), G, 1)
-        ctx.prefetch_reference_device(recs[1].data_ptr(), G)   # warm-up only: allocates the second reference buffers (dropped below)
-        run_record()                             # warm-up: pools allocated
-        torch.cuda.synchronize()
-        gz_bytes[0] = 0
-        t0 = time.perf_counter()
-        tot_b = tot_r = 0
-        for r in range(4):
-            ctx.set_reference_device(recs[r].data_ptr(), G, r + 1)
-            if r + 1 < 4:                        # the next record is uploaded and prepared beside this one's simulation
-                ctx.prefetch_reference_device(recs[r + 1].data_ptr(), G)
-            run_record()
-            st = ctx.stats()
-            tot_b += st.res_len_total
-            tot_r += st.res_num
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        print(json.dumps({"metric": "whole job wall time", "value": dt, "unit": "s", "higher_is_better": False,
-                          "bases": tot_b, "reads": tot_r, "bases_per_sec": tot_b / dt, "n_gpus": 1,
-                          "compressed_bytes": gz_bytes[0] if a.deflate else None,
-                          "config": {"workload": f"wgs errhmm ERRHMM-ONT depth 20, 4 records x {G} bp, seed 1, "
-                                                 "quota loop + serial tail + statistics; " +
-                                                 ("FASTQ + MAF compressed on the GPU (BGZF members) and copied to pinned host memory"
-                                                  if a.deflate else "text emitted into HBM, not copied out")}}))
-        ctx.close()
-        return
-
-    S = max(1, min(a.slots, P.load().pbsim_slot_count()))
-
-    def begin(i):
-        ctx.select_slot(i % S)
-        ctx.batch_walk_begin(1 + (i * world + rank) * B, B)
-
-    def finish(i):
-        ctx.select_slot(i % S)
-        pass0 = ctx.batch_walk_end()
-        before = 0
-        if world > 1:
-            mine = torch.tensor([pass0], dtype=torch.int64, device=cdev)
-            allv = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allv, mine)        # C3: quota prefix across ranks
-            before = int(sum(int(v.item()) for v in allv[:rank]))
-        # weak-scaling bench: every rank walks a full batch per step, so the prefix is folded to
-        # keep each batch below the record's quota (the quota cut itself is covered by the tests)
-        return ctx.batch_finalize(before % max(1, quota // 4))
-
-    def run(first_step, n_steps):
-        """n_steps batches through an S-deep pipeline; returns their BatchInfos."""
-        infos, pending, nxt = [], [], first_step
-        while len(infos) < n_steps:
-            while len(pending) < S and nxt < first_step + n_steps:
-                begin(nxt)
-                pending.append(nxt)
-                nxt += 1
-            infos.append(finish(pending.pop(0)))
-        return infos
-
-    run(0, S)                 # untimed setup: every slot allocates its pools once
-    run(S, a.warmup)          # the W untimed warmup steps
+    deliver = not a.hbm_only
+    for _ in range(max(1, a.warmup)):            # at least one untimed run: every slot allocates its pools
+        run_job(deliver)
     ctx.prof_reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    bases = reads = ref_b = maf_c = text_b = 0
-    for info in run(S + a.warmup, a.steps):
-        bases += info.bases
-        reads += info.n_final
-        ref_b += info.ref_bases
-        maf_c += info.maf_columns
-        text_b += info.read_text_bytes + info.maf_text_bytes
+    sinks, counters = [], []
+    for _ in range(a.steps):
+        sinks.append(run_job(deliver))
+        counters.append(ctx.job_counters())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    walk_ms, launches, total_ms = ctx.prof_get()
+    walk_ms, launches, _ = ctx.prof_get()
+    walk_busy_ms = ctx.prof_walk_busy()
 
-    tot = torch.tensor([bases, reads, ref_b, maf_c, text_b], dtype=torch.int64, device=cdev)
+    # the statistics of a record are identical on every rank (merged); bytes delivered and reads walked are per rank
+    job_bases = sum(v[1] for v in sinks[0].stats.values())
+    job_reads = sum(v[0] for v in sinks[0].stats.values())
+    gz_total = sum(v[2] + v[3] for v in sinks[0].stats.values())
+    mine = torch.tensor([sum(c["reads_walked"] for c in counters), sum(c["reads_delivered"] for c in counters),
+                         sum(s.read_bytes + s.maf_bytes for s in sinks), sum(c["comm_us"] for c in counters)],
+                        dtype=torch.int64, device=cdev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
-        dist.all_reduce(tot)                   # C2: counters reduced across ranks
+        dist.all_reduce(mine)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    g_bases, g_reads, g_ref, g_maf, g_text = (int(x) for x in tot.tolist())
+    walked, delivered, host_bytes, comm_us = (int(x) for x in mine.tolist())
     dt_max = float(tmax.item())
 
+    extras = {}
+    if not a.no_extras:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_job(False)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        extras["whole_job_hbm"] = {"value": job_bases / (time.perf_counter() - t1), "unit": "bases/s",
+                                   "note": "the same job, FASTQ + MAF text left in HBM (no compression, no copy)"}
+
     if rank == 0:
-        # algorithmic bytes (SURVEY 8d): ref_bases*1 + read_bases*2 + maf_columns*2
-        alg_bytes_launch = (ref_b * 1 + bases * 2 + maf_c * 2) / max(1, launches)
-        walk_s = walk_ms / 1e3 / max(1, launches)
-        achieved = alg_bytes_launch / walk_s / 1e9 if walk_s > 0 else 0.0
+        K = a.steps
+        c0 = counters[0]
+        # algorithmic bytes: ref_bases*1 + read_bases*2 + maf_columns*2, of this rank's delivered reads
+        alg_bytes = sum(c["ref_bases"] + 2 * c["bases"] + 2 * c["maf_columns"] for c in counters)
+        own_bytes = sum(c["ref_bases"] + 2 * c["maf_columns"] for c in counters)   # what the walk kernel itself moves
+        walk_s = walk_ms / 1e3
+        achieved = alg_bytes / walk_s / 1e9 if walk_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01x_walk_traffic.json")
         if not qs and os.path.exists(tpath):     # PMC pass of the same kernel (tools/pmc_traffic.sh), scaled per base
             tj = json.load(open(tpath))
-            traffic = tj["traffic_bytes_per_launch"] / tj["bases_per_launch"] * (bases / max(1, launches))
+            traffic = tj["traffic_bytes_per_launch"] / tj["bases_per_launch"] * (sum(c["bases"] for c in counters) / max(1, launches))
         out = {
-            "metric": "simulated bases/sec", "value": g_bases / dt_max, "unit": "bases/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt_max * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "reads_per_sec": g_reads / dt_max,
-            "config": {"workload": ("wgs qshmm QSHMM-RSII pass-num 10" if qs else "wgs errhmm ERRHMM-ONT") +
-                                   " depth 20, default length/accuracy, uniform ACGT record "
-                                   f"of {G} bp resident in HBM (one of the 4 records of the 3 Gbp genome)",
-                       "param_overrides": a.param, "reads_per_step_per_gpu": B, "bases_per_step": g_bases // a.steps,
-                       "text_bytes_per_step": g_text // a.steps, "parallelism": f"read-block x{world}", "slots_in_flight": S},
+            "metric": "simulated bases/sec", "value": job_bases * K / dt_max, "unit": "bases/s",
+            "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": dt_max * 1e3 / K,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "reads_per_sec": job_reads * K / dt_max,
+            "value_definition": ("bases of the whole job / wall time of one run of it, incl. GPU compression of FASTQ + MAF and their "
+                                 "copy into pinned host memory (SURVEY 8d: K1+K2+K3 incl. batch D2H)" if deliver else
+                                 "bases of the whole job / wall time, text left in HBM (--hbm-only experiment)"),
+            "config": {"workload": f"{desc}, default length/accuracy, seed 1; the WHOLE job: {NR} records x {G} bp uniform ACGT "
+                                   "resident in HBM, quota loop + truncated tail reads + statistics per record; " +
+                                   ("FASTQ + MAF compressed on the GPU (BGZF members) and delivered into pinned host memory"
+                                    if deliver else "text left in HBM"),
+                       "param_overrides": a.param, "bases_per_step": job_bases, "reads_per_step": job_reads,
+                       "rounds_per_step": c0["rounds"], "parallelism": f"read blocks of every round x{world} ranks",
+                       "speculation_waste": (walked - delivered) / max(1, walked),
+                       "comm_wait_frac": comm_us / 1e6 / max(1e-9, dt_max * world)},
+            "delivery": {"host_bytes_per_step": host_bytes // K, "compressed_bytes_per_job": gz_total,
+                         "pcie_frac": host_bytes / dt_max / world / (PCIE_PEAK_GBS * 1e9),
+                         "note": "bytes over each GPU's PCIe link / time / 63 GB/s (Gen5 x16): the link is this metric's roofline"},
             "roofline": {"bound": "hbm", "kernel": "k_walk_qshmm" if qs else "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01x_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE, raw x1024; see note there)",
-                         "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": walk_s * 1e3,
-                         "walk_share_of_step": (walk_ms / 1e3) / dt if dt > 0 else None,
+                         "alg_bytes_per_launch": alg_bytes / max(1, launches), "avg_launch_ms": walk_ms / max(1, launches),
+                         "launches": launches,
+                         "note": "achieved = algorithmic bytes of the path (SURVEY 8d: 1 ref + 2 read + 2 quality... per base) of rank 0's "
+                                 "delivered reads / summed duration of its walk launches (HIP events on the walk streams, every launch of "
+                                 "the timed region incl. tail reads); walks of different slots overlap, so walk_busy counts that time once",
+                         "walk_busy_ms": walk_busy_ms,
+                         "achieved_busy": alg_bytes / (walk_busy_ms / 1e3) / 1e9 if walk_busy_ms > 0 else None,
+                         "walk_own": {"bytes_per_base": own_bytes / max(1, sum(c["bases"] for c in counters)),
+                                      "achieved": own_bytes / walk_s / 1e9 if walk_s > 0 else None,
+                                      "note": "what the walk kernel itself moves: 1 B per reference base gathered + 2 MAF rows; the read and "
+                                              "quality bytes are written by the text kernels.  PMC (profiles/r01x_walk_pmc.json): the "
+                                              "reference gather fetches 3.0x its bytes (one 64-B sector per 8-byte window refill)"},
+                         "walk_share_of_step": walk_busy_ms / 1e3 / dt if dt > 0 else None,
                          # the kernel's real ceiling is integer issue, not HBM: PMC pass of the same kernel
-                         "issue_bound": None if qs else issue_bound(maf_c / max(1, launches), walk_s)},
+                         "issue_bound": None if qs else issue_bound(sum(c["maf_columns"] for c in counters) / max(1, launches),
+                                                                    walk_s / max(1, launches))},
         }
+        out.update(extras)
+    ctx.close()
+    if rank == 0 and world == 1 and not a.no_extras and not qs:
+        try:
+            out["steady_state_hbm"] = steady_state(a, torch, harness, P, local, model, recs[0].data_ptr(), G)
+        except Exception as e:
+            out["steady_state_hbm"] = {"error": str(e)}
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(model if not qs else "ERRHMM-ONT.model", int(min(depth, 20)))
             except Exception as e:  # the baseline is reported, never required
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out))
-    ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -295,7 +295,8 @@ int pbsim_job_run(pbsim_ctx *ctx, const pbsim_comm *comm, const pbsim_record_sin
 int64_t pbsim_job_sam_header(pbsim_ctx *ctx, int64_t record, char *buf, int64_t cap);
 int64_t pbsim_job_bam_header(pbsim_ctx *ctx, int64_t record, char *buf, int64_t cap);
 /* what the last pbsim_job_run did, for bench.py: [0] reads walked (speculation included), [1] reads delivered,
- * [2] rounds, [3] bases delivered (all passes), [4] wall microseconds, [5] microseconds this rank waited in collectives */
+ * [2] rounds, [3] bases delivered (all passes), [4] wall microseconds, [5] microseconds this rank waited in collectives,
+ * [6] reference bases consumed and [7] MAF columns written by the delivered reads (roofline accounting) */
 int pbsim_job_counters(pbsim_ctx *ctx, int64_t out[8]);
 
 /* Statistics primitives for callers that shard a unit set over several contexts themselves (trans / templ:
@@ -325,6 +326,8 @@ int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int device);
  * measured on the engine's own stream, and the number of launches. */
 int pbsim_prof_reset(pbsim_ctx *ctx);
 int pbsim_prof_get(pbsim_ctx *ctx, double *walk_ms, int64_t *walk_launches, double *total_ms);
+/* milliseconds since the reset during which at least one walk kernel ran (the launches of different slots overlap) */
+int pbsim_prof_walk_busy(pbsim_ctx *ctx, double *busy_ms);
 /* raw HIP stream handle (hipStream_t) of the engine, for external event timing */
 void *pbsim_stream(pbsim_ctx *ctx);
 

@@ -141,6 +141,7 @@ API = [
     ("pbsim_set_scratch_bytes", C.c_int, [C.c_void_p, C.c_int64]),
     ("pbsim_prof_reset", C.c_int, [C.c_void_p]),
     ("pbsim_prof_get", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    ("pbsim_prof_walk_busy", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_stream", C.c_void_p, [C.c_void_p]),
     ("pbsim_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("pbsim_dump_table", C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
@@ -554,7 +555,8 @@ class Context:
     def job_counters(self):
         a = (C.c_int64 * 8)()
         _check(self.lib.pbsim_job_counters(self.h, a))
-        return dict(reads_walked=a[0], reads_delivered=a[1], rounds=a[2], bases=a[3], wall_us=a[4], comm_us=a[5])
+        return dict(reads_walked=a[0], reads_delivered=a[1], rounds=a[2], bases=a[3], wall_us=a[4], comm_us=a[5],
+                    ref_bases=a[6], maf_columns=a[7])
 
     def job_sam_header(self, record):
         n = self.lib.pbsim_job_sam_header(self.h, record, None, 0)
@@ -603,6 +605,11 @@ class Context:
         a, b, c = C.c_double(0), C.c_int64(0), C.c_double(0)
         _check(self.lib.pbsim_prof_get(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def prof_walk_busy(self):
+        a = C.c_double(0)
+        _check(self.lib.pbsim_prof_walk_busy(self.h, C.byref(a)))
+        return a.value
 
     def dump_table(self, which):
         n = self.lib.pbsim_dump_table(self.h, which, None, 0)

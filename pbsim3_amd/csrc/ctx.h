@@ -255,6 +255,8 @@ struct pbsim_ctx {
   // profiling
   double prof_walk_ms = 0, prof_total_ms = 0;
   int64_t prof_walk_launches = 0;
+  hipEvent_t ev_prof_base = nullptr;                     // pbsim_prof_reset: time zero of the walk intervals
+  std::vector<std::pair<float, float>> prof_intervals;   // [start, end] ms of every walk launch since the reset
 };
 
 // ---- internals shared by engine.cpp and job.cpp ---------------------------------------------------------------------

@@ -290,6 +290,7 @@ void pbsim_destroy(pbsim_ctx *c) {
     if (sl.walk_stream) (void)hipStreamDestroy(sl.walk_stream);
     if (sl.ev_prep) (void)hipEventDestroy(sl.ev_prep);
   }
+  if (c->ev_prof_base) (void)hipEventDestroy(c->ev_prof_base);
   if (c->prefetch_stream) (void)hipStreamDestroy(c->prefetch_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -667,6 +668,12 @@ int pbsim_batch_walk_end(pbsim_ctx *c, int64_t *pass0_bases) {
   if (!read_flags(c, &f)) return PBSIM_FAILED;
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->s().ev1, c->s().ev2) == hipSuccess) c->prof_walk_ms += ms;
+  if (c->ev_prof_base) {
+    float a = 0, b = 0;
+    if (hipEventElapsedTime(&a, c->ev_prof_base, c->s().ev1) == hipSuccess &&
+        hipEventElapsedTime(&b, c->ev_prof_base, c->s().ev2) == hipSuccess)
+      c->prof_intervals.emplace_back(a, b);
+  }
   if (hipEventElapsedTime(&ms, c->s().ev0, c->s().ev3) == hipSuccess) c->prof_total_ms += ms;
   c->prof_walk_launches++;
   if (f.error & kErrScratchBudget) {
@@ -1799,6 +1806,32 @@ int pbsim_prof_reset(pbsim_ctx *c) {
   if (!c) return fail("bad argument");
   c->prof_walk_ms = c->prof_total_ms = 0;
   c->prof_walk_launches = 0;
+  c->prof_intervals.clear();
+  if (c->device >= 0 && c->stream) {
+    HIP_OK(hipSetDevice(c->device));
+    if (!c->ev_prof_base) HIP_OK(hipEventCreate(&c->ev_prof_base));
+    HIP_OK(hipEventRecord(c->ev_prof_base, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+  }
+  return PBSIM_SUCCEEDED;
+}
+// time during which at least one walk kernel was running (union of the launches' intervals): walks of different slots
+// overlap by design, so the sum of their durations counts that time more than once
+int pbsim_prof_walk_busy(pbsim_ctx *c, double *busy_ms) {
+  if (!c || !busy_ms) return fail("bad argument");
+  std::vector<std::pair<float, float>> v = c->prof_intervals;
+  std::sort(v.begin(), v.end());
+  double busy = 0, end = -1e30;
+  for (const auto &iv : v) {
+    if (iv.first > end) {
+      busy += iv.second - iv.first;
+      end = iv.second;
+    } else if (iv.second > end) {
+      busy += iv.second - end;
+      end = iv.second;
+    }
+  }
+  *busy_ms = busy;
   return PBSIM_SUCCEEDED;
 }
 int pbsim_prof_get(pbsim_ctx *c, double *walk_ms, int64_t *walk_launches, double *total_ms) {

@@ -71,7 +71,7 @@ struct Job {
   std::deque<Round> fifo;
   double mean = 0;
   int depth = 3;
-  int64_t reads_walked = 0, reads_delivered = 0, rounds = 0, bases = 0;
+  int64_t reads_walked = 0, reads_delivered = 0, rounds = 0, bases = 0, ref_bases = 0, maf_columns = 0;
   double comm_us = 0;
   bool trace = false;
   double t_start = 0;
@@ -259,6 +259,8 @@ struct Job {
       reads_walked += 1;
       reads_delivered += bi.n_final;
       bases += bi.bases;
+      ref_bases += bi.ref_bases;
+      maf_columns += bi.maf_columns;
       if (trace)
         fprintf(stderr, "[pbsim job r%d] t=%.1f ms rec %d tail read %lld: %.1f ms\n", rank, (t0 - t_start) / 1e3, rec + 1,
                 (long long)R.next_read, (now_us() - t0) / 1e3);
@@ -405,6 +407,8 @@ struct Job {
       if (!account_slot(c, &R.st)) return PBSIM_FAILED;
       reads_delivered += bi.n_final;
       bases += bi.bases;
+      ref_bases += bi.ref_bases;
+      maf_columns += bi.maf_columns;
     }
     R.read_off += read_all;
     R.maf_off += maf_all;
@@ -611,7 +615,7 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   J.trace = getenv("PBSIM_TRACE") != nullptr;
   J.t_start = now_us();
   const char *jd = getenv("PBSIM_JOB_DEPTH");
-  J.depth = std::max(1, std::min(kMaxSlots - 1, jd ? atoi(jd) : 3));
+  J.depth = std::max(1, std::min(kMaxSlots - 2, jd ? atoi(jd) : 3));
   const int W = J.W;
   // ---- the records' preparation (upload + k_hp_*) has been running since pbsim_job_add_record: collect it
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));
@@ -654,7 +658,9 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   // ---- batch size: a few rounds per record and rank, not below what keeps a walk longer than its longest read
   const int P = c->p.pass_num;
   const int regions = has_quality(c) ? 3 : 2;
-  double target = (double)max_quota * P / ((double)kRoundsPerRecord * W);
+  const char *jr = getenv("PBSIM_JOB_ROUNDS");  // experiment knob: rounds per record the batches are sized for
+  const int rounds_per_record = std::max(1, jr ? atoi(jr) : kRoundsPerRecord);
+  double target = (double)max_quota * P / ((double)rounds_per_record * W);
   target = std::max(target, std::min(kMinBatchBases, (double)max_quota * P / W));
   if (J.sink && (J.sink->on_read_text || J.sink->on_maf_text)) target = std::min(target, kSinkBatchBases);
   if (c->scratch_auto) {
@@ -662,7 +668,10 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     HIP_OK(hipMemGetInfo(&free_b, &total_b));
     size_t held = 0;
     for (Slot &sl : c->slots) held += sl.d_scratch.bytes;
-    const double want = target * 1.07 * regions * 1.3 + (64 << 20);
+    // what batch_capacity_for() charges a read: `regions` rows of 2 * length + pad columns, 12 % slack for the per-wave rounding
+    const double mean_len = std::max(1.0, c->hdr.mean_len);
+    // (a read yields ~0.97 of its length in bases, and a round overshoots its share of the quota by 0.5 %: 8 % headroom)
+    const double want = (target / P / mean_len) * P * ((double)regions * (2.0 * mean_len + kScratchPad) * 1.12 + 64.0) * 1.08 + (64 << 20);
     const double share = std::min(48.0 * (1LL << 30), 0.10 * (double)(free_b + held));
     const int64_t auto_b = (int64_t)std::max(256.0 * (1 << 20), std::min(want, share));
     if (auto_b > c->scratch_budget || c->scratch_budget > 2 * auto_b) c->scratch_budget = auto_b;
@@ -676,7 +685,7 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   for (size_t i = 0; i < n; i++) {
     Rec &R = J.recs[i];
     const double m = std::min<double>(c->hdr.mean_len, (double)R.ref.len);
-    R.cap = std::max<int64_t>(1, std::min<int64_t>(batch_capacity_for(c, R.ref.len), (int64_t)(target / P / m) + 1));
+    R.cap = std::max<int64_t>(1, std::min<int64_t>(batch_capacity_for(c, R.ref.len), (int64_t)(1.08 * target / P / m) + 64));
   }
   J.mean = std::min<double>(J.mean, (double)c->job_records[0]->len);
   for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
@@ -692,6 +701,8 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   c->job_counters[3] = J.bases;
   c->job_counters[4] = (int64_t)(now_us() - J.t_start);
   c->job_counters[5] = (int64_t)J.comm_us;
+  c->job_counters[6] = J.ref_bases;
+  c->job_counters[7] = J.maf_columns;
   return ok;
 }
 

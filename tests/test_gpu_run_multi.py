@@ -31,7 +31,8 @@ def test_run_multi_two_ranks(case, batch, tmp_path):
     for k in keys:
         assert harness.sha(outs[k]) == want[k]["sha256"], k
     assert not [k for k in outs if ".rank" in k]
-    report = harness.strip_report("\n".join(l for l in p.stderr.splitlines() if not l.startswith(("W1", "W0", "[", "*")) and "amdgpu.ids" not in l))
+    err = p.stderr[p.stderr.index(":::: Simulation parameters"):]      # torchrun's own banner lines come first
+    report = harness.strip_report("\n".join(l for l in err.splitlines() if "amdgpu.ids" not in l and not l.startswith(("W0", "W1", "[W", "[E"))))
     assert harness.sha(report.encode()) == want[".stderr"]["sha256"], report
 
 
