@@ -271,6 +271,7 @@ int finalize_text(pbsim_ctx *c, pbsim_batch_info *info);
 std::string sam_header_text(const pbsim_ctx *c, int64_t unit);
 // pbsim.cpp:3986-4005 / 2293-2316 for the n_final reads of the selected slot's finalized batch, into `st`
 int account_slot(pbsim_ctx *c, StatsAcc *st);
+int account_of(pbsim_ctx *c, Slot &sl, StatsAcc *st);  // the same on an explicit slot (no use of the selected-slot cursor)
 // one finished task (pbsim.cpp:3986-4005): lengths, error counts, the accuracy value and its histogram bin
 void stats_add_task(StatsAcc *st, int64_t len_max, bool quality, long len, long nsub, long nins, long ndel, double qsum,
                     std::vector<double> *values);

@@ -832,34 +832,39 @@ int pbsim_batch_fetch(pbsim_ctx *c, char *read_text, char *maf_text) {
 
 // pbsim.cpp:3986-4005 (errhmm) / 2293-2316 (qshmm), applied in read order so the
 // order-dependent double sum `accuracy_total` matches the CPU bit for bit
-extern "C++" int pbsim::account_slot(pbsim_ctx *c, StatsAcc *st) {
-  if (!c || !c->s().b_finalized) return fail("pbsim_batch_account: no finalized batch");
+extern "C++" int pbsim::account_of(pbsim_ctx *c, Slot &sl, StatsAcc *st) {
+  if (!c || !sl.b_finalized) return fail("pbsim_batch_account: no finalized batch");
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
   const int P = c->p.pass_num;
-  const int64_t n_tasks = c->s().b_info.n_final * P;
+  const int64_t n_tasks = sl.b_info.n_final * P;
   if (n_tasks == 0) return PBSIM_SUCCEEDED;
-  HIP_OK(c->s().h_stats.ensure((size_t)n_tasks * 24));
-  int32_t *ol = reinterpret_cast<int32_t *>(c->s().h_stats.p);
+  HIP_OK(sl.h_stats.ensure((size_t)n_tasks * 24));
+  int32_t *ol = reinterpret_cast<int32_t *>(sl.h_stats.p);
   int32_t *ns = ol + n_tasks, *ni = ns + n_tasks, *nd = ni + n_tasks;
   double *qs = reinterpret_cast<double *>(nd + n_tasks);
-  HIP_OK(hipMemcpyAsync(ol, c->s().d_out_len.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
-  HIP_OK(hipMemcpyAsync(ns, c->s().d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
-  HIP_OK(hipMemcpyAsync(ni, c->s().d_nins.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
-  HIP_OK(hipMemcpyAsync(nd, c->s().d_ndel.p, n_tasks * 4, hipMemcpyDeviceToHost, c->s().stream));
+  HIP_OK(hipMemcpyAsync(ol, sl.d_out_len.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
+  HIP_OK(hipMemcpyAsync(ns, sl.d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
+  HIP_OK(hipMemcpyAsync(ni, sl.d_nins.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
+  HIP_OK(hipMemcpyAsync(nd, sl.d_ndel.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
   const bool quality = has_quality_row(c);
-  if (quality) HIP_OK(hipMemcpyAsync(qs, c->s().d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, c->s().stream));
-  HIP_OK(hipStreamSynchronize(c->s().stream));
-  st->res_num += c->s().b_info.n_final;
+  if (quality) HIP_OK(hipMemcpyAsync(qs, sl.d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, sl.stream));
+  HIP_OK(hipStreamSynchronize(sl.stream));
+  st->res_num += sl.b_info.n_final;
   std::vector<double> *values = nullptr;
   if (st->keep_values) {
     st->blocks.emplace_back();
-    st->blocks.back().first_task = (c->s().b_first - 1) * P;
+    st->blocks.back().first_task = (sl.b_first - 1) * P;
     values = &st->blocks.back().values;
     values->reserve((size_t)n_tasks);
   }
   for (int64_t t = 0; t < n_tasks; t++) stats_add_task(st, c->p.len_max, quality, ol[t], ns[t], ni[t], nd[t], quality ? qs[t] : 0.0, values);
   return PBSIM_SUCCEEDED;
+}
+
+extern "C++" int pbsim::account_slot(pbsim_ctx *c, StatsAcc *st) {
+  if (!c) return fail("pbsim_batch_account: bad argument");
+  return account_of(c, c->s(), st);
 }
 
 int pbsim_batch_account(pbsim_ctx *c) { return c ? account_slot(c, &c->st) : fail("pbsim_batch_account: bad argument"); }
@@ -1178,6 +1183,7 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
     int64_t first, n;
   };
   std::vector<Pending> fifo;
+  int tail_slot = -1;             // slot on which the first truncated read was started ahead of time (-1: none)
   auto drop_pending = [&]() {  // speculative batches beyond a cut or after an error
     for (const Pending &pd : fifo) {
       c->cur = pd.slot;
@@ -1185,6 +1191,12 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
       c->s().b_enqueued = false;
     }
     fifo.clear();
+    if (tail_slot >= 0) {  // a truncated read begun ahead of time must not outlive a failed run either
+      c->cur = tail_slot;
+      (void)hipStreamSynchronize(c->s().stream);
+      c->s().b_enqueued = false;
+      tail_slot = -1;
+    }
     c->cur = 0;
   };
   const bool trace = getenv("PBSIM_TRACE") != nullptr;  // per-batch host timings on stderr
@@ -1194,7 +1206,6 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
   int64_t spec_read = 1;          // first read not yet enqueued
   double spec_total = 0;          // expected pass-0 bases once everything enqueued has finished
   bool serial = false;
-  int tail_slot = -1;             // slot on which the first truncated read was started ahead of time (-1: none)
   while (len_total < quota) {
     if (serial) {
       pbsim_batch_info bi;

@@ -23,8 +23,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <future>
+#include <mutex>
 #include <thread>
 
 #include "ctx.h"
@@ -50,6 +54,7 @@ struct Rec {
   bool done = false;         // bulk_done and no tail pending on this rank
   int owner = -1;            // rank that runs the tail (-1: none)
   int tail_slot = -1;        // owner: slot of the truncated read in flight
+  bool tail_waiting = false; // owner: a truncated read is due but no slot was free
   int64_t read_off = 0, maf_off = 0;            // bytes of the bulk rounds, all ranks (identical everywhere)
   int64_t tail_read = 0, tail_maf = 0;          // owner: bytes of its tail reads
   StatsAcc st;
@@ -60,6 +65,78 @@ struct Round {
   int rec, slot;
   int64_t first, n_per;
   double mean;               // bases per read assumed when it was begun
+};
+
+// One host thread that takes finished batches off the main loop's hands: GPU compression + copy into pinned memory, the sink
+// callbacks (file writes in the CLI) and the per-task statistics.  Strictly FIFO, so the pieces of a record reach a
+// sequential sink in order and accuracy_total is accumulated in read order.
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv, cv_idle;
+  std::deque<std::function<void()>> q;
+  bool stop = false, running = false;
+  int active = 0;
+  void start(int device) {
+    running = true;
+    th = std::thread([this, device]() {
+      (void)hipSetDevice(device);
+      for (;;) {
+        std::function<void()> f;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return stop || !q.empty(); });
+          if (q.empty()) return;
+          f = std::move(q.front());
+          q.pop_front();
+          active++;
+        }
+        f();
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          active--;
+        }
+        cv_idle.notify_all();
+      }
+    });
+  }
+  void post(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      q.push_back(std::move(f));
+    }
+    cv.notify_one();
+  }
+  void drain() {
+    if (!running) return;
+    std::unique_lock<std::mutex> lk(mu);
+    cv_idle.wait(lk, [&] { return q.empty() && active == 0; });
+  }
+  void finish() {
+    if (!running) return;
+    drain();
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    th.join();
+    running = false;
+  }
+  ~Worker() { finish(); }
+};
+
+// a bulk round between "text emitted" and "delivered": stage 1 (worker) brings the bytes to host memory and learns their
+// sizes, the main loop exchanges the sizes (collective), stage 2 (worker) hands them to the sink and accounts the tasks
+struct Delivery {
+  int slot = -1, rec = -1;
+  bool mine = false;
+  int64_t n_per = 0;
+  std::shared_ptr<std::promise<int>> stage1;
+  std::future<int> stage1_done;
+  int64_t sizes[2] = {0, 0};
+  std::vector<int64_t> B;   // gather B of the round
+  int cut = -1;
 };
 
 struct Job {
@@ -75,6 +152,27 @@ struct Job {
   double comm_us = 0;
   bool trace = false;
   double t_start = 0;
+  Worker worker;
+  std::atomic<bool> delivering[kMaxSlots];
+  std::atomic<bool> wfailed{false};
+  std::mutex werr_mu;
+  std::string werr;
+  std::unique_ptr<Delivery> pending;  // the one round whose sizes have not been exchanged yet
+
+  Job() {
+    for (auto &d : delivering) d = false;
+  }
+
+  void worker_fail() {  // on the worker thread: keep the (thread local) message for the main loop
+    std::lock_guard<std::mutex> lk(werr_mu);
+    if (!wfailed) werr = g_err;
+    wfailed = true;
+  }
+  int check_worker() {
+    if (!wfailed) return PBSIM_SUCCEEDED;
+    std::lock_guard<std::mutex> lk(werr_mu);
+    return fail(werr);
+  }
 
   int gather(const int64_t *send, int64_t n, std::vector<int64_t> *recv) {
     recv->assign((size_t)W * n, 0);
@@ -89,6 +187,7 @@ struct Job {
   }
 
   bool slot_busy(int s) const {
+    if (delivering[s]) return true;
     for (const Round &r : fifo)
       if (r.slot == s) return true;
     for (const Rec &r : recs)
@@ -101,6 +200,23 @@ struct Job {
     return -1;
   }
   int bulk_in_flight() const { return (int)fifo.size(); }
+  // A slot for a bulk round.  WHETHER a round is begun must not depend on how far this rank's worker has got (the ranks would
+  // fall out of step), so the main loop decides from the gathered state alone and then waits here for a slot.  One always
+  // comes free: at most `depth` rounds, one pending delivery and one tail read hold slots that only the main loop can
+  // release; every other slot is with the worker, which needs nobody.
+  int acquire_slot() {
+    for (;;) {
+      const int s = free_slot();
+      if (s >= 0) return s;
+      std::unique_lock<std::mutex> lk(worker.mu);
+      worker.cv_idle.wait_for(lk, std::chrono::milliseconds(2));
+    }
+  }
+  bool a_tail_is_running() const {
+    for (const Rec &r : recs)
+      if (r.tail_slot >= 0) return true;
+    return false;
+  }
 
   void drop_round(const Round &r) {
     c->cur = r.slot;
@@ -118,6 +234,7 @@ struct Job {
     }
   }
   void drop_everything() {
+    worker.drain();
     for (const Round &r : fifo) drop_round(r);
     fifo.clear();
     for (Rec &r : recs)
@@ -129,31 +246,59 @@ struct Job {
       }
   }
 
-  // ---- delivery of the selected slot's finalized batch ---------------------------------------------------------------
-  // text mode: sizes are known from the batch info; deflate mode on several ranks: the batch is compressed into the
-  // lanes' pinned arenas first (sizes unknown before), the sizes are exchanged, then the pieces go out at their offsets.
-  int send_plain(int rec, int64_t read_at, int64_t maf_at) {
-    const pbsim_batch_info &bi = c->s().b_info;
-    if (!sink) return PBSIM_SUCCEEDED;
+  bool wants_text() const { return sink && (sink->on_read_text || sink->on_maf_text); }
+  bool deflated() const { return wants_text() && c->deflate == 3; }
+
+  // ---- delivery primitives on an explicit slot (they run on the worker thread; nothing here touches c->cur) ---------------
+  int fetch_plain(Slot &sl) {
+    const pbsim_batch_info &bi = sl.b_info;
     const bool want_r = sink->on_read_text && bi.read_text_bytes, want_m = sink->on_maf_text && bi.maf_text_bytes;
-    if (want_r) HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
-    if (want_m) HIP_OK(c->s().h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
-    if ((want_r || want_m) &&
-        !pbsim_batch_fetch(c, want_r ? (char *)c->s().h_read_text.p : nullptr, want_m ? (char *)c->s().h_maf_text.p : nullptr))
-      return PBSIM_FAILED;
-    if (want_r && !sink->on_read_text(sink->user, recs[(size_t)rec].ref.unit, (const char *)c->s().h_read_text.p, bi.read_text_bytes, read_at))
+    if (want_r) {
+      HIP_OK(sl.h_read_text.ensure((size_t)bi.read_text_bytes + 16));
+      HIP_OK(hipMemcpyAsync(sl.h_read_text.p, sl.d_read_text.p, (size_t)bi.read_text_bytes, hipMemcpyDeviceToHost, sl.stream));
+    }
+    if (want_m) {
+      HIP_OK(sl.h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
+      HIP_OK(hipMemcpyAsync(sl.h_maf_text.p, sl.d_maf_text.p, (size_t)bi.maf_text_bytes, hipMemcpyDeviceToHost, sl.stream));
+    }
+    HIP_OK(hipStreamSynchronize(sl.stream));
+    return PBSIM_SUCCEEDED;
+  }
+  int sink_plain(Slot &sl, int64_t unit, int64_t read_at, int64_t maf_at) {
+    const pbsim_batch_info &bi = sl.b_info;
+    if (sink->on_read_text && bi.read_text_bytes &&
+        !sink->on_read_text(sink->user, unit, (const char *)sl.h_read_text.p, bi.read_text_bytes, read_at))
       return fail("sink aborted (read text)");
-    if (want_m && !sink->on_maf_text(sink->user, recs[(size_t)rec].ref.unit, (const char *)c->s().h_maf_text.p, bi.maf_text_bytes, maf_at))
+    if (sink->on_maf_text && bi.maf_text_bytes &&
+        !sink->on_maf_text(sink->user, unit, (const char *)sl.h_maf_text.p, bi.maf_text_bytes, maf_at))
       return fail("sink aborted (MAF text)");
     return PBSIM_SUCCEEDED;
   }
-
-  // compressed, streamed piece by piece at running offsets (one rank, or the tail owner): returns the bytes sent
-  int send_deflated_stream(int rec, int64_t read_at, int64_t maf_at, int64_t *read_gz, int64_t *maf_gz) {
-    const pbsim_batch_info &bi = c->s().b_info;
-    Slot &sl = c->s();
+  // the two text streams of a slot through `lane(which)`, side by side on two threads when the sinks are independent
+  // (pbsim_set_deflate bit 2: two files are written by two threads; a file's writers would serialise on its inode)
+  template <class F>
+  int both_lanes(Slot &sl, F &&lane) {
+    const pbsim_batch_info &bi = sl.b_info;
+    if (c->deflate_parallel && bi.read_text_bytes && bi.maf_text_bytes && sink->on_read_text && sink->on_maf_text) {
+      int ok_read = PBSIM_SUCCEEDED;
+      std::string err_read;
+      std::thread t([&]() {
+        (void)hipSetDevice(c->device);
+        ok_read = lane(0);
+        if (!ok_read) err_read = g_err;  // the error string is thread local: carry the second thread's over
+      });
+      const int ok_maf = lane(1);
+      t.join();
+      if (!ok_read) return fail(err_read);
+      return ok_maf;
+    }
+    return lane(0) && lane(1);
+  }
+  // compressed and streamed piece by piece at running offsets (sizes out): one rank, or a tail read
+  int stream_deflated(Slot &sl, int64_t unit, int64_t read_at, int64_t maf_at, int64_t *read_gz, int64_t *maf_gz) {
+    const pbsim_batch_info &bi = sl.b_info;
     *read_gz = *maf_gz = 0;
-    auto lane = [&](int which, std::string *err) -> int {
+    return both_lanes(sl, [&](int which) -> int {
       const bool is_read = which == 0;
       const int64_t n = is_read ? bi.read_text_bytes : bi.maf_text_bytes;
       auto cb = is_read ? sink->on_read_text : sink->on_maf_text;
@@ -161,41 +306,24 @@ struct Job {
       const int64_t base = is_read ? read_at : maf_at;
       const uint8_t *d = is_read ? sl.d_read_text.as<uint8_t>() : sl.d_maf_text.as<uint8_t>();
       if (!cb || n == 0) return PBSIM_SUCCEEDED;
-      const int ok = deflate_pieces(c, sl.df[which], d, n, [&](const char *z, int64_t k) {
-        if (!cb(sink->user, recs[(size_t)rec].ref.unit, z, k, base + *sent)) return fail(is_read ? "sink aborted (read text)" : "sink aborted (MAF text)");
+      return deflate_pieces(c, sl.df[which], d, n, [&](const char *z, int64_t k) {
+        if (!cb(sink->user, unit, z, k, base + *sent)) return fail(is_read ? "sink aborted (read text)" : "sink aborted (MAF text)");
         *sent += k;
         return PBSIM_SUCCEEDED;
       });
-      if (!ok && err) *err = g_err;
-      return ok;
-    };
-    if (c->deflate_parallel && bi.read_text_bytes && bi.maf_text_bytes && sink->on_read_text && sink->on_maf_text) {
-      if (!ensure_deflate_ready(c)) return PBSIM_FAILED;
-      int ok_read = PBSIM_SUCCEEDED;
-      std::string err_read;
-      std::thread t([&]() {
-        (void)hipSetDevice(c->device);
-        ok_read = lane(0, &err_read);
-      });
-      const int ok_maf = lane(1, nullptr);
-      t.join();
-      if (!ok_read) return fail(err_read);  // the error string is thread local: carry the second thread's over
-      return ok_maf;
-    }
-    return lane(0, nullptr) && lane(1, nullptr);
+    });
   }
-
-  // compress the batch into the lanes' arenas (sizes out), to be flushed by arena_flush once the offsets are known
-  int arena_fill(int64_t *read_gz, int64_t *maf_gz) {
-    const pbsim_batch_info &bi = c->s().b_info;
-    Slot &sl = c->s();
+  // several ranks: a rank learns where its bytes go only after every rank has compressed its block, so the whole batch is
+  // compressed into the lanes' pinned arenas first (sizes out) and flushed once the offsets are known
+  int arena_fill(Slot &sl, int64_t *read_gz, int64_t *maf_gz) {
+    const pbsim_batch_info &bi = sl.b_info;
     *read_gz = *maf_gz = 0;
-    for (int which = 0; which < 2; which++) {
+    return both_lanes(sl, [&](int which) -> int {
       DfLane &L = sl.df[which];
       L.arena_reset();
       const int64_t n = which == 0 ? bi.read_text_bytes : bi.maf_text_bytes;
       auto cb = which == 0 ? sink->on_read_text : sink->on_maf_text;
-      if (!cb || n == 0) continue;
+      if (!cb || n == 0) return PBSIM_SUCCEEDED;
       const uint8_t *d = which == 0 ? sl.d_read_text.as<uint8_t>() : sl.d_maf_text.as<uint8_t>();
       bool oom = false;
       const std::function<char *(int64_t)> place = [&](int64_t k) -> char * {
@@ -208,54 +336,155 @@ struct Job {
       int64_t tot = 0;
       for (const auto &sg : L.arena_segs) tot += sg.second;
       (which == 0 ? *read_gz : *maf_gz) = tot;
-    }
-    return PBSIM_SUCCEEDED;
+      return PBSIM_SUCCEEDED;
+    });
   }
-  int arena_flush(int rec, int64_t read_at, int64_t maf_at) {
-    Slot &sl = c->s();
-    for (int which = 0; which < 2; which++) {
+  int arena_flush(Slot &sl, int64_t unit, int64_t read_at, int64_t maf_at) {
+    return both_lanes(sl, [&](int which) -> int {
       auto cb = which == 0 ? sink->on_read_text : sink->on_maf_text;
       int64_t at = which == 0 ? read_at : maf_at;
       for (const auto &sg : sl.df[which].arena_segs) {
-        if (!cb(sink->user, recs[(size_t)rec].ref.unit, sg.first, sg.second, at)) return fail(which == 0 ? "sink aborted (read text)" : "sink aborted (MAF text)");
+        if (!cb(sink->user, unit, sg.first, sg.second, at)) return fail(which == 0 ? "sink aborted (read text)" : "sink aborted (MAF text)");
         at += sg.second;
       }
       sl.df[which].arena_segs.clear();
+      return PBSIM_SUCCEEDED;
+    });
+  }
+
+  // ---- a bulk round's delivery: stage 1 now, the rest once the sizes of all ranks are known -------------------------------
+  // mode of the bytes: none (text stays in HBM) | plain text | members streamed (one rank) | members via the arena (ranks)
+  void submit_stage1(Delivery *d) {
+    d->stage1 = std::make_shared<std::promise<int>>();
+    d->stage1_done = d->stage1->get_future();
+    if (!d->mine) {
+      d->stage1->set_value(PBSIM_SUCCEEDED);
+      return;
     }
-    return PBSIM_SUCCEEDED;
+    delivering[d->slot] = true;
+    Slot *sl = &c->slots[d->slot];
+    Rec *R = &recs[(size_t)d->rec];
+    auto prom = d->stage1;
+    int64_t *sizes = d->sizes;
+    const int64_t read_at = R->read_off, maf_at = R->maf_off;  // one rank: the offsets simply run up (streamed in stage 1)
+    worker.post([this, sl, R, prom, sizes, read_at, maf_at]() {
+      int ok = PBSIM_SUCCEEDED;
+      if (!wants_text()) {
+        sizes[0] = sizes[1] = 0;
+      } else if (!deflated()) {
+        ok = fetch_plain(*sl);
+        sizes[0] = sink->on_read_text ? sl->b_info.read_text_bytes : 0;
+        sizes[1] = sink->on_maf_text ? sl->b_info.maf_text_bytes : 0;
+      } else if (W == 1) {
+        ok = stream_deflated(*sl, R->ref.unit, read_at, maf_at, &sizes[0], &sizes[1]);
+      } else {
+        ok = arena_fill(*sl, &sizes[0], &sizes[1]);
+      }
+      if (!ok) worker_fail();
+      prom->set_value(ok);
+    });
+  }
+  // collective: exchange the sizes of the pending round, place every rank's bytes, hand the rest to the worker
+  int complete_pending() {
+    if (!pending) return PBSIM_SUCCEEDED;
+    std::unique_ptr<Delivery> d = std::move(pending);
+    Rec &R = recs[(size_t)d->rec];
+    const double t0 = now_us();
+    const int ok1 = d->stage1_done.get();
+    const double t1 = now_us();
+    int64_t mine2[3] = {d->mine ? d->sizes[0] : 0, d->mine ? d->sizes[1] : 0, ok1 ? 0 : 1};
+    std::vector<int64_t> S;
+    if (!gather(mine2, 3, &S)) return PBSIM_FAILED;
+    int64_t read_at = R.read_off, maf_at = R.maf_off, read_all = 0, maf_all = 0, bad = 0;
+    for (int q = 0; q < W; q++) {
+      if (q < rank) {
+        read_at += S[(size_t)q * 3];
+        maf_at += S[(size_t)q * 3 + 1];
+      }
+      read_all += S[(size_t)q * 3];
+      maf_all += S[(size_t)q * 3 + 1];
+      bad += S[(size_t)q * 3 + 2];
+    }
+    if (bad) return ok1 ? fail("another rank of the job failed") : check_worker();
+    R.read_off += read_all;
+    R.maf_off += maf_all;
+    if (d->mine) {
+      Slot *sl = &c->slots[d->slot];
+      Rec *Rp = &R;
+      const int slot = d->slot;
+      const bool flush = deflated() && W > 1, plain = wants_text() && !deflated();
+      worker.post([this, sl, Rp, slot, flush, plain, read_at, maf_at]() {
+        int ok = PBSIM_SUCCEEDED;
+        if (flush) ok = arena_flush(*sl, Rp->ref.unit, read_at, maf_at);
+        else if (plain) ok = sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
+        if (ok) ok = account_of(c, *sl, &Rp->st);
+        if (!ok) worker_fail();
+        delivering[slot] = false;
+      });
+    }
+    if (trace)
+      fprintf(stderr, "[pbsim job r%d] t=%.1f ms rec %d delivery: waited %.1f ms for the bytes (%lld + %lld)\n", rank,
+              (t0 - t_start) / 1e3, d->rec + 1, (t1 - t0) / 1e3, (long long)d->sizes[0], (long long)d->sizes[1]);
+    return check_worker();
   }
 
   // ---- the tail of a record (owner rank only) ------------------------------------------------------------------------
   int tail_begin(Rec &R) {
-    if (free_slot() < 0)  // another record's tail holds the spare slot: let it finish first
-      for (size_t r = 0; r < recs.size(); r++)
-        if (recs[r].tail_slot >= 0 && !tail_poll((int)r, true)) return PBSIM_FAILED;
-    const int s = free_slot();
-    if (s < 0) return fail("internal: no free slot for a truncated read");
+    const int s = a_tail_is_running() ? -1 : free_slot();  // one truncated read at a time (see acquire_slot)
+    if (s < 0) {  // every slot is busy (deliveries in flight): tail_poll starts the read as soon as one is free
+      R.tail_waiting = true;
+      return PBSIM_SUCCEEDED;
+    }
+    R.tail_waiting = false;
     c->cur = s;
     if (!walk_begin(c, R.ref, R.next_read, 1, R.quota - R.len_total)) return PBSIM_FAILED;
     R.tail_slot = s;
     return PBSIM_SUCCEEDED;
   }
-  // one step of the chain if the read in flight has finished (or `block`); begins the next truncated read if one is due
+  // one step of the chain if the read in flight has finished (or `block`); begins the next truncated read if one is due.
+  // A tail read's bytes follow the record's bulk bytes: nothing is delivered while the sizes of the record's last round are
+  // still to be exchanged (complete_pending, a collective, is the main loop's business -- only the owner is here).
   int tail_poll(int rec, bool block) {
     Rec &R = recs[(size_t)rec];
-    while (R.tail_slot >= 0) {
+    for (;;) {
+      if (R.tail_waiting) {
+        if (block) {  // another record's chain first (one truncated read at a time), then a slot from the worker
+          for (size_t o = 0; o < recs.size(); o++)
+            if ((int)o != rec && recs[o].tail_slot >= 0 && !tail_poll((int)o, true)) return PBSIM_FAILED;
+          if (free_slot() < 0) worker.drain();
+        }
+        if (!tail_begin(R)) return PBSIM_FAILED;
+        if (R.tail_waiting) return block ? fail("internal: no slot for a truncated read") : PBSIM_SUCCEEDED;
+      }
+      if (R.tail_slot < 0) return PBSIM_SUCCEEDED;
+      if (pending && pending->rec == rec) return block ? fail("internal: tail before the record's last sizes") : PBSIM_SUCCEEDED;
       c->cur = R.tail_slot;
       if (!block && hipEventQuery(c->s().ev3) != hipSuccess) return PBSIM_SUCCEEDED;
       const double t0 = now_us();
       if (!pbsim_batch_walk_end(c, nullptr)) return PBSIM_FAILED;
       pbsim_batch_info bi;
       if (!finalize_cut(c, R.len_total, &bi) || !finalize_text(c, &bi)) return PBSIM_FAILED;
-      int64_t nr = bi.read_text_bytes, nm = bi.maf_text_bytes;
-      if (sink && c->deflate == 3) {
-        if (!send_deflated_stream(rec, R.read_off + R.tail_read, R.maf_off + R.tail_maf, &nr, &nm)) return PBSIM_FAILED;
-      } else if (!send_plain(rec, R.read_off + R.tail_read, R.maf_off + R.tail_maf)) {
-        return PBSIM_FAILED;
-      }
-      if (!account_slot(c, &R.st)) return PBSIM_FAILED;
-      R.tail_read += nr;
-      R.tail_maf += nm;
+      const int slot = R.tail_slot;
+      Slot *sl = &c->slots[slot];
+      Rec *Rp = &R;
+      delivering[slot] = true;
+      worker.post([this, sl, Rp, slot]() {  // FIFO behind the record's bulk deliveries: offsets and accounting stay in read order
+        int ok = PBSIM_SUCCEEDED;
+        int64_t nr = 0, nm = 0;
+        const int64_t read_at = Rp->read_off + Rp->tail_read, maf_at = Rp->maf_off + Rp->tail_maf;
+        if (deflated()) {
+          ok = stream_deflated(*sl, Rp->ref.unit, read_at, maf_at, &nr, &nm);
+        } else if (wants_text()) {
+          ok = fetch_plain(*sl) && sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
+          nr = sink->on_read_text ? sl->b_info.read_text_bytes : 0;
+          nm = sink->on_maf_text ? sl->b_info.maf_text_bytes : 0;
+        }
+        if (ok) ok = account_of(c, *sl, &Rp->st);
+        Rp->tail_read += nr;
+        Rp->tail_maf += nm;
+        if (!ok) worker_fail();
+        delivering[slot] = false;
+      });
       reads_walked += 1;
       reads_delivered += bi.n_final;
       bases += bi.bases;
@@ -271,15 +500,18 @@ struct Job {
         if (!tail_begin(R)) return PBSIM_FAILED;
       } else {
         R.done = true;
+        return PBSIM_SUCCEEDED;
       }
     }
-    return PBSIM_SUCCEEDED;
   }
 
   // ---- merge + completion of a record (collective) -------------------------------------------------------------------
   int finish_record(int rec) {
     Rec &R = recs[(size_t)rec];
+    if (!complete_pending()) return PBSIM_FAILED;  // every rank is here at the same point of the round sequence
     if (rank == R.owner && !tail_poll(rec, true)) return PBSIM_FAILED;
+    worker.drain();  // every delivery of the record has reached the sink and the statistics
+    if (!check_worker()) return PBSIM_FAILED;
     int64_t extra[2] = {R.tail_read, R.tail_maf};
     const double t0 = now_us();
     if (!stats_merge(&R.st, c->p, W > 1 ? comm : nullptr, extra, 2)) return PBSIM_FAILED;
@@ -307,8 +539,7 @@ struct Job {
     if (remaining <= 0) n_total = 64;
     int64_t n_per = std::min<int64_t>((n_total + W - 1) / W, R.cap);
     n_per = std::max<int64_t>(n_per, 1);
-    const int s = free_slot();
-    if (s < 0) return fail("internal: no free slot");
+    const int s = acquire_slot();
     c->cur = s;
     if (!walk_begin(c, R.ref, R.spec_read + (int64_t)rank * n_per, n_per, -1)) return PBSIM_FAILED;
     fifo.push_back(Round{rec, s, R.spec_read, n_per, mean});
@@ -331,6 +562,7 @@ struct Job {
       my_err = g_err;
       code = (my_err.rfind("scratch budget exceeded", 0) == 0 && rd.n_per > 1) ? 1 : 2;
     }
+    if (wfailed) code = 2;
     const double t1 = now_us();
     std::vector<int64_t> A, B;
     const int64_t sendA[2] = {pass0, code};
@@ -343,18 +575,20 @@ struct Job {
     }
     if (worst == 2) {
       drop_everything();
+      if (wfailed) return check_worker();
       return fail(code == 2 ? my_err : "another rank of the job failed");
     }
     if (worst == 1) {
       // skewed lengths: some rank's block does not fit its scratch pool.  Everything in flight is void (later rounds were sized
-      // with the same cap); every record falls back to what is confirmed and this record retries with half the cap.
+      // with the same cap); every record falls back to what is confirmed and retries with half the cap.
+      if (!complete_pending()) return PBSIM_FAILED;
       drop_everything();
       for (Rec &r : recs) {
         r.spec_read = r.next_read;
         r.spec_total = (double)r.len_total;
+        r.cap = std::min(r.cap, std::max<int64_t>(1, rd.n_per / 2));
         if (r.owner == rank && r.bulk_done && !r.done && !tail_begin(r)) return PBSIM_FAILED;
       }
-      for (Rec &r : recs) r.cap = std::min(r.cap, std::max<int64_t>(1, rd.n_per / 2));
       return PBSIM_SUCCEEDED;
     }
     pbsim_batch_info bi;
@@ -368,50 +602,21 @@ struct Job {
       if (B[(size_t)q * 5] < rd.n_per) cut = q;
     const int last_valid = cut < 0 ? W - 1 : cut;
     const bool mine = rank <= last_valid && bi.n_final > 0;
-    const bool deflated = sink && c->deflate == 3;
-    // ---- deliver
-    int64_t sizes_r[2] = {mine ? bi.read_text_bytes : 0, mine ? bi.maf_text_bytes : 0};
-    std::vector<int64_t> S;
-    if (deflated && W > 1) {
-      c->cur = rd.slot;
-      if (mine && !arena_fill(&sizes_r[0], &sizes_r[1])) return PBSIM_FAILED;
-      if (!gather(sizes_r, 2, &S)) return PBSIM_FAILED;
-    } else {
-      S.assign((size_t)W * 2, 0);
-      for (int q = 0; q <= last_valid; q++) {
-        S[(size_t)q * 2] = B[(size_t)q * 5] > 0 ? B[(size_t)q * 5 + 3] : 0;
-        S[(size_t)q * 2 + 1] = B[(size_t)q * 5] > 0 ? B[(size_t)q * 5 + 4] : 0;
-      }
-    }
-    int64_t read_at = R.read_off, maf_at = R.maf_off, read_all = 0, maf_all = 0;
-    for (int q = 0; q < W; q++) {
-      if (q < rank) {
-        read_at += S[(size_t)q * 2];
-        maf_at += S[(size_t)q * 2 + 1];
-      }
-      read_all += S[(size_t)q * 2];
-      maf_all += S[(size_t)q * 2 + 1];
-    }
-    c->cur = rd.slot;
+    // ---- delivery: the previous round's sizes first (its bytes have been on their way while this round was finalised), then
+    // this round's bytes start moving
+    if (!complete_pending()) return PBSIM_FAILED;
+    pending.reset(new Delivery);
+    pending->slot = rd.slot;
+    pending->rec = rd.rec;
+    pending->mine = mine;
+    pending->n_per = rd.n_per;
+    submit_stage1(pending.get());
     if (mine) {
-      if (deflated && W > 1) {
-        if (!arena_flush(rd.rec, read_at, maf_at)) return PBSIM_FAILED;
-      } else if (deflated) {
-        int64_t nr = 0, nm = 0;
-        if (!send_deflated_stream(rd.rec, read_at, maf_at, &nr, &nm)) return PBSIM_FAILED;
-        read_all = nr;
-        maf_all = nm;
-      } else if (!send_plain(rd.rec, read_at, maf_at)) {
-        return PBSIM_FAILED;
-      }
-      if (!account_slot(c, &R.st)) return PBSIM_FAILED;
       reads_delivered += bi.n_final;
       bases += bi.bases;
       ref_bases += bi.ref_bases;
       maf_columns += bi.maf_columns;
     }
-    R.read_off += read_all;
-    R.maf_off += maf_all;
     const double t3 = now_us();
     // ---- the record's state, identical on every rank
     const double n_round = (double)W * (double)rd.n_per;
@@ -448,7 +653,7 @@ struct Job {
     }
     if (trace)
       fprintf(stderr,
-              "[pbsim job r%d] t=%.1f ms rec %d round first=%lld n=%lldx%d final=%lld cut=%d wait_walk=%.1f finalize=%.1f deliver=%.1f "
+              "[pbsim job r%d] t=%.1f ms rec %d round first=%lld n=%lldx%d final=%lld cut=%d wait_walk=%.1f finalize=%.1f handover=%.1f "
               "comm=%.1f ms\n",
               rank, (t0 - t_start) / 1e3, rd.rec + 1, (long long)rd.first, (long long)rd.n_per, W, (long long)bi.n_final, cut,
               (t1 - t0) / 1e3, (t2 - t1) / 1e3, (t3 - t2) / 1e3, comm_us / 1e3);
@@ -458,7 +663,9 @@ struct Job {
   int run() {
     const int n = (int)recs.size();
     int merged = 0;
+    worker.start(c->device);
     for (;;) {
+      if (!check_worker()) return PBSIM_FAILED;
       // ---- keep the pipeline full: the earliest record that still lacks reads in flight
       while (bulk_in_flight() < depth) {
         int cand = -1;
@@ -482,24 +689,25 @@ struct Job {
           merged++;
           continue;
         }
-        if (free_slot() < 0) break;
-        // one slot stays free for a tail (the owner is not known in advance)
-        int busy = 0;
-        for (int s = 0; s < kMaxSlots; s++) busy += slot_busy(s);
-        if (busy >= kMaxSlots - 1) break;
         if (!begin_round(cand)) return PBSIM_FAILED;
       }
       // ---- tails make progress between rounds
       for (int r = 0; r < n; r++)
-        if (recs[(size_t)r].tail_slot >= 0 && !tail_poll(r, false)) return PBSIM_FAILED;
-      if (fifo.empty()) break;
+        if ((recs[(size_t)r].tail_slot >= 0 || recs[(size_t)r].tail_waiting) && !tail_poll(r, false)) return PBSIM_FAILED;
+      if (fifo.empty()) {
+        for (int r = 0; r < n; r++)
+          if (!recs[(size_t)r].bulk_done) return fail("internal: a record lacks reads but nothing is in flight");
+        break;
+      }
       if (!process_round()) return PBSIM_FAILED;
     }
+    if (!complete_pending()) return PBSIM_FAILED;
     for (; merged < n; merged++) {
       if (!recs[(size_t)merged].bulk_done) return fail("internal: a record was left unfinished");
       if (!finish_record(merged)) return PBSIM_FAILED;
     }
-    return PBSIM_SUCCEEDED;
+    worker.finish();
+    return check_worker();
   }
 };
 
@@ -615,7 +823,7 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   J.trace = getenv("PBSIM_TRACE") != nullptr;
   J.t_start = now_us();
   const char *jd = getenv("PBSIM_JOB_DEPTH");
-  J.depth = std::max(1, std::min(kMaxSlots - 2, jd ? atoi(jd) : 3));
+  J.depth = std::max(1, std::min(kMaxSlots - 3, jd ? atoi(jd) : 3));  // + one pending delivery + one tail read < kMaxSlots
   const int W = J.W;
   // ---- the records' preparation (upload + k_hp_*) has been running since pbsim_job_add_record: collect it
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));
@@ -689,10 +897,12 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   }
   J.mean = std::min<double>(J.mean, (double)c->job_records[0]->len);
   for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
+  if (J.deflated() && !ensure_deflate_ready(c)) return PBSIM_FAILED;  // before the worker and its lane threads use the tables
   const int ok = J.run();
   if (!ok) {
     const std::string keep = g_err;
     J.drop_everything();
+    J.worker.finish();
     g_err = keep;
   }
   c->job_counters[0] = J.reads_walked;

@@ -105,3 +105,34 @@ def test_failure_on_one_rank_stops_the_job(tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 255
     assert "ERROR" in p.stderr
+
+
+@pytest.mark.parametrize("which", ["read", "maf"])
+def test_sink_failure_on_either_thread_reaches_the_caller(which):
+    """pbsim_set_deflate bit 2 serves the read sink from a second host thread; pbsim_last_error() is thread local, so a
+    callback that fails THERE must still surface in the calling thread (untested)"""
+    import ctypes as C
+    import numpy as np
+    import pbsim3_amd as P
+    rng = np.random.default_rng(2)
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 300_000)].tobytes()
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=3.0)
+    with P.Context(p, 0) as ctx:
+        ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+        ctx.set_deflate(7)
+        ctx.job_add_record(genome)
+        bad = P.REC_TEXT_CB(lambda u, r, t, n, o: 0)
+        good = P.REC_TEXT_CB(lambda u, r, t, n, o: 1)
+        sink = P.RecordSink(None, bad if which == "read" else good, bad if which == "maf" else good, P.REC_DONE_CB())
+        with pytest.raises(P.PbsimError, match="sink aborted \\(%s text\\)" % ("read" if which == "read" else "MAF")):
+            P._check(ctx.lib.pbsim_job_run(ctx.h, None, C.byref(sink)))
+        # the context stays usable: the same job runs through with a sink that accepts everything
+        outs, done = ctx.job_run()
+        assert done[1][0].res_num > 0 and len(outs[1][0]) == done[1][1] > 0
+        # and the per-record driver with a sink that fails on its second thread
+        ctx.set_reference(genome, 1)
+        s2 = P.Sink(None, P.SINK_CB(lambda u, t, n: 0 if which == "read" else 1), P.SINK_CB(lambda u, t, n: 0 if which == "maf" else 1))
+        with pytest.raises(P.PbsimError, match="sink aborted"):
+            P._check(ctx.lib.pbsim_simulate_wgs(ctx.h, C.byref(s2)))
+        rt, mt = ctx.simulate_wgs()
+        assert len(rt) > 0 and len(mt) > 0
