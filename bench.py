@@ -402,6 +402,7 @@ def main():
     dt = time.perf_counter() - t0
     walk_ms, launches, _ = ctx.prof_get()
     walk_busy_ms = ctx.prof_walk_busy()
+    tail_ms, tail_launches = ctx.prof_tail()
 
     # the statistics of a record are identical on every rank (merged); bytes delivered and reads walked are per rank
     job_bases = sum(v[1] for v in sinks[0].stats.values())
@@ -422,6 +423,11 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_job(False)                      # untimed: this mode sizes its batches (and pools) differently
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t1 = time.perf_counter()
         run_job(False)
         torch.cuda.synchronize()
@@ -467,6 +473,9 @@ def main():
                          "traffic_source": "profiles/r01x_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE, raw x1024; see note there)",
                          "alg_bytes_per_launch": alg_bytes / max(1, launches), "avg_launch_ms": walk_ms / max(1, launches),
                          "launches": launches,
+                         "tail_read_launches": {"launches": tail_launches, "avg_ms": tail_ms / max(1, tail_launches),
+                                                "note": "walk launches that carry one truncated tail read (the latency of a single "
+                                                        "lane): counted apart from the launches above"},
                          "note": "achieved = algorithmic bytes of the path (SURVEY 8d: 1 ref + 2 read + 2 quality... per base) of rank 0's "
                                  "delivered reads / summed duration of its walk launches (HIP events on the walk streams, every launch of "
                                  "the timed region incl. tail reads); walks of different slots overlap, so walk_busy counts that time once",

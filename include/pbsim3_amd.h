@@ -326,6 +326,9 @@ int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int device);
  * measured on the engine's own stream, and the number of launches. */
 int pbsim_prof_reset(pbsim_ctx *ctx);
 int pbsim_prof_get(pbsim_ctx *ctx, double *walk_ms, int64_t *walk_launches, double *total_ms);
+/* pbsim_prof_get counts the walk launches of batches; a launch that carries one truncated tail read (pbsim.cpp:3795-3800:
+ * the latency of a single lane, no bytes to speak of) is counted here instead */
+int pbsim_prof_tail(pbsim_ctx *ctx, double *tail_ms, int64_t *tail_launches);
 /* milliseconds since the reset during which at least one walk kernel ran (the launches of different slots overlap) */
 int pbsim_prof_walk_busy(pbsim_ctx *ctx, double *busy_ms);
 /* raw HIP stream handle (hipStream_t) of the engine, for external event timing */

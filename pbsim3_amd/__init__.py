@@ -142,6 +142,7 @@ API = [
     ("pbsim_prof_reset", C.c_int, [C.c_void_p]),
     ("pbsim_prof_get", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("pbsim_prof_walk_busy", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("pbsim_prof_tail", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("pbsim_stream", C.c_void_p, [C.c_void_p]),
     ("pbsim_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("pbsim_dump_table", C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
@@ -605,6 +606,11 @@ class Context:
         a, b, c = C.c_double(0), C.c_int64(0), C.c_double(0)
         _check(self.lib.pbsim_prof_get(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def prof_tail(self):
+        a, b = C.c_double(0), C.c_int64(0)
+        _check(self.lib.pbsim_prof_tail(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def prof_walk_busy(self):
         a = C.c_double(0)

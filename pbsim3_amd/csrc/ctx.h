@@ -93,7 +93,7 @@ constexpr int kMaxSlots = 6;
 // k_text_rows prefetches whole 256-column tiles without bounds checks: up to two tiles (2 x 64 dwords x 256 B) past the
 // last wave's last row
 constexpr size_t kScratchSlack = 64u << 10;
-constexpr double kSinkBatchBases = 2.5e9;  // pbsim_simulate_wgs: expected bases per batch when the text goes to a sink
+constexpr double kSinkBatchBases = 5.0e9;  // pbsim_simulate_wgs: expected bases per batch when the text goes to a sink
 
 // One deflate pipeline: staging for one piece of DF_PIECE_CHUNKS chunks, double-buffered dense output + pinned copies, its
 // own streams.  A slot owns two, so that its read text and its MAF text can be compressed, copied and handed to their
@@ -253,8 +253,8 @@ struct pbsim_ctx {
   int64_t job_first_unit = 1;    // genome.num of the job's first record (pbsim_job_begin)
 
   // profiling
-  double prof_walk_ms = 0, prof_total_ms = 0;
-  int64_t prof_walk_launches = 0;
+  double prof_walk_ms = 0, prof_total_ms = 0, prof_tail_ms = 0;
+  int64_t prof_walk_launches = 0, prof_tail_launches = 0;   // walk launches of batches / of single truncated tail reads
   hipEvent_t ev_prof_base = nullptr;                     // pbsim_prof_reset: time zero of the walk intervals
   std::vector<std::pair<float, float>> prof_intervals;   // [start, end] ms of every walk launch since the reset
 };

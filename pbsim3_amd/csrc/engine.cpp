@@ -524,7 +524,13 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   HIP_OK(c->s().d_qsum.ensure(n_tasks * 8));
   HIP_OK(c->s().d_cum.ensure((n_reads + 1) * 8));
   HIP_OK(c->s().d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
-  HIP_OK(c->s().d_scratch.ensure((size_t)c->scratch_budget + kScratchSlack, true));
+  // The pool is the budget, unless this batch cannot need that much: a wave's rows hold at most 2 * Lmax + pad columns
+  // (Lmax = the longest read the header can draw), so a handful of reads (the truncated tail reads) gets by with little.
+  const double lmax = (double)std::min<int64_t>(c->p.len_max, std::max<int64_t>(ref.len, 1));
+  const double worst = (double)waves_max * regions_of(c) * (2.0 * lmax + kScratchPad + 4) * 64.0;
+  const int64_t pool = std::max<int64_t>((int64_t)c->s().d_scratch.bytes - (int64_t)kScratchSlack,
+                                         (int64_t)std::min<double>((double)c->scratch_budget, worst));
+  HIP_OK(c->s().d_scratch.ensure((size_t)pool + kScratchSlack, true));
 
   HIP_OK(hipEventRecord(c->s().ev0, c->s().stream));
   HIP_OK(hipMemsetAsync(c->s().d_flags.p, 0, sizeof(DeviceFlags), c->s().stream));
@@ -581,7 +587,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   s.wg_start = s.wg_hist + (kLenBuckets + 1);
   s.wg_order = c->s().d_wg_order.as<int32_t>();
   s.regions = regions_of(c);
-  s.scratch_bytes = c->scratch_budget;
+  s.scratch_bytes = std::min<int64_t>(pool, c->scratch_budget);
   s.flags = flags;
   launch_task_sort(s, c->s().stream);
 
@@ -667,15 +673,19 @@ int pbsim_batch_walk_end(pbsim_ctx *c, int64_t *pass0_bases) {
   DeviceFlags f;
   if (!read_flags(c, &f)) return PBSIM_FAILED;
   float ms = 0;
-  if (hipEventElapsedTime(&ms, c->s().ev1, c->s().ev2) == hipSuccess) c->prof_walk_ms += ms;
-  if (c->ev_prof_base) {
+  // the profile is about the walk kernel at work: a launch that carries a single truncated tail read (latency of one lane,
+  // no bytes to speak of) is counted apart
+  const bool bulk = c->s().b_n > 1;
+  if (hipEventElapsedTime(&ms, c->s().ev1, c->s().ev2) == hipSuccess) (bulk ? c->prof_walk_ms : c->prof_tail_ms) += ms;
+  if (!bulk) c->prof_tail_launches++;
+  if (bulk && c->ev_prof_base) {
     float a = 0, b = 0;
     if (hipEventElapsedTime(&a, c->ev_prof_base, c->s().ev1) == hipSuccess &&
         hipEventElapsedTime(&b, c->ev_prof_base, c->s().ev2) == hipSuccess)
       c->prof_intervals.emplace_back(a, b);
   }
   if (hipEventElapsedTime(&ms, c->s().ev0, c->s().ev3) == hipSuccess) c->prof_total_ms += ms;
-  c->prof_walk_launches++;
+  if (bulk) c->prof_walk_launches++;
   if (f.error & kErrScratchBudget) {
     char buf[160];
     snprintf(buf, sizeof buf, "scratch budget exceeded: batch needs %lld bytes, pool holds %lld",
@@ -1815,8 +1825,8 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
 
 int pbsim_prof_reset(pbsim_ctx *c) {
   if (!c) return fail("bad argument");
-  c->prof_walk_ms = c->prof_total_ms = 0;
-  c->prof_walk_launches = 0;
+  c->prof_walk_ms = c->prof_total_ms = c->prof_tail_ms = 0;
+  c->prof_walk_launches = c->prof_tail_launches = 0;
   c->prof_intervals.clear();
   if (c->device >= 0 && c->stream) {
     HIP_OK(hipSetDevice(c->device));
@@ -1828,6 +1838,12 @@ int pbsim_prof_reset(pbsim_ctx *c) {
 }
 // time during which at least one walk kernel was running (union of the launches' intervals): walks of different slots
 // overlap by design, so the sum of their durations counts that time more than once
+int pbsim_prof_tail(pbsim_ctx *c, double *tail_ms, int64_t *tail_launches) {
+  if (!c) return fail("bad argument");
+  if (tail_ms) *tail_ms = c->prof_tail_ms;
+  if (tail_launches) *tail_launches = c->prof_tail_launches;
+  return PBSIM_SUCCEEDED;
+}
 int pbsim_prof_walk_busy(pbsim_ctx *c, double *busy_ms) {
   if (!c || !busy_ms) return fail("bad argument");
   std::vector<std::pair<float, float>> v = c->prof_intervals;

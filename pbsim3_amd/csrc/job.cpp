@@ -194,16 +194,18 @@ struct Job {
       if (r.tail_slot == s) return true;
     return false;
   }
+  // The last slot belongs to the truncated tail reads (one read at a time: its pools stay small), the others to the rounds.
+  static constexpr int kTailSlot = kMaxSlots - 1;
   int free_slot() const {
-    for (int s = 0; s < kMaxSlots; s++)
+    for (int s = 0; s < kTailSlot; s++)
       if (!slot_busy(s)) return s;
     return -1;
   }
   int bulk_in_flight() const { return (int)fifo.size(); }
   // A slot for a bulk round.  WHETHER a round is begun must not depend on how far this rank's worker has got (the ranks would
   // fall out of step), so the main loop decides from the gathered state alone and then waits here for a slot.  One always
-  // comes free: at most `depth` rounds, one pending delivery and one tail read hold slots that only the main loop can
-  // release; every other slot is with the worker, which needs nobody.
+  // comes free: at most `depth` rounds and one pending delivery hold slots that only the main loop can release; every other
+  // slot is with the worker, which needs nobody.
   int acquire_slot() {
     for (;;) {
       const int s = free_slot();
@@ -430,7 +432,7 @@ struct Job {
 
   // ---- the tail of a record (owner rank only) ------------------------------------------------------------------------
   int tail_begin(Rec &R) {
-    const int s = a_tail_is_running() ? -1 : free_slot();  // one truncated read at a time (see acquire_slot)
+    const int s = (a_tail_is_running() || slot_busy(kTailSlot)) ? -1 : kTailSlot;  // one truncated read at a time, on its own slot
     if (s < 0) {  // every slot is busy (deliveries in flight): tail_poll starts the read as soon as one is free
       R.tail_waiting = true;
       return PBSIM_SUCCEEDED;
@@ -451,7 +453,7 @@ struct Job {
         if (block) {  // another record's chain first (one truncated read at a time), then a slot from the worker
           for (size_t o = 0; o < recs.size(); o++)
             if ((int)o != rec && recs[o].tail_slot >= 0 && !tail_poll((int)o, true)) return PBSIM_FAILED;
-          if (free_slot() < 0) worker.drain();
+          if (slot_busy(kTailSlot)) worker.drain();
         }
         if (!tail_begin(R)) return PBSIM_FAILED;
         if (R.tail_waiting) return block ? fail("internal: no slot for a truncated read") : PBSIM_SUCCEEDED;
@@ -823,7 +825,8 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   J.trace = getenv("PBSIM_TRACE") != nullptr;
   J.t_start = now_us();
   const char *jd = getenv("PBSIM_JOB_DEPTH");
-  J.depth = std::max(1, std::min(kMaxSlots - 3, jd ? atoi(jd) : 3));  // + one pending delivery + one tail read < kMaxSlots
+  // rounds in flight: + one pending delivery < the slots of the rounds
+  J.depth = std::max(1, std::min(kMaxSlots - 3, jd ? atoi(jd) : 3));
   const int W = J.W;
   // ---- the records' preparation (upload + k_hp_*) has been running since pbsim_job_add_record: collect it
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));
@@ -874,8 +877,19 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   if (c->scratch_auto) {
     size_t free_b = 0, total_b = 0;
     HIP_OK(hipMemGetInfo(&free_b, &total_b));
-    size_t held = 0;
-    for (Slot &sl : c->slots) held += sl.d_scratch.bytes;
+    size_t held = 0, held_text = 0;
+    for (Slot &sl : c->slots) {
+      held += sl.d_scratch.bytes;
+      held_text += sl.d_read_text.bytes + sl.d_maf_text.bytes;
+    }
+    {
+      // every slot a round passes through (in flight, pending, with the worker) keeps its scratch rows AND its text until the
+      // bytes are delivered: bound the batch so that all of them fit 70 % of what the GPU has left
+      const double text_per_base = P > 1 ? 8.5 : 4.3;                  // FASTQ 2.0 | SAM text ~6.1 (BAM records less), MAF 2.13
+      const double scratch_per_base = (double)regions * 2.0 * 1.12 * 1.08 + 0.1;
+      const double fit = 0.70 * (double)(free_b + held + held_text) / ((double)(J.depth + 2) * (text_per_base + scratch_per_base));
+      target = std::min(target, std::max(fit, 1.0e8));
+    }
     // what batch_capacity_for() charges a read: `regions` rows of 2 * length + pad columns, 12 % slack for the per-wave rounding
     const double mean_len = std::max(1.0, c->hdr.mean_len);
     // (a read yields ~0.97 of its length in bases, and a round overshoots its share of the quota by 0.5 %: 8 % headroom)
