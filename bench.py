@@ -278,12 +278,12 @@ class CountingSink:
         return 1
 
 
-def steady_state(a, torch, harness, P, local, model, genome_ptr, G):
+def steady_state(a, torch, harness, P, local, model, genome_ptr, G, qs=False, pass_num=1):
     """the batch pipeline alone: two slots, one record, full batches, no quota cut, text left in HBM (the round-1 headline)"""
-    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=20.0)
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=1, depth=20.0, pass_num=pass_num)
     ctx = P.Context(p, local)
     ctx.set_scratch_bytes(int(a.scratch_gib * (1 << 30)))
-    ctx.load_errhmm(harness.model_path(model))
+    (ctx.load_qshmm if qs else ctx.load_errhmm)(harness.model_path(model))
     ctx.set_reference_device(genome_ptr, G, 1)
     B, S = ctx.batch_capacity(), 2
 
@@ -302,12 +302,19 @@ def steady_state(a, torch, harness, P, local, model, genome_ptr, G):
         return infos
     run(0, S)
     torch.cuda.synchronize()
+    ctx.prof_reset()
     t0 = time.perf_counter()
     infos = run(S, 4)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    walk_ms, launches, _ = ctx.prof_get()
     ctx.close()
+    alg = sum(i.ref_bases + 2 * i.bases + 2 * i.maf_columns for i in infos)
+    ach = alg / (walk_ms / 1e3) / 1e9 if walk_ms > 0 else None
     return {"value": sum(i.bases for i in infos) / dt, "unit": "bases/s", "steps": 4, "reads_per_step": B,
+            "walk": {"avg_launch_ms": walk_ms / max(1, launches), "achieved": ach, "frac": ach / HBM_PEAK_GBS if ach else None,
+                     "note": "the walk kernel in this regime: one launch of a full batch at a time beside the other slot's text "
+                             "emission (what round 1 reported as roofline)"},
             "note": "two batches in flight on one record, every read final (no quota cut), FASTQ + MAF text left in HBM"}
 
 
@@ -493,9 +500,9 @@ def main():
         }
         out.update(extras)
     ctx.close()
-    if rank == 0 and world == 1 and not a.no_extras and not qs:
+    if rank == 0 and world == 1 and not a.no_extras:
         try:
-            out["steady_state_hbm"] = steady_state(a, torch, harness, P, local, model, recs[0].data_ptr(), G)
+            out["steady_state_hbm"] = steady_state(a, torch, harness, P, local, model, recs[0].data_ptr(), G, qs, pass_num)
         except Exception as e:
             out["steady_state_hbm"] = {"error": str(e)}
     if rank == 0:

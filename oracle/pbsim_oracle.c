@@ -142,6 +142,10 @@ static inline long R_hdr(int slot) {
 static inline long R_walk(int sub, int slot) {
   g_draws++;
   if (sim.rng == RNG_GLIBC) return rand();
+  /* sub-block 2 (the deletion test of a column, one draw): the block of event column >> 2 serves four columns, word
+   * column & 3 (contract of round 2) */
+  if (sub == 2)
+    return (long)orc_keyed_draw(sim.seed, ORC_STREAM_WALK, g_unit, g_read, g_pass, g_event >> 2, 2u, g_event & 3u);
   return (long)orc_keyed_draw(sim.seed, ORC_STREAM_WALK, g_unit, g_read, g_pass, g_event,
                               (uint32_t)sub, (uint32_t)slot);
 }

@@ -107,6 +107,9 @@ extern "C" int pbshim_draw(int line, long unit, long read, long pass, long event
   if (s->kind == K_HDR)
     return (int)orc_keyed_draw(g_seed, ORC_STREAM_HDR, (uint32_t)unit, (uint32_t)(read + 1),
                                0, 0, 0, (uint32_t)s->slot);
+  if (s->sub == 2) /* the deletion test of a column: block of event column >> 2, word column & 3 */
+    return (int)orc_keyed_draw(g_seed, ORC_STREAM_WALK, (uint32_t)unit, (uint32_t)read,
+                               (uint32_t)pass, (uint32_t)event >> 2, 2u, (uint32_t)event & 3u);
   return (int)orc_keyed_draw(g_seed, ORC_STREAM_WALK, (uint32_t)unit, (uint32_t)read,
                              (uint32_t)pass, (uint32_t)event, (uint32_t)s->sub, (uint32_t)s->slot);
 }

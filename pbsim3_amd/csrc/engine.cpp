@@ -645,7 +645,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     w.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
     w.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     w.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
-    launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8, c->qct.all_rv_100,
+    launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8 + 94 * 32, c->qct.all_rv_100,
                       ref.hp_flag, ws);
   }
   HIP_OK(hipEventRecord(c->s().ev2, ws));

@@ -881,7 +881,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
 // ---------------------------------------------------------------------------
 // K2q: QSHMM walk (pbsim.cpp:2209-2282).  Column m is either an emitted base or
 // a deleted reference base.  Every column m >= 1 first takes the deletion test
-// of sub-block 2 (the inner while of :2268-2281); a column that is not deleted
+// of sub-block 2 (the inner while of :2268-2281; word m & 3 of the block of event m >> 2); a column that is not deleted
 // emits a base from sub-block 0: w.x state | w.y quality | w.z error class |
 // w.w nucleotide; sub-block 1 w.x = non-ACGT substitution.
 // ---------------------------------------------------------------------------
@@ -909,6 +909,20 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
     s_qprob[i] = a.qprob[i];
   }
   for (int i = tid; i < 94 * 12; i += kWG) s_del[i] = a.del_thr[i];
+  // With the default --hp-del-bias 1 a quality's deletion threshold depends on hp only through "none yet" (slot 0, Q15),
+  // hp == 11 (bias 0.0, Q1: never) and everything else (one value): everything a column needs of its quality Q then sits in
+  // ONE 32-byte row {sub_thre, ins_thre, del (hp 1..10), del (slot 0) | qprob f64 | -} -- a 16-byte and an 8-byte read behind
+  // the quality lookup instead of four table reads spread over two columns.
+  uint32_t *s_row = reinterpret_cast<uint32_t *>(s_qprob + 94);
+  if (kHpBits)
+    for (int i = tid; i < 94; i += kWG) {
+      s_row[i * 8 + 0] = a.sub_thre[i];
+      s_row[i * 8 + 1] = a.ins_thre[i];
+      s_row[i * 8 + 2] = a.del_thr[i * 12 + 1];
+      s_row[i * 8 + 3] = a.del_thr[i * 12 + 0];
+      *reinterpret_cast<double *>(&s_row[i * 8 + 4]) = a.qprob[i];
+      s_row[i * 8 + 6] = s_row[i * 8 + 7] = 0;
+    }
   __syncthreads();
   const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
   const uint32_t init_rv = hdr[1], has_model = hdr[2], freq_rv = hdr[3];
@@ -943,6 +957,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
 
   int ro = 0, q = 0, m = 0;
   uint32_t state = 0, last_q = 0, hp_prev = 0;  // hp of the last consumed reference base; none yet -> slot 0 (Q15)
+  uint32_t del_norm = 0, del_none = 0;          // kHpBits: the last emitted quality's deletion thresholds (hp 1..10 | slot 0)
   uint32_t acc_r = 0, acc_f = 0, acc_q = 0;
   int nsub = 0;
   double qsum = 0.0;
@@ -955,13 +970,13 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   const WalkLane lane_d = walk_lane(a.seed, read_idx, pass, 2u);  // deletion-test blocks
 
   while (__any(act)) {
-    U4 E[4], D[4];
+    U4 E[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j);
-      E[j] = walk_block_fast(lane_e, a.seed, a.unit, ev);
-      D[j] = walk_block_fast(lane_d, a.seed, a.unit, ev);
-    }
+    for (int j = 0; j < 4; j++)
+      E[j] = walk_block_fast(lane_e, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j));
+    // the deletion tests of the group's four columns are the four words of ONE block (event = column >> 2)
+    const U4 Dq = walk_block_fast(lane_d, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group));
+    const uint32_t D[4] = {Dq.x, Dq.y, Dq.z, Dq.w};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const U4 w = E[j];
@@ -969,7 +984,9 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
       cur.at(ro, act, &raw, &hp);
       const uint32_t nt = s_comp[raw + comp_off];
       // every column m >= 1 first takes the deletion test of the inner while (pbsim.cpp:2268-2281)
-      const bool deleted = (m > 0) && (D[j].x % 1000000u) < s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)];
+      const uint32_t del_thr = kHpBits ? ((hp_prev == 11u) ? 0u : (hp_prev == 0u) ? del_none : del_norm)
+                                       : s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)];
+      const bool deleted = (m > 0) && (D[j] % 1000000u) < del_thr;
       // ---- emission (computed for every lane, used where the column is not deleted)
       uint32_t qv, st = state;
       if (has_model) {
@@ -998,10 +1015,24 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
       const bool emit = act && !deleted;
       state = emit ? st : state;
       last_q = emit ? qv : last_q;
-      qsum += emit ? s_qprob[qv] : 0.0;  // ordered double sum (pbsim.cpp:2309-2313); + 0.0 leaves it unchanged
+      uint32_t thr_sub, thr_ins;
+      double qp;
+      if (kHpBits) {
+        const uint4 row = *reinterpret_cast<const uint4 *>(&s_row[qv * 8u]);
+        qp = *reinterpret_cast<const double *>(&s_row[qv * 8u + 4u]);
+        thr_sub = row.x;
+        thr_ins = row.y;
+        del_norm = emit ? row.z : del_norm;
+        del_none = emit ? row.w : del_none;
+      } else {
+        thr_sub = s_subt[qv];
+        thr_ins = s_ins[qv];
+        qp = s_qprob[qv];
+      }
+      qsum += emit ? qp : 0.0;  // ordered double sum (pbsim.cpp:2309-2313); + 0.0 leaves it unchanged
       const uint32_t x = w.z % 1000000u;
-      const bool is_sub = x < s_subt[qv];             // pbsim.cpp:2233-2249
-      const bool is_ins = !is_sub && x < s_ins[qv];   // pbsim.cpp:2250-2258
+      const bool is_sub = x < thr_sub;             // pbsim.cpp:2233-2249
+      const bool is_ins = !is_sub && x < thr_ins;   // pbsim.cpp:2250-2258
       uint32_t subb = s_sub[nt * 4u + w.w % 3u];
       if (emit && is_sub && subb == 0) {  // non-ACGT reference base: one more draw (rare)
         const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 1u);
@@ -1127,20 +1158,19 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
     int qwin_idx = 0;
 
     while (__any(act)) {
-      U4 E[4], D[4];
+      U4 E[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t ev = (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j);
-        E[j] = walk_block_fast(lane_e, a.seed, a.unit, ev);
-        D[j] = walk_block_fast(lane_d, a.seed, a.unit, ev);
-      }
+      for (int j = 0; j < 4; j++)
+        E[j] = walk_block_fast(lane_e, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j));
+      const U4 Dq = walk_block_fast(lane_d, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group));
+      const uint32_t D[4] = {Dq.x, Dq.y, Dq.z, Dq.w};   // deletion tests of the four columns (event = column >> 2)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const U4 w = E[j];
         uint32_t raw, hp;
         cur.at(ro, act, &raw, &hp);
         const uint32_t nt = s_comp[raw + comp_off];
-        const bool deleted = (m > 0) && (D[j].x % 1000000u) < s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)];
+        const bool deleted = (m > 0) && (D[j] % 1000000u) < s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)];
         if (act && (q >> 3) != qwin_idx) {  // next 8 quality characters of the string
           qwin_idx = q >> 3;
           qwin = qsrc[qwin_idx];
