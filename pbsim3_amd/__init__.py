@@ -220,18 +220,18 @@ BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0,
 
 
 def make_comm(rank, world, all_gather, all_reduce, broadcast=None):
-    """pbsim_comm from Python callables:
-         all_gather(list[int]) -> list[list[int]] (rank-major), all_reduce(list[int], op) -> list[int],
+    """pbsim_comm from Python callables (numpy int64 arrays in and out; the statistics merge moves millions of values):
+         all_gather(array[n]) -> array[world, n] (rank-major), all_reduce(array[n], op) -> array[n],
          broadcast(ptr:int, nbytes:int, root:int, on_device:bool) -> None (optional, C1).
     The returned Comm keeps the ctypes trampolines alive (comm._keep)."""
     def _g(user, send, n, recv):
         try:
-            out = all_gather([send[i] for i in range(n)])
-            k = 0
-            for row in out:
-                for v in row:
-                    recv[k] = v
-                    k += 1
+            import numpy as np
+            if n == 0:
+                return 1
+            a = np.ctypeslib.as_array(send, shape=(n,))
+            out = np.ctypeslib.as_array(recv, shape=(world * n,))
+            out[:] = np.asarray(all_gather(a), dtype=np.int64).reshape(-1)   # rank-major
             return 1
         except Exception:
             import traceback
@@ -275,11 +275,11 @@ def torch_comm(dist, device):
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
 
-    def all_gather(vals):
-        t = torch.tensor(vals, dtype=torch.int64, device=device)
+    def all_gather(arr):
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
         out = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(out, t)
-        return [o.tolist() for o in out]
+        return torch.stack(out).cpu().numpy()
 
     def all_reduce(arr, op):
         t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)

@@ -87,6 +87,13 @@ __device__ __forceinline__ uint32_t complement4(uint32_t w) {
 
 // w % 3 of a 31-bit draw: 3 q == -q (mod 4) and the remainder is below 4, so w - 3 q == (w + q) & 3
 __device__ __forceinline__ uint32_t mod3(uint32_t w) { return (w + __umulhi(w, 0x55555556u)) & 3u; }
+// `draw % n` for the three table resolutions.  A 32 x 32 multiply (v_mul_hi_u32, v_mul_lo_u32, v_mad_u64_u32) issues at a
+// quarter of the rate of an ordinary VALU instruction, a 24-bit one (v_mul_u32_u24) at the full rate, and the walks are
+// bound by exactly that issue rate: the quotient comes from one multiply-high, the product quotient * n from the 24-bit
+// multiplier (the remainder is below 2^24, so 24 bits of the difference are all of it, whatever the quotient's size).
+__device__ __forceinline__ uint32_t mod100(uint32_t x) { return (x - __umul24(__umulhi(x, 0x51EB851Fu) >> 5, 100u)) & 0xffffffu; }
+__device__ __forceinline__ uint32_t mod1000(uint32_t x) { return (x - __umul24(__umulhi(x, 0x10624DD3u) >> 6, 1000u)) & 0xffffffu; }
+__device__ __forceinline__ uint32_t mod1e6(uint32_t x) { return (x - __umul24(__umulhi(x, 0x431BDE83u) >> 18, 1000000u)) & 0xffffffu; }
 
 // inserted base (mut.ins_nt, pbsim.cpp:5485): "ATGC"[w % 8] for w % 8 < 4, else a copy of the reference base --
 // one byte select from the eight bytes {nt nt nt nt | C G T A}
@@ -814,7 +821,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
         uint32_t idx;
         if (kFastRv) {
           // the initial-state table sits right in front of the transition rows (host_tables.cpp): it is row 0
-          idx = a.init_off + __umul24((q == 0) ? 0u : state, 1000u) + w.x % 1000u;
+          idx = a.init_off + __umul24((q == 0) ? 0u : state, 1000u) + mod1000(w.x);
         } else {
           uint32_t mod = (q == 0) ? init_rv : tran_rv;  // Q2: re-initialise while nothing has been emitted
           mod = mod ? mod : 1u;
@@ -828,9 +835,9 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
         // last dword holds the deletion thresholds of hp != 11 | hp == 11: one 16-byte read serves the whole step.
         const uint4 em = *reinterpret_cast<const uint4 *>(lds + a.emis_off + state * 16u);
         const uint32_t thr = kHpBits ? __builtin_amdgcn_ubfe(em.w, (raw >> 3) & 16u, 16u) : row[4 + (hp < 12u ? hp : 11u)];
-        const bool del = (w.y % 1000u + 1u) <= thr;
+        const bool del = (mod1000(w.y) + 1u) <= thr;
         const uint32_t quo = __umulhi(w.z, em.x) >> (em.y & 0xffffu);
-        const uint32_t rem = w.z - quo * (em.y >> 16);
+        const uint32_t rem = (w.z - __umul24(quo, em.y >> 16)) & 0xffffffu;  // rem < d <= 1000: 24 bits of the difference
         e = (uint32_t)(rem >= (em.z & 0xffffu)) + (uint32_t)(rem >= (em.z >> 16));
         e = del ? 3u : e;
       }
@@ -986,13 +993,13 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
       // every column m >= 1 first takes the deletion test of the inner while (pbsim.cpp:2268-2281)
       const uint32_t del_thr = kHpBits ? ((hp_prev == 11u) ? 0u : (hp_prev == 0u) ? del_none : del_norm)
                                        : s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)];
-      const bool deleted = (m > 0) && (D[j] % 1000000u) < del_thr;
+      const bool deleted = (m > 0) & (mod1e6(D[j]) < del_thr);
       // ---- emission (computed for every lane, used where the column is not deleted)
       uint32_t qv, st = state;
       if (has_model) {
         uint32_t idx;
         if (kFastRv) {
-          idx = a.init_off + __umul24((q == 0) ? 0u : state, 100u) + w.x % 100u;  // init table = row 0 (host_tables.cpp)
+          idx = a.init_off + __umul24((q == 0) ? 0u : state, 100u) + mod100(w.x);  // init table = row 0 (host_tables.cpp)
         } else {
           uint32_t mod = (q == 0) ? init_rv : rvs[2 * state];
           mod = mod ? mod : 1u;
@@ -1001,7 +1008,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
         st = lds[idx];
         uint32_t eidx;
         if (kFastRv) {
-          eidx = a.emis_off + (st - 1u) * 100u + w.y % 100u;
+          eidx = a.emis_off + __umul24(st - 1u, 100u) + mod100(w.y);
         } else {
           uint32_t emod = rvs[2 * st + 1];
           emod = emod ? emod : 1u;
@@ -1030,10 +1037,10 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
         qp = s_qprob[qv];
       }
       qsum += emit ? qp : 0.0;  // ordered double sum (pbsim.cpp:2309-2313); + 0.0 leaves it unchanged
-      const uint32_t x = w.z % 1000000u;
+      const uint32_t x = mod1e6(w.z);
       const bool is_sub = x < thr_sub;             // pbsim.cpp:2233-2249
       const bool is_ins = !is_sub && x < thr_ins;   // pbsim.cpp:2250-2258
-      uint32_t subb = s_sub[nt * 4u + w.w % 3u];
+      uint32_t subb = s_sub[nt * 4u + mod3(w.w)];
       if (emit && is_sub && subb == 0) {  // non-ACGT reference base: one more draw (rare)
         const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 1u);
         subb = (kATGC >> ((v.x & 3u) * 8u)) & 0xffu;
@@ -1170,7 +1177,7 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
         uint32_t raw, hp;
         cur.at(ro, act, &raw, &hp);
         const uint32_t nt = s_comp[raw + comp_off];
-        const bool deleted = (m > 0) && (D[j] % 1000000u) < s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)];
+        const bool deleted = (m > 0) & (mod1e6(D[j]) < s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)]);
         if (act && (q >> 3) != qwin_idx) {  // next 8 quality characters of the string
           qwin_idx = q >> 3;
           qwin = qsrc[qwin_idx];
@@ -1180,10 +1187,10 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
         const bool emit = act && !deleted;
         last_q = emit ? qv : last_q;
         qsum += emit ? s_qprob[qv] : 0.0;  // ordered sum, pbsim.cpp:1857-1860
-        const uint32_t x = w.z % 1000000u;
+        const uint32_t x = mod1e6(w.z);
         const bool is_sub = x < s_subt[qv];
         const bool is_ins = !is_sub && x < s_ins[qv];
-        uint32_t subb = s_sub[nt * 4u + w.w % 3u];
+        uint32_t subb = s_sub[nt * 4u + mod3(w.w)];
         if (emit && is_sub && subb == 0) {  // non-ACGT reference base (:1794-1796)
           const U4 v = walk_block(a.seed, a.unit, read_idx, 0u, (uint32_t)(group * 4 + j), 1u);
           subb = (kATGC >> ((v.x & 3u) * 8u)) & 0xffu;
