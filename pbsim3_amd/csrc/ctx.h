@@ -100,6 +100,7 @@ constexpr double kSinkBatchBases = 5.0e9;  // pbsim_simulate_wgs: expected bases
 // sinks side by side (pbsim_set_deflate bit 2).
 struct DfLane {
   DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];
+  DevBuf d_df_code;                    // the current call's code table (DF_TABLE_BYTES) + its histogram scratch
   HostBuf h_df_total, h_df_out[2];
   hipStream_t stream = nullptr;        // kernels of this lane
   hipStream_t copy_stream = nullptr;   // D2H of compressed pieces

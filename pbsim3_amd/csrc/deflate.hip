@@ -232,40 +232,220 @@ __device__ __forceinline__ SegTokens seg_tokens(const uint32_t (&seg)[kSegDw], i
   return t;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The code table of a stream.  The text of one deflate call (a batch's FASTQ, its MAF, its BAM records) is statistically
+// the same from its first chunk to its last, so the Huffman code is fitted ONCE per call -- to the token histogram of the
+// call's first kSampleChunks chunks, every symbol floored at one occurrence so that any later chunk stays encodable -- and
+// every member carries the same (precomputed) block header.  Per chunk that leaves tokenising, the CRC, one table lookup
+// per literal for the size, one for the bits: no histogram atomics, no sort, no serial tree construction.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSampleChunks = DF_SAMPLE_CHUNKS;
+constexpr int kHdrDw = DF_TABLE_HDR_DW;   // header image: member dwords 4.. (BSIZE field left zero, prefix, code lengths)
+
+struct DfTable {             // device memory, DF_TABLE_BYTES
+  uint32_t code[kSyms];      // reversed code | length << 16
+  uint32_t hdr_end_bits;     // bit position in the member image where the tokens start (144 + prefix + header symbols)
+  uint32_t pad[3];
+  uint32_t hdr[kHdrDw];      // image dwords 4 .. 4 + kHdrDw - 1
+};
+static_assert(sizeof(DfTable) <= DF_TABLE_BYTES, "DF_TABLE_BYTES too small");
+
+// the thread's 128 bytes of chunk `chunk` in registers + its token masks; also leaves the padded image in s_in
+__device__ __forceinline__ void load_chunk(const uint8_t *__restrict__ text, int64_t n_bytes, int64_t chunk, uint32_t *s_in,
+                                           uint32_t (&seg)[kSegDw], int *n_out, int *seg_n_out, uint32_t *prev_dw) {
+  const int tid = threadIdx.x;
+  const int64_t base = chunk * (int64_t)kChunk;
+  const int n = (int)((n_bytes - base) < (int64_t)kChunk ? (n_bytes - base) : (int64_t)kChunk);
+  const uint4 *src4 = reinterpret_cast<const uint4 *>(text + base);
+  for (int q = tid; q < kChunk / 16; q += kThreads) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (q * 16 < n) v = src4[q];   // the text buffers carry 16 bytes of slack past their end
+    const int d = q * 4;
+    uint32_t *dst = &s_in[d + (d >> 5)];
+    dst[0] = v.x;
+    dst[1] = v.y;
+    dst[2] = v.z;
+    dst[3] = v.w;
+  }
+  __syncthreads();
+  const int beg = tid * kSeg;
+  *n_out = n;
+  *seg_n_out = n - beg < 0 ? 0 : (n - beg < kSeg ? n - beg : kSeg);
+#pragma unroll
+  for (int j = 0; j < kSegDw; ++j) seg[j] = s_in[tid * (kSegDw + 1) + j];
+  *prev_dw = tid ? s_in[tid * (kSegDw + 1) - 2] : 0u;
+  __syncthreads();
+}
+
+// token histogram of the sample: hist[0..285] += literals / length symbols, hist[256] += 1 per chunk
+__global__ __launch_bounds__(kThreads) void k_deflate_hist(const uint8_t *__restrict__ text, int64_t n_bytes,
+                                                            uint32_t *__restrict__ hist) {
+  __shared__ uint32_t s_in[kInDw];
+  __shared__ uint32_t s_hist[3 * kSyms + 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 3 * kSyms + 64; i += kThreads) s_hist[i] = 0;
+  uint32_t seg[kSegDw], prev_dw;
+  int n, seg_n;
+  load_chunk(text, n_bytes, blockIdx.x, s_in, seg, &n, &seg_n, &prev_dw);
+  const SegTokens tk = seg_tokens(seg, seg_n, prev_dw, tid == 0);
+  const uint32_t copy = (uint32_t)(lane % 3) * kSyms, dummy = 3 * kSyms + lane;
+#pragma unroll
+  for (int j = 0; j < kSegDw; ++j) {
+    const uint32_t nl = m_nibble(tk.lit, j);
+    if (nl == 0) continue;
+    const uint32_t w = seg[j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(&s_hist[((nl >> k) & 1u) ? copy + ((w >> (8 * k)) & 255u) : dummy], 1u);
+  }
+  Mask128 st = tk.start;
+  while (st.lo | st.hi) {
+    const int pos = m_first(st);
+    st = m_clear(st, pos);
+    uint32_t sy, eb, ev;
+    length_symbol((uint32_t)m_run(tk.cover, pos), &sy, &eb, &ev);
+    atomicAdd(&s_hist[copy + sy], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < 286; i += kThreads) {
+    const uint32_t f = s_hist[i] + s_hist[kSyms + i] + s_hist[2 * kSyms + i] + (i == 256 ? 1u : 0u);
+    if (f) atomicAdd(&hist[i], f);
+  }
+}
+
+// one workgroup: histogram (+1 per symbol) -> length-limited Huffman code -> canonical codes -> the block header bits
+__global__ __launch_bounds__(kThreads) void k_deflate_build(const uint32_t *__restrict__ hist, DfTable *__restrict__ tbl) {
+  __shared__ uint32_t s_freq[kSyms], s_sfreq[kSyms], s_w[kSyms], s_code[kSyms];
+  __shared__ uint16_t s_sorted[kSyms], s_par[kSyms], s_leafpar[kSyms], s_dep[kSyms];
+  __shared__ uint8_t s_len[kSyms];
+  __shared__ uint32_t s_cnt[16], s_first[16];
+  __shared__ uint32_t s_img[4 + kHdrDw];
+  const int tid = threadIdx.x;
+  constexpr int m = 286;  // every symbol is used (floor of one occurrence)
+  for (int i = tid; i < kSyms; i += kThreads) {
+    s_freq[i] = i < m ? hist[i] + 1u : 0u;
+    s_code[i] = 0;
+    s_len[i] = 0;
+  }
+  for (int i = tid; i < 4 + kHdrDw; i += kThreads) s_img[i] = 0;
+  if (tid < 16) s_cnt[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < m; i += kThreads) {  // rank sort by (freq, symbol)
+    const uint32_t fi = s_freq[i];
+    uint32_t rank = 0;
+    for (int u = 0; u < m; ++u) {
+      const uint32_t g = s_freq[u];
+      rank += (g < fi) | ((g == fi) & (u < i));
+    }
+    s_sorted[rank] = (uint16_t)i;
+    s_sfreq[rank] = fi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // two-queue merge on the sorted leaves, depths limited to 15 (tests/deflate_model.py huffman_lengths)
+    int leaf = 0, root = 0;
+    for (int nxt = 0; nxt < m - 1; ++nxt) {
+      uint32_t tot = 0;
+      for (int k = 0; k < 2; ++k) {
+        const bool take_leaf = leaf < m && (root >= nxt || s_sfreq[leaf] <= s_w[root]);
+        if (take_leaf) {
+          tot += s_sfreq[leaf];
+          s_leafpar[leaf] = (uint16_t)nxt;
+          ++leaf;
+        } else {
+          tot += s_w[root];
+          s_par[root] = (uint16_t)nxt;
+          ++root;
+        }
+      }
+      s_w[nxt] = tot;
+    }
+    s_dep[m - 2] = 0;
+    for (int i = m - 3; i >= 0; --i) s_dep[i] = s_dep[s_par[i]] + 1;
+    for (int i = 0; i < m; ++i) {
+      int d = s_dep[s_leafpar[i]] + 1;
+      if (d > 15) d = 15;
+      s_cnt[d] += 1;
+    }
+    uint32_t total = 0;
+    for (int l = 1; l <= 15; ++l) total += s_cnt[l] << (15 - l);
+    while (total > (1u << 15)) {
+      s_cnt[15] -= 1;
+      for (int l = 14; l >= 1; --l)
+        if (s_cnt[l]) {
+          s_cnt[l] -= 1;
+          s_cnt[l + 1] += 2;
+          break;
+        }
+      total -= 1;
+    }
+    int i = 0;
+    for (int l = 15; l >= 1; --l)
+      for (uint32_t k = 0; k < s_cnt[l]; ++k) s_len[s_sorted[i++]] = (uint8_t)l;
+    uint32_t code = 0;
+    s_cnt[0] = 0;
+    for (int l = 1; l <= 15; ++l) {
+      code = (code + s_cnt[l - 1]) << 1;
+      s_first[l] = code;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += kThreads) {  // canonical: index among the symbols of the same length, in symbol order
+    const uint32_t l = s_len[i];
+    uint32_t idx = 0;
+    for (int u = 0; u < i; ++u) idx += s_len[u] == l;
+    s_code[i] = rev_bits(s_first[l] + idx, l) | (l << 16);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // the block header behind the 18 BGZF bytes: prefix (HLIT = 286, HDIST = 1, HCLEN = 19, the fixed code-length code),
+    // then the 286 + 1 code lengths; a length that repeats is run-length coded with symbol 16 (3..6 copies of the previous)
+    BitWriter bw;
+    bw.init(s_img, kHeadBits);
+    bw.put64(kPrefixLo | ((uint64_t)(m - 257) << 3), 64);
+    bw.put(kPrefixHi, kPrefixBits - 64);
+    uint32_t bits = kHeadBits + kPrefixBits;
+    int p = 0;
+    const int npos = m + 1;
+    while (p < npos) {
+      const uint32_t v = p < m ? s_len[p] : 1u;   // the single distance code has length 1
+      bw.put(cl_code(v), cl_len(v));
+      bits += cl_len(v);
+      ++p;
+      int r = 0;
+      while (p + r < npos && (p + r < m ? s_len[p + r] : 1u) == v) ++r;
+      while (r >= 3) {
+        const int t = r < 6 ? r : 6;
+        bw.put(cl_code(16) | ((uint32_t)(t - 3) << cl_len(16)), cl_len(16) + 2);
+        bits += cl_len(16) + 2;
+        r -= t;
+        p += t;
+      }
+    }
+    bw.flush();
+    tbl->hdr_end_bits = bits;
+  }
+  __syncthreads();
+  for (int i = tid; i < kSyms; i += kThreads) tbl->code[i] = s_code[i];
+  for (int i = tid; i < kHdrDw; i += kThreads) tbl->hdr[i] = s_img[4 + i];
+}
+
 __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__restrict__ text, int64_t n_bytes,
                                                               uint8_t *__restrict__ slots, int32_t *__restrict__ sizes,
                                                               const uint32_t *__restrict__ crc_table,
                                                               const uint32_t *__restrict__ pow128, uint32_t x8rem,
+                                                              const DfTable *__restrict__ tbl,
                                                               unsigned long long *__restrict__ prof) {
-  // The chunk's LDS image lives only until every thread holds its 128 bytes in registers; the same memory is then
-  // the (zeroed) output buffer the member is assembled in.  49 KB per workgroup = three workgroups per CU.
+  // The chunk's LDS image lives only until every thread holds its 128 bytes in registers; the same memory is then the CRC
+  // tables' home and finally the (zeroed) output buffer the member is assembled in.  35 KB per workgroup.
   __shared__ uint32_t s_in[kInDw];
   static_assert(kOutDw <= kInDw, "the output image must fit the input image");
   uint32_t *const s_out = s_in;
-  __shared__ uint32_t s_hist[3 * kSyms + 64];  // three copies, by lane % 3, against same-address serialisation; + one dummy bin per lane
-  __shared__ uint32_t s_code[kSyms];     // reversed code | length << 16
-  __shared__ uint8_t s_len[kSyms];       // code length by symbol
-  // Between the register load and the emission the image is free: the CRC tables and the Huffman construction's
-  // work arrays live in its first 2 680 dwords and are zeroed again before the first bit is written.  39.6 KB of
-  // LDS per workgroup = four workgroups per CU.
-  uint32_t *const s_crc = s_in;                 // [1024] slice-by-4 tables
-  uint32_t *const s_ufreq = s_in + 1024;        // [288] used symbols in symbol order: frequency
-  uint32_t *const s_sfreq = s_in + 1312;        // [288] frequencies in sorted order
-  uint32_t *const s_w = s_in + 1600;            // [288] internal node weights
-  uint16_t *const s_usym = reinterpret_cast<uint16_t *>(s_in + 1888);     // [288] used symbols in symbol order
-  uint16_t *const s_sorted = reinterpret_cast<uint16_t *>(s_in + 2032);   // [288] used symbols, ascending (freq, symbol)
-  uint16_t *const s_par = reinterpret_cast<uint16_t *>(s_in + 2176);      // [288] parent of internal node
-  uint16_t *const s_leafpar = reinterpret_cast<uint16_t *>(s_in + 2320);  // [288] parent of leaf
-  uint16_t *const s_dep = reinterpret_cast<uint16_t *>(s_in + 2464);      // [288] depth of internal node
-  uint8_t *const s_ulen = reinterpret_cast<uint8_t *>(s_in + 2608);       // [288] code length by used index
-  constexpr int kWorkDw = 2680;
-  __shared__ uint64_t s_nz[5];           // header positions with a non-zero code length (bits >= npos set)
-  __shared__ uint32_t s_cnt[16], s_first[16];
+  __shared__ uint32_t s_code[kSyms];     // reversed code | length << 16 (the stream's table; [287] = 0)
+  uint32_t *const s_crc = s_in;          // [1024] slice-by-4 tables, between the register load and the emission
   __shared__ uint32_t s_wave[kThreads / 64];
-  __shared__ uint32_t s_wcnt[8];
-  __shared__ uint32_t s_misc[4];         // 0 n_used, 1 any_match, 3 crc
+  __shared__ uint32_t s_misc[4];         // 3 crc
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long t_prev = prof ? wall_clock64() : 0;
   int phase = 0;
   auto mark = [&]() {   // PBSIM_DEFLATE_PROF: per-phase time of lane 0, summed over chunks (100 MHz ticks)
@@ -277,68 +457,21 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
     ++phase;
   };
   const int64_t chunk = blockIdx.x;
-  const int64_t base = chunk * (int64_t)kChunk;
-  const int n = (int)((n_bytes - base) < (int64_t)kChunk ? (n_bytes - base) : (int64_t)kChunk);
-  const uint8_t *src = text + base;
   uint8_t *slot = slots + chunk * (int64_t)DF_SLOT;
-
-  // ---- stage: chunk -> padded LDS image, tables, zeroed work areas
-  {
-    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
-    for (int q = tid; q < kChunk / 16; q += kThreads) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (q * 16 < n) v = src4[q];   // the text buffers carry 16 bytes of slack past their end
-      const int d = q * 4;
-      uint32_t *dst = &s_in[d + (d >> 5)];
-      dst[0] = v.x;
-      dst[1] = v.y;
-      dst[2] = v.z;
-      dst[3] = v.w;
-    }
-    for (int i = tid; i < kSyms; i += kThreads) {
-      s_code[i] = 0;
-      s_len[i] = 0;
-    }
-    for (int i = tid; i < 3 * kSyms + 64; i += kThreads) s_hist[i] = 0;
-    if (tid < 16) s_cnt[tid] = 0;
-    if (tid < 4) s_misc[tid] = 0;
-  }
-  __syncthreads();
-  mark();  // 0 stage
-
+  for (int i = tid; i < kSyms; i += kThreads) s_code[i] = i < 286 ? tbl->code[i] : 0u;
+  if (tid < 4) s_misc[tid] = 0;
+  uint32_t seg[kSegDw], prev_dw;  // the thread's segment, in registers from here on (every loop over it is fully unrolled)
+  int n, seg_n;
+  load_chunk(text, n_bytes, chunk, s_in, seg, &n, &seg_n, &prev_dw);
   const int beg = tid * kSeg;
-  const int seg_n = n - beg < 0 ? 0 : (n - beg < kSeg ? n - beg : kSeg);
-  uint32_t seg[kSegDw];  // the thread's segment, in registers from here on (every loop over it is fully unrolled)
-#pragma unroll
-  for (int j = 0; j < kSegDw; ++j) seg[j] = s_in[tid * (kSegDw + 1) + j];
-  const uint32_t prev_dw = tid ? s_in[tid * (kSegDw + 1) - 2] : 0u;
-  __syncthreads();
-  for (int i = tid; i < kInDw; i += kThreads) s_in[i] = (i < 1024) ? crc_table[i] : 0u;  // work area, then output buffer
+  mark();  // 0 stage
+  for (int i = tid; i < kInDw; i += kThreads) s_in[i] = (i < 1024) ? crc_table[i] : 0u;  // CRC tables, then the output buffer
   __syncthreads();
   const SegTokens tk = seg_tokens(seg, seg_n, prev_dw, tid == 0);
 
-  // ---- pass 1: histogram + CRC of the segment
+  // ---- CRC of the segment, and the size of its tokens
+  uint32_t tok_bits = 0;
   {
-    const uint32_t copy = (uint32_t)(lane % 3) * kSyms, dummy = 3 * kSyms + lane;   // non-literal positions count into the lane's dummy bin
-    uint32_t *hist = &s_hist[copy];
-#pragma unroll
-    for (int j = 0; j < kSegDw; ++j) {
-      const uint32_t nl = m_nibble(tk.lit, j);
-      if (nl == 0) continue;   // also true beyond the segment's end
-      const uint32_t w = seg[j];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        atomicAdd(&s_hist[((nl >> k) & 1u) ? copy + ((w >> (8 * k)) & 255u) : dummy], 1u);
-    }
-    Mask128 st = tk.start;
-    if (st.lo | st.hi) s_misc[1] = 1;
-    while (st.lo | st.hi) {
-      const int pos = m_first(st);
-      st = m_clear(st, pos);
-      uint32_t s, eb, ev;
-      length_symbol((uint32_t)m_run(tk.cover, pos), &s, &eb, &ev);
-      atomicAdd(&hist[s], 1u);
-    }
     uint32_t c = tid == 0 ? 0xFFFFFFFFu : 0u;
     const int full = seg_n >> 2;
 #pragma unroll
@@ -360,184 +493,8 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c ^= __shfl_xor(c, d, 64);
     if (lane == 0) atomicXor(&s_misc[3], c);
-    if (tid == 0) s_hist[256] = 1;  // end of block
   }
-  __syncthreads();
-  mark();  // 1 histogram + crc
-
-  // ---- used symbols in symbol order, then rank sort by (freq, symbol)
-  {
-    uint32_t f[2], pre[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int s = tid + h * kThreads;
-      f[h] = s < 286 ? s_hist[s] + s_hist[kSyms + s] + s_hist[2 * kSyms + s] : 0u;
-      const uint64_t b = __ballot(f[h] != 0);
-      pre[h] = (uint32_t)__popcll(b & ((1ull << lane) - 1));
-      if (lane == 0) s_wcnt[h * 4 + wave] = (uint32_t)__popcll(b);
-    }
-    __syncthreads();
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t x = s_wcnt[i];
-      if (i < wave) pre[0] += x;
-      if (i < 4 + wave) pre[1] += x;
-      m += x;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      if (f[h]) {
-        s_usym[pre[h]] = (uint16_t)(tid + h * kThreads);
-        s_ufreq[pre[h]] = f[h];
-      }
-    if (tid == 0) s_misc[0] = m;
-    __syncthreads();
-    for (uint32_t i = tid; i < m; i += kThreads) {
-      const uint32_t fi = s_ufreq[i];
-      uint32_t rank = 0;
-#pragma unroll 4
-      for (uint32_t u = 0; u < m; ++u) {
-        const uint32_t g = s_ufreq[u];
-        rank += (g < fi) | ((g == fi) & (u < i));
-      }
-      s_sorted[rank] = s_usym[i];
-      s_sfreq[rank] = fi;
-    }
-  }
-  __syncthreads();
-  mark();  // 2 sort
-
-  // ---- Huffman depths (one lane; n_used is a few dozen for this text), limited to 15 bits
-  const int m_used = (int)s_misc[0];
-  if (tid == 0) {
-    const int m = m_used;
-    if (m == 1) {
-      s_cnt[1] = 1;
-    } else {
-      int leaf = 0, root = 0;
-      for (int nxt = 0; nxt < m - 1; ++nxt) {
-        uint32_t tot = 0;
-        for (int k = 0; k < 2; ++k) {
-          const bool take_leaf = leaf < m && (root >= nxt || s_sfreq[leaf] <= s_w[root]);
-          if (take_leaf) {
-            tot += s_sfreq[leaf];
-            s_leafpar[leaf] = (uint16_t)nxt;
-            ++leaf;
-          } else {
-            tot += s_w[root];
-            s_par[root] = (uint16_t)nxt;
-            ++root;
-          }
-        }
-        s_w[nxt] = tot;
-      }
-      s_dep[m - 2] = 0;
-      for (int i = m - 3; i >= 0; --i) s_dep[i] = s_dep[s_par[i]] + 1;
-      for (int i = 0; i < m; ++i) {
-        int d = s_dep[s_leafpar[i]] + 1;
-        if (d > 15) d = 15;
-        s_cnt[d] += 1;
-      }
-      uint32_t total = 0;
-      for (int l = 1; l <= 15; ++l) total += s_cnt[l] << (15 - l);
-      while (total > (1u << 15)) {
-        s_cnt[15] -= 1;
-        for (int l = 14; l >= 1; --l)
-          if (s_cnt[l]) {
-            s_cnt[l] -= 1;
-            s_cnt[l + 1] += 2;
-            break;
-          }
-        total -= 1;
-      }
-    }
-    int i = 0;
-    for (int l = 15; l >= 1; --l)
-      for (uint32_t k = 0; k < s_cnt[l]; ++k) s_len[s_sorted[i++]] = (uint8_t)l;
-    uint32_t code = 0;
-    s_cnt[0] = 0;
-    for (int l = 1; l <= 15; ++l) {
-      code = (code + s_cnt[l - 1]) << 1;
-      s_first[l] = code;
-    }
-  }
-  __syncthreads();
-  mark();  // 3 huffman build
-
-  // ---- canonical codes: index among the used symbols of the same length, in symbol order
-  for (int i = tid; i < m_used; i += kThreads) s_ulen[i] = s_len[s_usym[i]];
-  __syncthreads();
-  for (int i = tid; i < m_used; i += kThreads) {
-    const uint32_t l = s_ulen[i];
-    uint32_t idx = 0;
-#pragma unroll 4
-    for (int u = 0; u < i; ++u) idx += s_ulen[u] == l;
-    s_code[s_usym[i]] = rev_bits(s_first[l] + idx, l) | (l << 16);
-  }
-  const uint32_t any_match = s_misc[1];
-  const int hlit = (int)s_usym[m_used - 1] + 1;   // >= 257: symbol 256 is always used
-  const int npos = hlit + 1;                       // + the one distance code length
-  {  // non-zero mask of the header's code length sequence
-    const int p0 = tid;
-    const uint32_t v0 = p0 < hlit ? s_len[p0] : (p0 == hlit ? any_match : 1u);
-    const uint64_t b0 = __ballot(v0 != 0);
-    if (lane == 0) s_nz[wave] = b0;
-    if (wave == 0) {
-      const int p1 = 256 + lane;
-      const uint32_t v1 = p1 < hlit ? s_len[p1] : (p1 == hlit ? any_match : 1u);
-      const uint64_t b1 = __ballot(v1 != 0);
-      if (lane == 0) s_nz[4] = b1;
-    }
-  }
-  __syncthreads();
-  mark();  // 4 canonical codes
-
-  // ---- sizes: header symbols (two positions per thread) and the thread's tokens
-  uint64_t hbits[2] = {0, 0};
-  uint32_t hn[2] = {0, 0};
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int p = 2 * tid + h;
-    if (p >= npos) continue;
-    const uint32_t v = p < hlit ? s_len[p] : any_match;
-    if (v) {
-      hbits[h] = cl_code(v);
-      hn[h] = cl_len(v);
-    } else if (p == 0 || ((s_nz[(p - 1) >> 6] >> ((p - 1) & 63)) & 1ull)) {  // first zero of a run
-      // run length = distance to the next non-zero position (bits >= npos are set)
-      int wi = p >> 6;
-      uint64_t bits = s_nz[wi] >> (p & 63);   // bit 0 (position p) is clear
-      int r;
-      if (bits) {
-        r = __builtin_ctzll(bits);
-      } else {
-        r = 64 - (p & 63);
-        for (++wi; s_nz[wi] == 0; ++wi) r += 64;
-        r += __builtin_ctzll(s_nz[wi]);
-      }
-      uint64_t acc = 0;
-      uint32_t nb = 0;
-      while (r >= 11) {
-        const int t = r < 138 ? r : 138;
-        acc |= (uint64_t)(cl_code(18) | ((uint32_t)(t - 11) << 3)) << nb;
-        nb += 10;
-        r -= t;
-      }
-      if (r >= 3) {
-        acc |= (uint64_t)(cl_code(17) | ((uint32_t)(r - 3) << 3)) << nb;
-        nb += 6;
-        r = 0;
-      }
-      for (; r > 0; --r) {
-        acc |= (uint64_t)cl_code(0) << nb;
-        nb += 3;
-      }
-      hbits[h] = acc;
-      hn[h] = nb;
-    }
-  }
-  uint32_t tok_bits = 0;
+  mark();  // 1 crc
   {
 #pragma unroll
     for (int j = 0; j < kSegDw; ++j) {
@@ -545,59 +502,47 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       if (nl == 0) continue;
       const uint32_t w = seg[j];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)   // s_code[287] is never assigned: zero length for non-literal positions
+      for (int k = 0; k < 4; ++k)   // s_code[287] is zero: no length for non-literal positions
         tok_bits += s_code[((nl >> k) & 1u) ? (w >> (8 * k)) & 255u : 287u] >> 16;
     }
     Mask128 st = tk.start;
     while (st.lo | st.hi) {
       const int pos = m_first(st);
       st = m_clear(st, pos);
-      uint32_t s, eb, ev;
-      length_symbol((uint32_t)m_run(tk.cover, pos), &s, &eb, &ev);
-      tok_bits += (s_code[s] >> 16) + eb + 1;
+      uint32_t sy, eb, ev;
+      length_symbol((uint32_t)m_run(tk.cover, pos), &sy, &eb, &ev);
+      tok_bits += (s_code[sy] >> 16) + eb + 1;
     }
   }
-  uint32_t hdr_total, tok_total;
-  const uint32_t hdr_off = block_scan_excl(hn[0] + hn[1], s_wave, &hdr_total);
+  uint32_t tok_total;
   const uint32_t tok_off = block_scan_excl(tok_bits, s_wave, &tok_total);
+  const uint32_t hdr_end = tbl->hdr_end_bits;
   const uint32_t eob_len = s_code[256] >> 16;
-  const uint32_t payload_bits = kPrefixBits + hdr_total + tok_total + eob_len;
+  const uint32_t payload_bits = hdr_end - kHeadBits + tok_total + eob_len;
   const uint32_t payload_bytes = (payload_bits + 7) >> 3;
   const bool huff = (18 + payload_bytes + 8 <= (uint32_t)kOutBytes) && (payload_bytes < (uint32_t)n + 5);
   const uint32_t crc = s_misc[3] ^ 0xFFFFFFFFu;
-  mark();  // 5 sizes + scans
+  mark();  // 2 sizes + scan
 
   if (huff) {
     const uint32_t member = 18 + payload_bytes + 8;
-    __syncthreads();  // everybody is done with the work arrays
-    for (int i = tid; i < kWorkDw; i += kThreads) s_in[i] = 0;
+    __syncthreads();  // everybody is done with the CRC tables
+    for (int i = tid; i < 1024; i += kThreads) s_in[i] = 0;
     __syncthreads();
+    // BGZF header: 1f 8b 08 04 | mtime 0 | xfl 0 | os ff | xlen 6 | 'B' 'C' 2 0 | bsize-1, then the stream's block header
+    if (tid < kHdrDw) s_out[4 + tid] = tbl->hdr[tid];
     if (tid == 0) {
-      // BGZF header: 1f 8b 08 04 | mtime 0 | xfl 0 | os ff | xlen 6 | 'B' 'C' 2 0 | bsize-1
       s_out[0] = 0x04088b1fu;
       s_out[1] = 0;
       s_out[2] = 0x0006ff00u;
       s_out[3] = 0x00024342u;
-      BitWriter bw;
-      bw.init(s_out, 16 * 8);
-      bw.put(member - 1, 16);
-      bw.put64(kPrefixLo | ((uint64_t)(hlit - 257) << 3), 64);
-      bw.put(kPrefixHi, kPrefixBits - 64);
-      bw.flush();
     }
     __syncthreads();  // the plain stores above precede everybody's ds_or
-    mark();  // 6 prefix
+    if (tid == 0) atomicOr(&s_out[4], member - 1);
+    mark();  // 3 header
     {
       BitWriter bw;
-      bw.init(s_out, kHeadBits + kPrefixBits + hdr_off);
-      bw.put64(hbits[0], hn[0]);
-      bw.put64(hbits[1], hn[1]);
-      bw.flush();
-    }
-    mark();  // 7 header symbols
-    {
-      BitWriter bw;
-      bw.init(s_out, kHeadBits + kPrefixBits + hdr_total + tok_off);
+      bw.init(s_out, hdr_end + tok_off);
       // (the rare match path stays a rolled loop: the unrolled literal path is what has to fit the instruction cache)
 #pragma unroll
       for (int j = 0; j < kSegDw; ++j) {
@@ -632,10 +577,10 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       }
       bw.flush();
     }
-    mark();  // 8 tokens (lane 0's own)
+    mark();  // 4 tokens (lane 0's own)
     if (tid == 0) {
       BitWriter bw;
-      bw.init(s_out, kHeadBits + kPrefixBits + hdr_total + tok_total);
+      bw.init(s_out, hdr_end + tok_total);
       bw.put(s_code[256] & 0xFFFFu, eob_len);
       bw.flush();
       bw.init(s_out, (18 + payload_bytes) * 8);
@@ -644,11 +589,11 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       bw.flush();
     }
     __syncthreads();
-    mark();  // 9 trailer + barrier
+    mark();  // 5 trailer + barrier
     uint32_t *dst = reinterpret_cast<uint32_t *>(slot);
     for (uint32_t i = tid; i < (member + 3) / 4; i += kThreads) dst[i] = s_out[i];
     if (tid == 0) sizes[chunk] = (int32_t)member;
-    mark();  // 10 store
+    mark();  // 6 store
   } else {
     // stored block (RFC 1951 3.2.4): incompressible input, rare for this text
     const uint32_t member = 18 + 5 + (uint32_t)n + 8;
@@ -770,14 +715,24 @@ void deflate_host_tables(uint32_t *crc_table, uint32_t *pow128) {
   }
 }
 
+void launch_deflate_table(const uint8_t *text, int64_t n_bytes, uint32_t *hist, void *table, hipStream_t s) {
+  if (n_bytes <= 0) return;
+  const int64_t nch = (n_bytes + DF_CHUNK - 1) / DF_CHUNK;
+  const int64_t ns = nch < kSampleChunks ? nch : kSampleChunks;
+  const int64_t sample_bytes = ns * (int64_t)DF_CHUNK < n_bytes ? ns * (int64_t)DF_CHUNK : n_bytes;
+  (void)hipMemsetAsync(hist, 0, 288 * sizeof(uint32_t), s);
+  hipLaunchKernelGGL(k_deflate_hist, dim3((unsigned)ns), dim3(kThreads), 0, s, text, sample_bytes, hist);
+  hipLaunchKernelGGL(k_deflate_build, dim3(1), dim3(kThreads), 0, s, (const uint32_t *)hist, reinterpret_cast<DfTable *>(table));
+}
+
 void launch_deflate(const uint8_t *text, int64_t n_bytes, uint8_t *slots, int32_t *sizes, int64_t *offsets,
-                    uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, hipStream_t s,
+                    uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, const void *table, hipStream_t s,
                     unsigned long long *d_prof) {
   if (n_bytes <= 0) return;
   const int64_t nch = (n_bytes + DF_CHUNK - 1) / DF_CHUNK;
   const uint32_t x8rem = host_xpow8((uint64_t)(n_bytes % DF_CHUNK) & 127u);
   hipLaunchKernelGGL(k_deflate_chunks, dim3((unsigned)nch), dim3(kThreads), 0, s, text, n_bytes, slots, sizes,
-                     d_crc_table, d_pow128, x8rem, d_prof);
+                     d_crc_table, d_pow128, x8rem, reinterpret_cast<const DfTable *>(table), d_prof);
   hipLaunchKernelGGL(k_deflate_offsets, dim3(1), dim3(256), 0, s, (const int32_t *)sizes, (int)nch, offsets);
   hipLaunchKernelGGL(k_deflate_compact, dim3((unsigned)nch), dim3(256), 0, s, (const uint8_t *)slots,
                      (const int64_t *)offsets, dense);

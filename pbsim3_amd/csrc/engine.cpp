@@ -953,8 +953,11 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   HIP_OK(sl.d_df_sizes.ensure((size_t)max_ch * 4));
   HIP_OK(sl.d_df_offsets.ensure((size_t)(max_ch + 1) * 8));
   HIP_OK(sl.h_df_total.ensure(16));
+  HIP_OK(sl.d_df_code.ensure(DF_TABLE_BYTES + 288 * 4));
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
   if (!sl.stream) HIP_OK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+  // the call's code table: fitted once to the head of the text (deflate.hip), shared by all its members
+  launch_deflate_table(d_text, n, reinterpret_cast<uint32_t *>(sl.d_df_code.as<uint8_t>() + DF_TABLE_BYTES), sl.d_df_code.p, sl.stream);
   unsigned long long *d_prof = nullptr;
   if (getenv("PBSIM_DEFLATE_PROF")) {
     HIP_OK(c->d_df_prof.ensure(128));
@@ -980,7 +983,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     if (!place) HIP_OK(sl.h_df_out[k].ensure((size_t)max_ch * DF_SLOT));
     if (used[k]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[k], 0));  // piece k-2 has left this dense buffer
     launch_deflate(d_text + off, len, sl.d_df_slots.as<uint8_t>(), sl.d_df_sizes.as<int32_t>(),
-                   sl.d_df_offsets.as<int64_t>(), sl.d_df_dense[k].as<uint8_t>(), tab, tab + 1024, sl.stream, d_prof);
+                   sl.d_df_offsets.as<int64_t>(), sl.d_df_dense[k].as<uint8_t>(), tab, tab + 1024, sl.d_df_code.p, sl.stream, d_prof);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(sl.h_df_total.p, sl.d_df_offsets.as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
     HIP_OK(hipEventRecord(sl.ev_df[k], sl.stream));
@@ -1004,10 +1007,9 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     unsigned long long t[16];
     HIP_OK(hipMemcpy(t, d_prof, 128, hipMemcpyDeviceToHost));
     const double nch = (double)((n + DF_CHUNK - 1) / DF_CHUNK);
-    static const char *names[11] = {"stage", "hist+crc", "sort", "build", "codes", "sizes", "prefix", "hdrsyms", "tokens",
-                                    "trailer", "store"};
+    static const char *names[7] = {"stage", "crc", "sizes+scan", "header", "tokens", "trailer", "store"};
     fprintf(stderr, "[deflate prof] %.0f chunks; us per chunk (lane 0):", nch);
-    for (int i = 0; i < 11; ++i) fprintf(stderr, " %s %.1f", names[i], t[i] / nch / 100);
+    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f", names[i], t[i] / nch / 100);
     fprintf(stderr, "\n");
   }
   if (pending && !consume(pending_ptr, pending)) return PBSIM_FAILED;

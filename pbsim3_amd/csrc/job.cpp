@@ -370,6 +370,7 @@ struct Job {
     int64_t *sizes = d->sizes;
     const int64_t read_at = R->read_off, maf_at = R->maf_off;  // one rank: the offsets simply run up (streamed in stage 1)
     worker.post([this, sl, R, prom, sizes, read_at, maf_at]() {
+      const double w0 = now_us();
       int ok = PBSIM_SUCCEEDED;
       if (!wants_text()) {
         sizes[0] = sizes[1] = 0;
@@ -383,6 +384,9 @@ struct Job {
         ok = arena_fill(*sl, &sizes[0], &sizes[1]);
       }
       if (!ok) worker_fail();
+      if (trace)
+        fprintf(stderr, "[pbsim job r%d] t=%.1f ms   worker: bytes of rec %lld on their way for %.1f ms (%lld + %lld)\n", rank,
+                (w0 - t_start) / 1e3, (long long)R->ref.unit, (now_us() - w0) / 1e3, (long long)sizes[0], (long long)sizes[1]);
       prom->set_value(ok);
     });
   }
@@ -415,14 +419,18 @@ struct Job {
       Rec *Rp = &R;
       const int slot = d->slot;
       const bool flush = deflated() && W > 1, plain = wants_text() && !deflated();
-      worker.post([this, sl, Rp, slot, flush, plain, read_at, maf_at]() {
-        int ok = PBSIM_SUCCEEDED;
-        if (flush) ok = arena_flush(*sl, Rp->ref.unit, read_at, maf_at);
-        else if (plain) ok = sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
-        if (ok) ok = account_of(c, *sl, &Rp->st);
-        if (!ok) worker_fail();
-        delivering[slot] = false;
-      });
+      // The per-task statistics are accounted HERE, on the main loop (it waits for the link most of the time), not on the
+      // worker, whose time is the link's: rounds are completed in the order of the reads, so accuracy_total keeps its order.
+      if (!account_of(c, *sl, &R.st)) return PBSIM_FAILED;
+      if (flush || plain) {
+        worker.post([this, sl, Rp, slot, flush, read_at, maf_at]() {
+          const int ok = flush ? arena_flush(*sl, Rp->ref.unit, read_at, maf_at) : sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
+          if (!ok) worker_fail();
+          delivering[slot] = false;
+        });
+      } else {
+        delivering[slot] = false;  // streamed in stage 1 (or nothing to deliver): the slot is free
+      }
     }
     if (trace)
       fprintf(stderr, "[pbsim job r%d] t=%.1f ms rec %d delivery: waited %.1f ms for the bytes (%lld + %lld)\n", rank,

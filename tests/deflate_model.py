@@ -8,10 +8,12 @@ byte for byte, not only through a decompress round trip.
 
     tokens   : each THREAD owns SEG consecutive bytes; a byte equal to its predecessor (distance-1 match candidate)
                extends a run, runs of >= 3 become one match (length <= SEG), shorter runs stay literals
-    lit/len  : Huffman over the chunk's histogram (two-queue merge on the (freq, symbol)-sorted leaves), depths folded
-               to <= 15 by moving leaves down from the shortest deeper level, lengths re-dealt in sorted order
-    header   : HLIT = last used symbol + 1, HDIST = 1, HCLEN = 19; the code-length alphabet uses a FIXED complete code
-               (lengths CL_LEN below); zeros are run-length coded with 17/18 only, 16 is never produced
+    lit/len  : ONE Huffman code per call (a batch's FASTQ, MAF or BAM text is statistically uniform), fitted to the token
+               histogram of the call's first SAMPLE_CHUNKS chunks with every symbol floored at one occurrence (two-queue
+               merge on the (freq, symbol)-sorted leaves, depths folded to <= 15 by moving leaves down from the shortest
+               deeper level, lengths re-dealt in sorted order)
+    header   : the same in every member: HLIT = 286, HDIST = 1, HCLEN = 19; the code-length alphabet uses a FIXED complete
+               code (lengths CL_LEN below); repeated lengths are run-length coded with 16
     fallback : a stored block when the Huffman block would not be smaller
 """
 import struct
@@ -145,58 +147,65 @@ class Bits:
         return self.acc.to_bytes((self.n + 7) // 8, "little")
 
 
+SAMPLE_CHUNKS = 64          # chunks of a call's text the code table is fitted to (deflate.hip kSampleChunks)
+
+
 def header_symbols(seq):
-    """code-length symbols (sym, extra_bits, extra_value) for the lengths sequence; zeros use 17/18 only"""
+    """code-length symbols (sym, extra_bits, extra_value) for the lengths sequence of a stream table: no zeros occur
+    (every symbol is floored at one occurrence); a length that repeats is coded with 16 (3..6 copies of the previous)"""
     out = []
-    i = 0
-    while i < len(seq):
-        if seq[i]:
-            out.append((seq[i], 0, 0))
-            i += 1
-            continue
-        j = i
-        while j < len(seq) and seq[j] == 0:
-            j += 1
-        r = j - i
-        while r >= 11:
-            t = min(r, 138)
-            out.append((18, 7, t - 11))
+    p = 0
+    while p < len(seq):
+        v = seq[p]
+        out.append((v, 0, 0))
+        p += 1
+        r = 0
+        while p + r < len(seq) and seq[p + r] == v:
+            r += 1
+        while r >= 3:
+            t = min(r, 6)
+            out.append((16, 2, t - 3))
             r -= t
-        if r >= 3:
-            out.append((17, 3, r - 3))
-            r = 0
-        out.extend([(0, 0, 0)] * r)
-        i = j
+            p += t
     return out
 
 
-def deflate_block(data):
-    toks = tokenize(data)
-    freq = [0] * 286
-    any_match = False
-    for kind, v in toks:
-        if kind == "lit":
-            freq[v] += 1
-        else:
-            freq[length_symbol(v)[0]] += 1
-            any_match = True
-    freq[256] = 1
+def chunk_tokens(data):
+    """tokens of one chunk (runs never cross a chunk or a thread segment)"""
+    return tokenize(data)
+
+
+def build_table(sample):
+    """(codes, lens, header bit string as (value, nbits)) fitted to the first SAMPLE_CHUNKS chunks of a call's text"""
+    freq = [1] * 286                       # the floor: any later chunk stays encodable
+    for i in range(0, len(sample), CHUNK):
+        for kind, v in chunk_tokens(sample[i:i + CHUNK]):
+            if kind == "lit":
+                freq[v] += 1
+            else:
+                freq[length_symbol(v)[0]] += 1
+        freq[256] += 1                     # end of block, once per chunk
     lens = huffman_lengths(freq)
     codes = canonical(lens)
-    hlit = max(s for s in range(286) if lens[s]) + 1
-    hlit = max(hlit, 257)
     b = Bits()
     b.put(1, 1)
     b.put(2, 2)
-    b.put(hlit - 257, 5)
+    b.put(286 - 257, 5)
     b.put(0, 5)
     b.put(15, 4)
     for s in CL_ORDER:
         b.put(CL_LEN[s], 3)
-    for sym, eb, ev in header_symbols(lens[:hlit] + [1 if any_match else 0]):
+    for sym, eb, ev in header_symbols(lens + [1]):   # + the single distance code (distance 1), length 1
         b.put(CL_CODE[sym], CL_LEN[sym])
         b.put(ev, eb)
-    for kind, v in toks:
+    return codes, lens, (b.acc, b.n)
+
+
+def deflate_block(data, table):
+    codes, lens, (hacc, hn) = table
+    b = Bits()
+    b.put(hacc, hn)
+    for kind, v in chunk_tokens(data):
         if kind == "lit":
             b.put(codes[v], lens[v])
         else:
@@ -212,12 +221,16 @@ def deflate_block(data):
     return out
 
 
-def member(data):
-    body = deflate_block(data)
+def member(data, table):
+    body = deflate_block(data, table)
     total = 18 + len(body) + 8
     return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", total - 1) + body +
             struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
 
 
 def compress(data):
-    return b"".join(member(data[i:i + CHUNK]) for i in range(0, len(data), CHUNK))
+    """one deflate call: the table is fitted to the head of the text, every member uses it"""
+    if not data:
+        return b""
+    table = build_table(data[:SAMPLE_CHUNKS * CHUNK])
+    return b"".join(member(data[i:i + CHUNK], table) for i in range(0, len(data), CHUNK))

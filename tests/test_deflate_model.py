@@ -1,6 +1,6 @@
 """CPU: the executable specification of the GPU DEFLATE encoder (tests/deflate_model.py) produces streams zlib
 accepts -- gzip members with correct CRC32/ISIZE, BGZF framing, every code path of the format (stored fallback,
-distance-1 matches, the depth limiter, the fixed code-length code with 17/18 zero runs)."""
+distance-1 matches, the depth limiter, the per-call code table whose repeated lengths are coded with 16)."""
 import gzip
 import os
 import random
@@ -66,5 +66,13 @@ def test_fixed_code_length_code_is_complete():
 
 def test_stored_fallback_for_incompressible_input():
     data = os.urandom(5000)
-    z = D.member(data)
+    z = D.member(data, D.build_table(data))
     assert z[18] == 0x01 and len(z) == 18 + 5 + len(data) + 8
+
+
+def test_symbols_unseen_in_the_sample_stay_encodable():
+    """the code is fitted to the call's first SAMPLE_CHUNKS chunks; every symbol keeps a code (floor of one occurrence),
+    so text that changes character later (here: random bytes behind 2.1 MB of DNA) still round-trips"""
+    data = dna(D.SAMPLE_CHUNKS * D.CHUNK + 5000, 3) + os.urandom(70000) + b"!" * 5000
+    z = D.compress(data)
+    assert gzip.decompress(z) == data
