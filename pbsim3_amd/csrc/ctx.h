@@ -46,7 +46,9 @@ struct DevBuf {
   hipError_t ensure(size_t n, bool exact = false) {
     if (n <= bytes) return hipSuccess;
     release();
-    size_t want = exact ? n : n + n / 8 + 256;
+    // (hipFree waits for the whole device: a buffer that creeps up in small steps -- the text of one truncated tail read
+    // after the other -- would stall every kernel in flight each time, so small buffers start at a size they never outgrow)
+    size_t want = exact ? n : std::max<size_t>(n + n / 8 + 256, 64u << 10);
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
       p = nullptr;
@@ -72,7 +74,7 @@ struct HostBuf {  // pinned staging
     if (p) (void)hipHostFree(p);
     p = nullptr;
     bytes = 0;
-    size_t want = n + n / 8 + 4096;
+    size_t want = std::max<size_t>(n + n / 8 + 4096, 1u << 20);
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e != hipSuccess) {
       p = nullptr;
@@ -180,7 +182,7 @@ struct Slot {
   DevBuf d_out_len, d_maf_len, d_nsub, d_nins, d_ndel, d_qsum;
   DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len, d_row_dst;
   DevBuf d_scratch, d_read_text, d_maf_text;
-  HostBuf h_read_text, h_maf_text, h_stats;
+  HostBuf h_read_text, h_maf_text, h_stats, h_flags;
   DfLane df[2];                        // deflate staging: [0] read text (or any single stream), [1] MAF text beside it
   hipStream_t walk_stream = nullptr;   // low priority: the walk kernel only
   hipEvent_t ev_prep = nullptr;        // header + sort done (walk_stream waits for it)

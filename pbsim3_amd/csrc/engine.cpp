@@ -96,9 +96,15 @@ int ensure_class_tables(pbsim_ctx *c) {
   return PBSIM_SUCCEEDED;
 }
 
+// Through PINNED staging: a device-to-host copy into pageable memory (a stack variable) is not asynchronous -- the runtime
+// stages it and waits in ways that depend on everything else the device is doing; with three walks in flight such a
+// "small" read took tens of milliseconds.
 int read_flags(pbsim_ctx *c, DeviceFlags *f) {
-  HIP_OK(hipMemcpyAsync(f, c->s().d_flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost, c->s().stream));
-  HIP_OK(hipStreamSynchronize(c->s().stream));
+  Slot &sl = c->s();
+  HIP_OK(sl.h_flags.ensure(sizeof(DeviceFlags) + 64));
+  HIP_OK(hipMemcpyAsync(sl.h_flags.p, sl.d_flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost, sl.stream));
+  HIP_OK(hipStreamSynchronize(sl.stream));
+  memcpy(f, sl.h_flags.p, sizeof(DeviceFlags));
   return PBSIM_SUCCEEDED;
 }
 
@@ -622,7 +628,9 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   w.ndel = c->s().d_ndel.as<int32_t>();
   w.qsum = c->s().d_qsum.as<double>();
   w.flags = flags;
-  hipStream_t ws = c->s().walk_stream;
+  // the walk of a batch goes to the slot's LOW priority stream; a single truncated tail read is the opposite case -- one
+  // workgroup whose latency a record's completion waits for -- and must not queue behind the pending workgroups of the batches
+  hipStream_t ws = (n_reads == 1 && truncate_remaining >= 0) ? c->s().stream : c->s().walk_stream;
   HIP_OK(hipEventRecord(c->s().ev_prep, c->s().stream));
   HIP_OK(hipStreamWaitEvent(ws, c->s().ev_prep, 0));
   HIP_OK(hipEventRecord(c->s().ev1, ws));
@@ -756,8 +764,10 @@ extern "C++" int pbsim::finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbs
   const int64_t n_final = f.n_final;
   int64_t cum_final = c->s().b_pass0;
   if (n_final < c->s().b_n) {
-    HIP_OK(hipMemcpyAsync(&cum_final, c->s().d_cum.as<int64_t>() + n_final, 8, hipMemcpyDeviceToHost, c->s().stream));
+    int64_t *pin = reinterpret_cast<int64_t *>((char *)c->s().h_flags.p + sizeof(DeviceFlags));  // pinned (read_flags)
+    HIP_OK(hipMemcpyAsync(pin, c->s().d_cum.as<int64_t>() + n_final, 8, hipMemcpyDeviceToHost, c->s().stream));
     HIP_OK(hipStreamSynchronize(c->s().stream));
+    cum_final = *pin;
   }
   pbsim_batch_info bi;
   memset(&bi, 0, sizeof bi);
@@ -806,8 +816,9 @@ extern "C++" int pbsim::finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
     bi.bases = f.sums[3];
     bi.ref_bases = f.sums[4];
     bi.maf_columns = f.sums[5];
-    HIP_OK(c->s().d_read_text.ensure((size_t)bi.read_text_bytes + 16));
-    HIP_OK(c->s().d_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
+    // (8 MiB at least: the text of any single read fits, so the slot of the truncated tail reads never reallocates)
+    HIP_OK(c->s().d_read_text.ensure(std::max<size_t>((size_t)bi.read_text_bytes + 16, 8u << 20)));
+    HIP_OK(c->s().d_maf_text.ensure(std::max<size_t>((size_t)bi.maf_text_bytes + 16, 8u << 20)));
     t.read_text = c->s().d_read_text.as<char>();
     t.maf_text = c->s().d_maf_text.as<char>();
     launch_text_emit(t, c->s().b_slots_max, flags, c->s().stream);

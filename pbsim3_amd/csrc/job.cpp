@@ -12,7 +12,7 @@
 //   cut     = the first block the quota rule stops in (pbsim.cpp:3792-3800); later blocks / rounds of the record are void
 //   tail    = the truncated reads behind the cut, one at a time (each depends on the one before), on the cut's rank only,
 //             on a slot of their own, polled between rounds -- no other rank waits for them
-//   merge   = per record, at a fixed point of the round sequence (before record n+2 begins, or at the end): statistics of
+//   merge   = per record, at a fixed point of the round sequence (before record n+3 begins, or at the end): statistics of
 //             all ranks summed (C2), accuracy_total folded in read order; then on_record_done everywhere
 //
 // Record n+1's rounds begin as soon as record n has enough reads in flight, so the last text emission and the tail of
@@ -472,8 +472,14 @@ struct Job {
       if (!block && hipEventQuery(c->s().ev3) != hipSuccess) return PBSIM_SUCCEEDED;
       const double t0 = now_us();
       if (!pbsim_batch_walk_end(c, nullptr)) return PBSIM_FAILED;
+      const double ta = now_us();
       pbsim_batch_info bi;
-      if (!finalize_cut(c, R.len_total, &bi) || !finalize_text(c, &bi)) return PBSIM_FAILED;
+      if (!finalize_cut(c, R.len_total, &bi)) return PBSIM_FAILED;
+      const double tb = now_us();
+      if (!finalize_text(c, &bi)) return PBSIM_FAILED;
+      if (trace)
+        fprintf(stderr, "[pbsim job r%d]   tail step: walk_end %.2f cut %.2f text %.2f ms (len %lld)\n", rank, (ta - t0) / 1e3,
+                (tb - ta) / 1e3, (now_us() - tb) / 1e3, (long long)bi.bases);
       const int slot = R.tail_slot;
       Slot *sl = &c->slots[slot];
       Rec *Rp = &R;
@@ -691,9 +697,9 @@ struct Job {
           }
           if (cand < 0) break;
         }
-        if (cand >= merged + 2) {
-          // at most two records' statistics are open at a time: merge the oldest first (a collective at a point of the round
-          // sequence that every rank reaches alike)
+        if (cand >= merged + 3) {
+          // at most three records' statistics are open at a time: merge the oldest first (a collective at a point of the
+          // round sequence that every rank reaches alike; by then its tail reads have long finished beside the next rounds)
           if (!recs[(size_t)merged].bulk_done) break;  // its rounds are still in flight: pop first
           if (!finish_record(merged)) return PBSIM_FAILED;
           merged++;
@@ -895,14 +901,17 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
       // bytes are delivered: bound the batch so that all of them fit 70 % of what the GPU has left
       const double text_per_base = P > 1 ? 8.5 : 4.3;                  // FASTQ 2.0 | SAM text ~6.1 (BAM records less), MAF 2.13
       const double scratch_per_base = (double)regions * 2.0 * 1.12 * 1.08 + 0.1;
-      const double fit = 0.70 * (double)(free_b + held + held_text) / ((double)(J.depth + 2) * (text_per_base + scratch_per_base));
+      // (rounds in flight + one whose delivery is pending + one with the worker; nothing is held back when the text stays put)
+      const bool delivering_text = J.sink && (J.sink->on_read_text || J.sink->on_maf_text);
+      const double slots_used = (double)J.depth + (delivering_text ? 2.0 : 1.0);
+      const double fit = 0.70 * (double)(free_b + held + held_text) / (slots_used * (text_per_base + scratch_per_base));
       target = std::min(target, std::max(fit, 1.0e8));
     }
     // what batch_capacity_for() charges a read: `regions` rows of 2 * length + pad columns, 12 % slack for the per-wave rounding
     const double mean_len = std::max(1.0, c->hdr.mean_len);
     // (a read yields ~0.97 of its length in bases, and a round overshoots its share of the quota by 0.5 %: 8 % headroom)
     const double want = (target / P / mean_len) * P * ((double)regions * (2.0 * mean_len + kScratchPad) * 1.12 + 64.0) * 1.08 + (64 << 20);
-    const double share = std::min(48.0 * (1LL << 30), 0.10 * (double)(free_b + held));
+    const double share = std::min(48.0 * (1LL << 30), 0.14 * (double)(free_b + held));
     const int64_t auto_b = (int64_t)std::max(256.0 * (1 << 20), std::min(want, share));
     if (auto_b > c->scratch_budget || c->scratch_budget > 2 * auto_b) c->scratch_budget = auto_b;
   }

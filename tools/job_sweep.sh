@@ -2,7 +2,7 @@
 # GPU box: whole-job wall time (text left in HBM) over the job pipeline's knobs: rounds per record x rounds in flight
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-for rounds in 2 3; do
+for rounds in 2 3 4; do
   for depth in 2 3; do
     echo "== PBSIM_JOB_ROUNDS=$rounds PBSIM_JOB_DEPTH=$depth"
     PBSIM_JOB_ROUNDS=$rounds PBSIM_JOB_DEPTH=$depth python bench.py --no-cpu-baseline --no-extras --hbm-only --steps 2 2>/dev/null |
