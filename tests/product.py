@@ -43,3 +43,24 @@ def run_wgs(args, device=0, scratch_mb=None, deflate=False):
             outs["_%04d.maf" % i] = mt
             stats.append(ctx.stats())
     return outs, stats
+
+
+def run_wgs_job(args, device=0, scratch_mb=None):
+    """The same run through the job pipeline (pbsim_job_*: all records resident, one pipeline of rounds)."""
+    p, a = params_from_args(args)
+    outs, stats = {}, []
+    with P.Context(p, device) as ctx:
+        if scratch_mb:
+            ctx.set_scratch_bytes(scratch_mb << 20)
+        (ctx.load_errhmm if p.method == P.METHOD_ERR else ctx.load_qshmm)(a["--errhmm" if p.method == P.METHOD_ERR else "--qshmm"])
+        for r in read_fasta(a["--genome"]):
+            ctx.job_add_record(r)
+        texts, done = ctx.job_run()
+        for i in sorted(texts):
+            rt, mt = bytes(texts[i][0]), bytes(texts[i][1])
+            if p.pass_num > 1:
+                rt = ctx.job_sam_header(i) + rt
+            outs["_%04d.%s" % (i, "fq" if p.pass_num == 1 else "sam")] = rt
+            outs["_%04d.maf" % i] = mt
+            stats.append(done[i][0])
+    return outs, stats
