@@ -904,7 +904,8 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
       // (rounds in flight + one whose delivery is pending + one with the worker; nothing is held back when the text stays put)
       const bool delivering_text = J.sink && (J.sink->on_read_text || J.sink->on_maf_text);
       const double slots_used = (double)J.depth + (delivering_text ? 2.0 : 1.0);
-      const double fit = 0.70 * (double)(free_b + held + held_text) / (slots_used * (text_per_base + scratch_per_base));
+      const char *ff = getenv("PBSIM_JOB_FIT");  // experiment knob: share of the free HBM the slots may take
+      const double fit = (ff ? atof(ff) : 0.70) * (double)(free_b + held + held_text) / (slots_used * (text_per_base + scratch_per_base));
       target = std::min(target, std::max(fit, 1.0e8));
     }
     // what batch_capacity_for() charges a read: `regions` rows of 2 * length + pad columns, 12 % slack for the per-wave rounding

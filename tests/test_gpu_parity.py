@@ -52,7 +52,7 @@ def test_wgs_qshmm_and_multipass_match_oracle_and_golden(case, tmp_path):
 def test_job_pipeline_matches_golden(case):
     """the same commands through pbsim_job_* (all records resident, one pipeline of rounds; a 4 MB scratch pool forces many rounds)"""
     args = harness.resolve(CASES[case]["args"])
-    outs, _ = product.run_wgs_job(args, scratch_mb=4)
+    outs, _ = product.run_wgs_job(args, scratch_mb=32 if "default" in case else 4)
     gold = MANIFEST[f"{case}/philox"]
     for k, v in outs.items():
         assert harness.sha(v) == gold[k]["sha256"], (case, k)
