@@ -243,6 +243,7 @@ struct pbsim_ctx {
   int64_t scratch_budget = 0;  // bytes of wave scratch per slot
   bool scratch_auto = true;    // sized per record by pbsim_simulate_wgs unless PBSIM_SCRATCH_MB / pbsim_set_scratch_bytes said otherwise
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
+  int walk_lds_kb = 27;        // walk workgroups per CU: 27 KB -> five (batch primitives), 41 KB -> three (the job pipeline)
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
   int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)
   bool deflate_parallel = false;  // pbsim_set_deflate bit 2: the two sinks are served from two host threads

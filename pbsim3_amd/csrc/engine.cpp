@@ -640,7 +640,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     w.emis_off = c->ect.emis_off;
     w.init_off = c->ect.init_off;
     w.tran_off = c->ect.tran_off;
-    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws);
+    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
   } else {
     w.stride = c->qct.stride;
     w.rv_off = c->qct.rv_off;
@@ -654,7 +654,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     w.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     w.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
     launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8 + 94 * 32, c->qct.all_rv_100,
-                      ref.hp_flag, ws);
+                      ref.hp_flag, ws, c->walk_lds_kb);
   }
   HIP_OK(hipEventRecord(c->s().ev2, ws));
   HIP_OK(hipStreamWaitEvent(c->s().stream, c->s().ev2, 0));

@@ -930,7 +930,10 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   J.mean = std::min<double>(J.mean, (double)c->job_records[0]->len);
   for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
   if (J.deflated() && !ensure_deflate_ready(c)) return PBSIM_FAILED;  // before the worker and its lane threads use the tables
+  const int keep_lds = c->walk_lds_kb;
+  c->walk_lds_kb = 41;  // three walk workgroups per CU: the round loop waits on many short kernels (kernels.hip walk_lds)
   const int ok = J.run();
+  c->walk_lds_kb = keep_lds;
   if (!ok) {
     const std::string keep = g_err;
     J.drop_everything();

@@ -178,10 +178,11 @@ void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int flag_hp11, int64_t 
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s);
 void launch_header_trans(const HeaderArgs &a, hipStream_t s);
 void launch_task_sort(const SortArgs &a, hipStream_t s);
+// min_lds_kb: LDS to ask for at least, i.e. a cap on the walk's workgroups per CU (kernels.hip walk_lds)
 void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                        hipStream_t s);
+                        hipStream_t s, int min_lds_kb);
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                       hipStream_t s);
+                       hipStream_t s, int min_lds_kb);
 void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s);
 // exclusive scan of int64 (in-place allowed: out may equal in); tmp needs (n/1024+2) int64
 void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total, hipStream_t s);

@@ -2019,18 +2019,19 @@ void launch_task_sort(const SortArgs &a, hipStream_t s) {
 
 // A walk workgroup lives for milliseconds (until its longest read ends) and six of them fill a CU's registers and LDS: the
 // short kernels and copies of the other slots -- text emission, scans, the flag reads the host waits for -- then queue until
-// one of them ends (measured: a 200-byte device-to-host read took up to 39 ms beside three walks).  Asking for at least
-// 41 KB of LDS per walk workgroup caps them at three per CU (160 KB); the walk itself does not slow down (it is bound by
-// VALU issue, which three waves per SIMD already saturate), everything else finds room at once.  PBSIM_WALK_LDS_KB overrides.
-static uint32_t walk_lds(uint32_t lds_bytes) {
-  static const int pad_kb = getenv("PBSIM_WALK_LDS_KB") ? atoi(getenv("PBSIM_WALK_LDS_KB")) : 41;
-  const uint32_t pad = (uint32_t)pad_kb << 10;
+// one of them ends (measured: a 200-byte device-to-host read took up to 39 ms beside three walks).  Asking for more LDS per
+// walk workgroup than it needs caps the workgroups per CU (160 KB): `min_lds_kb` 27 -> five per CU (neutral for the walk,
+// same-box A/B), 41 -> three per CU (the walk alone 6 % slower, but the job pipeline, whose round loop waits on many short
+// kernels, 8 % faster; the two-giant-batches steady state 11 % slower -- so the caller chooses).  PBSIM_WALK_LDS_KB overrides.
+static uint32_t walk_lds(uint32_t lds_bytes, int min_lds_kb) {
+  static const int env_kb = getenv("PBSIM_WALK_LDS_KB") ? atoi(getenv("PBSIM_WALK_LDS_KB")) : -1;
+  const uint32_t pad = (uint32_t)(env_kb >= 0 ? env_kb : min_lds_kb) << 10;
   return lds_bytes > pad ? lds_bytes : pad;
 }
 
 void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                        hipStream_t s) {
-  lds_bytes = walk_lds(lds_bytes);
+                        hipStream_t s, int min_lds_kb) {
+  lds_bytes = walk_lds(lds_bytes, min_lds_kb);
   const dim3 grid((unsigned)(n_slots_max / kWG)), block(kWG);
   if (fast_rv && hp_bits) hipLaunchKernelGGL((k_walk_errhmm<true, true>), grid, block, lds_bytes, s, a);
   else if (fast_rv) hipLaunchKernelGGL((k_walk_errhmm<true, false>), grid, block, lds_bytes, s, a);
@@ -2039,8 +2040,8 @@ void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byt
 }
 
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                       hipStream_t s) {
-  lds_bytes = walk_lds(lds_bytes);
+                       hipStream_t s, int min_lds_kb) {
+  lds_bytes = walk_lds(lds_bytes, min_lds_kb);
   const dim3 grid((unsigned)(n_slots_max / kWG)), block(kWG);
   if (fast_rv && hp_bits) hipLaunchKernelGGL((k_walk_qshmm<true, true>), grid, block, lds_bytes, s, a);
   else if (fast_rv) hipLaunchKernelGGL((k_walk_qshmm<true, false>), grid, block, lds_bytes, s, a);
