@@ -218,7 +218,7 @@ def bench_trans(a, torch, harness, P, local):
 
 def issue_bound(columns_per_launch, walk_s):
     """The walk's real ceiling is integer issue, not HBM: figures of the PMC pass of the same kernel (tools/pmc_kernel.sh)."""
-    path = os.path.join(ROOT, "profiles", "r01x_walk_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02z_walk_pmc.json")
     if not os.path.exists(path):
         return None
     pj = json.load(open(path))
@@ -226,7 +226,7 @@ def issue_bound(columns_per_launch, walk_s):
     return {"valu_busy_frac": pj["valu_busy_fraction"], "valu_per_wave_step": valu,
             "int_lane_ops_per_sec": valu * columns_per_launch / walk_s if walk_s > 0 else None,
             "lds_table_hit_rate": 1.0,          # every HMM table read is an LDS read (4 per column)
-            "source": "profiles/r01x_walk_pmc.json (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD-cycles)"}
+            "source": "profiles/r02z_walk_pmc.json (SQ_INSTS_VALU x 4 cycles / SIMD-cycles)"}
 
 
 def make_records(torch, dist, dev, cdev, rank, world, n_rec, G):
@@ -452,7 +452,7 @@ def main():
         walk_s = walk_ms / 1e3
         achieved = alg_bytes / walk_s / 1e9 if walk_s > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01x_walk_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02z_walk_traffic.json")
         if not qs and os.path.exists(tpath):     # PMC pass of the same kernel (tools/pmc_traffic.sh), scaled per base
             tj = json.load(open(tpath))
             traffic = tj["traffic_bytes_per_launch"] / tj["bases_per_launch"] * (sum(c["bases"] for c in counters) / max(1, launches))
@@ -477,7 +477,7 @@ def main():
                          "note": "bytes over each GPU's PCIe link / time / 63 GB/s (Gen5 x16): the link is this metric's roofline"},
             "roofline": {"bound": "hbm", "kernel": "k_walk_qshmm" if qs else "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01x_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE, raw x1024; see note there)",
+                         "traffic_source": "profiles/r02z_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE in separate passes, raw x1024, three walk workgroups per CU as in the job)",
                          "alg_bytes_per_launch": alg_bytes / max(1, launches), "avg_launch_ms": walk_ms / max(1, launches),
                          "launches": launches,
                          "tail_read_launches": {"launches": tail_launches, "avg_ms": tail_ms / max(1, tail_launches),
@@ -491,8 +491,8 @@ def main():
                          "walk_own": {"bytes_per_base": own_bytes / max(1, sum(c["bases"] for c in counters)),
                                       "achieved": own_bytes / walk_s / 1e9 if walk_s > 0 else None,
                                       "note": "what the walk kernel itself moves: 1 B per reference base gathered + 2 MAF rows; the read and "
-                                              "quality bytes are written by the text kernels.  PMC (profiles/r01x_walk_pmc.json): the "
-                                              "reference gather fetches 3.0x its bytes (one 64-B sector per 8-byte window refill)"},
+                                              "quality bytes are written by the text kernels.  PMC (profiles/r02z_walk_pmc.json): the "
+                                              "reference gather fetches 0.93x its bytes at three walk workgroups per CU (2.5x at five: one 64-B sector per 8-byte window refill)"},
                          "walk_share_of_step": walk_busy_ms / 1e3 / dt if dt > 0 else None,
                          # the kernel's real ceiling is integer issue, not HBM: PMC pass of the same kernel
                          "issue_bound": None if qs else issue_bound(sum(c["maf_columns"] for c in counters) / max(1, launches),
