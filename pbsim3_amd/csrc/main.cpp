@@ -6,6 +6,7 @@
 //                                     --comm rccl: RCCL communicator over xGMI for C1 / C2 / C3 (rccl_comm.h; distinct GPUs)
 // Every rank runs the same pbsim_cli_main(argv): the job is deterministic in the values the ranks exchange, so they stay
 // in lockstep; rank 0 prints the report and creates the files, every rank writes its own byte ranges.
+#include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,6 +22,7 @@
 int main(int argc, char **argv) {
   std::vector<int> devices;
   std::string comm_kind = "host";
+  bool selftest = false;  // --comm-selftest: run C1 / C2 / C3 once on the communicator of --devices / --comm and check the values
   for (int i = 1; i < argc; i++) {
     const char *a = argv[i];
     const char *v = NULL;
@@ -45,12 +47,14 @@ int main(int argc, char **argv) {
     }
     if (!strncmp(a, "--comm=", 7)) comm_kind = a + 7;
     else if (!strcmp(a, "--comm") && i + 1 < argc) comm_kind = argv[i + 1];
+    if (!strcmp(a, "--comm-selftest")) selftest = true;
   }
   if (comm_kind != "host" && comm_kind != "rccl") {
     fprintf(stderr, "ERROR (comm: %s): host or rccl.\n", comm_kind.c_str());
     return 255;
   }
-  if (devices.empty()) return pbsim_cli_main(argc, argv, NULL, -1) & 255;
+  if (devices.empty() && !selftest) return pbsim_cli_main(argc, argv, NULL, -1) & 255;
+  if (devices.empty()) devices.push_back(0);
 
   const int world = (int)devices.size();
   pbsim::ThreadCommShared shared(devices);
@@ -68,6 +72,52 @@ int main(int argc, char **argv) {
       return 255;
     }
     for (int r = 0; r < world; r++) comms[(size_t)r] = pbsim::rccl_comm(&rccl[(size_t)r]);
+  }
+  if (selftest) {
+    std::vector<int> bad((size_t)world, 0);
+    auto one = [&](int r) {
+      const pbsim_comm &cm = comms[(size_t)r];
+      (void)hipSetDevice(devices[(size_t)r]);
+      // C3: all-gather (rank-major)
+      int64_t send[3] = {r, 10 * r, -r};
+      std::vector<int64_t> recv((size_t)world * 3, 77);
+      if (!cm.all_gather_i64(cm.user, send, 3, recv.data())) bad[(size_t)r] |= 1;
+      for (int q = 0; q < world; q++)
+        if (recv[(size_t)q * 3] != q || recv[(size_t)q * 3 + 1] != 10 * q || recv[(size_t)q * 3 + 2] != -q) bad[(size_t)r] |= 1;
+      // C2: all-reduce sum / min / max
+      const int ops[3] = {PBSIM_OP_SUM, PBSIM_OP_MIN, PBSIM_OP_MAX};
+      const int64_t want[3] = {(int64_t)world * (world - 1) / 2, 0, world - 1};
+      for (int k = 0; k < 3; k++) {
+        std::vector<int64_t> buf(1000, r);
+        if (!cm.all_reduce_i64(cm.user, buf.data(), (int64_t)buf.size(), ops[k])) bad[(size_t)r] |= 2;
+        for (int64_t v : buf)
+          if (v != want[k]) bad[(size_t)r] |= 2;
+      }
+      // C1: broadcast of device memory from the last rank
+      const int root = world - 1;
+      const size_t nbytes = 1 << 20;
+      void *d = NULL;
+      std::vector<unsigned char> h(nbytes);
+      if (hipMalloc(&d, nbytes) != hipSuccess) bad[(size_t)r] |= 4;
+      for (size_t i = 0; i < nbytes; i++) h[i] = (unsigned char)((i * 131 + (size_t)r) & 255);
+      (void)hipMemcpy(d, h.data(), nbytes, hipMemcpyHostToDevice);
+      (void)hipDeviceSynchronize();
+      if (!cm.broadcast || !cm.broadcast(cm.user, d, (int64_t)nbytes, root, 1)) bad[(size_t)r] |= 4;
+      (void)hipMemcpy(h.data(), d, nbytes, hipMemcpyDeviceToHost);
+      for (size_t i = 0; i < nbytes; i++)
+        if (h[i] != (unsigned char)((i * 131 + (size_t)root) & 255)) bad[(size_t)r] |= 4;
+      (void)hipFree(d);
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < world; r++) th.emplace_back(one, r);
+    one(0);
+    for (std::thread &t : th) t.join();
+    if (comm_kind == "rccl") pbsim::rccl_destroy_all(&rccl);
+    int any = 0;
+    for (int r = 0; r < world; r++) any |= bad[(size_t)r];
+    fprintf(stderr, "comm selftest (%s, %d rank%s): all-gather %s, all-reduce %s, device broadcast %s\n", comm_kind.c_str(), world,
+            world == 1 ? "" : "s", (any & 1) ? "FAILED" : "ok", (any & 2) ? "FAILED" : "ok", (any & 4) ? "FAILED" : "ok");
+    return any ? 255 : 0;
   }
   std::vector<int> rc((size_t)world, 0);
   std::vector<std::thread> th;

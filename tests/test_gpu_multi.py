@@ -136,3 +136,23 @@ def test_sink_failure_on_either_thread_reaches_the_caller(which):
             P._check(ctx.lib.pbsim_simulate_wgs(ctx.h, C.byref(s2)))
         rt, mt = ctx.simulate_wgs()
         assert len(rt) > 0 and len(mt) > 0
+
+
+@pytest.mark.parametrize("devices,comm", [("0,0,0", "host"), ("0", "rccl")])
+def test_communicators_selftest(devices, comm):
+    """C1 / C2 / C3 once on each communicator of the `pbsim` binary: the host barrier with three contexts on the one GPU,
+    and RCCL (librccl opened at run time, ncclCommInitAll + ncclAllGather / ncclAllReduce / ncclBroadcast on device memory)
+    as a communicator of one -- all this box can offer; more ranks need distinct GPUs"""
+    p = subprocess.run([CLI, "--devices", devices, "--comm", comm, "--comm-selftest"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "all-gather ok, all-reduce ok, device broadcast ok" in p.stderr
+
+
+def test_genome_in_several_jobs(tmp_path):
+    """a genome larger than the resident-reference budget runs as several jobs whose record numbering continues, and
+    --hp-del-bias != 1 then takes its census over ALL records first (pbsim.cpp:677-696): one record per job here"""
+    for case in ("wgs_errhmm_ont_hpbias5", "wgs_qshmm_rsii_pass3"):
+        d = tmp_path / case
+        d.mkdir()
+        outs = run_devices(CASES[case]["args"], str(d), 2, scratch_mb=4, env={"PBSIM_JOB_REF_GB": "0.00001"})
+        check_against_golden(outs, case)
