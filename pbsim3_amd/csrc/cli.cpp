@@ -220,6 +220,8 @@ void print_help() {
 
 void check(int ok) {
   if (!ok) {
+    // a rank that only learnt of another rank's failure lets that rank report first (they share this process's stderr and exit)
+    if (!strncmp(pbsim_last_error(), "another rank", 12)) usleep(300000);
     fprintf(stderr, "ERROR: %s\n", pbsim_last_error());
     quit(-1);
   }
@@ -283,13 +285,14 @@ void parse_args(int argc, char **argv, Cli &c) {
       break;
     case 9: {
       std::string buf = optarg;
-      char *tp = strtok(&buf[0], ":");
+      char *tok_save = nullptr;
+      char *tp = strtok_r(&buf[0], ":", &tok_save);
       for (int num = 0; num < 3; num++) {
         if (!tp) die(" (difference-ratio: %s): Format is sub:ins:del.", optarg);
         long r = atoi(tp);
         if (strlen(tp) >= 5 || r < 0 || r > 1000) die(" (difference-ratio: %s): Acceptable range is 0-1000.", optarg);
         (num == 0 ? c.p.sub_ratio : num == 1 ? c.p.ins_ratio : c.p.del_ratio) = r;
-        tp = strtok(NULL, ":");
+        tp = strtok_r(NULL, ":", &tok_save);
       }
       break;
     }
@@ -794,7 +797,7 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
                          [](void *u, const char *t, int64_t k) { ((Keep *)u)->r->append(t, (size_t)k); return 1; },
                          [](void *u, const char *t, int64_t k) { ((Keep *)u)->m->append(t, (size_t)k); return 1; }};
       check(pbsim_stats_keep_values(ctx, 1));
-      check(pbsim_simulate_units_range(ctx, first, n, &sink));
+      check(pbsim_simulate_units_range(ctx, n > 0 ? first : 1, n, &sink));  // more ranks than reads: the last ranks take none
       check(pbsim_stats_merge(ctx, comm));
       const bool bam = c.p.pass_num > 1;
       const std::string rname = c.prefix + (c.p.pass_num == 1 ? (c.no_gzip ? ".fq" : ".fq.gz") : (c.no_gzip ? ".sam" : ".bam"));

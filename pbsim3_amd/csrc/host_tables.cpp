@@ -70,17 +70,18 @@ bool parse_errhmm(const char *path, ErrModel *m, std::string *err) {
   m->acc_max = 0;
   std::unique_ptr<char[]> line(new char[kLineMax]);
   bool ok = true;
+  char *tok_save = nullptr;  // strtok_r: several ranks of one process parse their models at the same time
   while (ok && fgets(line.get(), kLineMax, fp)) {
     chomp(line.get());
     int acc;
-    char *tok = strtok(line.get(), " ");
+    char *tok = strtok_r(line.get(), " ", &tok_save);
     if (!tok) continue;
     if (!(ok = token_to_class(tok, &acc, err))) break;
     m->exist[acc] = 1;
     m->acc_min = std::min(m->acc_min, acc);
     m->acc_max = std::max(m->acc_max, acc);
-    const char *kind = strtok(NULL, " ");
-    const char *st = strtok(NULL, " ");
+    const char *kind = strtok_r(NULL, " ", &tok_save);
+    const char *st = strtok_r(NULL, " ", &tok_save);
     if (!kind || !st) {
       *err = "malformed model line";
       ok = false;
@@ -93,12 +94,12 @@ bool parse_errhmm(const char *path, ErrModel *m, std::string *err) {
       break;
     }
     if (!strcmp(kind, "IP")) {
-      const char *v = strtok(NULL, " ");
+      const char *v = strtok_r(NULL, " ", &tok_save);
       m->ip[acc][state] = v ? atof(v) : 0.0;
       m->state_max[acc] = state;
     } else if (!strcmp(kind, "EP")) {
       int n = 0;
-      for (char *v = strtok(NULL, " "); v; v = strtok(NULL, " ")) {
+      for (char *v = strtok_r(NULL, " ", &tok_save); v; v = strtok_r(NULL, " ", &tok_save)) {
         if (n >= 4) {
           *err = "ERRHMM EP row has more than 4 columns";
           ok = false;
@@ -108,7 +109,7 @@ bool parse_errhmm(const char *path, ErrModel *m, std::string *err) {
       }
     } else if (!strcmp(kind, "TP")) {
       int n = 0;
-      for (char *v = strtok(NULL, " "); v; v = strtok(NULL, " ")) {
+      for (char *v = strtok_r(NULL, " ", &tok_save); v; v = strtok_r(NULL, " ", &tok_save)) {
         if (++n > kStateMax) {
           *err = "model TP row exceeds STATE_MAX (50) columns";
           ok = false;
@@ -131,6 +132,7 @@ bool parse_qshmm(const char *path, QsModel *m, std::string *err) {
   memset(m, 0, sizeof(*m));
   std::unique_ptr<char[]> line(new char[kLineMax]);
   bool ok = true;
+  char *tok_save = nullptr;  // strtok_r: several ranks of one process parse their models at the same time
   // the reference's unchecked `qshmm.xx[accuracy][state][num] = atof(tp)` on the flat block (see QsModel)
   auto store = [&](long at, double v) {
     if (at < 0 || at >= QsModel::kIpN + QsModel::kEpN + QsModel::kTpN) {
@@ -143,12 +145,12 @@ bool parse_qshmm(const char *path, QsModel *m, std::string *err) {
   while (ok && fgets(line.get(), kLineMax, fp)) {
     chomp(line.get());
     int acc;
-    char *tok = strtok(line.get(), " ");
+    char *tok = strtok_r(line.get(), " ", &tok_save);
     if (!tok) continue;
     if (!(ok = token_to_class(tok, &acc, err))) break;
     m->exist[acc] = 1;
-    const char *kind = strtok(NULL, " ");
-    const char *st = strtok(NULL, " ");
+    const char *kind = strtok_r(NULL, " ", &tok_save);
+    const char *st = strtok_r(NULL, " ", &tok_save);
     if (!kind || !st) {
       *err = "malformed model line";
       ok = false;
@@ -161,14 +163,14 @@ bool parse_qshmm(const char *path, QsModel *m, std::string *err) {
       break;
     }
     if (!strcmp(kind, "IP")) {
-      const char *v = strtok(NULL, " ");
+      const char *v = strtok_r(NULL, " ", &tok_save);
       ok = store(QsModel::ip_at(acc, state), v ? atof(v) : 0.0);
     } else if (!strcmp(kind, "EP")) {
       int n = 0;
-      for (char *v = strtok(NULL, " "); v && ok; v = strtok(NULL, " ")) ok = store(QsModel::ep_at(acc, state, n++), atof(v));
+      for (char *v = strtok_r(NULL, " ", &tok_save); v && ok; v = strtok_r(NULL, " ", &tok_save)) ok = store(QsModel::ep_at(acc, state, n++), atof(v));
     } else if (!strcmp(kind, "TP")) {
       int n = 0;
-      for (char *v = strtok(NULL, " "); v && ok; v = strtok(NULL, " ")) ok = store(QsModel::tp_at(acc, state, ++n), atof(v));
+      for (char *v = strtok_r(NULL, " ", &tok_save); v && ok; v = strtok_r(NULL, " ", &tok_save)) ok = store(QsModel::tp_at(acc, state, ++n), atof(v));
     }
   }
   fclose(fp);

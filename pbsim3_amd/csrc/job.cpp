@@ -744,7 +744,7 @@ static int job_add(pbsim_ctx *c, const void *seq, int64_t len, hipMemcpyKind kin
   r->len = len;
   HIP_OK(r->seq.ensure((size_t)len + 64, true));
   HIP_OK(hipMemcpyAsync(r->seq.p, seq, (size_t)len, kind, c->prefetch_stream));
-  if (kind == hipMemcpyHostToDevice) HIP_OK(hipStreamSynchronize(c->prefetch_stream));  // the caller may reuse its buffer
+  HIP_OK(hipStreamSynchronize(c->prefetch_stream));  // the caller may reuse (or free) its buffer; the preparation stays asynchronous
   HIP_OK(hipMemsetAsync(r->seq.as<uint8_t>() + len, 0, 64, c->prefetch_stream));
   if (!prepare_enqueue(c, r->seq.as<uint8_t>(), r->hp, r->tiles, r->flags, len, c->prefetch_stream)) return PBSIM_FAILED;
   c->job_records.push_back(std::move(r));
@@ -771,6 +771,7 @@ int pbsim_job_add_record_comm(pbsim_ctx *c, const uint8_t *seq, int64_t len, con
   }
   HIP_OK(hipDeviceSynchronize());
   if (!comm->broadcast(comm->user, tmp.p, len, root, 1)) return fail("pbsim_comm.broadcast failed");
+  HIP_OK(hipDeviceSynchronize());  // whatever stream the communicator used: the bytes are in `tmp` before they are copied on
   if (!job_add(c, tmp.p, len, hipMemcpyDeviceToDevice)) return PBSIM_FAILED;
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));  // tmp is released on return
   return PBSIM_SUCCEEDED;

@@ -74,6 +74,9 @@ inline int tc_broadcast(void *user, void *p, int64_t bytes, int32_t root, int32_
     } else {  // GPU to GPU over xGMI
       ok = hipMemcpyPeer(p, sh->device[(size_t)r->rank], src, sh->device[(size_t)root], (size_t)bytes) == hipSuccess;
     }
+    // a device-to-device hipMemcpy returns before the bytes have moved: the root must not free its buffer, and this rank
+    // must not read its own, before they have
+    if (on_device) ok = ok && hipDeviceSynchronize() == hipSuccess;
   }
   pthread_barrier_wait(&sh->bar);
   return ok;

@@ -161,10 +161,11 @@ bool read_transcripts(const char *file, std::vector<Transcript> *out, long *tota
     const bool nl = chomp(line.get());
     if (first_chunk) {
       cur = Transcript();
-      char *tp = strtok(line.get(), "\t");
-      const char *a = strtok(NULL, "\t");
-      const char *b = strtok(NULL, "\t");
-      const char *s = strtok(NULL, "\t");
+      char *tok_save = nullptr;
+      char *tp = strtok_r(line.get(), "\t", &tok_save);
+      const char *a = strtok_r(NULL, "\t", &tok_save);
+      const char *b = strtok_r(NULL, "\t", &tok_save);
+      const char *s = strtok_r(NULL, "\t", &tok_save);
       if (!tp || !a || !b || !s) {
         fclose(fp);
         *err = "malformed transcript line (expected id<TAB>plus<TAB>minus<TAB>sequence)";
