@@ -79,8 +79,19 @@ for k in range(k0, k1):
         env = dict(os.environ, PBSIM_SCRATCH_MB=str(r.choice([3, 4, 6, 12, 48])))
         if r.random() < 0.25:
             env["PBSIM_JOB_REF_GB"] = "0.0001"   # ~50 kbases of reference per job: the genome runs as several jobs
-        p = subprocess.run([CLI] + harness.resolve(args) + ["--prefix", td + "/p/out", "--devices", ",".join(["0"] * ranks)] +
-                           ([] if zipped else ["--no-gzip"]), capture_output=True, text=True, cwd=td + "/p", env=env)
+        if os.environ.get("FUZZ_TORCHRUN"):   # the same job as one process per rank under torchrun (torch.distributed gloo communicator)
+            ranks = max(2, min(ranks, 3))
+            env["PYTHONPATH"] = R
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+                   "127.0.0.1", "--master-port", str(29600 + k % 300), "-m", "pbsim3_amd.run_multi"] + harness.resolve(args) + \
+                  ["--prefix", td + "/p/out", "--backend", "gloo", "--one-gpu"] + ([] if zipped else ["--no-gzip"])
+        else:
+            cmd = [CLI] + harness.resolve(args) + ["--prefix", td + "/p/out", "--devices", ",".join(["0"] * ranks)] + \
+                  ([] if zipped else ["--no-gzip"])
+        p = subprocess.run(cmd, capture_output=True, text=True, cwd=td + "/p", env=env)
+        if os.environ.get("FUZZ_TORCHRUN") and ":::: Simulation parameters" in p.stderr:   # torchrun's banner comes first
+            p.stderr = "\n".join(l for l in p.stderr[p.stderr.index(":::: Simulation parameters"):].splitlines()
+                                 if "amdgpu.ids" not in l and not l.startswith(("W0", "W1", "[W", "[E", "[Gloo", "[rank")))
         if p.returncode != 0:
             if "scratch budget exceeded" in p.stderr or "scratch pool too small" in p.stderr:
                 print(k, "pool too small for a single read, skipped")
