@@ -186,6 +186,8 @@ struct Slot {
   DfLane df[2];                        // deflate staging: [0] read text (or any single stream), [1] MAF text beside it
   hipStream_t walk_stream = nullptr;   // low priority: the walk kernel only
   hipEvent_t ev_prep = nullptr;        // header + sort done (walk_stream waits for it)
+  hipStream_t coop_stream = nullptr;   // the long reads' walk (k_walk_errhmm_coop), beside the batch's lane walk
+  hipEvent_t ev_coop = nullptr;
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
   bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
   int64_t b_pass0 = 0;

@@ -261,6 +261,8 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
       return nullptr;
     }
     (void)hipEventCreateWithFlags(&sl.ev_prep, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&sl.ev_coop, hipEventDisableTiming);
+    if (hipStreamCreateWithPriority(&sl.coop_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) sl.coop_stream = nullptr;
     (void)hipEventCreate(&sl.ev0);
     (void)hipEventCreate(&sl.ev1);
     (void)hipEventCreate(&sl.ev2);
@@ -295,6 +297,8 @@ void pbsim_destroy(pbsim_ctx *c) {
     }
     if (sl.walk_stream) (void)hipStreamDestroy(sl.walk_stream);
     if (sl.ev_prep) (void)hipEventDestroy(sl.ev_prep);
+    if (sl.coop_stream) (void)hipStreamDestroy(sl.coop_stream);
+    if (sl.ev_coop) (void)hipEventDestroy(sl.ev_coop);
   }
   if (c->ev_prof_base) (void)hipEventDestroy(c->ev_prof_base);
   if (c->prefetch_stream) (void)hipStreamDestroy(c->prefetch_stream);
@@ -482,6 +486,28 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   return walk_begin(c, current_ref(c), first_read, n_reads, truncate_remaining);
 }
 
+// Reads of at least this length are walked by a whole wave each (k_walk_errhmm_coop) instead of one lane: the reads whose
+// lane walk would outlast the rest of the batch, and every read of a small batch (top-up rounds, the truncated tail reads
+// whose latency a record's completion waits for).  A column costs the wave walker about four times the instructions it
+// costs the lane walker, so on a GPU that several rounds keep busy the share must stay small: four mean lengths (1 % of the
+// reads, 2.6 % of the bases of the default length distribution; same-box sweep in profiles/r02z_coop_sweep.txt); a
+// smaller batch ends with its longest lane all the sooner, three mean lengths there.  A multiple of 256 (the sort's length
+// bucket).  PBSIM_COOP_LEN overrides: -1 never, n >= 0 that length.
+// A batch of a million reads hides its longest lane behind its own bulk (n * mean / 286 Gbases/s > 8 mean lengths * 0.42 us
+// whatever the mean): no wave walker there (the two-giant-batches steady state lost 5 % with it).
+constexpr int kCoopWorkgroups = 512, kCoopSmallBatch = 2048, kCoopLargeBatch = 300000, kCoopHugeBatch = 1000000;
+static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads) {
+  if (c->p.method != PBSIM_METHOD_ERR || !c->ect.all_rv_1000 || c->ect.smax > kCoopMaxStates) return INT32_MAX;
+  const char *env = getenv("PBSIM_COOP_LEN");
+  const int64_t n_tasks = n_reads * c->p.pass_num;
+  int64_t len = n_tasks <= kCoopSmallBatch ? 0 : (int64_t)((n_tasks >= kCoopLargeBatch ? 4.0 : 3.0) * c->hdr.mean_len);
+  if (n_tasks >= kCoopHugeBatch) len = -1;
+  if (env) len = atoll(env);
+  if (len < 0) return INT32_MAX;
+  len = (len + 255) / 256 * 256;
+  return len >= (int64_t)kLenBuckets << kLenShift ? INT32_MAX : (int32_t)len;
+}
+
 // header draw -> bucketing -> walk -> pass-0 prefix of reads [first_read, first_read + n_reads) of `ref`, on the selected slot
 extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining) {
   if (!c || n_reads < 1 || first_read < 1) return fail("pbsim_batch_walk: bad argument");
@@ -515,7 +541,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   HIP_OK(c->s().d_hist.ensure(nbins * kBinPad * 4));
   HIP_OK(c->s().d_bin_start.ensure(nbins * 4));
   HIP_OK(c->s().d_bin_cursor.ensure(nbins * kBinPad * 4));
-  HIP_OK(c->s().d_class_start.ensure((ncls + 1) * 4));
+  HIP_OK(c->s().d_class_start.ensure((2 * ncls + 2) * 4));  // class_start[ncls + 1] | coop_end[ncls]
   HIP_OK(c->s().d_task_of_slot.ensure(slots_max * 4));
   HIP_OK(c->s().d_slot_of_task.ensure(n_tasks * 4));
   HIP_OK(c->s().d_wave_cap.ensure(waves_max * 4));
@@ -584,6 +610,9 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   s.bin_start = c->s().d_bin_start.as<int32_t>();
   s.bin_cursor = c->s().d_bin_cursor.as<int32_t>();
   s.class_start = c->s().d_class_start.as<int32_t>();
+  s.coop_end = s.class_start + ncls + 1;
+  const int32_t coop_len = coop_min_len(c, n_reads);
+  s.coop_bucket = coop_len == INT32_MAX ? kLenBuckets : coop_len >> kLenShift;
   s.task_of_slot = c->s().d_task_of_slot.as<int32_t>();
   s.slot_of_task = c->s().d_slot_of_task.as<int32_t>();
   s.wave_cap = c->s().d_wave_cap.as<int32_t>();
@@ -618,6 +647,8 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   w.task_of_slot = s.task_of_slot;
   w.wg_order = s.wg_order;
   w.mean_len = (int32_t)c->hdr.mean_len;
+  w.coop_min_len = coop_len;
+  w.coop_end = s.coop_end;
   w.wave_cap = s.wave_cap;
   w.wave_off = s.wave_off;
   w.scratch = c->s().d_scratch.as<uint8_t>();
@@ -640,7 +671,20 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     w.emis_off = c->ect.emis_off;
     w.init_off = c->ect.init_off;
     w.tran_off = c->ect.tran_off;
-    launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
+    if (coop_len != INT32_MAX) {
+      // the long reads first, so that their workgroups are resident before the lane walk fills the CUs; beside a batch
+      // on a stream of their own, a lone tail read simply in front of the (then empty) lane walk
+      const char *cw = getenv("PBSIM_COOP_WG");  // experiment knob
+      const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(cw && atoi(cw) > 0 ? atoi(cw) : kCoopWorkgroups, (n_tasks + 3) / 4));
+      hipStream_t cs = (ws == c->s().walk_stream && c->s().coop_stream) ? c->s().coop_stream : ws;
+      if (cs != ws) HIP_OK(hipStreamWaitEvent(cs, c->s().ev_prep, 0));
+      launch_walk_errhmm_coop(w, n_wg, c->ect.stride + 512 + 1024, ref.hp_flag, cs);
+      if (cs != ws) HIP_OK(hipEventRecord(c->s().ev_coop, cs));
+      launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
+      if (cs != ws) HIP_OK(hipStreamWaitEvent(ws, c->s().ev_coop, 0));
+    } else {
+      launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
+    }
   } else {
     w.stride = c->qct.stride;
     w.rv_off = c->qct.rv_off;

@@ -405,6 +405,13 @@ bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBi
       return false;
     }
     for (long s = 1; s <= 1000; s++) dst[t->init_off + (s - 1)] = r.init[s];
+    {  // the highest state the class's tables can reach (k_walk_errhmm_coop walks every possible start state of a group)
+      uint32_t reach = 0;
+      for (long s = 1; s <= 1000; s++) reach = std::max<uint32_t>(reach, r.init[s]);
+      for (int j = 1; j <= smax; j++)
+        for (long s = 1; s <= 1000; s++) reach = std::max<uint32_t>(reach, r.tran[j][s]);
+      hdr[6] = reach;
+    }
     for (int j = 1; j <= smax; j++) {
       uint16_t *row = reinterpret_cast<uint16_t *>(dst + t->rows_off + 32u * (uint32_t)j);
       long e0 = 0, e1 = 0;

@@ -77,6 +77,8 @@ struct SortArgs {
   int32_t *bin_start;   // [ncls*kLenBuckets]
   int32_t *bin_cursor;  // [ncls*kLenBuckets*kBinPad]
   int32_t *class_start; // [ncls+1], multiples of kWG
+  int32_t coop_bucket;  // tasks of length bucket >= coop_bucket are walked by k_walk_errhmm_coop (kLenBuckets: none)
+  int32_t *coop_end;    // [ncls] end of those tasks' slots: they are the first of their class (longest first)
   int32_t *task_of_slot;
   int32_t *slot_of_task;
   int32_t *wave_cap;    // [n_waves_max] dwords per lane per region
@@ -104,6 +106,8 @@ struct WalkArgs {
   const int32_t *task_of_slot;
   const int32_t *wg_order;
   int32_t mean_len;          // E[L] of the length table (priority thresholds)
+  int32_t coop_min_len;      // errhmm: reads of at least this length belong to k_walk_errhmm_coop (a multiple of 256; INT32_MAX: none)
+  const int32_t *coop_end;   // [ncls] their slots are class_start[c] .. coop_end[c]
   const int32_t *wave_cap;
   const int64_t *wave_off;
   uint8_t *scratch;
@@ -181,6 +185,10 @@ void launch_task_sort(const SortArgs &a, hipStream_t s);
 // min_lds_kb: LDS to ask for at least, i.e. a cap on the walk's workgroups per CU (kernels.hip walk_lds)
 void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
                         hipStream_t s, int min_lds_kb);
+// the long reads of the batch (WalkArgs::coop_min_len), one wave per read; `n_wg` persistent workgroups; `lds_bytes` = the
+// lane walk's (class blob + byte tables), the waves' own areas are added here.  Classes of at most kCoopMaxStates states.
+constexpr int kCoopMaxStates = 31;
+void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bool hp_bits, hipStream_t s);
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
                        hipStream_t s, int min_lds_kb);
 void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s);

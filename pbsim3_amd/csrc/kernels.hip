@@ -463,12 +463,15 @@ __global__ __launch_bounds__(kScanBlock) void k_sort_scan(SortArgs a) {
     }
     const int base = s_base;
     int run = base + s_part[tid] - sum;
+    const int first_short = kLenBuckets - a.coop_bucket;  // bins are in descending length: the long reads' bins come first
     for (int k = 0; k < kPer; k++) {
       a.bin_start[c * kLenBuckets + tid * kPer + k] = run;
+      if (tid * kPer + k == first_short) a.coop_end[c] = run;
       run += v[k];
     }
     __syncthreads();
     if (tid == kScanBlock - 1) {
+      if (first_short >= kLenBuckets) a.coop_end[c] = base + s_part[kScanBlock - 1];
       a.class_start[c] = base;
       s_base = (base + s_part[kScanBlock - 1] + kWG - 1) / kWG * kWG;
     }
@@ -787,7 +790,8 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   uint32_t state = 0, tran_rv = 1;
   uint32_t acc_r = 0, acc_f = 0;
   int nsub = 0;
-  bool act = valid && L > 0;
+  const bool coop_lane = mode != kModeVerbatim && L >= a.coop_min_len;  // a long read: k_walk_errhmm_coop walks it
+  bool act = valid && L > 0 && !coop_lane;
   int group = 0;
   const WalkLane plane = walk_lane(a.seed, read_idx, pass, 0u);
 
@@ -875,13 +879,280 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     acc_f = 0;
     group++;
   }
-  if (valid) {
+  if (valid && !coop_lane) {
     if (ro < L) atomicOr(&a.flags->error, kErrScratchOverflow);
     a.out_len[task] = q;
     a.maf_len[task] = m;
     a.nsub[task] = nsub;
     a.nins[task] = m - ro;  // every column consumes a reference base except insertions
     a.ndel[task] = m - q;   // every column emits a read base except deletions
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2c: the same walk for the LONG reads of a batch, one WAVE per read.
+//
+// A lane of k_walk_errhmm needs ~0.4 us per column whatever else the GPU does, so the longest of a few hundred thousand
+// gamma-distributed lengths (70-76 k columns) holds a launch for ~30 ms and a single truncated tail read for milliseconds.
+// Nothing in a column's draws depends on the walk (the block is keyed by the column), and the state chain does
+// not depend on the reference: state[m] = tran[state[m-1]][x[m]].  A wave therefore takes 64 columns at a time, lane i
+// column m0 + i:
+//   1. every lane draws its column's block,
+//   2. the state chain runs through the 64 draws (LDS lookups; the only serial part),
+//   3. each lane classifies its column both ways (deleted / not deleted); which of the two holds depends on the
+//      homopolymer class of the reference base under the column's cursor, and the cursor on the insertions before it:
+//      a ballot + popcount gives every lane its cursor, the lanes re-decide, and the loop repeats while a decision moved a
+//      cursor (by induction over the lanes it ends in the sequential walk's answer; in practice after one or two turns),
+//   4. 64 columns of the two MAF rows leave as sixteen dwords each, in the lane walker's scratch layout.
+// Re-initialisation while nothing has been emitted (Q2: q == 0 selects the initial-state table) is handled the same way:
+// assume it for column 0 only, walk, compare with what the columns decided, repeat if the assumption was wrong.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// writes of one lane of the wave, reads of another: LDS operations of a wave complete in order, the compiler must keep it
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS of one wave of the wave walker: x[64] u16 | end states [8 groups][32 start states] | states[64] | two output rows
+constexpr int kCoopX = 0, kCoopEnd = 128, kCoopStates = 384, kCoopRows = 448, kCoopWaveLds = 576;
+static_assert(kCoopMaxStates == 31, "four chains of eight start states per lane");  // the shipped models have <= 29 states
+
+// States of the 64 columns: lane i receives the state after column i, given the state `s_in` in front of column 0.
+// The chain state[i] = tran[state[i - 1]][x[i]] is serial, so it is cut into eight groups of eight columns:
+//   A. lane (g, j) walks group g from the start states j, j + 8, j + 16, j + 24 (every state the group could start from),
+//      four independent chains of eight LDS lookups, and keeps the states they pass through;
+//   B. the groups' true start states follow from the end states of A, eight dependent lookups;
+//   C. the lane that walked group g from its true start state hands the eight states to the group's lanes.
+// `qz`: columns that start from the initial-state table (row 0 of the transition table) whatever the state in front.
+template <bool kInit>
+__device__ __forceinline__ uint32_t coop_chain(const uint8_t *lds, uint32_t init_off, uint32_t smax, uint32_t reach, uint8_t *s_w,
+                                               uint32_t x, uint64_t qz, uint32_t s_in, int lane) {
+  uint16_t *s_x = reinterpret_cast<uint16_t *>(s_w + kCoopX);
+  uint8_t *s_end = s_w + kCoopEnd, *s_st = s_w + kCoopStates;
+  const int g = lane >> 3, j = lane & 7;
+  wave_sync();
+  s_x[lane] = (uint16_t)x;
+  wave_sync();
+  const uint4 xv = *reinterpret_cast<const uint4 *>(s_x + g * 8);
+  const uint32_t xt[8] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16, xv.z & 0xffffu, xv.z >> 16, xv.w & 0xffffu, xv.w >> 16};
+  const uint32_t qg = kInit ? (uint32_t)(qz >> (g * 8)) & 0xffu : 0u;
+  uint32_t st[4], lo[4], hi[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    st[k] = (uint32_t)(j + 8 * k);
+    st[k] = st[k] > smax ? 0u : st[k];  // no such state: any row inside the table will do
+    lo[k] = hi[k] = 0;
+  }
+  auto walk_pair = [&](const int k0) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+#pragma unroll
+      for (int k = k0; k < k0 + 2; k++) {
+        uint32_t row = st[k];
+        if (kInit) row = ((qg >> t) & 1u) ? 0u : row;
+        st[k] = lds[init_off + __umul24(row, 1000u) + xt[t]];
+        if (t < 4) lo[k] |= st[k] << (8 * t);
+        else hi[k] |= st[k] << (8 * (t - 4));
+      }
+    }
+    s_end[g * 32 + j + 8 * k0] = (uint8_t)st[k0];
+    s_end[g * 32 + j + 8 * k0 + 8] = (uint8_t)st[k0 + 1];
+  };
+  walk_pair(0);
+  if (reach > 15u) walk_pair(2);  // most classes have fewer than sixteen states: half the work
+  wave_sync();
+  uint32_t s = s_in, sg = 0;
+#pragma unroll
+  for (int gg = 0; gg < 8; gg++) {
+    sg = (g == gg) ? s : sg;
+    s = s_end[gg * 32 + s];
+  }
+  const uint32_t k = sg >> 3;
+  const uint32_t plo = k == 0 ? lo[0] : k == 1 ? lo[1] : k == 2 ? lo[2] : lo[3];
+  const uint32_t phi = k == 0 ? hi[0] : k == 1 ? hi[1] : k == 2 ? hi[2] : hi[3];
+  if ((uint32_t)j == (sg & 7u)) *reinterpret_cast<uint2 *>(s_st + g * 8) = make_uint2(plo, phi);
+  wave_sync();
+  return s_st[lane];
+}
+
+template <bool kHpBits>
+__device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t *lds, const uint8_t *s_comp, const uint8_t *s_sub,
+                                               uint8_t *s_w, int slot, int lane) {
+  const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
+  const uint32_t smax = hdr[0], mode = hdr[2], rate_mag = hdr[3], reach = hdr[6];
+  uint8_t *s_tr = s_w + kCoopRows;
+  const int task = __builtin_amdgcn_readfirstlane(a.task_of_slot[slot]);
+  if (task < 0) return;
+  const int r = task / a.pass_num;
+  const uint32_t pass = (uint32_t)(task - r * a.pass_num);
+  const uint32_t read_idx = (uint32_t)(a.first_read + r);
+  const int L = __builtin_amdgcn_readfirstlane(a.len[r]);
+  const int64_t off = a.off[r] + (a.read_base ? a.read_base[r] : 0);
+  const bool minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
+  const int64_t wave = slot >> 6;
+  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);
+  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + (slot & 63);
+  uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
+  const int cap = 2 * L + kScratchPad;
+  const uint32_t comp_off = minus ? 256u : 0u;
+  const int64_t p_first = minus ? (off + L - 1) : off;
+  const int64_t p_last = a.ref.len - 1;
+
+  // reference window in read coordinates: lane j holds the bytes at wb + j and wb + 64 + j
+  int wb = 0;
+  auto ref_at = [&](int t, uint32_t *hpv) -> uint32_t {
+    int64_t p = minus ? (p_first - t) : (p_first + t);
+    p = p < 0 ? 0 : (p > p_last ? p_last : p);
+    if (!kHpBits) *hpv = a.ref.hp[p];
+    return a.ref.seq[p];
+  };
+  uint32_t hp_a = 0, hp_b = 0;
+  uint32_t win_a = ref_at(lane, &hp_a), win_b = ref_at(64 + lane, &hp_b);
+
+  int m0 = 0, ro0 = 0, q0 = 0, nsub = 0;
+  uint32_t st_in = 0;
+  bool more = L > 0;
+  while (more) {
+    const uint32_t event = (uint32_t)(m0 + lane);
+    const U4 w = walk_block(a.seed, a.unit, read_idx, pass, event, 0u);
+    const uint32_t x = mod1000(w.x), y1 = mod1000(w.y) + 1u, w3 = mod3(w.w);
+    U4 v = U4{0, 0, 0, 0};
+    bool have_v = false;
+    if (mode != kModeInRange) {  // out-of-range accuracy classes re-draw from sub-block 1 (Q3)
+      v = walk_block(a.seed, a.unit, read_idx, pass, event, 1u);
+      have_v = true;
+    }
+    uint64_t qz = (q0 == 0) ? 1ull : 0ull;
+    uint32_t st, e, raw = 0;
+    uint64_t valid;
+    for (;;) {
+      st = (q0 == 0) ? coop_chain<true>(lds, a.init_off, smax, reach, s_w, x, qz, st_in, lane)
+                     : coop_chain<false>(lds, a.init_off, smax, reach, s_w, x, 0ull, st_in, lane);
+      const uint4 em = *reinterpret_cast<const uint4 *>(lds + a.emis_off + st * 16u);
+      const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + st * 32u);
+      const uint32_t quo = __umulhi(w.z, em.x) >> (em.y & 0xffffu);
+      const uint32_t rem = (w.z - __umul24(quo, em.y >> 16)) & 0xffffffu;
+      const uint32_t ce = (uint32_t)(rem >= (em.z & 0xffffu)) + (uint32_t)(rem >= (em.z >> 16));
+      // the column's class if it is not deleted (e_keep) / if it is (e_del)
+      uint32_t e_keep = ce, e_del = 3u;
+      if (mode == kModeBelow) {
+        if (ce == 0 && v.x % 100u + 1u <= rate_mag) e_keep = v.y % 3u + 1u;
+      } else if (mode == kModeAbove) {
+        const bool redraw = v.x % 100u + 1u <= rate_mag;
+        if (ce != 0 && redraw) e_keep = 0;
+        if (redraw) e_del = 0;
+      }
+      e = e_keep;
+      for (;;) {
+        const uint64_t nonins = __ballot(e != 2u);
+        const int roi = ro0 + (int)mbcnt64(nonins);
+        const int wi = roi - wb;  // 0 .. 127 for the columns that count
+        const uint32_t va = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)win_a);
+        const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)win_b);
+        raw = (wi & 64) ? vb : va;
+        uint32_t thr;
+        if (kHpBits) {
+          thr = __builtin_amdgcn_ubfe(em.w, (raw >> 3) & 16u, 16u);
+        } else {
+          const uint32_t ha = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)hp_a);
+          const uint32_t hb = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)hp_b);
+          const uint32_t hp = (wi & 64) ? hb : ha;
+          thr = row[4 + (hp < 12u ? hp : 11u)];
+        }
+        const uint32_t en = (y1 <= thr) ? e_del : e_keep;
+        const bool counts = roi < L && m0 + lane < cap;
+        valid = __ballot(counts);
+        const uint64_t moved = __ballot(counts && ((en != 2u) != (e != 2u)));
+        e = en;
+        if (!moved) break;
+      }
+      if (q0 != 0) break;
+      // Q2: the columns up to and including the first one that emits a base start from the initial-state table
+      const uint64_t emits = __ballot(e != 3u) & valid;
+      const uint64_t qa = emits ? ((2ull << __builtin_ctzll(emits)) - 1ull) : ~0ull;
+      if (((qa ^ qz) & valid) == 0) break;
+      qz = qa;
+    }
+    const int nv = __builtin_popcountll(valid);
+    // ---- emit
+    const uint32_t nt = s_comp[raw + comp_off];
+    uint32_t subb = s_sub[nt * 4u + w3];  // 0 for a non-ACGT reference base
+    if (e == 1u && subb == 0) {
+      if (!have_v) v = walk_block(a.seed, a.unit, read_idx, pass, event, 1u);
+      subb = (kATGC >> ((v.z & 3u) * 8u)) & 0xffu;
+    }
+    const uint32_t cand = nt | (subb << 8) | (ins_base(w.w, nt) << 16);
+    const uint32_t rb = (cand >> (8u * e)) & 0xffu;  // byte e of {nt, substituted, inserted, 0}
+    const uint32_t fb = (e == 2u) ? (uint32_t)'-' : nt;
+    wave_sync();
+    s_tr[lane] = (uint8_t)rb;
+    s_tr[64 + lane] = (uint8_t)fb;
+    wave_sync();
+    if (lane * 4 < nv) {
+      const uint32_t dr = reinterpret_cast<const uint32_t *>(s_tr)[lane];
+      const uint32_t df = reinterpret_cast<const uint32_t *>(s_tr + 64)[lane];
+      scratch_store(&maf_read[(size_t)((m0 >> 2) + lane) * 64], dr);
+      scratch_store(&maf_ref[(size_t)((m0 >> 2) + lane) * 64], df);
+    }
+    nsub += __builtin_popcountll(__ballot(e == 1u) & valid);
+    q0 += __builtin_popcountll(__ballot(e != 3u) & valid);
+    ro0 += __builtin_popcountll(__ballot(e != 2u) & valid);
+    m0 += nv;
+    if (nv > 0) st_in = (uint32_t)__builtin_amdgcn_readlane((int)st, nv - 1);
+    more = nv == 64 && ro0 < L && m0 < cap;
+    if (more && ro0 - wb >= 64) {
+      wb += 64;
+      win_a = win_b;
+      hp_a = hp_b;
+      win_b = ref_at(wb + 64 + lane, &hp_b);
+    }
+  }
+  if (lane == 0) {
+    if (ro0 < L) atomicOr(&a.flags->error, kErrScratchOverflow);
+    a.out_len[task] = q0;
+    a.maf_len[task] = m0;
+    a.nsub[task] = nsub;
+    a.nins[task] = m0 - ro0;
+    a.ndel[task] = m0 - q0;
+  }
+}
+
+template <bool kHpBits>
+__global__ __launch_bounds__(kWG) void k_walk_errhmm_coop(WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (a.flags->error & kErrScratchBudget) return;
+  uint8_t *s_comp = lds + a.stride;
+  uint8_t *s_sub = s_comp + 512;
+  uint8_t *s_w = s_sub + 1024 + wv * kCoopWaveLds;
+  // units of four tasks (one per wave, one class per workgroup), dealt round-robin to the persistent workgroups
+  int staged = -1, c = 0, ubase = 0;
+  for (int u = blockIdx.x;; u += gridDim.x) {
+    int nc = 0;
+    for (; c < a.ncls; c++) {
+      nc = a.coop_end[c] - a.class_start[c];
+      nc = nc > 0 ? nc : 0;
+      const int nu = (nc + 3) >> 2;
+      if (u < ubase + nu) break;
+      ubase += nu;
+    }
+    if (c >= a.ncls) break;
+    if (staged != c) {
+      __syncthreads();  // the other waves may still read the previous class
+      stage_class(a, c, lds, s_comp, s_sub, tid, kHpBits);
+      __syncthreads();
+      staged = c;
+    }
+    const int k = (u - ubase) * 4 + wv;
+    const uint32_t mode = reinterpret_cast<const uint32_t *>(lds)[2];
+    if (k < nc && mode != kModeVerbatim) coop_walk_task<kHpBits>(a, lds, s_comp, s_sub, s_w, a.class_start[c] + k, lane);
   }
 }
 
@@ -2037,6 +2308,13 @@ void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byt
   else if (fast_rv) hipLaunchKernelGGL((k_walk_errhmm<true, false>), grid, block, lds_bytes, s, a);
   else if (hp_bits) hipLaunchKernelGGL((k_walk_errhmm<false, true>), grid, block, lds_bytes, s, a);
   else hipLaunchKernelGGL((k_walk_errhmm<false, false>), grid, block, lds_bytes, s, a);
+}
+
+void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bool hp_bits, hipStream_t s) {
+  const dim3 grid((unsigned)n_wg), block(kWG);
+  lds_bytes += (kWG / 64) * kCoopWaveLds;
+  if (hp_bits) hipLaunchKernelGGL((k_walk_errhmm_coop<true>), grid, block, lds_bytes, s, a);
+  else hipLaunchKernelGGL((k_walk_errhmm_coop<false>), grid, block, lds_bytes, s, a);
 }
 
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,

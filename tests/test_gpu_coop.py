@@ -1,0 +1,74 @@
+"""k_walk_errhmm_coop (one wave per long read) against k_walk_errhmm (one lane per read): the two walks of the ERRHMM
+path must produce the same bytes whatever share of the reads each of them takes.  PBSIM_COOP_LEN picks the share: -1 none,
+0 every read, n the reads of at least n bases (rounded up to the sort's 256-base bucket); the default is three mean lengths,
+and every read of a small batch.  The golden cases (small batches: every read on the wave walker by default) are repeated
+on the lane walker."""
+import numpy as np
+import pytest
+
+import harness
+import product
+from cases import CASES
+from test_gpu_parity import MANIFEST, WGS_ERR
+
+pytestmark = pytest.mark.gpu
+
+
+def genome(n, seed):
+    rng = np.random.default_rng(seed)
+    g = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+    for p in rng.integers(0, n - 40, n // 2000):          # homopolymers past the hp == 11 class, and some non-ACGT bases
+        g[p:p + int(rng.integers(8, 30))] = g[p]
+    for p in rng.integers(0, n - 8, n // 5000):
+        g[p:p + int(rng.integers(1, 6))] = ord("N")
+    return g.tobytes()
+
+
+def run(coop, monkeypatch, records, model="ERRHMM-ONT.model", **kw):
+    import pbsim3_amd as P
+    if coop is None:
+        monkeypatch.delenv("PBSIM_COOP_LEN", raising=False)
+    else:
+        monkeypatch.setenv("PBSIM_COOP_LEN", str(coop))
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, **kw)
+    with P.Context(p, 0) as ctx:
+        ctx.set_scratch_bytes(256 << 20)
+        ctx.load_errhmm(harness.model_path(model))
+        for r in records:
+            ctx.job_add_record(r)
+        outs, done = ctx.job_run()
+    texts = {k: (bytes(v[0]), bytes(v[1])) for k, v in outs.items()}
+    stats = {k: tuple(getattr(v[0], f[0]) for f in v[0]._fields_) + tuple(v[1:]) for k, v in done.items()}
+    return texts, stats
+
+
+RUNS = {
+    "ont_default": dict(seed=7, depth=15.0),
+    "onthq_hp_bias": dict(seed=3, depth=10.0, model="ERRHMM-ONT-HQ.model", hp_del_bias=2.0),
+    "sequel_pass3_short_reads": dict(seed=5, depth=6.0, model="ERRHMM-SEQUEL.model", pass_num=3, len_mean=3000.0, len_sd=2500.0),
+    "rsii_high_accuracy": dict(seed=11, depth=8.0, model="ERRHMM-RSII.model", accuracy_mean=0.99),
+    "ont_low_accuracy_deletions": dict(seed=13, depth=8.0, accuracy_mean=0.70, sub_ratio=1, ins_ratio=1, del_ratio=8),
+    "ont_short_min_length": dict(seed=17, depth=8.0, len_mean=400.0, len_sd=300.0, len_min=1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_wave_walker_matches_lane_walker(name, monkeypatch):
+    recs = [genome(1_500_000, 1), genome(700_000, 2)]
+    want = run(-1, monkeypatch, recs, **RUNS[name])
+    assert sum(len(a) + len(b) for a, b in want[0].values()) > 10_000_000
+    for coop in (0, None, 4096, 20000):
+        got = run(coop, monkeypatch, recs, **RUNS[name])
+        assert got[1] == want[1], (name, coop)
+        for k in want[0]:
+            assert got[0][k] == want[0][k], (name, coop, k)
+
+
+@pytest.mark.parametrize("case", WGS_ERR + ["wgs_errhmm_sequel_pass3"])
+@pytest.mark.parametrize("coop", [-1, 512])
+def test_goldens_with_another_share(case, coop, monkeypatch):
+    monkeypatch.setenv("PBSIM_COOP_LEN", str(coop))
+    outs, _ = product.run_wgs_job(harness.resolve(CASES[case]["args"]), scratch_mb=32 if "default" in case else 4)
+    gold = MANIFEST[f"{case}/philox"]
+    for k, v in outs.items():
+        assert harness.sha(v) == gold[k]["sha256"], (case, coop, k)
