@@ -486,21 +486,23 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
   return walk_begin(c, current_ref(c), first_read, n_reads, truncate_remaining);
 }
 
-// Reads of at least this length are walked by a whole wave each (k_walk_errhmm_coop) instead of one lane: the reads whose
-// lane walk would outlast the rest of the batch, and every read of a small batch (top-up rounds, the truncated tail reads
-// whose latency a record's completion waits for).  A column costs the wave walker about four times the instructions it
-// costs the lane walker, so on a GPU that several rounds keep busy the share must stay small: four mean lengths (1 % of the
-// reads, 2.6 % of the bases of the default length distribution; same-box sweep in profiles/r02z_coop_sweep.txt); a
-// smaller batch ends with its longest lane all the sooner, three mean lengths there.  A multiple of 256 (the sort's length
-// bucket).  PBSIM_COOP_LEN overrides: -1 never, n >= 0 that length.
-// A batch of a million reads hides its longest lane behind its own bulk (n * mean / 286 Gbases/s > 8 mean lengths * 0.42 us
-// whatever the mean): no wave walker there (the two-giant-batches steady state lost 5 % with it).
-constexpr int kCoopWorkgroups = 512, kCoopSmallBatch = 2048, kCoopLargeBatch = 300000, kCoopHugeBatch = 1000000;
+// Reads of at least this length are walked by a whole wave each (k_walk_errhmm_coop) instead of one lane.  A lane needs
+// ~0.4 us per column whatever else the GPU does, so a launch lasts as long as its longest read (~30 ms for the default
+// length distribution) unless its bulk lasts longer; the wave walker takes a read through in ~40 cycles per column but
+// moves a third of the lane walker's columns per second when the GPU is full (100 against 286 G columns/s).  The split that
+// ends both at the same time grows with the batch (same-box sweep, one launch at a time, profiles/r02z_coop_split.txt:
+// 50 k reads 34 -> 5.8 ms from half a mean length, 100 k 34 -> 8.1 ms from one, 200 k 36 -> 12 ms from 1.5, 450 k
+// 36 -> 19 ms from 2-3; the job pipeline, three rounds of 450 k reads in flight, is flat from 2.5 to 4): mean length x
+// reads / 150 k, between 0.5 and 4; small batches (top-up rounds, the truncated tail reads a record's completion waits
+// for) go to the wave walker entirely, and a batch of a million reads hides its longest lane behind its own bulk.
+// A multiple of 256 (the sort's length bucket).  PBSIM_COOP_LEN overrides: -1 never, n >= 0 that length.
+constexpr int kCoopWorkgroups = 1024, kCoopSmallBatch = 20000, kCoopHugeBatch = 1000000;
 static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads) {
   if (c->p.method != PBSIM_METHOD_ERR || !c->ect.all_rv_1000 || c->ect.smax > kCoopMaxStates) return INT32_MAX;
   const char *env = getenv("PBSIM_COOP_LEN");
   const int64_t n_tasks = n_reads * c->p.pass_num;
-  int64_t len = n_tasks <= kCoopSmallBatch ? 0 : (int64_t)((n_tasks >= kCoopLargeBatch ? 4.0 : 3.0) * c->hdr.mean_len);
+  int64_t len = (int64_t)(std::min(4.0, std::max(0.5, (double)n_tasks / 150000.0)) * c->hdr.mean_len);
+  if (n_tasks <= kCoopSmallBatch) len = 0;
   if (n_tasks >= kCoopHugeBatch) len = -1;
   if (env) len = atoll(env);
   if (len < 0) return INT32_MAX;
@@ -559,7 +561,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   // The pool is the budget, unless this batch cannot need that much: a wave's rows hold at most 2 * Lmax + pad columns
   // (Lmax = the longest read the header can draw), so a handful of reads (the truncated tail reads) gets by with little.
   const double lmax = (double)std::min<int64_t>(c->p.len_max, std::max<int64_t>(ref.len, 1));
-  const double worst = (double)waves_max * regions_of(c) * (2.0 * lmax + kScratchPad + 4) * 64.0;
+  const double worst = (double)waves_max * regions_of(c) * (2.0 * lmax + kScratchPad + 64) * 64.0;
   const int64_t pool = std::max<int64_t>((int64_t)c->s().d_scratch.bytes - (int64_t)kScratchSlack,
                                          (int64_t)std::min<double>((double)c->scratch_budget, worst));
   HIP_OK(c->s().d_scratch.ensure((size_t)pool + kScratchSlack, true));
@@ -613,6 +615,13 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   s.coop_end = s.class_start + ncls + 1;
   const int32_t coop_len = coop_min_len(c, n_reads);
   s.coop_bucket = coop_len == INT32_MAX ? kLenBuckets : coop_len >> kLenShift;
+  s.coop_classes = 0;
+  if (coop_len != INT32_MAX)  // verbatim classes (no HMM at all) stay with the lane walker
+    for (int i = 0; i < ncls; i++) {
+      uint32_t mode;
+      memcpy(&mode, c->ect.blob.data() + (size_t)i * c->ect.stride + 8, 4);
+      if (mode != kModeVerbatim) s.coop_classes |= 1ull << i;
+    }
   s.task_of_slot = c->s().d_task_of_slot.as<int32_t>();
   s.slot_of_task = c->s().d_slot_of_task.as<int32_t>();
   s.wave_cap = c->s().d_wave_cap.as<int32_t>();

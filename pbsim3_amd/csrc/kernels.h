@@ -18,6 +18,10 @@ constexpr int kBinPad = PBSIM_BIN_PAD;  // int32 slots per counter of the sort's
 constexpr int kLenShift = 8;        // bucket = len >> 8  (len_max 1e6 -> 3907 buckets)
 constexpr int kScratchPad = 64;     // per-task slack: cap = 2*L + kScratchPad columns (pbsim.cpp:5488 uses 2*len_max+1)
 constexpr int kMaxClasses = 64;
+// wave_cap[w] bit 30: the 64 tasks of this scratch block are all walked by k_walk_errhmm_coop and its rows are stored task
+// by task (row r of task l at r * cap * 256 + l * cap * 4 bytes) instead of interleaved dword by dword: a wave that walks
+// ONE read writes 64 consecutive bytes per row and step there, not sixteen dwords 256 bytes apart
+constexpr int32_t kWaveTransposed = 1 << 30;
 constexpr int kHpTile = 4096;       // bases per workgroup in the homopolymer kernels
 
 // error flag bits written by kernels into EngineFlags::error
@@ -79,6 +83,7 @@ struct SortArgs {
   int32_t *class_start; // [ncls+1], multiples of kWG
   int32_t coop_bucket;  // tasks of length bucket >= coop_bucket are walked by k_walk_errhmm_coop (kLenBuckets: none)
   int32_t *coop_end;    // [ncls] end of those tasks' slots: they are the first of their class (longest first)
+  uint64_t coop_classes; // bit c: class c takes part (not a verbatim class)
   int32_t *task_of_slot;
   int32_t *slot_of_task;
   int32_t *wave_cap;    // [n_waves_max] dwords per lane per region

@@ -463,7 +463,8 @@ __global__ __launch_bounds__(kScanBlock) void k_sort_scan(SortArgs a) {
     }
     const int base = s_base;
     int run = base + s_part[tid] - sum;
-    const int first_short = kLenBuckets - a.coop_bucket;  // bins are in descending length: the long reads' bins come first
+    // bins are in descending length: the long reads' bins come first (none in a class that takes no part)
+    const int first_short = ((a.coop_classes >> c) & 1ull) ? kLenBuckets - a.coop_bucket : 0;
     for (int k = 0; k < kPer; k++) {
       a.bin_start[c * kLenBuckets + tid * kPer + k] = run;
       if (tid * kPer + k == first_short) a.coop_end[c] = run;
@@ -502,17 +503,22 @@ __global__ __launch_bounds__(256) void k_wave_cap(SortArgs a) {
   const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n_waves = a.n_slots_max / 64;
   if (w >= n_waves) return;
-  int lmax = -1;
+  int lmax = -1, lmin = 0x7fffffff, cls = 0;
   if (w * 64 < a.flags->total_slots) {
     for (int l = 0; l < 64; l++) {
       const int task = a.task_of_slot[w * 64 + l];
       if (task >= 0) {
         const int L = a.len[task / a.pass_num];
         lmax = (L > lmax) ? L : lmax;
+        lmin = (L < lmin) ? L : lmin;
+        cls = a.acc[task / a.pass_num] - a.acc_lo;
       }
     }
   }
-  a.wave_cap[w] = (lmax < 0) ? 0 : (2 * lmax + kScratchPad + 3) / 4;
+  // rows of whole 64-byte lines; a block whose tasks all belong to the wave walker is stored task by task
+  const int cap = (lmax < 0) ? 0 : ((2 * lmax + kScratchPad + 3) / 4 + 15) & ~15;
+  const bool coop = lmax >= 0 && a.coop_bucket < kLenBuckets && (lmin >> kLenShift) >= a.coop_bucket && ((a.coop_classes >> cls) & 1ull);
+  a.wave_cap[w] = cap | (coop ? kWaveTransposed : 0);
 }
 
 __global__ __launch_bounds__(kScanBlock) void k_wave_scan(SortArgs a) {
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(kScanBlock) void k_wave_scan(SortArgs a) {
     long long v[kPer], sum = 0;
     for (int k = 0; k < kPer; k++) {
       const int64_t w = w0 + (int64_t)tid * kPer + k;
-      v[k] = (w < n_waves) ? (long long)a.wave_cap[w] * 256LL * a.regions : 0;
+      v[k] = (w < n_waves) ? (long long)(a.wave_cap[w] & ~kWaveTransposed) * 256LL * a.regions : 0;
       sum += v[k];
     }
     s_part[tid] = sum;
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     // strand: wgs by parity of the read number (pbsim.cpp:3820-3826, Q9); trans by expression (:4516-4522)
     minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
   }
-  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);  // wave-uniform: keeps row offsets scalar
+  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]) & ~kWaveTransposed;  // wave-uniform: keeps row offsets scalar
   walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
   const int64_t woff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.wave_off[wave] >> 32)) << 32) |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wave_off[wave]);
@@ -995,8 +1001,13 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
   const int64_t off = a.off[r] + (a.read_base ? a.read_base[r] : 0);
   const bool minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
   const int64_t wave = slot >> 6;
-  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);
-  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + (slot & 63);
+  const int cap_raw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);
+  const int cap_dw = cap_raw & ~kWaveTransposed;
+  // a block of wave-walked tasks only keeps each task's rows contiguous (kWaveTransposed); in the one block per class that
+  // also holds lane-walked tasks the rows are interleaved dword by dword
+  const bool transposed = (cap_raw & kWaveTransposed) != 0;
+  const size_t row_step = transposed ? 1 : 64;
+  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + (transposed ? (size_t)(slot & 63) * cap_dw : (size_t)(slot & 63));
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
   const int cap = 2 * L + kScratchPad;
   const uint32_t comp_off = minus ? 256u : 0u;
@@ -1093,12 +1104,14 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
     s_tr[lane] = (uint8_t)rb;
     s_tr[64 + lane] = (uint8_t)fb;
     wave_sync();
+#ifndef PBSIM_COOP_NOSTORE  // experiment: the walk without its scratch writes
     if (lane * 4 < nv) {
       const uint32_t dr = reinterpret_cast<const uint32_t *>(s_tr)[lane];
       const uint32_t df = reinterpret_cast<const uint32_t *>(s_tr + 64)[lane];
-      scratch_store(&maf_read[(size_t)((m0 >> 2) + lane) * 64], dr);
-      scratch_store(&maf_ref[(size_t)((m0 >> 2) + lane) * 64], df);
+      scratch_store(&maf_read[(size_t)((m0 >> 2) + lane) * row_step], dr);
+      scratch_store(&maf_ref[(size_t)((m0 >> 2) + lane) * row_step], df);
     }
+#endif
     nsub += __builtin_popcountll(__ballot(e == 1u) & valid);
     q0 += __builtin_popcountll(__ballot(e != 3u) & valid);
     ro0 += __builtin_popcountll(__ballot(e != 2u) & valid);
@@ -2062,7 +2075,9 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     mmax = __shfl(v, 0, 64);
   }
   if (mmax == 0) return;
-  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);  // wave-uniform: keeps row offsets scalar
+  const int cap_raw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);  // wave-uniform: keeps row offsets scalar
+  const int cap_dw = cap_raw & ~kWaveTransposed;
+  const bool transposed = (cap_raw & kWaveTransposed) != 0;  // rows stored task by task (k_walk_errhmm_coop)
   const uint32_t *region =
       reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave] + (size_t)pass * cap_dw * 256);
   uint32_t *tile = s_tile + wv * 16 * kTileStride;
@@ -2075,9 +2090,10 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
   // tile are issued before this tile is served, so their latency hides behind the four serving steps
   // (no bounds checks: columns past a row's end are never used, and the pool ends with kScratchSlack bytes of slack)
   uint32_t pre[16];
-  const uint32_t *lane_src = region + wv * 16 + lt + (size_t)(16 * lc) * 64;
+  const uint32_t *lane_src = transposed ? region + (size_t)(wv * 16 + lt) * cap_dw + 16 * lc : region + wv * 16 + lt + (size_t)(16 * lc) * 64;
+  const size_t dw_step = transposed ? 1 : 64;  // dword d of the lane's task: interleaved 64 dwords apart, transposed adjacent
 #pragma unroll
-  for (int c = 0; c < 16; ++c) pre[c] = scratch_load(lane_src + (size_t)c * 64);
+  for (int c = 0; c < 16; ++c) pre[c] = scratch_load(lane_src + (size_t)c * dw_step);
   for (int s0 = 0, t = 0; s0 < mmax; s0 += 256, ++t) {
     // carry: the previous tile's last 16 bytes move in front (lane = task row x dword)
     if (t > 0) tile[lt * kTileStride + lc] = tile[lt * kTileStride + 64 + lc];
@@ -2088,7 +2104,7 @@ __global__ __launch_bounds__(256) void k_text_rows(TextArgs a, const DeviceFlags
     if (s0 + 256 < mmax) {
       const int c1 = (s0 + 256) >> 2;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) pre[c] = scratch_load(lane_src + (size_t)(c1 + c) * 64);
+      for (int c = 0; c < 16; ++c) pre[c] = scratch_load(lane_src + (size_t)(c1 + c) * dw_step);
     }
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {
