@@ -188,6 +188,8 @@ struct Slot {
   hipEvent_t ev_prep = nullptr;        // header + sort done (walk_stream waits for it)
   hipStream_t coop_stream = nullptr;   // the long reads' walk (k_walk_errhmm_coop), beside the batch's lane walk
   hipEvent_t ev_coop = nullptr;
+  hipEvent_t ev_text = nullptr;        // the batch's text has been emitted (finalize_text; waited for by whoever reads the text
+                                       // on another stream or thread when pbsim_ctx::defer_text_sync)
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
   bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
   int64_t b_pass0 = 0;
@@ -245,6 +247,7 @@ struct pbsim_ctx {
   int64_t scratch_budget = 0;  // bytes of wave scratch per slot
   bool scratch_auto = true;    // sized per record by pbsim_simulate_wgs unless PBSIM_SCRATCH_MB / pbsim_set_scratch_bytes said otherwise
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
+  bool defer_text_sync = false;  // finalize_text returns once the sizes are known; the text emission is still in flight (job pipeline)
   int walk_lds_kb = 27;        // walk workgroups per CU: 27 KB -> five (batch primitives), 41 KB -> three (the job pipeline)
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
   int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)

@@ -262,6 +262,7 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
     }
     (void)hipEventCreateWithFlags(&sl.ev_prep, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&sl.ev_coop, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&sl.ev_text, hipEventDisableTiming);
     if (hipStreamCreateWithPriority(&sl.coop_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) sl.coop_stream = nullptr;
     (void)hipEventCreate(&sl.ev0);
     (void)hipEventCreate(&sl.ev1);
@@ -299,6 +300,7 @@ void pbsim_destroy(pbsim_ctx *c) {
     if (sl.ev_prep) (void)hipEventDestroy(sl.ev_prep);
     if (sl.coop_stream) (void)hipStreamDestroy(sl.coop_stream);
     if (sl.ev_coop) (void)hipEventDestroy(sl.ev_coop);
+    if (sl.ev_text) (void)hipEventDestroy(sl.ev_text);
   }
   if (c->ev_prof_base) (void)hipEventDestroy(c->ev_prof_base);
   if (c->prefetch_stream) (void)hipStreamDestroy(c->prefetch_stream);
@@ -876,7 +878,9 @@ extern "C++" int pbsim::finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
     t.maf_text = c->s().d_maf_text.as<char>();
     launch_text_emit(t, c->s().b_slots_max, flags, c->s().stream);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(c->s().stream));
+    HIP_OK(hipEventRecord(c->s().ev_text, c->s().stream));
+    // the job pipeline's round loop does not wait for the emission (5-8 ms a round): its delivery thread does (ev_text)
+    if (!c->defer_text_sync) HIP_OK(hipStreamSynchronize(c->s().stream));
   }
   c->s().b_info = bi;
   c->s().b_finalized = true;

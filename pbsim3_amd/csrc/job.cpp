@@ -372,7 +372,9 @@ struct Job {
     worker.post([this, sl, R, prom, sizes, read_at, maf_at]() {
       const double w0 = now_us();
       int ok = PBSIM_SUCCEEDED;
-      if (!wants_text()) {
+      if (wants_text() && hipEventSynchronize(sl->ev_text) != hipSuccess) ok = fail("hipEventSynchronize failed (text emission)");
+      if (!ok) {
+      } else if (!wants_text()) {
         sizes[0] = sizes[1] = 0;
       } else if (!deflated()) {
         ok = fetch_plain(*sl);
@@ -487,8 +489,10 @@ struct Job {
       worker.post([this, sl, Rp, slot]() {  // FIFO behind the record's bulk deliveries: offsets and accounting stay in read order
         int ok = PBSIM_SUCCEEDED;
         int64_t nr = 0, nm = 0;
+        if (wants_text() && hipEventSynchronize(sl->ev_text) != hipSuccess) ok = fail("hipEventSynchronize failed (text emission)");
         const int64_t read_at = Rp->read_off + Rp->tail_read, maf_at = Rp->maf_off + Rp->tail_maf;
-        if (deflated()) {
+        if (!ok) {
+        } else if (deflated()) {
           ok = stream_deflated(*sl, Rp->ref.unit, read_at, maf_at, &nr, &nm);
         } else if (wants_text()) {
           ok = fetch_plain(*sl) && sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
@@ -933,8 +937,12 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   if (J.deflated() && !ensure_deflate_ready(c)) return PBSIM_FAILED;  // before the worker and its lane threads use the tables
   const int keep_lds = c->walk_lds_kb;
   c->walk_lds_kb = 41;  // three walk workgroups per CU: the round loop waits on many short kernels (kernels.hip walk_lds)
-  const int ok = J.run();
+  c->defer_text_sync = true;  // the round loop does not wait for a round's text emission; the delivery thread does
+  int ok = J.run();
+  c->defer_text_sync = false;
   c->walk_lds_kb = keep_lds;
+  for (Slot &sl : c->slots)  // text left in HBM (no sink): its emission ends with the job
+    if (sl.stream && hipStreamSynchronize(sl.stream) != hipSuccess && ok) ok = fail("hipStreamSynchronize failed at the end of the job");
   if (!ok) {
     const std::string keep = g_err;
     J.drop_everything();
