@@ -188,6 +188,7 @@ struct Slot {
   hipEvent_t ev_prep = nullptr;        // header + sort done (walk_stream waits for it)
   hipStream_t coop_stream = nullptr;   // the long reads' walk (k_walk_errhmm_coop), beside the batch's lane walk
   hipEvent_t ev_coop = nullptr;
+  bool stats_fetched = false;          // the per-task counters of the final reads are already in h_stats (finalize_text, deferred mode)
   hipEvent_t ev_text = nullptr;        // the batch's text has been emitted (finalize_text; waited for by whoever reads the text
                                        // on another stream or thread when pbsim_ctx::defer_text_sync)
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;

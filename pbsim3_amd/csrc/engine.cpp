@@ -263,7 +263,9 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
     (void)hipEventCreateWithFlags(&sl.ev_prep, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&sl.ev_coop, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&sl.ev_text, hipEventDisableTiming);
-    if (hipStreamCreateWithPriority(&sl.coop_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) sl.coop_stream = nullptr;
+    // (normal priority: streams of one priority share a few hardware queues, and a packet waits for the one in front of it in
+    // its queue -- a 10 ms walk of long reads among the HIGH priority streams held up other slots' flag reads for 30 ms)
+    if (hipStreamCreateWithFlags(&sl.coop_stream, hipStreamNonBlocking) != hipSuccess) sl.coop_stream = nullptr;
     (void)hipEventCreate(&sl.ev0);
     (void)hipEventCreate(&sl.ev1);
     (void)hipEventCreate(&sl.ev2);
@@ -724,6 +726,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   c->s().b_enqueued = true;
   c->s().b_walked = false;
   c->s().b_finalized = false;
+  c->s().stats_fetched = false;
   return PBSIM_SUCCEEDED;
 }
 
@@ -846,6 +849,7 @@ extern "C++" int pbsim::finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbs
 }
 
 // Second half: text sizes, their scans, and the text itself into the slot's device buffers.
+static int fetch_stats(pbsim_ctx *c, Slot &sl, int64_t n_tasks);
 extern "C++" int pbsim::finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
   DeviceFlags *flags = c->s().d_flags.as<DeviceFlags>();
   DeviceFlags f;
@@ -857,6 +861,10 @@ extern "C++" int pbsim::finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
     HIP_OK(c->s().d_rt_len.ensure(n_tasks * 8));
     HIP_OK(c->s().d_mt_len.ensure(n_tasks * 8));
     HIP_OK(c->s().d_row_dst.ensure(n_tasks * 6 * 8));
+    // deferred mode: the counters the statistics need travel now, in front of the text emission this call no longer waits
+    // for (the read_flags below waits for them): pbsim_batch_account then finds them in place
+    c->s().stats_fetched = c->defer_text_sync;
+    if (c->defer_text_sync && !fetch_stats(c, c->s(), n_tasks)) return PBSIM_FAILED;
     HIP_OK(hipMemsetAsync(&flags->sums[1], 0, 5 * sizeof(int64_t), c->s().stream));
     TextArgs t;
     fill_text_args(c, &t, n_final);
@@ -910,13 +918,8 @@ int pbsim_batch_fetch(pbsim_ctx *c, char *read_text, char *maf_text) {
 
 // pbsim.cpp:3986-4005 (errhmm) / 2293-2316 (qshmm), applied in read order so the
 // order-dependent double sum `accuracy_total` matches the CPU bit for bit
-extern "C++" int pbsim::account_of(pbsim_ctx *c, Slot &sl, StatsAcc *st) {
-  if (!c || !sl.b_finalized) return fail("pbsim_batch_account: no finalized batch");
-  NEED_DEVICE(c);
-  HIP_OK(hipSetDevice(c->device));
-  const int P = c->p.pass_num;
-  const int64_t n_tasks = sl.b_info.n_final * P;
-  if (n_tasks == 0) return PBSIM_SUCCEEDED;
+// the per-task counters of the batch's final reads -> h_stats (pinned), asynchronously on the slot's stream
+static int fetch_stats(pbsim_ctx *c, Slot &sl, int64_t n_tasks) {
   HIP_OK(sl.h_stats.ensure((size_t)n_tasks * 24));
   int32_t *ol = reinterpret_cast<int32_t *>(sl.h_stats.p);
   int32_t *ns = ol + n_tasks, *ni = ns + n_tasks, *nd = ni + n_tasks;
@@ -925,9 +928,25 @@ extern "C++" int pbsim::account_of(pbsim_ctx *c, Slot &sl, StatsAcc *st) {
   HIP_OK(hipMemcpyAsync(ns, sl.d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
   HIP_OK(hipMemcpyAsync(ni, sl.d_nins.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
   HIP_OK(hipMemcpyAsync(nd, sl.d_ndel.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
+  if (has_quality_row(c)) HIP_OK(hipMemcpyAsync(qs, sl.d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, sl.stream));
+  return PBSIM_SUCCEEDED;
+}
+
+extern "C++" int pbsim::account_of(pbsim_ctx *c, Slot &sl, StatsAcc *st) {
+  if (!c || !sl.b_finalized) return fail("pbsim_batch_account: no finalized batch");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  const int P = c->p.pass_num;
+  const int64_t n_tasks = sl.b_info.n_final * P;
+  if (n_tasks == 0) return PBSIM_SUCCEEDED;
+  if (!sl.stats_fetched) {  // (deferred mode: finalize_text fetched them in front of the text emission and waited)
+    if (!fetch_stats(c, sl, n_tasks)) return PBSIM_FAILED;
+    HIP_OK(hipStreamSynchronize(sl.stream));
+  }
+  const int32_t *ol = reinterpret_cast<const int32_t *>(sl.h_stats.p);
+  const int32_t *ns = ol + n_tasks, *ni = ns + n_tasks, *nd = ni + n_tasks;
+  const double *qs = reinterpret_cast<const double *>(nd + n_tasks);
   const bool quality = has_quality_row(c);
-  if (quality) HIP_OK(hipMemcpyAsync(qs, sl.d_qsum.p, n_tasks * 8, hipMemcpyDeviceToHost, sl.stream));
-  HIP_OK(hipStreamSynchronize(sl.stream));
   st->res_num += sl.b_info.n_final;
   std::vector<double> *values = nullptr;
   if (st->keep_values) {
