@@ -104,8 +104,11 @@ struct DfLane {
   DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];
   DevBuf d_df_code;                    // the current call's code table (DF_TABLE_BYTES) + its histogram scratch
   HostBuf h_df_total, h_df_out[2];
-  hipStream_t stream = nullptr;        // kernels of this lane
-  hipStream_t copy_stream = nullptr;   // D2H of compressed pieces
+  // kernels of this lane | D2H of compressed pieces: the streams of pbsim_ctx::df_streams (shared by the slots' lanes of the
+  // same index -- one delivery runs at a time, and hardware queues are few: with a pair of streams per slot and lane, which
+  // lanes had their kernels and their copies in ONE queue, one behind the other, was a matter of creation order)
+  hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;
   hipEvent_t ev_df[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
   // Pinned arena that holds ALL compressed pieces of one batch (job.cpp, several ranks): a rank learns where its bytes go in
   // the record's stream only after every rank has compressed its block, so the pieces wait here, D2H-copied straight in.
@@ -248,6 +251,7 @@ struct pbsim_ctx {
   int64_t scratch_budget = 0;  // bytes of wave scratch per slot
   bool scratch_auto = true;    // sized per record by pbsim_simulate_wgs unless PBSIM_SCRATCH_MB / pbsim_set_scratch_bytes said otherwise
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
+  hipStream_t df_streams[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [lane][kernels | copies]
   bool defer_text_sync = false;  // finalize_text returns once the sizes are known; the text emission is still in flight (job pipeline)
   int walk_lds_kb = 27;        // walk workgroups per CU: 27 KB -> five (batch primitives), 41 KB -> three (the job pipeline)
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text

@@ -291,8 +291,6 @@ void pbsim_destroy(pbsim_ctx *c) {
     if (sl.ev3) (void)hipEventDestroy(sl.ev3);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
     for (DfLane &L : sl.df) {
-      if (L.stream) (void)hipStreamDestroy(L.stream);
-      if (L.copy_stream) (void)hipStreamDestroy(L.copy_stream);
       for (int i = 0; i < 2; i++) {
         if (L.ev_df[i]) (void)hipEventDestroy(L.ev_df[i]);
         if (L.ev_cp[i]) (void)hipEventDestroy(L.ev_cp[i]);
@@ -304,6 +302,9 @@ void pbsim_destroy(pbsim_ctx *c) {
     if (sl.ev_coop) (void)hipEventDestroy(sl.ev_coop);
     if (sl.ev_text) (void)hipEventDestroy(sl.ev_text);
   }
+  for (auto &lane : c->df_streams)
+    for (hipStream_t &st : lane)
+      if (st) (void)hipStreamDestroy(st);
   if (c->ev_prof_base) (void)hipEventDestroy(c->ev_prof_base);
   if (c->prefetch_stream) (void)hipStreamDestroy(c->prefetch_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1042,7 +1043,12 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   HIP_OK(sl.h_df_total.ensure(16));
   HIP_OK(sl.d_df_code.ensure(DF_TABLE_BYTES + 288 * 4));
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
-  if (!sl.stream) HIP_OK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+  int lane_index = 0;
+  for (Slot &slot : c->slots)
+    if (&slot.df[1] == &sl) lane_index = 1;
+  for (int i = 0; i < 2; i++)
+    if (!c->df_streams[lane_index][i]) HIP_OK(hipStreamCreateWithFlags(&c->df_streams[lane_index][i], hipStreamNonBlocking));
+  sl.stream = c->df_streams[lane_index][0];
   // the call's code table: fitted once to the head of the text (deflate.hip), shared by all its members
   launch_deflate_table(d_text, n, reinterpret_cast<uint32_t *>(sl.d_df_code.as<uint8_t>() + DF_TABLE_BYTES), sl.d_df_code.p, sl.stream);
   unsigned long long *d_prof = nullptr;
@@ -1053,7 +1059,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   }
   // Copies run on their own stream: the D2H of piece k-1 overlaps the kernels of piece k (and the host's consume()).
   if (!sl.copy_stream) {
-    HIP_OK(hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking));
+    sl.copy_stream = c->df_streams[lane_index][1];
     for (int i = 0; i < 2; i++) {
       HIP_OK(hipEventCreateWithFlags(&sl.ev_df[i], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&sl.ev_cp[i], hipEventDisableTiming));
@@ -1063,6 +1069,10 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   const char *pending_ptr = nullptr;
   bool used[2] = {false, false};
   int k = 0;
+  const bool trace = getenv("PBSIM_DEFLATE_TRACE") != nullptr;  // where a call's wall time goes: kernels | link | consumer
+  const auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_kernel = 0, t_copy = 0, t_consume = 0, t_begin = now();
+  int64_t out_bytes = 0;
   for (int64_t off = 0; off < n; off += piece, k ^= 1) {
     const int64_t len = std::min(piece, n - off);
     const int64_t nch = (len + DF_CHUNK - 1) / DF_CHUNK;
@@ -1074,8 +1084,11 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(sl.h_df_total.p, sl.d_df_offsets.as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
     HIP_OK(hipEventRecord(sl.ev_df[k], sl.stream));
+    const double t0 = now();
     HIP_OK(hipStreamSynchronize(sl.stream));
+    t_kernel += now() - t0;
     const int64_t total = *reinterpret_cast<int64_t *>(sl.h_df_total.p);
+    out_bytes += total;
     HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[k], 0));
     char *dst = place ? (*place)(total) : (char *)sl.h_df_out[k].p;
     if (!dst) return fail("deflate: no room for a compressed piece");
@@ -1083,13 +1096,24 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     HIP_OK(hipEventRecord(sl.ev_cp[k], sl.copy_stream));
     used[k] = true;
     if (pending) {
+      const double t1 = now();
       HIP_OK(hipEventSynchronize(sl.ev_cp[k ^ 1]));
+      const double t2 = now();
       if (!consume(pending_ptr, pending)) return PBSIM_FAILED;
+      t_copy += t2 - t1;
+      t_consume += now() - t2;
     }
     pending = total;
     pending_ptr = dst;
   }
-  HIP_OK(hipStreamSynchronize(sl.copy_stream));
+  {
+    const double t1 = now();
+    HIP_OK(hipStreamSynchronize(sl.copy_stream));
+    t_copy += now() - t1;
+  }
+  if (trace)
+    fprintf(stderr, "[deflate] %.1f MB -> %.1f MB in %.1f ms: waited %.1f ms for kernels, %.1f ms for copies, %.1f ms in the consumer\n",
+            n / 1e6, out_bytes / 1e6, now() - t_begin, t_kernel, t_copy, t_consume);
   if (d_prof) {
     unsigned long long t[16];
     HIP_OK(hipMemcpy(t, d_prof, 128, hipMemcpyDeviceToHost));

@@ -393,7 +393,18 @@ struct Job {
     });
   }
   // collective: exchange the sizes of the pending round, place every rank's bytes, hand the rest to the worker
-  int complete_pending() {
+  // `defer_account`: the caller hands the worker its next round first and calls account_deferred() right after (the
+  // statistics of 450 k reads take the main thread ~10 ms, during which the link would idle)
+  Slot *acct_slot = nullptr;
+  Rec *acct_rec = nullptr;
+  int account_deferred() {
+    if (!acct_slot) return PBSIM_SUCCEEDED;
+    Slot *sl = acct_slot;
+    acct_slot = nullptr;
+    return account_of(c, *sl, &acct_rec->st);
+  }
+  int complete_pending(bool defer_account = false) {
+    if (!account_deferred()) return PBSIM_FAILED;
     if (!pending) return PBSIM_SUCCEEDED;
     std::unique_ptr<Delivery> d = std::move(pending);
     Rec &R = recs[(size_t)d->rec];
@@ -423,7 +434,9 @@ struct Job {
       const bool flush = deflated() && W > 1, plain = wants_text() && !deflated();
       // The per-task statistics are accounted HERE, on the main loop (it waits for the link most of the time), not on the
       // worker, whose time is the link's: rounds are completed in the order of the reads, so accuracy_total keeps its order.
-      if (!account_of(c, *sl, &R.st)) return PBSIM_FAILED;
+      acct_slot = sl;
+      acct_rec = &R;
+      if (!defer_account && !account_deferred()) return PBSIM_FAILED;
       if (flush || plain) {
         worker.post([this, sl, Rp, slot, flush, read_at, maf_at]() {
           const int ok = flush ? arena_flush(*sl, Rp->ref.unit, read_at, maf_at) : sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
@@ -624,13 +637,14 @@ struct Job {
     const bool mine = rank <= last_valid && bi.n_final > 0;
     // ---- delivery: the previous round's sizes first (its bytes have been on their way while this round was finalised), then
     // this round's bytes start moving
-    if (!complete_pending()) return PBSIM_FAILED;
+    if (!complete_pending(true)) return PBSIM_FAILED;
     pending.reset(new Delivery);
     pending->slot = rd.slot;
     pending->rec = rd.rec;
     pending->mine = mine;
     pending->n_per = rd.n_per;
     submit_stage1(pending.get());
+    if (!account_deferred()) return PBSIM_FAILED;  // the previous round's statistics, while the worker moves this round's bytes
     if (mine) {
       reads_delivered += bi.n_final;
       bases += bi.bases;
