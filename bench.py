@@ -482,9 +482,9 @@ def main():
                          "launches": launches,
                          "tail_read_launches": {"launches": tail_launches, "avg_ms": tail_ms / max(1, tail_launches),
                                                 "note": "walk launches that carry one truncated tail read (the latency of a single "
-                                                        "lane): counted apart from the launches above"},
+                                                        "read; the wave walker k_walk_errhmm_coop takes ERRHMM ones): counted apart from the launches above"},
                          "note": "achieved = algorithmic bytes of the path (SURVEY 8d: 1 ref + 2 read + 2 quality... per base) of rank 0's "
-                                 "delivered reads / summed duration of its walk launches (HIP events on the walk streams, every launch of "
+                                 "delivered reads / summed duration of its walk launches (a launch = the lane walker + the wave walker of the batch's long reads beside it; HIP events on the walk streams, every launch of "
                                  "the timed region incl. tail reads); walks of different slots overlap, so walk_busy counts that time once",
                          "walk_busy_ms": walk_busy_ms,
                          "achieved_busy": alg_bytes / (walk_busy_ms / 1e3) / 1e9 if walk_busy_ms > 0 else None,
