@@ -72,3 +72,19 @@ def test_goldens_with_another_share(case, coop, monkeypatch):
     gold = MANIFEST[f"{case}/philox"]
     for k, v in outs.items():
         assert harness.sha(v) == gold[k]["sha256"], (case, coop, k)
+
+
+def test_split_on_several_ranks(tmp_path, monkeypatch):
+    """the rounds of a multi-rank job with both walkers at work: thread ranks on one GPU vs the oracle"""
+    from test_gpu_multi import run_devices
+    args = ["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-ONT-HQ.model", "--genome", "INPUT:quirk.fa",
+            "--depth", "40", "--seed", "4", "--length-mean", "1500", "--length-sd", "1100"]
+    (tmp_path / "o").mkdir()
+    want = harness.run_oracle(args, "philox", str(tmp_path / "o"))
+    for coop in ("1024", "2560"):
+        monkeypatch.setenv("PBSIM_COOP_LEN", coop)
+        d = tmp_path / ("m" + coop)
+        d.mkdir()
+        got = run_devices(args, str(d), 3, scratch_mb=6)
+        for k in want:
+            assert got[k] == want[k], (coop, k)
