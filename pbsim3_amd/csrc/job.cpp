@@ -858,9 +858,13 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   J.trace = getenv("PBSIM_TRACE") != nullptr;
   J.t_start = now_us();
   const char *jd = getenv("PBSIM_JOB_DEPTH");
-  // rounds in flight: + one pending delivery < the slots of the rounds
-  J.depth = std::max(1, std::min(kMaxSlots - 3, jd ? atoi(jd) : 3));
+  // Rounds in flight (+ one pending delivery < the slots of the rounds).  Three keep a GPU full whose text stays in HBM or whose
+  // link carries a fraction of the job (several ranks).  A job that delivers all its bytes over one or two links is bound by
+  // them (80 ms a round against 18 ms of walk): one round in flight is as fast (1334 vs 1336 ms), its walk does not share the
+  // GPU with two others (18.5 instead of 29.3 ms a launch) and half the slots stay unallocated.
   const int W = J.W;
+  const bool delivers = J.sink && (J.sink->on_read_text || J.sink->on_maf_text);
+  J.depth = std::max(1, std::min(kMaxSlots - 3, jd ? atoi(jd) : (delivers && W <= 2 ? 1 : 3)));
   // ---- the records' preparation (upload + k_hp_*) has been running since pbsim_job_add_record: collect it
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));
   const size_t n = c->job_records.size();
