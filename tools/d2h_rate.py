@@ -1,0 +1,53 @@
+"""GPU box: what the PCIe link moves device -> pinned host memory with the copy engines: one stream and two streams at once,
+pieces of 83 MB (a compressed MAF piece) and 256 MB; idle GPU and with a compute kernel running beside the copies.
+usage: python tools/d2h_rate.py [numa node]"""
+import os
+import sys
+import time
+
+
+def cpus_of(node):
+    out = set()
+    for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+if len(sys.argv) > 1:      # run on (and allocate from) the CPUs of one NUMA node
+    os.sched_setaffinity(0, cpus_of(int(sys.argv[1])))
+import torch
+
+dev = torch.device("cuda", 0)
+
+
+def run(piece_mb, streams, busy):
+    n = piece_mb << 20
+    src = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(streams)]
+    dst = [torch.empty(n, dtype=torch.uint8).pin_memory() for _ in range(streams)]
+    st = [torch.cuda.Stream() for _ in range(streams)]
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device=dev)
+    reps = max(4, 2048 // piece_mb)
+    for warm in (True, False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if busy:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    a = (a @ a).clamp_(-1, 1)
+        for r in range(reps):
+            for i in range(streams):
+                with torch.cuda.stream(st[i]):
+                    dst[i].copy_(src[i], non_blocking=True)
+        for s in st:
+            s.synchronize()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+    return reps * streams * n / dt / 1e9
+
+
+for busy in (False, True):
+    for piece in (83, 256):
+        for streams in (1, 2):
+            print("GPU %s, %3d MB pieces, %d stream(s): %.1f GB/s" % ("busy" if busy else "idle", piece, streams, run(piece, streams, busy)))
