@@ -100,16 +100,19 @@ constexpr double kSinkBatchBases = 5.0e9;  // pbsim_simulate_wgs: expected bases
 // One deflate pipeline: staging for one piece of DF_PIECE_CHUNKS chunks, double-buffered dense output + pinned copies, its
 // own streams.  A slot owns two, so that its read text and its MAF text can be compressed, copied and handed to their
 // sinks side by side (pbsim_set_deflate bit 2).
+constexpr int kDfBuffers = 3;
 struct DfLane {
-  DevBuf d_df_slots, d_df_sizes, d_df_offsets, d_df_dense[2];
+  DevBuf d_df_slots[2], d_df_sizes[2], d_df_offsets[2];  // a piece's per-chunk staging: two sets, piece k + 1 is compressed while
+                                                         // piece k's total travels to the host
+  DevBuf d_df_dense[kDfBuffers];                         // compressed pieces: one being written, two waiting for / on the link
   DevBuf d_df_code;                    // the current call's code table (DF_TABLE_BYTES) + its histogram scratch
-  HostBuf h_df_total, h_df_out[2];
+  HostBuf h_df_total, h_df_out[kDfBuffers];
   // kernels of this lane | D2H of compressed pieces: the streams of pbsim_ctx::df_streams (shared by the slots' lanes of the
   // same index -- one delivery runs at a time, and hardware queues are few: with a pair of streams per slot and lane, which
   // lanes had their kernels and their copies in ONE queue, one behind the other, was a matter of creation order)
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_df[2] = {nullptr, nullptr}, ev_cp[2] = {nullptr, nullptr};
+  hipEvent_t ev_df[kDfBuffers] = {}, ev_cp[kDfBuffers] = {};
   // Pinned arena that holds ALL compressed pieces of one batch (job.cpp, several ranks): a rank learns where its bytes go in
   // the record's stream only after every rank has compressed its block, so the pieces wait here, D2H-copied straight in.
   std::vector<std::unique_ptr<HostBuf>> arena_blocks;

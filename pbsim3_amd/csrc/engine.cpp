@@ -291,7 +291,7 @@ void pbsim_destroy(pbsim_ctx *c) {
     if (sl.ev3) (void)hipEventDestroy(sl.ev3);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
     for (DfLane &L : sl.df) {
-      for (int i = 0; i < 2; i++) {
+      for (int i = 0; i < kDfBuffers; i++) {
         if (L.ev_df[i]) (void)hipEventDestroy(L.ev_df[i]);
         if (L.ev_cp[i]) (void)hipEventDestroy(L.ev_cp[i]);
       }
@@ -1037,10 +1037,13 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
   const int64_t piece = (int64_t)DF_PIECE_CHUNKS * DF_CHUNK;
   const int64_t max_ch = std::min<int64_t>(DF_PIECE_CHUNKS, (n + DF_CHUNK - 1) / DF_CHUNK);
-  HIP_OK(sl.d_df_slots.ensure((size_t)max_ch * DF_SLOT));
-  HIP_OK(sl.d_df_sizes.ensure((size_t)max_ch * 4));
-  HIP_OK(sl.d_df_offsets.ensure((size_t)(max_ch + 1) * 8));
-  HIP_OK(sl.h_df_total.ensure(16));
+  const int64_t n_pieces = (n + piece - 1) / piece;
+  for (int i = 0; i < (n_pieces > 1 ? 2 : 1); i++) {
+    HIP_OK(sl.d_df_slots[i].ensure((size_t)max_ch * DF_SLOT));
+    HIP_OK(sl.d_df_sizes[i].ensure((size_t)max_ch * 4));
+    HIP_OK(sl.d_df_offsets[i].ensure((size_t)(max_ch + 1) * 8));
+  }
+  HIP_OK(sl.h_df_total.ensure(8 * kDfBuffers));
   HIP_OK(sl.d_df_code.ensure(DF_TABLE_BYTES + 288 * 4));
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
   int lane_index = 0;
@@ -1057,63 +1060,105 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     HIP_OK(hipMemsetAsync(c->d_df_prof.p, 0, 128, sl.stream));
     d_prof = c->d_df_prof.as<unsigned long long>();
   }
-  // Copies run on their own stream: the D2H of piece k-1 overlaps the kernels of piece k (and the host's consume()).
+  // The kernels of a piece, its copy and the host's consume() are three stages that must not wait for each other's round trips:
+  // the lane's stream always holds the NEXT piece's kernels (piece k + 1 is launched before piece k's total is read back, on
+  // the second set of staging buffers), the copy stream the next copy, and the host consumes piece k - 1 while piece k travels.
+  // (Launching a piece only after the previous one's total had arrived left the link idle whenever the other lane was not
+  // copying: 1.5 ms of kernels + a host round trip per 1.46 ms of copy.)
   if (!sl.copy_stream) {
     sl.copy_stream = c->df_streams[lane_index][1];
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kDfBuffers; i++) {
       HIP_OK(hipEventCreateWithFlags(&sl.ev_df[i], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&sl.ev_cp[i], hipEventDisableTiming));
     }
   }
-  int64_t pending = 0;  // bytes of the previous piece, in h_df_out[k ^ 1], copy possibly still in flight
-  const char *pending_ptr = nullptr;
-  bool used[2] = {false, false};
-  int k = 0;
   const bool trace = getenv("PBSIM_DEFLATE_TRACE") != nullptr;  // where a call's wall time goes: kernels | link | consumer
   const auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_kernel = 0, t_copy = 0, t_consume = 0, t_begin = now();
   int64_t out_bytes = 0;
-  for (int64_t off = 0; off < n; off += piece, k ^= 1) {
-    const int64_t len = std::min(piece, n - off);
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;  // trace: begin / end of every copy on the copy stream
+  bool used[kDfBuffers] = {false, false, false};
+  int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
+  // piece j: kernels on staging set j & 1 into dense buffer j % 3; its total lands in h_total[j % 3]
+  auto launch = [&](int64_t j) -> int {
+    const int b = (int)(j % kDfBuffers), a = (int)(j & 1);
+    const int64_t off = j * piece, len = std::min(piece, n - off);
     const int64_t nch = (len + DF_CHUNK - 1) / DF_CHUNK;
-    HIP_OK(sl.d_df_dense[k].ensure((size_t)max_ch * DF_SLOT, true));
-    if (!place) HIP_OK(sl.h_df_out[k].ensure((size_t)max_ch * DF_SLOT));
-    if (used[k]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[k], 0));  // piece k-2 has left this dense buffer
-    launch_deflate(d_text + off, len, sl.d_df_slots.as<uint8_t>(), sl.d_df_sizes.as<int32_t>(),
-                   sl.d_df_offsets.as<int64_t>(), sl.d_df_dense[k].as<uint8_t>(), tab, tab + 1024, sl.d_df_code.p, sl.stream, d_prof);
+    HIP_OK(sl.d_df_dense[b].ensure((size_t)max_ch * DF_SLOT, true));
+    if (!place) HIP_OK(sl.h_df_out[b].ensure((size_t)max_ch * DF_SLOT));
+    if (used[b]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - 3 has left this dense buffer
+    launch_deflate(d_text + off, len, sl.d_df_slots[a].as<uint8_t>(), sl.d_df_sizes[a].as<int32_t>(), sl.d_df_offsets[a].as<int64_t>(),
+                   sl.d_df_dense[b].as<uint8_t>(), tab, tab + 1024, sl.d_df_code.p, sl.stream, d_prof);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(sl.h_df_total.p, sl.d_df_offsets.as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
-    HIP_OK(hipEventRecord(sl.ev_df[k], sl.stream));
+    HIP_OK(hipMemcpyAsync(&h_total[b], sl.d_df_offsets[a].as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
+    HIP_OK(hipEventRecord(sl.ev_df[b], sl.stream));
+    return PBSIM_SUCCEEDED;
+  };
+  const char *prev_ptr = nullptr;  // piece k - 1: copy possibly still in flight
+  int64_t prev_bytes = 0;
+  int prev_buf = 0;
+  if (!launch(0)) return PBSIM_FAILED;
+  if (n_pieces > 1 && !launch(1)) return PBSIM_FAILED;
+  for (int64_t k = 0; k < n_pieces; k++) {
+    const int b = (int)(k % kDfBuffers);
     const double t0 = now();
-    HIP_OK(hipStreamSynchronize(sl.stream));
+    HIP_OK(hipEventSynchronize(sl.ev_df[b]));
     t_kernel += now() - t0;
-    const int64_t total = *reinterpret_cast<int64_t *>(sl.h_df_total.p);
+    const int64_t total = h_total[b];
     out_bytes += total;
-    HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[k], 0));
-    char *dst = place ? (*place)(total) : (char *)sl.h_df_out[k].p;
+    HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[b], 0));
+    char *dst = place ? (*place)(total) : (char *)sl.h_df_out[b].p;
     if (!dst) return fail("deflate: no room for a compressed piece");
-    HIP_OK(hipMemcpyAsync(dst, sl.d_df_dense[k].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
-    HIP_OK(hipEventRecord(sl.ev_cp[k], sl.copy_stream));
-    used[k] = true;
-    if (pending) {
+    if (trace) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      HIP_OK(hipEventCreate(&e0));
+      HIP_OK(hipEventCreate(&e1));
+      tev.emplace_back(e0, e1);
+      HIP_OK(hipEventRecord(e0, sl.copy_stream));
+    }
+    HIP_OK(hipMemcpyAsync(dst, sl.d_df_dense[b].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
+    if (trace) HIP_OK(hipEventRecord(tev.back().second, sl.copy_stream));
+    HIP_OK(hipEventRecord(sl.ev_cp[b], sl.copy_stream));
+    used[b] = true;
+    if (prev_bytes) {  // (before piece k + 2 is launched: it re-uses piece k - 1's buffers)
       const double t1 = now();
-      HIP_OK(hipEventSynchronize(sl.ev_cp[k ^ 1]));
+      HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
       const double t2 = now();
-      if (!consume(pending_ptr, pending)) return PBSIM_FAILED;
+      if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
       t_copy += t2 - t1;
       t_consume += now() - t2;
     }
-    pending = total;
-    pending_ptr = dst;
+    prev_ptr = dst;
+    prev_bytes = total;
+    prev_buf = b;
+    // piece k's staging set is free (its total has arrived), the dense buffer of piece k - 1 once its copy is through (a
+    // stream wait inside launch): keep the kernels one piece ahead
+    if (k + 2 < n_pieces && !launch(k + 2)) return PBSIM_FAILED;
   }
-  {
+  if (prev_bytes) {
     const double t1 = now();
-    HIP_OK(hipStreamSynchronize(sl.copy_stream));
-    t_copy += now() - t1;
+    HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
+    const double t2 = now();
+    if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
+    t_copy += t2 - t1;
+    t_consume += now() - t2;
   }
-  if (trace)
-    fprintf(stderr, "[deflate] %.1f MB -> %.1f MB in %.1f ms: waited %.1f ms for kernels, %.1f ms for copies, %.1f ms in the consumer\n",
-            n / 1e6, out_bytes / 1e6, now() - t_begin, t_kernel, t_copy, t_consume);
+  if (trace) {
+    double t_link = 0, t_span = 0;
+    float ms = 0;
+    for (auto &e : tev) {
+      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) t_link += ms;
+    }
+    if (!tev.empty() && hipEventElapsedTime(&ms, tev.front().first, tev.back().second) == hipSuccess) t_span = ms;
+    for (auto &e : tev) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+    fprintf(stderr,
+            "[deflate] %.1f MB -> %.1f MB in %.1f ms: waited %.1f ms for kernels, %.1f ms for copies, %.1f ms in the consumer; copies: "
+            "%.1f ms on the engine within a span of %.1f ms (%.1f GB/s while copying)\n",
+            n / 1e6, out_bytes / 1e6, now() - t_begin, t_kernel, t_copy, t_consume, t_link, t_span, t_link > 0 ? out_bytes / t_link / 1e6 : 0.0);
+  }
   if (d_prof) {
     unsigned long long t[16];
     HIP_OK(hipMemcpy(t, d_prof, 128, hipMemcpyDeviceToHost));
@@ -1123,7 +1168,6 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f", names[i], t[i] / nch / 100);
     fprintf(stderr, "\n");
   }
-  if (pending && !consume(pending_ptr, pending)) return PBSIM_FAILED;
   return PBSIM_SUCCEEDED;
 }
 

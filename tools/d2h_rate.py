@@ -1,5 +1,5 @@
 """GPU box: what the PCIe link moves device -> pinned host memory with the copy engines: one stream and two streams at once,
-pieces of 83 MB (a compressed MAF piece) and 256 MB; idle GPU and with a compute kernel running beside the copies.
+pieces of 83 MB (a compressed MAF piece) and 256 MB; idle GPU, with a GEMM and with an HBM-streaming kernel beside the copies.
 usage: python tools/d2h_rate.py [numa node]"""
 import os
 import sys
@@ -28,14 +28,19 @@ def run(piece_mb, streams, busy):
     st = [torch.cuda.Stream() for _ in range(streams)]
     side = torch.cuda.Stream()
     a = torch.randn(8192, 8192, device=dev)
+    global big1, big2
     reps = max(4, 2048 // piece_mb)
     for warm in (True, False):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if busy:
+        if busy == "gemm":
             with torch.cuda.stream(side):
                 for _ in range(6):
                     a = (a @ a).clamp_(-1, 1)
+        elif busy == "hbm":     # a kernel that streams HBM at full rate beside the copies
+            with torch.cuda.stream(side):
+                for _ in range(40):
+                    big2.copy_(big1)
         for r in range(reps):
             for i in range(streams):
                 with torch.cuda.stream(st[i]):
@@ -47,7 +52,9 @@ def run(piece_mb, streams, busy):
     return reps * streams * n / dt / 1e9
 
 
-for busy in (False, True):
+big1 = torch.empty(4 << 30, dtype=torch.uint8, device=dev)
+big2 = torch.empty(4 << 30, dtype=torch.uint8, device=dev)
+for busy in (None, "gemm", "hbm"):
     for piece in (83, 256):
         for streams in (1, 2):
-            print("GPU %s, %3d MB pieces, %d stream(s): %.1f GB/s" % ("busy" if busy else "idle", piece, streams, run(piece, streams, busy)))
+            print("GPU %s, %3d MB pieces, %d stream(s): %.1f GB/s" % (busy or "idle", piece, streams, run(piece, streams, busy)))
