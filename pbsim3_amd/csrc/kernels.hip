@@ -904,12 +904,15 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
 // not depend on the reference: state[m] = tran[state[m-1]][x[m]].  A wave therefore takes 64 columns at a time, lane i
 // column m0 + i:
 //   1. every lane draws its column's block,
-//   2. the state chain runs through the 64 draws (LDS lookups; the only serial part),
+//   2. the state chain runs through the 64 draws (coop_chain: eight speculated groups of eight, the only serial part),
 //   3. each lane classifies its column both ways (deleted / not deleted); which of the two holds depends on the
 //      homopolymer class of the reference base under the column's cursor, and the cursor on the insertions before it:
 //      a ballot + popcount gives every lane its cursor, the lanes re-decide, and the loop repeats while a decision moved a
 //      cursor (by induction over the lanes it ends in the sequential walk's answer; in practice after one or two turns),
-//   4. 64 columns of the two MAF rows leave as sixteen dwords each, in the lane walker's scratch layout.
+//   4. 64 columns of the two MAF rows leave as sixteen dwords each: 64 consecutive bytes per row in a scratch block whose tasks
+//      all belong to this kernel (kWaveTransposed: rows stored task by task), sixteen stores 256 bytes apart in the one block
+//      per class it shares with the lane walker (rows interleaved dword by dword; written that way by a whole batch the
+//      kernel was bound by those partial lines: 39 instead of 100 G columns/s).
 // Re-initialisation while nothing has been emitted (Q2: q == 0 selects the initial-state table) is handled the same way:
 // assume it for column 0 only, walk, compare with what the columns decided, repeat if the assumption was wrong.
 // ---------------------------------------------------------------------------
