@@ -54,6 +54,27 @@ def run(piece_mb, streams, busy):
 
 big1 = torch.empty(4 << 30, dtype=torch.uint8, device=dev)
 big2 = torch.empty(4 << 30, dtype=torch.uint8, device=dev)
+def run_cycling(piece_mb, n_dst, streams=2):
+    """the same copies into n_dst different pinned buffers in turn (a working set the host's caches cannot hold)"""
+    n = piece_mb << 20
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = [torch.empty(n, dtype=torch.uint8).pin_memory() for _ in range(n_dst)]
+    st = [torch.cuda.Stream() for _ in range(streams)]
+    reps = max(2 * n_dst, 4096 // piece_mb)
+    for warm in (True, False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in range(reps):
+            with torch.cuda.stream(st[r % streams]):
+                dst[r % n_dst].copy_(src, non_blocking=True)
+        for s in st:
+            s.synchronize()
+        dt = time.perf_counter() - t0
+    return reps * n / dt / 1e9
+
+
+for n_dst in (1, 2, 8, 24):
+    print("two streams, 83 MB pieces into %2d pinned buffers in turn (%4d MB): %.1f GB/s" % (n_dst, 83 * n_dst, run_cycling(83, n_dst)))
 for busy in (None, "gemm", "hbm"):
     for piece in (83, 256):
         for streams in (1, 2):
