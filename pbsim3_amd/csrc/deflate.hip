@@ -543,7 +543,12 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
     {
       BitWriter bw;
       bw.init(s_out, hdr_end + tok_off);
-      // (the rare match path stays a rolled loop: the unrolled literal path is what has to fit the instruction cache)
+      // One code path for every dword.  A match covers >= 3 positions, so at most one starts in a dword; its start position is
+      // not a literal (s_code[287] == 0 bits stands in for it), and the positions behind it in the dword are covered except
+      // byte 3 of a 3-byte match that starts at byte 0.  In stream order the dword's tokens are therefore
+      //     [match if it starts at byte 0] c0 c1 [match if at byte 1 or 2] c2 c3 [match if at byte 3]
+      // with zero-length entries wherever nothing is emitted.  (A separate loop for dwords that hold a match start was
+      // executed, exec-masked, for 96 % of the dwords: some lane of the 64 nearly always has one.)
 #pragma unroll
       for (int j = 0; j < kSegDw; ++j) {
         const uint32_t nl = m_nibble(tk.lit, j), ns = m_nibble(tk.start, j);
@@ -552,28 +557,27 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
         uint32_t c[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = s_code[((nl >> k) & 1u) ? (w >> (8 * k)) & 255u : 287u];   // [287] == 0
-        if (ns == 0) {
-          // literals only: two codes (<= 30 bits) per accumulator step, no per-byte branches
-#pragma unroll
-          for (int k = 0; k < 4; k += 2) {
-            const uint32_t l0 = c[k] >> 16;
-            bw.put((c[k] & 0xFFFFu) | ((c[k + 1] & 0xFFFFu) << l0), l0 + (c[k + 1] >> 16));
-          }
-        } else {
-#pragma unroll 1
-          for (int k = 0; k < 4; ++k) {
-            if ((nl >> k) & 1u) {
-              const uint32_t ck = s_code[(w >> (8 * k)) & 255u];
-              bw.put(ck & 0xFFFFu, ck >> 16);
-            } else if ((ns >> k) & 1u) {
-              uint32_t sy, eb, ev;
-              length_symbol((uint32_t)m_run(tk.cover, 4 * j + k), &sy, &eb, &ev);
-              const uint32_t cm = s_code[sy];
-              // code, extra bits, then the single distance code (one 0 bit)
-              bw.put((cm & 0xFFFFu) | (ev << (cm >> 16)), (cm >> 16) + eb + 1);
-            }
-          }
+        uint32_t mv = 0, ml = 0, ks = 4;
+        if (ns) {
+          ks = (uint32_t)__builtin_ctz(ns);
+          uint32_t sy, eb, ev;
+          length_symbol((uint32_t)m_run(tk.cover, 4 * j + (int)ks), &sy, &eb, &ev);
+          const uint32_t cm = s_code[sy];
+          mv = (cm & 0xFFFFu) | (ev << (cm >> 16));  // code, extra bits, then the single distance code (one 0 bit)
+          ml = (cm >> 16) + eb + 1;
         }
+        bw.put(ks == 0 ? mv : 0u, ks == 0 ? ml : 0u);
+        {
+          const uint32_t l0 = c[0] >> 16;   // two codes (<= 30 bits) per accumulator step
+          bw.put((c[0] & 0xFFFFu) | ((c[1] & 0xFFFFu) << l0), l0 + (c[1] >> 16));
+        }
+        const bool mid = ks == 1 || ks == 2;
+        bw.put(mid ? mv : 0u, mid ? ml : 0u);
+        {
+          const uint32_t l2 = c[2] >> 16;
+          bw.put((c[2] & 0xFFFFu) | ((c[3] & 0xFFFFu) << l2), l2 + (c[3] >> 16));
+        }
+        bw.put(ks == 3 ? mv : 0u, ks == 3 ? ml : 0u);
       }
       bw.flush();
     }
