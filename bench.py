@@ -11,10 +11,13 @@ batch D2H"; what the CLI does for .fq.gz / .maf.gz except the file writes).  `va
 step.  Sub-fields give the same job with the text left in HBM (whole_job_hbm) and the steady-state batch pipeline on one
 record (steady_state_hbm).
 
---gpus N (torchrun, one rank per GPU): the SAME job, strong scaling.  Rank 0 generates the records, RCCL broadcasts them
-(C1), every round of the pipeline is sharded by read block over the ranks, the ranks exchange only integers (C3 all-gather
-per round, C2 all-reduce per record) through torch.distributed (backend nccl = RCCL over xGMI); every rank delivers its
-own blocks to its own host memory.
+--gpus N: the SAME job on N ranks, one per GPU, strong scaling.  Under torchrun (WORLD_SIZE set) this process is one of the
+ranks; started bare (`python bench.py --gpus 8`) it launches the N ranks itself -- `python -m torch.distributed.run` as a
+child process, before anything here has touched a GPU -- and exits with their status.  Rank 0 generates the records, RCCL
+broadcasts them (C1), every round of the pipeline is sharded by read block over the ranks, the ranks exchange only integers
+(C3 all-gather per round, C2 all-reduce per record) through torch.distributed (backend nccl = RCCL over xGMI); every rank
+delivers its own blocks to its own host memory, from threads and pinned buffers bound to its GPU's NUMA node.
+--one-gpu: the N ranks as N contexts on GPU 0 with gloo collectives (the plumbing check of a single-GPU box).
 """
 import argparse
 import json
@@ -318,6 +321,51 @@ def steady_state(a, torch, harness, P, local, model, genome_ptr, G, qs=False, pa
             "note": "two batches in flight on one record, every read final (no quota cut), FASTQ + MAF text left in HBM"}
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) as a child and leave with its exit
+    status.  This process has not imported torch nor made any HIP call, and it never replaces itself (no exec)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if a.one_gpu:
+        env["PBSIM_BENCH_BACKEND"] = "gloo"
+        env["PBSIM_BENCH_ONE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: launching %d ranks: %s\n" % (a.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def critical_path(bd_all, K):
+    """per-rank split of the round loop's wall time (pbsim_job_breakdown summed over the K timed runs), milliseconds per run"""
+    rows = []
+    for r, b in enumerate(bd_all):
+        wall = b["wall"]
+        named = {"walk": b["wait_walk"], "text_sizes": b["finalize"], "deflate_link": b["wait_bytes"],
+                 "collectives": b["collectives"] + b["merge"], "exposed_tail": b["tail_block"] + b["drain"],
+                 "statistics": b["account"], "enqueue": b["begin"] + b["tail_steps"], "slot_wait": b["slot_wait"]}
+        row = {k: v / 1e3 / K for k, v in named.items()}
+        row["other"] = (wall - sum(named.values())) / 1e3 / K
+        row["wall"] = wall / 1e3 / K
+        row["delivery_thread_busy"] = b["worker_busy"] / 1e3 / K
+        row["topup_rounds"] = b["topup_rounds"] / K
+        row["tail_reads"] = b["tail_reads"] / K
+        row["rank"] = r
+        rows.append(row)
+    worst = max(rows, key=lambda x: x["wall"])
+    return {"unit": "ms per run of the job, where the rank's round loop waited", "per_rank": rows,
+            "serial_share": max((x["exposed_tail"] + x["collectives"]) / max(1e-9, x["wall"]) for x in rows),
+            "slowest_rank": worst["rank"],
+            "note": "walk = waiting for the round in front to finish walking; text_sizes = quota cut + text sizes (three small reads); "
+                    "deflate_link = waiting for the previous round's bytes (GPU compression + PCIe); collectives = C3 gathers + C2 merges "
+                    "(incl. waiting for the slowest rank); exposed_tail = truncated tail reads and deliveries a record's merge had to wait "
+                    "for; serial_share = (exposed_tail + collectives) / wall of the worst rank"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,26 +380,42 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the whole_job_hbm / steady_state_hbm sub-measurements")
     ap.add_argument("--hbm-only", action="store_true", help="experiment: leave the text in HBM in the timed runs too")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="plumbing check: the --gpus N ranks as N contexts on GPU 0, gloo collectives (not a scaling measurement)")
     ap.add_argument("--param", action="append", default=[],
                     help="experiment only: override a pbsim_params field, e.g. --param len_sd=0 (not the headline workload)")
     a = ap.parse_args()
-
-    import ctypes as C
-    import torch
-    import harness
-    import pbsim3_amd as P
-
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))          # nothing above has touched a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): start it as "
+                 f"`python bench.py --gpus {a.gpus}` (it launches the ranks itself) or give torchrun --nproc-per-node {a.gpus}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    one_gpu = a.one_gpu or os.environ.get("PBSIM_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
+        os.environ.setdefault("PBSIM_BENCH_BACKEND", "gloo")
+
+    import ctypes as C
+    import pbsim3_amd as P
+    # host placement first: this thread, the threads the library starts and its pinned staging go to the GPU's NUMA node
+    numa = P.bind_host_to_device(local)
+    import torch
+    import harness
+
+    if not one_gpu and torch.cuda.device_count() < world:      # (device_count does not initialise the GPU)
+        sys.exit(f"bench.py: --gpus {world} but this node shows {torch.cuda.device_count()} GPU(s); "
+                 "--one-gpu runs the ranks as contexts on GPU 0 (plumbing check)")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # PBSIM_BENCH_BACKEND=gloo + PBSIM_BENCH_ONE_GPU=1: plumbing check of the N>1 path on a 1-GPU box
         backend = os.environ.get("PBSIM_BENCH_BACKEND", "nccl")
-        if os.environ.get("PBSIM_BENCH_ONE_GPU") == "1":
-            local = 0
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -399,10 +463,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sinks, counters = [], []
+    sinks, counters, bd_sum = [], [], {}
     for _ in range(a.steps):
         sinks.append(run_job(deliver))
         counters.append(ctx.job_counters())
+        bd = ctx.job_breakdown()
+        for k, v in bd.items():
+            bd_sum[k] = bd_sum.get(k, 0.0) + v
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -410,6 +477,7 @@ def main():
     walk_ms, launches, _ = ctx.prof_get()
     walk_busy_ms = ctx.prof_walk_busy()
     tail_ms, tail_launches = ctx.prof_tail()
+    sec = ctx.prof_secondary()
 
     # the statistics of a record are identical on every rank (merged); bytes delivered and reads walked are per rank
     job_bases = sum(v[1] for v in sinks[0].stats.values())
@@ -424,6 +492,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     walked, delivered, host_bytes, comm_us = (int(x) for x in mine.tolist())
     dt_max = float(tmax.item())
+    bd_keys = list(P.Context.BREAKDOWN)
+    bd_mine = torch.tensor([bd_sum.get(k, 0.0) for k in bd_keys], dtype=torch.float64, device=cdev)
+    bd_list = [bd_mine]
+    if world > 1:
+        bd_list = [torch.empty_like(bd_mine) for _ in range(world)]
+        dist.all_gather(bd_list, bd_mine)
+    bd_all = [dict(zip(bd_keys, t.tolist())) for t in bd_list]
 
     extras = {}
     if not a.no_extras:
@@ -498,6 +573,27 @@ def main():
                          "issue_bound": None if qs else issue_bound(sum(c["maf_columns"] for c in counters) / max(1, launches),
                                                                     walk_s / max(1, launches))},
         }
+        text_s, df_s = sec["text_ms"] / 1e3, sec["deflate_ms"] / 1e3
+        out["roofline"]["secondary"] = [
+            {"kernel": "k_text_rows (+ k_text_headers, k_text_fill: one text emission)", "bound": "hbm",
+             "achieved": (sec["text_in"] + sec["text_out"]) / text_s / 1e9 if text_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": (sec["text_in"] + sec["text_out"]) / text_s / 1e9 / HBM_PEAK_GBS if text_s > 0 else None,
+             "launches": sec["text_launches"], "avg_ms": sec["text_ms"] / max(1, sec["text_launches"]),
+             "bytes_read_per_launch": sec["text_in"] / max(1, sec["text_launches"]),
+             "bytes_written_per_launch": sec["text_out"] / max(1, sec["text_launches"]),
+             "note": "algorithmic bytes: the MAF rows read once (2 B per column; 3 with the quality row) + the text written once; HIP events "
+                     "on the slot's stream around the emission kernels, in the job (beside walks and deflate lanes)"},
+            {"kernel": "k_deflate_chunks", "bound": "valu-issue", "text_GBps": sec["deflate_in"] / df_s / 1e9 if df_s > 0 else None,
+             "member_GBps": sec["deflate_out"] / df_s / 1e9 if df_s > 0 else None,
+             "launches": sec["deflate_launches"], "avg_ms": sec["deflate_ms"] / max(1, sec["deflate_launches"]),
+             "text_bytes_per_launch": sec["deflate_in"] / max(1, sec["deflate_launches"]),
+             "solo_ref": "profiles/r02z_deflate_prof.txt: 0.36 ms per full-size launch alone (745 GB/s of text)",
+             "note": "integer issue / LDS bound, not HBM: GB/s of text a lane's launches turn into members, HIP events around "
+                     "k_deflate_chunks on the lane's stream; two lanes run side by side, so the GPU compresses up to twice this"}]
+        out["critical_path"] = critical_path(bd_all, K)
+        out["numa"] = numa or "unbound (one node, no topology, or PBSIM_NUMA_BIND=0)"
+        if one_gpu and world > 1:
+            out["config"]["one_gpu"] = f"{world} ranks as {world} contexts on ONE GPU, gloo collectives: plumbing, not scaling"
         out.update(extras)
     ctx.close()
     if rank == 0 and world == 1 and not a.no_extras:

@@ -260,6 +260,12 @@ typedef struct pbsim_comm {
   /* optional (C1): `bytes` bytes at `ptr` (device memory of this rank's GPU when on_device, else host memory) of rank
    * `root` to every rank.  NULL: the caller has every rank load the records itself. */
   int (*broadcast)(void *user, void *ptr, int64_t bytes, int32_t root, int32_t on_device);
+  /* optional: called by a rank whose job failed for a reason the other ranks cannot know yet.  It must make the collectives
+   * the other ranks are waiting in (or will enter) return 0, or end their processes.  Failures the library can foresee travel
+   * in the status words of its own exchanges and all ranks return PBSIM_FAILED together; for the rest (a HIP error between two
+   * exchanges) a communicator without `abort` leaves the other ranks waiting: the caller must then tear the process group
+   * down when pbsim_job_run fails on any rank.  NULL is allowed. */
+  int (*abort)(void *user);
 } pbsim_comm;
 
 /* Receiver of a job's output.  Text arrives as (record, bytes, offset): `offset` is the position of the piece inside the
@@ -298,6 +304,14 @@ int64_t pbsim_job_bam_header(pbsim_ctx *ctx, int64_t record, char *buf, int64_t 
  * [2] rounds, [3] bases delivered (all passes), [4] wall microseconds, [5] microseconds this rank waited in collectives,
  * [6] reference bases consumed and [7] MAF columns written by the delivered reads (roofline accounting) */
 int pbsim_job_counters(pbsim_ctx *ctx, int64_t out[8]);
+/* where this rank's round loop spent the wall time of the last pbsim_job_run, microseconds: [0] wall; the loop waited
+ * [1] for walks (pbsim_batch_walk_end of the round in front), [2] for the cut and the text sizes, [3] for the previous round's
+ * bytes to reach host memory (GPU compression + link), [4] in the per-round collectives, [5] accounting statistics,
+ * [6] for a record's truncated tail reads at its merge (exposed tail), [7] for the delivery thread at a merge, [8] for a free
+ * slot, [9] in the statistics merge (C2), [10] enqueueing rounds, [11] stepping tail reads between rounds; [12] time the
+ * delivery thread was busy (compression + copies + sink callbacks; runs beside the loop); [13] top-up rounds, [14] truncated
+ * tail reads walked by this rank, [15] rounds kept in flight. */
+int pbsim_job_breakdown(pbsim_ctx *ctx, double out[16]);
 
 /* Statistics primitives for callers that shard a unit set over several contexts themselves (trans / templ:
  * pbsim_simulate_units_range per rank): keep the per-task accuracy values while accounting (before simulating), then
@@ -321,6 +335,14 @@ int64_t pbsim_format_stats(const pbsim_params *p, const pbsim_stats *s, int64_t 
  * (torch.distributed).  Returns the process exit status (0, or 255 like the reference's exit(-1)). */
 int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int device);
 
+/* ---- host placement of a rank ----------------------------------------------------------
+ * The reference is one thread on one socket; a rank here is a thread that feeds one GPU and receives its output over PCIe.
+ * Binds the calling thread -- and the threads and page-locked buffers it creates afterwards -- to the CPUs and the memory of
+ * the NUMA node GPU `device` is attached to (sysfs: KFD topology -> PCI address -> numa_node / local_cpulist).  Call it
+ * before the first HIP call of the thread's process (pbsim_cli_main does, per rank).  `what` (optional) receives a one-line
+ * description, empty when there was nothing to bind to (one node, no topology, PBSIM_NUMA_BIND=0).  Always succeeds. */
+int pbsim_bind_host_to_device(int device, char *what, int64_t cap);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------
  * Accumulated HIP-event time of the walk kernel launches since the last reset,
  * measured on the engine's own stream, and the number of launches. */
@@ -331,6 +353,10 @@ int pbsim_prof_get(pbsim_ctx *ctx, double *walk_ms, int64_t *walk_launches, doub
 int pbsim_prof_tail(pbsim_ctx *ctx, double *tail_ms, int64_t *tail_launches);
 /* milliseconds since the reset during which at least one walk kernel ran (the launches of different slots overlap) */
 int pbsim_prof_walk_busy(pbsim_ctx *ctx, double *busy_ms);
+/* the two kernels next in line, timed with HIP events on the streams they run on, since the last reset:
+ * [0] ms, [1] launches, [2] bytes read (scratch rows), [3] bytes written (text) of the text emission (k_text_*);
+ * [4] ms, [5] launches, [6] text bytes in, [7] member bytes out of k_deflate_chunks */
+int pbsim_prof_secondary(pbsim_ctx *ctx, double out[8]);
 /* raw HIP stream handle (hipStream_t) of the engine, for external event timing */
 void *pbsim_stream(pbsim_ctx *ctx);
 

@@ -57,12 +57,14 @@ OP_SUM, OP_MIN, OP_MAX = 0, 1, 2
 GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64))
 REDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_int32)
 BCAST_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
+ABORT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
 class Comm(C.Structure):
     """pbsim_comm: blocking collectives over the ranks of a job (one context per GPU)."""
     _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32),
-                ("all_gather_i64", GATHER_CB), ("all_reduce_i64", REDUCE_CB), ("broadcast", BCAST_CB)]
+                ("all_gather_i64", GATHER_CB), ("all_reduce_i64", REDUCE_CB), ("broadcast", BCAST_CB),
+                ("abort", ABORT_CB)]
 
 
 REC_TEXT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_char), C.c_int64, C.c_int64)
@@ -86,6 +88,8 @@ API = [
     ("pbsim_job_sam_header", C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
     ("pbsim_job_bam_header", C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
     ("pbsim_job_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ("pbsim_job_breakdown", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("pbsim_bind_host_to_device", C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
     ("pbsim_stats_keep_values", C.c_int, [C.c_void_p, C.c_int]),
     ("pbsim_stats_merge", C.c_int, [C.c_void_p, C.POINTER(Comm)]),
     ("pbsim_stats_add_tasks", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -143,6 +147,7 @@ API = [
     ("pbsim_prof_get", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("pbsim_prof_walk_busy", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_prof_tail", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("pbsim_prof_secondary", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_stream", C.c_void_p, [C.c_void_p]),
     ("pbsim_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("pbsim_dump_table", C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
@@ -219,7 +224,7 @@ def default_params(**kw):
 BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
 
 
-def make_comm(rank, world, all_gather, all_reduce, broadcast=None):
+def make_comm(rank, world, all_gather, all_reduce, broadcast=None, abort=None):
     """pbsim_comm from Python callables (numpy int64 arrays in and out; the statistics merge moves millions of values):
          all_gather(array[n]) -> array[world, n] (rank-major), all_reduce(array[n], op) -> array[n],
          broadcast(ptr:int, nbytes:int, root:int, on_device:bool) -> None (optional, C1).
@@ -259,7 +264,16 @@ def make_comm(rank, world, all_gather, all_reduce, broadcast=None):
             traceback.print_exc()
             return 0
 
-    cbs = (GATHER_CB(_g), REDUCE_CB(_r), BCAST_CB(_b) if broadcast else BCAST_CB())
+    def _a(user):
+        try:
+            abort()
+            return 1
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 0
+
+    cbs = (GATHER_CB(_g), REDUCE_CB(_r), BCAST_CB(_b) if broadcast else BCAST_CB(), ABORT_CB(_a) if abort else ABORT_CB())
     comm = Comm(None, rank, world, *cbs)
     comm._keep = cbs
     return comm
@@ -286,7 +300,25 @@ def torch_comm(dist, device):
         dist.all_reduce(t, op={OP_SUM: dist.ReduceOp.SUM, OP_MIN: dist.ReduceOp.MIN, OP_MAX: dist.ReduceOp.MAX}[op])
         return t.cpu().numpy()
 
-    return make_comm(rank, world, all_gather, all_reduce, None)
+    def abort():
+        # one process per rank (torchrun): the other ranks wait in a collective this rank will never enter.  Ending this
+        # process is what tears the group down -- the launcher then ends the others (include/pbsim3_amd.h, pbsim_comm.abort).
+        import sys
+        sys.stderr.write("pbsim3_amd: rank %d failed inside the job (%s): leaving the process group\n"
+                         % (rank, load().pbsim_last_error().decode(errors="replace")))
+        sys.stderr.flush()
+        os._exit(1)
+
+    return make_comm(rank, world, all_gather, all_reduce, None, abort)
+
+
+def bind_host_to_device(device):
+    """Binds the calling thread (and the threads and pinned allocations it creates from now on) to the CPUs and the memory of
+    the NUMA node `device`'s PCIe slot hangs off; call before the first HIP call of the process.  Returns a description of what
+    was done ("" when there is nothing to bind to).  PBSIM_NUMA_BIND=0 turns it off."""
+    buf = C.create_string_buffer(512)
+    load().pbsim_bind_host_to_device(device, buf, 512)
+    return buf.value.decode(errors="replace")
 
 
 def cli_main(argv, comm=None, device=-1):
@@ -559,6 +591,15 @@ class Context:
         return dict(reads_walked=a[0], reads_delivered=a[1], rounds=a[2], bases=a[3], wall_us=a[4], comm_us=a[5],
                     ref_bases=a[6], maf_columns=a[7])
 
+    BREAKDOWN = ("wall", "wait_walk", "finalize", "wait_bytes", "collectives", "account", "tail_block", "drain", "slot_wait",
+                 "merge", "begin", "tail_steps", "worker_busy", "topup_rounds", "tail_reads", "depth")
+
+    def job_breakdown(self):
+        """where the round loop of the last job_run spent its wall time: {name: microseconds} (+ three counters)"""
+        a = (C.c_double * 16)()
+        _check(self.lib.pbsim_job_breakdown(self.h, a))
+        return dict(zip(self.BREAKDOWN, a))
+
     def job_sam_header(self, record):
         n = self.lib.pbsim_job_sam_header(self.h, record, None, 0)
         buf = C.create_string_buffer(n + 1)
@@ -611,6 +652,12 @@ class Context:
         a, b = C.c_double(0), C.c_int64(0)
         _check(self.lib.pbsim_prof_tail(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def prof_secondary(self):
+        a = (C.c_double * 8)()
+        _check(self.lib.pbsim_prof_secondary(self.h, a))
+        return dict(text_ms=a[0], text_launches=int(a[1]), text_in=int(a[2]), text_out=int(a[3]),
+                    deflate_ms=a[4], deflate_launches=int(a[5]), deflate_in=int(a[6]), deflate_out=int(a[7]))
 
     def prof_walk_busy(self):
         a = C.c_double(0)

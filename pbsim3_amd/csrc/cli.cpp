@@ -569,6 +569,8 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
     parse_args(argc, argv, c);
   }
   if (device >= 0) c.device = device;
+  // this rank's thread, the delivery threads it starts and their pinned staging: on the NUMA node of its GPU
+  (void)pbsim_bind_host_to_device(c.device, NULL, 0);
   const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
   const bool rank0 = rank == 0;
   const bool sampling = c.p.method == PBSIM_METHOD_SAMPLE;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -113,30 +114,65 @@ struct DfLane {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_df[kDfBuffers] = {}, ev_cp[kDfBuffers] = {};
+  hipEvent_t ev_k0[kDfBuffers] = {}, ev_k1[kDfBuffers] = {};  // timing: around k_deflate_chunks of the piece in dense buffer b
   // Pinned arena that holds ALL compressed pieces of one batch (job.cpp, several ranks): a rank learns where its bytes go in
   // the record's stream only after every rank has compressed its block, so the pieces wait here, D2H-copied straight in.
   std::vector<std::unique_ptr<HostBuf>> arena_blocks;
-  size_t arena_block = 0, arena_used = 0;
+  std::vector<size_t> arena_fill;      // bytes handed out of each block since the last reset
+  std::vector<char> arena_touched;     // block was used since the last trim (pbsim_job_run trims at its end)
   std::vector<std::pair<const char *, int64_t>> arena_segs;
+  size_t arena_bytes() const {
+    size_t n = 0;
+    for (const auto &b : arena_blocks) n += b->bytes;
+    return n;
+  }
   void arena_reset() {
-    arena_block = arena_used = 0;
+    std::fill(arena_fill.begin(), arena_fill.end(), 0);
     arena_segs.clear();
   }
-  char *arena_reserve(int64_t n) {
+  // First fit over the blocks (a block too small for one piece still takes the next smaller one); a new block only when no
+  // block has room, and never beyond `max_bytes` of pinned memory for this lane (0: no bound).
+  char *arena_reserve(int64_t n, size_t max_bytes) {
     const size_t kBlock = 256u << 20;
-    for (;; arena_block++, arena_used = 0) {
-      if (arena_block == arena_blocks.size()) {
-        arena_blocks.emplace_back(new HostBuf);
-        if (arena_blocks.back()->ensure(std::max(kBlock, (size_t)n)) != hipSuccess) return nullptr;
-      }
-      HostBuf &b = *arena_blocks[arena_block];
-      if (arena_used + (size_t)n <= b.bytes) {
-        char *p = (char *)b.p + arena_used;
-        arena_used += ((size_t)n + 63) & ~(size_t)63;
+    const size_t need = ((size_t)n + 63) & ~(size_t)63;
+    for (size_t i = 0; i < arena_blocks.size(); i++) {
+      HostBuf &b = *arena_blocks[i];
+      if (arena_fill[i] + need <= b.bytes) {
+        char *p = (char *)b.p + arena_fill[i];
+        arena_fill[i] += need;
+        arena_touched[i] = 1;
         arena_segs.emplace_back(p, n);
         return p;
       }
     }
+    const size_t want = std::max(kBlock, need);
+    if (max_bytes && arena_bytes() + want > max_bytes) return nullptr;
+    arena_blocks.emplace_back(new HostBuf);
+    arena_fill.push_back(0);
+    arena_touched.push_back(1);
+    if (arena_blocks.back()->ensure(want) != hipSuccess) {
+      arena_blocks.pop_back();
+      arena_fill.pop_back();
+      arena_touched.pop_back();
+      return nullptr;
+    }
+    arena_fill.back() = need;
+    arena_segs.emplace_back((char *)arena_blocks.back()->p, n);
+    return (char *)arena_blocks.back()->p;
+  }
+  // end of a job: blocks no round of this job touched go back to the host (a context that once ran a large job does not
+  // keep its page-locked memory for ever)
+  void arena_trim() {
+    size_t k = 0;
+    for (size_t i = 0; i < arena_blocks.size(); i++)
+      if (arena_touched[i]) {
+        if (k != i) arena_blocks[k] = std::move(arena_blocks[i]);
+        k++;
+      }
+    arena_blocks.resize(k);
+    arena_fill.assign(k, 0);
+    arena_touched.assign(k, 0);
+    arena_segs.clear();
   }
 };
 
@@ -195,6 +231,9 @@ struct Slot {
   hipStream_t coop_stream = nullptr;   // the long reads' walk (k_walk_errhmm_coop), beside the batch's lane walk
   hipEvent_t ev_coop = nullptr;
   bool stats_fetched = false;          // the per-task counters of the final reads are already in h_stats (finalize_text, deferred mode)
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // timing: around the text emission kernels (launch_text_emit)
+  bool text_timed = false;             // ev_t0 / ev_t1 hold an emission that has not been added to the profile yet
+  int64_t text_in = 0, text_out = 0;   // its bytes: scratch rows read, text written
   hipEvent_t ev_text = nullptr;        // the batch's text has been emitted (finalize_text; waited for by whoever reads the text
                                        // on another stream or thread when pbsim_ctx::defer_text_sync)
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
@@ -243,6 +282,9 @@ struct pbsim_ctx {
   int64_t unit = 0;
   int64_t census[kHpSlots] = {0};
   bool census_done = false;
+  bool census_from_job = false;  // census_done was set by pbsim_job_run from the job's own records (recomputed per run), not by pbsim_finish_hp_census
+  bool hp11_explicit = false;    // an hp == 11 base was counted by pbsim_add_hp_census (the pre-pass over all records, pbsim.cpp:677-696)
+  bool hp11_before_job = false;  // Q15 state in front of the job's first record (pbsim_job_begin): every pbsim_job_run starts from it
   // trans units (pbsim_set_transcripts)
   int64_t n_units = 0, trans_reads = 0;
   DevBuf d_read_unit, d_read_minus, d_read_base, d_unit_len, d_unit_rank, d_unit_names, d_off_table, d_ssp, d_ssp_rv;
@@ -267,6 +309,7 @@ struct pbsim_ctx {
   StatsAcc st;                   // of the current unit (pbsim_batch_account / pbsim_get_stats)
   std::vector<std::unique_ptr<JobRecord>> job_records;  // pbsim_job_add_record (job.cpp)
   int64_t job_counters[8] = {0};
+  double job_breakdown[16] = {0};  // pbsim_job_breakdown: where the round loop's wall time went (job.cpp)
   int64_t job_first_unit = 1;    // genome.num of the job's first record (pbsim_job_begin)
 
   // profiling
@@ -274,6 +317,11 @@ struct pbsim_ctx {
   int64_t prof_walk_launches = 0, prof_tail_launches = 0;   // walk launches of batches / of single truncated tail reads
   hipEvent_t ev_prof_base = nullptr;                     // pbsim_prof_reset: time zero of the walk intervals
   std::vector<std::pair<float, float>> prof_intervals;   // [start, end] ms of every walk launch since the reset
+  // secondary kernels (pbsim_prof_secondary): text emission and k_deflate_chunks, HIP events on their own streams
+  double prof_text_ms = 0, prof_deflate_ms = 0;
+  int64_t prof_text_launches = 0, prof_text_in = 0, prof_text_out = 0;
+  int64_t prof_deflate_launches = 0, prof_deflate_in = 0, prof_deflate_out = 0;
+  std::mutex prof_mu;            // the deflate lanes run on delivery threads
 };
 
 // ---- internals shared by engine.cpp and job.cpp ---------------------------------------------------------------------

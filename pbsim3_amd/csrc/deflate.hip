@@ -731,12 +731,14 @@ void launch_deflate_table(const uint8_t *text, int64_t n_bytes, uint32_t *hist, 
 
 void launch_deflate(const uint8_t *text, int64_t n_bytes, uint8_t *slots, int32_t *sizes, int64_t *offsets,
                     uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, const void *table, hipStream_t s,
-                    unsigned long long *d_prof) {
+                    unsigned long long *d_prof, hipEvent_t ev_begin, hipEvent_t ev_chunks_done) {
   if (n_bytes <= 0) return;
   const int64_t nch = (n_bytes + DF_CHUNK - 1) / DF_CHUNK;
   const uint32_t x8rem = host_xpow8((uint64_t)(n_bytes % DF_CHUNK) & 127u);
+  if (ev_begin) (void)hipEventRecord(ev_begin, s);
   hipLaunchKernelGGL(k_deflate_chunks, dim3((unsigned)nch), dim3(kThreads), 0, s, text, n_bytes, slots, sizes,
                      d_crc_table, d_pow128, x8rem, reinterpret_cast<const DfTable *>(table), d_prof);
+  if (ev_chunks_done) (void)hipEventRecord(ev_chunks_done, s);
   hipLaunchKernelGGL(k_deflate_offsets, dim3(1), dim3(256), 0, s, (const int32_t *)sizes, (int)nch, offsets);
   hipLaunchKernelGGL(k_deflate_compact, dim3((unsigned)nch), dim3(256), 0, s, (const uint8_t *)slots,
                      (const int64_t *)offsets, dense);

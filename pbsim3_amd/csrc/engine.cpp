@@ -263,6 +263,8 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
     (void)hipEventCreateWithFlags(&sl.ev_prep, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&sl.ev_coop, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&sl.ev_text, hipEventDisableTiming);
+    (void)hipEventCreate(&sl.ev_t0);
+    (void)hipEventCreate(&sl.ev_t1);
     // (normal priority: streams of one priority share a few hardware queues, and a packet waits for the one in front of it in
     // its queue -- a 10 ms walk of long reads among the HIGH priority streams held up other slots' flag reads for 30 ms)
     if (hipStreamCreateWithFlags(&sl.coop_stream, hipStreamNonBlocking) != hipSuccess) sl.coop_stream = nullptr;
@@ -294,6 +296,8 @@ void pbsim_destroy(pbsim_ctx *c) {
       for (int i = 0; i < kDfBuffers; i++) {
         if (L.ev_df[i]) (void)hipEventDestroy(L.ev_df[i]);
         if (L.ev_cp[i]) (void)hipEventDestroy(L.ev_cp[i]);
+        if (L.ev_k0[i]) (void)hipEventDestroy(L.ev_k0[i]);
+        if (L.ev_k1[i]) (void)hipEventDestroy(L.ev_k1[i]);
       }
     }
     if (sl.walk_stream) (void)hipStreamDestroy(sl.walk_stream);
@@ -301,6 +305,8 @@ void pbsim_destroy(pbsim_ctx *c) {
     if (sl.coop_stream) (void)hipStreamDestroy(sl.coop_stream);
     if (sl.ev_coop) (void)hipEventDestroy(sl.ev_coop);
     if (sl.ev_text) (void)hipEventDestroy(sl.ev_text);
+    if (sl.ev_t0) (void)hipEventDestroy(sl.ev_t0);
+    if (sl.ev_t1) (void)hipEventDestroy(sl.ev_t1);
   }
   for (auto &lane : c->df_streams)
     for (hipStream_t &st : lane)
@@ -347,6 +353,7 @@ int pbsim_add_hp_census(pbsim_ctx *c, const uint8_t *seq, int64_t len) {
   HIP_OK(hipMemsetAsync(c->d_seq_own.as<uint8_t>() + len, 0, 64, c->stream));
   if (!prepare_reference(c, c->d_seq_own.as<uint8_t>(), len, 0, c->census)) return PBSIM_FAILED;
   note_hp11(c, c->census);
+  if (c->census[11] > 0) c->hp11_explicit = c->hp11_before_job = true;  // seen by the pre-pass: in front of every record of the genome
   return PBSIM_SUCCEEDED;
 }
 
@@ -359,6 +366,7 @@ int pbsim_finish_hp_census(pbsim_ctx *c) {
     c->class_tables_dirty = true;
   }
   c->census_done = true;
+  c->census_from_job = false;
   return PBSIM_SUCCEEDED;
 }
 
@@ -694,7 +702,11 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
       if (cs != ws) HIP_OK(hipStreamWaitEvent(cs, c->s().ev_prep, 0));
       launch_walk_errhmm_coop(w, n_wg, c->ect.stride + 512 + 1024, ref.hp_flag, cs);
       if (cs != ws) HIP_OK(hipEventRecord(c->s().ev_coop, cs));
-      launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
+      // (every read on the wave walker -- a small batch of a model without verbatim classes, e.g. a truncated tail read --
+      // leaves the lane walker nothing to do: no empty launch, and the kernel's profile holds its bulk launches only)
+      const bool lanes_idle = coop_len == 0 && s.coop_classes == (ncls >= 64 ? ~0ull : (1ull << ncls) - 1);
+      if (!lanes_idle)
+        launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
       if (cs != ws) HIP_OK(hipStreamWaitEvent(ws, c->s().ev_coop, 0));
     } else {
       launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
@@ -851,6 +863,19 @@ extern "C++" int pbsim::finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbs
 
 // Second half: text sizes, their scans, and the text itself into the slot's device buffers.
 static int fetch_stats(pbsim_ctx *c, Slot &sl, int64_t n_tasks);
+// adds a finished text emission's event time to the profile (no wait: an emission still running is left for later)
+static void collect_text_timing(pbsim_ctx *c, Slot &sl) {
+  if (!sl.text_timed || hipEventQuery(sl.ev_t1) != hipSuccess) return;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, sl.ev_t0, sl.ev_t1) == hipSuccess) {
+    std::lock_guard<std::mutex> lk(c->prof_mu);
+    c->prof_text_ms += ms;
+    c->prof_text_launches++;
+    c->prof_text_in += sl.text_in;
+    c->prof_text_out += sl.text_out;
+  }
+  sl.text_timed = false;
+}
 extern "C++" int pbsim::finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
   DeviceFlags *flags = c->s().d_flags.as<DeviceFlags>();
   DeviceFlags f;
@@ -885,7 +910,13 @@ extern "C++" int pbsim::finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
     HIP_OK(c->s().d_maf_text.ensure(std::max<size_t>((size_t)bi.maf_text_bytes + 16, 8u << 20)));
     t.read_text = c->s().d_read_text.as<char>();
     t.maf_text = c->s().d_maf_text.as<char>();
+    collect_text_timing(c, c->s());  // the slot's previous emission finished long ago
+    HIP_OK(hipEventRecord(c->s().ev_t0, c->s().stream));
     launch_text_emit(t, c->s().b_slots_max, flags, c->s().stream);
+    HIP_OK(hipEventRecord(c->s().ev_t1, c->s().stream));
+    c->s().text_timed = true;
+    c->s().text_in = (int64_t)regions_of(c) * bi.maf_columns;  // the MAF rows (+ the quality row) of the emitted reads
+    c->s().text_out = bi.read_text_bytes + bi.maf_text_bytes;
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(c->s().ev_text, c->s().stream));
     // the job pipeline's round loop does not wait for the emission (5-8 ms a round): its delivery thread does (ev_text)
@@ -1070,6 +1101,8 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     for (int i = 0; i < kDfBuffers; i++) {
       HIP_OK(hipEventCreateWithFlags(&sl.ev_df[i], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&sl.ev_cp[i], hipEventDisableTiming));
+      HIP_OK(hipEventCreate(&sl.ev_k0[i]));
+      HIP_OK(hipEventCreate(&sl.ev_k1[i]));
     }
   }
   const bool trace = getenv("PBSIM_DEFLATE_TRACE") != nullptr;  // where a call's wall time goes: kernels | link | consumer
@@ -1088,7 +1121,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     if (!place) HIP_OK(sl.h_df_out[b].ensure((size_t)max_ch * DF_SLOT));
     if (used[b]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - 3 has left this dense buffer
     launch_deflate(d_text + off, len, sl.d_df_slots[a].as<uint8_t>(), sl.d_df_sizes[a].as<int32_t>(), sl.d_df_offsets[a].as<int64_t>(),
-                   sl.d_df_dense[b].as<uint8_t>(), tab, tab + 1024, sl.d_df_code.p, sl.stream, d_prof);
+                   sl.d_df_dense[b].as<uint8_t>(), tab, tab + 1024, sl.d_df_code.p, sl.stream, d_prof, sl.ev_k0[b], sl.ev_k1[b]);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(&h_total[b], sl.d_df_offsets[a].as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
     HIP_OK(hipEventRecord(sl.ev_df[b], sl.stream));
@@ -1106,6 +1139,16 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     t_kernel += now() - t0;
     const int64_t total = h_total[b];
     out_bytes += total;
+    {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, sl.ev_k0[b], sl.ev_k1[b]) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(c->prof_mu);
+        c->prof_deflate_ms += ms;
+        c->prof_deflate_launches++;
+        c->prof_deflate_in += std::min(piece, n - k * piece);
+        c->prof_deflate_out += total;
+      }
+    }
     HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[b], 0));
     char *dst = place ? (*place)(total) : (char *)sl.h_df_out[b].p;
     if (!dst) return fail("deflate: no room for a compressed piece");
@@ -1985,6 +2028,13 @@ int pbsim_prof_reset(pbsim_ctx *c) {
   c->prof_walk_ms = c->prof_total_ms = c->prof_tail_ms = 0;
   c->prof_walk_launches = c->prof_tail_launches = 0;
   c->prof_intervals.clear();
+  {
+    std::lock_guard<std::mutex> lk(c->prof_mu);
+    c->prof_text_ms = c->prof_deflate_ms = 0;
+    c->prof_text_launches = c->prof_text_in = c->prof_text_out = 0;
+    c->prof_deflate_launches = c->prof_deflate_in = c->prof_deflate_out = 0;
+  }
+  for (Slot &sl : c->slots) sl.text_timed = false;
   if (c->device >= 0 && c->stream) {
     HIP_OK(hipSetDevice(c->device));
     if (!c->ev_prof_base) HIP_OK(hipEventCreate(&c->ev_prof_base));
@@ -2023,6 +2073,21 @@ int pbsim_prof_get(pbsim_ctx *c, double *walk_ms, int64_t *walk_launches, double
   if (walk_ms) *walk_ms = c->prof_walk_ms;
   if (walk_launches) *walk_launches = c->prof_walk_launches;
   if (total_ms) *total_ms = c->prof_total_ms;
+  return PBSIM_SUCCEEDED;
+}
+int pbsim_prof_secondary(pbsim_ctx *c, double out[8]) {
+  if (!c || !out) return fail("bad argument");
+  if (c->device >= 0) (void)hipSetDevice(c->device);
+  for (Slot &sl : c->slots) collect_text_timing(c, sl);
+  std::lock_guard<std::mutex> lk(c->prof_mu);
+  out[0] = c->prof_text_ms;
+  out[1] = (double)c->prof_text_launches;
+  out[2] = (double)c->prof_text_in;
+  out[3] = (double)c->prof_text_out;
+  out[4] = c->prof_deflate_ms;
+  out[5] = (double)c->prof_deflate_launches;
+  out[6] = (double)c->prof_deflate_in;
+  out[7] = (double)c->prof_deflate_out;
   return PBSIM_SUCCEEDED;
 }
 void *pbsim_stream(pbsim_ctx *c) { return c ? (void *)c->stream : nullptr; }

@@ -5,10 +5,10 @@
 // (pbsim.cpp:667-759, 3792-4080).  Here every record is resident in HBM and the loop runs as rounds:
 //
 //   round   = W blocks of n reads of one record (W = ranks), rank r walks block r; speculative, un-truncated lengths
-//   pop     = rounds finish in the order they were begun; per round two small all-gathers:
+//   pop     = rounds finish in the order they were begun; per round three small all-gathers:
 //               A  pass-0 bases of every block          -> every rank's len_total in front of its block (quota prefix)
-//               B  (n_final, need_truncated, len_total_after, text bytes) of every block -> the cut, and every rank's
-//                  byte range inside the record's streams
+//               B  (n_final, need_truncated, len_total_after, status) of every block -> the cut
+//               C  (compressed bytes of both streams, status) of the previous round -> every rank's byte range
 //   cut     = the first block the quota rule stops in (pbsim.cpp:3792-3800); later blocks / rounds of the record are void
 //   tail    = the truncated reads behind the cut, one at a time (each depends on the one before), on the cut's rank only,
 //             on a slot of their own, polled between rounds -- no other rank waits for them
@@ -150,8 +150,14 @@ struct Job {
   int depth = 3;
   int64_t reads_walked = 0, reads_delivered = 0, rounds = 0, bases = 0, ref_bases = 0, maf_columns = 0;
   double comm_us = 0;
+  // where the round loop's wall time goes (pbsim_job_breakdown), microseconds
+  double bd_wait_walk = 0, bd_finalize = 0, bd_wait_bytes = 0, bd_account = 0, bd_tail_block = 0, bd_drain = 0, bd_slot_wait = 0,
+         bd_merge = 0, bd_begin = 0, bd_tail_steps = 0;
+  double bd_worker_busy = 0;  // written by the worker thread only, read after it has finished
+  int64_t n_topup = 0, n_tail_reads = 0;
   bool trace = false;
   double t_start = 0;
+  bool peer_failed = false;   // the failure came from another rank's status word (no need to abort the communicator)
   Worker worker;
   std::atomic<bool> delivering[kMaxSlots];
   std::atomic<bool> wfailed{false};
@@ -207,9 +213,13 @@ struct Job {
   // comes free: at most `depth` rounds and one pending delivery hold slots that only the main loop can release; every other
   // slot is with the worker, which needs nobody.
   int acquire_slot() {
+    const double t0 = now_us();
     for (;;) {
       const int s = free_slot();
-      if (s >= 0) return s;
+      if (s >= 0) {
+        bd_slot_wait += now_us() - t0;
+        return s;
+      }
       std::unique_lock<std::mutex> lk(worker.mu);
       worker.cv_idle.wait_for(lk, std::chrono::milliseconds(2));
     }
@@ -248,6 +258,7 @@ struct Job {
       }
   }
 
+  size_t arena_max = 0;  // bytes of pinned memory one lane's arena may hold
   bool wants_text() const { return sink && (sink->on_read_text || sink->on_maf_text); }
   bool deflated() const { return wants_text() && c->deflate == 3; }
 
@@ -329,12 +340,12 @@ struct Job {
       const uint8_t *d = which == 0 ? sl.d_read_text.as<uint8_t>() : sl.d_maf_text.as<uint8_t>();
       bool oom = false;
       const std::function<char *(int64_t)> place = [&](int64_t k) -> char * {
-        char *p = L.arena_reserve(k);
+        char *p = L.arena_reserve(k, arena_max);
         if (!p) oom = true;
         return p;
       };
       if (!deflate_pieces(c, L, d, n, [](const char *, int64_t) { return PBSIM_SUCCEEDED; }, &place))
-        return oom ? fail("out of pinned host memory for a compressed batch") : PBSIM_FAILED;
+        return oom ? fail("out of pinned host memory for a compressed batch (PBSIM_PINNED_ARENA_MB bounds a lane's arena)") : PBSIM_FAILED;
       int64_t tot = 0;
       for (const auto &sg : L.arena_segs) tot += sg.second;
       (which == 0 ? *read_gz : *maf_gz) = tot;
@@ -386,6 +397,7 @@ struct Job {
         ok = arena_fill(*sl, &sizes[0], &sizes[1]);
       }
       if (!ok) worker_fail();
+      bd_worker_busy += now_us() - w0;
       if (trace)
         fprintf(stderr, "[pbsim job r%d] t=%.1f ms   worker: bytes of rec %lld on their way for %.1f ms (%lld + %lld)\n", rank,
                 (w0 - t_start) / 1e3, (long long)R->ref.unit, (now_us() - w0) / 1e3, (long long)sizes[0], (long long)sizes[1]);
@@ -401,7 +413,10 @@ struct Job {
     if (!acct_slot) return PBSIM_SUCCEEDED;
     Slot *sl = acct_slot;
     acct_slot = nullptr;
-    return account_of(c, *sl, &acct_rec->st);
+    const double t0 = now_us();
+    const int ok = account_of(c, *sl, &acct_rec->st);
+    bd_account += now_us() - t0;
+    return ok;
   }
   int complete_pending(bool defer_account = false) {
     if (!account_deferred()) return PBSIM_FAILED;
@@ -411,6 +426,7 @@ struct Job {
     const double t0 = now_us();
     const int ok1 = d->stage1_done.get();
     const double t1 = now_us();
+    bd_wait_bytes += t1 - t0;
     int64_t mine2[3] = {d->mine ? d->sizes[0] : 0, d->mine ? d->sizes[1] : 0, ok1 ? 0 : 1};
     std::vector<int64_t> S;
     if (!gather(mine2, 3, &S)) return PBSIM_FAILED;
@@ -424,7 +440,10 @@ struct Job {
       maf_all += S[(size_t)q * 3 + 1];
       bad += S[(size_t)q * 3 + 2];
     }
-    if (bad) return ok1 ? fail("another rank of the job failed") : check_worker();
+    if (bad) {
+      if (ok1) peer_failed = true;
+      return ok1 ? fail("another rank of the job failed") : check_worker();
+    }
     R.read_off += read_all;
     R.maf_off += maf_all;
     if (d->mine) {
@@ -486,6 +505,7 @@ struct Job {
       c->cur = R.tail_slot;
       if (!block && hipEventQuery(c->s().ev3) != hipSuccess) return PBSIM_SUCCEEDED;
       const double t0 = now_us();
+      n_tail_reads++;
       if (!pbsim_batch_walk_end(c, nullptr)) return PBSIM_FAILED;
       const double ta = now_us();
       pbsim_batch_info bi;
@@ -529,6 +549,7 @@ struct Job {
       R.next_read += bi.n_final;
       R.len_total = bi.len_total_after;
       R.tail_slot = -1;
+      if (!block) bd_tail_steps += now_us() - t0;
       if (R.len_total < R.quota) {
         if (!tail_begin(R)) return PBSIM_FAILED;
       } else {
@@ -542,13 +563,28 @@ struct Job {
   int finish_record(int rec) {
     Rec &R = recs[(size_t)rec];
     if (!complete_pending()) return PBSIM_FAILED;  // every rank is here at the same point of the round sequence
-    if (rank == R.owner && !tail_poll(rec, true)) return PBSIM_FAILED;
+    const double tt = now_us();
+    int tail_ok = PBSIM_SUCCEEDED;
+    std::string tail_err;
+    if (rank == R.owner && !tail_poll(rec, true)) {  // carried to the other ranks by the merge's status word
+      tail_ok = PBSIM_FAILED;
+      tail_err = g_err;
+    }
+    const double td = now_us();
+    bd_tail_block += td - tt;
     worker.drain();  // every delivery of the record has reached the sink and the statistics
-    if (!check_worker()) return PBSIM_FAILED;
-    int64_t extra[2] = {R.tail_read, R.tail_maf};
+    bd_drain += now_us() - td;
+    // [2] = status: a rank whose tail or worker failed tells the others here instead of leaving them in the merge's collectives
+    int64_t extra[3] = {R.tail_read, R.tail_maf, (tail_ok && !wfailed) ? 0 : 1};
     const double t0 = now_us();
-    if (!stats_merge(&R.st, c->p, W > 1 ? comm : nullptr, extra, 2)) return PBSIM_FAILED;
-    comm_us += now_us() - t0;
+    if (!stats_merge(&R.st, c->p, W > 1 ? comm : nullptr, extra, 3)) return PBSIM_FAILED;
+    bd_merge += now_us() - t0;
+    if (!tail_ok) return fail(tail_err);
+    if (!check_worker()) return PBSIM_FAILED;
+    if (extra[2]) {
+      peer_failed = true;
+      return fail("another rank of the job failed");
+    }
     R.merged = R.done = true;
     pbsim_stats st;
     stats_finish(R.st, c->p, R.ref.len, &st);
@@ -574,7 +610,10 @@ struct Job {
     n_per = std::max<int64_t>(n_per, 1);
     const int s = acquire_slot();
     c->cur = s;
+    const double tb = now_us();
+    if (trace) fprintf(stderr, "[pbsim job r%d] begin rec %d first=%lld n_per=%lld\n", rank, rec + 1, (long long)R.spec_read, (long long)n_per);
     if (!walk_begin(c, R.ref, R.spec_read + (int64_t)rank * n_per, n_per, -1)) return PBSIM_FAILED;
+    bd_begin += now_us() - tb;
     fifo.push_back(Round{rec, s, R.spec_read, n_per, mean});
     R.spec_read += (int64_t)W * n_per;
     R.spec_total += (double)W * (double)n_per * mean;
@@ -597,6 +636,7 @@ struct Job {
     }
     if (wfailed) code = 2;
     const double t1 = now_us();
+    bd_wait_walk += t1 - t0;
     std::vector<int64_t> A, B;
     const int64_t sendA[2] = {pass0, code};
     if (!gather(sendA, 2, &A)) return PBSIM_FAILED;
@@ -609,6 +649,7 @@ struct Job {
     if (worst == 2) {
       drop_everything();
       if (wfailed) return check_worker();
+      if (code != 2) peer_failed = true;
       return fail(code == 2 ? my_err : "another rank of the job failed");
     }
     if (worst == 1) {
@@ -625,14 +666,23 @@ struct Job {
       return PBSIM_SUCCEEDED;
     }
     pbsim_batch_info bi;
-    if (!finalize_cut(c, before, &bi)) return PBSIM_FAILED;
-    if (!finalize_text(c, &bi)) return PBSIM_FAILED;
+    memset(&bi, 0, sizeof bi);
+    // a failure here travels in gather B's status word: every rank leaves the job at the same collective
+    const int fin_ok = finalize_cut(c, before, &bi) && finalize_text(c, &bi);
+    if (!fin_ok) my_err = g_err;
     const double t2 = now_us();
-    const int64_t sendB[5] = {bi.n_final, bi.need_truncated_read, bi.len_total_after, bi.read_text_bytes, bi.maf_text_bytes};
-    if (!gather(sendB, 5, &B)) return PBSIM_FAILED;
+    const int64_t sendB[4] = {bi.n_final, bi.need_truncated_read, bi.len_total_after, fin_ok ? 0 : 1};
+    if (!gather(sendB, 4, &B)) return PBSIM_FAILED;
+    int64_t bad_b = 0;
+    for (int q = 0; q < W; q++) bad_b += B[(size_t)q * 4 + 3];
+    if (bad_b) {
+      drop_everything();
+      if (fin_ok) peer_failed = true;
+      return fail(fin_ok ? "another rank of the job failed" : my_err);
+    }
     int cut = -1;
     for (int q = 0; q < W && cut < 0; q++)
-      if (B[(size_t)q * 5] < rd.n_per) cut = q;
+      if (B[(size_t)q * 4] < rd.n_per) cut = q;
     const int last_valid = cut < 0 ? W - 1 : cut;
     const bool mine = rank <= last_valid && bi.n_final > 0;
     // ---- delivery: the previous round's sizes first (its bytes have been on their way while this round was finalised), then
@@ -652,6 +702,7 @@ struct Job {
       maf_columns += bi.maf_columns;
     }
     const double t3 = now_us();
+    bd_finalize += t2 - t1;
     // ---- the record's state, identical on every rank
     const double n_round = (double)W * (double)rd.n_per;
     R.spec_total += (double)pass0_sum - n_round * rd.mean;
@@ -665,13 +716,13 @@ struct Job {
     }
     if (cut < 0) {
       R.next_read += (int64_t)W * rd.n_per;
-      R.len_total = B[(size_t)(W - 1) * 5 + 2];
+      R.len_total = B[(size_t)(W - 1) * 4 + 2];
     } else {
-      R.next_read += (int64_t)cut * rd.n_per + B[(size_t)cut * 5];
-      R.len_total = B[(size_t)cut * 5 + 2];
+      R.next_read += (int64_t)cut * rd.n_per + B[(size_t)cut * 4];
+      R.len_total = B[(size_t)cut * 4 + 2];
       R.spec_read = R.next_read;
       R.spec_total = (double)R.len_total;
-      if (B[(size_t)cut * 5 + 1] && R.len_total < R.quota) {  // pbsim.cpp:3795-3800: the next read is a truncated one
+      if (B[(size_t)cut * 4 + 1] && R.len_total < R.quota) {  // pbsim.cpp:3795-3800: the next read is a truncated one
         R.owner = cut;
         R.bulk_done = true;
       }
@@ -714,6 +765,7 @@ struct Job {
             if (!recs[(size_t)r].bulk_done && !has) cand = r;
           }
           if (cand < 0) break;
+          n_topup++;
         }
         if (cand >= merged + 3) {
           // at most three records' statistics are open at a time: merge the oldest first (a collective at a point of the
@@ -780,14 +832,24 @@ int pbsim_job_add_record_comm(pbsim_ctx *c, const uint8_t *seq, int64_t len, con
   if (!c) return fail("pbsim_job_add_record_comm: bad argument");
   NEED_DEVICE(c);
   HIP_OK(hipSetDevice(c->device));
-  if (len < 1 || len > 1000000000LL) return fail("pbsim_job_add_record_comm: bad length");
+  // every rank learns whether every rank is ready BEFORE the broadcast: a rank that returned early would leave the others in it
   DevBuf tmp;
-  HIP_OK(tmp.ensure((size_t)len, true));
-  if (comm->rank == root) {
-    if (!seq) return fail("pbsim_job_add_record_comm: the root rank must pass the record");
-    HIP_OK(hipMemcpy(tmp.p, seq, (size_t)len, hipMemcpyHostToDevice));
+  int ok = PBSIM_SUCCEEDED;
+  if (len < 1 || len > 1000000000LL) ok = fail("pbsim_job_add_record_comm: bad length");
+  if (ok && tmp.ensure((size_t)len, true) != hipSuccess) ok = fail("pbsim_job_add_record_comm: out of device memory");
+  if (ok && comm->rank == root) {
+    if (!seq) ok = fail("pbsim_job_add_record_comm: the root rank must pass the record");
+    else if (hipMemcpy(tmp.p, seq, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) ok = fail("pbsim_job_add_record_comm: upload failed");
   }
-  HIP_OK(hipDeviceSynchronize());
+  if (ok && hipDeviceSynchronize() != hipSuccess) ok = fail("pbsim_job_add_record_comm: device error");
+  if (comm->all_reduce_i64) {
+    const std::string keep = g_err;
+    int64_t bad = ok ? 0 : 1;
+    if (!comm->all_reduce_i64(comm->user, &bad, 1, PBSIM_OP_MAX)) return fail("pbsim_comm.all_reduce_i64 failed");
+    if (bad) return ok ? fail("pbsim_job_add_record_comm: another rank failed") : fail(keep);
+  } else if (!ok) {
+    return PBSIM_FAILED;
+  }
   if (!comm->broadcast(comm->user, tmp.p, len, root, 1)) return fail("pbsim_comm.broadcast failed");
   HIP_OK(hipDeviceSynchronize());  // whatever stream the communicator used: the bytes are in `tmp` before they are copied on
   if (!job_add(c, tmp.p, len, hipMemcpyDeviceToDevice)) return PBSIM_FAILED;
@@ -804,6 +866,16 @@ int pbsim_job_clear(pbsim_ctx *c) { return pbsim_job_begin(c, 1); }
 int pbsim_job_begin(pbsim_ctx *c, int64_t first_record) {
   if (!c || first_record < 1) return fail("pbsim_job_begin: bad argument");
   c->job_first_unit = first_record;
+  // Q15 state in front of the job's first record: a job that starts at record 1 starts a genome (only what an explicit
+  // census pass has seen counts), a later job of the same genome carries on from the job before it.  Every pbsim_job_run
+  // starts from this value, so re-running a job gives the same bytes as its first run.
+  c->hp11_before_job = first_record == 1 ? c->hp11_explicit : c->bias.hp11_seen;
+  if (first_record == 1 && c->census_from_job) {  // the census of the previous genome's records: the next job takes its own
+    c->census_done = c->census_from_job = false;
+    hp_bias_default(&c->bias);
+    c->class_tables_dirty = true;
+  }
+  c->bias.hp11_seen = c->hp11_before_job;
   if (c->prefetch_stream) (void)hipStreamSynchronize(c->prefetch_stream);
   for (Slot &sl : c->slots) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
@@ -831,6 +903,12 @@ int64_t pbsim_job_bam_header(pbsim_ctx *c, int64_t record, char *buf, int64_t ca
     memcpy(buf + 8 + h.size(), &zero, 4);
   }
   return n;
+}
+
+int pbsim_job_breakdown(pbsim_ctx *c, double out[16]) {
+  if (!c || !out) return fail("bad argument");
+  memcpy(out, c->job_breakdown, sizeof c->job_breakdown);
+  return PBSIM_SUCCEEDED;
 }
 
 int pbsim_job_counters(pbsim_ctx *c, int64_t out[8]) {
@@ -872,16 +950,23 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   for (size_t i = 0; i < n; i++)
     HIP_OK(hipMemcpy(&fl[i], c->job_records[i]->flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost));
   int64_t census[kHpSlots] = {0};
-  bool any11 = c->bias.hp11_seen;
+  bool any11 = c->hp11_before_job;
   for (size_t i = 0; i < n; i++) {
     for (int k = 0; k < kHpSlots; k++) census[k] += (int64_t)fl[i].hpfreq[k];
     any11 |= fl[i].hpfreq[11] > 0;
   }
-  if (c->p.hp_del_bias != 1 && !c->census_done) {  // pbsim.cpp:677-696: the census of ALL records comes before the first read
-    hp_bias_from_census(c->p.hp_del_bias, census, &c->bias);
-    c->bias.hp11_seen = any11;  // the pre-pass has run get_genome_seq over every record (hpfreq[11]++, pbsim.cpp:1058)
-    c->class_tables_dirty = true;
-    c->census_done = true;
+  c->bias.hp11_seen = c->hp11_before_job;  // every run of the job starts from the same Q15 state
+  // pbsim.cpp:677-696: the census of ALL records comes before the first read.  Without pbsim_finish_hp_census the job's own
+  // records are the genome; recomputed per run (records may have been added since the last one).
+  if (c->p.hp_del_bias != 1 && (!c->census_done || c->census_from_job)) {
+    HpBias nb = c->bias;
+    hp_bias_from_census(c->p.hp_del_bias, census, &nb);
+    nb.hp11_seen = any11;  // the pre-pass has run get_genome_seq over every record (hpfreq[11]++, pbsim.cpp:1058)
+    if (!c->census_done || memcmp(nb.bias, c->bias.bias, sizeof nb.bias) != 0) c->class_tables_dirty = true;
+    c->bias = nb;
+    c->census_done = c->census_from_job = true;
+  } else if (c->p.hp_del_bias != 1 && c->hp11_explicit) {
+    c->bias.hp11_seen = true;
   }
   J.recs.resize(n);
   bool seen11 = c->bias.hp11_seen;
@@ -939,20 +1024,52 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     const int64_t auto_b = (int64_t)std::max(256.0 * (1 << 20), std::min(want, share));
     if (auto_b > c->scratch_budget || c->scratch_budget > 2 * auto_b) c->scratch_budget = auto_b;
   }
-  if (W > 1) {  // every rank must size its rounds alike: the smallest pool decides
-    int64_t b = c->scratch_budget;
-    if (!comm->all_reduce_i64(comm->user, &b, 1, PBSIM_OP_MIN)) return fail("pbsim_comm.all_reduce_i64 failed");
-    c->scratch_budget = b;
+  if (const char *tr = getenv("PBSIM_JOB_TARGET_RANKS")) {  // test hook: a batch target per rank, "a,b,c" (ranks that see
+    std::vector<double> v;                                 // different free memory size their rounds from different numbers)
+    for (const char *q = tr; *q;) {
+      char *e = nullptr;
+      v.push_back(strtod(q, &e));
+      if (e == q) break;
+      q = *e == ',' ? e + 1 : e;
+    }
+    if (!v.empty() && v[(size_t)J.rank % v.size()] > 0) target = v[(size_t)J.rank % v.size()];
+  }
+  // Every rank must size its rounds alike: a round gives rank r the reads first + r * n_per .. and the cut compares every
+  // block with the same n_per, so EVERY input of the caps that a rank derives from its own GPU (the pool, and the batch target
+  // once the free memory bounds it) goes through one MIN over the ranks.
+  std::vector<int64_t> agree(n + 1);
+  agree[0] = c->scratch_budget;
+  if (W > 1) {
+    if (!comm->all_reduce_i64(comm->user, agree.data(), 1, PBSIM_OP_MIN)) return fail("pbsim_comm.all_reduce_i64 failed");
+    c->scratch_budget = agree[0];
   }
   J.mean = 0.97 * c->hdr.mean_len;  // bases a read yields (deletions outweigh insertions in most models); measured from round 1 on
   for (size_t i = 0; i < n; i++) {
     Rec &R = J.recs[i];
     const double m = std::min<double>(c->hdr.mean_len, (double)R.ref.len);
     R.cap = std::max<int64_t>(1, std::min<int64_t>(batch_capacity_for(c, R.ref.len), (int64_t)(1.08 * target / P / m) + 64));
+    agree[i + 1] = R.cap;
+  }
+  if (W > 1) {
+    if (!comm->all_reduce_i64(comm->user, agree.data(), (int64_t)agree.size(), PBSIM_OP_MIN)) return fail("pbsim_comm.all_reduce_i64 failed");
+    for (size_t i = 0; i < n; i++) J.recs[i].cap = agree[i + 1];
   }
   J.mean = std::min<double>(J.mean, (double)c->job_records[0]->len);
   for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
-  if (J.deflated() && !ensure_deflate_ready(c)) return PBSIM_FAILED;  // before the worker and its lane threads use the tables
+  {
+    const char *am = getenv("PBSIM_PINNED_ARENA_MB");  // pinned host memory one lane's arena may hold (several ranks: a round's
+    J.arena_max = (size_t)(am && atoll(am) > 0 ? atoll(am) : 16384) << 20;  // members wait there for their offsets)
+  }
+  // (several ranks: a failure in front of the first collective of the round loop is agreed on first, like every later one)
+  int ready = (!J.deflated() || ensure_deflate_ready(c)) ? PBSIM_SUCCEEDED : PBSIM_FAILED;  // before the worker and its lane threads use the tables
+  if (W > 1) {
+    const std::string keep = g_err;
+    int64_t bad = ready ? 0 : 1;
+    if (!comm->all_reduce_i64(comm->user, &bad, 1, PBSIM_OP_MAX)) return fail("pbsim_comm.all_reduce_i64 failed");
+    if (bad) return ready ? fail("another rank of the job failed") : fail(keep);
+  } else if (!ready) {
+    return PBSIM_FAILED;
+  }
   const int keep_lds = c->walk_lds_kb;
   c->walk_lds_kb = 41;  // three walk workgroups per CU: the round loop waits on many short kernels (kernels.hip walk_lds)
   c->defer_text_sync = true;  // the round loop does not wait for a round's text emission; the delivery thread does
@@ -963,9 +1080,35 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     if (sl.stream && hipStreamSynchronize(sl.stream) != hipSuccess && ok) ok = fail("hipStreamSynchronize failed at the end of the job");
   if (!ok) {
     const std::string keep = g_err;
+    // A failure that only this rank knows of (not one that came in through a collective's status word) would leave the other
+    // ranks waiting in their next collective: the communicator's abort, when it has one, releases them.  Without it the caller
+    // must tear the process group down (include/pbsim3_amd.h).
+    if (W > 1 && !J.peer_failed && comm->abort) comm->abort(comm->user);
     J.drop_everything();
     J.worker.finish();
     g_err = keep;
+  }
+  for (Slot &sl : c->slots)
+    for (DfLane &L : sl.df) L.arena_trim();
+  {
+    const double wall = now_us() - J.t_start;
+    double *b = c->job_breakdown;
+    b[0] = wall;
+    b[1] = J.bd_wait_walk;
+    b[2] = J.bd_finalize;
+    b[3] = J.bd_wait_bytes;
+    b[4] = J.comm_us;
+    b[5] = J.bd_account;
+    b[6] = J.bd_tail_block;
+    b[7] = J.bd_drain;
+    b[8] = J.bd_slot_wait;
+    b[9] = J.bd_merge;
+    b[10] = J.bd_begin;
+    b[11] = J.bd_tail_steps;
+    b[12] = J.bd_worker_busy;
+    b[13] = (double)J.n_topup;
+    b[14] = (double)J.n_tail_reads;
+    b[15] = (double)J.depth;
   }
   c->job_counters[0] = J.reads_walked;
   c->job_counters[1] = J.reads_delivered;

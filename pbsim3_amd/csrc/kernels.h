@@ -223,6 +223,7 @@ void launch_deflate_table(const uint8_t *text, int64_t n_bytes, uint32_t *hist, 
 // slots: nch * DF_SLOT bytes, sizes: nch, offsets: nch + 1, dense: nch * DF_SLOT bytes worst case; table from launch_deflate_table
 void launch_deflate(const uint8_t *text, int64_t n_bytes, uint8_t *slots, int32_t *sizes, int64_t *offsets,
                     uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, const void *table, hipStream_t s,
-                    unsigned long long *d_prof = nullptr /* PBSIM_DEFLATE_PROF: per-phase tick sums */);
+                    unsigned long long *d_prof = nullptr /* PBSIM_DEFLATE_PROF: per-phase tick sums */,
+                    hipEvent_t ev_begin = nullptr, hipEvent_t ev_chunks_done = nullptr /* recorded around k_deflate_chunks */);
 
 }  // namespace pbsim

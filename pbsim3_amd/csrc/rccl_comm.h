@@ -7,8 +7,14 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -20,6 +26,8 @@ struct RcclApi {
   void *lib = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
+  std::atomic<bool> aborted{false};                 // pbsim_comm.abort of any rank of this process
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -46,6 +54,7 @@ struct RcclApi {
     PBSIM_RCCL_SYM(AllGather, "ncclAllGather")
     PBSIM_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef PBSIM_RCCL_SYM
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
     return true;
   }
 };
@@ -69,28 +78,72 @@ struct RcclRank {
   }
 };
 
+// The watchdog: a collective is waited for by polling its stream.  One that does not come back within PBSIM_COMM_TIMEOUT_S
+// seconds (default 600) means that some rank never entered it -- it failed, or the ranks fell out of step -- and nothing the
+// process could do would bring it back: say so and end the process (a fresh exit; no restart in-process).  A rank whose job
+// failed calls pbsim_comm.abort: the others then give their communicators up and return 0 instead of waiting for the timeout.
+inline bool rccl_wait(RcclRank *r, const char *what) {
+  static const double timeout_s = [] {
+    const char *e = getenv("PBSIM_COMM_TIMEOUT_S");
+    return e && atof(e) > 0 ? atof(e) : 600.0;
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long spins = 0;; spins++) {
+    const hipError_t e = hipStreamQuery(r->stream);
+    if (e == hipSuccess) return true;
+    if (e != hipErrorNotReady) return false;
+    if (r->api->aborted.load(std::memory_order_relaxed)) {
+      if (r->comm && r->api->CommAbort) (void)r->api->CommAbort(r->comm);
+      r->comm = nullptr;
+      return false;
+    }
+    if (spins < 4000) {
+      sched_yield();
+      continue;
+    }
+    usleep(50);
+    if ((spins & 1023) == 0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+      fprintf(stderr,
+              "ERROR: rank %d of %d: the RCCL %s did not complete within %.0f s (PBSIM_COMM_TIMEOUT_S): another rank failed or the "
+              "ranks fell out of step.  Aborting the process.\n",
+              r->rank, r->world, what, timeout_s);
+      fflush(stderr);
+      _exit(124);
+    }
+  }
+}
+
+inline int rccl_abort(void *user) {
+  ((RcclRank *)user)->api->aborted.store(true);
+  return 1;
+}
+
 inline int rccl_all_gather(void *user, const int64_t *send, int64_t n, int64_t *recv) {
   RcclRank *r = (RcclRank *)user;
+  if (!r->comm || r->api->aborted.load()) return 0;
   if (!r->ensure((size_t)n * 8, (size_t)n * 8 * (size_t)r->world)) return 0;
   if (hipMemcpyAsync(r->d_send, send, (size_t)n * 8, hipMemcpyHostToDevice, r->stream) != hipSuccess) return 0;
   if (r->api->AllGather(r->d_send, r->d_recv, (size_t)n, ncclInt64, r->comm, r->stream) != ncclSuccess) return 0;  // C3
   if (hipMemcpyAsync(recv, r->d_recv, (size_t)n * 8 * (size_t)r->world, hipMemcpyDeviceToHost, r->stream) != hipSuccess) return 0;
-  return hipStreamSynchronize(r->stream) == hipSuccess;
+  return rccl_wait(r, "all-gather");
 }
 
 inline int rccl_all_reduce(void *user, int64_t *buf, int64_t n, int32_t op) {
   RcclRank *r = (RcclRank *)user;
+  if (!r->comm || r->api->aborted.load()) return 0;
   if (n == 0) return 1;
   if (!r->ensure((size_t)n * 8, (size_t)n * 8)) return 0;
   const ncclRedOp_t rop = op == PBSIM_OP_SUM ? ncclSum : op == PBSIM_OP_MIN ? ncclMin : ncclMax;
   if (hipMemcpyAsync(r->d_send, buf, (size_t)n * 8, hipMemcpyHostToDevice, r->stream) != hipSuccess) return 0;
   if (r->api->AllReduce(r->d_send, r->d_recv, (size_t)n, ncclInt64, rop, r->comm, r->stream) != ncclSuccess) return 0;  // C2
   if (hipMemcpyAsync(buf, r->d_recv, (size_t)n * 8, hipMemcpyDeviceToHost, r->stream) != hipSuccess) return 0;
-  return hipStreamSynchronize(r->stream) == hipSuccess;
+  return rccl_wait(r, "all-reduce");
 }
 
 inline int rccl_broadcast(void *user, void *p, int64_t bytes, int32_t root, int32_t on_device) {
   RcclRank *r = (RcclRank *)user;
+  if (!r->comm || r->api->aborted.load()) return 0;
   if (hipSetDevice(r->device) != hipSuccess) return 0;
   if (!r->stream && hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return 0;
   void *d = p;
@@ -101,7 +154,7 @@ inline int rccl_broadcast(void *user, void *p, int64_t bytes, int32_t root, int3
   }
   if (r->api->Broadcast(d, d, (size_t)bytes, ncclUint8, root, r->comm, r->stream) != ncclSuccess) return 0;  // C1
   if (!on_device && r->rank != root && hipMemcpyAsync(p, d, (size_t)bytes, hipMemcpyDeviceToHost, r->stream) != hipSuccess) return 0;
-  return hipStreamSynchronize(r->stream) == hipSuccess;
+  return rccl_wait(r, "broadcast");
 }
 
 inline RcclApi &rccl_api() {
@@ -139,7 +192,7 @@ inline bool rccl_init_all(const std::vector<int> &devices, std::vector<RcclRank>
 inline void rccl_destroy_all(std::vector<RcclRank> *ranks) {
   for (RcclRank &r : *ranks) {
     (void)hipSetDevice(r.device);
-    if (r.stream) (void)hipStreamSynchronize(r.stream);
+    if (r.stream && r.comm) (void)hipStreamSynchronize(r.stream);
     if (r.comm) (void)r.api->CommDestroy(r.comm);
     if (r.d_send) (void)hipFree(r.d_send);
     if (r.d_recv) (void)hipFree(r.d_recv);
@@ -156,6 +209,7 @@ inline pbsim_comm rccl_comm(RcclRank *r) {
   c.all_gather_i64 = rccl_all_gather;
   c.all_reduce_i64 = rccl_all_reduce;
   c.broadcast = rccl_broadcast;
+  c.abort = rccl_abort;
   return c;
 }
 

@@ -28,13 +28,13 @@ def main(argv=None):
                 backend = val
             else:
                 os.environ["PBSIM_SCRATCH_MB"] = val
-    import torch
-    import torch.distributed as dist
-
     import pbsim3_amd as P
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    P.bind_host_to_device(local)   # before the first HIP call: this rank's threads and pinned staging on its GPU's NUMA node
+    import torch
+    import torch.distributed as dist
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -134,3 +134,45 @@ def compare_bam_with_sam(bam, sam_text):
                 assert x[5:7] == "C," and v == [int(y) for y in val.split(",")[1:]]
             else:
                 assert v == [float(y) for y in val.split(",")[1:]]
+
+
+@pytest.mark.parametrize("case", ["wgs_qshmm_rsii_pass3", "wgs_errhmm_sequel_pass3", "wgs_qshmm_onthq_pass2_hpbias2",
+                                  "trans_errhmm_sequel_acc99_pass2"])
+def test_native_bam_through_the_independent_reader(case, tmp_path):
+    """The same files through tests/bam_spec_reader.py -- a reader written from SAMv1 4.1 / 4.2 alone that shares nothing
+    with the parser above or with the writer (it stands in for samtools, which this image lacks): container framing, every
+    mandatory column as SAM text, every optional field with its type letter."""
+    import bam_spec_reader as R
+    args = harness.resolve(CASES[case]["args"])
+    p = subprocess.run([CLI] + args + ["--prefix", str(tmp_path / "out")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    gold_dir = tmp_path / "g"
+    gold_dir.mkdir()
+    gold = harness.run_oracle(CASES[case]["args"], "philox", str(gold_dir))
+    sams = sorted(k for k in gold if k.endswith(".sam"))
+    assert sams
+    for k in sams:
+        text, refs, recs = R.read_bam((tmp_path / ("out" + k[:-4] + ".bam")).read_bytes())
+        lines = gold[k].decode().split("\n")
+        assert text.decode() == "".join(l + "\n" for l in lines if l.startswith("@")) and refs == []
+        body = [l.split("\t") for l in lines if l and not l.startswith("@")]
+        assert len(recs) == len(body)
+        for a, f in zip(recs, body):
+            want = f[:11]
+            want[9] = want[9].upper()      # 4-bit codes carry no case (Q6: a lower-case first base exists in SAM text only)
+            assert R.sam_fields(a, refs) == want
+            assert a["bin"] == R.reg2bin(a["pos"], a["pos"] + 1)
+            assert len(a["aux"]) == len(f) - 11
+            for (tag, typ, val), col in zip(a["aux"], f[11:]):
+                t, ty, v = col.split(":", 2)
+                assert tag == t
+                if ty == "i":
+                    assert val == int(v) and typ == R.smallest_int_type(int(v))
+                elif ty == "f":
+                    assert typ == "f" and val == np.float32(float(v))
+                elif ty == "Z":
+                    assert typ == "Z" and val == v
+                else:
+                    assert ty == "B" and typ == "B" + v[0]
+                    nums = v.split(",")[1:]
+                    assert val == ([int(x) for x in nums] if v[0] != "f" else [float(np.float32(float(x))) for x in nums])

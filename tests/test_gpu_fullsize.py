@@ -1,0 +1,314 @@
+"""The BENCHMARKED path at the BENCHMARKED size, content-checked.
+
+bench.py times pbsim_job_run + pbsim_set_deflate(7) + the delivery threads + the wave walker at its default split on 750 Mbp
+records at depth 20 and, at that size, only counts bytes.  Here the same path delivers one such record (15 Gbases, 1.7 M
+reads, 63 GB of text, ~2 M gzip members) and every member is looked at: each carries the CRC-32 and the length of the 32 KiB
+of text it holds (RFC 1952), and CRC-32 composes -- crc(A || B) = shift(crc(A), |B|) xor crc(B) -- so the members of a
+stream, folded in offset order, give the CRC-32 and length of the record's WHOLE FASTQ resp. MAF text whatever the batch
+partition, the rank count or the walker that produced it.  That pair, and the record's statistics, must be identical for
+
+    one rank | one rank without the wave walker | one rank with a small scratch pool (other batches) | three ranks
+
+and the statistics equal pbsim_simulate_wgs's (the per-record driver).  Every 997th member is inflated with zlib and checked
+against its own trailer, so the CRCs are CRCs of what the members really hold.  A second test compares 300 Mbases delivered
+through the same path -- compressed sinks, default split -- with the oracle byte for byte."""
+import ctypes as C
+import os
+import struct
+import threading
+import zlib
+
+import numpy as np
+import pytest
+
+import harness
+
+pytestmark = pytest.mark.gpu
+
+G = 750_000_000
+
+
+# ---- CRC-32 of a concatenation from the parts' CRCs (GF(2) shift operators; zlib's crc32_combine is not in Python's zlib) ----
+def _apply(mat, vec):
+    s, i = 0, 0
+    while vec:
+        if vec & 1:
+            s ^= mat[i]
+        vec >>= 1
+        i += 1
+    return s
+
+
+def _mul(a, b):  # operator a after operator b
+    return [_apply(a, col) for col in b]
+
+
+def shift_operator(nbytes):
+    """32 x 32 GF(2) matrix (columns as ints) that advances a CRC-32 register over nbytes zero bytes"""
+    one_bit = [0xedb88320] + [1 << (n - 1) for n in range(1, 32)]
+    m = one_bit
+    for _ in range(3):
+        m = _mul(m, m)            # 1 -> 2 -> 4 -> 8 zero bits
+    result = [1 << n for n in range(32)]
+    while nbytes:
+        if nbytes & 1:
+            result = _mul(m, result)
+        m = _mul(m, m)
+        nbytes >>= 1
+    return result
+
+
+class CrcFold:
+    """running (crc, length) of a stream given its pieces' (crc, length) in order"""
+
+    def __init__(self):
+        self.crc, self.n = 0, 0
+        self.ops = {}
+        full = shift_operator(32768)
+        self.tab = [[_apply(full, b << (8 * k)) for b in range(256)] for k in range(4)]
+
+    def add(self, crc, n):
+        if n == 32768:
+            c, t = self.crc, self.tab
+            self.crc = t[0][c & 255] ^ t[1][(c >> 8) & 255] ^ t[2][(c >> 16) & 255] ^ t[3][c >> 24] ^ crc
+        elif n:
+            op = self.ops.get(n)
+            if op is None:
+                op = self.ops[n] = shift_operator(n)
+            self.crc = _apply(op, self.crc) ^ crc
+        self.n += n
+
+
+def test_crc_fold_is_crc_of_the_concatenation():
+    rng = np.random.default_rng(3)
+    parts = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (32768, 32768, 5, 32768, 1, 20000, 32768)]
+    f = CrcFold()
+    for p in parts:
+        f.add(zlib.crc32(p), len(p))
+    assert (f.crc, f.n) == (zlib.crc32(b"".join(parts)), sum(map(len, parts)))
+
+
+def walk_members(buf, fold_pieces, sample_every, counter):
+    """buf: numpy uint8 view of whole members; appends (crc, isize) of each to fold_pieces, inflates a sample"""
+    at, n = 0, len(buf)
+    mv = memoryview(buf)
+    while at < n:
+        assert buf[at] == 31 and buf[at + 1] == 139 and buf[at + 12] == 66 and buf[at + 13] == 67, "not a BGZF member"
+        size = (int(buf[at + 16]) | (int(buf[at + 17]) << 8)) + 1
+        crc, isize = struct.unpack_from("<II", mv, at + size - 8)
+        fold_pieces.append((crc, isize))
+        counter[0] += 1
+        if counter[0] % sample_every == 0:
+            data = zlib.decompress(bytes(mv[at + 18:at + size - 8]), -15)
+            assert len(data) == isize and zlib.crc32(data) == crc
+        at += size
+    assert at == n, "a piece does not end on a member boundary"
+
+
+class MemberSink:
+    """receives (offset, members) pieces of the two streams of one record, possibly from several ranks and threads"""
+
+    def __init__(self, P):
+        self.P = P
+        self.lock = threading.Lock()
+        self.pieces = ([], [])       # per stream: (offset, nbytes, [(crc, isize), ...])
+        self.count = ([0], [0])
+        self.done = {}
+
+    def sink_for(self, rank):
+        P = self.P
+
+        def put(which, rec, text, n, off):
+            buf = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(n,))
+            got = []
+            walk_members(buf, got, 997, self.count[which])
+            with self.lock:
+                self.pieces[which].append((off, n, got))
+            return 1
+
+        def fin(user, rec, st, rb, mb):
+            s = P.Stats()
+            C.memmove(C.byref(s), st, C.sizeof(P.Stats))
+            with self.lock:
+                self.done[rank] = (s, rb, mb)
+            return 1
+
+        cbs = (P.REC_TEXT_CB(lambda u, r, t, n, o: put(0, r, t, n, o)), P.REC_TEXT_CB(lambda u, r, t, n, o: put(1, r, t, n, o)),
+               P.REC_DONE_CB(fin))
+        sink = P.RecordSink(None, *cbs)
+        sink._keep = cbs
+        return sink
+
+    def digest(self):
+        out = []
+        for which in (0, 1):
+            fold = CrcFold()
+            at = 0
+            for off, n, got in sorted(self.pieces[which], key=lambda x: x[0]):
+                assert off == at, "the pieces of a stream do not tile it"
+                for crc, isize in got:
+                    fold.add(crc, isize)
+                at += n
+            total = self.done[0][1 + which]
+            assert at == total
+            out.append((fold.crc, fold.n, at))
+        return out
+
+
+def thread_comms(P, world):
+    """pbsim_comm for `world` contexts in this process, one Python thread each: a barrier over shared lists"""
+    bar = threading.Barrier(world)
+    slots = [None] * world
+
+    def make(rank):
+        def all_gather(arr):
+            slots[rank] = np.array(arr, dtype=np.int64)
+            bar.wait()
+            out = np.stack(slots)
+            bar.wait()
+            return out
+
+        def all_reduce(arr, op):
+            slots[rank] = np.array(arr, dtype=np.int64)
+            bar.wait()
+            stack = np.stack(slots)
+            out = stack.sum(0) if op == P.OP_SUM else stack.min(0) if op == P.OP_MIN else stack.max(0)
+            bar.wait()
+            return out
+
+        return P.make_comm(rank, world, all_gather, all_reduce, None, abort=bar.abort)
+    return [make(r) for r in range(world)]
+
+
+def stats_key(s):
+    return (s.res_num, s.res_len_total, s.res_len_min, s.res_len_max, s.res_sub_num, s.res_ins_num, s.res_del_num,
+            struct.pack("<dd", s.res_accuracy_mean, s.res_accuracy_sd), struct.pack("<dd", s.res_len_mean, s.res_len_sd))
+
+
+@pytest.fixture(scope="module")
+def record():
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    t = torch.cat([lut[torch.randint(0, 4, (min(64_000_000, G - o),), dtype=torch.uint8, device="cuda", generator=g).long()]
+                   for o in range(0, G, 64_000_000)])
+    torch.cuda.synchronize()
+    yield t
+    del t
+
+
+def run_job(P, record, world=1, scratch_gib=None, env=None):
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        msink = MemberSink(P)
+        ctxs = []
+        for r in range(world):
+            p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=20.0)
+            ctx = P.Context(p, 0)
+            ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+            if scratch_gib:
+                ctx.set_scratch_bytes(int(scratch_gib * (1 << 30)))
+            ctx.set_deflate(7)
+            ctx.job_add_record_device(record.data_ptr(), record.numel())
+            ctxs.append(ctx)
+        comms = thread_comms(P, world) if world > 1 else [None]
+        errs = [None] * world
+
+        def one(r):
+            sink = msink.sink_for(r)
+            ok = ctxs[r].lib.pbsim_job_run(ctxs[r].h, C.byref(comms[r]) if comms[r] is not None else None, C.byref(sink))
+            if not ok:
+                errs[r] = ctxs[r].lib.pbsim_last_error().decode(errors="replace")
+
+        th = [threading.Thread(target=one, args=(r,)) for r in range(1, world)]
+        for t in th:
+            t.start()
+        one(0)
+        for t in th:
+            t.join()
+        assert errs == [None] * world, errs
+        counters = [c.job_counters() for c in ctxs]
+        for c in ctxs:
+            c.close()
+        assert all(stats_key(msink.done[r][0]) == stats_key(msink.done[0][0]) for r in range(world))   # merged: same everywhere
+        return msink.digest(), stats_key(msink.done[0][0]), counters, msink.count
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_benchmarked_path_content_is_invariant(record):
+    import pbsim3_amd as P
+    base_digest, base_stats, counters, count = run_job(P, record)
+    (fq_crc, fq_n, fq_gz), (maf_crc, maf_n, maf_gz) = base_digest
+    n_reads, bases = base_stats[0], base_stats[1]
+    assert 15_000_000_000 <= bases < 15_000_000_000 + 1_000_000 and 1_500_000 < n_reads < 1_900_000
+    assert counters[0]["rounds"] >= 3 and count[0][0] > 900_000 and count[1][0] > 900_000
+    # FASTQ: "@S1_<n>\n" + bases + "\n+S1_<n>\n" + '!' x bases + "\n": 2 x bases + per-read framing
+    assert 2 * bases < fq_n < 2 * bases + 40 * n_reads and maf_n > 2 * bases
+    assert fq_gz < 0.2 * fq_n and maf_gz < 0.35 * maf_n
+    variants = {
+        "lane walker only (PBSIM_COOP_LEN=-1)": dict(env={"PBSIM_COOP_LEN": "-1"}),
+        "6 GiB scratch pool (other batches)": dict(scratch_gib=6),
+        "three ranks": dict(world=3),
+        "three ranks, 3 GiB scratch pools": dict(world=3, scratch_gib=3),
+    }
+    for name, kw in variants.items():
+        digest, stats, cnt, _ = run_job(P, record, **kw)
+        assert stats == base_stats, name
+        assert [d[:2] for d in digest] == [(fq_crc, fq_n), (maf_crc, maf_n)], name
+        if kw.get("world", 1) > 1:
+            assert all(c["reads_delivered"] > 0 for c in cnt), name            # every rank delivered blocks
+            assert sum(c["reads_delivered"] for c in cnt) == n_reads
+    # the per-record driver reaches the same statistics (its own batching, no job pipeline)
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=20.0)
+    with P.Context(p, 0) as ctx:
+        ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+        ctx.set_reference_device(record.data_ptr(), record.numel(), 1)
+        ctx.simulate_wgs(collect=False)
+        assert stats_key(ctx.stats()) == base_stats
+
+
+def test_compressed_job_path_matches_oracle_300_mbases(tmp_path):
+    """15 Mbp x depth 20 through pbsim_job_run + pbsim_set_deflate(7) with the default lane / wave split (one batch of
+    ~33 k reads: reads of half a mean length and more go to the wave walker): inflated, the two streams equal the
+    oracle's files byte for byte; so do the statistics."""
+    import pbsim3_amd as P
+    rng = np.random.default_rng(99)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 15_000_000)]
+    fa = tmp_path / "g.fa"
+    with open(fa, "wb") as f:
+        f.write(b">chr1\n")
+        lines = seq.reshape(-1, 100)
+        f.write(np.concatenate([lines, np.full((lines.shape[0], 1), 10, np.uint8)], axis=1).tobytes())
+    args = ["--strategy", "wgs", "--method", "errhmm", "--errhmm", harness.model_path("ERRHMM-ONT.model"),
+            "--genome", str(fa), "--depth", "20", "--seed", "21"]
+    od = tmp_path / "o"
+    od.mkdir()
+    want = harness.run_oracle(args, "philox", str(od))
+    assert len(want["_0001.fq"]) > 600_000_000
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=21, depth=20.0)
+    with P.Context(p, 0) as ctx:
+        ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+        ctx.set_deflate(7)
+        ctx.job_add_record(seq.tobytes())
+        texts, done = ctx.job_run()
+        st = done[1][0]
+        rep = ctx.format_stats(st, 1)
+    for which, key in ((0, "_0001.fq"), (1, "_0001.maf")):
+        raw = bytes(texts[1][which])
+        d = zlib.decompressobj(31)
+        out = []
+        while raw:                                  # multi-member gzip
+            out.append(d.decompress(raw))
+            raw = d.unused_data
+            if d.eof and raw:
+                d = zlib.decompressobj(31)
+        got = b"".join(out)
+        assert len(got) == len(want[key]) and got == want[key], key
+    assert rep in want[".stderr"].decode()

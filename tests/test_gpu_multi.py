@@ -156,3 +156,77 @@ def test_genome_in_several_jobs(tmp_path):
         d.mkdir()
         outs = run_devices(CASES[case]["args"], str(d), 2, scratch_mb=4, env={"PBSIM_JOB_REF_GB": "0.00001"})
         check_against_golden(outs, case)
+
+
+@pytest.mark.parametrize("case,targets", [("wgs_errhmm-ont_quirk", "400000,90000,250000"),
+                                          ("wgs_qshmm_rsii_pass3", "60000,300000,150000,100000")])
+def test_ranks_that_size_their_rounds_differently_still_agree(case, targets, tmp_path):
+    """with the automatic scratch pool a rank sizes its rounds from its OWN free memory; ranks whose GPUs
+    report different free bytes then derived different reads-per-round, and their blocks overlapped or left gaps.  The caps
+    now go through one MIN over the ranks.  PBSIM_JOB_TARGET_RANKS injects a different batch target per rank (what
+    differing hipMemGetInfo values do once the free memory bounds the batch): the output still equals the reference's, and
+    every rank begins every round with the same block size."""
+    ranks = targets.count(",") + 1
+    env = {"PBSIM_JOB_TARGET_RANKS": targets, "PBSIM_TRACE": "1"}
+    import pbsim3_amd.build as b
+    b.build()
+    e = dict(os.environ, **env)
+    p = subprocess.run([CLI] + harness.resolve(CASES[case]["args"]) + ["--prefix", str(tmp_path / "out"), "--devices",
+                                                                       ",".join(["0"] * ranks), "--no-gzip"],
+                       capture_output=True, text=True, cwd=str(tmp_path), env=e)
+    assert p.returncode == 0, p.stderr[-4000:]
+    begun = {}
+    for line in p.stderr.splitlines():
+        if line.startswith("[pbsim job r") and " begin rec " in line:
+            r = int(line[len("[pbsim job r"):line.index("]")])
+            begun.setdefault(r, []).append(line.split("] begin ", 1)[1])
+    assert sorted(begun) == list(range(ranks)) and len(begun[0]) >= 3
+    assert all(begun[r] == begun[0] for r in begun), begun
+    report = "\n".join(l for l in p.stderr.splitlines() if not l.startswith("[pbsim"))
+    outs = harness.collect(str(tmp_path))
+    outs[".stderr"] = harness.strip_report(report).encode()
+    check_against_golden(outs, case)
+
+
+def test_job_rerun_and_second_genome_on_one_context():
+    """a context's homopolymer census and its Q15 state (an hp == 11 base has been counted) belong to
+    ONE run of ONE genome.  Re-running a job gives the same bytes as its first run; a second genome on the same context takes
+    its own census (--hp-del-bias != 1) and starts from a clean Q15 state -- each equals a fresh context's output."""
+    import numpy as np
+    import pbsim3_amd as P
+    rng = np.random.default_rng(8)
+
+    def rand(n):
+        return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+
+    a = rand(400_000)
+    a[1000:1015] = ord("A")                      # a run of 15: hp == 11 bases (Q1 / Q15)
+    a[5000:5009] = ord("C")
+    b_ = rand(300_000)                           # no long runs, other homopolymer census
+    for i in range(0, 300_000 - 8, 997):
+        b_[i:i + 6] = ord("G")
+    ga, gb = a.tobytes(), b_.tobytes()
+
+    def fresh(genome, method, bias):
+        p = P.default_params(strategy=P.STRATEGY_WGS, method=method, seed=4, depth=3.0, hp_del_bias=bias)
+        with P.Context(p, 0) as ctx:
+            (ctx.load_errhmm if method == P.METHOD_ERR else ctx.load_qshmm)(
+                harness.model_path("ERRHMM-ONT.model" if method == P.METHOD_ERR else "QSHMM-RSII.model"))
+            ctx.job_add_record(genome)
+            texts, done = ctx.job_run()
+            return bytes(texts[1][0]), bytes(texts[1][1])
+
+    for method, bias in ((P.METHOD_QS, 1.0), (P.METHOD_QS, 3.0), (P.METHOD_ERR, 4.0)):
+        want_a, want_b = fresh(ga, method, bias), fresh(gb, method, bias)
+        p = P.default_params(strategy=P.STRATEGY_WGS, method=method, seed=4, depth=3.0, hp_del_bias=bias)
+        with P.Context(p, 0) as ctx:
+            (ctx.load_errhmm if method == P.METHOD_ERR else ctx.load_qshmm)(
+                harness.model_path("ERRHMM-ONT.model" if method == P.METHOD_ERR else "QSHMM-RSII.model"))
+            ctx.job_add_record(ga)
+            for _ in range(2):                   # the same job twice
+                texts, _ = ctx.job_run()
+                assert (bytes(texts[1][0]), bytes(texts[1][1])) == want_a, (method, bias)
+            ctx.job_begin(1)                     # a second genome on the same context
+            ctx.job_add_record(gb)
+            texts, _ = ctx.job_run()
+            assert (bytes(texts[1][0]), bytes(texts[1][1])) == want_b, (method, bias)

@@ -45,3 +45,21 @@ def test_table_builders_under_asan(tmp_path):
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert p.stdout.count(" ok stride ") == len(MODELS)
     assert "emission_magic bad 0" in p.stdout
+
+
+def test_comm_abort_releases_waiting_ranks(tmp_path):
+    """pbsim_comm.abort of the in-process communicator (csrc/thread_comm.h): a rank that leaves the job between two
+    exchanges releases the ranks waiting in the next collective -- they fail instead of hanging (job.cpp)."""
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "comm_abort")
+    cmd = ["g++"] + FLAGS + ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(HERE, "comm_abort_driver.cpp"),
+                             "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0 and "sanitize" in p.stderr:
+        pytest.skip("no sanitizer runtime")
+    assert p.returncode == 0, p.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=60, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+    assert "first 8 second_failed 3 third_failed 3" in p.stdout
