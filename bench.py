@@ -333,6 +333,9 @@ def launch_ranks(a):
     if a.one_gpu:
         env["PBSIM_BENCH_BACKEND"] = "gloo"
         env["PBSIM_BENCH_ONE_GPU"] = "1"
+        # every rank sizes its rounds from the free HBM of "its" GPU: N contexts on one GPU each get a 1/N share of it (their
+        # rounds are then smaller than on N GPUs, where every rank has 288 GB to itself)
+        env.setdefault("PBSIM_JOB_FIT", "%.4f" % (0.6 / a.gpus))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stderr.write("bench.py: launching %d ranks: %s\n" % (a.gpus, " ".join(cmd)))

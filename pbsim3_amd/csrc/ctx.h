@@ -103,9 +103,10 @@ constexpr double kSinkBatchBases = 5.0e9;  // pbsim_simulate_wgs: expected bases
 // sinks side by side (pbsim_set_deflate bit 2).
 constexpr int kDfBuffers = 3;
 struct DfLane {
-  DevBuf d_df_slots[2], d_df_sizes[2], d_df_offsets[2];  // a piece's per-chunk staging: two sets, piece k + 1 is compressed while
-                                                         // piece k's total travels to the host
-  DevBuf d_df_dense[kDfBuffers];                         // compressed pieces: one being written, two waiting for / on the link
+  DevBuf d_df_status, d_df_ctl;        // look-back words of the launch in progress (told apart by `epoch`), ticket + total
+  uint32_t epoch = 0;                  // one per launch on this lane
+  DevBuf d_df_dense[kDfBuffers];       // compressed pieces: one being written, two waiting for / on the link (not in direct mode:
+                                       // the members then go straight into h_df_out, page-locked host memory)
   DevBuf d_df_code;                    // the current call's code table (DF_TABLE_BYTES) + its histogram scratch
   HostBuf h_df_total, h_df_out[kDfBuffers];
   // kernels of this lane | D2H of compressed pieces: the streams of pbsim_ctx::df_streams (shared by the slots' lanes of the

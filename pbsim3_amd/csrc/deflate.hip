@@ -429,8 +429,91 @@ __global__ __launch_bounds__(kThreads) void k_deflate_build(const uint32_t *__re
   for (int i = tid; i < kHdrDw; i += kThreads) tbl->hdr[i] = s_img[4 + i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Where a member goes: straight to its final place.  The members of a launch are packed densely, so member c starts at the
+// sum of the sizes in front of it -- and a workgroup knows its member's size long before it has the bits (the sizes come out
+// of the token scan, the emission follows).  Decoupled look-back: the workgroup publishes its size as soon as it has it
+// (status word = epoch | flag | value; flag 1 = this member's size, 2 = inclusive prefix), emits its bits, and only then
+// looks back over its predecessors' words -- 64 at a time, one per lane of the first wave -- until it meets an inclusive
+// prefix; by then the workgroups in front of it have usually published theirs, and the wait is one read.  Chunk numbers are
+// tickets drawn from a counter (not blockIdx), so a workgroup only ever waits for workgroups that started before it.  The
+// status words carry the launch's epoch: no array is cleared between launches.
+//   dense may be device memory (a piece that a copy carries to the host) or page-locked HOST memory mapped into the GPU's
+// address space: the member then crosses the link as the workgroup's own stores, no copy exists at all.  Either way a
+// member leaves LDS once, as 16-byte stores at the destination's alignment (the image is read at the byte offset that
+// makes them so), byte stores on its ragged ends.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DfCtl {               // device memory, zeroed by launch_deflate in front of every launch
+  uint32_t ticket;
+  uint32_t pad;
+  int64_t total;             // bytes of the launch's members (written by the workgroup of the last chunk)
+};
+static_assert(sizeof(DfCtl) == DF_CTL_BYTES, "DF_CTL_BYTES");
+
+constexpr uint64_t kStSize = 1ull << 32, kStPrefix = 2ull << 32;
+__device__ __forceinline__ uint64_t st_word(uint32_t epoch, uint64_t flag, uint32_t v) { return ((uint64_t)epoch << 34) | flag | v; }
+
+// exclusive prefix of chunk c (> 0) from the status words in front of it; called by the 64 lanes of one wave
+__device__ __forceinline__ uint32_t look_back(const uint64_t *status, int64_t c, uint32_t epoch, int lane) {
+  uint32_t sum = 0;
+  int64_t hi = c - 1;  // the window is chunks hi, hi - 1, ..., hi - 63
+  for (;;) {
+    const int64_t i = hi - lane;
+    uint64_t w = 0;
+    if (i >= 0) w = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool mine = i >= 0 && (uint32_t)(w >> 34) == epoch && ((w >> 32) & 3u) != 0;
+    const uint64_t ready = __ballot(mine || i < 0);
+    const uint64_t pref = __ballot(mine && ((w >> 32) & 3u) == 2u);
+    // lanes 0 .. k - 1 ready, where k = first lane that is not; the nearest inclusive prefix inside them ends the walk
+    const int k = ~ready ? __builtin_ctzll(~ready) : 64;
+    const uint64_t usable = k >= 64 ? ~0ull : ((1ull << k) - 1);
+    const uint64_t stop = pref & usable;
+    if (stop) {
+      const int e = __builtin_ctzll(stop);  // lanes 0..e: sizes of hi .. hi - e + 1 and the inclusive prefix of hi - e
+      uint32_t v = (lane <= e && i >= 0) ? (uint32_t)w : 0u;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      return sum + v;
+    }
+    if (k == 0) {  // the chunk right in front has not published yet
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    uint32_t v = (lane < k && i >= 0) ? (uint32_t)w : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    sum += v;
+    hi -= k;
+    if (hi < 0) return sum;  // walked past chunk 0: everything in front was sizes
+  }
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// s_img[0 .. bytes) -> dst (any alignment): 16-byte stores where dst is 16-byte aligned, bytes on the ragged ends
+__device__ __forceinline__ void store_member(uint8_t *dst, const uint32_t *s_img, uint32_t bytes, int tid) {
+  const uint32_t head = min((uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u), bytes);
+  const uint8_t *s8 = reinterpret_cast<const uint8_t *>(s_img);
+  if ((uint32_t)tid < head) dst[tid] = s8[tid];
+  const uint32_t nvec = (bytes - head) >> 4;
+  const uint32_t sh = head & 3u, dw0 = head >> 2;
+  u32x4 *d4 = reinterpret_cast<u32x4 *>(dst + head);
+  for (uint32_t v = tid; v < nvec; v += kThreads) {
+    const uint32_t *p = s_img + dw0 + 4u * v;  // image bytes head + 16 v ..: dwords p[0..4] shifted by sh bytes
+    const uint32_t a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];   // (the image is padded past the member)
+    u32x4 o;
+    o.x = __builtin_amdgcn_alignbyte(b, a, sh);
+    o.y = __builtin_amdgcn_alignbyte(c, b, sh);
+    o.z = __builtin_amdgcn_alignbyte(d, c, sh);
+    o.w = __builtin_amdgcn_alignbyte(e, d, sh);
+    __builtin_nontemporal_store(o, &d4[v]);
+  }
+  const uint32_t done = head + 16u * nvec;
+  if ((uint32_t)tid < bytes - done) dst[done + tid] = s8[done + tid];
+}
+
 __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__restrict__ text, int64_t n_bytes,
-                                                              uint8_t *__restrict__ slots, int32_t *__restrict__ sizes,
+                                                              uint8_t *__restrict__ dense, uint64_t *__restrict__ status,
+                                                              DfCtl *__restrict__ ctl, uint32_t epoch,
                                                               const uint32_t *__restrict__ crc_table,
                                                               const uint32_t *__restrict__ pow128, uint32_t x8rem,
                                                               const DfTable *__restrict__ tbl,
@@ -443,7 +526,7 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
   __shared__ uint32_t s_code[kSyms];     // reversed code | length << 16 (the stream's table; [287] = 0)
   uint32_t *const s_crc = s_in;          // [1024] slice-by-4 tables, between the register load and the emission
   __shared__ uint32_t s_wave[kThreads / 64];
-  __shared__ uint32_t s_misc[4];         // 3 crc
+  __shared__ uint32_t s_misc[4];         // 0 ticket, 1 exclusive prefix, 3 crc
 
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long t_prev = prof ? wall_clock64() : 0;
@@ -456,10 +539,11 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
     }
     ++phase;
   };
-  const int64_t chunk = blockIdx.x;
-  uint8_t *slot = slots + chunk * (int64_t)DF_SLOT;
   for (int i = tid; i < kSyms; i += kThreads) s_code[i] = i < 286 ? tbl->code[i] : 0u;
-  if (tid < 4) s_misc[tid] = 0;
+  if (tid < 4) s_misc[tid] = tid == 0 ? atomicAdd(&ctl->ticket, 1u) : 0u;
+  __syncthreads();
+  const int64_t chunk = s_misc[0];
+  const int64_t n_chunks = (n_bytes + kChunk - 1) / kChunk;
   uint32_t seg[kSegDw], prev_dw;  // the thread's segment, in registers from here on (every loop over it is fully unrolled)
   int n, seg_n;
   load_chunk(text, n_bytes, chunk, s_in, seg, &n, &seg_n, &prev_dw);
@@ -522,10 +606,13 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
   const uint32_t payload_bytes = (payload_bits + 7) >> 3;
   const bool huff = (18 + payload_bytes + 8 <= (uint32_t)kOutBytes) && (payload_bytes < (uint32_t)n + 5);
   const uint32_t crc = s_misc[3] ^ 0xFFFFFFFFu;
+  const uint32_t member = huff ? 18 + payload_bytes + 8 : 18 + 5 + (uint32_t)n + 8;
+  // the size is known: publish it (chunk 0's size is its inclusive prefix), the bits follow
+  if (tid == 0)
+    __hip_atomic_store(&status[chunk], st_word(epoch, chunk == 0 ? kStPrefix : kStSize, member), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   mark();  // 2 sizes + scan
 
   if (huff) {
-    const uint32_t member = 18 + payload_bytes + 8;
     __syncthreads();  // everybody is done with the CRC tables
     for (int i = tid; i < 1024; i += kThreads) s_in[i] = 0;
     __syncthreads();
@@ -592,15 +679,32 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       bw.put((uint32_t)n, 32);
       bw.flush();
     }
+    // where the member goes: the first wave looks back while the others finish their bits
+    if (tid < 64 && chunk > 0) {
+      const uint32_t excl = look_back(status, chunk, epoch, tid);
+      if (tid == 0) {
+        s_misc[1] = excl;
+        __hip_atomic_store(&status[chunk], st_word(epoch, kStPrefix, excl + member), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     __syncthreads();
-    mark();  // 5 trailer + barrier
-    uint32_t *dst = reinterpret_cast<uint32_t *>(slot);
-    for (uint32_t i = tid; i < (member + 3) / 4; i += kThreads) dst[i] = s_out[i];
-    if (tid == 0) sizes[chunk] = (int32_t)member;
+    mark();  // 5 trailer + look-back + barrier
+    const uint32_t off = s_misc[1];
+    store_member(dense + off, s_out, member, tid);
+    if (tid == 0 && chunk == n_chunks - 1) ctl->total = (int64_t)off + member;
     mark();  // 6 store
   } else {
     // stored block (RFC 1951 3.2.4): incompressible input, rare for this text
-    const uint32_t member = 18 + 5 + (uint32_t)n + 8;
+    if (tid < 64 && chunk > 0) {
+      const uint32_t excl = look_back(status, chunk, epoch, tid);
+      if (tid == 0) {
+        s_misc[1] = excl;
+        __hip_atomic_store(&status[chunk], st_word(epoch, kStPrefix, excl + member), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    uint8_t *slot = dense + s_misc[1];
+    if (tid == 0 && chunk == n_chunks - 1) ctl->total = (int64_t)s_misc[1] + member;
     if (tid == 0) {
       const uint8_t head[23] = {0x1f, 0x8b, 8,   4,   0,   0,
                                 0,    0,    0,   0xff, 6,  0,
@@ -610,7 +714,6 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       uint8_t *t = slot + 23 + n;
       for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i));
       for (int i = 0; i < 4; ++i) t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
-      sizes[chunk] = (int32_t)member;
     }
 #pragma unroll
     for (int j = 0; j < kSegDw; ++j)
@@ -618,65 +721,6 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
       for (int k = 0; k < 4; ++k)
         if (4 * j + k < seg_n) slot[23 + beg + 4 * j + k] = (uint8_t)(seg[j] >> (8 * k));
   }
-}
-
-// offsets[c] = sum of sizes[< c], offsets[n] = total; n <= 8192 (one block of 256 -- a workgroup of the walk kernel's
-// footprint gets a CU at once, a 1024-thread block waits behind concurrent walks -- 32 per thread)
-__global__ __launch_bounds__(256) void k_deflate_offsets(const int32_t *__restrict__ sizes, int n,
-                                                         int64_t *__restrict__ offsets) {
-  __shared__ uint32_t s_w[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int kPer = DF_PIECE_CHUNKS / 256;
-  uint32_t sum = 0;
-  for (int k = 0; k < kPer; ++k) {
-    const int i = tid * kPer + k;
-    sum += i < n ? (uint32_t)sizes[i] : 0u;
-  }
-  uint32_t inc = sum;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  if (lane == 63) s_w[wave] = inc;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-  for (int w = 0; w < 4; ++w) {
-    if (w < wave) base += s_w[w];
-    tot += s_w[w];
-  }
-  uint32_t run = base + inc - sum;
-  for (int k = 0; k < kPer; ++k) {
-    const int i = tid * kPer + k;
-    if (i < n) {
-      offsets[i] = run;
-      run += (uint32_t)sizes[i];
-    }
-  }
-  if (tid == 0) offsets[n] = tot;
-}
-
-// dense[offsets[c] ..) = slot c's member; destinations are byte-aligned, so interior dwords are
-// rebuilt from two aligned source dwords
-__global__ __launch_bounds__(256) void k_deflate_compact(const uint8_t *__restrict__ slots,
-                                                         const int64_t *__restrict__ offsets,
-                                                         uint8_t *__restrict__ dense) {
-  const int64_t c = blockIdx.x;
-  const int64_t off = offsets[c];
-  const int size = (int)(offsets[c + 1] - off);
-  const uint8_t *src = slots + c * (int64_t)DF_SLOT;
-  uint8_t *dst = dense + off;
-  const int head = (int)((4 - (off & 3)) & 3) < size ? (int)((4 - (off & 3)) & 3) : size;
-  if ((int)threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
-  const int ndw = (size - head) >> 2;
-  const uint32_t *src32 = reinterpret_cast<const uint32_t *>(src);
-  uint32_t *dst32 = reinterpret_cast<uint32_t *>(dst + head);
-  for (int i = threadIdx.x; i < ndw; i += 256) {
-    const uint32_t lo = src32[i], hi = src32[i + 1];   // head in 0..3; the slot is padded past the member
-    dst32[i] = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)head);
-  }
-  const int done = head + 4 * ndw;
-  if ((int)threadIdx.x < size - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
 }
 
 uint32_t host_gf2_mul(uint32_t a, uint32_t b) {
@@ -729,19 +773,18 @@ void launch_deflate_table(const uint8_t *text, int64_t n_bytes, uint32_t *hist, 
   hipLaunchKernelGGL(k_deflate_build, dim3(1), dim3(kThreads), 0, s, (const uint32_t *)hist, reinterpret_cast<DfTable *>(table));
 }
 
-void launch_deflate(const uint8_t *text, int64_t n_bytes, uint8_t *slots, int32_t *sizes, int64_t *offsets,
-                    uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, const void *table, hipStream_t s,
+void launch_deflate(const uint8_t *text, int64_t n_bytes, uint64_t *status, void *ctl, uint32_t epoch, uint8_t *dense,
+                    const uint32_t *d_crc_table, const uint32_t *d_pow128, const void *table, hipStream_t s,
                     unsigned long long *d_prof, hipEvent_t ev_begin, hipEvent_t ev_chunks_done) {
   if (n_bytes <= 0) return;
   const int64_t nch = (n_bytes + DF_CHUNK - 1) / DF_CHUNK;
   const uint32_t x8rem = host_xpow8((uint64_t)(n_bytes % DF_CHUNK) & 127u);
+  (void)hipMemsetAsync(ctl, 0, DF_CTL_BYTES, s);  // the ticket counter; the status words are told apart by the epoch
   if (ev_begin) (void)hipEventRecord(ev_begin, s);
-  hipLaunchKernelGGL(k_deflate_chunks, dim3((unsigned)nch), dim3(kThreads), 0, s, text, n_bytes, slots, sizes,
-                     d_crc_table, d_pow128, x8rem, reinterpret_cast<const DfTable *>(table), d_prof);
+  hipLaunchKernelGGL(k_deflate_chunks, dim3((unsigned)nch), dim3(kThreads), 0, s, text, n_bytes, dense, status,
+                     reinterpret_cast<DfCtl *>(ctl), epoch & 0x3fffffffu, d_crc_table, d_pow128, x8rem,
+                     reinterpret_cast<const DfTable *>(table), d_prof);
   if (ev_chunks_done) (void)hipEventRecord(ev_chunks_done, s);
-  hipLaunchKernelGGL(k_deflate_offsets, dim3(1), dim3(256), 0, s, (const int32_t *)sizes, (int)nch, offsets);
-  hipLaunchKernelGGL(k_deflate_compact, dim3((unsigned)nch), dim3(256), 0, s, (const uint8_t *)slots,
-                     (const int64_t *)offsets, dense);
 }
 
 }  // namespace pbsim

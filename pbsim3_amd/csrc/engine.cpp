@@ -1069,11 +1069,15 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   const int64_t piece = (int64_t)DF_PIECE_CHUNKS * DF_CHUNK;
   const int64_t max_ch = std::min<int64_t>(DF_PIECE_CHUNKS, (n + DF_CHUNK - 1) / DF_CHUNK);
   const int64_t n_pieces = (n + piece - 1) / piece;
-  for (int i = 0; i < (n_pieces > 1 ? 2 : 1); i++) {
-    HIP_OK(sl.d_df_slots[i].ensure((size_t)max_ch * DF_SLOT));
-    HIP_OK(sl.d_df_sizes[i].ensure((size_t)max_ch * 4));
-    HIP_OK(sl.d_df_offsets[i].ensure((size_t)(max_ch + 1) * 8));
-  }
+  HIP_OK(sl.d_df_status.ensure((size_t)DF_PIECE_CHUNKS * 8));
+  HIP_OK(sl.d_df_ctl.ensure(DF_CTL_BYTES));
+  // Direct mode: the members leave the GPU as the deflate workgroups' own stores into page-locked host memory (no dense
+  // buffer in HBM, no copy); needs the lane's own staging as the destination, so not when the caller places the pieces.
+  static const bool direct_default = [] {
+    const char *e = getenv("PBSIM_DEFLATE_DIRECT");
+    return e ? atoi(e) != 0 : false;
+  }();
+  const bool direct = direct_default && !place;
   HIP_OK(sl.h_df_total.ensure(8 * kDfBuffers));
   HIP_OK(sl.d_df_code.ensure(DF_TABLE_BYTES + 288 * 4));
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
@@ -1114,16 +1118,17 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
   // piece j: kernels on staging set j & 1 into dense buffer j % 3; its total lands in h_total[j % 3]
   auto launch = [&](int64_t j) -> int {
-    const int b = (int)(j % kDfBuffers), a = (int)(j & 1);
+    const int b = (int)(j % kDfBuffers);
     const int64_t off = j * piece, len = std::min(piece, n - off);
-    const int64_t nch = (len + DF_CHUNK - 1) / DF_CHUNK;
-    HIP_OK(sl.d_df_dense[b].ensure((size_t)max_ch * DF_SLOT, true));
-    if (!place) HIP_OK(sl.h_df_out[b].ensure((size_t)max_ch * DF_SLOT));
-    if (used[b]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - 3 has left this dense buffer
-    launch_deflate(d_text + off, len, sl.d_df_slots[a].as<uint8_t>(), sl.d_df_sizes[a].as<int32_t>(), sl.d_df_offsets[a].as<int64_t>(),
-                   sl.d_df_dense[b].as<uint8_t>(), tab, tab + 1024, sl.d_df_code.p, sl.stream, d_prof, sl.ev_k0[b], sl.ev_k1[b]);
+    if (!direct) HIP_OK(sl.d_df_dense[b].ensure((size_t)max_ch * DF_SLOT + 64, true));
+    if (!place) HIP_OK(sl.h_df_out[b].ensure((size_t)max_ch * DF_SLOT + 64));
+    if (used[b] && !direct) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - 3 has left this dense buffer
+    // (direct: piece j - 3 was consumed on this thread before piece j is launched -- the host buffer is free)
+    uint8_t *dense = direct ? (uint8_t *)sl.h_df_out[b].p : sl.d_df_dense[b].as<uint8_t>();
+    launch_deflate(d_text + off, len, sl.d_df_status.as<uint64_t>(), sl.d_df_ctl.p, ++sl.epoch, dense, tab, tab + 1024,
+                   sl.d_df_code.p, sl.stream, d_prof, sl.ev_k0[b], sl.ev_k1[b]);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(&h_total[b], sl.d_df_offsets[a].as<int64_t>() + nch, 8, hipMemcpyDeviceToHost, sl.stream));
+    HIP_OK(hipMemcpyAsync(&h_total[b], sl.d_df_ctl.as<uint8_t>() + 8, 8, hipMemcpyDeviceToHost, sl.stream));
     HIP_OK(hipEventRecord(sl.ev_df[b], sl.stream));
     return PBSIM_SUCCEEDED;
   };
@@ -1149,23 +1154,25 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
         c->prof_deflate_out += total;
       }
     }
-    HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[b], 0));
     char *dst = place ? (*place)(total) : (char *)sl.h_df_out[b].p;
     if (!dst) return fail("deflate: no room for a compressed piece");
-    if (trace) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      HIP_OK(hipEventCreate(&e0));
-      HIP_OK(hipEventCreate(&e1));
-      tev.emplace_back(e0, e1);
-      HIP_OK(hipEventRecord(e0, sl.copy_stream));
+    if (!direct) {
+      HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[b], 0));
+      if (trace) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIP_OK(hipEventCreate(&e0));
+        HIP_OK(hipEventCreate(&e1));
+        tev.emplace_back(e0, e1);
+        HIP_OK(hipEventRecord(e0, sl.copy_stream));
+      }
+      HIP_OK(hipMemcpyAsync(dst, sl.d_df_dense[b].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
+      if (trace) HIP_OK(hipEventRecord(tev.back().second, sl.copy_stream));
+      HIP_OK(hipEventRecord(sl.ev_cp[b], sl.copy_stream));
     }
-    HIP_OK(hipMemcpyAsync(dst, sl.d_df_dense[b].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
-    if (trace) HIP_OK(hipEventRecord(tev.back().second, sl.copy_stream));
-    HIP_OK(hipEventRecord(sl.ev_cp[b], sl.copy_stream));
     used[b] = true;
     if (prev_bytes) {  // (before piece k + 2 is launched: it re-uses piece k - 1's buffers)
       const double t1 = now();
-      HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
+      if (!direct) HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
       const double t2 = now();
       if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
       t_copy += t2 - t1;
@@ -1180,7 +1187,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   }
   if (prev_bytes) {
     const double t1 = now();
-    HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
+    if (!direct) HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
     const double t2 = now();
     if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
     t_copy += t2 - t1;

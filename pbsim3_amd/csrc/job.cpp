@@ -668,9 +668,11 @@ struct Job {
     pbsim_batch_info bi;
     memset(&bi, 0, sizeof bi);
     // a failure here travels in gather B's status word: every rank leaves the job at the same collective
+    const double tf = now_us();
     const int fin_ok = finalize_cut(c, before, &bi) && finalize_text(c, &bi);
     if (!fin_ok) my_err = g_err;
     const double t2 = now_us();
+    bd_finalize += t2 - tf;
     const int64_t sendB[4] = {bi.n_final, bi.need_truncated_read, bi.len_total_after, fin_ok ? 0 : 1};
     if (!gather(sendB, 4, &B)) return PBSIM_FAILED;
     int64_t bad_b = 0;
@@ -702,7 +704,6 @@ struct Job {
       maf_columns += bi.maf_columns;
     }
     const double t3 = now_us();
-    bd_finalize += t2 - t1;
     // ---- the record's state, identical on every rank
     const double n_round = (double)W * (double)rd.n_per;
     R.spec_total += (double)pass0_sum - n_round * rd.mean;

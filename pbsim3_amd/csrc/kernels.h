@@ -211,7 +211,7 @@ void launch_text_emit(const TextArgs &a, int64_t n_slots_max, const DeviceFlags 
 // ---- deflate.hip: text -> BGZF-framed gzip members, one per DF_CHUNK input bytes
 #define DF_CHUNK 32768
 #define DF_SLOT (DF_CHUNK + 64)          // per-chunk staging stride (a stored member is DF_CHUNK + 31 bytes)
-#define DF_PIECE_CHUNKS 8192             // chunks per launch (k_deflate_offsets scans them in one block)
+#define DF_PIECE_CHUNKS 8192             // chunks per launch (a piece: 256 MiB of text)
 #define DF_SAMPLE_CHUNKS 64              // chunks of a call's text the code table is fitted to (2 MiB)
 #define DF_TABLE_HDR_DW 96               // dwords of precomputed block header (prefix + 287 code lengths, run-length coded)
 #define DF_TABLE_BYTES 2048              // device bytes of one code table
@@ -219,10 +219,14 @@ void deflate_host_tables(uint32_t *crc_table /*4 x 256, slice-by-4*/, uint32_t *
 // the code table of a call: token histogram of the first DF_SAMPLE_CHUNKS chunks of text[0..n_bytes) (hist: 288 u32 of
 // scratch), every symbol floored at one occurrence, length-limited Huffman, canonical codes, block header -> table
 void launch_deflate_table(const uint8_t *text, int64_t n_bytes, uint32_t *hist, void *table, hipStream_t s);
-// text (16-byte aligned, 16 bytes of readable slack) -> dense[0 .. offsets[nch]);  nch = ceil(n_bytes / DF_CHUNK) <= DF_PIECE_CHUNKS;
-// slots: nch * DF_SLOT bytes, sizes: nch, offsets: nch + 1, dense: nch * DF_SLOT bytes worst case; table from launch_deflate_table
-void launch_deflate(const uint8_t *text, int64_t n_bytes, uint8_t *slots, int32_t *sizes, int64_t *offsets,
-                    uint8_t *dense, const uint32_t *d_crc_table, const uint32_t *d_pow128, const void *table, hipStream_t s,
+// text (16-byte aligned, 16 bytes of readable slack) -> the members of its nch = ceil(n_bytes / DF_CHUNK) <= DF_PIECE_CHUNKS
+// chunks, packed densely from dense[0] in chunk order (decoupled look-back: a member is written once, at its final place);
+// dense: device memory or page-locked host memory mapped into the device (nch * DF_SLOT bytes worst case, 16 bytes of slack);
+// status: DF_PIECE_CHUNKS u64 look-back words (never cleared: `epoch` must differ from launch to launch on the same array);
+// ctl: DF_CTL_BYTES, ctl[8..16) receives the total as int64; table from launch_deflate_table
+#define DF_CTL_BYTES 16
+void launch_deflate(const uint8_t *text, int64_t n_bytes, uint64_t *status, void *ctl, uint32_t epoch, uint8_t *dense,
+                    const uint32_t *d_crc_table, const uint32_t *d_pow128, const void *table, hipStream_t s,
                     unsigned long long *d_prof = nullptr /* PBSIM_DEFLATE_PROF: per-phase tick sums */,
                     hipEvent_t ev_begin = nullptr, hipEvent_t ev_chunks_done = nullptr /* recorded around k_deflate_chunks */);
 

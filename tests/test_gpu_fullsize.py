@@ -10,7 +10,7 @@ partition, the rank count or the walker that produced it.  That pair, and the re
     one rank | one rank without the wave walker | one rank with a small scratch pool (other batches) | three ranks
 
 and the statistics equal pbsim_simulate_wgs's (the per-record driver).  Every 997th member is inflated with zlib and checked
-against its own trailer, so the CRCs are CRCs of what the members really hold.  A second test compares 300 Mbases delivered
+against its own trailer (tests/member_walk.c, zlib), so the CRCs are CRCs of what the members really hold.  A second test compares 300 Mbases delivered
 through the same path -- compressed sinks, default split -- with the oracle byte for byte."""
 import ctypes as C
 import os
@@ -28,81 +28,53 @@ pytestmark = pytest.mark.gpu
 G = 750_000_000
 
 
-# ---- CRC-32 of a concatenation from the parts' CRCs (GF(2) shift operators; zlib's crc32_combine is not in Python's zlib) ----
-def _apply(mat, vec):
-    s, i = 0, 0
-    while vec:
-        if vec & 1:
-            s ^= mat[i]
-        vec >>= 1
-        i += 1
-    return s
+# ---- the members of a piece -> (members, CRC-32, length) of the text they hold: tests/member_walk.c (host cc + zlib) ----
+_helper = None
 
 
-def _mul(a, b):  # operator a after operator b
-    return [_apply(a, col) for col in b]
+def helper():
+    global _helper
+    if _helper is None:
+        import subprocess
+        import tempfile
+        d = tempfile.mkdtemp(prefix="member_walk_")
+        so = os.path.join(d, "member_walk.so")
+        subprocess.run(["cc", "-O2", "-shared", "-fPIC", os.path.join(harness.ROOT, "tests", "member_walk.c"), "-lz", "-o", so],
+                       check=True)
+        lib = C.CDLL(so)
+        lib.walk_members.restype = C.c_long
+        lib.walk_members.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_ulong), C.POINTER(C.c_long), C.c_long, C.c_long]
+        lib.fold.restype = C.c_ulong
+        lib.fold.argtypes = [C.c_ulong, C.c_ulong, C.c_long]
+        lib.walk_members(None, 0, C.byref(C.c_ulong(0)), C.byref(C.c_long(0)), 0, 0)   # builds its tables (once, before threads)
+        _helper = lib
+    return _helper
 
 
-def shift_operator(nbytes):
-    """32 x 32 GF(2) matrix (columns as ints) that advances a CRC-32 register over nbytes zero bytes"""
-    one_bit = [0xedb88320] + [1 << (n - 1) for n in range(1, 32)]
-    m = one_bit
-    for _ in range(3):
-        m = _mul(m, m)            # 1 -> 2 -> 4 -> 8 zero bits
-    result = [1 << n for n in range(32)]
-    while nbytes:
-        if nbytes & 1:
-            result = _mul(m, result)
-        m = _mul(m, m)
-        nbytes >>= 1
-    return result
+def walk_piece(ptr, n, first_index=0, sample_every=997):
+    crc, ln = C.c_ulong(0), C.c_long(0)
+    k = helper().walk_members(ptr, n, C.byref(crc), C.byref(ln), first_index, sample_every)
+    assert k >= 0, "bad member at byte %d of a piece (framing, or a trailer that does not match its data)" % (-1 - k)
+    return k, crc.value, ln.value
 
 
-class CrcFold:
-    """running (crc, length) of a stream given its pieces' (crc, length) in order"""
-
-    def __init__(self):
-        self.crc, self.n = 0, 0
-        self.ops = {}
-        full = shift_operator(32768)
-        self.tab = [[_apply(full, b << (8 * k)) for b in range(256)] for k in range(4)]
-
-    def add(self, crc, n):
-        if n == 32768:
-            c, t = self.crc, self.tab
-            self.crc = t[0][c & 255] ^ t[1][(c >> 8) & 255] ^ t[2][(c >> 16) & 255] ^ t[3][c >> 24] ^ crc
-        elif n:
-            op = self.ops.get(n)
-            if op is None:
-                op = self.ops[n] = shift_operator(n)
-            self.crc = _apply(op, self.crc) ^ crc
-        self.n += n
-
-
-def test_crc_fold_is_crc_of_the_concatenation():
+def test_member_walk_against_zlib():
     rng = np.random.default_rng(3)
-    parts = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (32768, 32768, 5, 32768, 1, 20000, 32768)]
-    f = CrcFold()
-    for p in parts:
-        f.add(zlib.crc32(p), len(p))
-    assert (f.crc, f.n) == (zlib.crc32(b"".join(parts)), sum(map(len, parts)))
+    parts = [rng.integers(65, 70, n, dtype=np.uint8).tobytes() for n in (32768, 32768, 5, 32768, 1, 20000, 32768)]
 
-
-def walk_members(buf, fold_pieces, sample_every, counter):
-    """buf: numpy uint8 view of whole members; appends (crc, isize) of each to fold_pieces, inflates a sample"""
-    at, n = 0, len(buf)
-    mv = memoryview(buf)
-    while at < n:
-        assert buf[at] == 31 and buf[at + 1] == 139 and buf[at + 12] == 66 and buf[at + 13] == 67, "not a BGZF member"
-        size = (int(buf[at + 16]) | (int(buf[at + 17]) << 8)) + 1
-        crc, isize = struct.unpack_from("<II", mv, at + size - 8)
-        fold_pieces.append((crc, isize))
-        counter[0] += 1
-        if counter[0] % sample_every == 0:
-            data = zlib.decompress(bytes(mv[at + 18:at + size - 8]), -15)
-            assert len(data) == isize and zlib.crc32(data) == crc
-        at += size
-    assert at == n, "a piece does not end on a member boundary"
+    def member(data):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        z = co.compress(data) + co.flush()
+        return (bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", 18 + len(z) + 8 - 1) + z +
+                struct.pack("<II", zlib.crc32(data), len(data)))
+    raw = b"".join(member(p) for p in parts)
+    buf = C.create_string_buffer(raw, len(raw))
+    assert walk_piece(C.cast(buf, C.c_void_p), len(raw), 0, 1) == (len(parts), zlib.crc32(b"".join(parts)), sum(map(len, parts)))
+    bad = bytearray(raw)
+    bad[-8] ^= 1                                     # a trailer that does not describe its data
+    buf = C.create_string_buffer(bytes(bad), len(bad))
+    with pytest.raises(AssertionError):
+        walk_piece(C.cast(buf, C.c_void_p), len(bad), 0, 1)
 
 
 class MemberSink:
@@ -111,19 +83,17 @@ class MemberSink:
     def __init__(self, P):
         self.P = P
         self.lock = threading.Lock()
-        self.pieces = ([], [])       # per stream: (offset, nbytes, [(crc, isize), ...])
-        self.count = ([0], [0])
+        self.pieces = ([], [])       # per stream: (offset, nbytes, members, crc, text length)
         self.done = {}
+        helper()
 
     def sink_for(self, rank):
         P = self.P
 
         def put(which, rec, text, n, off):
-            buf = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(n,))
-            got = []
-            walk_members(buf, got, 997, self.count[which])
+            k, crc, ln = walk_piece(C.cast(text, C.c_void_p), n)     # (ctypes releases the GIL for the walk)
             with self.lock:
-                self.pieces[which].append((off, n, got))
+                self.pieces[which].append((off, n, k, crc, ln))
             return 1
 
         def fin(user, rec, st, rb, mb):
@@ -140,18 +110,18 @@ class MemberSink:
         return sink
 
     def digest(self):
+        """per stream: (CRC-32 of the whole text, its length, compressed bytes, members)"""
         out = []
         for which in (0, 1):
-            fold = CrcFold()
-            at = 0
-            for off, n, got in sorted(self.pieces[which], key=lambda x: x[0]):
+            crc = ln = at = members = 0
+            for off, n, k, pcrc, pln in sorted(self.pieces[which], key=lambda x: x[0]):
                 assert off == at, "the pieces of a stream do not tile it"
-                for crc, isize in got:
-                    fold.add(crc, isize)
+                crc = helper().fold(crc, pcrc, pln)
+                ln += pln
+                members += k
                 at += n
-            total = self.done[0][1 + which]
-            assert at == total
-            out.append((fold.crc, fold.n, at))
+            assert at == self.done[0][1 + which]
+            out.append((crc, ln, at, members))
         return out
 
 
@@ -233,7 +203,7 @@ def run_job(P, record, world=1, scratch_gib=None, env=None):
         for c in ctxs:
             c.close()
         assert all(stats_key(msink.done[r][0]) == stats_key(msink.done[0][0]) for r in range(world))   # merged: same everywhere
-        return msink.digest(), stats_key(msink.done[0][0]), counters, msink.count
+        return msink.digest(), stats_key(msink.done[0][0]), counters
     finally:
         for k, v in old.items():
             if v is None:
@@ -244,11 +214,11 @@ def run_job(P, record, world=1, scratch_gib=None, env=None):
 
 def test_benchmarked_path_content_is_invariant(record):
     import pbsim3_amd as P
-    base_digest, base_stats, counters, count = run_job(P, record)
-    (fq_crc, fq_n, fq_gz), (maf_crc, maf_n, maf_gz) = base_digest
+    base_digest, base_stats, counters = run_job(P, record)
+    (fq_crc, fq_n, fq_gz, fq_members), (maf_crc, maf_n, maf_gz, maf_members) = base_digest
     n_reads, bases = base_stats[0], base_stats[1]
     assert 15_000_000_000 <= bases < 15_000_000_000 + 1_000_000 and 1_500_000 < n_reads < 1_900_000
-    assert counters[0]["rounds"] >= 3 and count[0][0] > 900_000 and count[1][0] > 900_000
+    assert counters[0]["rounds"] >= 3 and fq_members > 900_000 and maf_members > 900_000
     # FASTQ: "@S1_<n>\n" + bases + "\n+S1_<n>\n" + '!' x bases + "\n": 2 x bases + per-read framing
     assert 2 * bases < fq_n < 2 * bases + 40 * n_reads and maf_n > 2 * bases
     assert fq_gz < 0.2 * fq_n and maf_gz < 0.35 * maf_n
@@ -259,7 +229,7 @@ def test_benchmarked_path_content_is_invariant(record):
         "three ranks, 3 GiB scratch pools": dict(world=3, scratch_gib=3),
     }
     for name, kw in variants.items():
-        digest, stats, cnt, _ = run_job(P, record, **kw)
+        digest, stats, cnt = run_job(P, record, **kw)
         assert stats == base_stats, name
         assert [d[:2] for d in digest] == [(fq_crc, fq_n), (maf_crc, maf_n)], name
         if kw.get("world", 1) > 1:
@@ -311,4 +281,4 @@ def test_compressed_job_path_matches_oracle_300_mbases(tmp_path):
                 d = zlib.decompressobj(31)
         got = b"".join(out)
         assert len(got) == len(want[key]) and got == want[key], key
-    assert rep in want[".stderr"].decode()
+    assert rep.rstrip("\n") in want[".stderr"].decode()
