@@ -22,23 +22,56 @@
 #define MAX_RECORDS 64
 
 /* ---- the communicator: all-gather and all-reduce of int64 over a barrier -------------------------------------------- */
-static pthread_barrier_t g_bar;
-static int g_world;
+/* A barrier that can be given up (pbsim_comm.abort): a rank whose job failed between two exchanges will never enter the
+ * next collective; it calls abort, every waiter wakes, and this and all later collectives return 0 -- the other ranks'
+ * pbsim_job_run then fails too instead of waiting for ever (a pthread_barrier_t has no such exit). */
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER;
+static int g_world, g_count, g_aborted;
+static unsigned long g_gen;
 static const int64_t *g_ptr[MAX_RANKS];
+
+static int barrier(void) { /* 1: everybody arrived, 0: aborted */
+  pthread_mutex_lock(&g_mu);
+  int ok = !g_aborted;
+  if (ok) {
+    const unsigned long gen = g_gen;
+    if (++g_count == g_world) {
+      g_count = 0;
+      g_gen++;
+      pthread_cond_broadcast(&g_cv);
+    } else {
+      while (gen == g_gen && !g_aborted) pthread_cond_wait(&g_cv, &g_mu);
+      ok = gen != g_gen;
+    }
+  }
+  pthread_mutex_unlock(&g_mu);
+  return ok;
+}
+static int comm_abort(void *user) {
+  (void)user;
+  pthread_mutex_lock(&g_mu);
+  g_aborted = 1;
+  pthread_cond_broadcast(&g_cv);
+  pthread_mutex_unlock(&g_mu);
+  return 1;
+}
 
 static int gather(void *user, const int64_t *send, int64_t n, int64_t *recv) {
   const int rank = *(int *)user;
   g_ptr[rank] = send;
-  pthread_barrier_wait(&g_bar);
+  if (!barrier()) return 0;
   for (int q = 0; q < g_world; q++) memcpy(recv + (size_t)q * (size_t)n, g_ptr[q], (size_t)n * 8);
-  pthread_barrier_wait(&g_bar);
-  return 1;
+  return barrier(); /* nobody's send buffer goes away before everybody has read it */
 }
 static int reduce(void *user, int64_t *buf, int64_t n, int32_t op) {
   const int rank = *(int *)user;
   int64_t *out = malloc((size_t)(n ? n : 1) * 8);
   g_ptr[rank] = buf;
-  pthread_barrier_wait(&g_bar);
+  if (!barrier()) {
+    free(out);
+    return 0;
+  }
   for (int64_t i = 0; i < n; i++) {
     int64_t v = g_ptr[0][i];
     for (int q = 1; q < g_world; q++) {
@@ -47,10 +80,10 @@ static int reduce(void *user, int64_t *buf, int64_t n, int32_t op) {
     }
     out[i] = v;
   }
-  pthread_barrier_wait(&g_bar);
-  memcpy(buf, out, (size_t)n * 8);
+  const int ok = barrier();
+  if (ok) memcpy(buf, out, (size_t)n * 8);
   free(out);
-  return 1;
+  return ok;
 }
 
 /* ---- the sink: every rank writes its pieces at their offsets ---------------------------------------------------------- */
@@ -110,7 +143,7 @@ static void *run_rank(void *arg) {
     f.maf[r] = open(name, O_WRONLY);
     ok = ok && f.fq[r] >= 0 && f.maf[r] >= 0;
   }
-  pbsim_comm comm = {&j->rank, j->rank, g_world, gather, reduce, NULL};
+  pbsim_comm comm = {&j->rank, j->rank, g_world, gather, reduce, NULL, comm_abort};
   pbsim_record_sink sink = {&f, on_read, on_maf, on_done};
   /* every rank MUST reach the job together (the collectives inside would wait forever for a rank that gave up) */
   int64_t all_ok = ok;
@@ -165,7 +198,6 @@ int main(int argc, char **argv) {
     snprintf(name, sizeof name, "%s_%04d.maf", argv[6], r);
     close(open(name, O_WRONLY | O_CREAT | O_TRUNC, 0666));
   }
-  pthread_barrier_init(&g_bar, NULL, (unsigned)g_world);
   pthread_t th[MAX_RANKS];
   for (int q = 0; q < g_world; q++) {
     jobs[q] = jobs[0];

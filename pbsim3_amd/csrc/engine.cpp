@@ -423,6 +423,18 @@ static int set_reference_common(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int64
   c->d_seq = d_seq;
   c->ref_len = len;
   c->unit = record_index;
+  c->packed_ok = false;
+  if (getenv("PBSIM_PACKED_REF") && atoi(getenv("PBSIM_PACKED_REF")) && c->p.method == PBSIM_METHOD_ERR && c->seq_hp_flag) {
+    // EXPERIMENT: a 4-bit copy of the prepared record for the lane walker
+    HIP_OK(c->d_packed.ensure((size_t)((len + 15) / 16 + 2) * 8, true));
+    DevBuf &fl = prefetched ? c->d_ref_flags_next : c->d_ref_flags;
+    HIP_OK(hipMemsetAsync(fl.p, 0, 4, c->stream));
+    launch_pack_ref(d_seq, len, c->d_packed.as<uint64_t>(), fl.as<DeviceFlags>(), c->stream);
+    uint32_t err = 0;
+    HIP_OK(hipMemcpyAsync(&err, fl.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->packed_ok = !(err & kErrPackedBad);
+  }
   for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
   return PBSIM_SUCCEEDED;
 }
@@ -435,6 +447,7 @@ extern "C++" RefDesc pbsim::current_ref(const pbsim_ctx *c) {
   r.len = c->ref_len;
   r.unit = c->unit;
   r.hp_flag = c->seq_hp_flag;
+  r.packed = c->packed_ok ? c->d_packed.as<uint64_t>() : nullptr;
   r.hp11 = c->bias.hp11_seen;
   return r;
 }
@@ -658,6 +671,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   w.ref.seq = ref.seq;
   w.ref.hp = ref.hp;
   w.ref.len = ref.len;
+  w.ref.packed = ref.packed;
   w.len = h.len;
   w.off = h.off;
   if (trans) {
@@ -706,10 +720,12 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
       // leaves the lane walker nothing to do: no empty launch, and the kernel's profile holds its bulk launches only)
       const bool lanes_idle = coop_len == 0 && s.coop_classes == (ncls >= 64 ? ~0ull : (1ull << ncls) - 1);
       if (!lanes_idle)
-        launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
+        launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb,
+                           ref.packed != nullptr);
       if (cs != ws) HIP_OK(hipStreamWaitEvent(ws, c->s().ev_coop, 0));
     } else {
-      launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
+      launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb,
+                         ref.packed != nullptr);
     }
   } else {
     w.stride = c->qct.stride;
