@@ -2325,6 +2325,24 @@ __device__ __forceinline__ uint32_t bam_base_code(uint32_t c) {
   }
 }
 
+// four ASCII bases (one dword, first base in the low byte) -> two BAM bytes (low 16 bits: first base in the high nibble).
+// A / C / G / T in either case take the v_perm path: index (c >> 1) & 3 = 0 A, 1 C, 2 T, 3 G picks the code from one constant
+// and the letter back from another (the check that the dword held nothing else); anything else (N, IUPAC codes) goes base by base.
+__device__ __forceinline__ uint32_t bam_pack4(uint32_t w) {
+  const uint32_t u = w & 0xDFDFDFDFu;                       // upper case (htslib's seq_nt16_table is case-insensitive)
+  const uint32_t idx = (u >> 1) & 0x03030303u;
+  uint32_t c = __builtin_amdgcn_perm(0u, 0x04080201u, idx);  // A 1, C 2, T 8, G 4
+  if (__builtin_amdgcn_perm(0u, 0x47544341u, idx) != u)       // 'A' 'C' 'T' 'G'
+    c = bam_base_code(w & 255u) | (bam_base_code((w >> 8) & 255u) << 8) | (bam_base_code((w >> 16) & 255u) << 16) |
+        (bam_base_code(w >> 24) << 24);
+  const uint32_t x = ((c & 0x000F000Fu) << 4) | ((c >> 8) & 0x000F000Fu);  // bytes 0 and 2 hold the two packed bytes
+  return (x & 0xFFu) | ((x >> 8) & 0xFF00u);
+}
+
+// One wave per task.  Everything moves as 16-byte vectors at the DESTINATION's alignment (a record's fields sit at byte
+// offsets): the ASCII bases are read as aligned dwords and shifted into place (v_alignbyte), qualities and the pw fill are in
+// place.  (The first version moved single bytes through a 16-way switch per base: as much GPU time as k_text_rows itself --
+// 2.7 s of the 4.7 s configs[2] job, profiles/r03_qshmm_timeline.txt.)
 __global__ __launch_bounds__(256) void k_bam_finish(TextArgs a) {
   short_kernel_priority();
   const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -2335,15 +2353,56 @@ __global__ __launch_bounds__(256) void k_bam_finish(TextArgs a) {
   uint8_t *seq = reinterpret_cast<uint8_t *>(a.read_text) + rd[0];
   uint8_t *qual = reinterpret_cast<uint8_t *>(a.read_text) + rd[1];
   uint8_t *pw = reinterpret_cast<uint8_t *>(a.read_text) + rd[5];
-  for (int i = lane; i < (q + 1) / 2; i += 64) {
-    const uint32_t hi = bam_base_code(pw[2 * i]);
-    const uint32_t lo = (2 * i + 1 < q) ? bam_base_code(pw[2 * i + 1]) : 0u;
-    seq[i] = (uint8_t)((hi << 4) | lo);
+  // ---- bases: q ASCII bytes at pw -> (q + 1) / 2 packed bytes at seq; whole 16-byte vectors cover full byte pairs only
+  {
+    const int nfull = q >> 1;  // packed bytes that take two bases
+    const int head = min(nfull, (int)((16 - (reinterpret_cast<uintptr_t>(seq) & 15)) & 15));
+    if (lane < head) seq[lane] = (uint8_t)((bam_base_code(pw[2 * lane]) << 4) | bam_base_code(pw[2 * lane + 1]));
+    const int nvec = (nfull - head) >> 4;
+    uint4 *d16 = reinterpret_cast<uint4 *>(seq + head);
+    for (int v = lane; v < nvec; v += 64) {
+      const uint8_t *src = pw + 2 * (head + 16 * v);  // 32 bases
+      const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3);
+      const uint32_t *p = reinterpret_cast<const uint32_t *>(src - sh);
+      uint32_t in[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) in[k] = p[k];   // (k == 8 is read for sh != 0 only in effect; the text buffer has slack)
+      uint32_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(in[2 * k + 1], in[2 * k], sh);
+        const uint32_t w1 = __builtin_amdgcn_alignbyte(in[2 * k + 2], in[2 * k + 1], sh);
+        o[k] = bam_pack4(w0) | (bam_pack4(w1) << 16);
+      }
+      d16[v] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    const int done = head + 16 * nvec;
+    for (int i = done + lane; i < (q + 1) / 2; i += 64) {
+      const uint32_t hi = bam_base_code(pw[2 * i]);
+      const uint32_t lo = (2 * i + 1 < q) ? bam_base_code(pw[2 * i + 1]) : 0u;
+      seq[i] = (uint8_t)((hi << 4) | lo);
+    }
   }
-  for (int i = lane; i < q; i += 64) qual[i] = (uint8_t)(qual[i] - 33u);
+  // ---- qualities: ASCII -> phred, in place (every byte is >= 33: the subtraction never borrows across bytes)
+  {
+    const int head = min(q, (int)((16 - (reinterpret_cast<uintptr_t>(qual) & 15)) & 15));
+    if (lane < head) qual[lane] = (uint8_t)(qual[lane] - 33u);
+    const int nvec = (q - head) >> 4;
+    uint4 *d16 = reinterpret_cast<uint4 *>(qual + head);
+    for (int v = lane; v < nvec; v += 64) {
+      uint4 x = d16[v];
+      x.x -= 0x21212121u;
+      x.y -= 0x21212121u;
+      x.z -= 0x21212121u;
+      x.w -= 0x21212121u;
+      d16[v] = x;
+    }
+    const int done = head + 16 * nvec;
+    if (lane < q - done) qual[done + lane] = (uint8_t)(qual[done + lane] - 33u);
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < q; i += 64) pw[i] = 9;
+  fill_run(reinterpret_cast<char *>(pw), q, 9, 9, lane);  // every lane has read its bases: the pw array takes its values
 }
 
 }  // namespace

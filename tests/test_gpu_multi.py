@@ -158,22 +158,36 @@ def test_genome_in_several_jobs(tmp_path):
         check_against_golden(outs, case)
 
 
-@pytest.mark.parametrize("case,targets", [("wgs_errhmm-ont_quirk", "400000,90000,250000"),
-                                          ("wgs_qshmm_rsii_pass3", "60000,300000,150000,100000")])
-def test_ranks_that_size_their_rounds_differently_still_agree(case, targets, tmp_path):
+@pytest.mark.parametrize("method,targets", [("errhmm", "2000000,500000,1000000"), ("qshmm", "700000,2500000,400000,1200000")])
+def test_ranks_that_size_their_rounds_differently_still_agree(method, targets, tmp_path):
     """with the automatic scratch pool a rank sizes its rounds from its OWN free memory; ranks whose GPUs
     report different free bytes then derived different reads-per-round, and their blocks overlapped or left gaps.  The caps
     now go through one MIN over the ranks.  PBSIM_JOB_TARGET_RANKS injects a different batch target per rank (what
-    differing hipMemGetInfo values do once the free memory bounds the batch): the output still equals the reference's, and
-    every rank begins every round with the same block size."""
+    differing hipMemGetInfo values do once the free memory bounds the batch) on a record whose rounds ARE bound by it
+    (2 Mbp x depth 6, reads of ~1.2 kb: 10 k reads, caps of 400-1900 reads): the output still equals the oracle's, and
+    every rank begins every round with the same block size -- the smallest rank's."""
+    import numpy as np
     ranks = targets.count(",") + 1
-    env = {"PBSIM_JOB_TARGET_RANKS": targets, "PBSIM_TRACE": "1"}
+    rng = np.random.default_rng(31)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2_000_000)]
+    fa = tmp_path / "g.fa"
+    with open(fa, "wb") as f:
+        f.write(b">chr1\n")
+        lines = seq.reshape(-1, 80)
+        f.write(np.concatenate([lines, np.full((lines.shape[0], 1), 10, np.uint8)], axis=1).tobytes())
+    model = "ERRHMM-ONT.model" if method == "errhmm" else "QSHMM-RSII.model"
+    args = ["--strategy", "wgs", "--method", method, "--" + method, harness.model_path(model), "--genome", str(fa),
+            "--depth", "6", "--seed", "13", "--length-mean", "1200", "--length-sd", "900"]
+    od = tmp_path / "o"
+    od.mkdir()
+    want = harness.run_oracle(args, "philox", str(od))
     import pbsim3_amd.build as b
     b.build()
-    e = dict(os.environ, **env)
-    p = subprocess.run([CLI] + harness.resolve(CASES[case]["args"]) + ["--prefix", str(tmp_path / "out"), "--devices",
-                                                                       ",".join(["0"] * ranks), "--no-gzip"],
-                       capture_output=True, text=True, cwd=str(tmp_path), env=e)
+    e = dict(os.environ, PBSIM_JOB_TARGET_RANKS=targets, PBSIM_TRACE="1")
+    wd = tmp_path / "w"
+    wd.mkdir()
+    p = subprocess.run([CLI] + args + ["--prefix", str(wd / "out"), "--devices", ",".join(["0"] * ranks), "--no-gzip"],
+                       capture_output=True, text=True, cwd=str(wd), env=e)
     assert p.returncode == 0, p.stderr[-4000:]
     begun = {}
     for line in p.stderr.splitlines():
@@ -182,10 +196,16 @@ def test_ranks_that_size_their_rounds_differently_still_agree(case, targets, tmp
             begun.setdefault(r, []).append(line.split("] begin ", 1)[1])
     assert sorted(begun) == list(range(ranks)) and len(begun[0]) >= 3
     assert all(begun[r] == begun[0] for r in begun), begun
+    n_per = int(begun[0][0].split("n_per=")[1])
+    smallest = min(float(x) for x in targets.split(","))
+    want_n = 1.08 * smallest / 1200.0 + 64                                      # the smallest rank's cap decides
+    assert 0.85 * want_n < n_per < 1.15 * want_n, (n_per, want_n)                # (E[L] of the length table is ~1200)
     report = "\n".join(l for l in p.stderr.splitlines() if not l.startswith("[pbsim"))
-    outs = harness.collect(str(tmp_path))
-    outs[".stderr"] = harness.strip_report(report).encode()
-    check_against_golden(outs, case)
+    outs = harness.collect(str(wd))
+    outs[".stderr"] = harness.strip_report(report + "\n").encode()
+    assert sorted(outs) == sorted(want)
+    for k in outs:
+        assert outs[k] == want[k], k
 
 
 def test_job_rerun_and_second_genome_on_one_context():
