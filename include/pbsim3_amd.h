@@ -313,6 +313,15 @@ int pbsim_job_counters(pbsim_ctx *ctx, int64_t out[8]);
  * tail reads walked by this rank, [15] rounds kept in flight. */
 int pbsim_job_breakdown(pbsim_ctx *ctx, double out[16]);
 
+/* The sampling method (pbsim_simulate_sample, pbsim.cpp:1694-1949) on several ranks, for the current record: one context per
+ * GPU, every rank has set the same reference and profile.  The copies of one string are a chain, strings are independent, and
+ * the test `len_total < quota` at a read's start (pbsim.cpp:1749) is the wgs quota rule's prefix dependence -- a round gives
+ * rank r the r-th run of a sweep's strings, three all-gathers of a few integers place the quota prefix, the cut and every
+ * rank's byte range.  The sink receives (record, bytes, offset) like a job's (record = the record_index of
+ * pbsim_set_reference); on_record_done reports the merged statistics on every rank (pbsim_get_stats too).  The concatenation
+ * of all ranks' bytes in offset order is what pbsim_simulate_sample delivers on one GPU. */
+int pbsim_simulate_sample_comm(pbsim_ctx *ctx, const pbsim_comm *comm, const pbsim_record_sink *sink);
+
 /* Statistics primitives for callers that shard a unit set over several contexts themselves (trans / templ:
  * pbsim_simulate_units_range per rank): keep the per-task accuracy values while accounting (before simulating), then
  * merge -- afterwards pbsim_get_stats on every rank reports the whole unit set exactly as one GPU would

@@ -126,6 +126,7 @@ API = [
     ("pbsim_bam_header", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("pbsim_set_sample_profile", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     ("pbsim_simulate_sample", C.c_int, [C.c_void_p, C.POINTER(Sink)]),
+    ("pbsim_simulate_sample_comm", C.c_int, [C.c_void_p, C.POINTER(Comm), C.POINTER(RecordSink)]),
     ("pbsim_set_deflate", C.c_int, [C.c_void_p, C.c_int]),
     ("pbsim_deflate_bound", C.c_int64, [C.c_int64]),
     ("pbsim_batch_fetch_deflated", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

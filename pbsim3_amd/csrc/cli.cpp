@@ -577,7 +577,6 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
   const std::string profile_fq = "sample_profile_" + c.profile_id + ".fastq",
                     profile_stats = "sample_profile_" + c.profile_id + ".stats";
   if (world > 1) {
-    if (sampling) die(": --method sample runs on one GPU (its chains of copies are serial per sampled read).");
     if (!c.no_gzip && (!c.gzip_on_gpu || c.use_samtools))
       die(": several GPUs write their own byte ranges of the outputs: use --gzip gpu (default) or --no-gzip.");
   }
@@ -592,8 +591,9 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       if (!pbsim::read_sample_fastq(c.sample.c_str(), (long)c.p.len_min, (long)c.p.len_max, c.accuracy_min,
                                     c.accuracy_max, &prof, &e))
         die(": %s", e.c_str());
-      if (c.sam_store && !pbsim::write_sample_profile(profile_fq, profile_stats, prof, &e)) die(": %s", e.c_str());
+      if (c.sam_store && rank0 && !pbsim::write_sample_profile(profile_fq, profile_stats, prof, &e)) die(": %s", e.c_str());
     }
+    if (rank0) {
     fprintf(stderr, ":::: sample reads stats ::::\n\n");  // print_sample_stats, pbsim.cpp:1336-1360
     if (c.sam_reuse) {
       fprintf(stderr, "file name : %s\n", profile_fq.c_str());
@@ -613,6 +613,7 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
     fprintf(stderr, "read length mean (SD) : %f (%f)\n", prof.len_mean_filtered, prof.len_sd_filtered);
     fprintf(stderr, "read accuracy mean (SD) : %f (%f)\n", prof.accuracy_mean_filtered, prof.accuracy_sd_filtered);
     fprintf(stderr, "\n");
+    }
   }
 
   pbsim_ctx *ctx = pbsim_create(&c.p, c.device);
@@ -698,9 +699,14 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
     }
     check(pbsim_job_begin(ctx, 1));
   } else if (c.p.strategy == PBSIM_STRATEGY_WGS) {  // the sampling method, or SAM text into a samtools pipe: record by record
-    if (world > 1) die(": this combination of options runs on one GPU.");
+    if (world > 1 && !sampling) die(": this combination of options runs on one GPU.");
     pbsim::GenomeInfo gi;
-    if (!pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
+    if (rank0 && !pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
+    if (world > 1) {  // the record count travels; every rank then reads the <prefix>_NNNN.ref files rank 0 wrote
+      int64_t nrec = rank0 ? gi.num_seq : 0;
+      if (!comm->all_reduce_i64(comm->user, &nrec, 1, PBSIM_OP_SUM)) die(": communicator failed");
+      gi.num_seq = (long)nrec;
+    }
     std::string seq;
     if (c.p.hp_del_bias != 1) {
       for (long n = 1; n <= gi.num_seq; n++) {
@@ -712,6 +718,22 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
     for (long n = 1; n <= gi.num_seq; n++) {
       if (!pbsim::load_ref_record(c.prefix.c_str(), n, &seq, &err)) die(": %s", err.c_str());
       check(pbsim_set_reference(ctx, (const uint8_t *)seq.data(), (int64_t)seq.size(), n));
+      if (world > 1) {
+        // the sampling method on several ranks (pbsim.cpp:1694-1949): string blocks per rank, every rank writes its byte
+        // ranges of the record's two files (rank 0 creates them), the merged statistics come back on every rank
+        JobFiles jf;
+        jf.cli = &c;
+        jf.ctx = ctx;
+        jf.comm = comm;
+        jf.first = n;
+        jf.recs.emplace_back(new RecFiles);
+        if (rank0) open_record(jf, n, true);
+        barrier(comm);  // the files exist
+        if (!rank0) open_record(jf, n, false);
+        pbsim_record_sink rsink = {&jf, job_read, job_maf, job_done};
+        check(pbsim_simulate_sample_comm(ctx, comm, &rsink));
+        continue;
+      }
       Out o_read, o_maf;
       if (c.p.pass_num == 1) {
         snprintf(name, sizeof name, "%s_%04ld.fq", c.prefix.c_str(), n);

@@ -101,7 +101,7 @@ constexpr double kSinkBatchBases = 5.0e9;  // pbsim_simulate_wgs: expected bases
 // One deflate pipeline: staging for one piece of DF_PIECE_CHUNKS chunks, double-buffered dense output + pinned copies, its
 // own streams.  A slot owns two, so that its read text and its MAF text can be compressed, copied and handed to their
 // sinks side by side (pbsim_set_deflate bit 2).
-constexpr int kDfBuffers = 3;
+constexpr int kDfBuffers = 5;  // at most: the lane's kernels run `ahead` pieces in front of the copies (ahead + 1 buffers in use)
 struct DfLane {
   DevBuf d_df_status, d_df_ctl;        // look-back words of the launch in progress (told apart by `epoch`), ticket + total
   uint32_t epoch = 0;                  // one per launch on this lane
@@ -182,7 +182,6 @@ struct DfLane {
 struct RefDesc {
   const uint8_t *seq = nullptr;  // upper-cased bases (bit 7 = hp == 11 when hp_flag)
   const uint8_t *hp = nullptr;   // homopolymer length per base
-  const uint64_t *packed = nullptr;  // EXPERIMENT (PBSIM_PACKED_REF=1): 4-bit codes, 16 per qword
   int64_t len = 0;
   int64_t unit = 0;              // genome.num (wgs, 1-based) or 0
   bool hp_flag = false;
@@ -246,7 +245,7 @@ struct Slot {
 
 // One record of a job (pbsim_job_add_record): resident in HBM for the whole job
 struct JobRecord {
-  DevBuf seq, hp, tiles, flags, packed;
+  DevBuf seq, hp, tiles, flags;
   int64_t len = 0;
   RefDesc ref;
 };
@@ -273,8 +272,6 @@ struct pbsim_ctx {
   bool qs_tabs_ready[2] = {false, false};
   // reference
   DevBuf d_seq_own, d_hp, d_tiles, d_ref_flags;
-  DevBuf d_packed;               // EXPERIMENT (PBSIM_PACKED_REF=1): 4-bit copy of the current unit
-  bool packed_ok = false;
   // the NEXT record, uploaded and prepared beside the current record's simulation (pbsim_prefetch_reference*)
   DevBuf d_seq_next, d_hp_next, d_tiles_next, d_ref_flags_next;
   hipStream_t prefetch_stream = nullptr;

@@ -423,18 +423,6 @@ static int set_reference_common(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int64
   c->d_seq = d_seq;
   c->ref_len = len;
   c->unit = record_index;
-  c->packed_ok = false;
-  if (getenv("PBSIM_PACKED_REF") && atoi(getenv("PBSIM_PACKED_REF")) && c->p.method == PBSIM_METHOD_ERR && c->seq_hp_flag) {
-    // EXPERIMENT: a 4-bit copy of the prepared record for the lane walker
-    HIP_OK(c->d_packed.ensure((size_t)((len + 15) / 16 + 2) * 8, true));
-    DevBuf &fl = prefetched ? c->d_ref_flags_next : c->d_ref_flags;
-    HIP_OK(hipMemsetAsync(fl.p, 0, 4, c->stream));
-    launch_pack_ref(d_seq, len, c->d_packed.as<uint64_t>(), fl.as<DeviceFlags>(), c->stream);
-    uint32_t err = 0;
-    HIP_OK(hipMemcpyAsync(&err, fl.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
-    c->packed_ok = !(err & kErrPackedBad);
-  }
   for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
   return PBSIM_SUCCEEDED;
 }
@@ -447,7 +435,6 @@ extern "C++" RefDesc pbsim::current_ref(const pbsim_ctx *c) {
   r.len = c->ref_len;
   r.unit = c->unit;
   r.hp_flag = c->seq_hp_flag;
-  r.packed = c->packed_ok ? c->d_packed.as<uint64_t>() : nullptr;
   r.hp11 = c->bias.hp11_seen;
   return r;
 }
@@ -671,7 +658,6 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   w.ref.seq = ref.seq;
   w.ref.hp = ref.hp;
   w.ref.len = ref.len;
-  w.ref.packed = ref.packed;
   w.len = h.len;
   w.off = h.off;
   if (trans) {
@@ -720,12 +706,10 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
       // leaves the lane walker nothing to do: no empty launch, and the kernel's profile holds its bulk launches only)
       const bool lanes_idle = coop_len == 0 && s.coop_classes == (ncls >= 64 ? ~0ull : (1ull << ncls) - 1);
       if (!lanes_idle)
-        launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb,
-                           ref.packed != nullptr);
+        launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
       if (cs != ws) HIP_OK(hipStreamWaitEvent(ws, c->s().ev_coop, 0));
     } else {
-      launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb,
-                         ref.packed != nullptr);
+      launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
     }
   } else {
     w.stride = c->qct.stride;
@@ -1130,11 +1114,14 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   double t_kernel = 0, t_copy = 0, t_consume = 0, t_begin = now();
   int64_t out_bytes = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;  // trace: begin / end of every copy on the copy stream
-  bool used[kDfBuffers] = {false, false, false};
+  bool used[kDfBuffers] = {false};
+  // pieces the lane's kernels run ahead of the piece whose copy is being enqueued (ahead + 1 dense buffers in use)
+  static const int ahead_env = getenv("PBSIM_DEFLATE_AHEAD") ? atoi(getenv("PBSIM_DEFLATE_AHEAD")) : 2;
+  const int ahead = std::max(1, std::min(kDfBuffers - 1, ahead_env)), nbuf = ahead + 1;
   int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
   // piece j: kernels on staging set j & 1 into dense buffer j % 3; its total lands in h_total[j % 3]
   auto launch = [&](int64_t j) -> int {
-    const int b = (int)(j % kDfBuffers);
+    const int b = (int)(j % nbuf);
     const int64_t off = j * piece, len = std::min(piece, n - off);
     if (!direct) HIP_OK(sl.d_df_dense[b].ensure((size_t)max_ch * DF_SLOT + 64, true));
     if (!place) HIP_OK(sl.h_df_out[b].ensure((size_t)max_ch * DF_SLOT + 64));
@@ -1151,10 +1138,10 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   const char *prev_ptr = nullptr;  // piece k - 1: copy possibly still in flight
   int64_t prev_bytes = 0;
   int prev_buf = 0;
-  if (!launch(0)) return PBSIM_FAILED;
-  if (n_pieces > 1 && !launch(1)) return PBSIM_FAILED;
+  for (int64_t j = 0; j < std::min<int64_t>(ahead, n_pieces); j++)
+    if (!launch(j)) return PBSIM_FAILED;
   for (int64_t k = 0; k < n_pieces; k++) {
-    const int b = (int)(k % kDfBuffers);
+    const int b = (int)(k % nbuf);
     const double t0 = now();
     HIP_OK(hipEventSynchronize(sl.ev_df[b]));
     t_kernel += now() - t0;
@@ -1199,7 +1186,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     prev_buf = b;
     // piece k's staging set is free (its total has arrived), the dense buffer of piece k - 1 once its copy is through (a
     // stream wait inside launch): keep the kernels one piece ahead
-    if (k + 2 < n_pieces && !launch(k + 2)) return PBSIM_FAILED;
+    if (k + ahead < n_pieces && !launch(k + ahead)) return PBSIM_FAILED;
   }
   if (prev_bytes) {
     const double t1 = now();
@@ -1713,228 +1700,446 @@ int pbsim_set_sample_profile(pbsim_ctx *c, int64_t n, const uint8_t *const *qual
 // order, and a read is made as long as len_total < quota at its start.  A chunk = a run of consecutive strings
 // with all their copies; its strings walk in parallel, one lane each (k_walk_sample), and everything after the walk
 // (prefix in read order, the cut, text, statistics) is the ordinary batch machinery.
-int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
-  if (!c) return fail("bad argument");
-  NEED_DEVICE(c);
+extern "C++" {
+namespace {
+
+// Host side of the chunks: which strings a chunk holds and how their copies are laid out in the scratch pool (plan),
+// and the upload + walk + pass-0 prefix of a planned chunk on slot 0 (launch).  Shared by the one-GPU driver and the
+// sharded one; where a chunk ends never changes a byte (tests/test_gpu_sample.py).
+struct SampleChunks {
+  struct Ent {
+    int64_t line, num;  // string index, copies to make in this chunk
+    int32_t len;        // its current length (shorter than the file's once a chain is carried over)
+  };
+  struct Chunk {
+    std::vector<Ent> cand;
+    size_t n_c = 0;              // strings of cand[] the chunk takes
+    int64_t n_tasks = 0;
+    int64_t next_probe = 0;      // the string after the last one that was looked at
+    std::vector<int32_t> h_len, h_vbase, h_cap, h_tos, h_sot;
+    std::vector<int64_t> h_qoff, h_woff;
+  };
+  pbsim_ctx *c;
+  int64_t F, G, interval = 1, sample_num = 0;
+  // a string whose copies do not fit one chunk continues in the next one: copies done so far, current length
+  int64_t carry_line = -1, carry_done = 0;
+  int32_t carry_len = 0;
+  std::vector<int32_t> order;
+
+  int init(int64_t quota) {
+    F = (int64_t)c->sq_len.size();
+    G = c->ref_len;
+    sample_num = quota / c->sq_total;            // :1718-1728
+    const int64_t residue = quota % c->sq_total;
+    interval = 1;
+    if (residue != 0) {
+      interval = (int64_t)((double)(c->sq_total / residue) * 2 + 0.5);
+      if (interval > (int64_t)(F * 0.5)) interval = (int64_t)(F * 0.5);
+    }
+    if (interval < 1) return fail("sample profile holds a single read: the reference divides by zero here (pbsim.cpp:1741)");
+    return PBSIM_SUCCEEDED;
+  }
+  int64_t copies_of(int64_t sv, int64_t line) const { return sample_num + (((sv + line) % interval == 0) ? 1 : 0); }
+  // strings of [line, F) that have copies in this sweep (the sharded driver deals them out in equal runs)
+  int64_t count_candidates(int64_t sv, int64_t line) const {
+    int64_t n = 0;
+    for (int64_t l = line; l < F; l++) n += (copies_of(sv, l) - (l == carry_line ? carry_done : 0)) > 0;
+    return n;
+  }
+
+  // the chunk that starts at `line`: at most max_cand strings, shrunk until its scratch fits the pool.  ck->cand empty: no
+  // string from `line` on has copies (ck->next_probe == F).
+  int plan(int64_t sv, int64_t line, size_t max_cand, Chunk *ck) {
+    ck->cand.clear();
+    int64_t probe = line;
+    while (probe < F && ck->cand.size() < max_cand) {
+      int64_t k = copies_of(sv, probe);
+      int32_t len = c->sq_len[(size_t)probe];
+      if (probe == carry_line) {
+        k -= carry_done;
+        len = carry_len;
+      }
+      if (k > 0) ck->cand.push_back(Ent{probe, k, len});
+      probe++;
+    }
+    ck->next_probe = probe;
+    ck->n_c = 0;
+    ck->n_tasks = 0;
+    if (ck->cand.empty()) return PBSIM_SUCCEEDED;
+    // ---- lay the chunk out.  Reads stay in file order; LANES are dealt by length (the longest strings share a
+    // wave), one virtual wave of scratch per copy.  Shrink the chunk until it fits the pool.
+    std::vector<Ent> &cand = ck->cand;
+    size_t n_c = cand.size();
+    int64_t need = 0, n_tasks = 0;
+    for (;;) {
+      order.resize(n_c);
+      for (size_t i = 0; i < n_c; i++) order[i] = (int32_t)i;
+      std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cand[(size_t)x].len > cand[(size_t)y].len; });
+      ck->h_vbase.assign(1, 0);
+      ck->h_cap.clear();
+      ck->h_woff.clear();
+      need = 0;
+      n_tasks = 0;
+      for (size_t w0 = 0; w0 < n_c; w0 += 64) {
+        int64_t kmax = 0, lmax = 0;
+        for (size_t i = w0; i < std::min(n_c, w0 + 64); i++) {
+          const Ent &e = cand[(size_t)order[i]];
+          kmax = std::max(kmax, e.num);
+          lmax = std::max<int64_t>(lmax, std::min<int64_t>(e.len, G));
+          n_tasks += e.num;
+        }
+        const int64_t cap_dw = (2 * lmax + kScratchPad + 3) / 4;
+        for (int64_t k = 0; k < kmax; k++) {
+          ck->h_cap.push_back((int32_t)cap_dw);
+          ck->h_woff.push_back(need);
+          need += cap_dw * 256 * 3;
+        }
+        ck->h_vbase.push_back((int32_t)ck->h_cap.size());
+      }
+      if (need <= c->scratch_budget && n_tasks <= 0x3fffffff && ck->h_cap.size() <= 0x1ffffff) break;
+      if (n_c > 1) {
+        n_c = (n_c + 1) / 2;
+        continue;
+      }
+      // one string alone: make as many of its copies as fit, the chain continues in the next chunk
+      const int64_t per_copy = need / cand[0].num;
+      const int64_t kfit = c->scratch_budget / std::max<int64_t>(per_copy, 1);
+      if (kfit < 1) return fail("scratch pool too small for a single sampled read (pbsim_set_scratch_bytes)");
+      cand[0].num = std::min(cand[0].num, kfit);
+    }
+    ck->h_len.assign(((n_c + 63) / 64) * 64, 0);
+    ck->h_qoff.assign(ck->h_len.size(), 0);
+    ck->h_tos.assign(ck->h_cap.size() * 64, -1);
+    ck->h_sot.resize((size_t)n_tasks);
+    {
+      std::vector<int32_t> pos_of(n_c);
+      for (size_t i = 0; i < n_c; i++) pos_of[(size_t)order[i]] = (int32_t)i;
+      int64_t t = 0;
+      for (size_t e = 0; e < n_c; e++) {  // tasks in file order, lanes in length order
+        const size_t pos = (size_t)pos_of[e];
+        ck->h_len[pos] = cand[e].len;
+        ck->h_qoff[pos] = c->sq_off[(size_t)cand[e].line];
+        const int64_t v0 = ck->h_vbase[pos / 64];
+        for (int64_t k = 0; k < cand[e].num; k++) {
+          const int64_t slot = (v0 + k) * 64 + (int64_t)(pos % 64);
+          ck->h_tos[(size_t)slot] = (int32_t)t;
+          ck->h_sot[(size_t)t] = (int32_t)slot;
+          t++;
+        }
+      }
+    }
+    ck->n_c = n_c;
+    ck->n_tasks = n_tasks;
+    return PBSIM_SUCCEEDED;
+  }
+  // where a chunk leaves the sweep: past its last string, unless that string still has copies to make
+  bool last_unfinished(int64_t sv, const Chunk &ck, int64_t *last_done) const {
+    const Ent &last = ck.cand[ck.n_c - 1];
+    *last_done = (last.line == carry_line ? carry_done : 0) + last.num;
+    return *last_done < copies_of(sv, last.line);
+  }
+
+  // upload + walk + pass-0 prefix of the chunk on slot 0; its reads are first_read .. first_read + n_tasks - 1
+  int launch(const Chunk &ck, int64_t first_read) {
+    Slot &sl = c->s();
+    const int64_t n_tasks = ck.n_tasks;
+    const int64_t n_lines = (int64_t)ck.h_len.size(), n_lw = (int64_t)ck.h_vbase.size() - 1, V = (int64_t)ck.h_cap.size();
+    if (first_read - 1 + n_tasks > 0xfffffff0LL) return fail("read index exceeds 32 bits");
+    // ---- device state of the batch
+    HIP_OK(sl.d_flags.ensure(sizeof(DeviceFlags)));
+    HIP_OK(sl.d_len.ensure(n_tasks * 4));
+    HIP_OK(sl.d_off.ensure(n_tasks * 4));
+    HIP_OK(sl.d_task_of_slot.ensure(V * 64 * 4));
+    HIP_OK(sl.d_slot_of_task.ensure(n_tasks * 4));
+    HIP_OK(sl.d_wave_cap.ensure(V * 4));
+    HIP_OK(sl.d_wave_off.ensure(V * 8));
+    HIP_OK(sl.d_out_len.ensure(n_tasks * 4));
+    HIP_OK(sl.d_maf_len.ensure(n_tasks * 4));
+    HIP_OK(sl.d_nsub.ensure(n_tasks * 4));
+    HIP_OK(sl.d_nins.ensure(n_tasks * 4));
+    HIP_OK(sl.d_ndel.ensure(n_tasks * 4));
+    HIP_OK(sl.d_qsum.ensure(n_tasks * 8));
+    HIP_OK(sl.d_cum.ensure((n_tasks + 1) * 8));
+    HIP_OK(sl.d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
+    HIP_OK(sl.d_scratch.ensure((size_t)c->scratch_budget + kScratchSlack, true));
+    HIP_OK(c->d_sq_line_len.ensure(n_lines * 4));
+    HIP_OK(c->d_sq_line_qoff.ensure(n_lines * 8));
+    HIP_OK(c->d_sq_vbase.ensure((n_lw + 1) * 4));
+    DeviceFlags f0;
+    memset(&f0, 0, sizeof f0);
+    f0.total_slots = V * 64;
+    f0.n_final = n_tasks;
+    HIP_OK(hipMemcpyAsync(sl.d_flags.p, &f0, sizeof f0, hipMemcpyHostToDevice, sl.stream));
+    HIP_OK(hipMemcpyAsync(c->d_sq_line_len.p, ck.h_len.data(), n_lines * 4, hipMemcpyHostToDevice, sl.stream));
+    HIP_OK(hipMemcpyAsync(c->d_sq_line_qoff.p, ck.h_qoff.data(), n_lines * 8, hipMemcpyHostToDevice, sl.stream));
+    HIP_OK(hipMemcpyAsync(c->d_sq_vbase.p, ck.h_vbase.data(), (n_lw + 1) * 4, hipMemcpyHostToDevice, sl.stream));
+    HIP_OK(hipMemcpyAsync(sl.d_task_of_slot.p, ck.h_tos.data(), V * 64 * 4, hipMemcpyHostToDevice, sl.stream));
+    HIP_OK(hipMemcpyAsync(sl.d_slot_of_task.p, ck.h_sot.data(), n_tasks * 4, hipMemcpyHostToDevice, sl.stream));
+    HIP_OK(hipMemcpyAsync(sl.d_wave_cap.p, ck.h_cap.data(), V * 4, hipMemcpyHostToDevice, sl.stream));
+    HIP_OK(hipMemcpyAsync(sl.d_wave_off.p, ck.h_woff.data(), V * 8, hipMemcpyHostToDevice, sl.stream));
+    DeviceFlags *flags = sl.d_flags.as<DeviceFlags>();
+    SampleArgs a;
+    memset(&a, 0, sizeof a);
+    a.seed = c->p.seed;
+    a.unit = (uint32_t)c->unit;
+    a.first_read = first_read;
+    a.n_lines = (int32_t)n_lines;
+    a.n_line_waves = (int32_t)n_lw;
+    a.ref.seq = c->d_seq;
+    a.ref.hp = c->d_hp.as<uint8_t>();
+    a.ref.len = G;
+    a.quals = c->d_sq.as<uint8_t>();
+    a.line_qoff = c->d_sq_line_qoff.as<int64_t>();
+    a.line_len = c->d_sq_line_len.as<int32_t>();
+    a.vbase = c->d_sq_vbase.as<int32_t>();
+    a.task_of_slot = sl.d_task_of_slot.as<int32_t>();
+    a.wave_cap = sl.d_wave_cap.as<int32_t>();
+    a.wave_off = sl.d_wave_off.as<int64_t>();
+    a.scratch = sl.d_scratch.as<uint8_t>();
+    a.span = sl.d_len.as<int32_t>();
+    a.off = sl.d_off.as<int32_t>();
+    a.out_len = sl.d_out_len.as<int32_t>();
+    a.maf_len = sl.d_maf_len.as<int32_t>();
+    a.nsub = sl.d_nsub.as<int32_t>();
+    a.nins = sl.d_nins.as<int32_t>();
+    a.ndel = sl.d_ndel.as<int32_t>();
+    a.qsum = sl.d_qsum.as<double>();
+    const uint8_t *t = c->d_qs_tabs_v[c->bias.hp11_seen].as<uint8_t>();
+    a.sub_thre = reinterpret_cast<const uint32_t *>(t);
+    a.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
+    a.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
+    a.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
+    a.flags = flags;
+    launch_walk_sample(a, c->seq_hp_flag, sl.stream);
+    launch_gather_pass0_scan(a.out_len, n_tasks, 1, sl.d_cum.as<int64_t>(), sl.d_scan_tmp.as<int64_t>(),
+                             &flags->sums[0], sl.stream);
+    HIP_OK(hipGetLastError());
+    DeviceFlags f;
+    if (!read_flags(c, &f)) return PBSIM_FAILED;
+    if (f.error & kErrScratchOverflow) return fail("a sampled read produced more MAF columns than its scratch holds");
+    sl.b_first = first_read;
+    sl.b_n = n_tasks;
+    sl.b_slots_max = V * 64;
+    sl.b_truncated = false;
+    sl.b_enqueued = false;
+    sl.b_walked = true;
+    sl.b_finalized = false;
+    sl.b_pass0 = f.sums[0];
+    return PBSIM_SUCCEEDED;
+  }
+};
+
+int sample_common_checks(pbsim_ctx *c) {
   if (c->p.method != PBSIM_METHOD_SAMPLE) return fail("pbsim_simulate_sample: method is not sample");
   if (!c->d_seq) return fail("no reference set (pbsim_set_reference)");
   if (c->sq_len.empty()) return fail("no sample profile set (pbsim_set_sample_profile)");
   HIP_OK(hipSetDevice(c->device));
   if (!ensure_class_tables(c) || !ensure_qs_tabs(c, c->bias.hp11_seen)) return PBSIM_FAILED;
+  return PBSIM_SUCCEEDED;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
+  if (!c) return fail("bad argument");
+  NEED_DEVICE(c);
+  if (!sample_common_checks(c)) return PBSIM_FAILED;
   pbsim_reset_stats(c);
   c->cur = 0;
   Slot &sl = c->s();
   sl.ref = current_ref(c);
-  const int64_t quota = pbsim_unit_quota(c), F = (int64_t)c->sq_len.size(), G = c->ref_len;
-  int64_t sample_num = quota / c->sq_total;            // :1718-1728
-  const int64_t residue = quota % c->sq_total;
-  int64_t interval = 1;
-  if (residue != 0) {
-    interval = (int64_t)((double)(c->sq_total / residue) * 2 + 0.5);
-    if (interval > (int64_t)(F * 0.5)) interval = (int64_t)(F * 0.5);
-  }
-  if (interval < 1) return fail("sample profile holds a single read: the reference divides by zero here (pbsim.cpp:1741)");
+  const int64_t quota = pbsim_unit_quota(c);
+  SampleChunks S;
+  S.c = c;
+  if (!S.init(quota)) return PBSIM_FAILED;
+  const int64_t F = S.F;
   int64_t len_total = 0, res = 0;
   bool done = false;
-  std::vector<int32_t> h_len, h_vbase, h_cap, h_tos, h_sot;
-  std::vector<int64_t> h_qoff, h_woff;
-  struct Ent {
-    int64_t line, num;  // string index, copies to make in this chunk
-    int32_t len;        // its current length (shorter than the file's once a chain is carried over)
-  };
-  std::vector<Ent> cand;
-  std::vector<int32_t> order;
-  // a string whose copies do not fit one chunk continues in the next one: copies done so far, current length
-  int64_t carry_line = -1, carry_done = 0;
-  int32_t carry_len = 0;
+  SampleChunks::Chunk ck;
   while (len_total < quota && !done) {
     const int64_t sv = (int64_t)(header_block(c->p.seed, (uint32_t)c->unit, (uint32_t)(res + 1)).w % (uint32_t)F);  // :1732
     int64_t line = 0;
     while (line < F && len_total < quota && !done) {
-      // ---- candidates: consecutive strings (file order = read order) that have copies in this sweep
-      cand.clear();
-      int64_t probe = line;
-      while (probe < F && cand.size() < (size_t)1 << 18) {
-        int64_t k = sample_num + (((sv + probe) % interval == 0) ? 1 : 0);
-        int32_t len = c->sq_len[(size_t)probe];
-        if (probe == carry_line) {
-          k -= carry_done;
-          len = carry_len;
-        }
-        if (k > 0) cand.push_back(Ent{probe, k, len});
-        probe++;
-      }
-      if (cand.empty()) {
-        line = probe;
+      if (!S.plan(sv, line, (size_t)1 << 18, &ck)) return PBSIM_FAILED;
+      if (ck.cand.empty()) {
+        line = ck.next_probe;
         continue;
       }
-      // ---- lay the chunk out.  Reads stay in file order; LANES are dealt by length (the longest strings share a
-      // wave), one virtual wave of scratch per copy.  Shrink the chunk until it fits the pool.
-      size_t n_c = cand.size();
-      int64_t need = 0, n_tasks = 0;
-      for (;;) {
-        order.resize(n_c);
-        for (size_t i = 0; i < n_c; i++) order[i] = (int32_t)i;
-        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cand[(size_t)x].len > cand[(size_t)y].len; });
-        h_vbase.assign(1, 0);
-        h_cap.clear();
-        h_woff.clear();
-        need = 0;
-        n_tasks = 0;
-        for (size_t w0 = 0; w0 < n_c; w0 += 64) {
-          int64_t kmax = 0, lmax = 0;
-          for (size_t i = w0; i < std::min(n_c, w0 + 64); i++) {
-            const Ent &e = cand[(size_t)order[i]];
-            kmax = std::max(kmax, e.num);
-            lmax = std::max<int64_t>(lmax, std::min<int64_t>(e.len, G));
-            n_tasks += e.num;
-          }
-          const int64_t cap_dw = (2 * lmax + kScratchPad + 3) / 4;
-          for (int64_t k = 0; k < kmax; k++) {
-            h_cap.push_back((int32_t)cap_dw);
-            h_woff.push_back(need);
-            need += cap_dw * 256 * 3;
-          }
-          h_vbase.push_back((int32_t)h_cap.size());
-        }
-        if (need <= c->scratch_budget && n_tasks <= 0x3fffffff && h_cap.size() <= 0x1ffffff) break;
-        if (n_c > 1) {
-          n_c = (n_c + 1) / 2;
-          continue;
-        }
-        // one string alone: make as many of its copies as fit, the chain continues in the next chunk
-        const int64_t per_copy = need / cand[0].num;
-        const int64_t kfit = c->scratch_budget / std::max<int64_t>(per_copy, 1);
-        if (kfit < 1) return fail("scratch pool too small for a single sampled read (pbsim_set_scratch_bytes)");
-        cand[0].num = std::min(cand[0].num, kfit);
-      }
-      h_len.assign(((n_c + 63) / 64) * 64, 0);
-      h_qoff.assign(h_len.size(), 0);
-      h_tos.assign(h_cap.size() * 64, -1);
-      h_sot.resize((size_t)n_tasks);
-      {
-        std::vector<int32_t> pos_of(n_c);
-        for (size_t i = 0; i < n_c; i++) pos_of[(size_t)order[i]] = (int32_t)i;
-        int64_t t = 0;
-        for (size_t e = 0; e < n_c; e++) {  // tasks in file order, lanes in length order
-          const size_t pos = (size_t)pos_of[e];
-          h_len[pos] = cand[e].len;
-          h_qoff[pos] = c->sq_off[(size_t)cand[e].line];
-          const int64_t v0 = h_vbase[pos / 64];
-          for (int64_t k = 0; k < cand[e].num; k++) {
-            const int64_t slot = (v0 + k) * 64 + (int64_t)(pos % 64);
-            h_tos[(size_t)slot] = (int32_t)t;
-            h_sot[(size_t)t] = (int32_t)slot;
-            t++;
-          }
-        }
-      }
-      // where this chunk leaves the sweep: past its last string, unless that string still has copies to make
-      const Ent last = cand[n_c - 1];
-      const int64_t last_total = sample_num + (((sv + last.line) % interval == 0) ? 1 : 0);
-      const int64_t last_done = (last.line == carry_line ? carry_done : 0) + last.num;
-      const bool last_unfinished = last_done < last_total;
-      const int64_t n_lines = (int64_t)h_len.size(), n_lw = (int64_t)h_vbase.size() - 1, V = (int64_t)h_cap.size();
-      if (res + n_tasks > 0xfffffff0LL) return fail("read index exceeds 32 bits");
-      // ---- device state of the batch
-      HIP_OK(sl.d_flags.ensure(sizeof(DeviceFlags)));
-      HIP_OK(sl.d_len.ensure(n_tasks * 4));
-      HIP_OK(sl.d_off.ensure(n_tasks * 4));
-      HIP_OK(sl.d_task_of_slot.ensure(V * 64 * 4));
-      HIP_OK(sl.d_slot_of_task.ensure(n_tasks * 4));
-      HIP_OK(sl.d_wave_cap.ensure(V * 4));
-      HIP_OK(sl.d_wave_off.ensure(V * 8));
-      HIP_OK(sl.d_out_len.ensure(n_tasks * 4));
-      HIP_OK(sl.d_maf_len.ensure(n_tasks * 4));
-      HIP_OK(sl.d_nsub.ensure(n_tasks * 4));
-      HIP_OK(sl.d_nins.ensure(n_tasks * 4));
-      HIP_OK(sl.d_ndel.ensure(n_tasks * 4));
-      HIP_OK(sl.d_qsum.ensure(n_tasks * 8));
-      HIP_OK(sl.d_cum.ensure((n_tasks + 1) * 8));
-      HIP_OK(sl.d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
-      HIP_OK(sl.d_scratch.ensure((size_t)c->scratch_budget + kScratchSlack, true));
-      HIP_OK(c->d_sq_line_len.ensure(n_lines * 4));
-      HIP_OK(c->d_sq_line_qoff.ensure(n_lines * 8));
-      HIP_OK(c->d_sq_vbase.ensure((n_lw + 1) * 4));
-      DeviceFlags f0;
-      memset(&f0, 0, sizeof f0);
-      f0.total_slots = V * 64;
-      f0.n_final = n_tasks;
-      HIP_OK(hipMemcpyAsync(sl.d_flags.p, &f0, sizeof f0, hipMemcpyHostToDevice, sl.stream));
-      HIP_OK(hipMemcpyAsync(c->d_sq_line_len.p, h_len.data(), n_lines * 4, hipMemcpyHostToDevice, sl.stream));
-      HIP_OK(hipMemcpyAsync(c->d_sq_line_qoff.p, h_qoff.data(), n_lines * 8, hipMemcpyHostToDevice, sl.stream));
-      HIP_OK(hipMemcpyAsync(c->d_sq_vbase.p, h_vbase.data(), (n_lw + 1) * 4, hipMemcpyHostToDevice, sl.stream));
-      HIP_OK(hipMemcpyAsync(sl.d_task_of_slot.p, h_tos.data(), V * 64 * 4, hipMemcpyHostToDevice, sl.stream));
-      HIP_OK(hipMemcpyAsync(sl.d_slot_of_task.p, h_sot.data(), n_tasks * 4, hipMemcpyHostToDevice, sl.stream));
-      HIP_OK(hipMemcpyAsync(sl.d_wave_cap.p, h_cap.data(), V * 4, hipMemcpyHostToDevice, sl.stream));
-      HIP_OK(hipMemcpyAsync(sl.d_wave_off.p, h_woff.data(), V * 8, hipMemcpyHostToDevice, sl.stream));
-      DeviceFlags *flags = sl.d_flags.as<DeviceFlags>();
-      SampleArgs a;
-      memset(&a, 0, sizeof a);
-      a.seed = c->p.seed;
-      a.unit = (uint32_t)c->unit;
-      a.first_read = res + 1;
-      a.n_lines = (int32_t)n_lines;
-      a.n_line_waves = (int32_t)n_lw;
-      a.ref.seq = c->d_seq;
-      a.ref.hp = c->d_hp.as<uint8_t>();
-      a.ref.len = G;
-      a.quals = c->d_sq.as<uint8_t>();
-      a.line_qoff = c->d_sq_line_qoff.as<int64_t>();
-      a.line_len = c->d_sq_line_len.as<int32_t>();
-      a.vbase = c->d_sq_vbase.as<int32_t>();
-      a.task_of_slot = sl.d_task_of_slot.as<int32_t>();
-      a.wave_cap = sl.d_wave_cap.as<int32_t>();
-      a.wave_off = sl.d_wave_off.as<int64_t>();
-      a.scratch = sl.d_scratch.as<uint8_t>();
-      a.span = sl.d_len.as<int32_t>();
-      a.off = sl.d_off.as<int32_t>();
-      a.out_len = sl.d_out_len.as<int32_t>();
-      a.maf_len = sl.d_maf_len.as<int32_t>();
-      a.nsub = sl.d_nsub.as<int32_t>();
-      a.nins = sl.d_nins.as<int32_t>();
-      a.ndel = sl.d_ndel.as<int32_t>();
-      a.qsum = sl.d_qsum.as<double>();
-      const uint8_t *t = c->d_qs_tabs_v[c->bias.hp11_seen].as<uint8_t>();
-      a.sub_thre = reinterpret_cast<const uint32_t *>(t);
-      a.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
-      a.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
-      a.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
-      a.flags = flags;
-      launch_walk_sample(a, c->seq_hp_flag, sl.stream);
-      launch_gather_pass0_scan(a.out_len, n_tasks, 1, sl.d_cum.as<int64_t>(), sl.d_scan_tmp.as<int64_t>(),
-                               &flags->sums[0], sl.stream);
-      HIP_OK(hipGetLastError());
-      DeviceFlags f;
-      if (!read_flags(c, &f)) return PBSIM_FAILED;
-      if (f.error & kErrScratchOverflow) return fail("a sampled read produced more MAF columns than its scratch holds");
-      sl.b_first = res + 1;
-      sl.b_n = n_tasks;
-      sl.b_slots_max = V * 64;
-      sl.b_truncated = false;
-      sl.b_enqueued = false;
-      sl.b_walked = true;
-      sl.b_finalized = false;
-      sl.b_pass0 = f.sums[0];
+      const SampleChunks::Ent last = ck.cand[ck.n_c - 1];
+      int64_t last_done = 0;
+      const bool last_unfinished = S.last_unfinished(sv, ck, &last_done);
+      if (!S.launch(ck, res + 1)) return PBSIM_FAILED;
       pbsim_batch_info bi;
       if (!pbsim_batch_finalize(c, len_total, &bi)) return PBSIM_FAILED;
       if (!deliver(c, sink)) return PBSIM_FAILED;
       len_total = bi.len_total_after;
       res += bi.n_final;
-      if (bi.n_final < n_tasks) done = true;  // the quota was reached inside this chunk (:1735, :1749)
+      if (bi.n_final < ck.n_tasks) done = true;  // the quota was reached inside this chunk (:1735, :1749)
       if (last_unfinished && !done) {
-        carry_line = last.line;
-        carry_done = last_done;
-        HIP_OK(hipMemcpy(&carry_len, sl.d_out_len.as<int32_t>() + (n_tasks - 1), 4, hipMemcpyDeviceToHost));
+        S.carry_line = last.line;
+        S.carry_done = last_done;
+        HIP_OK(hipMemcpy(&S.carry_len, sl.d_out_len.as<int32_t>() + (ck.n_tasks - 1), 4, hipMemcpyDeviceToHost));
         line = last.line;
       } else {
-        carry_line = -1;
-        carry_done = 0;
+        S.carry_line = -1;
+        S.carry_done = 0;
         line = last.line + 1;
       }
     }
-    sample_num = 0;  // :1922
-    carry_line = -1;
+    S.sample_num = 0;  // :1922
+    S.carry_line = -1;
+  }
+  return PBSIM_SUCCEEDED;
+}
+
+// The same record on several ranks (one context per GPU, every rank holds the record and the profile).  The copies of ONE
+// string are a chain (each copy is as long as the read the previous one produced), but strings are independent, and the
+// quota test at a read's start (`len_total < quota`, pbsim.cpp:1749) is the same prefix dependence as the wgs quota rule: a
+// round = W chunks of consecutive strings of one sweep, rank r walks chunk r, and three small all-gathers per round place
+// the quota prefix (A: pass-0 bases), the cut (B: reads made, bases behind them) and every rank's byte range in the
+// record's two streams (C).  Chunks in front of the cut are delivered, the rest of the round is void.  Every number the
+// planner uses is the same on all ranks (the pool size is agreed first), so all ranks plan the same chunks.  A string whose
+// copies do not fit one chunk's pool (the carry-over of the one-GPU driver) is refused here: give the ranks a larger pool.
+int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink) {
+  if (!c) return fail("bad argument");
+  NEED_DEVICE(c);
+  if (!comm || comm->world <= 1) return fail("pbsim_simulate_sample_comm: a communicator of at least two ranks (else pbsim_simulate_sample)");
+  if (!comm->all_gather_i64 || !comm->all_reduce_i64) return fail("pbsim_comm: all_gather_i64 and all_reduce_i64 must be set");
+  const int W = comm->world, rank = comm->rank;
+  int ok = sample_common_checks(c);
+  SampleChunks S;
+  S.c = c;
+  const int64_t quota = ok ? pbsim_unit_quota(c) : 0;
+  if (ok) ok = S.init(quota);
+  {  // every rank is ready, and plans with the same pool
+    std::string keep = g_err;
+    int64_t v[2] = {ok ? 0 : 1, -c->scratch_budget};
+    if (!comm->all_reduce_i64(comm->user, v, 2, PBSIM_OP_MAX)) return fail("pbsim_comm.all_reduce_i64 failed");
+    if (v[0]) return ok ? fail("another rank failed") : fail(keep);
+    c->scratch_budget = -v[1];
+  }
+  pbsim_reset_stats(c);
+  c->st.keep_values = true;
+  c->cur = 0;
+  Slot &sl = c->s();
+  sl.ref = current_ref(c);
+  const int64_t F = S.F;
+  int64_t len_total = 0, res = 0, read_off = 0, maf_off = 0;
+  bool done = false;
+  std::vector<SampleChunks::Chunk> cks((size_t)W);
+  std::string buf_r, buf_m;
+  struct Keep {
+    std::string *r, *m;
+  } keep = {&buf_r, &buf_m};
+  const pbsim_sink collect = {&keep,
+                              [](void *u, const char *t, int64_t k) { ((Keep *)u)->r->append(t, (size_t)k); return 1; },
+                              [](void *u, const char *t, int64_t k) { ((Keep *)u)->m->append(t, (size_t)k); return 1; }};
+  auto gather = [&](const int64_t *send, int n, std::vector<int64_t> *recv) -> int {
+    recv->assign((size_t)W * n, 0);
+    return comm->all_gather_i64(comm->user, send, n, recv->data()) ? PBSIM_SUCCEEDED : fail("pbsim_comm.all_gather_i64 failed");
+  };
+  std::vector<int64_t> A, B, Cs;
+  while (len_total < quota && !done) {
+    const int64_t sv = (int64_t)(header_block(c->p.seed, (uint32_t)c->unit, (uint32_t)(res + 1)).w % (uint32_t)F);  // :1732
+    int64_t line = 0;
+    while (line < F && len_total < quota && !done) {
+      // ---- the round's chunks: the sweep's remaining strings in W equal runs (at most; the pool may cut a run short)
+      const int64_t left = S.count_candidates(sv, line);
+      if (left == 0) break;
+      const size_t per = (size_t)std::min<int64_t>((left + W - 1) / W, (int64_t)1 << 18);
+      int n_chunks = 0;
+      int64_t at = line, first = res + 1, my_first = 0;
+      int local = PBSIM_SUCCEEDED;
+      std::string local_err;
+      for (int q = 0; q < W && at < F; q++) {
+        SampleChunks::Chunk &ck = cks[(size_t)q];
+        if (!S.plan(sv, at, per, &ck)) {
+          local = PBSIM_FAILED;  // (the same on every rank: the plan depends on nothing local)
+          local_err = g_err;
+          break;
+        }
+        if (ck.cand.empty()) break;
+        int64_t last_done = 0;
+        if (S.last_unfinished(sv, ck, &last_done)) {
+          local = PBSIM_FAILED;
+          local_err = "the copies of one sampled read do not fit a rank's scratch pool: the sharded sampling method needs a larger "
+                      "pool (pbsim_set_scratch_bytes / PBSIM_SCRATCH_MB), or run this profile on one GPU";
+          break;
+        }
+        if (q == rank) my_first = first;
+        first += ck.n_tasks;
+        at = ck.cand[ck.n_c - 1].line + 1;
+        n_chunks++;
+      }
+      if (!local) return fail(local_err);
+      const bool mine = rank < n_chunks;
+      // ---- walk, A: pass-0 bases of every chunk -> the quota prefix
+      int64_t sendA[2] = {0, 0};
+      if (mine) {
+        if (S.launch(cks[(size_t)rank], my_first)) sendA[0] = sl.b_pass0;
+        else sendA[1] = 1, local_err = g_err;
+      }
+      if (!gather(sendA, 2, &A)) return PBSIM_FAILED;
+      int64_t before = len_total, bad = 0;
+      for (int q = 0; q < W; q++) {
+        bad += A[(size_t)q * 2 + 1];
+        if (q < rank) before += A[(size_t)q * 2];
+      }
+      if (bad) return sendA[1] ? fail(local_err) : fail("another rank failed");
+      // ---- the cut inside my chunk, B: reads made and bases behind them -> the first chunk that stops short
+      pbsim_batch_info bi;
+      memset(&bi, 0, sizeof bi);
+      int64_t sendB[3] = {0, before, 0};
+      if (mine) {
+        if (finalize_cut(c, before, &bi)) sendB[0] = bi.n_final, sendB[1] = bi.len_total_after;
+        else sendB[2] = 1, local_err = g_err;
+      }
+      if (!gather(sendB, 3, &B)) return PBSIM_FAILED;
+      bad = 0;
+      for (int q = 0; q < W; q++) bad += B[(size_t)q * 3 + 2];
+      if (bad) return sendB[2] ? fail(local_err) : fail("another rank failed");
+      int cut = -1;
+      for (int q = 0; q < n_chunks && cut < 0; q++)
+        if (B[(size_t)q * 3] < cks[(size_t)q].n_tasks) cut = q;
+      const int last_valid = cut < 0 ? n_chunks - 1 : cut;
+      // ---- text of the valid chunks, C: byte counts -> every rank's range in the record's streams
+      buf_r.clear();
+      buf_m.clear();
+      int64_t sendC[3] = {0, 0, 0};
+      if (mine && rank <= last_valid && bi.n_final > 0) {
+        if (finalize_text(c, &bi) && deliver(c, &collect)) sendC[0] = (int64_t)buf_r.size(), sendC[1] = (int64_t)buf_m.size();
+        else sendC[2] = 1, local_err = g_err;
+      }
+      if (!gather(sendC, 3, &Cs)) return PBSIM_FAILED;
+      bad = 0;
+      int64_t r_at = read_off, m_at = maf_off;
+      for (int q = 0; q < W; q++) {
+        bad += Cs[(size_t)q * 3 + 2];
+        if (q < rank) r_at += Cs[(size_t)q * 3], m_at += Cs[(size_t)q * 3 + 1];
+        read_off += Cs[(size_t)q * 3];
+        maf_off += Cs[(size_t)q * 3 + 1];
+      }
+      if (bad) return sendC[2] ? fail(local_err) : fail("another rank failed");
+      if (sink && sink->on_read_text && !buf_r.empty() && !sink->on_read_text(sink->user, c->unit, buf_r.data(), (int64_t)buf_r.size(), r_at))
+        return fail("sink aborted (read text)");
+      if (sink && sink->on_maf_text && !buf_m.empty() && !sink->on_maf_text(sink->user, c->unit, buf_m.data(), (int64_t)buf_m.size(), m_at))
+        return fail("sink aborted (MAF text)");
+      // ---- the record's state, identical on every rank
+      for (int q = 0; q <= last_valid; q++) res += B[(size_t)q * 3];
+      len_total = B[(size_t)last_valid * 3 + 1];
+      if (cut >= 0) done = true;  // the quota was reached inside this round (:1735, :1749)
+      line = cks[(size_t)last_valid].cand[cks[(size_t)last_valid].n_c - 1].line + 1;
+    }
+    S.sample_num = 0;  // :1922
+  }
+  int64_t extra[2] = {0, 0};
+  if (!stats_merge(&c->st, c->p, comm, extra, 0)) return PBSIM_FAILED;
+  c->st.keep_values = false;
+  if (sink && sink->on_record_done) {
+    pbsim_stats st;
+    stats_finish(c->st, c->p, c->ref_len, &st);
+    if (!sink->on_record_done(sink->user, c->unit, &st, read_off, maf_off)) return fail("sink aborted (record done)");
   }
   return PBSIM_SUCCEEDED;
 }

@@ -818,12 +818,6 @@ static int job_add(pbsim_ctx *c, const void *seq, int64_t len, hipMemcpyKind kin
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));  // the caller may reuse (or free) its buffer; the preparation stays asynchronous
   HIP_OK(hipMemsetAsync(r->seq.as<uint8_t>() + len, 0, 64, c->prefetch_stream));
   if (!prepare_enqueue(c, r->seq.as<uint8_t>(), r->hp, r->tiles, r->flags, len, c->prefetch_stream)) return PBSIM_FAILED;
-  if (getenv("PBSIM_PACKED_REF") && atoi(getenv("PBSIM_PACKED_REF")) && c->p.method == PBSIM_METHOD_ERR && c->p.hp_del_bias == 1) {
-    // EXPERIMENT: a 4-bit copy of the prepared record for the lane walker
-    HIP_OK(r->packed.ensure((size_t)((len + 15) / 16 + 2) * 8, true));
-    launch_pack_ref(r->seq.as<uint8_t>(), len, r->packed.as<uint64_t>(), r->flags.as<DeviceFlags>(), c->prefetch_stream);
-    HIP_OK(hipGetLastError());
-  }
   c->job_records.push_back(std::move(r));
   return PBSIM_SUCCEEDED;
 }
@@ -986,7 +980,6 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     jr.ref.len = jr.len;
     jr.ref.unit = c->job_first_unit + (int64_t)i;
     jr.ref.hp_flag = c->p.hp_del_bias == 1 && !fl[i].high_bytes;
-    jr.ref.packed = (jr.packed.p && jr.ref.hp_flag && !(fl[i].error & kErrPackedBad)) ? jr.packed.as<uint64_t>() : nullptr;
     jr.ref.hp11 = seen11;
     Rec &R = J.recs[i];
     R.ref = jr.ref;

@@ -45,9 +45,7 @@ struct RefView {
   const uint8_t *seq;  // upper-cased, padded to a multiple of 16 bytes; bit 7 = hp == 11 when the unit was prepared with flag_hp11
   const uint8_t *hp;   // homopolymer length per base, 1..11
   int64_t len;
-  const uint64_t *packed;  // EXPERIMENT: 16 bases per qword, nibble = code (A C G T N = 0..4) | hp == 11 << 3; NULL: none
 };
-constexpr uint32_t kErrPackedBad = 1u << 8;  // k_pack_ref: the record holds a byte other than A C G T N (it keeps its byte form)
 
 
 struct HeaderArgs {
@@ -190,11 +188,8 @@ void launch_header_wgs(const HeaderArgs &a, hipStream_t s);
 void launch_header_trans(const HeaderArgs &a, hipStream_t s);
 void launch_task_sort(const SortArgs &a, hipStream_t s);
 // min_lds_kb: LDS to ask for at least, i.e. a cap on the walk's workgroups per CU (kernels.hip walk_lds)
-// EXPERIMENT: prepared sequence bytes (upper case, bit 7 = hp == 11) -> 4-bit codes, 16 per qword; flags->error |= kErrPackedBad
-// when a byte is not one of A C G T N
-void launch_pack_ref(const uint8_t *seq, int64_t len, uint64_t *packed, DeviceFlags *flags, hipStream_t s);
 void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                        hipStream_t s, int min_lds_kb, bool packed = false /* EXPERIMENT: read a.ref.packed (fast_rv && hp_bits only) */);
+                        hipStream_t s, int min_lds_kb);
 // the long reads of the batch (WalkArgs::coop_min_len), one wave per read; `n_wg` persistent workgroups; `lds_bytes` = the
 // lane walk's (class blob + byte tables), the waves' own areas are added here.  Classes of at most kCoopMaxStates states.
 constexpr int kCoopMaxStates = 31;

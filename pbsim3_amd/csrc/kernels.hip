@@ -705,82 +705,6 @@ struct RefCursor {
   }
 };
 
-// EXPERIMENT ("packed reference"): the same window over 4-bit codes, 16 bases per qword -- half the
-// gathered bytes and half the refills, one 64-bit shift + mask per column instead of one v_perm_b32.
-struct RefCursorPacked {
-  const uint64_t *lane_w;
-  int64_t p_first;
-  uint32_t pl0, pl0s, smask, cur_wl;
-  int wstep, rel;
-  uint64_t wseq, nseq;
-  bool minus, need_next;
-  __device__ __forceinline__ void init(const WalkArgs &a, int64_t off, int L, bool minus_, bool act) {
-    minus = minus_;
-    p_first = minus ? (off + L - 1) : off;
-    pl0 = (uint32_t)p_first;
-    smask = minus ? 0xffffffffu : 0u;
-    pl0s = pl0 - smask;
-    wstep = minus ? -1 : 1;
-    lane_w = a.ref.packed + (p_first >> 4);
-    rel = 0;
-    cur_wl = pl0 >> 4;
-    wseq = nseq = 0;
-    need_next = false;
-    if (act) {
-      wseq = lane_w[0];
-      const int nrel = ((p_first >> 4) + wstep < 0) ? 0 : wstep;
-      nseq = lane_w[nrel];
-    }
-  }
-  // raw = the nibble: code | hp == 11 << 3
-  __device__ __forceinline__ void at(int ro, bool act, uint32_t *raw, uint32_t *hp) {
-    const uint32_t pl = ((uint32_t)ro ^ smask) + pl0s;
-    const bool cross = act && ((pl >> 4) != cur_wl);
-    wseq = cross ? nseq : wseq;
-    cur_wl = cross ? (pl >> 4) : cur_wl;
-    need_next = need_next || cross;
-    *raw = (uint32_t)(wseq >> ((pl & 15u) << 2)) & 15u;
-    *hp = (*raw & 8u) ? 11u : 1u;
-  }
-  __device__ __forceinline__ void refill(bool act) {
-    rel = (int)cur_wl - (int)(pl0 >> 4);
-    if (need_next && act) {
-      const int nrel = ((p_first >> 4) + rel + wstep < 0) ? rel : rel + wstep;
-      nseq = lane_w[nrel];
-      need_next = false;
-    }
-  }
-};
-template <bool kHpBits, bool kPacked>
-struct CursorOf {
-  typedef RefCursor<kHpBits> type;
-};
-template <bool kHpBits>
-struct CursorOf<kHpBits, true> {
-  typedef RefCursorPacked type;
-};
-
-// 16 prepared sequence bytes -> one qword of codes (EXPERIMENT)
-__global__ __launch_bounds__(256) void k_pack_ref(const uint8_t *__restrict__ seq, int64_t len, uint64_t *__restrict__ packed,
-                                                  DeviceFlags *flags) {
-  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t n_words = (len + 15) / 16 + 2;
-  if (w >= n_words) return;
-  uint64_t out = 0;
-  bool bad = false;
-  for (int k = 0; k < 16; k++) {
-    const int64_t i = w * 16 + k;
-    uint32_t b = i < len ? seq[i] : (uint32_t)'N';
-    const uint32_t flag = (b >> 4) & 8u;
-    b &= 0x7fu;
-    uint32_t code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
-    bad |= (code == 4u && b != 'N');
-    out |= (uint64_t)(code | flag) << (4 * k);
-  }
-  packed[w] = out;
-  if (bad) atomicOr(&flags->error, kErrPackedBad);
-}
-
 // stages the accuracy class blob of this workgroup and the two byte LUTs behind it:
 // s_comp[0..255] identity, [256..511] revcomp's base map; s_sub[c*4+k] = substitution k
 // of base c (pbsim.cpp:5481-5484), 0 for a non-ACGT base
@@ -826,7 +750,7 @@ struct StepOut {
 // accuracy classes, non-ACGT substitutions), and the look-ahead refill.
 // kHpBits: --hp-del-bias 1 (default): the deletion threshold depends on hp only through
 // hp == 11 (Q1), so the walk reads the 1-bit-per-base mask instead of the hp byte array.
-template <bool kFastRv, bool kHpBits, bool kPacked = false>
+template <bool kFastRv, bool kHpBits>
 __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -838,15 +762,6 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   uint8_t *s_comp = lds + a.stride;
   uint8_t *s_sub = s_comp + 512;
   stage_class(a, cls, lds, s_comp, s_sub, tid, kHpBits);
-  if (kPacked) {  // the byte LUT's first 16 entries map a nibble (code | flag << 3) to its base resp. its complement
-    __syncthreads();
-    if (tid < 16) {
-      const uint32_t code = tid & 7u;
-      const uint32_t b = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : 'N';
-      s_comp[tid] = (uint8_t)b;
-      s_comp[256 + tid] = (uint8_t)complement(b);
-    }
-  }
   __syncthreads();
   const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
   const uint32_t init_rv = hdr[1], mode = hdr[2], rate_mag = hdr[3];
@@ -887,7 +802,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   const WalkLane plane = walk_lane(a.seed, read_idx, pass, 0u);
 
   const uint32_t comp_off = minus ? 256u : 0u;
-  typename CursorOf<kHpBits, kPacked>::type cur;
+  RefCursor<kHpBits> cur;
   cur.init(a, off, L, minus, act);
 
   while (__any(act)) {
@@ -929,8 +844,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
         // `z % emis_rv` is a multiply-high with the state's magic number (host_tables.cpp emission_magic).  The row's
         // last dword holds the deletion thresholds of hp != 11 | hp == 11: one 16-byte read serves the whole step.
         const uint4 em = *reinterpret_cast<const uint4 *>(lds + a.emis_off + state * 16u);
-        const uint32_t thr = kHpBits ? __builtin_amdgcn_ubfe(em.w, kPacked ? (raw << 1) & 16u : (raw >> 3) & 16u, 16u)
-                                     : row[4 + (hp < 12u ? hp : 11u)];
+        const uint32_t thr = kHpBits ? __builtin_amdgcn_ubfe(em.w, (raw >> 3) & 16u, 16u) : row[4 + (hp < 12u ? hp : 11u)];
         const bool del = (mod1000(w.y) + 1u) <= thr;
         const uint32_t quo = __umulhi(w.z, em.x) >> (em.y & 0xffffu);
         const uint32_t rem = (w.z - __umul24(quo, em.y >> 16)) & 0xffffffu;  // rem < d <= 1000: 24 bits of the difference
@@ -2464,17 +2378,11 @@ static uint32_t walk_lds(uint32_t lds_bytes, int min_lds_kb) {
   return lds_bytes > pad ? lds_bytes : pad;
 }
 
-void launch_pack_ref(const uint8_t *seq, int64_t len, uint64_t *packed, DeviceFlags *flags, hipStream_t s) {
-  const int64_t n_words = (len + 15) / 16 + 2;
-  hipLaunchKernelGGL(k_pack_ref, dim3(blocks_for(n_words, 256)), dim3(256), 0, s, seq, len, packed, flags);
-}
-
 void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                        hipStream_t s, int min_lds_kb, bool packed) {
+                        hipStream_t s, int min_lds_kb) {
   lds_bytes = walk_lds(lds_bytes, min_lds_kb);
   const dim3 grid((unsigned)(n_slots_max / kWG)), block(kWG);
-  if (fast_rv && hp_bits && packed && a.ref.packed) hipLaunchKernelGGL((k_walk_errhmm<true, true, true>), grid, block, lds_bytes, s, a);
-  else if (fast_rv && hp_bits) hipLaunchKernelGGL((k_walk_errhmm<true, true>), grid, block, lds_bytes, s, a);
+  if (fast_rv && hp_bits) hipLaunchKernelGGL((k_walk_errhmm<true, true>), grid, block, lds_bytes, s, a);
   else if (fast_rv) hipLaunchKernelGGL((k_walk_errhmm<true, false>), grid, block, lds_bytes, s, a);
   else if (hp_bits) hipLaunchKernelGGL((k_walk_errhmm<false, true>), grid, block, lds_bytes, s, a);
   else hipLaunchKernelGGL((k_walk_errhmm<false, false>), grid, block, lds_bytes, s, a);

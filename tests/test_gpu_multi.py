@@ -250,3 +250,48 @@ def test_job_rerun_and_second_genome_on_one_context():
             ctx.job_add_record(gb)
             texts, _ = ctx.job_run()
             assert (bytes(texts[1][0]), bytes(texts[1][1])) == want_b, (method, bias)
+
+
+SAMPLE = sorted(c for c in CASES if c.startswith("wgs_sample"))
+
+
+@pytest.mark.parametrize("case", SAMPLE)
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_sampling_method_sharded_by_string_blocks(case, ranks, tmp_path):
+    """--method sample on several ranks (pbsim_simulate_sample_comm, pbsim.cpp:1694-1949): a round gives rank r the r-th run of
+    a sweep's strings, the quota test at each read's start is placed by the same prefix gathers as the wgs quota rule.  Every
+    file, the stored profile and the stderr report equal what the reference produced for the same command line."""
+    outs = run_devices(CASES[case]["args"], str(tmp_path), ranks, case=CASES[case])
+    check_against_golden(outs, case)
+
+
+def test_sampling_method_sharded_compressed_and_larger(tmp_path):
+    """a profile of 3 000 strings against a 3 Mbp record at depth 12 on 4 ranks, outputs compressed on the GPU: several sweeps,
+    hundreds of strings per rank and round, the cut in the middle of a round; inflated files and report equal the oracle's."""
+    import random
+    import numpy as np
+    r = random.Random(77)
+    fq = tmp_path / "prof.fastq"
+    with open(fq, "w") as f:
+        for i in range(3000):
+            n = min(30000, max(120, int(r.gammavariate(1.6, 2500))))
+            q = "".join(chr(33 + min(60, max(2, int(r.gauss(14, 6))))) for _ in range(n))
+            f.write("@p%d\n%s\n+\n%s\n" % (i, "A" * n, q))
+    rng = np.random.default_rng(5)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 3_000_000)]
+    fa = tmp_path / "g.fa"
+    with open(fa, "wb") as f:
+        f.write(b">chr1\n")
+        lines = seq.reshape(-1, 60)
+        f.write(np.concatenate([lines, np.full((lines.shape[0], 1), 10, np.uint8)], axis=1).tobytes())
+    args = ["--strategy", "wgs", "--method", "sample", "--sample", str(fq), "--genome", str(fa), "--depth", "12", "--seed", "19"]
+    od = tmp_path / "o"
+    od.mkdir()
+    want = harness.run_oracle(args, "philox", str(od))
+    wd = tmp_path / "w"
+    wd.mkdir()
+    outs = run_devices(args, str(wd), 4, extra=())
+    assert sorted(outs) == sorted(want)
+    for k in outs:
+        got = gzip.decompress(outs[k]) if k.endswith((".fq", ".maf")) else outs[k]
+        assert got == want[k], k
