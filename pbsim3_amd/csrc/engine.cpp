@@ -2040,6 +2040,7 @@ int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim
     return comm->all_gather_i64(comm->user, send, n, recv->data()) ? PBSIM_SUCCEEDED : fail("pbsim_comm.all_gather_i64 failed");
   };
   std::vector<int64_t> A, B, Cs;
+  const bool trace = getenv("PBSIM_TRACE") != nullptr;
   while (len_total < quota && !done) {
     const int64_t sv = (int64_t)(header_block(c->p.seed, (uint32_t)c->unit, (uint32_t)(res + 1)).w % (uint32_t)F);  // :1732
     int64_t line = 0;
@@ -2074,6 +2075,9 @@ int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim
       }
       if (!local) return fail(local_err);
       const bool mine = rank < n_chunks;
+      if (trace)
+        fprintf(stderr, "[pbsim sample r%d] sweep sv=%lld line=%lld left=%lld chunks=%d first=%lld len_total=%lld\n", rank, (long long)sv,
+                (long long)line, (long long)left, n_chunks, (long long)(res + 1), (long long)len_total);
       // ---- walk, A: pass-0 bases of every chunk -> the quota prefix
       int64_t sendA[2] = {0, 0};
       if (mine) {
@@ -2130,6 +2134,9 @@ int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim
       len_total = B[(size_t)last_valid * 3 + 1];
       if (cut >= 0) done = true;  // the quota was reached inside this round (:1735, :1749)
       line = cks[(size_t)last_valid].cand[cks[(size_t)last_valid].n_c - 1].line + 1;
+      if (trace)
+        fprintf(stderr, "[pbsim sample r%d]   round done: cut=%d res=%lld len_total=%lld next line=%lld\n", rank, cut, (long long)res,
+                (long long)len_total, (long long)line);
     }
     S.sample_num = 0;  // :1922
   }

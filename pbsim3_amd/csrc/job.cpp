@@ -1008,7 +1008,8 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     {
       // every slot a round passes through (in flight, pending, with the worker) keeps its scratch rows AND its text until the
       // bytes are delivered: bound the batch so that all of them fit 70 % of what the GPU has left
-      const double text_per_base = P > 1 ? 8.5 : 4.3;                  // FASTQ 2.0 | SAM text ~6.1 (BAM records less), MAF 2.13
+      // FASTQ 2.0 | SAM text ~6.1 | BAM records ~3.6 (bases 0.5, qualities 1, the ip and pw arrays 1 each); MAF 2.2
+      const double text_per_base = P > 1 ? (c->bam_output ? 6.0 : 8.5) : 4.3;
       const double scratch_per_base = (double)regions * 2.0 * 1.12 * 1.08 + 0.1;
       // (rounds in flight + one whose delivery is pending + one with the worker; nothing is held back when the text stays put)
       const bool delivering_text = J.sink && (J.sink->on_read_text || J.sink->on_maf_text);

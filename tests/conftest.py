@@ -20,3 +20,16 @@ except ImportError:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """A test that waits for ever (ranks of a job that fell out of step, a kernel that spins) must fail, not hold the GPU box
+    until the caller's limit: every test gets a ceiling (pytest-timeout; signal method, so a hanging subprocess.run is
+    interrupted and its child killed)."""
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for it in items:
+        if not any(m.name == "timeout" for m in it.iter_markers()):
+            it.add_marker(pytest.mark.timeout(300))
