@@ -1072,12 +1072,13 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   } else if (!ready) {
     return PBSIM_FAILED;
   }
-  const int keep_lds = c->walk_lds_kb;
-  c->walk_lds_kb = 41;  // three walk workgroups per CU: the round loop waits on many short kernels (kernels.hip walk_lds)
+  // (Round 2 ran the job's walks at three workgroups per CU -- 41 KB of LDS asked for -- because the round loop then waited on
+  // many short kernels queued behind walk workgroups.  Since the loop no longer waits for text emission and statistics that
+  // costs more than it gives: same-box A/B in round 3, whole job in HBM 180 -> 193 Gbases/s (ERRHMM) and 161 -> 172 G subread
+  // bases/s (QSHMM x10) at the batch primitives' five per CU, delivered job unchanged -- profiles/r03_occupancy_ab.txt.)
   c->defer_text_sync = true;  // the round loop does not wait for a round's text emission; the delivery thread does
   int ok = J.run();
   c->defer_text_sync = false;
-  c->walk_lds_kb = keep_lds;
   for (Slot &sl : c->slots)  // text left in HBM (no sink): its emission ends with the job
     if (sl.stream && hipStreamSynchronize(sl.stream) != hipSuccess && ok) ok = fail("hipStreamSynchronize failed at the end of the job");
   if (!ok) {
