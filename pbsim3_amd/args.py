@@ -1,5 +1,7 @@
-"""pbsim command line -> pbsim_params (the Python mirror of set_sim_param, pbsim.cpp:1451-1688,
-used by the multi-GPU front-end and by the tests; the single-GPU front-end is csrc/cli.cpp)."""
+"""pbsim command line -> pbsim_params: a TEST-SIDE mirror of the option table (tests/product.py drives the C ABI from a
+command line with it).  It maps options to fields and nothing more -- the validation of set_sim_param (pbsim.cpp:1451-1688)
+lives in csrc/cli.cpp (pbsim_cli_main), which every front-end of the product goes through (the `pbsim` binary,
+pbsim3_amd.run_multi)."""
 from . import default_params
 
 

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kThreads) void k_deflate_build(const uint32_t *__re
 // ---------------------------------------------------------------------------------------------------------------------
 struct DfCtl {               // device memory, zeroed by launch_deflate in front of every launch
   uint32_t ticket;
-  uint32_t pad;
+  uint32_t error;            // 1: a look-back gave up waiting (never seen; every spin is bounded all the same)
   int64_t total;             // bytes of the launch's members (written by the workgroup of the last chunk)
 };
 static_assert(sizeof(DfCtl) == DF_CTL_BYTES, "DF_CTL_BYTES");
@@ -454,10 +454,16 @@ constexpr uint64_t kStSize = 1ull << 32, kStPrefix = 2ull << 32;
 __device__ __forceinline__ uint64_t st_word(uint32_t epoch, uint64_t flag, uint32_t v) { return ((uint64_t)epoch << 34) | flag | v; }
 
 // exclusive prefix of chunk c (> 0) from the status words in front of it; called by the 64 lanes of one wave
-__device__ __forceinline__ uint32_t look_back(const uint64_t *status, int64_t c, uint32_t epoch, int lane) {
+__device__ __forceinline__ uint32_t look_back(const uint64_t *status, int64_t c, uint32_t epoch, int lane, uint32_t *error) {
   uint32_t sum = 0;
   int64_t hi = c - 1;  // the window is chunks hi, hi - 1, ..., hi - 63
-  for (;;) {
+  // (a workgroup only waits for workgroups that drew their tickets before it, and those need nothing from it; the bound is
+  // for the case that can not happen -- a kernel that spins for ever takes the GPU with it)
+  for (uint32_t spins = 0;; spins++) {
+    if (spins > (1u << 24)) {  // ~2 s of s_sleep
+      if (lane == 0) atomicOr(error, 1u);
+      return sum;
+    }
     const int64_t i = hi - lane;
     uint64_t w = 0;
     if (i >= 0) w = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
     }
     // where the member goes: the first wave looks back while the others finish their bits
     if (tid < 64 && chunk > 0) {
-      const uint32_t excl = look_back(status, chunk, epoch, tid);
+      const uint32_t excl = look_back(status, chunk, epoch, tid, &ctl->error);
       if (tid == 0) {
         s_misc[1] = excl;
         __hip_atomic_store(&status[chunk], st_word(epoch, kStPrefix, excl + member), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(kThreads) void k_deflate_chunks(const uint8_t *__re
   } else {
     // stored block (RFC 1951 3.2.4): incompressible input, rare for this text
     if (tid < 64 && chunk > 0) {
-      const uint32_t excl = look_back(status, chunk, epoch, tid);
+      const uint32_t excl = look_back(status, chunk, epoch, tid, &ctl->error);
       if (tid == 0) {
         s_misc[1] = excl;
         __hip_atomic_store(&status[chunk], st_word(epoch, kStPrefix, excl + member), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

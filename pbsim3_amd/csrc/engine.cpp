@@ -1078,7 +1078,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     return e ? atoi(e) != 0 : false;
   }();
   const bool direct = direct_default && !place;
-  HIP_OK(sl.h_df_total.ensure(8 * kDfBuffers));
+  HIP_OK(sl.h_df_total.ensure(DF_CTL_BYTES * kDfBuffers));
   HIP_OK(sl.d_df_code.ensure(DF_TABLE_BYTES + 288 * 4));
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
   int lane_index = 0;
@@ -1131,7 +1131,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     launch_deflate(d_text + off, len, sl.d_df_status.as<uint64_t>(), sl.d_df_ctl.p, ++sl.epoch, dense, tab, tab + 1024,
                    sl.d_df_code.p, sl.stream, d_prof, sl.ev_k0[b], sl.ev_k1[b]);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(&h_total[b], sl.d_df_ctl.as<uint8_t>() + 8, 8, hipMemcpyDeviceToHost, sl.stream));
+    HIP_OK(hipMemcpyAsync(&h_total[2 * b], sl.d_df_ctl.p, DF_CTL_BYTES, hipMemcpyDeviceToHost, sl.stream));  // ticket | error, total
     HIP_OK(hipEventRecord(sl.ev_df[b], sl.stream));
     return PBSIM_SUCCEEDED;
   };
@@ -1145,7 +1145,8 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     const double t0 = now();
     HIP_OK(hipEventSynchronize(sl.ev_df[b]));
     t_kernel += now() - t0;
-    const int64_t total = h_total[b];
+    const int64_t total = h_total[2 * b + 1];
+    if ((uint64_t)h_total[2 * b] >> 32) return fail("deflate: a workgroup's look-back gave up waiting for its predecessors");
     out_bytes += total;
     {
       float ms = 0;

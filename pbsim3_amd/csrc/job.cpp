@@ -997,6 +997,7 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   double target = (double)max_quota * P / ((double)rounds_per_record * W);
   target = std::max(target, std::min(kMinBatchBases, (double)max_quota * P / W));
   if (J.sink && (J.sink->on_read_text || J.sink->on_maf_text)) target = std::min(target, kSinkBatchBases);
+  double text_budget = 0;  // text bytes a slot is expected to hold
   if (c->scratch_auto) {
     size_t free_b = 0, total_b = 0;
     HIP_OK(hipMemGetInfo(&free_b, &total_b));
@@ -1007,16 +1008,18 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     }
     {
       // every slot a round passes through (in flight, pending, with the worker) keeps its scratch rows AND its text until the
-      // bytes are delivered: bound the batch so that all of them fit 70 % of what the GPU has left
-      // FASTQ 2.0 | SAM text ~6.1 | BAM records ~3.6 (bases 0.5, qualities 1, the ip and pw arrays 1 each); MAF 2.2
-      const double text_per_base = P > 1 ? (c->bam_output ? 6.0 : 8.5) : 4.3;
+      // bytes are delivered: bound the batch so that all of them fit 75 % of what the GPU has left
+      // FASTQ 2.0 | SAM text ~6.1 | BAM records ~3.5 (bases 0.5, qualities 1, the ip and pw arrays 1 each); MAF 2.23; the text
+      // buffers are grown with 12.5 % of slack (DevBuf::ensure)
+      const double text_per_base = 1.125 * (P > 1 ? (c->bam_output ? 5.8 : 8.4) : 4.25);
       const double scratch_per_base = (double)regions * 2.0 * 1.12 * 1.08 + 0.1;
       // (rounds in flight + one whose delivery is pending + one with the worker; nothing is held back when the text stays put)
       const bool delivering_text = J.sink && (J.sink->on_read_text || J.sink->on_maf_text);
       const double slots_used = (double)J.depth + (delivering_text ? 2.0 : 1.0);
       const char *ff = getenv("PBSIM_JOB_FIT");  // experiment knob: share of the free HBM the slots may take
-      const double fit = (ff ? atof(ff) : 0.70) * (double)(free_b + held + held_text) / (slots_used * (text_per_base + scratch_per_base));
+      const double fit = (ff ? atof(ff) : 0.75) * (double)(free_b + held + held_text) / (slots_used * (text_per_base + scratch_per_base));
       target = std::min(target, std::max(fit, 1.0e8));
+      text_budget = text_per_base * target;
     }
     // what batch_capacity_for() charges a read: `regions` rows of 2 * length + pad columns, 12 % slack for the per-wave rounding
     const double mean_len = std::max(1.0, c->hdr.mean_len);
@@ -1025,6 +1028,17 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     const double share = std::min(48.0 * (1LL << 30), 0.14 * (double)(free_b + held));
     const int64_t auto_b = (int64_t)std::max(256.0 * (1 << 20), std::min(want, share));
     if (auto_b > c->scratch_budget || c->scratch_budget > 2 * auto_b) c->scratch_budget = auto_b;
+    // `fit` counts what the slots already hold as theirs to re-use, but a buffer only ever grows: a context that ran a job
+    // with larger batches (the same records delivered through a sink, then with the text left in HBM: other slot counts, other
+    // batch sizes) would keep the larger buffers AND allocate the new slots' -- give back what is much larger than this job's
+    // batches need (everything is idle here; the next round re-allocates at the right size)
+    for (Slot &sl : c->slots) {
+      if ((double)sl.d_scratch.bytes > 1.25 * ((double)c->scratch_budget + (double)kScratchSlack)) sl.d_scratch.release();
+      if ((double)(sl.d_read_text.bytes + sl.d_maf_text.bytes) > 1.25 * text_budget + (32 << 20)) {
+        sl.d_read_text.release();
+        sl.d_maf_text.release();
+      }
+    }
   }
   if (const char *tr = getenv("PBSIM_JOB_TARGET_RANKS")) {  // test hook: a batch target per rank, "a,b,c" (ranks that see
     std::vector<double> v;                                 // different free memory size their rounds from different numbers)
