@@ -508,6 +508,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        ctx.release_pools()                 # another kind of job on this context: other slot counts and batch sizes
         t1 = time.perf_counter()
         run_job(False)                      # untimed: this mode sizes its batches (and pools) differently
         torch.cuda.synchronize()

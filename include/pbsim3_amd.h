@@ -230,6 +230,10 @@ int64_t pbsim_unit_quota(pbsim_ctx *ctx);
 int64_t pbsim_batch_capacity(pbsim_ctx *ctx);
 /* scratch pool per slot in bytes (default: PBSIM_SCRATCH_MB env or 8 GiB) */
 int pbsim_set_scratch_bytes(pbsim_ctx *ctx, int64_t bytes);
+/* A context sizes its pools for the jobs it runs and keeps them (re-allocating tens of GB stalls a job for seconds): one that
+ * switches to another KIND of job -- output delivered through a sink, then left in HBM; another pass count -- should give the
+ * old pools back first.  Releases the slots' scratch pools, text and compression buffers; nothing may be in flight. */
+int pbsim_release_pools(pbsim_ctx *ctx);
 
 /* ---- the whole job on one or several GPUs -------------------------------------
  * main() runs its records one after the other (pbsim.cpp:667-759).  Here ALL records of the genome are made resident in

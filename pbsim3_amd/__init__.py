@@ -144,6 +144,7 @@ API = [
     ("pbsim_unit_quota", C.c_int64, [C.c_void_p]),
     ("pbsim_batch_capacity", C.c_int64, [C.c_void_p]),
     ("pbsim_set_scratch_bytes", C.c_int, [C.c_void_p, C.c_int64]),
+    ("pbsim_release_pools", C.c_int, [C.c_void_p]),
     ("pbsim_prof_reset", C.c_int, [C.c_void_p]),
     ("pbsim_prof_get", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     ("pbsim_prof_walk_busy", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
@@ -640,6 +641,9 @@ class Context:
 
     def set_scratch_bytes(self, n):
         _check(self.lib.pbsim_set_scratch_bytes(self.h, n))
+
+    def release_pools(self):
+        _check(self.lib.pbsim_release_pools(self.h))
 
     def prof_reset(self):
         _check(self.lib.pbsim_prof_reset(self.h))

@@ -337,6 +337,27 @@ int pbsim_load_qshmm(pbsim_ctx *c, const char *path) {
   return PBSIM_SUCCEEDED;
 }
 
+// gives the slots' large device buffers (scratch pools, text, deflate staging) back; the next batch re-allocates what it needs
+int pbsim_release_pools(pbsim_ctx *c) {
+  if (!c) return fail("bad argument");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  for (Slot &sl : c->slots) {
+    if (sl.b_enqueued) return fail("pbsim_release_pools: a batch is in flight");
+    if (sl.stream) HIP_OK(hipStreamSynchronize(sl.stream));
+  }
+  HIP_OK(hipDeviceSynchronize());
+  for (Slot &sl : c->slots) {
+    sl.d_scratch.release();
+    sl.d_read_text.release();
+    sl.d_maf_text.release();
+    for (DfLane &L : sl.df)
+      for (DevBuf &b : L.d_df_dense) b.release();
+    sl.b_walked = sl.b_finalized = false;
+  }
+  return PBSIM_SUCCEEDED;
+}
+
 int pbsim_set_scratch_bytes(pbsim_ctx *c, int64_t bytes) {
   if (!c || bytes < (1 << 20)) return fail("pbsim_set_scratch_bytes: bad argument");
   c->scratch_budget = bytes;

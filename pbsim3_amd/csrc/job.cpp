@@ -997,7 +997,6 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   double target = (double)max_quota * P / ((double)rounds_per_record * W);
   target = std::max(target, std::min(kMinBatchBases, (double)max_quota * P / W));
   if (J.sink && (J.sink->on_read_text || J.sink->on_maf_text)) target = std::min(target, kSinkBatchBases);
-  double text_budget = 0;  // text bytes a slot is expected to hold
   if (c->scratch_auto) {
     size_t free_b = 0, total_b = 0;
     HIP_OK(hipMemGetInfo(&free_b, &total_b));
@@ -1019,7 +1018,6 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
       const char *ff = getenv("PBSIM_JOB_FIT");  // experiment knob: share of the free HBM the slots may take
       const double fit = (ff ? atof(ff) : 0.75) * (double)(free_b + held + held_text) / (slots_used * (text_per_base + scratch_per_base));
       target = std::min(target, std::max(fit, 1.0e8));
-      text_budget = text_per_base * target;
     }
     // what batch_capacity_for() charges a read: `regions` rows of 2 * length + pad columns, 12 % slack for the per-wave rounding
     const double mean_len = std::max(1.0, c->hdr.mean_len);
@@ -1027,18 +1025,11 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     const double want = (target / P / mean_len) * P * ((double)regions * (2.0 * mean_len + kScratchPad) * 1.12 + 64.0) * 1.08 + (64 << 20);
     const double share = std::min(48.0 * (1LL << 30), 0.14 * (double)(free_b + held));
     const int64_t auto_b = (int64_t)std::max(256.0 * (1 << 20), std::min(want, share));
-    if (auto_b > c->scratch_budget || c->scratch_budget > 2 * auto_b) c->scratch_budget = auto_b;
-    // `fit` counts what the slots already hold as theirs to re-use, but a buffer only ever grows: a context that ran a job
-    // with larger batches (the same records delivered through a sink, then with the text left in HBM: other slot counts, other
-    // batch sizes) would keep the larger buffers AND allocate the new slots' -- give back what is much larger than this job's
-    // batches need (everything is idle here; the next round re-allocates at the right size)
-    for (Slot &sl : c->slots) {
-      if ((double)sl.d_scratch.bytes > 1.25 * ((double)c->scratch_budget + (double)kScratchSlack)) sl.d_scratch.release();
-      if ((double)(sl.d_read_text.bytes + sl.d_maf_text.bytes) > 1.25 * text_budget + (32 << 20)) {
-        sl.d_read_text.release();
-        sl.d_maf_text.release();
-      }
-    }
+    // (a pool changes size only when it is clearly wrong: what the slots hold moves the free-memory figures from run to run, and
+    // re-allocating every pool of a context stalls the job that does it for seconds; the caps below follow the pool.  A
+    // context that switches between kinds of jobs -- delivered through a sink, then text left in HBM: other slot counts,
+    // other batch sizes -- keeps its larger buffers AND allocates the new slots': pbsim_release_pools() in between)
+    if ((double)auto_b > 1.10 * (double)c->scratch_budget || c->scratch_budget > 2 * auto_b) c->scratch_budget = auto_b;
   }
   if (const char *tr = getenv("PBSIM_JOB_TARGET_RANKS")) {  // test hook: a batch target per rank, "a,b,c" (ranks that see
     std::vector<double> v;                                 // different free memory size their rounds from different numbers)
@@ -1090,9 +1081,15 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   // many short kernels queued behind walk workgroups.  Since the loop no longer waits for text emission and statistics that
   // costs more than it gives: same-box A/B in round 3, whole job in HBM 180 -> 193 Gbases/s (ERRHMM) and 161 -> 172 G subread
   // bases/s (QSHMM x10) at the batch primitives' five per CU, delivered job unchanged -- profiles/r03_occupancy_ab.txt.)
+  // A job that compresses its output keeps three: the deflate workgroups need 35 KB of LDS each, and beside five walk
+  // workgroups per CU they found none -- configs[2], whose walks run most of the time, delivered 26 instead of 32 G subread
+  // bases/s (for configs[1], whose walks take a fifth of the time, it makes no difference either way).
+  const int keep_lds = c->walk_lds_kb;
+  if (J.deflated()) c->walk_lds_kb = std::max(c->walk_lds_kb, 41);
   c->defer_text_sync = true;  // the round loop does not wait for a round's text emission; the delivery thread does
   int ok = J.run();
   c->defer_text_sync = false;
+  c->walk_lds_kb = keep_lds;
   for (Slot &sl : c->slots)  // text left in HBM (no sink): its emission ends with the job
     if (sl.stream && hipStreamSynchronize(sl.stream) != hipSuccess && ok) ok = fail("hipStreamSynchronize failed at the end of the job");
   if (!ok) {
