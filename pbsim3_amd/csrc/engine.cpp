@@ -1087,10 +1087,16 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
                    const std::function<char *(int64_t)> *place = nullptr) {
   if (n <= 0) return PBSIM_SUCCEEDED;
   if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
-  const int64_t piece = (int64_t)DF_PIECE_CHUNKS * DF_CHUNK;
-  const int64_t max_ch = std::min<int64_t>(DF_PIECE_CHUNKS, (n + DF_CHUNK - 1) / DF_CHUNK);
+  // chunks per piece = per launch and per copy (experiment knob PBSIM_DEFLATE_PIECE_CHUNKS; a piece's members stay below 4 GiB)
+  static const int64_t piece_chunks = [] {
+    const char *e = getenv("PBSIM_DEFLATE_PIECE_CHUNKS");
+    const int64_t v = e ? atoll(e) : DF_PIECE_CHUNKS;
+    return std::max<int64_t>(256, std::min<int64_t>(65536, v));
+  }();
+  const int64_t piece = piece_chunks * DF_CHUNK;
+  const int64_t max_ch = std::min<int64_t>(piece_chunks, (n + DF_CHUNK - 1) / DF_CHUNK);
   const int64_t n_pieces = (n + piece - 1) / piece;
-  HIP_OK(sl.d_df_status.ensure((size_t)DF_PIECE_CHUNKS * 8));
+  HIP_OK(sl.d_df_status.ensure((size_t)piece_chunks * 8));
   HIP_OK(sl.d_df_ctl.ensure(DF_CTL_BYTES));
   // Direct mode: the members leave the GPU as the deflate workgroups' own stores into page-locked host memory (no dense
   // buffer in HBM, no copy); needs the lane's own staging as the destination, so not when the caller places the pieces.
