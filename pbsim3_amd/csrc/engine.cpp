@@ -530,7 +530,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
 // reads / 150 k, between 0.5 and 4; small batches (top-up rounds, the truncated tail reads a record's completion waits
 // for) go to the wave walker entirely, and a batch of a million reads hides its longest lane behind its own bulk.
 // A multiple of 256 (the sort's length bucket).  PBSIM_COOP_LEN overrides: -1 never, n >= 0 that length.
-constexpr int kCoopWorkgroups = 1024, kCoopSmallBatch = 20000, kCoopHugeBatch = 1000000;
+constexpr int kCoopWorkgroups = 4096 / kCoopWaves, kCoopSmallBatch = 20000, kCoopHugeBatch = 1000000;  // 4096 persistent waves
 static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads) {
   if (c->p.method != PBSIM_METHOD_ERR || !c->ect.all_rv_1000 || c->ect.smax > kCoopMaxStates) return INT32_MAX;
   const char *env = getenv("PBSIM_COOP_LEN");
@@ -718,7 +718,8 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
       // the long reads first, so that their workgroups are resident before the lane walk fills the CUs; beside a batch
       // on a stream of their own, a lone tail read simply in front of the (then empty) lane walk
       const char *cw = getenv("PBSIM_COOP_WG");  // experiment knob
-      const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(cw && atoi(cw) > 0 ? atoi(cw) : kCoopWorkgroups, (n_tasks + 3) / 4));
+      const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(cw && atoi(cw) > 0 ? atoi(cw) : kCoopWorkgroups,
+                                                                   (n_tasks + kCoopWaves - 1) / kCoopWaves));
       hipStream_t cs = (ws == c->s().walk_stream && c->s().coop_stream) ? c->s().coop_stream : ws;
       if (cs != ws) HIP_OK(hipStreamWaitEvent(cs, c->s().ev_prep, 0));
       launch_walk_errhmm_coop(w, n_wg, c->ect.stride + 512 + 1024, ref.hp_flag, cs);

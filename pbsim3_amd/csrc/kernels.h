@@ -193,6 +193,10 @@ void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byt
 // the long reads of the batch (WalkArgs::coop_min_len), one wave per read; `n_wg` persistent workgroups; `lds_bytes` = the
 // lane walk's (class blob + byte tables), the waves' own areas are added here.  Classes of at most kCoopMaxStates states.
 constexpr int kCoopMaxStates = 31;
+// Waves (= reads in flight) per workgroup of the wave walker; they share one class blob in LDS (24-31 KB).  (Eight per blob --
+// the same waves per CU in half the LDS, so that the lane walker beside it keeps three workgroups per CU instead of one --
+// was tried in round 3: whole job in HBM 187 against 192-194 Gbases/s on other boxes, no gain; profiles/r03_occupancy_ab.txt.)
+constexpr int kCoopWaves = 4;
 void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bool hp_bits, hipStream_t s);
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
                        hipStream_t s, int min_lds_kb);

@@ -709,10 +709,11 @@ struct RefCursor {
 // s_comp[0..255] identity, [256..511] revcomp's base map; s_sub[c*4+k] = substitution k
 // of base c (pbsim.cpp:5481-5484), 0 for a non-ACGT base
 __device__ __forceinline__ void stage_class(const WalkArgs &a, int cls, uint8_t *lds, uint8_t *s_comp, uint8_t *s_sub,
-                                            int tid, bool hp_flag) {
+                                            int tid, bool hp_flag, int n_threads = kWG) {
   const uint4 *src = reinterpret_cast<const uint4 *>(a.cls_blob + (size_t)cls * a.stride);
   uint4 *dst = reinterpret_cast<uint4 *>(lds);
-  for (uint32_t i = tid; i < a.stride / 16; i += kWG) dst[i] = src[i];
+  for (uint32_t i = tid; i < a.stride / 16; i += n_threads) dst[i] = src[i];
+  if (tid >= 256) return;  // the byte LUTs have 256 entries
   const uint32_t c = (uint32_t)tid;
   const uint32_t base = hp_flag ? (c & 0x7fu) : c;  // bit 7 of a sequence byte is the hp == 11 flag, not part of the base
   s_comp[c] = (uint8_t)base;
@@ -1139,7 +1140,7 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
 }
 
 template <bool kHpBits>
-__global__ __launch_bounds__(kWG) void k_walk_errhmm_coop(WalkArgs a) {
+__global__ __launch_bounds__(kCoopWaves * 64) void k_walk_errhmm_coop(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1148,25 +1149,25 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm_coop(WalkArgs a) {
   uint8_t *s_comp = lds + a.stride;
   uint8_t *s_sub = s_comp + 512;
   uint8_t *s_w = s_sub + 1024 + wv * kCoopWaveLds;
-  // units of four tasks (one per wave, one class per workgroup), dealt round-robin to the persistent workgroups
+  // units of kCoopWaves tasks (one per wave, one class per workgroup), dealt round-robin to the persistent workgroups
   int staged = -1, c = 0, ubase = 0;
   for (int u = blockIdx.x;; u += gridDim.x) {
     int nc = 0;
     for (; c < a.ncls; c++) {
       nc = a.coop_end[c] - a.class_start[c];
       nc = nc > 0 ? nc : 0;
-      const int nu = (nc + 3) >> 2;
+      const int nu = (nc + kCoopWaves - 1) / kCoopWaves;
       if (u < ubase + nu) break;
       ubase += nu;
     }
     if (c >= a.ncls) break;
     if (staged != c) {
       __syncthreads();  // the other waves may still read the previous class
-      stage_class(a, c, lds, s_comp, s_sub, tid, kHpBits);
+      stage_class(a, c, lds, s_comp, s_sub, tid, kHpBits, kCoopWaves * 64);
       __syncthreads();
       staged = c;
     }
-    const int k = (u - ubase) * 4 + wv;
+    const int k = (u - ubase) * kCoopWaves + wv;
     const uint32_t mode = reinterpret_cast<const uint32_t *>(lds)[2];
     if (k < nc && mode != kModeVerbatim) coop_walk_task<kHpBits>(a, lds, s_comp, s_sub, s_w, a.class_start[c] + k, lane);
   }
@@ -2389,8 +2390,8 @@ void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byt
 }
 
 void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bool hp_bits, hipStream_t s) {
-  const dim3 grid((unsigned)n_wg), block(kWG);
-  lds_bytes += (kWG / 64) * kCoopWaveLds;
+  const dim3 grid((unsigned)n_wg), block(kCoopWaves * 64);
+  lds_bytes += kCoopWaves * kCoopWaveLds;
   if (hp_bits) hipLaunchKernelGGL((k_walk_errhmm_coop<true>), grid, block, lds_bytes, s, a);
   else hipLaunchKernelGGL((k_walk_errhmm_coop<false>), grid, block, lds_bytes, s, a);
 }
