@@ -366,6 +366,8 @@ int pbsim_prof_get(pbsim_ctx *ctx, double *walk_ms, int64_t *walk_launches, doub
 int pbsim_prof_tail(pbsim_ctx *ctx, double *tail_ms, int64_t *tail_launches);
 /* milliseconds since the reset during which at least one walk kernel ran (the launches of different slots overlap) */
 int pbsim_prof_walk_busy(pbsim_ctx *ctx, double *busy_ms);
+/* launches of a wave walker (one wave per task: k_walk_errhmm_coop / k_walk_qshmm_coop) since the last reset (or creation) */
+int64_t pbsim_prof_wave_launches(pbsim_ctx *ctx);
 /* the two kernels next in line, timed with HIP events on the streams they run on, since the last reset:
  * [0] ms, [1] launches, [2] bytes read (scratch rows), [3] bytes written (text) of the text emission (k_text_*);
  * [4] ms, [5] launches, [6] text bytes in, [7] member bytes out of k_deflate_chunks */

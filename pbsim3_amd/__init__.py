@@ -150,6 +150,7 @@ API = [
     ("pbsim_prof_walk_busy", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_prof_tail", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("pbsim_prof_secondary", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("pbsim_prof_wave_launches", C.c_int64, [C.c_void_p]),
     ("pbsim_stream", C.c_void_p, [C.c_void_p]),
     ("pbsim_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("pbsim_dump_table", C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
@@ -663,6 +664,9 @@ class Context:
         _check(self.lib.pbsim_prof_secondary(self.h, a))
         return dict(text_ms=a[0], text_launches=int(a[1]), text_in=int(a[2]), text_out=int(a[3]),
                     deflate_ms=a[4], deflate_launches=int(a[5]), deflate_in=int(a[6]), deflate_out=int(a[7]))
+
+    def prof_wave_launches(self):
+        return self.lib.pbsim_prof_wave_launches(self.h)
 
     def prof_walk_busy(self):
         a = C.c_double(0)

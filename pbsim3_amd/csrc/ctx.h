@@ -316,6 +316,7 @@ struct pbsim_ctx {
   // profiling
   double prof_walk_ms = 0, prof_total_ms = 0, prof_tail_ms = 0;
   int64_t prof_walk_launches = 0, prof_tail_launches = 0;   // walk launches of batches / of single truncated tail reads
+  int64_t prof_wave_launches = 0;                           // launches of a wave walker (k_walk_errhmm_coop / k_walk_qshmm_coop)
   hipEvent_t ev_prof_base = nullptr;                     // pbsim_prof_reset: time zero of the walk intervals
   std::vector<std::pair<float, float>> prof_intervals;   // [start, end] ms of every walk launch since the reset
   // secondary kernels (pbsim_prof_secondary): text emission and k_deflate_chunks, HIP events on their own streams

@@ -531,11 +531,19 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
 // for) go to the wave walker entirely, and a batch of a million reads hides its longest lane behind its own bulk.
 // A multiple of 256 (the sort's length bucket).  PBSIM_COOP_LEN overrides: -1 never, n >= 0 that length.
 constexpr int kCoopWorkgroups = 4096 / kCoopWaves, kCoopSmallBatch = 20000, kCoopHugeBatch = 1000000;  // 4096 persistent waves
-static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads) {
-  if (c->p.method != PBSIM_METHOD_ERR || !c->ect.all_rv_1000 || c->ect.smax > kCoopMaxStates) return INT32_MAX;
+static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads, bool hp_flag) {
+  const bool qs = c->p.method == PBSIM_METHOD_QS;
+  if (qs) {  // k_walk_qshmm_coop: moduli of 100, the hp == 11 flag in the sequence bytes (default --hp-del-bias), <= 63 states
+    if (!c->qct.all_rv_100 || !hp_flag || c->qct.smax > kQCoopMaxStates) return INT32_MAX;
+  } else if (c->p.method != PBSIM_METHOD_ERR || !c->ect.all_rv_1000 || c->ect.smax > kCoopMaxStates) {
+    return INT32_MAX;
+  }
   const char *env = getenv("PBSIM_COOP_LEN");
   const int64_t n_tasks = n_reads * c->p.pass_num;
   int64_t len = (int64_t)(std::min(4.0, std::max(0.5, (double)n_tasks / 150000.0)) * c->hdr.mean_len);
+  // (QSHMM: the batches of a multi-pass job are large and its job runs at its steady-state regime's rate without -- the wave
+  // walker takes the small batches: truncated tail reads, top-up rounds, the small rounds of many ranks)
+  if (qs) len = -1;
   if (n_tasks <= kCoopSmallBatch) len = 0;
   if (n_tasks >= kCoopHugeBatch) len = -1;
   if (env) len = atoll(env);
@@ -647,14 +655,19 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   s.bin_cursor = c->s().d_bin_cursor.as<int32_t>();
   s.class_start = c->s().d_class_start.as<int32_t>();
   s.coop_end = s.class_start + ncls + 1;
-  const int32_t coop_len = coop_min_len(c, n_reads);
+  const int32_t coop_len = coop_min_len(c, n_reads, ref.hp_flag);
   s.coop_bucket = coop_len == INT32_MAX ? kLenBuckets : coop_len >> kLenShift;
   s.coop_classes = 0;
-  if (coop_len != INT32_MAX)  // verbatim classes (no HMM at all) stay with the lane walker
+  if (coop_len != INT32_MAX)  // verbatim classes (ERRHMM) / classes without a model (QSHMM) stay with the lane walker
     for (int i = 0; i < ncls; i++) {
-      uint32_t mode;
-      memcpy(&mode, c->ect.blob.data() + (size_t)i * c->ect.stride + 8, 4);
-      if (mode != kModeVerbatim) s.coop_classes |= 1ull << i;
+      uint32_t mode;  // hdr[2]: ERRHMM mode | QSHMM has_model
+      if (c->p.method == PBSIM_METHOD_ERR) {
+        memcpy(&mode, c->ect.blob.data() + (size_t)i * c->ect.stride + 8, 4);
+        if (mode != kModeVerbatim) s.coop_classes |= 1ull << i;
+      } else {
+        memcpy(&mode, c->qct.blob.data() + (size_t)i * c->qct.stride + 8, 4);
+        if (mode != 0) s.coop_classes |= 1ull << i;
+      }
     }
   s.task_of_slot = c->s().d_task_of_slot.as<int32_t>();
   s.slot_of_task = c->s().d_slot_of_task.as<int32_t>();
@@ -723,6 +736,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
       hipStream_t cs = (ws == c->s().walk_stream && c->s().coop_stream) ? c->s().coop_stream : ws;
       if (cs != ws) HIP_OK(hipStreamWaitEvent(cs, c->s().ev_prep, 0));
       launch_walk_errhmm_coop(w, n_wg, c->ect.stride + 512 + 1024, ref.hp_flag, cs);
+      c->prof_wave_launches++;
       if (cs != ws) HIP_OK(hipEventRecord(c->s().ev_coop, cs));
       // (every read on the wave walker -- a small batch of a model without verbatim classes, e.g. a truncated tail read --
       // leaves the lane walker nothing to do: no empty launch, and the kernel's profile holds its bulk launches only)
@@ -745,8 +759,25 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     w.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
     w.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     w.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
-    launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8 + 94 * 32, c->qct.all_rv_100,
-                      ref.hp_flag, ws, c->walk_lds_kb);
+    bool lanes_idle = false;
+    if (coop_len != INT32_MAX) {  // the wave walker first, beside a batch on a stream of its own (as for ERRHMM above)
+      const char *cw = getenv("PBSIM_COOP_WG");
+      const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(cw && atoi(cw) > 0 ? atoi(cw) : kCoopWorkgroups, (n_tasks + 3) / 4));
+      hipStream_t cs = (ws == c->s().walk_stream && c->s().coop_stream) ? c->s().coop_stream : ws;
+      if (cs != ws) HIP_OK(hipStreamWaitEvent(cs, c->s().ev_prep, 0));
+      launch_walk_qshmm_coop(w, n_wg, c->qct.stride + 512 + 1024, cs);
+      c->prof_wave_launches++;
+      if (cs != ws) HIP_OK(hipEventRecord(c->s().ev_coop, cs));
+      lanes_idle = coop_len == 0 && s.coop_classes == (ncls >= 64 ? ~0ull : (1ull << ncls) - 1);
+      if (!lanes_idle)
+        launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8 + 94 * 32, c->qct.all_rv_100,
+                          ref.hp_flag, ws, c->walk_lds_kb);
+      if (cs != ws) HIP_OK(hipStreamWaitEvent(ws, c->s().ev_coop, 0));
+    } else {
+      launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8 + 94 * 32, c->qct.all_rv_100,
+                        ref.hp_flag, ws, c->walk_lds_kb);
+    }
+    (void)lanes_idle;
   }
   HIP_OK(hipEventRecord(c->s().ev2, ws));
   HIP_OK(hipStreamWaitEvent(c->s().stream, c->s().ev2, 0));
@@ -2290,7 +2321,7 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
 int pbsim_prof_reset(pbsim_ctx *c) {
   if (!c) return fail("bad argument");
   c->prof_walk_ms = c->prof_total_ms = c->prof_tail_ms = 0;
-  c->prof_walk_launches = c->prof_tail_launches = 0;
+  c->prof_walk_launches = c->prof_tail_launches = c->prof_wave_launches = 0;
   c->prof_intervals.clear();
   {
     std::lock_guard<std::mutex> lk(c->prof_mu);
@@ -2339,6 +2370,7 @@ int pbsim_prof_get(pbsim_ctx *c, double *walk_ms, int64_t *walk_launches, double
   if (total_ms) *total_ms = c->prof_total_ms;
   return PBSIM_SUCCEEDED;
 }
+int64_t pbsim_prof_wave_launches(pbsim_ctx *c) { return c ? c->prof_wave_launches : -1; }
 int pbsim_prof_secondary(pbsim_ctx *c, double out[8]) {
   if (!c || !out) return fail("bad argument");
   if (c->device >= 0) (void)hipSetDevice(c->device);

@@ -589,6 +589,11 @@ bool build_qs_class_tables(const QsModel &m, const HeaderTables &h, const HpBias
         rv[2 * j + 1] = (uint16_t)emis_rv[j];
         if (reach[j] && (tran_rv[j] != 100 || emis_rv[j] != 100)) t->all_rv_100 = false;
       }
+      {  // the highest state the class's expanded tables name (k_walk_qshmm_coop walks every possible start state of a group)
+        uint32_t top = 0;
+        for (uint32_t q = 0; q < 100u * (uint32_t)(smax + 1); q++) top = std::max<uint32_t>(top, dst[t->init_off + q]);
+        hdr[6] = top;
+      }
     } else {
       hdr[2] = 0;
       expand_cdf(

@@ -198,6 +198,10 @@ constexpr int kCoopMaxStates = 31;
 // was tried in round 3: whole job in HBM 187 against 192-194 Gbases/s on other boxes, no gain; profiles/r03_occupancy_ab.txt.)
 constexpr int kCoopWaves = 4;
 void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bool hp_bits, hipStream_t s);
+// the QSHMM wave walker (classes with a model whose moduli are all 100, hp flag in the sequence bytes, <= 63 states);
+// `lds_bytes` = class blob + byte tables, the quality rows and the waves' areas are added here
+constexpr int kQCoopMaxStates = 63;
+void launch_walk_qshmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, hipStream_t s);
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
                        hipStream_t s, int min_lds_kb);
 void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s);

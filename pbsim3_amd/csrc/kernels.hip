@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
     // strand: wgs by parity of the read number (pbsim.cpp:3820-3826, Q9); trans by expression (:4516-4522)
     minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
   }
-  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);  // wave-uniform: keeps row offsets scalar
+  const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]) & ~kWaveTransposed;  // wave-uniform: keeps row offsets scalar
   walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
   const int64_t woff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.wave_off[wave] >> 32)) << 32) |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wave_off[wave]);
@@ -1256,7 +1256,8 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   uint32_t acc_r = 0, acc_f = 0, acc_q = 0;
   int nsub = 0;
   double qsum = 0.0;
-  bool act = valid && L > 0;
+  const bool coop_lane = has_model && L >= a.coop_min_len;  // a long task: k_walk_qshmm_coop walks it
+  bool act = valid && L > 0 && !coop_lane;
   int group = 0;
   const uint32_t comp_off = minus ? 256u : 0u;
   RefCursor<kHpBits> cur;
@@ -1359,7 +1360,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
     acc_q = 0;
     group++;
   }
-  if (valid) {
+  if (valid && !coop_lane) {
     if (ro < L) atomicOr(&a.flags->error, kErrScratchOverflow);
     a.out_len[task] = q;
     a.maf_len[task] = m;
@@ -1367,6 +1368,278 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
     a.nins[task] = m - ro;
     a.ndel[task] = m - q;
     a.qsum[task] = qsum;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2qc: the QSHMM walk for the LONG tasks of a batch (and every task of a small one), one WAVE per task, 64 columns per step
+// (round 3).  Every draw of a column is keyed by the column, as in the ERRHMM wave walker -- but here the state chain is NOT
+// independent of what the columns decide: a deleted column does not advance the state (pbsim.cpp:2268-2281 loops over the
+// reference, the state moves per emitted base), and whether column m is deleted depends on the quality the last emitted
+// column drew, i.e. on the state chain in front of it.  A step therefore iterates to the sequential walk's fixed point:
+//   guess which columns are deleted -> state chain that passes deleted columns through (qcoop_chain: eight groups of eight
+//   columns from every possible start state) -> qualities -> every column's deletion test from the quality of the nearest
+//   emitted column in front of it and the homopolymer flag under its cursor (ballot + popcount give the cursors) -> compare
+//   with the guess, repeat with the outcome.
+// Column p's outcome depends on columns < p only, so each turn extends the correct prefix by at least one column and the
+// fixed point is the sequential answer; in practice two or three turns (95 % of the deletion draws lie above every quality's
+// threshold and ~2 % below every one: a wrong state in front of a column rarely flips it).  The ordered f64 sum of error
+// probabilities (pbsim.cpp:2309-2313; the %f report and the accuracy histogram depend on its exact value) is added lane by
+// lane in column order.  kFastRv && kHpBits classes with a model only; everything else stays with the lane walker.
+// ---------------------------------------------------------------------------
+constexpr int kQCoopX = 0, kQCoopEnd = 128, kQCoopStates = 640, kQCoopRows = 704, kQCoopWaveLds = 896;
+
+// state after each of the 64 columns, given s_in in front of column 0; `delm`: columns that leave the state alone;
+// `init0`: column 0 starts from the initial-state table (row 0 of the transition table) whatever s_in is
+__device__ __forceinline__ uint32_t qcoop_chain(const uint8_t *lds, uint32_t init_off, uint32_t n_chains, uint8_t *s_w, uint32_t x,
+                                                uint64_t delm, bool init0, uint32_t s_in, int lane) {
+  uint16_t *s_x = reinterpret_cast<uint16_t *>(s_w + kQCoopX);
+  uint8_t *s_end = s_w + kQCoopEnd, *s_st = s_w + kQCoopStates;
+  const int g = lane >> 3, j = lane & 7;
+  wave_sync();
+  s_x[lane] = (uint16_t)x;
+  wave_sync();
+  const uint4 xv = *reinterpret_cast<const uint4 *>(s_x + g * 8);
+  const uint32_t xt[8] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16, xv.z & 0xffffu, xv.z >> 16, xv.w & 0xffffu, xv.w >> 16};
+  const uint32_t dg = (uint32_t)(delm >> (g * 8)) & 0xffu;
+  const bool first_init = init0 && g == 0;
+  uint32_t lo[8], hi[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) lo[k] = hi[k] = 0;
+  auto walk_pair = [&](const int k0) {
+    uint32_t st[2] = {(uint32_t)(j + 8 * k0), (uint32_t)(j + 8 * k0 + 8)};
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        uint32_t row = st[k];
+        if (t == 0) row = first_init ? 0u : row;
+        const uint32_t nx = lds[init_off + __umul24(row, 100u) + xt[t]];
+        st[k] = ((dg >> t) & 1u) ? st[k] : nx;
+        if (t < 4) lo[k0 + k] |= st[k] << (8 * t);
+        else hi[k0 + k] |= st[k] << (8 * (t - 4));
+      }
+    }
+    s_end[g * 64 + j + 8 * k0] = (uint8_t)st[0];
+    s_end[g * 64 + j + 8 * k0 + 8] = (uint8_t)st[1];
+  };
+  walk_pair(0);
+  if (n_chains > 2) walk_pair(2);
+  if (n_chains > 4) walk_pair(4);
+  if (n_chains > 6) walk_pair(6);
+  wave_sync();
+  uint32_t s = s_in, sg = 0;
+#pragma unroll
+  for (int gg = 0; gg < 8; gg++) {
+    sg = (g == gg) ? s : sg;
+    s = s_end[gg * 64 + s];
+  }
+  const uint32_t k = sg >> 3;
+  uint32_t plo = lo[0], phi = hi[0];
+#pragma unroll
+  for (int kk = 1; kk < 8; kk++) {
+    plo = (k == (uint32_t)kk) ? lo[kk] : plo;
+    phi = (k == (uint32_t)kk) ? hi[kk] : phi;
+  }
+  if ((uint32_t)j == (sg & 7u)) *reinterpret_cast<uint2 *>(s_st + g * 8) = make_uint2(plo, phi);
+  wave_sync();
+  return s_st[lane];
+}
+
+__device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t *lds, const uint8_t *s_comp, const uint8_t *s_sub,
+                                                const uint32_t *s_row, uint8_t *s_w, int slot, int lane) {
+  const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
+  const uint32_t n_chains = (hdr[6] + 8u) >> 3;  // start states 0 .. reach in chains of eight
+  uint8_t *s_tr = s_w + kQCoopRows;
+  const int task = __builtin_amdgcn_readfirstlane(a.task_of_slot[slot]);
+  if (task < 0) return;
+  const int r = task / a.pass_num;
+  const uint32_t pass = (uint32_t)(task - r * a.pass_num);
+  const uint32_t read_idx = (uint32_t)(a.first_read + r);
+  const int L = __builtin_amdgcn_readfirstlane(a.len[r]);
+  const int64_t off = a.off[r] + (a.read_base ? a.read_base[r] : 0);
+  const bool minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
+  const int64_t wave = slot >> 6;
+  const int cap_raw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);
+  const int cap_dw = cap_raw & ~kWaveTransposed;
+  const bool transposed = (cap_raw & kWaveTransposed) != 0;
+  const size_t row_step = transposed ? 1 : 64;
+  uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + (transposed ? (size_t)(slot & 63) * cap_dw : (size_t)(slot & 63));
+  uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
+  uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;
+  const int cap = 2 * L + kScratchPad;
+  const uint32_t comp_off = minus ? 256u : 0u;
+  const int64_t p_first = minus ? (off + L - 1) : off;
+  const int64_t p_last = a.ref.len - 1;
+  int wb = 0;
+  auto ref_at = [&](int t) -> uint32_t {
+    int64_t p = minus ? (p_first - t) : (p_first + t);
+    p = p < 0 ? 0 : (p > p_last ? p_last : p);
+    return a.ref.seq[p];
+  };
+  uint32_t win_a = ref_at(lane), win_b = ref_at(64 + lane);
+  auto win_at = [&](int wi) -> uint32_t {  // window byte at read offset wb + wi, wi in 0 .. 127
+    const uint32_t va = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)win_a);
+    const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)win_b);
+    return (wi & 64) ? vb : va;
+  };
+
+  int m0 = 0, ro0 = 0, q0 = 0, nsub = 0;
+  uint32_t st_in = 0, lastq_in = 0;
+  uint32_t hpf_in = 0;  // bit 7 of the last consumed reference byte (hp == 11 flag); meaningless while ro0 == 0
+  double qsum = 0.0;
+  bool more = L > 0;
+  while (more) {
+    const uint32_t event = (uint32_t)(m0 + lane);
+    const U4 w = walk_block(a.seed, a.unit, read_idx, pass, event, 0u);
+    const U4 dq = walk_block(a.seed, a.unit, read_idx, pass, event >> 2, 2u);
+    const uint32_t dsel = event & 3u;
+    const uint32_t dw = dsel == 0 ? dq.x : dsel == 1 ? dq.y : dsel == 2 ? dq.z : dq.w;
+    const uint32_t x = mod100(w.x), y = mod100(w.y), z = mod1e6(w.z), d = mod1e6(dw);
+    const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // first guess: every column tested against the thresholds of the quality in front of the window
+    uint64_t delm = __ballot(event > 0u && d < s_row[lastq_in * 8u + 2u]);
+    uint32_t st, qv, raw = 0, roi_u = 0;
+    bool is_sub, is_ins, emitted;
+    uint64_t valid, consm;
+    double qp;
+    for (;;) {
+      st = qcoop_chain(lds, a.init_off, n_chains, s_w, x, delm, q0 == 0, st_in, lane);
+      qv = lds[a.emis_off + __umul24(st - 1u, 100u) + y];
+      qv = (qv < 94u) ? qv : 93u;
+      const uint4 row = *reinterpret_cast<const uint4 *>(&s_row[qv * 8u]);
+      qp = *reinterpret_cast<const double *>(&s_row[qv * 8u + 4u]);
+      emitted = ((delm >> lane) & 1ull) == 0;
+      is_sub = z < row.x;               // pbsim.cpp:2233-2249
+      is_ins = !is_sub && z < row.y;    // pbsim.cpp:2250-2258
+      // the quality in front of this column: the nearest emitted column of the window, else the one carried in
+      const uint64_t em_below = ~delm & below;
+      const int src = em_below ? 63 - __builtin_clzll(em_below) : 0;
+      const uint32_t lq_w = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)qv);
+      const uint32_t lq = em_below ? lq_w : lastq_in;
+      const uint32_t thr_norm = s_row[lq * 8u + 2u], thr_none = s_row[lq * 8u + 3u];
+      // cursors: a column consumes a reference base unless it is an emitted insertion
+      consm = __ballot(!emitted || !is_ins);
+      const int roi = ro0 + (int)mbcnt64(consm);
+      roi_u = (uint32_t)roi;
+      const int wi = roi - wb;  // 0 .. 127 for the columns that count
+      raw = win_at(wi);
+      // hp flag of the last consumed base in front of this column: the window byte at roi - 1, or the one carried in
+      const uint32_t prevb = win_at((wi - 1) & 127);
+      const uint32_t hpf = (roi == ro0) ? hpf_in : (prevb & 0x80u);
+      const uint32_t thr = (roi == 0) ? thr_none : (hpf ? 0u : thr_norm);
+      const bool counts = roi < L && m0 + lane < cap;
+      valid = __ballot(counts);
+      const uint64_t newm = __ballot(event > 0u && d < thr);
+      if (((newm ^ delm) & valid) == 0) break;
+      delm = newm;
+    }
+    const int nv = __builtin_popcountll(valid);
+    const bool deleted = !emitted;
+    // ---- emit
+    const uint32_t nt = s_comp[raw + comp_off];
+    uint32_t subb = s_sub[nt * 4u + mod3(w.w)];
+    if (emitted && is_sub && subb == 0) {  // non-ACGT reference base: one more draw (rare)
+      const U4 v = walk_block(a.seed, a.unit, read_idx, pass, event, 1u);
+      subb = (kATGC >> ((v.x & 3u) * 8u)) & 0xffu;
+    }
+    const uint32_t insb = (w.w & 4u) ? nt : ((kATGC >> ((w.w & 3u) * 8u)) & 0xffu);
+    const uint32_t b = is_sub ? subb : is_ins ? insb : nt;
+    const uint32_t rb = deleted ? 0u : b;
+    const uint32_t fb = (!deleted && is_ins) ? (uint32_t)'-' : nt;
+    const uint32_t qb = deleted ? 0u : (qv + 33u);
+    wave_sync();
+    s_tr[lane] = (uint8_t)rb;
+    s_tr[64 + lane] = (uint8_t)fb;
+    s_tr[128 + lane] = (uint8_t)qb;
+    wave_sync();
+    if (lane * 4 < nv) {
+      const uint32_t dr = reinterpret_cast<const uint32_t *>(s_tr)[lane];
+      const uint32_t df = reinterpret_cast<const uint32_t *>(s_tr + 64)[lane];
+      const uint32_t dqv = reinterpret_cast<const uint32_t *>(s_tr + 128)[lane];
+      scratch_store(&maf_read[(size_t)((m0 >> 2) + lane) * row_step], dr);
+      scratch_store(&maf_ref[(size_t)((m0 >> 2) + lane) * row_step], df);
+      scratch_store(&qual_row[(size_t)((m0 >> 2) + lane) * row_step], dqv);
+    }
+    // ---- the ordered sum of error probabilities: lane by lane, in column order (+ 0.0 leaves it unchanged)
+    {
+      const double mine = (emitted && ((valid >> lane) & 1ull)) ? qp : 0.0;
+      const uint32_t mlo = (uint32_t)__double_as_longlong(mine), mhi = (uint32_t)((unsigned long long)__double_as_longlong(mine) >> 32);
+      for (int i = 0; i < nv; i++) {
+        const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, i), vhi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, i);
+        qsum += __longlong_as_double((long long)(((unsigned long long)vhi << 32) | vlo));
+      }
+    }
+    const uint64_t em_valid = ~delm & valid;
+    nsub += __builtin_popcountll(__ballot(emitted && is_sub) & valid);
+    q0 += __builtin_popcountll(em_valid);
+    const int ro_new = ro0 + __builtin_popcountll(consm & valid);
+    // carries into the next step: state and quality of the last column that had them, flag of the last consumed base
+    if (nv > 0) st_in = (uint32_t)__builtin_amdgcn_readlane((int)st, nv - 1);
+    if (em_valid) lastq_in = (uint32_t)__builtin_amdgcn_readlane((int)qv, 63 - __builtin_clzll(em_valid));
+    if (ro_new > ro0) {  // the last consuming column's base sits at read offset ro_new - 1
+      const uint32_t lastb = win_at((ro_new - 1 - wb) & 127);
+      hpf_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)lastb) & 0x80u;
+    }
+    ro0 = ro_new;
+    m0 += nv;
+    more = nv == 64 && ro0 < L && m0 < cap;
+    if (more && ro0 - wb >= 64) {
+      wb += 64;
+      win_a = win_b;
+      win_b = ref_at(wb + 64 + lane);
+    }
+    (void)roi_u;
+  }
+  if (lane == 0) {
+    if (ro0 < L) atomicOr(&a.flags->error, kErrScratchOverflow);
+    a.out_len[task] = q0;
+    a.maf_len[task] = m0;
+    a.nsub[task] = nsub;
+    a.nins[task] = m0 - ro0;
+    a.ndel[task] = m0 - q0;
+    a.qsum[task] = qsum;
+  }
+}
+
+__global__ __launch_bounds__(kWG) void k_walk_qshmm_coop(WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (a.flags->error & kErrScratchBudget) return;
+  uint8_t *s_comp = lds + a.stride;
+  uint8_t *s_sub = s_comp + 512;
+  uint32_t *s_row = reinterpret_cast<uint32_t *>(s_sub + 1024);   // [94][8]: sub_thre, ins_thre, del (hp 1..10), del (none) | qprob f64 | -
+  uint8_t *s_w = reinterpret_cast<uint8_t *>(s_row + 94 * 8) + wv * kQCoopWaveLds;
+  for (int i = tid; i < 94; i += kWG) {
+    s_row[i * 8 + 0] = a.sub_thre[i];
+    s_row[i * 8 + 1] = a.ins_thre[i];
+    s_row[i * 8 + 2] = a.del_thr[i * 12 + 1];
+    s_row[i * 8 + 3] = a.del_thr[i * 12 + 0];
+    *reinterpret_cast<double *>(&s_row[i * 8 + 4]) = a.qprob[i];
+    s_row[i * 8 + 6] = s_row[i * 8 + 7] = 0;
+  }
+  int staged = -1, c = 0, ubase = 0;
+  for (int u = blockIdx.x;; u += gridDim.x) {
+    int nc = 0;
+    for (; c < a.ncls; c++) {
+      nc = a.coop_end[c] - a.class_start[c];
+      nc = nc > 0 ? nc : 0;
+      const int nu = (nc + 3) >> 2;
+      if (u < ubase + nu) break;
+      ubase += nu;
+    }
+    if (c >= a.ncls) break;
+    if (staged != c) {
+      __syncthreads();  // the other waves may still read the previous class
+      stage_class(a, c, lds, s_comp, s_sub, tid, true);
+      __syncthreads();
+      staged = c;
+    }
+    const int k = (u - ubase) * 4 + wv;
+    const uint32_t has_model = reinterpret_cast<const uint32_t *>(lds)[2];
+    if (k < nc && has_model) qcoop_walk_task(a, lds, s_comp, s_sub, s_row, s_w, a.class_start[c] + k, lane);
   }
 }
 
@@ -2394,6 +2667,12 @@ void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bo
   lds_bytes += kCoopWaves * kCoopWaveLds;
   if (hp_bits) hipLaunchKernelGGL((k_walk_errhmm_coop<true>), grid, block, lds_bytes, s, a);
   else hipLaunchKernelGGL((k_walk_errhmm_coop<false>), grid, block, lds_bytes, s, a);
+}
+
+void launch_walk_qshmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, hipStream_t s) {
+  const dim3 grid((unsigned)n_wg), block(kWG);
+  lds_bytes += 94 * 32 + (kWG / 64) * kQCoopWaveLds;
+  hipLaunchKernelGGL(k_walk_qshmm_coop, grid, block, lds_bytes, s, a);
 }
 
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,

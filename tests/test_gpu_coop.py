@@ -88,3 +88,65 @@ def test_split_on_several_ranks(tmp_path, monkeypatch):
         got = run_devices(args, str(d), 3, scratch_mb=6)
         for k in want:
             assert got[k] == want[k], (coop, k)
+
+
+# ---- k_walk_qshmm_coop (round 3): the QSHMM walk with one wave per task, against the lane walker and the goldens ----------
+def run_qs(coop, monkeypatch, records, model="QSHMM-RSII.model", **kw):
+    import pbsim3_amd as P
+    if coop is None:
+        monkeypatch.delenv("PBSIM_COOP_LEN", raising=False)
+    else:
+        monkeypatch.setenv("PBSIM_COOP_LEN", str(coop))
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS, **kw)
+    with P.Context(p, 0) as ctx:
+        ctx.set_scratch_bytes(256 << 20)
+        ctx.load_qshmm(harness.model_path(model))
+        for r in records:
+            ctx.job_add_record(r)
+        outs, done = ctx.job_run()
+        waves = ctx.prof_wave_launches()
+    # the wave walker really took part (or really did not).  QSHMM-ONT-HQ is not eligible: its classes name states above
+    # STATE_MAX and not all of its moduli are 100 -- every task stays with the lane walker, whatever the split
+    assert (waves > 0) == (coop != -1 and "ONT-HQ" not in model), (coop, waves)
+    texts = {k: (bytes(v[0]), bytes(v[1])) for k, v in outs.items()}
+    stats = {k: tuple(getattr(v[0], f[0]) for f in v[0]._fields_) + tuple(v[1:]) for k, v in done.items()}
+    return texts, stats
+
+
+QS_RUNS = {
+    "rsii_default": dict(seed=7, depth=10.0),
+    "rsii_pass3": dict(seed=9, depth=4.0, pass_num=3, len_mean=4000.0, len_sd=3000.0),
+    "ont_deletion_heavy": dict(seed=3, depth=8.0, model="QSHMM-ONT.model", sub_ratio=5, ins_ratio=10, del_ratio=85, accuracy_mean=0.80),
+    "ont_insertion_heavy": dict(seed=5, depth=8.0, model="QSHMM-ONT.model", sub_ratio=5, ins_ratio=85, del_ratio=10),
+    "onthq_many_states": dict(seed=11, depth=8.0, model="QSHMM-ONT-HQ.model", accuracy_mean=0.95),
+    "rsii_short_min_length": dict(seed=17, depth=6.0, len_mean=400.0, len_sd=300.0, len_min=1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(QS_RUNS))
+def test_qshmm_wave_walker_matches_lane_walker(name, monkeypatch):
+    """every byte and every statistic -- the ordered f64 sum behind the accuracy mean and its histogram included -- whatever
+    share of the tasks the wave walker takes (0: all of them; n: tasks of at least n bases; default: small batches only)"""
+    recs = [genome(900_000, 1), genome(400_000, 2)]
+    want = run_qs(-1, monkeypatch, recs, **QS_RUNS[name])
+    assert sum(len(a) + len(b) for a, b in want[0].values()) > 5_000_000
+    for coop in (0, 4096, None):
+        got = run_qs(coop, monkeypatch, recs, **QS_RUNS[name])
+        assert got[1] == want[1], (name, coop)
+        for k in want[0]:
+            assert got[0][k] == want[0][k], (name, coop, k)
+
+
+QS_GOLD = sorted(c for c in CASES if c.startswith("wgs_qshmm"))
+
+
+@pytest.mark.parametrize("case", QS_GOLD)
+@pytest.mark.parametrize("coop", [0, -1, 512])
+def test_qshmm_goldens_on_either_walker(case, coop, monkeypatch):
+    """the reference's own QSHMM goldens (all three models, ratios, multi-pass, the Q15 hp-del-bias cases, which keep their
+    byte-form hp array and therefore the lane walker) with every task / no task / the long tasks on the wave walker"""
+    monkeypatch.setenv("PBSIM_COOP_LEN", str(coop))
+    outs, _ = product.run_wgs_job(harness.resolve(CASES[case]["args"]), scratch_mb=4)
+    gold = MANIFEST[f"{case}/philox"]
+    for k, v in outs.items():
+        assert harness.sha(v) == gold[k]["sha256"], (case, coop, k)
