@@ -18,6 +18,7 @@
 // deleted column), MAF reference row, and for QSHMM the quality per column; the
 // read sequence is the MAF read row with the deleted columns squeezed out (K3).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "kernels.h"
 #include "philox.h"
@@ -1406,27 +1407,31 @@ __device__ __forceinline__ uint32_t qcoop_chain(const uint8_t *lds, uint32_t ini
   uint32_t lo[8], hi[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) lo[k] = hi[k] = 0;
-  auto walk_pair = [&](const int k0) {
-    uint32_t st[2] = {(uint32_t)(j + 8 * k0), (uint32_t)(j + 8 * k0 + 8)};
+  // kN chains side by side: their eight dependent table reads each overlap (walked pair after pair the step took n/2 times as long)
+  auto walk = [&](auto tag) {
+    constexpr int kN = decltype(tag)::value;
+    uint32_t st[kN];
+#pragma unroll
+    for (int k = 0; k < kN; k++) st[k] = (uint32_t)(j + 8 * k);
 #pragma unroll
     for (int t = 0; t < 8; t++) {
 #pragma unroll
-      for (int k = 0; k < 2; k++) {
+      for (int k = 0; k < kN; k++) {
         uint32_t row = st[k];
         if (t == 0) row = first_init ? 0u : row;
         const uint32_t nx = lds[init_off + __umul24(row, 100u) + xt[t]];
         st[k] = ((dg >> t) & 1u) ? st[k] : nx;
-        if (t < 4) lo[k0 + k] |= st[k] << (8 * t);
-        else hi[k0 + k] |= st[k] << (8 * (t - 4));
+        if (t < 4) lo[k] |= st[k] << (8 * t);
+        else hi[k] |= st[k] << (8 * (t - 4));
       }
     }
-    s_end[g * 64 + j + 8 * k0] = (uint8_t)st[0];
-    s_end[g * 64 + j + 8 * k0 + 8] = (uint8_t)st[1];
+#pragma unroll
+    for (int k = 0; k < kN; k++) s_end[g * 64 + j + 8 * k] = (uint8_t)st[k];
   };
-  walk_pair(0);
-  if (n_chains > 2) walk_pair(2);
-  if (n_chains > 4) walk_pair(4);
-  if (n_chains > 6) walk_pair(6);
+  if (n_chains <= 2) walk(std::integral_constant<int, 2>());
+  else if (n_chains <= 4) walk(std::integral_constant<int, 4>());
+  else if (n_chains <= 6) walk(std::integral_constant<int, 6>());
+  else walk(std::integral_constant<int, 8>());
   wave_sync();
   uint32_t s = s_in, sg = 0;
 #pragma unroll
