@@ -1778,6 +1778,7 @@ struct SampleChunks {
     int64_t next_probe = 0;      // the string after the last one that was looked at
     std::vector<int32_t> h_len, h_vbase, h_cap, h_tos, h_sot;
     std::vector<int64_t> h_qoff, h_woff;
+    int32_t n_coop_waves = 0;    // leading line waves (the longest strings) whose strings get a wave each
   };
   pbsim_ctx *c;
   int64_t F, G, interval = 1, sample_num = 0;
@@ -1798,6 +1799,28 @@ struct SampleChunks {
     }
     if (interval < 1) return fail("sample profile holds a single read: the reference divides by zero here (pbsim.cpp:1741)");
     return PBSIM_SUCCEEDED;
+  }
+  // How many of the chunk's line waves (64 strings each, longest first) are walked one WAVE per string (k_walk_sample's
+  // scoop_walk_string): a string's copies are a serial chain, a lane takes 0.6 us per column, a wave 0.03 -- the longest strings
+  // set the launch's duration.  Default: every string of a small chunk (the lanes could not fill the GPU), else the waves whose
+  // strings all have at least twice the chunk's mean length.  PBSIM_COOP_LEN as for the HMM walks: -1 none, 0 all, n = length.
+  // Depends on the chunk alone, so every rank of a sharded run decides alike.
+  int32_t coop_waves(const std::vector<Ent> &cand, size_t n_c) const {
+    if (!c->seq_hp_flag || n_c == 0) return 0;
+    const int32_t n_w = (int32_t)((n_c + 63) / 64);
+    const char *e = getenv("PBSIM_COOP_LEN");
+    int64_t thr = e ? atoll(e) : -2;
+    if (thr == -1) return 0;
+    if (thr == 0) return n_w;
+    if (thr < 0) {
+      if (n_c <= 16384) return n_w;
+      double sum = 0;
+      for (size_t i = 0; i < n_c; i++) sum += cand[i].len;
+      thr = (int64_t)(2.0 * sum / (double)n_c);
+    }
+    int32_t n = 0;
+    while (n < n_w && cand[(size_t)order[std::min(n_c, (size_t)(n + 1) * 64) - 1]].len >= thr) n++;
+    return n;
   }
   int64_t copies_of(int64_t sv, int64_t line) const { return sample_num + (((sv + line) % interval == 0) ? 1 : 0); }
   // strings of [line, F) that have copies in this sweep (the sharded driver deals them out in equal runs)
@@ -1840,6 +1863,7 @@ struct SampleChunks {
       ck->h_woff.clear();
       need = 0;
       n_tasks = 0;
+      ck->n_coop_waves = coop_waves(cand, n_c);
       for (size_t w0 = 0; w0 < n_c; w0 += 64) {
         int64_t kmax = 0, lmax = 0;
         for (size_t i = w0; i < std::min(n_c, w0 + 64); i++) {
@@ -1849,8 +1873,9 @@ struct SampleChunks {
           n_tasks += e.num;
         }
         const int64_t cap_dw = (2 * lmax + kScratchPad + 3) / 4;
+        const int32_t transposed = (int64_t)(w0 / 64) < ck->n_coop_waves ? kWaveTransposed : 0;  // rows task by task
         for (int64_t k = 0; k < kmax; k++) {
-          ck->h_cap.push_back((int32_t)cap_dw);
+          ck->h_cap.push_back((int32_t)cap_dw | transposed);
           ck->h_woff.push_back(need);
           need += cap_dw * 256 * 3;
         }
@@ -1945,6 +1970,8 @@ struct SampleChunks {
     a.first_read = first_read;
     a.n_lines = (int32_t)n_lines;
     a.n_line_waves = (int32_t)n_lw;
+    a.n_coop_waves = ck.n_coop_waves;
+    a.n_coop_blocks = (int32_t)std::min<int64_t>(((int64_t)ck.n_coop_waves * 64 + 3) / 4, 768);
     a.ref.seq = c->d_seq;
     a.ref.hp = c->d_hp.as<uint8_t>();
     a.ref.len = G;

@@ -130,6 +130,8 @@ struct SampleArgs {
   int64_t first_read;         // read index of task 0
   int32_t n_lines;            // strings in this chunk
   int32_t n_line_waves;       // ceil(n_lines / 64)
+  int32_t n_coop_waves;       // the first n_coop_waves line waves (the longest strings): one WAVE per string (hp_bits only)
+  int32_t n_coop_blocks;      // workgroups 0 .. n_coop_blocks - 1 walk them, the others one lane per string
   RefView ref;
   const uint8_t *quals;       // filtered quality strings, each padded to a multiple of 8 bytes
   const int64_t *line_qoff;   // [n_lines] byte offset of the string

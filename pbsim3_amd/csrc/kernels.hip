@@ -1662,12 +1662,181 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm_coop(WalkArgs a) {
 //              else      error class    E.z % 1e6 vs sub_thre / ins_thre of qc[q]                (:1779-1810)
 //   ends when the reference window OR the quality string is used up                              (:1776)
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// K2sc (round 3): the strings of the chunk's longest line waves get one WAVE each, 64 columns per step -- the chain of a
+// string's copies is serial, and so is a copy's walk in the lane version (0.6 us per column on a GPU that the strings of a
+// profile cannot fill: a 60 000-character string held the launch for 40-80 ms).  There is no state chain here; what a column
+// decides depends on the columns in front of it only through two cursors, q (characters of the string used) and ro
+// (reference bases used), and a column is deleted or not by a test whose thresholds come from the character at q - 1 and the
+// homopolymer flag at ro - 1.  A step iterates over the deletion mask to the sequential walk's fixed point, exactly like the
+// QSHMM wave walker (column p's outcome depends on columns < p only: every turn extends the correct prefix).
+// LDS of one wave: 128-byte rings of the reference window and the string window, three output rows of 64 bytes.
+// ---------------------------------------------------------------------------
+constexpr int kSCoopRef = 0, kSCoopQ = 128, kSCoopRows = 256, kSCoopWaveLds = 448;
+
+__device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uint8_t *s_comp, const uint8_t *s_sub, const uint32_t *s_subt,
+                                                  const uint32_t *s_ins, const uint32_t *s_del, const double *s_qprob, uint8_t *s_w,
+                                                  int lw, int l, int lane) {
+  uint8_t *s_ref = s_w + kSCoopRef, *s_q = s_w + kSCoopQ, *s_tr = s_w + kSCoopRows;
+  const int line = lw * 64 + l;
+  if (line >= a.n_lines) return;
+  int Lcur = __builtin_amdgcn_readfirstlane(a.line_len[line]);
+  const uint8_t *qsrc = a.quals + a.line_qoff[line];
+  const int v0 = __builtin_amdgcn_readfirstlane(a.vbase[lw]), K = __builtin_amdgcn_readfirstlane(a.vbase[lw + 1]) - v0;
+  const int64_t G = a.ref.len;
+  const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int k = 0; k < K; ++k) {
+    const int64_t wave = v0 + k;
+    const int task = __builtin_amdgcn_readfirstlane(a.task_of_slot[wave * 64 + l]);
+    if (task < 0) break;  // a string's copies take the virtual waves v0 .. v0 + num - 1
+    const uint32_t read_idx = (uint32_t)(a.first_read + task);
+    int L = Lcur;
+    int64_t off = 0;
+    if ((int64_t)L >= G) L = (int)G;  // pbsim.cpp:1753-1759
+    else off = (int64_t)(header_block(a.seed, a.unit, read_idx).z % (uint32_t)(G - L + 1));
+    const bool minus = (read_idx & 1u) == 0;  // :1767-1773
+    const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]) & ~kWaveTransposed;
+    uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + (size_t)l * cap_dw;  // rows task by task
+    uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
+    uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;
+    const int cap = cap_dw * 4;
+    const uint32_t comp_off = minus ? 256u : 0u;
+    const int64_t p_first = minus ? (off + L - 1) : off;
+    const int64_t p_last = G - 1;
+    auto ref_at = [&](int t) -> uint8_t {
+      int64_t p = minus ? (p_first - t) : (p_first + t);
+      p = p < 0 ? 0 : (p > p_last ? p_last : p);
+      return a.ref.seq[p];
+    };
+    auto q_at = [&](int t) -> uint8_t { return qsrc[t < L ? t : (L > 0 ? L - 1 : 0)]; };
+    auto conv = [](uint32_t ch) -> uint32_t { return (ch >= 33u && ch < 127u) ? ch - 33u : 0u; };
+    // rings: positions wb .. wb + 127 of the read's reference window, qb .. qb + 127 of the string; the next 64 of each on their way
+    int wb = 0, qb = 0;
+    wave_sync();
+    s_ref[lane] = ref_at(lane);
+    s_ref[64 + lane] = ref_at(64 + lane);
+    s_q[lane] = q_at(lane);
+    s_q[64 + lane] = q_at(64 + lane);
+    uint8_t pre_ref = ref_at(128 + lane), pre_q = q_at(128 + lane);
+    wave_sync();
+
+    int m0 = 0, ro0 = 0, q0 = 0, nsub = 0;
+    uint32_t lastq_in = 0, hp_in = 0;  // nothing emitted, no reference base consumed yet: mut.hp[-1], observed 0 (Q15)
+    double qsum = 0.0;
+    bool more = L > 0;
+    while (more) {
+      const uint32_t event = (uint32_t)(m0 + lane);
+      const U4 w = walk_block(a.seed, a.unit, read_idx, 0u, event, 0u);
+      const U4 dq = walk_block(a.seed, a.unit, read_idx, 0u, event >> 2, 2u);
+      const uint32_t dsel = event & 3u;
+      const uint32_t dw = dsel == 0 ? dq.x : dsel == 1 ? dq.y : dsel == 2 ? dq.z : dq.w;
+      const uint32_t z = mod1e6(w.z), d = mod1e6(dw);
+      uint64_t delm = __ballot(event > 0u && d < s_del[lastq_in * 12u + hp_in]);  // first guess
+      uint32_t qv = 0, raw = 0;
+      bool is_sub = false, is_ins = false, emitted = true;
+      uint64_t valid = 0, consm = 0;
+      for (;;) {
+        emitted = ((delm >> lane) & 1ull) == 0;
+        const int qi = q0 + __builtin_popcountll(~delm & below);
+        qv = conv(s_q[qi & 127]);
+        const uint32_t lq = (qi == q0) ? lastq_in : conv(s_q[(qi - 1) & 127]);
+        is_sub = z < s_subt[qv];               // pbsim.cpp:1779-1810
+        is_ins = !is_sub && z < s_ins[qv];
+        consm = __ballot(!emitted || !is_ins);  // a column uses a reference base unless it is an emitted insertion
+        const int roi = ro0 + (int)mbcnt64(consm);
+        raw = s_ref[roi & 127];
+        const uint32_t prevb = s_ref[(roi - 1) & 127];
+        const uint32_t hsel = (roi == ro0) ? hp_in : ((prevb & 0x80u) ? 11u : 1u);
+        const uint32_t thr = s_del[lq * 12u + hsel];  // :1816-1831
+        valid = __ballot(roi < L && qi < L && m0 + lane < cap);  // :1776
+        const uint64_t newm = __ballot(event > 0u && d < thr);
+        if (((newm ^ delm) & valid) == 0) break;
+        delm = newm;
+      }
+      const int nv = __builtin_popcountll(valid);
+      const bool deleted = !emitted;
+      // ---- emit
+      const uint32_t nt = s_comp[raw + comp_off];
+      uint32_t subb = s_sub[nt * 4u + mod3(w.w)];
+      if (emitted && is_sub && subb == 0) {  // non-ACGT reference base (:1794-1796)
+        const U4 v = walk_block(a.seed, a.unit, read_idx, 0u, event, 1u);
+        subb = (kATGC >> ((v.x & 3u) * 8u)) & 0xffu;
+      }
+      const uint32_t insb = (w.w & 4u) ? nt : ((kATGC >> ((w.w & 3u) * 8u)) & 0xffu);
+      const uint32_t b = is_sub ? subb : is_ins ? insb : nt;
+      wave_sync();
+      s_tr[lane] = (uint8_t)(deleted ? 0u : b);
+      s_tr[64 + lane] = (uint8_t)((!deleted && is_ins) ? (uint32_t)'-' : nt);
+      s_tr[128 + lane] = (uint8_t)(deleted ? 0u : (qv + 33u));
+      wave_sync();
+      if (lane * 4 < nv) {
+        scratch_store(&maf_read[(size_t)(m0 >> 2) + lane], reinterpret_cast<const uint32_t *>(s_tr)[lane]);
+        scratch_store(&maf_ref[(size_t)(m0 >> 2) + lane], reinterpret_cast<const uint32_t *>(s_tr + 64)[lane]);
+        scratch_store(&qual_row[(size_t)(m0 >> 2) + lane], reinterpret_cast<const uint32_t *>(s_tr + 128)[lane]);
+      }
+      // ---- the ordered sum of error probabilities (pbsim.cpp:1857-1860): lane by lane, in column order (+ 0.0 changes nothing)
+      {
+        const double mine = (emitted && ((valid >> lane) & 1ull)) ? s_qprob[qv] : 0.0;
+        const uint32_t mlo = (uint32_t)__double_as_longlong(mine), mhi = (uint32_t)((unsigned long long)__double_as_longlong(mine) >> 32);
+        if (nv == 64) {
+#pragma unroll
+          for (int i = 0; i < 64; i++) {
+            const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, i), vhi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, i);
+            qsum += __longlong_as_double((long long)(((unsigned long long)vhi << 32) | vlo));
+          }
+        } else {
+          for (int i = 0; i < nv; i++) {
+            const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, i), vhi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, i);
+            qsum += __longlong_as_double((long long)(((unsigned long long)vhi << 32) | vlo));
+          }
+        }
+      }
+      const uint64_t em_valid = ~delm & valid;
+      nsub += __builtin_popcountll(__ballot(emitted && is_sub) & valid);
+      const int ro_new = ro0 + __builtin_popcountll(consm & valid);
+      if (em_valid) lastq_in = (uint32_t)__builtin_amdgcn_readlane((int)qv, 63 - __builtin_clzll(em_valid));
+      if (ro_new > ro0) hp_in = ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_ref[(ro_new - 1) & 127]) & 0x80u) ? 11u : 1u;
+      q0 += __builtin_popcountll(em_valid);
+      ro0 = ro_new;
+      m0 += nv;
+      more = nv == 64 && ro0 < L && q0 < L && m0 < cap;
+      if (more && ro0 - wb >= 64) {  // positions wb .. wb + 63 are behind the cursor: their slots take wb + 128 .. wb + 191
+        wave_sync();
+        s_ref[(wb + lane) & 127] = pre_ref;
+        wb += 64;
+        pre_ref = ref_at(wb + 128 + lane);
+        wave_sync();
+      }
+      if (more && q0 - qb >= 64) {
+        wave_sync();
+        s_q[(qb + lane) & 127] = pre_q;
+        qb += 64;
+        pre_q = q_at(qb + 128 + lane);
+        wave_sync();
+      }
+    }
+    if (lane == 0) {
+      if (ro0 < L && q0 < L) atomicOr(&a.flags->error, kErrScratchOverflow);
+      a.span[task] = ro0;         // seq_right - seq_left + 1 = ref_offset (:1846-1847)
+      a.off[task] = (int32_t)off;
+      a.out_len[task] = q0;
+      a.maf_len[task] = m0;
+      a.nsub[task] = nsub;
+      a.nins[task] = m0 - ro0;
+      a.ndel[task] = m0 - q0;
+      a.qsum[task] = qsum;
+    }
+    Lcur = q0;                    // the string is cut to this read's length (:1834)
+  }
+}
+
 template <bool kHpBits>
 __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
   __shared__ uint8_t s_comp[512];
   __shared__ uint8_t s_sub[1024];
   __shared__ uint32_t s_subt[96], s_ins[96], s_del[94 * 12];
   __shared__ double s_qprob[94];
+  __shared__ __attribute__((aligned(16))) uint8_t s_wave[(kWG / 64) * kSCoopWaveLds];
   const int tid = threadIdx.x;
   {
     const uint32_t c = (uint32_t)tid;
@@ -1688,7 +1857,15 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
   }
   __syncthreads();
   const int lane = tid & 63;
-  const int lw = (int)blockIdx.x * (kWG / 64) + (tid >> 6);
+  if ((int)blockIdx.x < a.n_coop_blocks) {
+    // the strings of line waves 0 .. n_coop_waves - 1 (the chunk's longest), one per wave, longest first, dealt round-robin
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_units = a.n_coop_waves * 64;
+    for (int u = (int)blockIdx.x * (kWG / 64) + wv; u < n_units; u += a.n_coop_blocks * (kWG / 64))
+      scoop_walk_string(a, s_comp, s_sub, s_subt, s_ins, s_del, s_qprob, s_wave + wv * kSCoopWaveLds, u >> 6, u & 63, lane);
+    return;
+  }
+  const int lw = a.n_coop_waves + ((int)blockIdx.x - a.n_coop_blocks) * (kWG / 64) + (tid >> 6);
   if (lw >= a.n_line_waves) return;
   const int line = lw * 64 + lane;
   const bool has_line = line < a.n_lines;
@@ -1709,7 +1886,7 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
       else off = (int64_t)(header_block(a.seed, a.unit, read_idx).z % (uint32_t)(G - L + 1));
     }
     const bool minus = (read_idx & 1u) == 0;  // :1767-1773
-    const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]);  // wave-uniform: keeps row offsets scalar
+    const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]) & ~kWaveTransposed;  // wave-uniform: keeps row offsets scalar
     const int64_t woff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.wave_off[wave] >> 32)) << 32) |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wave_off[wave]);
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + woff) + lane;
@@ -2692,7 +2869,8 @@ void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byte
 
 void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s) {
   if (a.n_line_waves <= 0) return;
-  const dim3 grid((unsigned)((a.n_line_waves + kWG / 64 - 1) / (kWG / 64))), block(kWG);
+  const int lane_waves = a.n_line_waves - a.n_coop_waves;
+  const dim3 grid((unsigned)(a.n_coop_blocks + (lane_waves + kWG / 64 - 1) / (kWG / 64))), block(kWG);
   if (hp_bits) hipLaunchKernelGGL((k_walk_sample<true>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((k_walk_sample<false>), grid, block, 0, s, a);
 }

@@ -14,6 +14,17 @@ pytestmark = pytest.mark.gpu
 INPUTS = os.path.join(harness.GOLDEN, "inputs")
 
 
+@pytest.fixture(autouse=True, params=["default", "-1", "0", "1500"])
+def walker_split(request, monkeypatch):
+    """which strings get a whole wave (scoop_walk_string, round 3) and which a lane: default = every string of these small
+    profiles; -1 none; 0 all; 1500 = the line waves whose strings all have >= 1500 characters.  Same bytes every time."""
+    if request.param == "default":
+        monkeypatch.delenv("PBSIM_COOP_LEN", raising=False)
+    else:
+        monkeypatch.setenv("PBSIM_COOP_LEN", request.param)
+    return request.param
+
+
 def run_product(argv, scratch_mb=None):
     p, a = A.parse(argv)
     quals = A.read_sample_fastq(a["--sample"], p.len_min, p.len_max,
@@ -91,4 +102,23 @@ def test_high_quality_profile(tmp_path):
             f.write("@h%d\n%s\n+\n%s\n" % (i, "C" * n, q))
     argv = ["--strategy", "wgs", "--method", "sample", "--sample", str(fq), "--genome", "INPUT:plain.fa",
             "--depth", "8", "--seed", "15", "--difference-ratio", "20:30:50"]
+    check(argv, tmp_path)
+
+
+def test_large_profile_default_split(tmp_path, walker_split):
+    """30 000 strings (more than a small chunk): by default the line waves of at least twice the mean length go to the wave
+    walker, the rest to the lanes; second sweep over every 2nd..nth string"""
+    if walker_split not in ("default", "-1"):
+        pytest.skip("the split is the default's")
+    import numpy as np
+    rng = np.random.default_rng(5)
+    n = 30000
+    lens = np.clip(rng.gamma(1.6, 250.0, n), 40, 6000).astype(int)
+    fq = tmp_path / "big.fastq"
+    with open(fq, "w") as f:
+        for i in range(n):
+            q = bytes((33 + np.clip(rng.integers(5, 35) + rng.integers(-4, 5, lens[i]), 0, 60)).astype(np.uint8)).decode()
+            f.write("@b%d\n%s\n+\n%s\n" % (i, "G" * lens[i], q))
+    argv = ["--strategy", "wgs", "--method", "sample", "--sample", str(fq), "--genome", "INPUT:plain.fa",
+            "--depth", "85", "--seed", "16", "--length-min", "40"]
     check(argv, tmp_path)
