@@ -275,6 +275,10 @@ struct pbsim_ctx {
   // the NEXT record, uploaded and prepared beside the current record's simulation (pbsim_prefetch_reference*)
   DevBuf d_seq_next, d_hp_next, d_tiles_next, d_ref_flags_next;
   hipStream_t prefetch_stream = nullptr;
+  // sampling method: k_sample_qsum runs beside the chunk's text emission (own stream); its sums are due at the statistics fetch
+  hipStream_t sq_stream = nullptr;
+  hipEvent_t ev_sq_walk = nullptr, ev_sq_done = nullptr;
+  bool sq_pending = false;
   const void *pf_src = nullptr;
   int64_t pf_len = 0;
   bool seq_hp_flag = false;  // bit 7 of the prepared sequence bytes carries hp == 11 (k_hp_final)

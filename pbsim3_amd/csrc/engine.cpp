@@ -313,6 +313,9 @@ void pbsim_destroy(pbsim_ctx *c) {
       if (st) (void)hipStreamDestroy(st);
   if (c->ev_prof_base) (void)hipEventDestroy(c->ev_prof_base);
   if (c->prefetch_stream) (void)hipStreamDestroy(c->prefetch_stream);
+  if (c->sq_stream) (void)hipStreamDestroy(c->sq_stream);
+  if (c->ev_sq_walk) (void)hipEventDestroy(c->ev_sq_walk);
+  if (c->ev_sq_done) (void)hipEventDestroy(c->ev_sq_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1009,6 +1012,10 @@ static int fetch_stats(pbsim_ctx *c, Slot &sl, int64_t n_tasks) {
   int32_t *ol = reinterpret_cast<int32_t *>(sl.h_stats.p);
   int32_t *ns = ol + n_tasks, *ni = ns + n_tasks, *nd = ni + n_tasks;
   double *qs = reinterpret_cast<double *>(nd + n_tasks);
+  if (c->sq_pending) {  // the wave-walked reads' sums (k_sample_qsum, beside the text emission)
+    HIP_OK(hipStreamWaitEvent(sl.stream, c->ev_sq_done, 0));
+    c->sq_pending = false;
+  }
   HIP_OK(hipMemcpyAsync(ol, sl.d_out_len.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
   HIP_OK(hipMemcpyAsync(ns, sl.d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
   HIP_OK(hipMemcpyAsync(ni, sl.d_nins.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
@@ -1785,7 +1792,7 @@ struct SampleChunks {
   // a string whose copies do not fit one chunk continues in the next one: copies done so far, current length
   int64_t carry_line = -1, carry_done = 0;
   int32_t carry_len = 0;
-  std::vector<int32_t> order;
+  std::vector<int32_t> order, order_tmp;
 
   int init(int64_t quota) {
     F = (int64_t)c->sq_len.size();
@@ -1801,10 +1808,12 @@ struct SampleChunks {
     return PBSIM_SUCCEEDED;
   }
   // How many of the chunk's line waves (64 strings each, longest first) are walked one WAVE per string (k_walk_sample's
-  // scoop_walk_string): a string's copies are a serial chain, a lane takes 0.6 us per column, a wave 0.03 -- the longest strings
-  // set the launch's duration.  Default: every string of a small chunk (the lanes could not fill the GPU), else the waves whose
-  // strings all have at least twice the chunk's mean length.  PBSIM_COOP_LEN as for the HMM walks: -1 none, 0 all, n = length.
-  // Depends on the chunk alone, so every rank of a sharded run decides alike.
+  // scoop_walk_string): a string's copies are a serial chain, a lane takes 0.6 us per column, a wave 0.03, and a chunk holds at
+  // most 2^18 strings -- four lane waves per SIMD, which cannot hide the lanes' latencies.  Default: every string (measured on
+  // 200 000 strings, 2 Gbases: 42-53 ms against 60 with the strings below twice the mean length on lanes and 78-152 with all of
+  // them there).  PBSIM_COOP_LEN as for the HMM walks: -1 none, 0 all, n = the line waves whose strings all have >= n
+  // characters.  --hp-del-bias keeps the lanes (byte-form homopolymer array).  Depends on the chunk alone: every rank of a
+  // sharded run decides alike.
   int32_t coop_waves(const std::vector<Ent> &cand, size_t n_c) const {
     if (!c->seq_hp_flag || n_c == 0) return 0;
     const int32_t n_w = (int32_t)((n_c + 63) / 64);
@@ -1812,15 +1821,27 @@ struct SampleChunks {
     int64_t thr = e ? atoll(e) : -2;
     if (thr == -1) return 0;
     if (thr == 0) return n_w;
-    if (thr < 0) {
-      if (n_c <= 16384) return n_w;
-      double sum = 0;
-      for (size_t i = 0; i < n_c; i++) sum += cand[i].len;
-      thr = (int64_t)(2.0 * sum / (double)n_c);
-    }
+    if (thr < 0) return n_w;
     int32_t n = 0;
     while (n < n_w && cand[(size_t)order[std::min(n_c, (size_t)(n + 1) * 64) - 1]].len >= thr) n++;
     return n;
+  }
+  // order[] = the first n_c strings by length, longest first, ties in file order: a stable LSD radix sort over the 20 bits a
+  // length has (<= 1 000 000, pbsim_set_sample_profile) -- std::stable_sort took 15 ms of a 65 ms job for 200 000 strings
+  void sort_by_length(const std::vector<Ent> &cand, size_t n_c) {
+    order.resize(n_c);
+    order_tmp.resize(n_c);
+    uint32_t cnt[1025];
+    for (int pass = 0; pass < 2; pass++) {
+      const int shift = pass * 10;
+      memset(cnt, 0, sizeof cnt);
+      auto key = [&](int32_t i) { return ((0xfffffu - (uint32_t)cand[(size_t)i].len) >> shift) & 1023u; };
+      if (pass == 0) for (size_t i = 0; i < n_c; i++) cnt[key((int32_t)i) + 1]++;
+      else for (size_t i = 0; i < n_c; i++) cnt[key(order_tmp[i]) + 1]++;
+      for (int b = 0; b < 1024; b++) cnt[b + 1] += cnt[b];
+      if (pass == 0) for (size_t i = 0; i < n_c; i++) order_tmp[cnt[key((int32_t)i)]++] = (int32_t)i;
+      else for (size_t i = 0; i < n_c; i++) order[cnt[key(order_tmp[i])]++] = order_tmp[i];
+    }
   }
   int64_t copies_of(int64_t sv, int64_t line) const { return sample_num + (((sv + line) % interval == 0) ? 1 : 0); }
   // strings of [line, F) that have copies in this sweep (the sharded driver deals them out in equal runs)
@@ -1855,9 +1876,7 @@ struct SampleChunks {
     size_t n_c = cand.size();
     int64_t need = 0, n_tasks = 0;
     for (;;) {
-      order.resize(n_c);
-      for (size_t i = 0; i < n_c; i++) order[i] = (int32_t)i;
-      std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return cand[(size_t)x].len > cand[(size_t)y].len; });
+      sort_by_length(cand, n_c);
       ck->h_vbase.assign(1, 0);
       ck->h_cap.clear();
       ck->h_woff.clear();
@@ -1972,6 +1991,7 @@ struct SampleChunks {
     a.n_line_waves = (int32_t)n_lw;
     a.n_coop_waves = ck.n_coop_waves;
     a.n_coop_blocks = (int32_t)std::min<int64_t>(((int64_t)ck.n_coop_waves * 64 + 3) / 4, 768);
+    a.n_coop_slots = ck.h_vbase[(size_t)ck.n_coop_waves] * 64;
     a.ref.seq = c->d_seq;
     a.ref.hp = c->d_hp.as<uint8_t>();
     a.ref.len = G;
@@ -1997,7 +2017,23 @@ struct SampleChunks {
     a.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     a.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
     a.flags = flags;
+    if (c->sq_pending) {  // (a chunk whose statistics were never fetched: its sums still read the pool)
+      HIP_OK(hipStreamWaitEvent(sl.stream, c->ev_sq_done, 0));
+      c->sq_pending = false;
+    }
     launch_walk_sample(a, c->seq_hp_flag, sl.stream);
+    if (a.n_coop_slots > 0) {
+      if (!c->sq_stream) {
+        HIP_OK(hipStreamCreateWithFlags(&c->sq_stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&c->ev_sq_walk, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&c->ev_sq_done, hipEventDisableTiming));
+      }
+      HIP_OK(hipEventRecord(c->ev_sq_walk, sl.stream));
+      HIP_OK(hipStreamWaitEvent(c->sq_stream, c->ev_sq_walk, 0));
+      launch_sample_qsum(a, c->sq_stream);
+      HIP_OK(hipEventRecord(c->ev_sq_done, c->sq_stream));
+      c->sq_pending = true;
+    }
     launch_gather_pass0_scan(a.out_len, n_tasks, 1, sl.d_cum.as<int64_t>(), sl.d_scan_tmp.as<int64_t>(),
                              &flags->sums[0], sl.stream);
     HIP_OK(hipGetLastError());

@@ -132,6 +132,7 @@ struct SampleArgs {
   int32_t n_line_waves;       // ceil(n_lines / 64)
   int32_t n_coop_waves;       // the first n_coop_waves line waves (the longest strings): one WAVE per string (hp_bits only)
   int32_t n_coop_blocks;      // workgroups 0 .. n_coop_blocks - 1 walk them, the others one lane per string
+  int32_t n_coop_slots;       // 64 x their virtual waves (k_sample_qsum: one lane per slot)
   RefView ref;
   const uint8_t *quals;       // filtered quality strings, each padded to a multiple of 8 bytes
   const int64_t *line_qoff;   // [n_lines] byte offset of the string
@@ -207,6 +208,7 @@ void launch_walk_qshmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, hip
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
                        hipStream_t s, int min_lds_kb);
 void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s);
+void launch_sample_qsum(const SampleArgs &a, hipStream_t s);  // the ordered quality sums of the wave-walked reads
 // exclusive scan of int64 (in-place allowed: out may equal in); tmp needs (n/1024+2) int64
 void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total, hipStream_t s);
 // cum[r] = pass-0 output bases of reads < r (exclusive scan), *total = their sum

@@ -1670,14 +1670,16 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm_coop(WalkArgs a) {
 // (reference bases used), and a column is deleted or not by a test whose thresholds come from the character at q - 1 and the
 // homopolymer flag at ro - 1.  A step iterates over the deletion mask to the sequential walk's fixed point, exactly like the
 // QSHMM wave walker (column p's outcome depends on columns < p only: every turn extends the correct prefix).
-// LDS of one wave: 128-byte rings of the reference window and the string window, three output rows of 64 bytes.
+// LDS of one wave: 128-byte rings of the reference window and the string window, three output rows of 64 bytes, the deletion
+// draws of 256 columns (one Philox block holds four columns' draws: the 64 lanes compute the blocks of four steps at once).
+// The ordered f64 sum of error probabilities is NOT taken here: 64 dependent adds per step were a third of the step's
+// instructions; k_sample_qsum takes it afterwards from the quality row, one LANE per read (the same additions in the same order).
 // ---------------------------------------------------------------------------
-constexpr int kSCoopRef = 0, kSCoopQ = 128, kSCoopRows = 256, kSCoopWaveLds = 448;
+constexpr int kSCoopRef = 0, kSCoopQ = 128, kSCoopRows = 256, kSCoopD = 448, kSCoopWaveLds = 448 + 1024;
 
-__device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uint8_t *s_comp, const uint8_t *s_sub, const uint32_t *s_subt,
-                                                  const uint32_t *s_ins, const uint32_t *s_del, const double *s_qprob, uint8_t *s_w,
-                                                  int lw, int l, int lane) {
-  uint8_t *s_ref = s_w + kSCoopRef, *s_q = s_w + kSCoopQ, *s_tr = s_w + kSCoopRows;
+__device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uint8_t *s_comp, const uint8_t *s_sub, const uint2 *s_si,
+                                                  const uint32_t *s_del, uint8_t *s_w, int lw, int l, int lane) {
+  uint8_t *s_ref = s_w + kSCoopRef, *s_q = s_w + kSCoopQ, *s_tr = s_w + kSCoopRows, *s_d = s_w + kSCoopD;
   const int line = lw * 64 + l;
   if (line >= a.n_lines) return;
   int Lcur = __builtin_amdgcn_readfirstlane(a.line_len[line]);
@@ -1722,14 +1724,17 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
 
     int m0 = 0, ro0 = 0, q0 = 0, nsub = 0;
     uint32_t lastq_in = 0, hp_in = 0;  // nothing emitted, no reference base consumed yet: mut.hp[-1], observed 0 (Q15)
-    double qsum = 0.0;
     bool more = L > 0;
     while (more) {
       const uint32_t event = (uint32_t)(m0 + lane);
       const U4 w = walk_block(a.seed, a.unit, read_idx, 0u, event, 0u);
-      const U4 dq = walk_block(a.seed, a.unit, read_idx, 0u, event >> 2, 2u);
-      const uint32_t dsel = event & 3u;
-      const uint32_t dw = dsel == 0 ? dq.x : dsel == 1 ? dq.y : dsel == 2 ? dq.z : dq.w;
+      if ((m0 & 255) == 0) {  // m0 is a multiple of 64 here: the blocks of columns m0 .. m0 + 255, lane i holds group m0 / 4 + i
+        const U4 dq = walk_block(a.seed, a.unit, read_idx, 0u, (uint32_t)(m0 >> 2) + (uint32_t)lane, 2u);
+        wave_sync();
+        *reinterpret_cast<uint4 *>(s_d + lane * 16) = make_uint4(dq.x, dq.y, dq.z, dq.w);
+        wave_sync();
+      }
+      const uint32_t dw = *reinterpret_cast<const uint32_t *>(s_d + (((m0 & 255) + lane) << 2));  // group (event >> 2), word (event & 3)
       const uint32_t z = mod1e6(w.z), d = mod1e6(dw);
       uint64_t delm = __ballot(event > 0u && d < s_del[lastq_in * 12u + hp_in]);  // first guess
       uint32_t qv = 0, raw = 0;
@@ -1738,10 +1743,13 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
       for (;;) {
         emitted = ((delm >> lane) & 1ull) == 0;
         const int qi = q0 + __builtin_popcountll(~delm & below);
-        qv = conv(s_q[qi & 127]);
-        const uint32_t lq = (qi == q0) ? lastq_in : conv(s_q[(qi - 1) & 127]);
-        is_sub = z < s_subt[qv];               // pbsim.cpp:1779-1810
-        is_ins = !is_sub && z < s_ins[qv];
+        // (every read is unconditional and the two of a pair are issued together: a branch around a read costs its latency)
+        const uint32_t c_at = s_q[qi & 127], c_prev = s_q[(qi - 1) & 127];
+        qv = conv(c_at);
+        const uint32_t lq = (qi == q0) ? lastq_in : conv(c_prev);
+        const uint2 si = s_si[qv];
+        is_sub = z < si.x;                      // pbsim.cpp:1779-1810
+        is_ins = !is_sub && z < si.y;
         consm = __ballot(!emitted || !is_ins);  // a column uses a reference base unless it is an emitted insertion
         const int roi = ro0 + (int)mbcnt64(consm);
         raw = s_ref[roi & 127];
@@ -1773,23 +1781,6 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
         scratch_store(&maf_read[(size_t)(m0 >> 2) + lane], reinterpret_cast<const uint32_t *>(s_tr)[lane]);
         scratch_store(&maf_ref[(size_t)(m0 >> 2) + lane], reinterpret_cast<const uint32_t *>(s_tr + 64)[lane]);
         scratch_store(&qual_row[(size_t)(m0 >> 2) + lane], reinterpret_cast<const uint32_t *>(s_tr + 128)[lane]);
-      }
-      // ---- the ordered sum of error probabilities (pbsim.cpp:1857-1860): lane by lane, in column order (+ 0.0 changes nothing)
-      {
-        const double mine = (emitted && ((valid >> lane) & 1ull)) ? s_qprob[qv] : 0.0;
-        const uint32_t mlo = (uint32_t)__double_as_longlong(mine), mhi = (uint32_t)((unsigned long long)__double_as_longlong(mine) >> 32);
-        if (nv == 64) {
-#pragma unroll
-          for (int i = 0; i < 64; i++) {
-            const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, i), vhi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, i);
-            qsum += __longlong_as_double((long long)(((unsigned long long)vhi << 32) | vlo));
-          }
-        } else {
-          for (int i = 0; i < nv; i++) {
-            const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, i), vhi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, i);
-            qsum += __longlong_as_double((long long)(((unsigned long long)vhi << 32) | vlo));
-          }
-        }
       }
       const uint64_t em_valid = ~delm & valid;
       nsub += __builtin_popcountll(__ballot(emitted && is_sub) & valid);
@@ -1823,8 +1814,7 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
       a.maf_len[task] = m0;
       a.nsub[task] = nsub;
       a.nins[task] = m0 - ro0;
-      a.ndel[task] = m0 - q0;
-      a.qsum[task] = qsum;
+      a.ndel[task] = m0 - q0;   // a.qsum[task]: k_sample_qsum
     }
     Lcur = q0;                    // the string is cut to this read's length (:1834)
   }
@@ -1835,6 +1825,7 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
   __shared__ uint8_t s_comp[512];
   __shared__ uint8_t s_sub[1024];
   __shared__ uint32_t s_subt[96], s_ins[96], s_del[94 * 12];
+  __shared__ uint2 s_si[96];  // {sub_thre, ins_thre}: one read for the wave walker
   __shared__ double s_qprob[94];
   __shared__ __attribute__((aligned(16))) uint8_t s_wave[(kWG / 64) * kSCoopWaveLds];
   const int tid = threadIdx.x;
@@ -1851,6 +1842,7 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
     for (int i = tid; i < 94; i += kWG) {
       s_subt[i] = a.sub_thre[i];
       s_ins[i] = a.ins_thre[i];
+      s_si[i] = make_uint2(a.sub_thre[i], a.ins_thre[i]);
       s_qprob[i] = a.qprob[i];
     }
     for (int i = tid; i < 94 * 12; i += kWG) s_del[i] = a.del_thr[i];
@@ -1862,7 +1854,7 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_units = a.n_coop_waves * 64;
     for (int u = (int)blockIdx.x * (kWG / 64) + wv; u < n_units; u += a.n_coop_blocks * (kWG / 64))
-      scoop_walk_string(a, s_comp, s_sub, s_subt, s_ins, s_del, s_qprob, s_wave + wv * kSCoopWaveLds, u >> 6, u & 63, lane);
+      scoop_walk_string(a, s_comp, s_sub, s_si, s_del, s_wave + wv * kSCoopWaveLds, u >> 6, u & 63, lane);
     return;
   }
   const int lw = a.n_coop_waves + ((int)blockIdx.x - a.n_coop_blocks) * (kWG / 64) + (tid >> 6);
@@ -1977,6 +1969,46 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
       Lcur = q;                   // the string is cut to this read's length (:1834)
     }
   }
+}
+
+// The ordered sum of error probabilities (pbsim.cpp:1857-1860) of the reads the wave walker made: one LANE per read over its
+// quality row (rows stored task by task; a deleted column holds 0, an emitted one its character), the additions the lane
+// walker performs column by column, in the same order.  `n_slots` = 64 x the virtual waves of the coop line waves.
+__global__ __launch_bounds__(256) void k_sample_qsum(SampleArgs a, int n_slots) {
+  __shared__ double s_qprob[94];
+  for (int i = threadIdx.x; i < 94; i += 256) s_qprob[i] = a.qprob[i];
+  __syncthreads();
+  const int slot = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (slot >= n_slots) return;
+  const int task = a.task_of_slot[slot];
+  if (task < 0) return;
+  const int wave = slot >> 6;
+  const int cap_dw = a.wave_cap[wave] & ~kWaveTransposed;
+  const uint32_t *row = reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave]) + (size_t)(slot & 63) * cap_dw + (size_t)cap_dw * 128;
+  const int n = a.maf_len[task];
+  const int n_dw = (n + 3) >> 2;
+  double sum = 0.0;
+  // sixteen dwords (64 columns) per turn, the next sixteen on their way while these are added: a lane's loads are its own
+  // row's, one 64-byte line per turn, and waiting for each cost 0.5 us per four columns
+  uint32_t cur[16], nxt[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) cur[i] = (i < n_dw) ? row[i] : 0u;
+  for (int g0 = 0; g0 < n_dw; g0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) nxt[i] = (g0 + 16 + i < n_dw) ? row[g0 + 16 + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t ch = (cur[i] >> (8 * j)) & 0xffu;
+        const double qp = s_qprob[ch >= 33u ? ch - 33u : 0u];
+        sum += ((g0 + i) * 4 + j < n && ch != 0) ? qp : 0.0;  // + 0.0 changes nothing
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) cur[i] = nxt[i];
+  }
+  a.qsum[task] = sum;
 }
 
 // ---------------------------------------------------------------------------
@@ -2873,6 +2905,11 @@ void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s) {
   const dim3 grid((unsigned)(a.n_coop_blocks + (lane_waves + kWG / 64 - 1) / (kWG / 64))), block(kWG);
   if (hp_bits) hipLaunchKernelGGL((k_walk_sample<true>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((k_walk_sample<false>), grid, block, 0, s, a);
+}
+
+void launch_sample_qsum(const SampleArgs &a, hipStream_t s) {
+  if (a.n_coop_slots <= 0) return;
+  hipLaunchKernelGGL(k_sample_qsum, dim3((unsigned)((a.n_coop_slots + 255) / 256)), dim3(256), 0, s, a, a.n_coop_slots);
 }
 
 void launch_exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t n, int64_t *tmp, int64_t *total,

@@ -16,8 +16,8 @@ INPUTS = os.path.join(harness.GOLDEN, "inputs")
 
 @pytest.fixture(autouse=True, params=["default", "-1", "0", "1500"])
 def walker_split(request, monkeypatch):
-    """which strings get a whole wave (scoop_walk_string, round 3) and which a lane: default = every string of these small
-    profiles; -1 none; 0 all; 1500 = the line waves whose strings all have >= 1500 characters.  Same bytes every time."""
+    """which strings get a whole wave (scoop_walk_string, round 3) and which a lane: default = 0 = every string; -1 none;
+    1500 = the line waves whose strings all have >= 1500 characters.  Same bytes every time."""
     if request.param == "default":
         monkeypatch.delenv("PBSIM_COOP_LEN", raising=False)
     else:
@@ -106,10 +106,10 @@ def test_high_quality_profile(tmp_path):
 
 
 def test_large_profile_default_split(tmp_path, walker_split):
-    """30 000 strings (more than a small chunk): by default the line waves of at least twice the mean length go to the wave
-    walker, the rest to the lanes; second sweep over every 2nd..nth string"""
-    if walker_split not in ("default", "-1"):
-        pytest.skip("the split is the default's")
+    """30 000 strings, 470 line waves, a second sweep over every nth string: all on waves (default), all on lanes, and the
+    line waves of >= 1500 characters on waves beside the others on lanes in one launch"""
+    if walker_split == "0":
+        pytest.skip("0 is the default")
     import numpy as np
     rng = np.random.default_rng(5)
     n = 30000

@@ -41,6 +41,11 @@ for k in range(k0, k1):
         except RuntimeError as e:
             print(k, "oracle refused:", str(e)[-90:].replace("\n", " "))
             continue
+        split = r.choice([None, None, "-1", "0", "300", "2000"])  # which strings get a wave each (scoop_walk_string), which a lane
+        if split is None:
+            os.environ.pop("PBSIM_COOP_LEN", None)
+        else:
+            os.environ["PBSIM_COOP_LEN"] = split
         try:
             got = run_product(args, r.choice([None, 16, 64]))
         except Exception as e:
@@ -49,7 +54,7 @@ for k in range(k0, k1):
             continue
         for key, v in got.items():
             if v != want[key]:
-                print(k, "MISMATCH", key, len(v), len(want[key]), args)
+                print(k, "MISMATCH", key, len(v), len(want[key]), "split", split, args)
                 bad += 1
                 break
 print("swept", k1 - k0, "cases,", bad, "bad")
