@@ -1812,10 +1812,9 @@ struct SampleChunks {
   // most 2^18 strings -- four lane waves per SIMD, which cannot hide the lanes' latencies.  Default: every string (measured on
   // 200 000 strings, 2 Gbases: 42-53 ms against 60 with the strings below twice the mean length on lanes and 78-152 with all of
   // them there).  PBSIM_COOP_LEN as for the HMM walks: -1 none, 0 all, n = the line waves whose strings all have >= n
-  // characters.  --hp-del-bias keeps the lanes (byte-form homopolymer array).  Depends on the chunk alone: every rank of a
-  // sharded run decides alike.
+  // characters.  Depends on the chunk alone: every rank of a sharded run decides alike.
   int32_t coop_waves(const std::vector<Ent> &cand, size_t n_c) const {
-    if (!c->seq_hp_flag || n_c == 0) return 0;
+    if (n_c == 0) return 0;
     const int32_t n_w = (int32_t)((n_c + 63) / 64);
     const char *e = getenv("PBSIM_COOP_LEN");
     int64_t thr = e ? atoll(e) : -2;

@@ -1675,11 +1675,13 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm_coop(WalkArgs a) {
 // The ordered f64 sum of error probabilities is NOT taken here: 64 dependent adds per step were a third of the step's
 // instructions; k_sample_qsum takes it afterwards from the quality row, one LANE per read (the same additions in the same order).
 // ---------------------------------------------------------------------------
-constexpr int kSCoopRef = 0, kSCoopQ = 128, kSCoopRows = 256, kSCoopD = 448, kSCoopWaveLds = 448 + 1024;
+constexpr int kSCoopRef = 0, kSCoopQ = 128, kSCoopRows = 256, kSCoopD = 448, kSCoopHp = 448 + 1024, kSCoopWaveLds = 448 + 1024 + 128;
 
+template <bool kHpBits>
 __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uint8_t *s_comp, const uint8_t *s_sub, const uint2 *s_si,
                                                   const uint32_t *s_del, uint8_t *s_w, int lw, int l, int lane) {
   uint8_t *s_ref = s_w + kSCoopRef, *s_q = s_w + kSCoopQ, *s_tr = s_w + kSCoopRows, *s_d = s_w + kSCoopD;
+  uint8_t *s_hp = s_w + kSCoopHp;  // !kHpBits (--hp-del-bias): the homopolymer classes come from the byte array, a third ring
   const int line = lw * 64 + l;
   if (line >= a.n_lines) return;
   int Lcur = __builtin_amdgcn_readfirstlane(a.line_len[line]);
@@ -1710,6 +1712,12 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
       p = p < 0 ? 0 : (p > p_last ? p_last : p);
       return a.ref.seq[p];
     };
+    auto hp_at = [&](int t) -> uint8_t {
+      int64_t p = minus ? (p_first - t) : (p_first + t);
+      p = p < 0 ? 0 : (p > p_last ? p_last : p);
+      return a.ref.hp[p];
+    };
+    auto hp_class = [](uint32_t b) -> uint32_t { return kHpBits ? ((b & 0x80u) ? 11u : 1u) : (b < 12u ? b : 11u); };
     auto q_at = [&](int t) -> uint8_t { return qsrc[t < L ? t : (L > 0 ? L - 1 : 0)]; };
     auto conv = [](uint32_t ch) -> uint32_t { return (ch >= 33u && ch < 127u) ? ch - 33u : 0u; };
     // rings: positions wb .. wb + 127 of the read's reference window, qb .. qb + 127 of the string; the next 64 of each on their way
@@ -1719,7 +1727,12 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
     s_ref[64 + lane] = ref_at(64 + lane);
     s_q[lane] = q_at(lane);
     s_q[64 + lane] = q_at(64 + lane);
-    uint8_t pre_ref = ref_at(128 + lane), pre_q = q_at(128 + lane);
+    uint8_t pre_ref = ref_at(128 + lane), pre_q = q_at(128 + lane), pre_hp = 0;
+    if (!kHpBits) {
+      s_hp[lane] = hp_at(lane);
+      s_hp[64 + lane] = hp_at(64 + lane);
+      pre_hp = hp_at(128 + lane);
+    }
     wave_sync();
 
     int m0 = 0, ro0 = 0, q0 = 0, nsub = 0;
@@ -1753,8 +1766,8 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
         consm = __ballot(!emitted || !is_ins);  // a column uses a reference base unless it is an emitted insertion
         const int roi = ro0 + (int)mbcnt64(consm);
         raw = s_ref[roi & 127];
-        const uint32_t prevb = s_ref[(roi - 1) & 127];
-        const uint32_t hsel = (roi == ro0) ? hp_in : ((prevb & 0x80u) ? 11u : 1u);
+        const uint32_t prevb = (kHpBits ? s_ref : s_hp)[(roi - 1) & 127];
+        const uint32_t hsel = (roi == ro0) ? hp_in : hp_class(prevb);
         const uint32_t thr = s_del[lq * 12u + hsel];  // :1816-1831
         valid = __ballot(roi < L && qi < L && m0 + lane < cap);  // :1776
         const uint64_t newm = __ballot(event > 0u && d < thr);
@@ -1786,7 +1799,7 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
       nsub += __builtin_popcountll(__ballot(emitted && is_sub) & valid);
       const int ro_new = ro0 + __builtin_popcountll(consm & valid);
       if (em_valid) lastq_in = (uint32_t)__builtin_amdgcn_readlane((int)qv, 63 - __builtin_clzll(em_valid));
-      if (ro_new > ro0) hp_in = ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_ref[(ro_new - 1) & 127]) & 0x80u) ? 11u : 1u;
+      if (ro_new > ro0) hp_in = hp_class((uint32_t)__builtin_amdgcn_readfirstlane((int)(kHpBits ? s_ref : s_hp)[(ro_new - 1) & 127]));
       q0 += __builtin_popcountll(em_valid);
       ro0 = ro_new;
       m0 += nv;
@@ -1794,8 +1807,10 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
       if (more && ro0 - wb >= 64) {  // positions wb .. wb + 63 are behind the cursor: their slots take wb + 128 .. wb + 191
         wave_sync();
         s_ref[(wb + lane) & 127] = pre_ref;
+        if (!kHpBits) s_hp[(wb + lane) & 127] = pre_hp;
         wb += 64;
         pre_ref = ref_at(wb + 128 + lane);
+        if (!kHpBits) pre_hp = hp_at(wb + 128 + lane);
         wave_sync();
       }
       if (more && q0 - qb >= 64) {
@@ -1854,7 +1869,7 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_units = a.n_coop_waves * 64;
     for (int u = (int)blockIdx.x * (kWG / 64) + wv; u < n_units; u += a.n_coop_blocks * (kWG / 64))
-      scoop_walk_string(a, s_comp, s_sub, s_si, s_del, s_wave + wv * kSCoopWaveLds, u >> 6, u & 63, lane);
+      scoop_walk_string<kHpBits>(a, s_comp, s_sub, s_si, s_del, s_wave + wv * kSCoopWaveLds, u >> 6, u & 63, lane);
     return;
   }
   const int lw = a.n_coop_waves + ((int)blockIdx.x - a.n_coop_blocks) * (kWG / 64) + (tid >> 6);
