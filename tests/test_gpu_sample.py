@@ -122,3 +122,53 @@ def test_large_profile_default_split(tmp_path, walker_split):
     argv = ["--strategy", "wgs", "--method", "sample", "--sample", str(fq), "--genome", "INPUT:plain.fa",
             "--depth", "85", "--seed", "16", "--length-min", "40"]
     check(argv, tmp_path)
+
+
+def test_wave_and_lane_walkers_agree_at_scale(monkeypatch, walker_split):
+    """40 000 strings with a long tail (up to 60 000 characters), ~330 Mbases, two sweeps: the bytes and the statistics of the
+    wave walker (default) equal the lane walker's, which the cases above pin to the oracle; the oracle would need half a
+    minute for this one.  Also under --hp-del-bias (the wave walker's third ring)."""
+    if walker_split != "default":
+        pytest.skip("runs its own splits")
+    import zlib
+    import numpy as np
+    rng = np.random.default_rng(21)
+    n = 40_000
+    k = (7500.0 / 6500.0) ** 2
+    lens = np.clip(rng.gamma(k, 7500.0 / k, n), 100, 60000).astype(np.int64)
+    level = rng.integers(6, 32, n)
+    noise = rng.integers(-5, 6, int(lens.sum()), dtype=np.int8)
+    quals, o = [], 0
+    for i in range(n):
+        quals.append((np.clip(level[i] + noise[o:o + lens[i]], 0, 93).astype(np.uint8) + 33).tobytes())
+        o += int(lens[i])
+    g = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 20_000_000)].copy()
+    for p in rng.integers(0, len(g) - 40, 4000):   # homopolymers past the hp == 11 class, some non-ACGT bases
+        g[p:p + int(rng.integers(8, 30))] = g[p]
+    for p in rng.integers(0, len(g) - 8, 1500):
+        g[p:p + int(rng.integers(1, 6))] = ord("N")
+    genome = g.tobytes()
+
+    def run(split, bias):
+        if split is None:
+            monkeypatch.delenv("PBSIM_COOP_LEN", raising=False)
+        else:
+            monkeypatch.setenv("PBSIM_COOP_LEN", split)
+        p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_SAMPLE, seed=9, depth=16.5, hp_del_bias=bias)
+        with P.Context(p, 0) as ctx:
+            ctx.set_scratch_bytes(6 << 30)
+            ctx.set_sample_profile(quals)
+            if bias != 1:
+                ctx.add_hp_census(genome)
+                ctx.finish_hp_census()
+            ctx.set_reference(genome, 1)
+            rt, mt = ctx.simulate_sample()
+            st = ctx.stats()
+            stats = tuple(getattr(st, f[0]) for f in st._fields_)
+        return zlib.crc32(rt), len(rt), zlib.crc32(mt), len(mt), stats
+
+    for bias in (1.0, 3.0):
+        want = run("-1", bias)
+        assert want[1] > 300_000_000 and want[4][0] > 0
+        assert run(None, bias) == want, bias
+        assert run("9000", bias) == want, bias
