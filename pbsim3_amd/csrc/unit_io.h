@@ -46,6 +46,9 @@ struct SampleProfile {
 // parse + filter a FASTQ (line-feed counting and BUF_SIZE chunking as in the reference)
 bool read_sample_fastq(const char *file, long len_min, long len_max, double acc_min, double acc_max, SampleProfile *out,
                        std::string *err);
+// the same through fgets, chunk by chunk as the reference reads it (files with NUL bytes, pipes; the checker of the fast path)
+bool read_sample_fastq_stdio(const char *file, long len_min, long len_max, double acc_min, double acc_max, SampleProfile *out,
+                             std::string *err);
 // sample_profile_<ID>.fastq (one quality string per line) + .stats ("key<TAB>value" lines)
 bool write_sample_profile(const std::string &fq, const std::string &stats, const SampleProfile &p, std::string *err);
 bool read_sample_profile(const std::string &fq, const std::string &stats, SampleProfile *out, std::string *err);

@@ -2,8 +2,27 @@
 #include <string>
 #include "unit_io.h"
 using namespace pbsim;
+static int compare(const char *file, long lmin, long lmax, double amin, double amax) {
+  SampleProfile a, b;
+  std::string ea, eb;
+  const bool oa = read_sample_fastq(file, lmin, lmax, amin, amax, &a, &ea), ob = read_sample_fastq_stdio(file, lmin, lmax, amin, amax, &b, &eb);
+  const bool same = oa == ob && ea == eb &&
+                    (!oa || (a.num == b.num && a.len_min == b.len_min && a.len_max == b.len_max && a.len_total == b.len_total &&
+                             a.num_filtered == b.num_filtered && a.len_min_filtered == b.len_min_filtered &&
+                             a.len_max_filtered == b.len_max_filtered && a.len_total_filtered == b.len_total_filtered &&
+                             a.len_mean_filtered == b.len_mean_filtered && a.len_sd_filtered == b.len_sd_filtered &&
+                             a.accuracy_mean_filtered == b.accuracy_mean_filtered && a.accuracy_sd_filtered == b.accuracy_sd_filtered &&
+                             a.quals == b.quals));
+  printf("cmp %s ok=%d kept=%ld same=%d %s\n", file, (int)oa, oa ? a.num_filtered : -1, (int)same, ea.c_str());
+  return same ? 0 : 1;
+}
 int main(int argc, char **argv) {
   std::string e;
+  if (argc > 2 && std::string(argv[1]) == "--cmp") {  // the mapped, threaded sample-FASTQ parse against the fgets one
+    int bad = 0;
+    for (int i = 2; i < argc; i++) bad += compare(argv[i], 100, 1000000, 0.75, 1.0) + compare(argv[i], 30, 5000, 0.5, 0.97);
+    return bad ? 1 : 0;
+  }
   SampleProfile p;
   if (!read_sample_fastq(argv[1], 100, 1000000, 0.75, 1.0, &p, &e)) { printf("ERR %s\n", e.c_str()); return 1; }
   printf("num %ld filt %ld tot %lld mean %f sd %f acc %f %f\n", p.num, p.num_filtered, p.len_total_filtered, p.len_mean_filtered, p.len_sd_filtered, p.accuracy_mean_filtered, p.accuracy_sd_filtered);

@@ -11,7 +11,7 @@ import harness
 
 CSRC = os.path.join(harness.ROOT, "pbsim3_amd", "csrc")
 HERE = os.path.join(harness.ROOT, "tests", "asan")
-FLAGS = ["-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+FLAGS = ["-std=c++17", "-g", "-O1", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
          "-I" + CSRC, "-I" + os.path.join(harness.ROOT, "include")]
 MODELS = ["ERRHMM-RSII.model", "ERRHMM-SEQUEL.model", "ERRHMM-ONT.model", "ERRHMM-ONT-HQ.model", "QSHMM-RSII.model",
           "QSHMM-ONT.model"]
@@ -37,6 +37,41 @@ def test_parsers_under_asan(tmp_path):
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert "num 153 filt 124 tot 133973" in p.stdout and "same=1" in p.stdout
     assert "rec 1 len 17104" in p.stdout and "tr 12 exp 45" in p.stdout
+
+
+def test_mapped_sample_parse_equals_the_fgets_parse(tmp_path):
+    """read_sample_fastq (mmap, memchr, per-string sums on threads) against read_sample_fastq_stdio (the reference's fgets loop,
+    BUF_SIZE chunks) under ASan: every statistic bit for bit and every kept string, on files with lines longer than BUF_SIZE,
+    CR LF, empty lines, a missing final line feed, a truncated record, characters outside '!'..'~', a NUL byte (falls back),
+    nothing in range (the same error), and 6 000 records (the threaded path)."""
+    import random
+    exe = build(tmp_path, "parsers_driver", "unit_io.cpp")
+    r = random.Random(7)
+
+    def rec(i, n, lo=5, hi=40, eol="\n"):
+        q = "".join(chr(33 + r.randint(lo, hi)) for _ in range(n))
+        return "@r%d%s%s%s+%s%s%s" % (i, eol, "A" * n, eol, eol, q, eol)
+
+    files = {}
+    files["plain"] = "".join(rec(i, r.randint(20, 3000)) for i in range(200))
+    files["long_lines"] = "".join(rec(i, r.choice([10239, 10240, 10241, 20479, 20480, 31000, 150])) for i in range(30))
+    files["crlf"] = "".join(rec(i, r.randint(100, 900), eol="\r\n") for i in range(50))
+    files["empty_lines"] = rec(0, 300) + "\n\n\n\n" + rec(1, 400) + "\n" + rec(2, 500) + rec(3, 200)
+    files["no_final_lf"] = "".join(rec(i, 250) for i in range(5))[:-1]
+    files["truncated"] = "".join(rec(i, 250) for i in range(5)) + "@last\nACGT\n+\n"
+    files["odd_bytes"] = rec(0, 300, 0, 0) + "@x\nAC\n+\n" + "\x7f\x80\xff \t" * 60 + "\n" + rec(1, 300, 60, 93)
+    files["with_nul"] = rec(0, 300) + "@n\nAC\n+\n" + "I" * 150 + "\0" + "I" * 150 + "\n" + rec(1, 300)
+    files["nothing_in_range"] = "".join(rec(i, 50, 0, 3) for i in range(10))
+    files["many"] = "".join(rec(i, r.randint(100, 1500)) for i in range(6000))
+    paths = []
+    for name, text in files.items():
+        p = tmp_path / (name + ".fastq")
+        p.write_bytes(text.encode("latin-1"))
+        paths.append(str(p))
+    p = subprocess.run([exe, "--cmp"] + paths, capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert p.stdout.count("same=1") == 2 * len(paths) and "same=0" not in p.stdout
+    assert "many.fastq ok=1 kept=6000" in p.stdout
 
 
 def test_table_builders_under_asan(tmp_path):
