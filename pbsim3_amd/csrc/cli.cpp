@@ -574,6 +574,16 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
   const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
   const bool rank0 = rank == 0;
   const bool sampling = c.p.method == PBSIM_METHOD_SAMPLE;
+  // PBSIM_TRACE: where the process's wall time goes, phase by phase (stderr, not part of the report)
+  const bool trace = getenv("PBSIM_TRACE") != nullptr;
+  struct timespec ts0;
+  clock_gettime(CLOCK_MONOTONIC, &ts0);
+  auto phase = [&](const char *what) {
+    if (!trace || !rank0) return;
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "[pbsim cli] %8.1f ms  %s\n", (t.tv_sec - ts0.tv_sec) * 1e3 + (t.tv_nsec - ts0.tv_nsec) * 1e-6, what);
+  };
   const std::string profile_fq = "sample_profile_" + c.profile_id + ".fastq",
                     profile_stats = "sample_profile_" + c.profile_id + ".stats";
   if (world > 1) {
@@ -616,8 +626,10 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
     }
   }
 
+  phase("parameters printed, sample profile parsed");
   pbsim_ctx *ctx = pbsim_create(&c.p, c.device);
   if (!ctx) check(0);
+  phase("context created (HIP initialised)");
   if (sampling) {
     std::vector<const uint8_t *> qp;
     std::vector<int64_t> ql;
@@ -626,6 +638,7 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       ql.push_back((int64_t)q.size());
     }
     check(pbsim_set_sample_profile(ctx, (int64_t)qp.size(), qp.data(), ql.data()));
+    phase("sample profile on the GPU");
   } else {
     check(c.p.method == PBSIM_METHOD_ERR ? pbsim_load_errhmm(ctx, c.model.c_str()) : pbsim_load_qshmm(ctx, c.model.c_str()));
   }
@@ -747,12 +760,15 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       open_sink(c, &o_maf, name, std::string(name) + ".gz", false);
       Two two = {&o_read, &o_maf};
       pbsim_sink sink = {&two, cb_read, cb_maf};
+      phase("record loaded, sinks open");
       check(sampling ? pbsim_simulate_sample(ctx, &sink) : pbsim_simulate_wgs(ctx, &sink));
+      phase("record simulated and delivered");
       pbsim_stats st;
       check(pbsim_get_stats(ctx, &st));
       print_simulation_stats(c, st, n);
       o_read.close();
       o_maf.close();
+      phase("files closed");
     }
   } else {  // pbsim.cpp:761-812 (trans), 813-866 (templ)
     const bool templ = c.p.strategy == PBSIM_STRATEGY_TEMPL;

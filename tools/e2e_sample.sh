@@ -22,10 +22,10 @@ print("fastq bytes", int(lens.sum())*2)
 PY
 for mode in "" "--no-gzip"; do
   t0=$(date +%s.%N)
-  pbsim3_amd/bin/pbsim --strategy wgs --method sample --sample $d/s.fastq --genome $d/g.fa --depth 20 --seed 1 --prefix $d/out $mode 2> $d/err.txt
+  PBSIM_TRACE=1 pbsim3_amd/bin/pbsim --strategy wgs --method sample --sample $d/s.fastq --genome $d/g.fa --depth 20 --seed 1 --prefix $d/out $mode 2> $d/err.txt
   rc=$?
   t1=$(date +%s.%N)
-  echo "mode=[$mode] rc=$rc wall $(python3 -c "print(round($t1 - $t0, 2))") s"; grep "read num\|depth :" $d/err.txt | tail -2; ls -la $d | grep out_0001 | awk '{print $5, $9}'
+  grep "pbsim cli" $d/err.txt; echo "mode=[$mode] rc=$rc wall $(python3 -c "print(round($t1 - $t0, 2))") s"; grep "read num\|depth :" $d/err.txt | tail -2; ls -la $d | grep out_0001 | awk '{print $5, $9}'
   rm -f $d/out_* sample_profile_*
 done
 rm -rf $d
