@@ -2007,7 +2007,7 @@ struct SampleChunks {
     a.n_line_waves = (int32_t)n_lw;
     a.n_coop_waves = ck.n_coop_waves;
     a.n_coop_blocks = (int32_t)std::min<int64_t>(((int64_t)ck.n_coop_waves * 64 + 3) / 4, 768);
-    a.n_coop_slots = ck.h_vbase[(size_t)ck.n_coop_waves] * 64;
+    a.n_coop_slots = (int64_t)ck.h_vbase[(size_t)ck.n_coop_waves] * 64;
     a.ref.seq = c->d_seq;
     a.ref.hp = c->d_hp.as<uint8_t>();
     a.ref.len = G;

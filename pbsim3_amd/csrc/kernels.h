@@ -132,7 +132,7 @@ struct SampleArgs {
   int32_t n_line_waves;       // ceil(n_lines / 64)
   int32_t n_coop_waves;       // the first n_coop_waves line waves (the longest strings): one WAVE per string (hp_bits only)
   int32_t n_coop_blocks;      // workgroups 0 .. n_coop_blocks - 1 walk them, the others one lane per string
-  int32_t n_coop_slots;       // 64 x their virtual waves (k_sample_qsum: one lane per slot)
+  int64_t n_coop_slots;       // 64 x their virtual waves (k_sample_qsum: one lane per slot)
   RefView ref;
   const uint8_t *quals;       // filtered quality strings, each padded to a multiple of 8 bytes
   const int64_t *line_qoff;   // [n_lines] byte offset of the string

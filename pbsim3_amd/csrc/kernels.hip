@@ -1989,15 +1989,15 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
 // The ordered sum of error probabilities (pbsim.cpp:1857-1860) of the reads the wave walker made: one LANE per read over its
 // quality row (rows stored task by task; a deleted column holds 0, an emitted one its character), the additions the lane
 // walker performs column by column, in the same order.  `n_slots` = 64 x the virtual waves of the coop line waves.
-__global__ __launch_bounds__(256) void k_sample_qsum(SampleArgs a, int n_slots) {
+__global__ __launch_bounds__(256) void k_sample_qsum(SampleArgs a, int64_t n_slots) {
   __shared__ double s_qprob[94];
   for (int i = threadIdx.x; i < 94; i += 256) s_qprob[i] = a.qprob[i];
   __syncthreads();
-  const int slot = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const int64_t slot = (int64_t)blockIdx.x * 256 + (int64_t)threadIdx.x;
   if (slot >= n_slots) return;
   const int task = a.task_of_slot[slot];
   if (task < 0) return;
-  const int wave = slot >> 6;
+  const int64_t wave = slot >> 6;
   const int cap_dw = a.wave_cap[wave] & ~kWaveTransposed;
   const uint32_t *row = reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave]) + (size_t)(slot & 63) * cap_dw + (size_t)cap_dw * 128;
   const int n = a.maf_len[task];
