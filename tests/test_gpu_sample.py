@@ -172,3 +172,16 @@ def test_wave_and_lane_walkers_agree_at_scale(monkeypatch, walker_split):
         assert want[1] > 300_000_000 and want[4][0] > 0
         assert run(None, bias) == want, bias
         assert run("9000", bias) == want, bias
+
+
+def test_strings_of_one_to_five_characters(tmp_path):
+    """--length-min 1: strings shorter than a group of four columns, next to ordinary ones and to strings longer than the record"""
+    r = random.Random(6)
+    fq = tmp_path / "short.fastq"
+    with open(fq, "w") as f:
+        for i, n in enumerate([1, 2, 3, 4, 5, 1, 700, 2, 63, 64, 65, 127, 128, 129, 30000, 3, 255, 256, 257]):
+            q = "".join(chr(33 + r.randint(4, 40)) for _ in range(n))
+            f.write("@s%d\n%s\n+\n%s\n" % (i, "T" * n, q))
+    argv = ["--strategy", "wgs", "--method", "sample", "--sample", str(fq), "--genome", "INPUT:quirk.fa",
+            "--depth", "9", "--seed", "17", "--length-min", "1", "--accuracy-min", "0.5"]
+    check(argv, tmp_path)
