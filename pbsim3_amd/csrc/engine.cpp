@@ -2006,7 +2006,13 @@ struct SampleChunks {
     a.n_lines = (int32_t)n_lines;
     a.n_line_waves = (int32_t)n_lw;
     a.n_coop_waves = ck.n_coop_waves;
-    a.n_coop_blocks = (int32_t)std::min<int64_t>(((int64_t)ck.n_coop_waves * 64 + 3) / 4, 768);
+    {
+      // persistent workgroups of the wave path: four per CU = the four waves per SIMD the kernel's 103 VGPRs allow (measured:
+      // 512 / 768 / 1024 / 1280 / 2048 workgroups -> 43.2 / 37.4 / 34.9 / 39.6 / 34.9 ms for the 2-Gbase bench; capping the
+      // kernel at 96 VGPRs for a fifth wave bought nothing).  PBSIM_SAMPLE_COOP_WG: experiment knob
+      const char *cb = getenv("PBSIM_SAMPLE_COOP_WG");
+      a.n_coop_blocks = (int32_t)std::min<int64_t>(((int64_t)ck.n_coop_waves * 64 + 3) / 4, cb && atoi(cb) > 0 ? atoi(cb) : 1024);
+    }
     a.n_coop_slots = (int64_t)ck.h_vbase[(size_t)ck.n_coop_waves] * 64;
     a.ref.seq = c->d_seq;
     a.ref.hp = c->d_hp.as<uint8_t>();

@@ -1,7 +1,8 @@
 """Where the sampling walk's time goes: the same 2.0-Gbase job (100 Mbp record, depth 20) over profiles of different length
 spread.  usage: python tools/sample_prof.py [clip ...]   (clip = longest string; 0 = every string 9 000 long)"""
-import sys, time, json
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import os, sys, time, json
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [R, os.path.join(R, "tests")]
 import numpy as np
 import torch
 import pbsim3_amd as P
