@@ -1865,11 +1865,18 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
   __syncthreads();
   const int lane = tid & 63;
   if ((int)blockIdx.x < a.n_coop_blocks) {
-    // the strings of line waves 0 .. n_coop_waves - 1 (the chunk's longest), one per wave, longest first, dealt round-robin
+    // the strings of line waves 0 .. n_coop_waves - 1 (the chunk's longest), one per wave, longest first: every wave draws its
+    // next string from a counter (flags->sums[7], zero at launch), so a wave that got a long string simply draws fewer
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_units = a.n_coop_waves * 64;
-    for (int u = (int)blockIdx.x * (kWG / 64) + wv; u < n_units; u += a.n_coop_blocks * (kWG / 64))
+    unsigned long long *ticket = reinterpret_cast<unsigned long long *>(&a.flags->sums[7]);
+    for (;;) {
+      unsigned long long t = 0;
+      if (lane == 0) t = atomicAdd(ticket, 1ull);
+      const int u = __builtin_amdgcn_readfirstlane((int)t);
+      if (u >= n_units) break;
       scoop_walk_string<kHpBits>(a, s_comp, s_sub, s_si, s_del, s_wave + wv * kSCoopWaveLds, u >> 6, u & 63, lane);
+    }
     return;
   }
   const int lw = a.n_coop_waves + ((int)blockIdx.x - a.n_coop_blocks) * (kWG / 64) + (tid >> 6);
