@@ -1907,8 +1907,9 @@ struct SampleChunks {
           lmax = std::max<int64_t>(lmax, std::min<int64_t>(e.len, G));
           n_tasks += e.num;
         }
-        const int64_t cap_dw = (2 * lmax + kScratchPad + 3) / 4;
         const int32_t transposed = (int64_t)(w0 / 64) < ck->n_coop_waves ? kWaveTransposed : 0;  // rows task by task
+        int64_t cap_dw = (2 * lmax + kScratchPad + 3) / 4;
+        if (transposed) cap_dw = (cap_dw + 3) & ~3LL;  // ... each on a 16-byte boundary (k_sample_qsum reads them 16 bytes at a time)
         for (int64_t k = 0; k < kmax; k++) {
           ck->h_cap.push_back((int32_t)cap_dw | transposed);
           ck->h_woff.push_back(need);

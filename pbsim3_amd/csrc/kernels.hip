@@ -2010,25 +2010,32 @@ __global__ __launch_bounds__(256) void k_sample_qsum(SampleArgs a, int64_t n_slo
   const int n = a.maf_len[task];
   const int n_dw = (n + 3) >> 2;
   double sum = 0.0;
-  // sixteen dwords (64 columns) per turn, the next sixteen on their way while these are added: a lane's loads are its own
-  // row's, one 64-byte line per turn, and waiting for each cost 0.5 us per four columns
-  uint32_t cur[16], nxt[16];
+  // 64 columns per turn as four 16-byte loads (the planner keeps a task-by-task row's capacity a multiple of four dwords, so
+  // every row starts on a 16-byte boundary), the next 64 on their way while these are added: a lane's loads are its own row's,
+  // one 64-byte line per turn -- 64 different lines per load instruction of the wave, so few, wide loads
+  const uint4 *row4 = reinterpret_cast<const uint4 *>(row);
+  const int n_q = (n_dw + 3) >> 2;
+  uint4 cur[4], nxt[4];
 #pragma unroll
-  for (int i = 0; i < 16; i++) cur[i] = (i < n_dw) ? row[i] : 0u;
-  for (int g0 = 0; g0 < n_dw; g0 += 16) {
+  for (int i = 0; i < 4; i++) cur[i] = (i < n_q) ? row4[i] : make_uint4(0u, 0u, 0u, 0u);
+  for (int g0 = 0; g0 < n_q; g0 += 4) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) nxt[i] = (g0 + 16 + i < n_dw) ? row[g0 + 16 + i] : 0u;
+    for (int i = 0; i < 4; i++) nxt[i] = (g0 + 4 + i < n_q) ? row4[g0 + 4 + i] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < 4; i++) {
+      const uint32_t w4[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t ch = (cur[i] >> (8 * j)) & 0xffu;
-        const double qp = s_qprob[ch >= 33u ? ch - 33u : 0u];
-        sum += ((g0 + i) * 4 + j < n && ch != 0) ? qp : 0.0;  // + 0.0 changes nothing
+      for (int d = 0; d < 4; d++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t ch = (w4[d] >> (8 * j)) & 0xffu;
+          const double qp = s_qprob[ch >= 33u ? ch - 33u : 0u];
+          sum += (((g0 + i) * 4 + d) * 4 + j < n && ch != 0) ? qp : 0.0;  // + 0.0 changes nothing
+        }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) cur[i] = nxt[i];
+    for (int i = 0; i < 4; i++) cur[i] = nxt[i];
   }
   a.qsum[task] = sum;
 }
