@@ -1997,8 +1997,12 @@ __global__ __launch_bounds__(kWG) void k_walk_sample(SampleArgs a) {
 // quality row (rows stored task by task; a deleted column holds 0, an emitted one its character), the additions the lane
 // walker performs column by column, in the same order.  `n_slots` = 64 x the virtual waves of the coop line waves.
 __global__ __launch_bounds__(256) void k_sample_qsum(SampleArgs a, int64_t n_slots) {
-  __shared__ double s_qprob[94];
-  for (int i = threadIdx.x; i < 94; i += 256) s_qprob[i] = a.qprob[i];
+  // indexed by the row's byte itself: 0 (a deleted column) adds 0.0, '!' + q adds qprob[q] -- no test per column
+  __shared__ double s_qp[256];
+  {
+    const int i = threadIdx.x;
+    s_qp[i] = (i >= 33 && i < 127) ? a.qprob[i - 33] : 0.0;
+  }
   __syncthreads();
   const int64_t slot = (int64_t)blockIdx.x * 256 + (int64_t)threadIdx.x;
   if (slot >= n_slots) return;
@@ -2008,13 +2012,15 @@ __global__ __launch_bounds__(256) void k_sample_qsum(SampleArgs a, int64_t n_slo
   const int cap_dw = a.wave_cap[wave] & ~kWaveTransposed;
   const uint32_t *row = reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave]) + (size_t)(slot & 63) * cap_dw + (size_t)cap_dw * 128;
   const int n = a.maf_len[task];
-  const int n_dw = (n + 3) >> 2;
+  const int n_full = n >> 2;                                             // dwords whose four columns all count
+  const uint32_t last_mask = (n & 3) ? (1u << (8 * (n & 3))) - 1u : 0u;  // the columns of the dword behind them that do
   double sum = 0.0;
   // 64 columns per turn as four 16-byte loads (the planner keeps a task-by-task row's capacity a multiple of four dwords, so
   // every row starts on a 16-byte boundary), the next 64 on their way while these are added: a lane's loads are its own row's,
-  // one 64-byte line per turn -- 64 different lines per load instruction of the wave, so few, wide loads
+  // one 64-byte line per turn -- 64 different lines per load instruction of the wave, so few, wide loads.  Bytes behind the
+  // read's last column are whatever the walk's last step left there: masked.
   const uint4 *row4 = reinterpret_cast<const uint4 *>(row);
-  const int n_q = (n_dw + 3) >> 2;
+  const int n_q = (n + 15) >> 4;
   uint4 cur[4], nxt[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) cur[i] = (i < n_q) ? row4[i] : make_uint4(0u, 0u, 0u, 0u);
@@ -2023,16 +2029,17 @@ __global__ __launch_bounds__(256) void k_sample_qsum(SampleArgs a, int64_t n_slo
     for (int i = 0; i < 4; i++) nxt[i] = (g0 + 4 + i < n_q) ? row4[g0 + 4 + i] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const uint32_t w4[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+      uint32_t w4[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+      double qp[16];
 #pragma unroll
       for (int d = 0; d < 4; d++) {
+        const int gi = (g0 + i) * 4 + d;
+        w4[d] = gi < n_full ? w4[d] : (gi == n_full ? (w4[d] & last_mask) : 0u);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t ch = (w4[d] >> (8 * j)) & 0xffu;
-          const double qp = s_qprob[ch >= 33u ? ch - 33u : 0u];
-          sum += (((g0 + i) * 4 + d) * 4 + j < n && ch != 0) ? qp : 0.0;  // + 0.0 changes nothing
-        }
+        for (int j = 0; j < 4; j++) qp[d * 4 + j] = s_qp[(w4[d] >> (8 * j)) & 0xffu];
       }
+#pragma unroll
+      for (int k = 0; k < 16; k++) sum += qp[k];  // in column order; + 0.0 changes nothing
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) cur[i] = nxt[i];
