@@ -707,6 +707,15 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   w.wg_order = s.wg_order;
   w.mean_len = (int32_t)c->hdr.mean_len;
   w.coop_min_len = coop_len;
+  {
+    // the wave walkers' units: drawn from a counter when every read of the batch is theirs and there are several units per
+    // workgroup (a small batch: the wave walk IS the batch's duration -- 50 000 reads 5.97 -> 4.43 ms, 20 000 reads 3.17 -> 2.59),
+    // dealt round-robin otherwise (beside a lane walk no gain, and the draw's two barriers per unit cost the job 1-2 %; one unit
+    // per workgroup has nothing to balance: QSHMM 500 reads x 10 passes 12.6 -> 13.3 ms; tools/coop_dynamic_ab.sh).
+    // PBSIM_COOP_DYNAMIC=0/1 forces either.
+    const char *cd = getenv("PBSIM_COOP_DYNAMIC");
+    w.coop_dynamic = cd ? atoi(cd) == 1 : (coop_len == 0 && n_tasks >= 4LL * kCoopWaves * kCoopWorkgroups);
+  }
   w.coop_end = s.coop_end;
   w.wave_cap = s.wave_cap;
   w.wave_off = s.wave_off;

@@ -112,6 +112,7 @@ struct WalkArgs {
   const int32_t *wg_order;
   int32_t mean_len;          // E[L] of the length table (priority thresholds)
   int32_t coop_min_len;      // errhmm: reads of at least this length belong to k_walk_errhmm_coop (a multiple of 256; INT32_MAX: none)
+  int32_t coop_dynamic;         // k_walk_errhmm_coop: units drawn from a counter (flags->sums[7]) instead of dealt round-robin
   const int32_t *coop_end;   // [ncls] their slots are class_start[c] .. coop_end[c]
   const int32_t *wave_cap;
   const int64_t *wave_off;

@@ -1150,9 +1150,18 @@ __global__ __launch_bounds__(kCoopWaves * 64) void k_walk_errhmm_coop(WalkArgs a
   uint8_t *s_comp = lds + a.stride;
   uint8_t *s_sub = s_comp + 512;
   uint8_t *s_w = s_sub + 1024 + wv * kCoopWaveLds;
-  // units of kCoopWaves tasks (one per wave, one class per workgroup), dealt round-robin to the persistent workgroups
+  // units of kCoopWaves tasks (one per wave, one class per workgroup), dealt round-robin to the persistent workgroups -- or
+  // (a.coop_dynamic) drawn from a counter: the units of a class are sorted longest first, a workgroup that drew long ones draws fewer
+  __shared__ int s_unit;
+  unsigned long long *ticket = reinterpret_cast<unsigned long long *>(&a.flags->sums[7]);
   int staged = -1, c = 0, ubase = 0;
   for (int u = blockIdx.x;; u += gridDim.x) {
+    if (a.coop_dynamic) {
+      __syncthreads();  // every wave has read the previous draw
+      if (tid == 0) s_unit = (int)atomicAdd(ticket, 1ull);
+      __syncthreads();
+      u = s_unit;
+    }
     int nc = 0;
     for (; c < a.ncls; c++) {
       nc = a.coop_end[c] - a.class_start[c];
@@ -1625,8 +1634,16 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm_coop(WalkArgs a) {
     *reinterpret_cast<double *>(&s_row[i * 8 + 4]) = a.qprob[i];
     s_row[i * 8 + 6] = s_row[i * 8 + 7] = 0;
   }
+  __shared__ int s_unit;  // a.coop_dynamic: units drawn from a counter, as in k_walk_errhmm_coop
+  unsigned long long *ticket = reinterpret_cast<unsigned long long *>(&a.flags->sums[7]);
   int staged = -1, c = 0, ubase = 0;
   for (int u = blockIdx.x;; u += gridDim.x) {
+    if (a.coop_dynamic) {
+      __syncthreads();
+      if (tid == 0) s_unit = (int)atomicAdd(ticket, 1ull);
+      __syncthreads();
+      u = s_unit;
+    }
     int nc = 0;
     for (; c < a.ncls; c++) {
       nc = a.coop_end[c] - a.class_start[c];
