@@ -708,13 +708,14 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   w.mean_len = (int32_t)c->hdr.mean_len;
   w.coop_min_len = coop_len;
   {
-    // the wave walkers' units: drawn from a counter when every read of the batch is theirs and there are several units per
-    // workgroup (a small batch: the wave walk IS the batch's duration -- 50 000 reads 5.97 -> 4.43 ms, 20 000 reads 3.17 -> 2.59),
-    // dealt round-robin otherwise (beside a lane walk no gain, and the draw's two barriers per unit cost the job 1-2 %; one unit
-    // per workgroup has nothing to balance: QSHMM 500 reads x 10 passes 12.6 -> 13.3 ms; tools/coop_dynamic_ab.sh).
-    // PBSIM_COOP_DYNAMIC=0/1 forces either.
+    // the wave walkers' units: drawn from a counter in batches of 16 k - 250 k tasks, where the wave walk decides the batch's
+    // duration and a workgroup gets several units (default split, walk kernels alone: 20 000 reads 3.17 -> 2.59 ms, 50 000
+    // 5.91 -> 4.27, 100 000 8.57 -> 7.59, 200 000 12.6 -> 12.2 -- the rounds of a job on 4-8 ranks); dealt round-robin
+    // otherwise: beside the lane walk of a full round there is no gain (400 000 reads 17.0 -> 17.2 ms, whole job -1 %: the
+    // draw costs two barriers per unit), and one unit per workgroup has nothing to balance (QSHMM 500 reads x 10 passes
+    // 12.6 -> 13.3 ms).  tools/coop_dynamic_ab.sh; PBSIM_COOP_DYNAMIC=0/1 forces either.
     const char *cd = getenv("PBSIM_COOP_DYNAMIC");
-    w.coop_dynamic = cd ? atoi(cd) == 1 : (coop_len == 0 && n_tasks >= 4LL * kCoopWaves * kCoopWorkgroups);
+    w.coop_dynamic = cd ? atoi(cd) == 1 : (coop_len != INT32_MAX && n_tasks >= 4LL * kCoopWaves * kCoopWorkgroups && n_tasks <= 250000);
   }
   w.coop_end = s.coop_end;
   w.wave_cap = s.wave_cap;
