@@ -150,3 +150,54 @@ def test_qshmm_goldens_on_either_walker(case, coop, monkeypatch):
     gold = MANIFEST[f"{case}/philox"]
     for k, v in outs.items():
         assert harness.sha(v) == gold[k]["sha256"], (case, coop, k)
+
+
+# ---- units drawn from a counter (PBSIM_COOP_DYNAMIC; the default for batches of 16 k - 250 k tasks) ------------------------
+@pytest.mark.parametrize("dynamic", ["1", "0"])
+def test_counter_drawn_units_change_nothing(dynamic, monkeypatch):
+    """both wave walkers with their units drawn from a counter (forced on small batches, where several classes and partial units
+    meet) and dealt round-robin: the lane walker's bytes and statistics"""
+    monkeypatch.setenv("PBSIM_COOP_DYNAMIC", dynamic)
+    recs = [genome(1_500_000, 1), genome(700_000, 2)]
+    for name in ("ont_default", "sequel_pass3_short_reads"):
+        want = run(-1, monkeypatch, recs, **RUNS[name])
+        for coop in (0, 4096):
+            got = run(coop, monkeypatch, recs, **RUNS[name])
+            assert got == want, (name, coop)
+    recs = [genome(900_000, 1), genome(400_000, 2)]
+    for name in ("rsii_default", "ont_deletion_heavy"):
+        want = run_qs(-1, monkeypatch, recs, **QS_RUNS[name])
+        for coop in (0, 4096):
+            got = run_qs(coop, monkeypatch, recs, **QS_RUNS[name])
+            assert got == want, (name, coop)
+
+
+def test_counter_drawn_units_at_their_default_size(monkeypatch):
+    """22 000 reads as ONE batch (the counter's default range) through the batch primitives: default split with the counter and
+    dealt round-robin, against the lane walker"""
+    import zlib
+    import pbsim3_amd as P
+    g = genome(24_000_000, 5)
+
+    def crc(coop, dynamic):
+        for k, v in (("PBSIM_COOP_LEN", coop), ("PBSIM_COOP_DYNAMIC", dynamic)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=3, depth=8.0)
+        with P.Context(p, 0) as ctx:
+            ctx.set_scratch_bytes(8 << 30)
+            ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+            ctx.set_reference(g, 1)
+            ctx.batch_walk(1, 22000)
+            info = ctx.batch_finalize(0)
+            rt, mt = ctx.batch_fetch(info)
+            waves = ctx.prof_wave_launches()
+        return (zlib.crc32(rt), len(rt), zlib.crc32(mt), len(mt), info.n_final, info.bases), waves
+
+    want, w0 = crc("-1", None)
+    assert w0 == 0 and want[4] > 16384              # the quota leaves the batch in the counter's range
+    got, w1 = crc(None, None)
+    assert w1 > 0 and got == want
+    assert crc(None, "0")[0] == want
