@@ -152,7 +152,7 @@ def cpu_baseline(model="ERRHMM-ONT.model", depth=20, sample_bp=4_000_000):
 def bench_sample(a, torch, harness, P, local):
     """Sampling method at scale: 200 000 synthetic quality strings (lengths gamma mean 9 000 / sd 7 000
     clipped to 100..60 000, per-read quality level Q8..Q30 with jitter), a 100 Mbp record, depth 20 -> 2.0 Gbases.
-    Whole job, text left in HBM; the chains make this path latency-bound (one lane per string)."""
+    Whole job, text left in HBM; one wave per string, 64 columns per step."""
     import numpy as np
     rng = np.random.default_rng(1)
     n = 200_000

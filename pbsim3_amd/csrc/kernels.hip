@@ -1669,18 +1669,20 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm_coop(WalkArgs a) {
 // K2s: the sampling method's walk (pbsim.cpp:1749-1834).  The quality string comes
 // from a sample FASTQ instead of an HMM; every filtered string is used for several
 // reads in a row and is cut to the length of the read it has just produced
-// (`mut.qc[read_offset] = '\0'`, :1834), so the copies of one string form a chain.
-// One lane per STRING: the lane walks its copies one after the other (the strings
-// of a chunk run in parallel, the chain inside a string is the reference's own
-// serial dependence).  Copy k of the 64 strings of wave w lands in "virtual wave"
-// vbase[w] + k of the scratch pool, so the text kernels see ordinary tasks.
+// (`mut.qc[read_offset] = '\0'`, :1834), so the copies of one string form a chain:
+// they are walked one after the other (the strings of a chunk run in parallel, the
+// chain inside a string is the reference's own serial dependence).  Copy k of the 64
+// strings of line wave w lands in "virtual wave" vbase[w] + k of the scratch pool, so
+// the text kernels see ordinary tasks.  k_walk_sample has two paths in one launch:
+// one WAVE per string (scoop_walk_string below, the default for every string) and
+// one LANE per string (the kernel's second half; PBSIM_COOP_LEN and the tests).
 //
 //   column m:  m >= 1 -> deletion test  D.x % 1e6 < del_thr[qc[q-1]][hp(last consumed base)]   (:1816-1831)
 //              else      error class    E.z % 1e6 vs sub_thre / ins_thre of qc[q]                (:1779-1810)
 //   ends when the reference window OR the quality string is used up                              (:1776)
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
-// K2sc (round 3): the strings of the chunk's longest line waves get one WAVE each, 64 columns per step -- the chain of a
+// K2sc (round 3): the strings of the chunk's first n_coop_waves line waves (by default all) get one WAVE each, 64 columns per step -- the chain of a
 // string's copies is serial, and so is a copy's walk in the lane version (0.6 us per column on a GPU that the strings of a
 // profile cannot fill: a 60 000-character string held the launch for 40-80 ms).  There is no state chain here; what a column
 // decides depends on the columns in front of it only through two cursors, q (characters of the string used) and ro
