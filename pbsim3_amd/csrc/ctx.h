@@ -228,6 +228,8 @@ struct Slot {
   HostBuf h_read_text, h_maf_text, h_stats, h_flags;
   DfLane df[2];                        // deflate staging: [0] read text (or any single stream), [1] MAF text beside it
   hipStream_t walk_stream = nullptr;   // low priority: the walk kernel only
+  hipEvent_t ev_sq_walk = nullptr, ev_sq_done = nullptr;  // sampling method: k_sample_qsum of this slot's chunk (ctx.sq_stream)
+  bool sq_pending = false;
   hipEvent_t ev_prep = nullptr;        // header + sort done (walk_stream waits for it)
   hipStream_t coop_stream = nullptr;   // the long reads' walk (k_walk_errhmm_coop), beside the batch's lane walk
   hipEvent_t ev_coop = nullptr;
@@ -277,8 +279,6 @@ struct pbsim_ctx {
   hipStream_t prefetch_stream = nullptr;
   // sampling method: k_sample_qsum runs beside the chunk's text emission (own stream); its sums are due at the statistics fetch
   hipStream_t sq_stream = nullptr;
-  hipEvent_t ev_sq_walk = nullptr, ev_sq_done = nullptr;
-  bool sq_pending = false;
   const void *pf_src = nullptr;
   int64_t pf_len = 0;
   bool seq_hp_flag = false;  // bit 7 of the prepared sequence bytes carries hp == 11 (k_hp_final)

@@ -314,8 +314,10 @@ void pbsim_destroy(pbsim_ctx *c) {
   if (c->ev_prof_base) (void)hipEventDestroy(c->ev_prof_base);
   if (c->prefetch_stream) (void)hipStreamDestroy(c->prefetch_stream);
   if (c->sq_stream) (void)hipStreamDestroy(c->sq_stream);
-  if (c->ev_sq_walk) (void)hipEventDestroy(c->ev_sq_walk);
-  if (c->ev_sq_done) (void)hipEventDestroy(c->ev_sq_done);
+  for (Slot &sl : c->slots) {
+    if (sl.ev_sq_walk) (void)hipEventDestroy(sl.ev_sq_walk);
+    if (sl.ev_sq_done) (void)hipEventDestroy(sl.ev_sq_done);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1022,9 +1024,9 @@ static int fetch_stats(pbsim_ctx *c, Slot &sl, int64_t n_tasks) {
   int32_t *ol = reinterpret_cast<int32_t *>(sl.h_stats.p);
   int32_t *ns = ol + n_tasks, *ni = ns + n_tasks, *nd = ni + n_tasks;
   double *qs = reinterpret_cast<double *>(nd + n_tasks);
-  if (c->sq_pending) {  // the wave-walked reads' sums (k_sample_qsum, beside the text emission)
-    HIP_OK(hipStreamWaitEvent(sl.stream, c->ev_sq_done, 0));
-    c->sq_pending = false;
+  if (sl.sq_pending) {  // the wave-walked reads' sums (k_sample_qsum, beside the text emission)
+    HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_sq_done, 0));
+    sl.sq_pending = false;
   }
   HIP_OK(hipMemcpyAsync(ol, sl.d_out_len.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
   HIP_OK(hipMemcpyAsync(ns, sl.d_nsub.p, n_tasks * 4, hipMemcpyDeviceToHost, sl.stream));
@@ -1970,8 +1972,8 @@ struct SampleChunks {
     return *last_done < copies_of(sv, last.line);
   }
 
-  // upload + walk + pass-0 prefix of the chunk on slot 0; its reads are first_read .. first_read + n_tasks - 1
-  int launch(const Chunk &ck, int64_t first_read) {
+  // upload + walk + pass-0 prefix of the chunk on the selected slot, not waited for; its reads are first_read .. first_read + n_tasks - 1
+  int enqueue(const Chunk &ck, int64_t first_read) {
     Slot &sl = c->s();
     const int64_t n_tasks = ck.n_tasks;
     const int64_t n_lines = (int64_t)ck.h_len.size(), n_lw = (int64_t)ck.h_vbase.size() - 1, V = (int64_t)ck.h_cap.size();
@@ -2050,26 +2052,33 @@ struct SampleChunks {
     a.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
     a.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
     a.flags = flags;
-    if (c->sq_pending) {  // (a chunk whose statistics were never fetched: its sums still read the pool)
-      HIP_OK(hipStreamWaitEvent(sl.stream, c->ev_sq_done, 0));
-      c->sq_pending = false;
+    if (sl.sq_pending) {  // (a chunk whose statistics were never fetched: its sums still read the pool)
+      HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_sq_done, 0));
+      sl.sq_pending = false;
     }
     launch_walk_sample(a, c->seq_hp_flag, sl.stream);
     if (a.n_coop_slots > 0) {
-      if (!c->sq_stream) {
-        HIP_OK(hipStreamCreateWithFlags(&c->sq_stream, hipStreamNonBlocking));
-        HIP_OK(hipEventCreateWithFlags(&c->ev_sq_walk, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&c->ev_sq_done, hipEventDisableTiming));
+      if (!c->sq_stream) HIP_OK(hipStreamCreateWithFlags(&c->sq_stream, hipStreamNonBlocking));
+      if (!sl.ev_sq_walk) {
+        HIP_OK(hipEventCreateWithFlags(&sl.ev_sq_walk, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&sl.ev_sq_done, hipEventDisableTiming));
       }
-      HIP_OK(hipEventRecord(c->ev_sq_walk, sl.stream));
-      HIP_OK(hipStreamWaitEvent(c->sq_stream, c->ev_sq_walk, 0));
+      HIP_OK(hipEventRecord(sl.ev_sq_walk, sl.stream));
+      HIP_OK(hipStreamWaitEvent(c->sq_stream, sl.ev_sq_walk, 0));
       launch_sample_qsum(a, c->sq_stream);
-      HIP_OK(hipEventRecord(c->ev_sq_done, c->sq_stream));
-      c->sq_pending = true;
+      HIP_OK(hipEventRecord(sl.ev_sq_done, c->sq_stream));
+      sl.sq_pending = true;
     }
     launch_gather_pass0_scan(a.out_len, n_tasks, 1, sl.d_cum.as<int64_t>(), sl.d_scan_tmp.as<int64_t>(),
                              &flags->sums[0], sl.stream);
     HIP_OK(hipGetLastError());
+    return PBSIM_SUCCEEDED;
+  }
+  // ... and the wait for it: the chunk's flags and pass-0 bases, the slot's batch state for pbsim_batch_finalize
+  int finish(const Chunk &ck, int64_t first_read) {
+    Slot &sl = c->s();
+    const int64_t n_tasks = ck.n_tasks, V = (int64_t)ck.h_cap.size();
+    sl.b_enqueued = false;
     DeviceFlags f;
     if (!read_flags(c, &f)) return PBSIM_FAILED;
     if (f.error & kErrScratchOverflow) return fail("a sampled read produced more MAF columns than its scratch holds");
@@ -2083,6 +2092,7 @@ struct SampleChunks {
     sl.b_pass0 = f.sums[0];
     return PBSIM_SUCCEEDED;
   }
+  int launch(const Chunk &ck, int64_t first_read) { return enqueue(ck, first_read) && finish(ck, first_read); }
 };
 
 int sample_common_checks(pbsim_ctx *c) {
@@ -2102,50 +2112,116 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
   NEED_DEVICE(c);
   if (!sample_common_checks(c)) return PBSIM_FAILED;
   pbsim_reset_stats(c);
-  c->cur = 0;
-  Slot &sl = c->s();
-  sl.ref = current_ref(c);
   const int64_t quota = pbsim_unit_quota(c);
   SampleChunks S;
   S.c = c;
   if (!S.init(quota)) return PBSIM_FAILED;
   const int64_t F = S.F;
+  for (int s = 0; s < 2; s++) c->slots[(size_t)s].ref = current_ref(c);
+  // Where the next chunk starts: a sweep (its sample_value, pbsim.cpp:1732, drawn from the number of reads made so far) and a
+  // string of it.  next_chunk plans the next chunk that holds anything, opening sweeps as it goes (:1922: from the second
+  // sweep on a string is used once or not at all).
+  struct Pos {
+    int64_t sv = 0, line = 0;
+    bool open = false;
+  } pos;
+  auto next_chunk = [&](int64_t res_now, Pos *at, SampleChunks::Chunk *ck) -> int {
+    for (;;) {
+      if (!at->open) {
+        at->sv = (int64_t)(header_block(c->p.seed, (uint32_t)c->unit, (uint32_t)(res_now + 1)).w % (uint32_t)F);
+        at->line = 0;
+        at->open = true;
+      }
+      while (at->line < F) {
+        if (!S.plan(at->sv, at->line, (size_t)1 << 18, ck)) return PBSIM_FAILED;
+        if (!ck->cand.empty()) return PBSIM_SUCCEEDED;
+        at->line = ck->next_probe;
+      }
+      S.sample_num = 0;
+      S.carry_line = -1;
+      at->open = false;
+    }
+  };
+  // Two slots: while a chunk's text emission, delivery and statistics are under way, the NEXT chunk is planned and walks --
+  // whenever the next chunk is determined by then (see `look` below).
+  DeferTextSync defer_guard(c);
+  SampleChunks::Chunk cks[2];
+  int cur = 0;
+  bool have = false;  // cks[cur] is planned and enqueued already
   int64_t len_total = 0, res = 0;
   bool done = false;
-  SampleChunks::Chunk ck;
+  auto drain = [&]() {
+    for (int s = 0; s < 2; s++)
+      if (c->slots[(size_t)s].stream) (void)hipStreamSynchronize(c->slots[(size_t)s].stream);
+    c->cur = 0;
+  };
   while (len_total < quota && !done) {
-    const int64_t sv = (int64_t)(header_block(c->p.seed, (uint32_t)c->unit, (uint32_t)(res + 1)).w % (uint32_t)F);  // :1732
-    int64_t line = 0;
-    while (line < F && len_total < quota && !done) {
-      if (!S.plan(sv, line, (size_t)1 << 18, &ck)) return PBSIM_FAILED;
-      if (ck.cand.empty()) {
-        line = ck.next_probe;
-        continue;
-      }
-      const SampleChunks::Ent last = ck.cand[ck.n_c - 1];
-      int64_t last_done = 0;
-      const bool last_unfinished = S.last_unfinished(sv, ck, &last_done);
-      if (!S.launch(ck, res + 1)) return PBSIM_FAILED;
-      pbsim_batch_info bi;
-      if (!pbsim_batch_finalize(c, len_total, &bi)) return PBSIM_FAILED;
-      if (!deliver(c, sink)) return PBSIM_FAILED;
-      len_total = bi.len_total_after;
-      res += bi.n_final;
-      if (bi.n_final < ck.n_tasks) done = true;  // the quota was reached inside this chunk (:1735, :1749)
-      if (last_unfinished && !done) {
-        S.carry_line = last.line;
-        S.carry_done = last_done;
-        HIP_OK(hipMemcpy(&S.carry_len, sl.d_out_len.as<int32_t>() + (ck.n_tasks - 1), 4, hipMemcpyDeviceToHost));
-        line = last.line;
-      } else {
-        S.carry_line = -1;
-        S.carry_done = 0;
-        line = last.line + 1;
+    SampleChunks::Chunk &ck = cks[cur];
+    c->cur = cur;
+    if (!have) {
+      if (!next_chunk(res, &pos, &ck) || !S.enqueue(ck, res + 1)) {
+        drain();
+        return PBSIM_FAILED;
       }
     }
-    S.sample_num = 0;  // :1922
-    S.carry_line = -1;
+    have = false;
+    const SampleChunks::Ent last = ck.cand[ck.n_c - 1];
+    int64_t last_done = 0;
+    const bool last_unfinished = S.last_unfinished(pos.sv, ck, &last_done);
+    if (!S.finish(ck, res + 1)) {
+      drain();
+      return PBSIM_FAILED;
+    }
+    // the quota cut and the text sizes; the text emission is enqueued, not waited for (DeferTextSync)
+    pbsim_batch_info bi;
+    if (!pbsim_batch_finalize(c, len_total, &bi)) {
+      drain();
+      return PBSIM_FAILED;
+    }
+    // every read of the chunk was made, its last string is finished and the quota is not reached: the next chunk is determined.
+    // It is planned, uploaded and set walking now, beside this chunk's text emission, delivery and statistics.
+    const bool look = !last_unfinished && bi.n_final == ck.n_tasks && bi.len_total_after < quota;
+    Pos pos2 = pos;
+    if (look) {
+      S.carry_line = -1;
+      S.carry_done = 0;
+      pos2.line = last.line + 1;
+      c->cur = 1 - cur;
+      if (!next_chunk(res + bi.n_final, &pos2, &cks[1 - cur]) || !S.enqueue(cks[1 - cur], res + bi.n_final + 1)) {
+        drain();
+        return PBSIM_FAILED;
+      }
+      c->cur = cur;
+    }
+    if (!deliver(c, sink)) {
+      drain();
+      return PBSIM_FAILED;
+    }
+    len_total = bi.len_total_after;
+    res += bi.n_final;
+    if (bi.n_final < ck.n_tasks) done = true;  // the quota was reached inside this chunk (:1735, :1749)
+    if (look) {
+      pos = pos2;
+      cur = 1 - cur;
+      have = true;
+      continue;
+    }
+    if (last_unfinished && !done) {
+      S.carry_line = last.line;
+      S.carry_done = last_done;
+      HIP_OK(hipMemcpy(&S.carry_len, c->s().d_out_len.as<int32_t>() + (ck.n_tasks - 1), 4, hipMemcpyDeviceToHost));
+      pos.line = last.line;
+    } else {
+      S.carry_line = -1;
+      S.carry_done = 0;
+      pos.line = last.line + 1;
+    }
   }
+  if (have) {  // (cannot happen: a chunk is only enqueued ahead when the total stays below the quota) -- nothing is left in flight
+    drain();
+    return fail("internal: a sampled chunk was left in flight");
+  }
+  c->cur = 0;
   return PBSIM_SUCCEEDED;
 }
 
