@@ -1883,9 +1883,12 @@ struct SampleChunks {
   // string from `line` on has copies (ck->next_probe == F).
   int plan(int64_t sv, int64_t line, size_t max_cand, Chunk *ck) {
     ck->cand.clear();
+    ck->cand.reserve((size_t)std::min<int64_t>((int64_t)max_cand, std::max<int64_t>(F - line, 0)));
     int64_t probe = line;
+    int64_t phase = interval > 0 ? (sv + probe) % interval : 0;  // (sv + probe) % interval, kept up to date without a division per string
     while (probe < F && ck->cand.size() < max_cand) {
-      int64_t k = copies_of(sv, probe);
+      int64_t k = sample_num + (phase == 0 ? 1 : 0);  // = copies_of(sv, probe)
+      if (++phase == interval) phase = 0;
       int32_t len = c->sq_len[(size_t)probe];
       if (probe == carry_line) {
         k -= carry_done;
@@ -2148,6 +2151,12 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
   SampleChunks::Chunk cks[2];
   int cur = 0;
   bool have = false;  // cks[cur] is planned and enqueued already
+  const bool trace = getenv("PBSIM_TRACE") != nullptr;
+  auto wall_ms = []() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  };
   int64_t len_total = 0, res = 0;
   bool done = false;
   auto drain = [&]() {
@@ -2159,10 +2168,17 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
     SampleChunks::Chunk &ck = cks[cur];
     c->cur = cur;
     if (!have) {
-      if (!next_chunk(res, &pos, &ck) || !S.enqueue(ck, res + 1)) {
+      const double t0 = trace ? wall_ms() : 0;
+      if (!next_chunk(res, &pos, &ck)) {
         drain();
         return PBSIM_FAILED;
       }
+      const double t1 = trace ? wall_ms() : 0;
+      if (!S.enqueue(ck, res + 1)) {
+        drain();
+        return PBSIM_FAILED;
+      }
+      if (trace) fprintf(stderr, "[pbsim sample] chunk of %zu strings, %lld reads: planned in %.2f ms, enqueued in %.2f ms\n", ck.n_c, (long long)ck.n_tasks, t1 - t0, wall_ms() - t1);
     }
     have = false;
     const SampleChunks::Ent last = ck.cand[ck.n_c - 1];
