@@ -2196,7 +2196,15 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
     }
     // every read of the chunk was made, its last string is finished and the quota is not reached: the next chunk is determined.
     // It is planned, uploaded and set walking now, beside this chunk's text emission, delivery and statistics.
-    const bool look = !last_unfinished && bi.n_final == ck.n_tasks && bi.len_total_after < quota;
+    bool look = !last_unfinished && bi.n_final == ck.n_tasks && bi.len_total_after < quota;
+    if (look && c->slots[(size_t)(1 - cur)].d_scratch.bytes < (size_t)c->scratch_budget) {
+      // the other slot has no pool yet: a second pool (and the text of a second chunk) must fit what the GPU has left, else
+      // the chunks simply follow each other on this slot as they did before round 3
+      size_t free_b = 0, total_b = 0;
+      HIP_OK(hipMemGetInfo(&free_b, &total_b));
+      const double text_now = (double)c->s().d_read_text.bytes + (double)c->s().d_maf_text.bytes;
+      if ((double)free_b < 1.1 * (double)c->scratch_budget + 1.5 * text_now + (double)(2ull << 30)) look = false;
+    }
     Pos pos2 = pos;
     if (look) {
       S.carry_line = -1;

@@ -185,3 +185,21 @@ def test_strings_of_one_to_five_characters(tmp_path):
     argv = ["--strategy", "wgs", "--method", "sample", "--sample", str(fq), "--genome", "INPUT:quirk.fa",
             "--depth", "9", "--seed", "17", "--length-min", "1", "--accuracy-min", "0.5"]
     check(argv, tmp_path)
+
+
+def test_second_slot_is_optional(tmp_path, walker_split):
+    """the driver sets the next chunk walking on a second slot while the current one is emitted -- unless a second scratch pool
+    does not fit the GPU's memory (here: a 150 GiB pool): then the chunks follow each other on one slot, same bytes"""
+    if walker_split != "default":
+        pytest.skip("one split is enough")
+    r = random.Random(8)
+    fq = tmp_path / "few.fastq"
+    with open(fq, "w") as f:
+        for i, n in enumerate([400, 900, 1500, 700, 2500, 350]):
+            q = "".join(chr(33 + r.randint(8, 30)) for _ in range(n))
+            f.write("@r%d\n%s\n+\n%s\n" % (i, "A" * n, q))
+    argv = ["--strategy", "wgs", "--method", "sample", "--sample", str(fq), "--genome", "INPUT:quirk.fa",
+            "--depth", "25", "--seed", "19"]
+    small = check(argv, tmp_path, 64)
+    big = check(argv, tmp_path, 150 * 1024)
+    assert small == big
