@@ -93,6 +93,56 @@ CASES["wgs_sample_reuse"] = dict(     # --sample-profile-id alone: the stored pr
                     "--depth", "1", "--seed", "4", "--accuracy-max", "0.99"],
     args=SAMPLE + ["--sample-profile-id", "g1", "--genome", "INPUT:plain.fa", "--depth", "2", "--seed", "5"])
 
+# ---- round 4 (VERDICT r3 "missing" 2, 4, 5; "weak": configs[0] verbatim) -------------------------------------------------
+# the reference's own runnable fixtures through its README commands (README.md:119-165; 100 transcripts / 2 260 reads,
+# 100 templates), committed gzip-compressed under inputs/ as data; default --seed is the clock, so the seed is named
+CASES["trans_qshmm_rsii_readme"] = dict(
+    args=["--strategy", "trans", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model",
+          "--transcript", "INPUT:sample.transcript", "--seed", "1"])
+CASES["trans_errhmm_rsii_readme"] = dict(
+    args=["--strategy", "trans", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-RSII.model",
+          "--transcript", "INPUT:sample.transcript", "--seed", "1"])
+CASES["templ_qshmm_rsii_readme"] = dict(
+    args=["--strategy", "templ", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model",
+          "--template", "INPUT:sample.template", "--seed", "1"])
+CASES["templ_qshmm_rsii_readme_pass10"] = dict(
+    args=["--strategy", "templ", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model",
+          "--template", "INPUT:sample.template", "--seed", "2", "--pass-num", "10"])
+# BASELINE.json configs[0] verbatim (sample/sample.fasta is not in the reference tree: a 1 Mbp record generated from
+# integer arithmetic, harness.synth_bases)
+CASES["wgs_errhmm_rsii_config0"] = dict(
+    args=["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-RSII.model", "--depth", "20",
+          "--genome", "INPUT:synth_1000000_1.fa", "--seed", "1"])
+# models whose cumulative tables do not end at 1000 / 100 (pbsim.cpp:3715-3789, 2066-2142: the moduli are whatever the
+# rows round to) and classes with more states than the wave walkers take: tests/golden/make_models.py
+CASES["wgs_errhmm_synthmod"] = dict(
+    args=["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:SYNTH-ERRHMM-MOD.model",
+          "--genome", "INPUT:quirk.fa", "--depth", "6", "--seed", "21"] + SHORT)
+CASES["wgs_errhmm_synthmod_acc95_hpbias3"] = dict(   # classes above the model's range (Q3) with odd moduli
+    args=["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:SYNTH-ERRHMM-MOD.model",
+          "--genome", "INPUT:quirk.fa", "--depth", "4", "--seed", "22", "--accuracy-mean", "0.95", "--hp-del-bias", "3",
+          "--pass-num", "2"] + SHORT)
+CASES["wgs_errhmm_synths35"] = dict(
+    args=["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:SYNTH-ERRHMM-S35.model",
+          "--genome", "INPUT:quirk.fa", "--depth", "6", "--seed", "23"] + SHORT)
+CASES["trans_errhmm_synthmod"] = dict(
+    args=["--strategy", "trans", "--method", "errhmm", "--errhmm", "MODEL:SYNTH-ERRHMM-MOD.model",
+          "--transcript", "INPUT:tiny.transcript", "--seed", "24"])
+CASES["wgs_qshmm_synthmod"] = dict(
+    args=["--strategy", "wgs", "--method", "qshmm", "--qshmm", "MODEL:SYNTH-QSHMM-MOD.model",
+          "--genome", "INPUT:quirk.fa", "--depth", "5", "--seed", "25"] + SHORT)
+CASES["wgs_qshmm_synthmod_pass3_acc92"] = dict(
+    args=["--strategy", "wgs", "--method", "qshmm", "--qshmm", "MODEL:SYNTH-QSHMM-MOD.model",
+          "--genome", "INPUT:quirk.fa", "--depth", "3", "--seed", "26", "--pass-num", "3", "--accuracy-mean", "0.92"] + SHORT)
+# reads near the reference's shape limit (FASTQ_LEN_MAX 1 000 000, pbsim.cpp:27): ONT ultra-long settings on a 3 Mbp
+# record -- rows of up to 2 M columns through the scratch layout, the text kernels and both walkers
+ULTRA = ["--length-mean", "200000", "--length-sd", "150000", "--length-max", "1000000", "--genome", "INPUT:synth_3000000_7.fa"]
+CASES["wgs_errhmm_ont_ultralong"] = dict(
+    args=["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-ONT.model", "--depth", "8", "--seed", "31"] + ULTRA)
+CASES["wgs_qshmm_rsii_ultralong_pass2"] = dict(
+    args=["--strategy", "wgs", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model", "--depth", "4", "--seed", "32",
+          "--pass-num", "2"] + ULTRA)
+
 # cases whose complete outputs are committed (gzip) in addition to the hashes
 FULL = ["wgs_errhmm-ont_quirk", "wgs_qshmm_rsii_pass3", "trans_errhmm_sequel"]
 

@@ -34,6 +34,64 @@ def model_path(name):
     return p
 
 
+INPUT_CACHE = os.path.join(GOLDEN, "inputs", "_unpacked")
+
+
+def synth_bases(n, seed):
+    """n pseudo-random A/C/G/T bytes from plain 64-bit integer arithmetic (splitmix64 of the position), so the file is
+    the same on every box and numpy version without being committed."""
+    import numpy as np
+    out = np.empty(n, dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    step = 1 << 22
+    with np.errstate(over="ignore"):
+        for a in range(0, n, step):
+            x = (np.arange(a, min(n, a + step), dtype=np.uint64) + np.uint64(seed * 0x632BE59BD9B4E019 & (2**64 - 1))) * np.uint64(0x9E3779B97F4A7C15)
+            x ^= x >> np.uint64(30)
+            x *= np.uint64(0xBF58476D1CE4E5B9)
+            x ^= x >> np.uint64(27)
+            x *= np.uint64(0x94D049BB133111EB)
+            x ^= x >> np.uint64(31)
+            out[a:a + len(x)] = lut[(x >> np.uint64(61)).astype(np.int64) & 3]
+    return out
+
+
+def input_path(name):
+    """tests/golden/inputs/<name>: committed as is, committed gzip-compressed (the reference's own sample files: data),
+    or generated on first use -- `synth_<bases>_<seed>.fa`: one FASTA record of that many synth_bases, 80 per line."""
+    import gzip
+    import re
+    p = os.path.join(GOLDEN, "inputs", name)
+    if os.path.exists(p):
+        return p
+    q = os.path.join(INPUT_CACHE, name)
+    if os.path.exists(q):
+        return q
+    os.makedirs(INPUT_CACHE, exist_ok=True)
+    tmp = q + ".%d.tmp" % os.getpid()
+    m = re.fullmatch(r"synth_(\d+)_(\d+)\.fa", name)
+    if os.path.exists(p + ".gz"):
+        with gzip.open(p + ".gz", "rb") as f, open(tmp, "wb") as g:
+            g.write(f.read())
+    elif m:
+        import numpy as np
+        n, seed = int(m.group(1)), int(m.group(2))
+        b = synth_bases(n, seed)
+        full = n // 80 * 80
+        lines = np.empty((full // 80, 81), dtype=np.uint8)
+        lines[:, :80] = b[:full].reshape(-1, 80)
+        lines[:, 80] = 10
+        with open(tmp, "wb") as g:
+            g.write(b">synth_%d_%d\n" % (n, seed))
+            g.write(lines.tobytes())
+            if full < n:
+                g.write(b[full:].tobytes() + b"\n")
+    else:
+        raise FileNotFoundError(name)
+    os.replace(tmp, q)
+    return q
+
+
 def build_oracle():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     return ORACLE
@@ -56,7 +114,7 @@ def resolve(args):
         if a.startswith("MODEL:"):
             out.append(model_path(a[6:]))
         elif a.startswith("INPUT:"):
-            out.append(os.path.join(GOLDEN, "inputs", a[6:]))
+            out.append(input_path(a[6:]))
         else:
             out.append(a)
     return out

@@ -5,6 +5,16 @@ import os
 import pbsim3_amd as P
 
 
+def scratch_mb_for(case):
+    """scratch pool (MB per slot) for a golden case through the job pipeline: a few MB force many rounds per record; a pool
+    must still hold one wave of the case's longest reads (64 lanes x rows x (2 L + 64) columns)"""
+    if "ultralong" in case:
+        return 1024
+    if "config0" in case:
+        return 64
+    return 32 if "default" in case else 4
+
+
 def read_fasta(path):
     from pbsim3_amd import args
     return args.read_fasta(path)[0]

@@ -68,7 +68,7 @@ def test_wave_walker_matches_lane_walker(name, monkeypatch):
 @pytest.mark.parametrize("coop", [-1, 512])
 def test_goldens_with_another_share(case, coop, monkeypatch):
     monkeypatch.setenv("PBSIM_COOP_LEN", str(coop))
-    outs, _ = product.run_wgs_job(harness.resolve(CASES[case]["args"]), scratch_mb=32 if "default" in case else 4)
+    outs, _ = product.run_wgs_job(harness.resolve(CASES[case]["args"]), scratch_mb=product.scratch_mb_for(case))
     gold = MANIFEST[f"{case}/philox"]
     for k, v in outs.items():
         assert harness.sha(v) == gold[k]["sha256"], (case, coop, k)
@@ -146,7 +146,7 @@ def test_qshmm_goldens_on_either_walker(case, coop, monkeypatch):
     """the reference's own QSHMM goldens (all three models, ratios, multi-pass, the Q15 hp-del-bias cases, which keep their
     byte-form hp array and therefore the lane walker) with every task / no task / the long tasks on the wave walker"""
     monkeypatch.setenv("PBSIM_COOP_LEN", str(coop))
-    outs, _ = product.run_wgs_job(harness.resolve(CASES[case]["args"]), scratch_mb=4)
+    outs, _ = product.run_wgs_job(harness.resolve(CASES[case]["args"]), scratch_mb=product.scratch_mb_for(case))
     gold = MANIFEST[f"{case}/philox"]
     for k, v in outs.items():
         assert harness.sha(v) == gold[k]["sha256"], (case, coop, k)

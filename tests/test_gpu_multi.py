@@ -62,7 +62,8 @@ def test_many_ranks_many_rounds(case, ranks, scratch_mb, tmp_path):
 @pytest.mark.parametrize("case,ranks", [("trans_errhmm_sequel", 2), ("trans_errhmm_ont_hpbias4", 3), ("trans_qshmm_rsii", 4),
                                         ("trans_errhmm_rsii_acc98", 3), ("trans_errhmm_sequel_acc99_pass2", 2),
                                         ("templ_errhmm_sequel", 2), ("templ_errhmm_rsii_pass3_hpbias2", 4),
-                                        ("templ_qshmm_rsii_pass2", 3)])
+                                        ("templ_qshmm_rsii_pass2", 3), ("trans_qshmm_rsii_readme", 3),
+                                        ("templ_qshmm_rsii_readme_pass10", 2), ("trans_errhmm_synthmod", 2)])
 def test_unit_strategies(case, ranks, tmp_path):
     """trans / templ: rank r takes the r-th block of the unit set's read numbering (pbsim_simulate_units_range); statistics
     merged with pbsim_stats_merge; files written by byte range"""

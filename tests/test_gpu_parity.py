@@ -8,7 +8,7 @@ import product
 from cases import CASES
 
 MANIFEST = harness.load_manifest()
-WGS_ERR = sorted(c for c in CASES if c.startswith("wgs_errhmm") and "pass3" not in c)
+WGS_ERR = sorted(c for c in CASES if c.startswith("wgs_errhmm") and "pass3" not in c)   # incl. configs[0] verbatim, the synthetic-moduli / 35- and 50-state models, ultra-long reads
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,8 @@ def test_wgs_errhmm_matches_oracle_and_golden(case, tmp_path):
         assert harness.sha(v) == gold[k]["sha256"], (case, k)
 
 
-WGS_OTHER = ["wgs_errhmm_sequel_pass3", "wgs_qshmm_rsii_pass1", "wgs_qshmm_rsii_pass3", "wgs_qshmm_ont_ratio"]
+WGS_OTHER = ["wgs_errhmm_sequel_pass3", "wgs_qshmm_rsii_pass1", "wgs_qshmm_rsii_pass3", "wgs_qshmm_ont_ratio",
+             "wgs_qshmm_synthmod", "wgs_qshmm_synthmod_pass3_acc92", "wgs_qshmm_rsii_ultralong_pass2"]
 
 
 @pytest.mark.parametrize("case", WGS_OTHER)
@@ -52,7 +53,7 @@ def test_wgs_qshmm_and_multipass_match_oracle_and_golden(case, tmp_path):
 def test_job_pipeline_matches_golden(case):
     """the same commands through pbsim_job_* (all records resident, one pipeline of rounds; a 4 MB scratch pool forces many rounds)"""
     args = harness.resolve(CASES[case]["args"])
-    outs, _ = product.run_wgs_job(args, scratch_mb=32 if "default" in case else 4)
+    outs, _ = product.run_wgs_job(args, scratch_mb=product.scratch_mb_for(case))
     gold = MANIFEST[f"{case}/philox"]
     for k, v in outs.items():
         assert harness.sha(v) == gold[k]["sha256"], (case, k)
