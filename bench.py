@@ -385,6 +385,9 @@ def main():
     ap.add_argument("--hbm-only", action="store_true", help="experiment: leave the text in HBM in the timed runs too")
     ap.add_argument("--one-gpu", action="store_true",
                     help="plumbing check: the --gpus N ranks as N contexts on GPU 0, gloo collectives (not a scaling measurement)")
+    ap.add_argument("--replay-ranks", default="",
+                    help="N=1 only: e.g. 2,4,8 -- additionally measure the per-rank critical path of the N-rank job on this one GPU, "
+                         "every rank alone against virtual ranks (tools/replay_ranks.py)")
     ap.add_argument("--param", action="append", default=[],
                     help="experiment only: override a pbsim_params field, e.g. --param len_sd=0 (not the headline workload)")
     a = ap.parse_args()
@@ -436,7 +439,9 @@ def main():
     qs = method == "qshmm"
     G, NR = a.record_len, a.records
 
+    t_c1 = time.perf_counter()
     recs = make_records(torch, dist, dev, cdev, rank, world, NR, G)
+    t_c1 = time.perf_counter() - t_c1      # generation on rank 0 + C1 (the broadcast of every record), outside the timed region
     p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=1, depth=depth, pass_num=pass_num)
     for kv in a.param:
         k, v = kv.split("=")
@@ -445,8 +450,12 @@ def main():
     (ctx.load_qshmm if qs else ctx.load_errhmm)(harness.model_path(model))
     if pass_num > 1:
         ctx.set_bam_output(True)
+    torch.cuda.synchronize()
+    t_k0 = time.perf_counter()
     for t in recs:
         ctx.job_add_record_device(t.data_ptr(), G)
+    torch.cuda.synchronize()               # K0 (upper-case + homopolymer pass, k_hp_*) of every record: also outside the timed region
+    t_k0 = time.perf_counter() - t_k0
     comm = P.torch_comm(dist, cdev) if world > 1 else None
     cref = C.byref(comm) if comm is not None else None
 
@@ -522,6 +531,32 @@ def main():
         extras["whole_job_hbm"] = {"value": job_bases / (time.perf_counter() - t1), "unit": "bases/s",
                                    "note": "the same job, FASTQ + MAF text left in HBM (no compression, no copy)"}
 
+    replays = None
+    if a.replay_ranks and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import replay_ranks as RR
+        t_tab = time.perf_counter()
+        tables = RR.build_tables(P, harness, p, model, qs, recs, G, local)
+        t_tab = time.perf_counter() - t_tab
+
+        def run_with(comm):
+            sink = CountingSink(P, C)
+            ctx.set_deflate(7 if deliver else 0)
+            if not deliver:
+                sink.sink = P.RecordSink(None, P.REC_TEXT_CB(), P.REC_TEXT_CB(), sink._cbs[2])
+            P._check(ctx.lib.pbsim_job_run(ctx.h, C.byref(comm), C.byref(sink.sink)))
+            return sink
+
+        t1_ms = dt_max * 1e3 / a.steps
+        replays = {"t1_ms": t1_ms, "table_build_s": t_tab, "table_reads": [len(t.out0) for t in tables], "by_world": {}}
+        for n in [int(x) for x in a.replay_ranks.split(",") if x]:
+            ctx.release_pools()
+            res = RR.replay(P, C, ctx, tables, n, run_with)
+            res["speedup_if_ranks_never_wait"] = t1_ms / res["max_rank_wall_ms"]
+            res["speedup_sync_upper_bound_of_time"] = t1_ms / res["sync_critical_path_ms"] if res["sync_critical_path_ms"] else None
+            replays["by_world"][str(n)] = res
+        ctx.release_pools()
+
     if rank == 0:
         K = a.steps
         c0 = counters[0]
@@ -594,11 +629,18 @@ def main():
              "solo_ref": "profiles/r02z_deflate_prof.txt: 0.36 ms per full-size launch alone (745 GB/s of text)",
              "note": "integer issue / LDS bound, not HBM: GB/s of text a lane's launches turn into members, HIP events around "
                      "k_deflate_chunks on the lane's stream; two lanes run side by side, so the GPU compresses up to twice this"}]
+        out["setup"] = {"records_generate_and_c1_broadcast_s": t_c1, "k0_prepare_s": t_k0,
+                        "value_incl_k0": job_bases / (dt_max / K + t_k0),
+                        "note": "outside the timed region (inputs resident in HBM when it starts): the records' generation on rank 0 and "
+                                "their broadcast to every rank (C1), and K0 = upper-case + homopolymer pass of every record on every rank; "
+                                "value_incl_k0 = the job's bases / (a step + K0), what a caller that hands over fresh records sees"}
         out["critical_path"] = critical_path(bd_all, K)
         out["numa"] = numa or "unbound (one node, no topology, or PBSIM_NUMA_BIND=0)"
         if one_gpu and world > 1:
             out["config"]["one_gpu"] = f"{world} ranks as {world} contexts on ONE GPU, gloo collectives: plumbing, not scaling"
         out.update(extras)
+        if replays:
+            out["replay"] = replays
     ctx.close()
     if rank == 0 and world == 1 and not a.no_extras:
         try:

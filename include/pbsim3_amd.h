@@ -220,6 +220,10 @@ int pbsim_batch_walk_begin(pbsim_ctx *ctx, int64_t first_read, int64_t n_reads, 
 int pbsim_batch_walk_end(pbsim_ctx *ctx, int64_t *pass0_bases);
 int pbsim_batch_finalize(pbsim_ctx *ctx, int64_t len_total_before, pbsim_batch_info *info);
 int pbsim_batch_fetch(pbsim_ctx *ctx, char *read_text, char *maf_text);
+/* after pbsim_batch_walk_end: the header draws and pass-0 results of the batch's reads, n_reads values each (any pointer may
+ * be NULL): raw length drawn (before the clip to the record, pbsim.cpp:3793-3794), length walked, pass-0 bases produced.  What
+ * the quota rule (pbsim.cpp:3792-3800) is a function of -- measurement / test hook. */
+int pbsim_batch_fetch_lengths(pbsim_ctx *ctx, int32_t *rawlen, int32_t *len, int32_t *out_len_pass0);
 /* adds the n_final reads of the finalized batch to the unit's statistics */
 int pbsim_batch_account(pbsim_ctx *ctx);
 /* resets the per-unit statistics (init_sim_res, pbsim.cpp:1437) */
@@ -295,7 +299,8 @@ int pbsim_job_add_record_device(pbsim_ctx *ctx, const void *seq_device, int64_t 
 int pbsim_job_add_record_comm(pbsim_ctx *ctx, const uint8_t *seq, int64_t len, const pbsim_comm *comm, int32_t root);
 int64_t pbsim_job_records(pbsim_ctx *ctx);
 /* drops the records; the next one added is record `first_record` (a genome larger than HBM runs as several jobs whose
- * numbering continues; --hp-del-bias != 1 then needs pbsim_add_hp_census / pbsim_finish_hp_census over ALL records first).
+ * numbering continues; --hp-del-bias != 1 then needs pbsim_add_hp_census / pbsim_finish_hp_census over ALL records first:
+ * pbsim_job_run of a job with first_record > 1 fails without it rather than taking a census per record group).
  * pbsim_job_clear = pbsim_job_begin(ctx, 1). */
 int pbsim_job_begin(pbsim_ctx *ctx, int64_t first_record);
 int pbsim_job_clear(pbsim_ctx *ctx);
@@ -316,6 +321,14 @@ int pbsim_job_counters(pbsim_ctx *ctx, int64_t out[8]);
  * delivery thread was busy (compression + copies + sink callbacks; runs beside the loop); [13] top-up rounds, [14] truncated
  * tail reads walked by this rank, [15] rounds kept in flight. */
 int pbsim_job_breakdown(pbsim_ctx *ctx, double out[16]);
+
+/* Which exchange of the round sequence this rank's pbsim_job_run is about to enter, readable from inside a pbsim_comm callback
+ * (same thread): [0] 1 = gather A (pass-0 bases of the round's blocks), 2 = gather B (the cut), 3 = gather C (byte counts of the
+ * previous round), 4 = a record's statistics merge, 5 = the agreement on pool size and caps in front of the round loop;
+ * [1] record (0-based index in the job), [2] first read of the round (rank r walks [2] + r * [3] ..), [3] reads per rank,
+ * [4] ranks, [5] the record's len_total and [7] its next read in front of the round, [6] its quota.  For communicators that
+ * model or replay the other ranks (bench.py --replay-ranks measures an N-rank job's per-rank critical path on one GPU). */
+int pbsim_job_progress(pbsim_ctx *ctx, int64_t out[8]);
 
 /* The sampling method (pbsim_simulate_sample, pbsim.cpp:1694-1949) on several ranks, for the current record: one context per
  * GPU, every rank has set the same reference and profile.  The copies of one string are a chain, strings are independent, and

@@ -88,6 +88,8 @@ API = [
     ("pbsim_job_sam_header", C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
     ("pbsim_job_bam_header", C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
     ("pbsim_job_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ("pbsim_job_progress", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ("pbsim_batch_fetch_lengths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pbsim_job_breakdown", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_bind_host_to_device", C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
     ("pbsim_stats_keep_values", C.c_int, [C.c_void_p, C.c_int]),
@@ -587,6 +589,19 @@ class Context:
                     bufs[which][off:off + len(data)] = data
             out[rec] = bufs
         return out, done
+
+    def job_progress(self):
+        """(phase, record, first_read, n_per, world, len_total, quota, next_read) of the exchange pbsim_job_run is about to enter"""
+        a = (C.c_int64 * 8)()
+        _check(self.lib.pbsim_job_progress(self.h, a))
+        return tuple(a)
+
+    def batch_fetch_lengths(self, n_reads):
+        """(rawlen, len, pass-0 bases) of the reads of the walked batch on the selected slot, numpy int32 arrays"""
+        import numpy as np
+        r, l, o = (np.empty(n_reads, dtype=np.int32) for _ in range(3))
+        _check(self.lib.pbsim_batch_fetch_lengths(self.h, r.ctypes.data, l.ctypes.data, o.ctypes.data))
+        return r, l, o
 
     def job_counters(self):
         a = (C.c_int64 * 8)()

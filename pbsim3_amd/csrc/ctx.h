@@ -314,6 +314,7 @@ struct pbsim_ctx {
   StatsAcc st;                   // of the current unit (pbsim_batch_account / pbsim_get_stats)
   std::vector<std::unique_ptr<JobRecord>> job_records;  // pbsim_job_add_record (job.cpp)
   int64_t job_counters[8] = {0};
+  int64_t job_progress[8] = {0}; // pbsim_job_progress: the exchange the round loop is about to enter
   double job_breakdown[16] = {0};  // pbsim_job_breakdown: where the round loop's wall time went (job.cpp)
   int64_t job_first_unit = 1;    // genome.num of the job's first record (pbsim_job_begin)
 

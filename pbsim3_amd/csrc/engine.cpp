@@ -847,6 +847,20 @@ int pbsim_batch_walk_end(pbsim_ctx *c, int64_t *pass0_bases) {
   return PBSIM_SUCCEEDED;
 }
 
+int pbsim_batch_fetch_lengths(pbsim_ctx *c, int32_t *rawlen, int32_t *len, int32_t *out_len_pass0) {
+  if (!c || !c->s().b_walked) return fail("pbsim_batch_fetch_lengths: no walked batch on this slot");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  Slot &sl = c->s();
+  const size_t n = (size_t)sl.b_n;
+  if (rawlen) HIP_OK(hipMemcpyAsync(rawlen, sl.d_rawlen.p, n * 4, hipMemcpyDeviceToHost, sl.stream));
+  if (len) HIP_OK(hipMemcpyAsync(len, sl.d_len.p, n * 4, hipMemcpyDeviceToHost, sl.stream));
+  if (out_len_pass0)  // out_len is per task (read-major, pass minor): every pass_num-th value
+    HIP_OK(hipMemcpy2DAsync(out_len_pass0, 4, sl.d_out_len.p, (size_t)c->p.pass_num * 4, 4, n, hipMemcpyDeviceToHost, sl.stream));
+  HIP_OK(hipStreamSynchronize(sl.stream));
+  return PBSIM_SUCCEEDED;
+}
+
 static void fill_text_args(pbsim_ctx *c, TextArgs *t, int64_t n_emit) {
   memset(t, 0, sizeof *t);
   t->first_read = c->s().b_first;
@@ -1147,6 +1161,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   const int64_t piece = piece_chunks * DF_CHUNK;
   const int64_t max_ch = std::min<int64_t>(piece_chunks, (n + DF_CHUNK - 1) / DF_CHUNK);
   const int64_t n_pieces = (n + piece - 1) / piece;
+  const size_t status_bytes_was = sl.d_df_status.bytes;  // (ensure() only ever grows: a new allocation has another size)
   HIP_OK(sl.d_df_status.ensure((size_t)piece_chunks * 8));
   HIP_OK(sl.d_df_ctl.ensure(DF_CTL_BYTES));
   // Direct mode: the members leave the GPU as the deflate workgroups' own stores into page-locked host memory (no dense
@@ -1165,6 +1180,10 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   for (int i = 0; i < 2; i++)
     if (!c->df_streams[lane_index][i]) HIP_OK(hipStreamCreateWithFlags(&c->df_streams[lane_index][i], hipStreamNonBlocking));
   sl.stream = c->df_streams[lane_index][0];
+  // The look-back trusts any status word that carries the launch's epoch and a flag, and the words are never cleared between
+  // launches -- so a NEW array must start from zeros (flag 0 = nothing published): hipMalloc hands back the freed array of a
+  // destroyed context or lane with that lane's old words in it, and a lane's epochs restart.
+  if (sl.d_df_status.bytes != status_bytes_was) HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
   // the call's code table: fitted once to the head of the text (deflate.hip), shared by all its members
   launch_deflate_table(d_text, n, reinterpret_cast<uint32_t *>(sl.d_df_code.as<uint8_t>() + DF_TABLE_BYTES), sl.d_df_code.p, sl.stream);
   unsigned long long *d_prof = nullptr;
@@ -1206,6 +1225,10 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     if (used[b] && !direct) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - 3 has left this dense buffer
     // (direct: piece j - 3 was consumed on this thread before piece j is launched -- the host buffer is free)
     uint8_t *dense = direct ? (uint8_t *)sl.h_df_out[b].p : sl.d_df_dense[b].as<uint8_t>();
+    if (((sl.epoch + 1) & 0x3fffffffu) == 0) {  // the epoch wraps: start over from a cleared array; epoch 0 is never used
+      HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
+      sl.epoch++;
+    }
     launch_deflate(d_text + off, len, sl.d_df_status.as<uint64_t>(), sl.d_df_ctl.p, ++sl.epoch, dense, tab, tab + 1024,
                    sl.d_df_code.p, sl.stream, d_prof, sl.ev_k0[b], sl.ev_k1[b]);
     HIP_OK(hipGetLastError());
@@ -2257,11 +2280,9 @@ int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
 // record's two streams (C).  Chunks in front of the cut are delivered, the rest of the round is void.  Every number the
 // planner uses is the same on all ranks (the pool size is agreed first), so all ranks plan the same chunks.  A string whose
 // copies do not fit one chunk's pool (the carry-over of the one-GPU driver) is refused here: give the ranks a larger pool.
-int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink) {
-  if (!c) return fail("bad argument");
-  NEED_DEVICE(c);
-  if (!comm || comm->world <= 1) return fail("pbsim_simulate_sample_comm: a communicator of at least two ranks (else pbsim_simulate_sample)");
-  if (!comm->all_gather_i64 || !comm->all_reduce_i64) return fail("pbsim_comm: all_gather_i64 and all_reduce_i64 must be set");
+// `*agreed`: the failure was learned through a collective's status word (or is the same on every rank by construction), so
+// every rank leaves at the same exchange; any other failure is this rank's alone and the caller releases the others (abort).
+static int sample_comm_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink, bool *agreed) {
   const int W = comm->world, rank = comm->rank;
   int ok = sample_common_checks(c);
   SampleChunks S;
@@ -2272,7 +2293,10 @@ int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim
     std::string keep = g_err;
     int64_t v[2] = {ok ? 0 : 1, -c->scratch_budget};
     if (!comm->all_reduce_i64(comm->user, v, 2, PBSIM_OP_MAX)) return fail("pbsim_comm.all_reduce_i64 failed");
-    if (v[0]) return ok ? fail("another rank failed") : fail(keep);
+    if (v[0]) {
+      *agreed = true;
+      return ok ? fail("another rank failed") : fail(keep);
+    }
     c->scratch_budget = -v[1];
   }
   pbsim_reset_stats(c);
@@ -2329,7 +2353,10 @@ int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim
         at = ck.cand[ck.n_c - 1].line + 1;
         n_chunks++;
       }
-      if (!local) return fail(local_err);
+      if (!local) {
+        *agreed = true;  // (the plan depends on nothing local: every rank refuses alike)
+        return fail(local_err);
+      }
       const bool mine = rank < n_chunks;
       if (trace)
         fprintf(stderr, "[pbsim sample r%d] sweep sv=%lld line=%lld left=%lld chunks=%d first=%lld len_total=%lld\n", rank, (long long)sv,
@@ -2346,7 +2373,10 @@ int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim
         bad += A[(size_t)q * 2 + 1];
         if (q < rank) before += A[(size_t)q * 2];
       }
-      if (bad) return sendA[1] ? fail(local_err) : fail("another rank failed");
+      if (bad) {
+        *agreed = true;
+        return sendA[1] ? fail(local_err) : fail("another rank failed");
+      }
       // ---- the cut inside my chunk, B: reads made and bases behind them -> the first chunk that stops short
       pbsim_batch_info bi;
       memset(&bi, 0, sizeof bi);
@@ -2358,7 +2388,10 @@ int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim
       if (!gather(sendB, 3, &B)) return PBSIM_FAILED;
       bad = 0;
       for (int q = 0; q < W; q++) bad += B[(size_t)q * 3 + 2];
-      if (bad) return sendB[2] ? fail(local_err) : fail("another rank failed");
+      if (bad) {
+        *agreed = true;
+        return sendB[2] ? fail(local_err) : fail("another rank failed");
+      }
       int cut = -1;
       for (int q = 0; q < n_chunks && cut < 0; q++)
         if (B[(size_t)q * 3] < cks[(size_t)q].n_tasks) cut = q;
@@ -2380,7 +2413,10 @@ int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim
         read_off += Cs[(size_t)q * 3];
         maf_off += Cs[(size_t)q * 3 + 1];
       }
-      if (bad) return sendC[2] ? fail(local_err) : fail("another rank failed");
+      if (bad) {
+        *agreed = true;
+        return sendC[2] ? fail(local_err) : fail("another rank failed");
+      }
       if (sink && sink->on_read_text && !buf_r.empty() && !sink->on_read_text(sink->user, c->unit, buf_r.data(), (int64_t)buf_r.size(), r_at))
         return fail("sink aborted (read text)");
       if (sink && sink->on_maf_text && !buf_m.empty() && !sink->on_maf_text(sink->user, c->unit, buf_m.data(), (int64_t)buf_m.size(), m_at))
@@ -2405,6 +2441,23 @@ int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim
     if (!sink->on_record_done(sink->user, c->unit, &st, read_off, maf_off)) return fail("sink aborted (record done)");
   }
   return PBSIM_SUCCEEDED;
+}
+
+int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink) {
+  if (!c) return fail("bad argument");
+  NEED_DEVICE(c);
+  if (!comm || comm->world <= 1) return fail("pbsim_simulate_sample_comm: a communicator of at least two ranks (else pbsim_simulate_sample)");
+  if (!comm->all_gather_i64 || !comm->all_reduce_i64) return fail("pbsim_comm: all_gather_i64 and all_reduce_i64 must be set");
+  bool agreed = false;
+  const int ok = sample_comm_run(c, comm, sink, &agreed);
+  if (!ok && !agreed && comm->abort) {
+    // a sink callback, the statistics merge, a HIP error between two exchanges: the other ranks cannot know and would wait
+    // in their next all-gather (for ever with a host barrier, until the watchdog with RCCL) -- ADVICE r3
+    const std::string keep = g_err;
+    comm->abort(comm->user);
+    g_err = keep;
+  }
+  return ok;
 }
 
 int pbsim_simulate_templ(pbsim_ctx *c, const pbsim_sink *sink) { return pbsim_simulate_trans(c, sink); }

@@ -180,6 +180,19 @@ struct Job {
     return fail(werr);
   }
 
+  // pbsim_job_progress: which exchange of the round sequence this rank is about to enter (a communicator that replays or
+  // models the other ranks -- bench.py --replay-ranks -- reads it from inside its callbacks)
+  void progress(int phase, int rec, int64_t first = 0, int64_t n_per = 0) {
+    int64_t *g = c->job_progress;
+    g[0] = phase;
+    g[1] = rec;
+    g[2] = first;
+    g[3] = n_per;
+    g[4] = W;
+    g[5] = rec >= 0 ? recs[(size_t)rec].len_total : 0;
+    g[6] = rec >= 0 ? recs[(size_t)rec].quota : 0;
+    g[7] = rec >= 0 ? recs[(size_t)rec].next_read : 0;
+  }
   int gather(const int64_t *send, int64_t n, std::vector<int64_t> *recv) {
     recv->assign((size_t)W * n, 0);
     if (W == 1) {
@@ -429,6 +442,7 @@ struct Job {
     bd_wait_bytes += t1 - t0;
     int64_t mine2[3] = {d->mine ? d->sizes[0] : 0, d->mine ? d->sizes[1] : 0, ok1 ? 0 : 1};
     std::vector<int64_t> S;
+    progress(3, d->rec, 0, d->n_per);
     if (!gather(mine2, 3, &S)) return PBSIM_FAILED;
     int64_t read_at = R.read_off, maf_at = R.maf_off, read_all = 0, maf_all = 0, bad = 0;
     for (int q = 0; q < W; q++) {
@@ -577,6 +591,7 @@ struct Job {
     // [2] = status: a rank whose tail or worker failed tells the others here instead of leaving them in the merge's collectives
     int64_t extra[3] = {R.tail_read, R.tail_maf, (tail_ok && !wfailed) ? 0 : 1};
     const double t0 = now_us();
+    progress(4, rec);
     if (!stats_merge(&R.st, c->p, W > 1 ? comm : nullptr, extra, 3)) return PBSIM_FAILED;
     bd_merge += now_us() - t0;
     if (!tail_ok) return fail(tail_err);
@@ -639,6 +654,7 @@ struct Job {
     bd_wait_walk += t1 - t0;
     std::vector<int64_t> A, B;
     const int64_t sendA[2] = {pass0, code};
+    progress(1, rd.rec, rd.first, rd.n_per);
     if (!gather(sendA, 2, &A)) return PBSIM_FAILED;
     int64_t worst = 0, pass0_sum = 0, before = R.len_total;
     for (int q = 0; q < W; q++) {
@@ -674,6 +690,7 @@ struct Job {
     const double t2 = now_us();
     bd_finalize += t2 - tf;
     const int64_t sendB[4] = {bi.n_final, bi.need_truncated_read, bi.len_total_after, fin_ok ? 0 : 1};
+    progress(2, rd.rec, rd.first, rd.n_per);
     if (!gather(sendB, 4, &B)) return PBSIM_FAILED;
     int64_t bad_b = 0;
     for (int q = 0; q < W; q++) bad_b += B[(size_t)q * 4 + 3];
@@ -912,19 +929,22 @@ int pbsim_job_breakdown(pbsim_ctx *c, double out[16]) {
   return PBSIM_SUCCEEDED;
 }
 
+int pbsim_job_progress(pbsim_ctx *c, int64_t out[8]) {
+  if (!c || !out) return fail("bad argument");
+  memcpy(out, c->job_progress, sizeof c->job_progress);
+  return PBSIM_SUCCEEDED;
+}
+
 int pbsim_job_counters(pbsim_ctx *c, int64_t out[8]) {
   if (!c || !out) return fail("bad argument");
   memcpy(out, c->job_counters, sizeof c->job_counters);
   return PBSIM_SUCCEEDED;
 }
 
-int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink) {
-  if (!c) return fail("bad argument");
-  NEED_DEVICE(c);
+// `*settled`: the other ranks know of the failure (it came through / went into a status word) or the communicator has been
+// aborted already; every other failing return is this rank's alone, and pbsim_job_run releases the others.
+static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink, bool *settled) {
   if (c->job_records.empty()) return fail("pbsim_job_run: no records (pbsim_job_add_record)");
-  if (comm && (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)) return fail("pbsim_comm: bad rank / world");
-  if (comm && comm->world > 1 && (!comm->all_gather_i64 || !comm->all_reduce_i64))
-    return fail("pbsim_comm: all_gather_i64 and all_reduce_i64 must be set");
   if (sink && c->deflate != 0 && c->deflate != 3)
     return fail("pbsim_job_run: pbsim_set_deflate must cover both sinks or none (mask 0, 3 or 7)");
   HIP_OK(hipSetDevice(c->device));
@@ -959,6 +979,12 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   c->bias.hp11_seen = c->hp11_before_job;  // every run of the job starts from the same Q15 state
   // pbsim.cpp:677-696: the census of ALL records comes before the first read.  Without pbsim_finish_hp_census the job's own
   // records are the genome; recomputed per run (records may have been added since the last one).
+  // A follow-on job of the same genome (pbsim_job_begin with first_record > 1) cannot take the census from its own records:
+  // the reference's pass covers ALL records before the first read, and a bias table per record group would silently differ
+  // from it.  The caller runs pbsim_add_hp_census / pbsim_finish_hp_census over the whole genome first (the CLI does).
+  if (c->p.hp_del_bias != 1 && c->job_first_unit > 1 && (!c->census_done || c->census_from_job))
+    return fail("pbsim_job_run: a job that continues a genome (pbsim_job_begin first_record > 1) with --hp-del-bias != 1 needs the "
+                "homopolymer census of ALL records first (pbsim_add_hp_census per record, then pbsim_finish_hp_census; pbsim.cpp:677-696)");
   if (c->p.hp_del_bias != 1 && (!c->census_done || c->census_from_job)) {
     HpBias nb = c->bias;
     hp_bias_from_census(c->p.hp_del_bias, census, &nb);
@@ -1046,6 +1072,7 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   // once the free memory bounds it) goes through one MIN over the ranks.
   std::vector<int64_t> agree(n + 1);
   agree[0] = c->scratch_budget;
+  J.progress(5, -1);
   if (W > 1) {
     if (!comm->all_reduce_i64(comm->user, agree.data(), 1, PBSIM_OP_MIN)) return fail("pbsim_comm.all_reduce_i64 failed");
     c->scratch_budget = agree[0];
@@ -1073,7 +1100,10 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     const std::string keep = g_err;
     int64_t bad = ready ? 0 : 1;
     if (!comm->all_reduce_i64(comm->user, &bad, 1, PBSIM_OP_MAX)) return fail("pbsim_comm.all_reduce_i64 failed");
-    if (bad) return ready ? fail("another rank of the job failed") : fail(keep);
+    if (bad) {
+      *settled = true;
+      return ready ? fail("another rank of the job failed") : fail(keep);
+    }
   } else if (!ready) {
     return PBSIM_FAILED;
   }
@@ -1098,6 +1128,7 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
     // ranks waiting in their next collective: the communicator's abort, when it has one, releases them.  Without it the caller
     // must tear the process group down (include/pbsim3_amd.h).
     if (W > 1 && !J.peer_failed && comm->abort) comm->abort(comm->user);
+    *settled = true;
     J.drop_everything();
     J.worker.finish();
     g_err = keep;
@@ -1132,6 +1163,24 @@ int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink 
   c->job_counters[5] = (int64_t)J.comm_us;
   c->job_counters[6] = J.ref_bases;
   c->job_counters[7] = J.maf_columns;
+  return ok;
+}
+
+int pbsim_job_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink) {
+  if (!c) return fail("bad argument");
+  NEED_DEVICE(c);
+  if (comm && (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)) return fail("pbsim_comm: bad rank / world");
+  if (comm && comm->world > 1 && (!comm->all_gather_i64 || !comm->all_reduce_i64))
+    return fail("pbsim_comm: all_gather_i64 and all_reduce_i64 must be set");
+  bool settled = false;
+  const int ok = job_run_impl(c, comm, sink, &settled);
+  if (!ok && !settled && comm && comm->world > 1 && comm->abort) {
+    // a failure in front of the job's first collective (no records, a HIP error while the records' preparation is collected,
+    // no memory for the pools): the other ranks are on their way into it
+    const std::string keep = g_err;
+    comm->abort(comm->user);
+    g_err = keep;
+  }
   return ok;
 }
 

@@ -126,9 +126,18 @@ extern "C" int pbsim_bind_host_to_device(int device, char *what, int64_t cap) {
   std::vector<GpuNode> gpus;
   if (!kfd_gpus(&gpus)) return PBSIM_SUCCEEDED;  // no KFD topology (no GPU driver): nothing to bind to
   // visible-device remapping: ROCr filters first, HIP indexes into what ROCr left
+  // HIP takes its list from HIP_VISIBLE_DEVICES, CUDA_VISIBLE_DEVICES (torch launchers set that one) or GPU_DEVICE_ORDINAL: all
+  // the same mask to the runtime.  When several are set and disagree, which one wins is the runtime's business -- binding to
+  // the wrong GPU's node is worse than not binding (every byte would cross the socket link), so stay unbound.
   int index = device;
-  for (const char *var : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"}) {
+  const char *hip_list = nullptr;
+  for (const char *var : {"HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"}) {
     const char *v = getenv(var);
+    if (!v || !*v) continue;
+    if (hip_list && strcmp(hip_list, v) != 0) return PBSIM_SUCCEEDED;
+    hip_list = v;
+  }
+  for (const char *v : {hip_list, (const char *)getenv("ROCR_VISIBLE_DEVICES")}) {
     if (!v || !*v) continue;
     std::vector<int> list;
     if (!parse_index_list(v, &list)) return PBSIM_SUCCEEDED;

@@ -15,6 +15,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -27,7 +28,6 @@ struct RcclApi {
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
-  std::atomic<bool> aborted{false};                 // pbsim_comm.abort of any rank of this process
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -61,6 +61,10 @@ struct RcclApi {
 
 struct RcclRank {
   RcclApi *api = nullptr;
+  // pbsim_comm.abort of any rank of THIS group (rccl_init_all makes one per group: a later communicator of the same process
+  // starts clean -- the flag used to live in the process-wide RcclApi and failed every later group)
+  std::shared_ptr<std::atomic<bool>> aborted;
+  bool is_aborted() const { return aborted && aborted->load(std::memory_order_relaxed); }
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   hipStream_t stream = nullptr;
@@ -92,11 +96,14 @@ inline bool rccl_wait(RcclRank *r, const char *what) {
     const hipError_t e = hipStreamQuery(r->stream);
     if (e == hipSuccess) return true;
     if (e != hipErrorNotReady) return false;
-    if (r->api->aborted.load(std::memory_order_relaxed)) {
-      if (r->comm && r->api->CommAbort) (void)r->api->CommAbort(r->comm);
+    if (r->is_aborted() && r->api->CommAbort) {
+      if (r->comm) (void)r->api->CommAbort(r->comm);
       r->comm = nullptr;
       return false;
     }
+    // (a librccl without ncclCommAbort: the collective's kernel keeps spinning on the stream, so the communicator is NOT
+    // dropped -- rccl_destroy_all would block in hipFree behind that kernel; the wait runs into the time-out below and the
+    // process ends)
     if (spins < 4000) {
       sched_yield();
       continue;
@@ -115,13 +122,14 @@ inline bool rccl_wait(RcclRank *r, const char *what) {
 }
 
 inline int rccl_abort(void *user) {
-  ((RcclRank *)user)->api->aborted.store(true);
+  RcclRank *r = (RcclRank *)user;
+  if (r->aborted) r->aborted->store(true);
   return 1;
 }
 
 inline int rccl_all_gather(void *user, const int64_t *send, int64_t n, int64_t *recv) {
   RcclRank *r = (RcclRank *)user;
-  if (!r->comm || r->api->aborted.load()) return 0;
+  if (!r->comm || r->is_aborted()) return 0;
   if (!r->ensure((size_t)n * 8, (size_t)n * 8 * (size_t)r->world)) return 0;
   if (hipMemcpyAsync(r->d_send, send, (size_t)n * 8, hipMemcpyHostToDevice, r->stream) != hipSuccess) return 0;
   if (r->api->AllGather(r->d_send, r->d_recv, (size_t)n, ncclInt64, r->comm, r->stream) != ncclSuccess) return 0;  // C3
@@ -131,7 +139,7 @@ inline int rccl_all_gather(void *user, const int64_t *send, int64_t n, int64_t *
 
 inline int rccl_all_reduce(void *user, int64_t *buf, int64_t n, int32_t op) {
   RcclRank *r = (RcclRank *)user;
-  if (!r->comm || r->api->aborted.load()) return 0;
+  if (!r->comm || r->is_aborted()) return 0;
   if (n == 0) return 1;
   if (!r->ensure((size_t)n * 8, (size_t)n * 8)) return 0;
   const ncclRedOp_t rop = op == PBSIM_OP_SUM ? ncclSum : op == PBSIM_OP_MIN ? ncclMin : ncclMax;
@@ -143,7 +151,7 @@ inline int rccl_all_reduce(void *user, int64_t *buf, int64_t n, int32_t op) {
 
 inline int rccl_broadcast(void *user, void *p, int64_t bytes, int32_t root, int32_t on_device) {
   RcclRank *r = (RcclRank *)user;
-  if (!r->comm || r->api->aborted.load()) return 0;
+  if (!r->comm || r->is_aborted()) return 0;
   if (hipSetDevice(r->device) != hipSuccess) return 0;
   if (!r->stream && hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) return 0;
   void *d = p;
@@ -178,9 +186,11 @@ inline bool rccl_init_all(const std::vector<int> &devices, std::vector<RcclRank>
     return false;
   }
   ranks->resize(devices.size());
+  const auto flag = std::make_shared<std::atomic<bool>>(false);
   for (size_t i = 0; i < devices.size(); i++) {
     RcclRank &r = (*ranks)[i];
     r.api = &api;
+    r.aborted = flag;
     r.comm = comms[i];
     r.rank = (int)i;
     r.world = (int)devices.size();

@@ -122,3 +122,20 @@ def test_randomized_buffers(ctx):
         assert gzip.decompress(got) == data, (it, n, k, run_p)
         if n <= 70000:
             assert got == deflate_model.compress(data), (it, n, k, run_p)
+
+
+def test_contexts_created_and_destroyed_in_a_loop():
+    """the look-back of k_deflate_chunks trusts any status word with the launch's epoch and a flag, the status
+    array is never cleared between launches, and a lane's epochs restart with every context -- while hipMalloc hands the
+    freed array of the context before back with that context's words in it.  A new array now starts from zeros: contexts in
+    a loop, each compressing buffers of several launches' worth of chunks (its epochs 1..n meet the words the one before
+    left at the same epochs), must keep producing streams that inflate to their input."""
+    import hashlib
+    block = dna(1 << 18, 21) + b"!" * 5000
+    for it in range(8):
+        with P.Context(P.default_params(), 0) as c:
+            for k in range(3):
+                n = (5 + 7 * ((it + k) % 4)) * (1 << 20) + 1000 * it + k
+                data = (block * (n // len(block) + 1))[:n]
+                got = c.deflate_buffer(data)
+                assert hashlib.sha1(gzip.decompress(got)).digest() == hashlib.sha1(data).digest(), (it, k, n)

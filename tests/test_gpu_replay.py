@@ -1,0 +1,68 @@
+"""tools/replay_ranks.py: a rank of an N-rank job run ALONE against "virtual ranks" -- a communicator that answers gathers A
+and B for the other ranks from a table of per-read (raw length, pass-0 bases) and the reference's quota rule
+(pbsim.cpp:3792-3800).  The harness checks the rank's own values against the table at every exchange; here its output is
+checked too: the text pieces the N replayed ranks deliver tile the one-GPU job's text exactly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import harness
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(harness.ROOT, "tools"))
+
+
+def genome(n, seed):
+    return harness.synth_bases(n, seed).tobytes()
+
+
+@pytest.mark.parametrize("method,world,scratch_mb", [("errhmm", 3, 6), ("errhmm", 8, 24), ("qshmm", 4, 8)])
+def test_replayed_ranks_tile_the_one_gpu_output(method, world, scratch_mb):
+    import ctypes as C
+    import torch
+    import pbsim3_amd as P
+    import replay_ranks as RR
+    qs = method == "qshmm"
+    model = "QSHMM-RSII.model" if qs else "ERRHMM-ONT.model"
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=5, depth=6.0,
+                         len_mean=1500.0, len_sd=1100.0, pass_num=2 if qs else 1)
+    G = 1_500_000
+    recs = [torch.frombuffer(bytearray(genome(G, 10 + i)), dtype=torch.uint8).cuda() for i in range(2)]
+    tables = RR.build_tables(P, harness, p, model, qs, recs, G, 0)
+    with P.Context(p, 0) as ctx:
+        ctx.set_scratch_bytes(scratch_mb << 20)
+        (ctx.load_qshmm if qs else ctx.load_errhmm)(harness.model_path(model))
+        for t in recs:
+            ctx.job_add_record_device(t.data_ptr(), G)
+        want, done = ctx.job_run()
+        want = {k: (bytes(v[0]), bytes(v[1])) for k, v in want.items()}
+        pieces = {k: ([], []) for k in want}
+        checked = rounds = 0
+        for r in range(world):
+            got = {k: ([], []) for k in want}
+
+            def put(which, rec, text, n, off, got=got):
+                got[rec][which].append(C.string_at(text, n))
+                return 1
+            cbs = (P.REC_TEXT_CB(lambda u, rec, t, n, o: put(0, rec, t, n, o)), P.REC_TEXT_CB(lambda u, rec, t, n, o: put(1, rec, t, n, o)),
+                   P.REC_DONE_CB(lambda u, rec, st, rb, mb: 1))
+            sink = P.RecordSink(None, *cbs)
+            vr = RR.VirtualRanks(P, ctx, r, world, tables)
+            P._check(ctx.lib.pbsim_job_run(ctx.h, C.byref(vr.comm), C.byref(sink)))
+            checked += vr.checked
+            rounds += ctx.job_counters()["rounds"]
+            for k in got:
+                for w in (0, 1):
+                    pieces[k][w].extend(got[k][w])
+        assert checked == 2 * rounds and rounds >= 2 * world      # gathers A and B of every round of every rank, against the table
+        for k in want:
+            for w in (0, 1):
+                text = want[k][w]
+                at = sorted((text.find(pc), len(pc)) for pc in pieces[k][w] if pc)
+                pos = 0
+                for start, n in at:                                 # the ranks' pieces tile the record's text: no gap, no overlap
+                    assert start == pos, (method, world, k, w, start, pos)
+                    pos += n
+                assert pos == len(text), (method, world, k, w)

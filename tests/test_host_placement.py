@@ -29,7 +29,7 @@ def make_tree(root, gpus):
 def bind(device, root, **env):
     code = ("import pbsim3_amd as P, sys; sys.stdout.write(P.bind_host_to_device(%d))" % device)
     e = dict(os.environ, PBSIM_SYSFS_ROOT=root, **env)
-    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "PBSIM_NUMA_BIND"):
+    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL", "ROCR_VISIBLE_DEVICES", "PBSIM_NUMA_BIND"):
         if k not in env:
             e.pop(k, None)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, cwd=ROOT)
@@ -50,6 +50,11 @@ def test_numa_binding_follows_the_gpu(tmp_path):
     assert bind(0, root, HIP_VISIBLE_DEVICES="2,0").startswith("gpu 0 (0001:85:00.0)")
     assert bind(1, root, ROCR_VISIBLE_DEVICES="1,2", HIP_VISIBLE_DEVICES="1,0").startswith("gpu 1 (0000:15:00.0)")
     assert bind(0, root, ROCR_VISIBLE_DEVICES="GPU-abcdef") == ""   # UUIDs: left alone
+    # HIP honours CUDA_VISIBLE_DEVICES (what torch launchers set) and GPU_DEVICE_ORDINAL like its own variable
+    assert bind(0, root, CUDA_VISIBLE_DEVICES="2").startswith("gpu 0 (0001:85:00.0)")
+    assert bind(1, root, GPU_DEVICE_ORDINAL="2,1").startswith("gpu 1 (0000:15:00.0)")
+    assert bind(0, root, CUDA_VISIBLE_DEVICES="2", HIP_VISIBLE_DEVICES="2").startswith("gpu 0 (0001:85:00.0)")
+    assert bind(0, root, CUDA_VISIBLE_DEVICES="2", HIP_VISIBLE_DEVICES="1") == ""   # they disagree: unbound, not mis-bound
     assert bind(0, root, PBSIM_NUMA_BIND="0") == ""
 
 

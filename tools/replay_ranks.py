@@ -1,0 +1,171 @@
+"""An N-rank job's per-rank critical path, measured on ONE GPU (bench.py --replay-ranks 2,4,8).
+
+A rank of an N-rank job exchanges only integers with the others: per round the pass-0 bases of every rank's block
+(gather A), the cut inside every block (gather B) and byte counts (gather C); per record the statistics.  A and B are pure
+functions of two per-read quantities -- the raw length a read's header draws and the pass-0 bases its walk produces -- so the
+values of the OTHER ranks can be served from a table of those two numbers for the first reads of every record, whatever the
+plan: rank r of N then runs ALONE on the GPU, at full speed, with its own link, pools and delivery threads, against a
+communicator that answers for the N - 1 others at once ("virtual ranks").  That is what a rank of a real N-GPU node does between
+its collectives; what the figure leaves out is the collectives' own latency over RCCL (a dozen small ones per job) and the
+contention of N ranks for host memory.
+
+  table    = batch primitives on one context: walk the reads 1 .. M of every record un-truncated, fetch (rawlen, pass-0 bases)
+  virtual  = pbsim_comm from Python callables; pbsim_job_progress tells which exchange of which round is being entered:
+               A: the blocks' pass-0 sums from the table      B: the quota rule (pbsim.cpp:3792-3800) on the table
+               C: every rank delivers what this one does       statistics / agreement: identity
+             the rank's OWN values are checked against the table at every exchange: the model of the protocol and job.cpp agree
+  result   = per rank: wall, breakdown; across ranks: max wall (ranks that never wait for each other) and the synchronised
+             critical path sum_k max_r segment(r, k) (every collective waits for its slowest rank; the GPU work a real rank has in
+             flight meanwhile is not credited: an upper bound)
+"""
+import time
+
+import numpy as np
+
+
+class ReadTable:
+    """(rawlen, pass-0 bases) of reads 1 .. M of one record, with prefix sums"""
+
+    def __init__(self, rawlen, out0):
+        self.rawlen = rawlen.astype(np.int64)
+        self.out0 = out0.astype(np.int64)
+        self.cum = np.concatenate([[0], np.cumsum(self.out0)])
+
+    def block_sum(self, first, n):
+        if first - 1 + n > len(self.out0):
+            raise RuntimeError("replay: the read table ends at read %d, the round needs %d" % (len(self.out0), first - 1 + n))
+        return int(self.cum[first - 1 + n] - self.cum[first - 1])
+
+    def cut(self, first, n, before, quota):
+        """pbsim.cpp:3792-3800 on reads first .. first + n - 1 with len_total = before in front of them:
+        (n_final, need_truncated_read, len_total_after)"""
+        lo = first - 1
+        t = before + (self.cum[lo:lo + n] - self.cum[lo])          # len_total at the start of each read
+        stop = (t >= quota) | (t + self.rawlen[lo:lo + n] > quota)
+        n_final = int(np.argmax(stop)) if stop.any() else n
+        after = before + int(self.cum[lo + n_final] - self.cum[lo])
+        return n_final, int(n_final < n and after < quota), after
+
+
+def build_tables(P, harness, p, model, qs, recs, G, local, margin=1.06):
+    """walks reads 1 .. M of every record (M: `margin` x the reads the quota takes + 20 000) with the batch primitives"""
+    tabs = []
+    with P.Context(p, local) as ctx:
+        (ctx.load_qshmm if qs else ctx.load_errhmm)(harness.model_path(model))
+        ctx.set_scratch_bytes(12 << 30)
+        for i, t in enumerate(recs):
+            ctx.set_reference_device(t.data_ptr(), G, i + 1)
+            quota = ctx.unit_quota()
+            cap = min(ctx.batch_capacity(), 400_000)
+            raw, out, tot, first, extra = [], [], 0, 1, None
+            while extra is None or extra > 0:
+                n = cap if extra is None else min(cap, extra)
+                ctx.select_slot(0)
+                ctx.batch_walk_begin(first, n)
+                ctx.batch_walk_end()
+                r, _, o = ctx.batch_fetch_lengths(n)
+                raw.append(r)
+                out.append(o)
+                tot += int(o.sum())
+                first += n
+                if extra is not None:
+                    extra -= n
+                elif tot >= quota:
+                    extra = int((margin - 1.0) * (first - 1)) + 20_000
+            tabs.append(ReadTable(np.concatenate(raw), np.concatenate(out)))
+    return tabs
+
+
+class VirtualRanks:
+    """pbsim_comm of rank `rank` of `world` whose other ranks are answered from the read tables"""
+
+    def __init__(self, P, ctx, rank, world, tables):
+        self.ctx, self.rank, self.world, self.tables = ctx, rank, world, tables
+        self.events = []          # (phase, t_enter, t_exit) per collective
+        self.checked = 0
+        self.comm = P.make_comm(rank, world, self.all_gather, self.all_reduce)
+
+    def all_gather(self, a):
+        t_in = time.perf_counter()
+        ph, rec, first, n_per, W, len_total, quota, _ = self.ctx.job_progress()
+        out = np.tile(np.asarray(a, dtype=np.int64), (W, 1))
+        if ph == 1 and len(a) == 2:
+            tab = self.tables[rec]
+            for q in range(W):
+                out[q, 0] = tab.block_sum(first + q * n_per, n_per)
+                out[q, 1] = 0
+            if a[1] == 0 and out[self.rank, 0] != a[0]:
+                raise RuntimeError("replay: gather A of rank %d differs from the table (%d vs %d)" % (self.rank, a[0], out[self.rank, 0]))
+            out[self.rank] = a
+            self.checked += 1
+        elif ph == 2 and len(a) == 4:
+            tab = self.tables[rec]
+            before = len_total
+            for q in range(W):
+                nf, need, after = tab.cut(first + q * n_per, n_per, before, quota)
+                out[q] = (nf, need, after, 0)
+                before += tab.block_sum(first + q * n_per, n_per)
+            if a[3] == 0 and tuple(out[self.rank, :3]) != tuple(a[:3]):
+                raise RuntimeError("replay: gather B of rank %d differs from the table (%s vs %s)" % (self.rank, list(a), list(out[self.rank])))
+            out[self.rank] = a
+            self.checked += 1
+        self.events.append((ph, t_in, time.perf_counter()))
+        return out
+
+    def all_reduce(self, a, op):
+        t_in = time.perf_counter()
+        ph = self.ctx.job_progress()[0]
+        self.events.append((ph + 10, t_in, time.perf_counter()))
+        return a                  # identical GPUs agree with themselves; the statistics of the other ranks are not needed
+
+
+def segments(events, t0, t1):
+    """compute time between collectives: [t0 -> first enter, exit -> next enter, ..., last exit -> t1]"""
+    seg, last = [], t0
+    for _, t_in, t_out in events:
+        seg.append(t_in - last)
+        last = t_out
+    seg.append(t1 - last)
+    return seg
+
+
+def replay(P, C, ctx, tables, world, run_job, runs=2):
+    """every rank of `world` alone on the GPU, `runs` timed runs each (after one warm-up of rank 0 that sizes the pools);
+    run_job(comm) -> sink runs the job once on `ctx`"""
+    run_job(VirtualRanks(P, ctx, 0, world, tables).comm)
+    per_rank = []
+    for r in range(world):
+        best = None
+        for _ in range(runs):
+            vr = VirtualRanks(P, ctx, r, world, tables)
+            t0 = time.perf_counter()
+            sink = run_job(vr.comm)
+            t1 = time.perf_counter()
+            bd = ctx.job_breakdown()
+            cn = ctx.job_counters()
+            row = {"rank": r, "wall_ms": (t1 - t0) * 1e3, "segments_ms": [x * 1e3 for x in segments(vr.events, t0, t1)],
+                   "phases": [e[0] for e in vr.events], "in_callbacks_ms": sum(e[2] - e[1] for e in vr.events) * 1e3,
+                   "exchanges_checked": vr.checked, "rounds": cn["rounds"], "reads_walked": cn["reads_walked"],
+                   "reads_delivered": cn["reads_delivered"], "bases": cn["bases"],
+                   "host_bytes": sink.read_bytes + sink.maf_bytes,
+                   "breakdown_ms": {k: v / 1e3 for k, v in bd.items() if k not in ("topup_rounds", "tail_reads", "depth")},
+                   "topup_rounds": bd["topup_rounds"], "tail_reads": bd["tail_reads"], "depth": bd["depth"]}
+            if best is None or row["wall_ms"] < best["wall_ms"]:
+                best = row
+        per_rank.append(best)
+    n_seg = {len(x["segments_ms"]) for x in per_rank}
+    sync = None
+    if len(n_seg) == 1:
+        k = n_seg.pop()
+        sync = sum(max(x["segments_ms"][i] for x in per_rank) for i in range(k))
+    worst = max(per_rank, key=lambda x: x["wall_ms"])
+    return {"world": world, "per_rank": per_rank, "max_rank_wall_ms": worst["wall_ms"], "slowest_rank": worst["rank"],
+            "mean_rank_wall_ms": sum(x["wall_ms"] for x in per_rank) / world,
+            "sync_critical_path_ms": sync,
+            "bases_delivered_all_ranks": sum(x["bases"] for x in per_rank),
+            "speculation_waste": 1.0 - sum(x["reads_delivered"] for x in per_rank) / max(1, sum(x["reads_walked"] for x in per_rank)),
+            "exposed_tail_ms_worst": max(x["breakdown_ms"]["tail_block"] + x["breakdown_ms"]["drain"] for x in per_rank),
+            "note": "every rank ran alone on the one GPU against virtual ranks (tools/replay_ranks.py): max_rank_wall = ranks that "
+                    "never wait for each other (lower bound of the job's time), sync_critical_path = every collective waits for its "
+                    "slowest rank and nothing overlaps the wait (upper bound); RCCL latency and host-memory contention of a real "
+                    "node are not in either"}
