@@ -164,6 +164,14 @@ struct Job {
   std::mutex werr_mu;
   std::string werr;
   std::unique_ptr<Delivery> pending;  // the one round whose sizes have not been exchanged yet
+  // deliveries of a record that are with the worker (posted, not finished): a record's merge waits for ITS bytes only -- the
+  // worker is FIFO, so that is as soon as it has passed them -- not for the rounds of later records behind them
+  std::unique_ptr<std::atomic<int>[]> rec_out;
+  void wait_record(int rec) {
+    if (!worker.running) return;
+    std::unique_lock<std::mutex> lk(worker.mu);
+    worker.cv_idle.wait(lk, [&] { return rec_out[(size_t)rec].load() == 0; });
+  }
 
   Job() {
     for (auto &d : delivering) d = false;
@@ -393,7 +401,9 @@ struct Job {
     auto prom = d->stage1;
     int64_t *sizes = d->sizes;
     const int64_t read_at = R->read_off, maf_at = R->maf_off;  // one rank: the offsets simply run up (streamed in stage 1)
-    worker.post([this, sl, R, prom, sizes, read_at, maf_at]() {
+    std::atomic<int> *out = &rec_out[(size_t)d->rec];
+    ++*out;
+    worker.post([this, sl, R, prom, sizes, read_at, maf_at, out]() {
       const double w0 = now_us();
       int ok = PBSIM_SUCCEEDED;
       if (wants_text() && hipEventSynchronize(sl->ev_text) != hipSuccess) ok = fail("hipEventSynchronize failed (text emission)");
@@ -414,6 +424,7 @@ struct Job {
       if (trace)
         fprintf(stderr, "[pbsim job r%d] t=%.1f ms   worker: bytes of rec %lld on their way for %.1f ms (%lld + %lld)\n", rank,
                 (w0 - t_start) / 1e3, (long long)R->ref.unit, (now_us() - w0) / 1e3, (long long)sizes[0], (long long)sizes[1]);
+      --*out;
       prom->set_value(ok);
     });
   }
@@ -471,10 +482,13 @@ struct Job {
       acct_rec = &R;
       if (!defer_account && !account_deferred()) return PBSIM_FAILED;
       if (flush || plain) {
-        worker.post([this, sl, Rp, slot, flush, read_at, maf_at]() {
+        std::atomic<int> *out = &rec_out[(size_t)d->rec];
+        ++*out;
+        worker.post([this, sl, Rp, slot, flush, read_at, maf_at, out]() {
           const int ok = flush ? arena_flush(*sl, Rp->ref.unit, read_at, maf_at) : sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
           if (!ok) worker_fail();
           delivering[slot] = false;
+          --*out;
         });
       } else {
         delivering[slot] = false;  // streamed in stage 1 (or nothing to deliver): the slot is free
@@ -533,7 +547,9 @@ struct Job {
       Slot *sl = &c->slots[slot];
       Rec *Rp = &R;
       delivering[slot] = true;
-      worker.post([this, sl, Rp, slot]() {  // FIFO behind the record's bulk deliveries: offsets and accounting stay in read order
+      std::atomic<int> *out = &rec_out[(size_t)rec];
+      ++*out;
+      worker.post([this, sl, Rp, slot, out]() {  // FIFO behind the record's bulk deliveries: offsets and accounting stay in read order
         int ok = PBSIM_SUCCEEDED;
         int64_t nr = 0, nm = 0;
         if (wants_text() && hipEventSynchronize(sl->ev_text) != hipSuccess) ok = fail("hipEventSynchronize failed (text emission)");
@@ -551,6 +567,7 @@ struct Job {
         Rp->tail_maf += nm;
         if (!ok) worker_fail();
         delivering[slot] = false;
+        --*out;
       });
       reads_walked += 1;
       reads_delivered += bi.n_final;
@@ -576,7 +593,11 @@ struct Job {
   // ---- merge + completion of a record (collective) -------------------------------------------------------------------
   int finish_record(int rec) {
     Rec &R = recs[(size_t)rec];
-    if (!complete_pending()) return PBSIM_FAILED;  // every rank is here at the same point of the round sequence
+    // The record's byte totals must be final: if the round whose sizes are still to be exchanged is one of ITS rounds, exchange
+    // them now (the same decision on every rank -- every rank is here at the same point of the round sequence).  A pending
+    // round of a LATER record stays pending: waiting for its bytes here would stall the loop for a whole delivery.
+    if (pending && pending->rec == rec && !complete_pending()) return PBSIM_FAILED;
+    if (!account_deferred()) return PBSIM_FAILED;  // (the statistics of the record's last round may still be due)
     const double tt = now_us();
     int tail_ok = PBSIM_SUCCEEDED;
     std::string tail_err;
@@ -586,7 +607,7 @@ struct Job {
     }
     const double td = now_us();
     bd_tail_block += td - tt;
-    worker.drain();  // every delivery of the record has reached the sink and the statistics
+    wait_record(rec);  // every delivery of the record has reached the sink and the statistics
     bd_drain += now_us() - td;
     // [2] = status: a rank whose tail or worker failed tells the others here instead of leaving them in the merge's collectives
     int64_t extra[3] = {R.tail_read, R.tail_maf, (tail_ok && !wfailed) ? 0 : 1};
@@ -622,6 +643,12 @@ struct Job {
     int64_t n_total = (int64_t)(1.005 * remaining / mean) + 64;
     if (remaining <= 0) n_total = 64;
     int64_t n_per = std::min<int64_t>((n_total + W - 1) / W, R.cap);
+    // Ramp-up: nothing moves over the link until the job's first round has been walked and its text emitted, and a full round
+    // walks for 12-30 ms.  The first two rounds of a job are a fifth and a half of a full one: bytes flow after ~4 ms, and each
+    // round's walk still hides behind the delivery of the round in front of it (a round's bytes take ~3x its walk).  The same
+    // on every rank (`rounds` counts the rounds begun).  PBSIM_JOB_RAMP=0 turns it off (A/B).
+    static const bool ramp_on = !(getenv("PBSIM_JOB_RAMP") && atoi(getenv("PBSIM_JOB_RAMP")) == 0);
+    if (ramp_on && rounds < 2) n_per = std::min<int64_t>(n_per, std::max<int64_t>(64, (int64_t)((double)R.cap * (rounds == 0 ? 0.2 : 0.5))));
     n_per = std::max<int64_t>(n_per, 1);
     const int s = acquire_slot();
     c->cur = s;
@@ -785,9 +812,10 @@ struct Job {
           if (cand < 0) break;
           n_topup++;
         }
-        if (cand >= merged + 3) {
-          // at most three records' statistics are open at a time: merge the oldest first (a collective at a point of the
-          // round sequence that every rank reaches alike; by then its tail reads have long finished beside the next rounds)
+        if (cand >= merged + 2) {
+          // at most two records' statistics are open at a time: merge the oldest first (a collective at a point of the
+          // round sequence that every rank reaches alike; by then its tail reads have finished beside the next record's rounds,
+          // and the merge waits for that record's own deliveries only -- the worker keeps moving the later rounds' bytes)
           if (!recs[(size_t)merged].bulk_done) break;  // its rounds are still in flight: pop first
           if (!finish_record(merged)) return PBSIM_FAILED;
           merged++;
@@ -805,11 +833,12 @@ struct Job {
       }
       if (!process_round()) return PBSIM_FAILED;
     }
-    if (!complete_pending()) return PBSIM_FAILED;
+    // (the last round's sizes are exchanged by the merge of its record: the records in front of it merge while its bytes move)
     for (; merged < n; merged++) {
       if (!recs[(size_t)merged].bulk_done) return fail("internal: a record was left unfinished");
       if (!finish_record(merged)) return PBSIM_FAILED;
     }
+    if (!complete_pending()) return PBSIM_FAILED;
     worker.finish();
     return check_worker();
   }
@@ -963,7 +992,10 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // GPU with two others (18.5 instead of 29.3 ms a launch) and half the slots stay unallocated.
   const int W = J.W;
   const bool delivers = J.sink && (J.sink->on_read_text || J.sink->on_maf_text);
-  J.depth = std::max(1, std::min(kMaxSlots - 3, jd ? atoi(jd) : (delivers && W <= 2 ? 1 : 3)));
+  // Several ranks (round 4, measured per rank against virtual ranks -- profiles/r04_replay_depth_ab.txt): every rank delivers
+  // its own blocks over its own link, so a rank of eight is in the same regime as one GPU alone: configs[4] 594 / 592 / 570 ms
+  // per rank with 3 / 2 / 1 rounds in flight, configs[1] 190 / 189 / 191.
+  J.depth = std::max(1, std::min(kMaxSlots - 3, jd ? atoi(jd) : (delivers ? 1 : 3)));
   // ---- the records' preparation (upload + k_hp_*) has been running since pbsim_job_add_record: collect it
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));
   const size_t n = c->job_records.size();
@@ -996,6 +1028,8 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     c->bias.hp11_seen = true;
   }
   J.recs.resize(n);
+  J.rec_out.reset(new std::atomic<int>[n]);
+  for (size_t i = 0; i < n; i++) J.rec_out[i] = 0;
   bool seen11 = c->bias.hp11_seen;
   int64_t max_quota = 0;
   for (size_t i = 0; i < n; i++) {

@@ -112,20 +112,23 @@ int stats_merge(StatsAcc *st, const pbsim_params &p, const pbsim_comm *comm, int
     }
     COMM_OK(comm->all_gather_i64(comm->user, desc.data(), max_blocks * 2, all_desc.data()));
     static_assert(sizeof(double) == sizeof(int64_t), "values travel as their bit patterns");
-    std::vector<int64_t> vals((size_t)std::max<int64_t>(max_values, 1), 0), all_vals((size_t)W * vals.size());
+    // (8 B per task of the record on every rank -- 40 MB for a 750 Mbp record at depth 60: not value-initialised, the
+    // collective writes all of it, and what lies behind a rank's own count is never read)
+    const size_t n_vals = (size_t)std::max<int64_t>(max_values, 1);
+    std::unique_ptr<int64_t[]> vals(new int64_t[n_vals]), all_vals(new int64_t[(size_t)W * n_vals]);
     size_t at = 0;
     for (const StatsAcc::Block &b : st->blocks) {
       if (!b.values.empty()) memcpy(&vals[at], b.values.data(), b.values.size() * 8);
       at += b.values.size();
     }
-    COMM_OK(comm->all_gather_i64(comm->user, vals.data(), (int64_t)vals.size(), all_vals.data()));
+    COMM_OK(comm->all_gather_i64(comm->user, vals.get(), (int64_t)n_vals, all_vals.get()));
     struct Piece {
       int64_t first, n;
       const int64_t *v;
     };
     std::vector<Piece> pieces;
     for (int r = 0; r < W; r++) {
-      const int64_t *v = &all_vals[(size_t)r * vals.size()];
+      const int64_t *v = &all_vals[(size_t)r * n_vals];
       for (int64_t i = 0; i < meta[(size_t)r * 2]; i++) {
         const int64_t first = all_desc[((size_t)r * max_blocks + i) * 2], n = all_desc[((size_t)r * max_blocks + i) * 2 + 1];
         pieces.push_back(Piece{first, n, v});

@@ -18,8 +18,8 @@ def genome(n, seed):
     return harness.synth_bases(n, seed).tobytes()
 
 
-@pytest.mark.parametrize("method,world,scratch_mb", [("errhmm", 3, 6), ("errhmm", 8, 24), ("qshmm", 4, 8)])
-def test_replayed_ranks_tile_the_one_gpu_output(method, world, scratch_mb):
+@pytest.mark.parametrize("method,world,target", [("errhmm", 3, 250_000), ("errhmm", 8, 120_000), ("qshmm", 4, 400_000)])
+def test_replayed_ranks_tile_the_one_gpu_output(method, world, target, monkeypatch):
     import ctypes as C
     import torch
     import pbsim3_amd as P
@@ -29,10 +29,13 @@ def test_replayed_ranks_tile_the_one_gpu_output(method, world, scratch_mb):
     p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=5, depth=6.0,
                          len_mean=1500.0, len_sd=1100.0, pass_num=2 if qs else 1)
     G = 1_500_000
+    # rounds of `target` bases per rank (the test hook that sizes the rounds; a pool too small for a block would make the job
+    # retry with halved caps -- every rank's business, which virtual ranks do not model and refuse)
+    monkeypatch.setenv("PBSIM_JOB_TARGET_RANKS", str(target))
     recs = [torch.frombuffer(bytearray(genome(G, 10 + i)), dtype=torch.uint8).cuda() for i in range(2)]
     tables = RR.build_tables(P, harness, p, model, qs, recs, G, 0)
     with P.Context(p, 0) as ctx:
-        ctx.set_scratch_bytes(scratch_mb << 20)
+        ctx.set_scratch_bytes(256 << 20)
         (ctx.load_qshmm if qs else ctx.load_errhmm)(harness.model_path(model))
         for t in recs:
             ctx.job_add_record_device(t.data_ptr(), G)
@@ -50,13 +53,16 @@ def test_replayed_ranks_tile_the_one_gpu_output(method, world, scratch_mb):
                    P.REC_DONE_CB(lambda u, rec, st, rb, mb: 1))
             sink = P.RecordSink(None, *cbs)
             vr = RR.VirtualRanks(P, ctx, r, world, tables)
-            P._check(ctx.lib.pbsim_job_run(ctx.h, C.byref(vr.comm), C.byref(sink)))
+            ok = ctx.lib.pbsim_job_run(ctx.h, C.byref(vr.comm), C.byref(sink))
+            assert vr.error is None, vr.error
+            P._check(ok)
             checked += vr.checked
             rounds += ctx.job_counters()["rounds"]
             for k in got:
                 for w in (0, 1):
                     pieces[k][w].extend(got[k][w])
-        assert checked == 2 * rounds and rounds >= 2 * world      # gathers A and B of every round of every rank, against the table
+        # gathers A and B of every round a rank popped were checked against the table (rounds begun behind a cut are dropped unexchanged)
+        assert checked % 2 == 0 and rounds <= checked <= 2 * rounds and rounds >= 2 * world
         for k in want:
             for w in (0, 1):
                 text = want[k][w]

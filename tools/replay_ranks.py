@@ -77,46 +77,66 @@ def build_tables(P, harness, p, model, qs, recs, G, local, margin=1.06):
 
 
 class VirtualRanks:
-    """pbsim_comm of rank `rank` of `world` whose other ranks are answered from the read tables"""
+    """pbsim_comm of rank `rank` of `world` whose other ranks are answered from the read tables.  The callbacks work on the
+    raw buffers (the library hands over zeroed receive buffers): the statistics merge of a large record gathers tens of MB,
+    of which only this rank's slice is written here -- a callback costs tens of microseconds, like a small collective."""
 
     def __init__(self, P, ctx, rank, world, tables):
-        self.ctx, self.rank, self.world, self.tables = ctx, rank, world, tables
+        import ctypes as C
+        self.C, self.ctx, self.rank, self.world, self.tables = C, ctx, rank, world, tables
         self.events = []          # (phase, t_enter, t_exit) per collective
         self.checked = 0
-        self.comm = P.make_comm(rank, world, self.all_gather, self.all_reduce)
+        self.error = None
+        self._cbs = (P.GATHER_CB(self._gather), P.REDUCE_CB(self._reduce), P.BCAST_CB(), P.ABORT_CB())
+        self.comm = P.Comm(None, rank, world, *self._cbs)
 
-    def all_gather(self, a):
+    def _gather(self, user, send, n, recv):
         t_in = time.perf_counter()
-        ph, rec, first, n_per, W, len_total, quota, _ = self.ctx.job_progress()
-        out = np.tile(np.asarray(a, dtype=np.int64), (W, 1))
-        if ph == 1 and len(a) == 2:
-            tab = self.tables[rec]
-            for q in range(W):
-                out[q, 0] = tab.block_sum(first + q * n_per, n_per)
-                out[q, 1] = 0
-            if a[1] == 0 and out[self.rank, 0] != a[0]:
-                raise RuntimeError("replay: gather A of rank %d differs from the table (%d vs %d)" % (self.rank, a[0], out[self.rank, 0]))
-            out[self.rank] = a
-            self.checked += 1
-        elif ph == 2 and len(a) == 4:
-            tab = self.tables[rec]
-            before = len_total
-            for q in range(W):
-                nf, need, after = tab.cut(first + q * n_per, n_per, before, quota)
-                out[q] = (nf, need, after, 0)
-                before += tab.block_sum(first + q * n_per, n_per)
-            if a[3] == 0 and tuple(out[self.rank, :3]) != tuple(a[:3]):
-                raise RuntimeError("replay: gather B of rank %d differs from the table (%s vs %s)" % (self.rank, list(a), list(out[self.rank])))
-            out[self.rank] = a
-            self.checked += 1
+        try:
+            ph, rec, first, n_per, W, len_total, quota, _ = self.ctx.job_progress()
+            r = self.rank
+            a = [send[i] for i in range(n)] if n <= 8 else None
+            if ph == 1 and n == 2:
+                if a[1] == 1:
+                    raise RuntimeError("replay: rank %d's block overflows its scratch pool; the retry with halved caps depends on "
+                                       "every rank's pool and is not modelled -- give the ranks a larger pool" % r)
+                tab = self.tables[rec]
+                for q in range(W):
+                    recv[2 * q] = tab.block_sum(first + q * n_per, n_per)
+                    recv[2 * q + 1] = 0
+                if a[1] == 0 and recv[2 * r] != a[0]:
+                    raise RuntimeError("replay: gather A of rank %d differs from the table (%d vs %d)" % (r, a[0], recv[2 * r]))
+                recv[2 * r], recv[2 * r + 1] = a
+                self.checked += 1
+            elif ph == 2 and n == 4:
+                tab = self.tables[rec]
+                before = len_total
+                for q in range(W):
+                    nf, need, after = tab.cut(first + q * n_per, n_per, before, quota)
+                    recv[4 * q], recv[4 * q + 1], recv[4 * q + 2], recv[4 * q + 3] = nf, need, after, 0
+                    before += tab.block_sum(first + q * n_per, n_per)
+                mine = [recv[4 * r + i] for i in range(3)]
+                if a[3] == 0 and mine != a[:3]:
+                    raise RuntimeError("replay: gather B of rank %d differs from the table (%s vs %s)" % (r, a, mine))
+                for i in range(4):
+                    recv[4 * r + i] = a[i]
+                self.checked += 1
+            elif ph == 3 and n == 3:      # gather C: every rank delivers what this one does
+                for q in range(W):
+                    for i in range(3):
+                        recv[3 * q + i] = a[i]
+            else:                         # the statistics merge: this rank's slice only (the others contribute nothing)
+                self.C.memmove(self.C.addressof(recv.contents) + 8 * n * r, send, 8 * n)
+        except Exception as e:            # noqa: BLE001 -- reported by the caller; the job fails through the callback's status
+            self.error = e
+            return 0
         self.events.append((ph, t_in, time.perf_counter()))
-        return out
+        return 1
 
-    def all_reduce(self, a, op):
-        t_in = time.perf_counter()
-        ph = self.ctx.job_progress()[0]
-        self.events.append((ph + 10, t_in, time.perf_counter()))
-        return a                  # identical GPUs agree with themselves; the statistics of the other ranks are not needed
+    def _reduce(self, user, buf, n, op):
+        t = time.perf_counter()           # identical GPUs agree with themselves; the other ranks' statistics are not needed
+        self.events.append((10, t, t))
+        return 1
 
 
 def segments(events, t0, t1):
@@ -132,19 +152,29 @@ def segments(events, t0, t1):
 def replay(P, C, ctx, tables, world, run_job, runs=2):
     """every rank of `world` alone on the GPU, `runs` timed runs each (after one warm-up of rank 0 that sizes the pools);
     run_job(comm) -> sink runs the job once on `ctx`"""
-    run_job(VirtualRanks(P, ctx, 0, world, tables).comm)
+    def go(vr):
+        try:
+            return run_job(vr.comm)
+        except Exception:
+            if vr.error is not None:
+                raise vr.error
+            raise
+    go(VirtualRanks(P, ctx, 0, world, tables))
     per_rank = []
-    for r in range(world):
+    import os
+    only = os.environ.get("PBSIM_REPLAY_ONLY")   # experiment knob: a subset of the ranks, e.g. "0,3,7"
+    for r in ([int(x) for x in only.split(",") if int(x) < world] if only else range(world)):
         best = None
         for _ in range(runs):
             vr = VirtualRanks(P, ctx, r, world, tables)
             t0 = time.perf_counter()
-            sink = run_job(vr.comm)
+            sink = go(vr)
             t1 = time.perf_counter()
             bd = ctx.job_breakdown()
             cn = ctx.job_counters()
-            row = {"rank": r, "wall_ms": (t1 - t0) * 1e3, "segments_ms": [x * 1e3 for x in segments(vr.events, t0, t1)],
-                   "phases": [e[0] for e in vr.events], "in_callbacks_ms": sum(e[2] - e[1] for e in vr.events) * 1e3,
+            in_cb = sum(e[2] - e[1] for e in vr.events)
+            row = {"rank": r, "wall_ms": (t1 - t0) * 1e3, "wall_less_callbacks_ms": (t1 - t0 - in_cb) * 1e3, "segments_ms": [x * 1e3 for x in segments(vr.events, t0, t1)],
+                   "phases": [e[0] for e in vr.events], "in_callbacks_ms": in_cb * 1e3, "collectives": len(vr.events),
                    "exchanges_checked": vr.checked, "rounds": cn["rounds"], "reads_walked": cn["reads_walked"],
                    "reads_delivered": cn["reads_delivered"], "bases": cn["bases"],
                    "host_bytes": sink.read_bytes + sink.maf_bytes,
@@ -160,7 +190,7 @@ def replay(P, C, ctx, tables, world, run_job, runs=2):
         sync = sum(max(x["segments_ms"][i] for x in per_rank) for i in range(k))
     worst = max(per_rank, key=lambda x: x["wall_ms"])
     return {"world": world, "per_rank": per_rank, "max_rank_wall_ms": worst["wall_ms"], "slowest_rank": worst["rank"],
-            "mean_rank_wall_ms": sum(x["wall_ms"] for x in per_rank) / world,
+            "mean_rank_wall_ms": sum(x["wall_ms"] for x in per_rank) / len(per_rank),
             "sync_critical_path_ms": sync,
             "bases_delivered_all_ranks": sum(x["bases"] for x in per_rank),
             "speculation_waste": 1.0 - sum(x["reads_delivered"] for x in per_rank) / max(1, sum(x["reads_walked"] for x in per_rank)),
