@@ -224,6 +224,7 @@ struct Slot {
   DevBuf d_task_of_slot, d_slot_of_task, d_wave_cap, d_wave_off, d_wg_tmp, d_wg_order;
   DevBuf d_out_len, d_maf_len, d_nsub, d_nins, d_ndel, d_qsum;
   DevBuf d_cum, d_scan_tmp, d_rt_len, d_mt_len, d_row_dst;
+  DevBuf d_chain, d_chain_mask;        // a chain of truncated reads: ChainState; the step's view of task_of_slot
   DevBuf d_scratch, d_read_text, d_maf_text;
   HostBuf h_read_text, h_maf_text, h_stats, h_flags;
   DfLane df[2];                        // deflate staging: [0] read text (or any single stream), [1] MAF text beside it
@@ -241,6 +242,7 @@ struct Slot {
                                        // on another stream or thread when pbsim_ctx::defer_text_sync)
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
   bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
+  bool b_chain = false;                // the batch is a chain of truncated reads (walk_begin(.., chain))
   int64_t b_pass0 = 0;
   pbsim_batch_info b_info;
 };
@@ -335,7 +337,11 @@ struct pbsim_ctx {
 namespace pbsim {
 RefDesc current_ref(const pbsim_ctx *c);
 int64_t quota_of(const pbsim_ctx *c, int64_t ref_len);  // (long long)(depth * len), pbsim.cpp:705
-int walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining);
+// chain: the n_reads reads are the truncated reads behind a quota cut, each depending on the one before (pbsim.cpp:3792-3800);
+// truncate_remaining = what is left of the quota in front of the first; ended by chain_end_finalize
+int walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining, bool chain = false);
+int chain_end_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out);
+constexpr int kChainReads = 6;  // steps enqueued per chain (a chain is 2-3 reads as a rule: each leaves ~3 % of its length)
 int64_t batch_capacity_for(const pbsim_ctx *c, int64_t ref_len);  // reads one batch is sized to (scratch budget)
 // the two halves of pbsim_batch_finalize on the selected slot: the quota cut, then text sizes + scans + text emission
 int finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out);

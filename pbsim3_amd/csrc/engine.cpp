@@ -558,8 +558,10 @@ static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads, bool hp_flag) {
 }
 
 // header draw -> bucketing -> walk -> pass-0 prefix of reads [first_read, first_read + n_reads) of `ref`, on the selected slot
-extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining) {
+extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining,
+                                   bool chain) {
   if (!c || n_reads < 1 || first_read < 1) return fail("pbsim_batch_walk: bad argument");
+  if (chain && (truncate_remaining < 0 || c->p.strategy != PBSIM_STRATEGY_WGS)) return fail("internal: a chain of truncated reads needs a quota");
   NEED_DEVICE(c);
   if (c->s().b_enqueued) return fail("pbsim_batch_walk_begin: this slot still has a batch in flight (pbsim_batch_walk_end)");
   if (c->p.method == PBSIM_METHOD_SAMPLE) return fail("the sampling method runs through pbsim_simulate_sample");
@@ -567,7 +569,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   if (!ref.seq) return fail("no reference set (pbsim_set_reference)");
   if (trans && (truncate_remaining >= 0 || first_read + n_reads - 1 > c->trans_reads))
     return fail("pbsim_batch_walk: read range outside the transcript set");
-  if (truncate_remaining >= 0 && n_reads != 1) return fail("a truncated batch holds exactly one read");
+  if (truncate_remaining >= 0 && n_reads != 1 && !chain) return fail("a truncated batch holds exactly one read");
   if (first_read + n_reads > 0xffffffffLL) return fail("read index exceeds 32 bits");
   HIP_OK(hipSetDevice(c->device));
   if (!ensure_header_tables(c) || !ensure_class_tables(c)) return PBSIM_FAILED;
@@ -605,6 +607,10 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   HIP_OK(c->s().d_qsum.ensure(n_tasks * 8));
   HIP_OK(c->s().d_cum.ensure((n_reads + 1) * 8));
   HIP_OK(c->s().d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
+  if (chain) {
+    HIP_OK(c->s().d_chain.ensure(64));
+    HIP_OK(c->s().d_chain_mask.ensure(slots_max * 4));
+  }
   // The pool is the budget, unless this batch cannot need that much: a wave's rows hold at most 2 * Lmax + pad columns
   // (Lmax = the longest read the header can draw), so a handful of reads (the truncated tail reads) gets by with little.
   const double lmax = (double)std::min<int64_t>(c->p.len_max, std::max<int64_t>(ref.len, 1));
@@ -718,6 +724,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     // 12.6 -> 13.3 ms).  tools/coop_dynamic_ab.sh; PBSIM_COOP_DYNAMIC=0/1 forces either.
     const char *cd = getenv("PBSIM_COOP_DYNAMIC");
     w.coop_dynamic = cd ? atoi(cd) == 1 : (coop_len != INT32_MAX && n_tasks >= 4LL * kCoopWaves * kCoopWorkgroups && n_tasks <= 250000);
+    if (chain) w.coop_dynamic = 0;  // (the steps of a chain share the batch's flags: the units' counter is not theirs to draw from)
   }
   w.coop_end = s.coop_end;
   w.wave_cap = s.wave_cap;
@@ -732,10 +739,21 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   w.flags = flags;
   // the walk of a batch goes to the slot's LOW priority stream; a single truncated tail read is the opposite case -- one
   // workgroup whose latency a record's completion waits for -- and must not queue behind the pending workgroups of the batches
-  hipStream_t ws = (n_reads == 1 && truncate_remaining >= 0) ? c->s().stream : c->s().walk_stream;
+  hipStream_t ws = (truncate_remaining >= 0) ? c->s().stream : c->s().walk_stream;
   HIP_OK(hipEventRecord(c->s().ev_prep, c->s().stream));
   HIP_OK(hipStreamWaitEvent(ws, c->s().ev_prep, 0));
   HIP_OK(hipEventRecord(c->s().ev1, ws));
+  // A chain of truncated reads (kernels.h ChainState): the header and the layout above stand for upper bounds -- every read
+  // at most what is left of the quota NOW -- and the steps below re-draw and walk one read after the other, all on this one
+  // stream, without a host round trip in between.  The walks of step k see a task map that holds read k's tasks only.
+  ChainState *d_chain = chain ? c->s().d_chain.as<ChainState>() : nullptr;
+  if (chain) launch_chain_init(d_chain, truncate_remaining, ws);
+  const int n_steps = chain ? (int)n_reads : 1;
+  for (int step = 0; step < n_steps; step++) {
+  if (chain) {
+    launch_chain_prepare(h, step, P, s.task_of_slot, c->s().d_chain_mask.as<int32_t>(), slots_max, d_chain, ws);
+    w.task_of_slot = c->s().d_chain_mask.as<int32_t>();
+  }
   if (c->p.method == PBSIM_METHOD_ERR) {
     w.stride = c->ect.stride;
     w.rows_off = c->ect.rows_off;
@@ -794,6 +812,8 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     }
     (void)lanes_idle;
   }
+  if (chain) launch_chain_update(step, P, w.out_len, d_chain, ws);
+  }  // steps
   HIP_OK(hipEventRecord(c->s().ev2, ws));
   HIP_OK(hipStreamWaitEvent(c->s().stream, c->s().ev2, 0));
   launch_gather_pass0_scan(w.out_len, n_reads, P, c->s().d_cum.as<int64_t>(), c->s().d_scan_tmp.as<int64_t>(),
@@ -803,6 +823,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   c->s().b_first = first_read;
   c->s().b_n = n_reads;
   c->s().b_slots_max = slots_max;
+  c->s().b_chain = chain;
   c->s().b_truncated = truncate_remaining >= 0 || trans;  // trans has no quota: every read is final
   c->s().b_enqueued = true;
   c->s().b_walked = false;
@@ -822,7 +843,7 @@ int pbsim_batch_walk_end(pbsim_ctx *c, int64_t *pass0_bases) {
   float ms = 0;
   // the profile is about the walk kernel at work: a launch that carries a single truncated tail read (latency of one lane,
   // no bytes to speak of) is counted apart
-  const bool bulk = c->s().b_n > 1;
+  const bool bulk = c->s().b_n > 1 && !c->s().b_chain;
   if (hipEventElapsedTime(&ms, c->s().ev1, c->s().ev2) == hipSuccess) (bulk ? c->prof_walk_ms : c->prof_tail_ms) += ms;
   if (!bulk) c->prof_tail_launches++;
   if (bulk && c->ev_prof_base) {
@@ -858,6 +879,30 @@ int pbsim_batch_fetch_lengths(pbsim_ctx *c, int32_t *rawlen, int32_t *len, int32
   if (out_len_pass0)  // out_len is per task (read-major, pass minor): every pass_num-th value
     HIP_OK(hipMemcpy2DAsync(out_len_pass0, 4, sl.d_out_len.p, (size_t)c->p.pass_num * 4, 4, n, hipMemcpyDeviceToHost, sl.stream));
   HIP_OK(hipStreamSynchronize(sl.stream));
+  return PBSIM_SUCCEEDED;
+}
+
+// The chain of truncated reads begun with walk_begin(.., chain) on the selected slot: waits for its steps, says how far it
+// got (reads made -- all final --, their pass-0 bases, whether the quota is reached) and emits the text of the reads made.
+extern "C++" int pbsim::chain_end_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out) {
+  if (!c || !c->s().b_enqueued || !c->s().b_chain) return fail("internal: no chain of truncated reads on this slot");
+  if (!pbsim_batch_walk_end(c, nullptr)) return PBSIM_FAILED;
+  Slot &sl = c->s();
+  ChainState *pin = reinterpret_cast<ChainState *>((char *)sl.h_flags.p + sizeof(DeviceFlags) + 16);  // pinned (read_flags)
+  HIP_OK(hipMemcpyAsync(pin, sl.d_chain.p, sizeof(ChainState), hipMemcpyDeviceToHost, sl.stream));
+  HIP_OK(hipStreamSynchronize(sl.stream));
+  const ChainState cs = *pin;
+  pbsim_batch_info bi;
+  memset(&bi, 0, sizeof bi);
+  bi.first_read = sl.b_first;
+  bi.n_reads = sl.b_n;
+  bi.n_final = cs.made;
+  bi.len_total_after = len_total_before + cs.total;
+  bi.quota_reached = cs.done != 0;
+  bi.need_truncated_read = !cs.done;
+  sl.b_info = bi;
+  if (!finalize_text(c, &bi)) return PBSIM_FAILED;
+  *out = bi;
   return PBSIM_SUCCEEDED;
 }
 

@@ -221,10 +221,17 @@ struct Job {
       if (r.tail_slot == s) return true;
     return false;
   }
-  // The last slot belongs to the truncated tail reads (one read at a time: its pools stay small), the others to the rounds.
-  static constexpr int kTailSlot = kMaxSlots - 1;
+  // The last two slots belong to the chains of truncated tail reads (a handful of reads: their pools stay small), the others
+  // to the rounds.  At most two records are open at a time (run(): a record is merged before the record after the next
+  // begins), so a record's chain never waits for another record's.
+  static constexpr int kTailSlot = kMaxSlots - 2;
   int free_slot() const {
     for (int s = 0; s < kTailSlot; s++)
+      if (!slot_busy(s)) return s;
+    return -1;
+  }
+  int free_tail_slot() const {
+    for (int s = kTailSlot; s < kMaxSlots; s++)
       if (!slot_busy(s)) return s;
     return -1;
   }
@@ -244,11 +251,6 @@ struct Job {
       std::unique_lock<std::mutex> lk(worker.mu);
       worker.cv_idle.wait_for(lk, std::chrono::milliseconds(2));
     }
-  }
-  bool a_tail_is_running() const {
-    for (const Rec &r : recs)
-      if (r.tail_slot >= 0) return true;
-    return false;
   }
 
   void drop_round(const Round &r) {
@@ -501,48 +503,44 @@ struct Job {
   }
 
   // ---- the tail of a record (owner rank only) ------------------------------------------------------------------------
+  // The truncated reads behind the cut (pbsim.cpp:3792-3800) depend on each other -- each takes what the one before left of
+  // the quota -- so they run as ONE chain on the device (engine.cpp walk_begin(.., chain): kChainReads steps enqueued back
+  // to back, no host round trip between two reads), followed by ONE text emission and ONE delivery for the reads it made.
+  // (Round 3 stepped the chain from here, read by read: 1.1-2.4 ms and a slot's worth of delivery per read.)
   int tail_begin(Rec &R) {
-    const int s = (a_tail_is_running() || slot_busy(kTailSlot)) ? -1 : kTailSlot;  // one truncated read at a time, on its own slot
-    if (s < 0) {  // every slot is busy (deliveries in flight): tail_poll starts the read as soon as one is free
+    const int s = free_tail_slot();
+    if (s < 0) {  // both chains' slots are still with the worker (deliveries in flight): tail_poll starts it as soon as one is free
       R.tail_waiting = true;
       return PBSIM_SUCCEEDED;
     }
     R.tail_waiting = false;
     c->cur = s;
-    if (!walk_begin(c, R.ref, R.next_read, 1, R.quota - R.len_total)) return PBSIM_FAILED;
+    if (!walk_begin(c, R.ref, R.next_read, kChainReads, R.quota - R.len_total, true)) return PBSIM_FAILED;
     R.tail_slot = s;
     return PBSIM_SUCCEEDED;
   }
-  // one step of the chain if the read in flight has finished (or `block`); begins the next truncated read if one is due.
-  // A tail read's bytes follow the record's bulk bytes: nothing is delivered while the sizes of the record's last round are
+  // collects the chain if it has finished (or `block`); begins the next one if the quota is still not reached.
+  // A chain's bytes follow the record's bulk bytes: nothing is delivered while the sizes of the record's last round are
   // still to be exchanged (complete_pending, a collective, is the main loop's business -- only the owner is here).
   int tail_poll(int rec, bool block) {
     Rec &R = recs[(size_t)rec];
     for (;;) {
       if (R.tail_waiting) {
-        if (block) {  // another record's chain first (one truncated read at a time), then a slot from the worker
-          for (size_t o = 0; o < recs.size(); o++)
-            if ((int)o != rec && recs[o].tail_slot >= 0 && !tail_poll((int)o, true)) return PBSIM_FAILED;
-          if (slot_busy(kTailSlot)) worker.drain();
+        if (block) {  // a slot from the worker
+          std::unique_lock<std::mutex> lk(worker.mu);
+          worker.cv_idle.wait(lk, [&] { return free_tail_slot() >= 0 || (worker.q.empty() && worker.active == 0); });
         }
         if (!tail_begin(R)) return PBSIM_FAILED;
-        if (R.tail_waiting) return block ? fail("internal: no slot for a truncated read") : PBSIM_SUCCEEDED;
+        if (R.tail_waiting) return block ? fail("internal: no slot for the truncated reads") : PBSIM_SUCCEEDED;
       }
       if (R.tail_slot < 0) return PBSIM_SUCCEEDED;
       if (pending && pending->rec == rec) return block ? fail("internal: tail before the record's last sizes") : PBSIM_SUCCEEDED;
       c->cur = R.tail_slot;
       if (!block && hipEventQuery(c->s().ev3) != hipSuccess) return PBSIM_SUCCEEDED;
       const double t0 = now_us();
-      n_tail_reads++;
-      if (!pbsim_batch_walk_end(c, nullptr)) return PBSIM_FAILED;
-      const double ta = now_us();
       pbsim_batch_info bi;
-      if (!finalize_cut(c, R.len_total, &bi)) return PBSIM_FAILED;
-      const double tb = now_us();
-      if (!finalize_text(c, &bi)) return PBSIM_FAILED;
-      if (trace)
-        fprintf(stderr, "[pbsim job r%d]   tail step: walk_end %.2f cut %.2f text %.2f ms (len %lld)\n", rank, (ta - t0) / 1e3,
-                (tb - ta) / 1e3, (now_us() - tb) / 1e3, (long long)bi.bases);
+      if (!chain_end_finalize(c, R.len_total, &bi)) return PBSIM_FAILED;
+      n_tail_reads += bi.n_final;
       const int slot = R.tail_slot;
       Slot *sl = &c->slots[slot];
       Rec *Rp = &R;
@@ -569,14 +567,14 @@ struct Job {
         delivering[slot] = false;
         --*out;
       });
-      reads_walked += 1;
+      reads_walked += bi.n_final;
       reads_delivered += bi.n_final;
       bases += bi.bases;
       ref_bases += bi.ref_bases;
       maf_columns += bi.maf_columns;
       if (trace)
-        fprintf(stderr, "[pbsim job r%d] t=%.1f ms rec %d tail read %lld: %.1f ms\n", rank, (t0 - t_start) / 1e3, rec + 1,
-                (long long)R.next_read, (now_us() - t0) / 1e3);
+        fprintf(stderr, "[pbsim job r%d] t=%.1f ms rec %d tail chain from read %lld: %lld reads, %.2f ms to collect\n", rank,
+                (t0 - t_start) / 1e3, rec + 1, (long long)R.next_read, (long long)bi.n_final, (now_us() - t0) / 1e3);
       R.next_read += bi.n_final;
       R.len_total = bi.len_total_after;
       R.tail_slot = -1;

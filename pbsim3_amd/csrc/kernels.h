@@ -71,6 +71,18 @@ struct HeaderArgs {
   const int32_t *ssp_rv;      // [rank_max+1]
 };
 
+// The truncated reads behind a record's quota cut (pbsim.cpp:3792-3800) form a chain: read k's length is what the reads in
+// front of it left of the quota.  The chain runs on the device as steps enqueued back to back (engine.cpp walk_chain_begin):
+// step k re-draws read k's header with the remaining quota (k_chain_prepare), walks read k alone (the walk kernels see a copy
+// of task_of_slot that holds read k's tasks only), and subtracts its pass-0 bases (k_chain_update).  No host round trip
+// between the reads; the host reads this block once when the steps are through.
+struct ChainState {
+  int64_t remaining;   // quota - len_total in front of the next read (<= 0: the quota is reached)
+  int64_t total;       // pass-0 bases of the reads made so far
+  int32_t made;        // reads made (they are final)
+  int32_t done;        // remaining <= 0
+};
+
 struct SortArgs {
   int64_t n_reads;
   int32_t pass_num;
@@ -191,6 +203,13 @@ void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int flag_hp11, int64_t 
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s);
 void launch_header_trans(const HeaderArgs &a, hipStream_t s);
 void launch_task_sort(const SortArgs &a, hipStream_t s);
+// chain step k, before its walk: header of read k with the chain's remaining quota (a.truncate_remaining is ignored; the
+// other reads' entries stay as they are), masked[slot] = task_of_slot[slot] for read k's tasks while the chain is running,
+// -1 everywhere else; after its walk: k_chain_update
+void launch_chain_prepare(const HeaderArgs &a, int k, int32_t pass_num, const int32_t *task_of_slot, int32_t *masked,
+                          int64_t n_slots_max, ChainState *chain, hipStream_t s);
+void launch_chain_update(int k, int32_t pass_num, const int32_t *out_len, ChainState *chain, hipStream_t s);
+void launch_chain_init(ChainState *chain, int64_t remaining, hipStream_t s);
 // min_lds_kb: LDS to ask for at least, i.e. a cap on the walk's workgroups per CU (kernels.hip walk_lds)
 void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
                         hipStream_t s, int min_lds_kb);

@@ -393,6 +393,55 @@ __global__ __launch_bounds__(256) void k_header_wgs(HeaderArgs a) {
   a.acc[i] = acc;
 }
 
+// K1c: the chain of truncated reads behind a quota cut (kernels.h ChainState).  One launch per step and side of the walk.
+__global__ void k_chain_init(ChainState *chain, int64_t remaining) {
+  chain->remaining = remaining;
+  chain->total = 0;
+  chain->made = 0;
+  chain->done = remaining <= 0;
+}
+
+__global__ __launch_bounds__(256) void k_chain_prepare(HeaderArgs a, int k, int32_t pass_num, const int32_t *task_of_slot,
+                                                        int32_t *masked, int64_t n_slots_max, const ChainState *chain) {
+  short_kernel_priority();
+  const bool running = !chain->done;  // (only k_chain_update, a kernel of its own between two steps, writes the state)
+  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot < n_slots_max) {
+    const int t = task_of_slot[slot];
+    masked[slot] = (running && t >= 0 && t / pass_num == k) ? t : -1;
+  }
+  if (slot == 0 && running) {  // pbsim.cpp:3793-3809 for read k with len_total = quota - remaining
+    const uint32_t read = (uint32_t)(a.first_read + k);
+    const U4 w = header_block(a.seed, a.unit, read);
+    int64_t L = a.prob2len[(int64_t)(w.x % (uint32_t)a.len_rv) + 1];
+    const int32_t raw = (int32_t)L;
+    if (L > chain->remaining) {
+      L = chain->remaining;
+      if (L < a.len_min) L = a.len_min;
+    }
+    int64_t off;
+    if (L >= a.ref_len) {
+      off = 0;
+      L = a.ref_len;
+    } else {
+      off = (int64_t)(w.z % (uint32_t)(a.ref_len - L + 1));
+    }
+    a.rawlen[k] = raw;
+    a.len[k] = (int32_t)L;
+    a.off[k] = (int32_t)off;
+    a.acc[k] = a.prob2acc[(int64_t)(w.y % (uint32_t)a.acc_rv) + 1];
+  }
+}
+
+__global__ void k_chain_update(int k, int32_t pass_num, const int32_t *out_len, ChainState *chain) {
+  if (chain->done) return;
+  const int64_t made = out_len[(int64_t)k * pass_num];  // only pass 0 counts toward the quota (pbsim.cpp:3989-3991)
+  chain->total += made;
+  chain->remaining -= made;
+  chain->made = k + 1;
+  if (chain->remaining <= 0) chain->done = 1;
+}
+
 // K1t: read header (trans).  pbsim.cpp:4488-4504 (= 2809-2825): no quota, start
 // position from the rank's bucket table, length clipped to the transcript end.
 __global__ __launch_bounds__(256) void k_header_trans(HeaderArgs a) {
@@ -2885,6 +2934,18 @@ void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int flag_hp11, int64_t 
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s) {
   if (a.n_reads <= 0) return;
   hipLaunchKernelGGL(k_header_wgs, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
+}
+
+void launch_chain_init(ChainState *chain, int64_t remaining, hipStream_t s) {
+  hipLaunchKernelGGL(k_chain_init, dim3(1), dim3(1), 0, s, chain, remaining);
+}
+void launch_chain_prepare(const HeaderArgs &a, int k, int32_t pass_num, const int32_t *task_of_slot, int32_t *masked,
+                          int64_t n_slots_max, ChainState *chain, hipStream_t s) {
+  hipLaunchKernelGGL(k_chain_prepare, dim3(blocks_for(n_slots_max, 256)), dim3(256), 0, s, a, k, pass_num, task_of_slot, masked,
+                     n_slots_max, chain);
+}
+void launch_chain_update(int k, int32_t pass_num, const int32_t *out_len, ChainState *chain, hipStream_t s) {
+  hipLaunchKernelGGL(k_chain_update, dim3(1), dim3(1), 0, s, k, pass_num, out_len, chain);
 }
 
 void launch_header_trans(const HeaderArgs &a, hipStream_t s) {
