@@ -114,6 +114,8 @@ struct DfLane {
   // lanes had their kernels and their copies in ONE queue, one behind the other, was a matter of creation order)
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;
+  bool own_streams = false;            // use `own` instead of the shared pair (job.cpp: the lanes of the tail chains' slots)
+  hipStream_t own[2] = {nullptr, nullptr};
   hipEvent_t ev_df[kDfBuffers] = {}, ev_cp[kDfBuffers] = {};
   hipEvent_t ev_k0[kDfBuffers] = {}, ev_k1[kDfBuffers] = {};  // timing: around k_deflate_chunks of the piece in dense buffer b
   // Pinned arena that holds ALL compressed pieces of one batch (job.cpp, several ranks): a rank learns where its bytes go in

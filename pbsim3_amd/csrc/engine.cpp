@@ -299,6 +299,8 @@ void pbsim_destroy(pbsim_ctx *c) {
         if (L.ev_k0[i]) (void)hipEventDestroy(L.ev_k0[i]);
         if (L.ev_k1[i]) (void)hipEventDestroy(L.ev_k1[i]);
       }
+      for (hipStream_t &st : L.own)
+        if (st) (void)hipStreamDestroy(st);
     }
     if (sl.walk_stream) (void)hipStreamDestroy(sl.walk_stream);
     if (sl.ev_prep) (void)hipEventDestroy(sl.ev_prep);
@@ -1224,7 +1226,14 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     if (&slot.df[1] == &sl) lane_index = 1;
   for (int i = 0; i < 2; i++)
     if (!c->df_streams[lane_index][i]) HIP_OK(hipStreamCreateWithFlags(&c->df_streams[lane_index][i], hipStreamNonBlocking));
-  sl.stream = c->df_streams[lane_index][0];
+  hipStream_t lane_streams[2] = {c->df_streams[lane_index][0], c->df_streams[lane_index][1]};
+  if (sl.own_streams) {  // a lane that runs BESIDE the bulk deliveries (the tail chains' worker): not behind their pieces in one stream
+    for (int i = 0; i < 2; i++)
+      if (!sl.own[i]) HIP_OK(hipStreamCreateWithFlags(&sl.own[i], hipStreamNonBlocking));
+    lane_streams[0] = sl.own[0];
+    lane_streams[1] = sl.own[1];
+  }
+  sl.stream = lane_streams[0];
   // The look-back trusts any status word that carries the launch's epoch and a flag, and the words are never cleared between
   // launches -- so a NEW array must start from zeros (flag 0 = nothing published): hipMalloc hands back the freed array of a
   // destroyed context or lane with that lane's old words in it, and a lane's epochs restart.
@@ -1242,8 +1251,8 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   // the second set of staging buffers), the copy stream the next copy, and the host consumes piece k - 1 while piece k travels.
   // (Launching a piece only after the previous one's total had arrived left the link idle whenever the other lane was not
   // copying: 1.5 ms of kernels + a host round trip per 1.46 ms of copy.)
-  if (!sl.copy_stream) {
-    sl.copy_stream = c->df_streams[lane_index][1];
+  sl.copy_stream = lane_streams[1];
+  if (!sl.ev_df[0]) {
     for (int i = 0; i < kDfBuffers; i++) {
       HIP_OK(hipEventCreateWithFlags(&sl.ev_df[i], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&sl.ev_cp[i], hipEventDisableTiming));

@@ -159,6 +159,13 @@ struct Job {
   double t_start = 0;
   bool peer_failed = false;   // the failure came from another rank's status word (no need to abort the communicator)
   Worker worker;
+  // The chains of truncated tail reads deliver their few KB through a worker of their own: behind the bulk worker's FIFO a
+  // record's tail bytes -- and with them the record's merge, which the main loop waits for -- queued behind the 30-40 ms
+  // deliveries of the NEXT record's rounds (measured per rank of eight: 3 x 32 ms of a 195 ms job, profiles/r04_replay_*).
+  Worker tail_worker;
+  std::mutex sink_mu[2];  // a callback is never called concurrently with itself (include/pbsim3_amd.h): the two workers share the sink
+  std::mutex out_mu;
+  std::condition_variable out_cv;
   std::atomic<bool> delivering[kMaxSlots];
   std::atomic<bool> wfailed{false};
   std::mutex werr_mu;
@@ -168,9 +175,13 @@ struct Job {
   // worker is FIFO, so that is as soon as it has passed them -- not for the rounds of later records behind them
   std::unique_ptr<std::atomic<int>[]> rec_out;
   void wait_record(int rec) {
-    if (!worker.running) return;
-    std::unique_lock<std::mutex> lk(worker.mu);
-    worker.cv_idle.wait(lk, [&] { return rec_out[(size_t)rec].load() == 0; });
+    std::unique_lock<std::mutex> lk(out_mu);
+    out_cv.wait(lk, [&] { return rec_out[(size_t)rec].load() == 0; });
+  }
+  void delivered_one(std::atomic<int> *out) {  // on a worker thread, at the end of a delivery
+    --*out;
+    { std::lock_guard<std::mutex> lk(out_mu); }
+    out_cv.notify_all();
   }
 
   Job() {
@@ -270,6 +281,7 @@ struct Job {
   }
   void drop_everything() {
     worker.drain();
+    tail_worker.drain();
     for (const Round &r : fifo) drop_round(r);
     fifo.clear();
     for (Rec &r : recs)
@@ -300,13 +312,15 @@ struct Job {
     HIP_OK(hipStreamSynchronize(sl.stream));
     return PBSIM_SUCCEEDED;
   }
+  int call_sink(int which, int64_t unit, const char *text, int64_t bytes, int64_t at) {
+    std::lock_guard<std::mutex> lk(sink_mu[which]);
+    return (which == 0 ? sink->on_read_text : sink->on_maf_text)(sink->user, unit, text, bytes, at);
+  }
   int sink_plain(Slot &sl, int64_t unit, int64_t read_at, int64_t maf_at) {
     const pbsim_batch_info &bi = sl.b_info;
-    if (sink->on_read_text && bi.read_text_bytes &&
-        !sink->on_read_text(sink->user, unit, (const char *)sl.h_read_text.p, bi.read_text_bytes, read_at))
+    if (sink->on_read_text && bi.read_text_bytes && !call_sink(0, unit, (const char *)sl.h_read_text.p, bi.read_text_bytes, read_at))
       return fail("sink aborted (read text)");
-    if (sink->on_maf_text && bi.maf_text_bytes &&
-        !sink->on_maf_text(sink->user, unit, (const char *)sl.h_maf_text.p, bi.maf_text_bytes, maf_at))
+    if (sink->on_maf_text && bi.maf_text_bytes && !call_sink(1, unit, (const char *)sl.h_maf_text.p, bi.maf_text_bytes, maf_at))
       return fail("sink aborted (MAF text)");
     return PBSIM_SUCCEEDED;
   }
@@ -343,7 +357,7 @@ struct Job {
       const uint8_t *d = is_read ? sl.d_read_text.as<uint8_t>() : sl.d_maf_text.as<uint8_t>();
       if (!cb || n == 0) return PBSIM_SUCCEEDED;
       return deflate_pieces(c, sl.df[which], d, n, [&](const char *z, int64_t k) {
-        if (!cb(sink->user, unit, z, k, base + *sent)) return fail(is_read ? "sink aborted (read text)" : "sink aborted (MAF text)");
+        if (!call_sink(which, unit, z, k, base + *sent)) return fail(is_read ? "sink aborted (read text)" : "sink aborted (MAF text)");
         *sent += k;
         return PBSIM_SUCCEEDED;
       });
@@ -380,7 +394,7 @@ struct Job {
       auto cb = which == 0 ? sink->on_read_text : sink->on_maf_text;
       int64_t at = which == 0 ? read_at : maf_at;
       for (const auto &sg : sl.df[which].arena_segs) {
-        if (!cb(sink->user, unit, sg.first, sg.second, at)) return fail(which == 0 ? "sink aborted (read text)" : "sink aborted (MAF text)");
+        if (!call_sink(which, unit, sg.first, sg.second, at)) return fail(which == 0 ? "sink aborted (read text)" : "sink aborted (MAF text)");
         at += sg.second;
       }
       sl.df[which].arena_segs.clear();
@@ -426,7 +440,7 @@ struct Job {
       if (trace)
         fprintf(stderr, "[pbsim job r%d] t=%.1f ms   worker: bytes of rec %lld on their way for %.1f ms (%lld + %lld)\n", rank,
                 (w0 - t_start) / 1e3, (long long)R->ref.unit, (now_us() - w0) / 1e3, (long long)sizes[0], (long long)sizes[1]);
-      --*out;
+      delivered_one(out);
       prom->set_value(ok);
     });
   }
@@ -490,7 +504,7 @@ struct Job {
           const int ok = flush ? arena_flush(*sl, Rp->ref.unit, read_at, maf_at) : sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
           if (!ok) worker_fail();
           delivering[slot] = false;
-          --*out;
+          delivered_one(out);
         });
       } else {
         delivering[slot] = false;  // streamed in stage 1 (or nothing to deliver): the slot is free
@@ -526,10 +540,7 @@ struct Job {
     Rec &R = recs[(size_t)rec];
     for (;;) {
       if (R.tail_waiting) {
-        if (block) {  // a slot from the worker
-          std::unique_lock<std::mutex> lk(worker.mu);
-          worker.cv_idle.wait(lk, [&] { return free_tail_slot() >= 0 || (worker.q.empty() && worker.active == 0); });
-        }
+        if (block) tail_worker.drain();  // a slot from the chains' worker
         if (!tail_begin(R)) return PBSIM_FAILED;
         if (R.tail_waiting) return block ? fail("internal: no slot for the truncated reads") : PBSIM_SUCCEEDED;
       }
@@ -547,7 +558,9 @@ struct Job {
       delivering[slot] = true;
       std::atomic<int> *out = &rec_out[(size_t)rec];
       ++*out;
-      worker.post([this, sl, Rp, slot, out]() {  // FIFO behind the record's bulk deliveries: offsets and accounting stay in read order
+      // (the record's bulk rounds have been exchanged and accounted -- pending is not one of them --, so its byte offsets are
+      // final and its statistics in read order when this runs)
+      tail_worker.post([this, sl, Rp, slot, out]() {
         int ok = PBSIM_SUCCEEDED;
         int64_t nr = 0, nm = 0;
         if (wants_text() && hipEventSynchronize(sl->ev_text) != hipSuccess) ok = fail("hipEventSynchronize failed (text emission)");
@@ -565,7 +578,7 @@ struct Job {
         Rp->tail_maf += nm;
         if (!ok) worker_fail();
         delivering[slot] = false;
-        --*out;
+        delivered_one(out);
       });
       reads_walked += bi.n_final;
       reads_delivered += bi.n_final;
@@ -792,6 +805,7 @@ struct Job {
     const int n = (int)recs.size();
     int merged = 0;
     worker.start(c->device);
+    tail_worker.start(c->device);
     for (;;) {
       if (!check_worker()) return PBSIM_FAILED;
       // ---- keep the pipeline full: the earliest record that still lacks reads in flight
@@ -838,6 +852,7 @@ struct Job {
     }
     if (!complete_pending()) return PBSIM_FAILED;
     worker.finish();
+    tail_worker.finish();
     return check_worker();
   }
 };
@@ -1026,6 +1041,8 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     c->bias.hp11_seen = true;
   }
   J.recs.resize(n);
+  for (int ts = Job::kTailSlot; ts < kMaxSlots; ts++)
+    for (DfLane &L : c->slots[ts].df) L.own_streams = true;
   J.rec_out.reset(new std::atomic<int>[n]);
   for (size_t i = 0; i < n; i++) J.rec_out[i] = 0;
   bool seen11 = c->bias.hp11_seen;
@@ -1163,6 +1180,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     *settled = true;
     J.drop_everything();
     J.worker.finish();
+    J.tail_worker.finish();
     g_err = keep;
   }
   for (Slot &sl : c->slots)
