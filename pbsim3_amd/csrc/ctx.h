@@ -343,6 +343,7 @@ int64_t quota_of(const pbsim_ctx *c, int64_t ref_len);  // (long long)(depth * l
 // truncate_remaining = what is left of the quota in front of the first; ended by chain_end_finalize
 int walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining, bool chain = false);
 int chain_end_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out);
+int chain_reads_for(const pbsim_ctx *c, int64_t ref_len, int64_t remaining);
 constexpr int kChainReads = 6;  // steps enqueued per chain (a chain is 2-3 reads as a rule: each leaves ~3 % of its length)
 int64_t batch_capacity_for(const pbsim_ctx *c, int64_t ref_len);  // reads one batch is sized to (scratch budget)
 // the two halves of pbsim_batch_finalize on the selected slot: the quota cut, then text sizes + scans + text emission

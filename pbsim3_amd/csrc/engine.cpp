@@ -615,8 +615,10 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   }
   // The pool is the budget, unless this batch cannot need that much: a wave's rows hold at most 2 * Lmax + pad columns
   // (Lmax = the longest read the header can draw), so a handful of reads (the truncated tail reads) gets by with little.
-  const double lmax = (double)std::min<int64_t>(c->p.len_max, std::max<int64_t>(ref.len, 1));
-  const double worst = (double)waves_max * regions_of(c) * (2.0 * lmax + kScratchPad + 64) * 64.0;
+  double lmax = (double)std::min<int64_t>(c->p.len_max, std::max<int64_t>(ref.len, 1));
+  if (truncate_remaining >= 0) lmax = std::min(lmax, (double)std::max<int64_t>(truncate_remaining, c->p.len_min));  // (pbsim.cpp:3795-3800)
+  // (only waves that hold a task take scratch: at most one per task)
+  const double worst = (double)std::min<int64_t>(waves_max, n_tasks) * regions_of(c) * (2.0 * lmax + kScratchPad + 64) * 64.0;
   const int64_t pool = std::max<int64_t>((int64_t)c->s().d_scratch.bytes - (int64_t)kScratchSlack,
                                          (int64_t)std::min<double>((double)c->scratch_budget, worst));
   HIP_OK(c->s().d_scratch.ensure((size_t)pool + kScratchSlack, true));
@@ -882,6 +884,17 @@ int pbsim_batch_fetch_lengths(pbsim_ctx *c, int32_t *rawlen, int32_t *len, int32
     HIP_OK(hipMemcpy2DAsync(out_len_pass0, 4, sl.d_out_len.p, (size_t)c->p.pass_num * 4, 4, n, hipMemcpyDeviceToHost, sl.stream));
   HIP_OK(hipStreamSynchronize(sl.stream));
   return PBSIM_SUCCEEDED;
+}
+
+// Reads a chain may hold (<= kChainReads): the layout of a chain stands for upper bounds -- every read as long as what is left of
+// the quota now -- and in the worst case every read sits in a scratch block of its own (64 lanes wide whatever it holds), so
+// a small pool (tests, PBSIM_SCRATCH_MB) takes fewer steps per chain; one read is what a single truncated batch needs.
+extern "C++" int pbsim::chain_reads_for(const pbsim_ctx *c, int64_t ref_len, int64_t remaining) {
+  const double lub = (double)std::min<int64_t>(std::min<int64_t>(c->p.len_max, std::max<int64_t>(ref_len, 1)),
+                                               std::max<int64_t>(remaining, c->p.len_min));
+  const double per_block = (double)regions_of(c) * 64.0 * (2.0 * lub + kScratchPad + 64.0);
+  const int64_t fit = (int64_t)((double)c->scratch_budget / (1.05 * per_block));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(kChainReads, fit));
 }
 
 // The chain of truncated reads begun with walk_begin(.., chain) on the selected slot: waits for its steps, says how far it

@@ -529,7 +529,8 @@ struct Job {
     }
     R.tail_waiting = false;
     c->cur = s;
-    if (!walk_begin(c, R.ref, R.next_read, kChainReads, R.quota - R.len_total, true)) return PBSIM_FAILED;
+    const int64_t remaining = R.quota - R.len_total;
+    if (!walk_begin(c, R.ref, R.next_read, chain_reads_for(c, R.ref.len, remaining), remaining, true)) return PBSIM_FAILED;
     R.tail_slot = s;
     return PBSIM_SUCCEEDED;
   }
