@@ -670,7 +670,10 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   s.bin_cursor = c->s().d_bin_cursor.as<int32_t>();
   s.class_start = c->s().d_class_start.as<int32_t>();
   s.coop_end = s.class_start + ncls + 1;
-  const int32_t coop_len = coop_min_len(c, n_reads, ref.hp_flag);
+  int32_t coop_len = coop_min_len(c, n_reads, ref.hp_flag);
+  // (a chain's layout stands for upper bounds of its reads' lengths, its walks see the lengths they end up with: a split by
+  // length would put a read on one walker's side of the layout and the other walker's side of the walk -- all or none)
+  if (chain && coop_len != INT32_MAX) coop_len = 0;
   s.coop_bucket = coop_len == INT32_MAX ? kLenBuckets : coop_len >> kLenShift;
   s.coop_classes = 0;
   if (coop_len != INT32_MAX)  // verbatim classes (ERRHMM) / classes without a model (QSHMM) stay with the lane walker
