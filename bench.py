@@ -219,17 +219,31 @@ def bench_trans(a, torch, harness, P, local):
     ctx.close()
 
 
+def newest_profile(suffix):
+    """the newest profiles/*<suffix> by name (rNN[x]_...: rounds sort lexically), or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*" + suffix)))
+    return files[-1] if files else None
+
+
 def issue_bound(columns_per_launch, walk_s):
-    """The walk's real ceiling is integer issue, not HBM: figures of the PMC pass of the same kernel (tools/pmc_kernel.sh)."""
-    path = os.path.join(ROOT, "profiles", "r02z_walk_pmc.json")
-    if not os.path.exists(path):
+    """The walk's real ceiling is integer issue, not HBM: figures of the newest PMC pass of the same kernel in profiles/
+    (tools/pmc_round.sh; not measured in this run -- counters need rocprofv3 around the process)."""
+    path = newest_profile("_walk_pmc.json")
+    if not path:
         return None
     pj = json.load(open(path))
     valu = pj["per_wave_step"]["valu"]          # VALU instructions per wave-step = per lane and MAF column
-    return {"valu_busy_frac": pj["valu_busy_fraction"], "valu_per_wave_step": valu,
-            "int_lane_ops_per_sec": valu * columns_per_launch / walk_s if walk_s > 0 else None,
-            "lds_table_hit_rate": 1.0,          # every HMM table read is an LDS read (4 per column)
-            "source": "profiles/r02z_walk_pmc.json (SQ_INSTS_VALU x 4 cycles / SIMD-cycles)"}
+    out = {"valu_busy_frac": pj["valu_busy_fraction"], "valu_per_wave_step": valu,
+           "int_lane_ops_per_sec": valu * columns_per_launch / walk_s if walk_s > 0 else None,
+           "lds_table_hit_rate": 1.0,          # every HMM table read is an LDS read (4 per column)
+           "source": "profiles/%s (SQ_INSTS_VALU x 4 cycles / SIMD-cycles; collected by tools/pmc_round.sh, not in this run)" % os.path.basename(path),
+           "round": pj.get("round", os.path.basename(path).split("_")[0])}
+    coop = pj.get("k_walk_errhmm_coop")
+    if coop and "per_wave_step" in coop:
+        out["wave_walker"] = {"valu_per_wave_step": coop["per_wave_step"].get("valu"), "salu_per_wave_step": coop["per_wave_step"].get("salu"),
+                              "lds_per_wave_step": coop["per_wave_step"].get("lds"), "valu_busy_frac": coop.get("valu_busy_fraction")}
+    return out
 
 
 def make_records(torch, dist, dev, cdev, rank, world, n_rec, G):
@@ -566,8 +580,10 @@ def main():
         walk_s = walk_ms / 1e3
         achieved = alg_bytes / walk_s / 1e9 if walk_s > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02z_walk_traffic.json")
-        if not qs and os.path.exists(tpath):     # PMC pass of the same kernel (tools/pmc_traffic.sh), scaled per base
+        tpath = newest_profile("_walk_pmc.json")
+        if tpath and "traffic_bytes_per_launch" not in json.load(open(tpath)):
+            tpath = newest_profile("_walk_traffic.json")
+        if not qs and tpath:     # PMC pass of the same kernel (tools/pmc_round.sh), scaled per base
             tj = json.load(open(tpath))
             traffic = tj["traffic_bytes_per_launch"] / tj["bases_per_launch"] * (sum(c["bases"] for c in counters) / max(1, launches))
         out = {
@@ -591,7 +607,9 @@ def main():
                          "note": "bytes over each GPU's PCIe link / time / 63 GB/s (Gen5 x16): the link is this metric's roofline"},
             "roofline": {"bound": "hbm", "kernel": "k_walk_qshmm" if qs else "k_walk_errhmm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r02z_walk_traffic.json (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE in separate passes, raw x1024, three walk workgroups per CU as in the job)",
+                         "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, raw x 1024, scaled by the "
+                                            "calibration of the same access patterns where the file has one; three walk workgroups per CU as in the "
+                                            "job; collected by tools/pmc_round.sh, not in this run)" % os.path.basename(tpath)) if tpath else None,
                          "alg_bytes_per_launch": alg_bytes / max(1, launches), "avg_launch_ms": walk_ms / max(1, launches),
                          "launches": launches,
                          "tail_read_launches": {"launches": tail_launches, "avg_ms": tail_ms / max(1, tail_launches),

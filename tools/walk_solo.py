@@ -34,6 +34,11 @@ for i in range(steps):
     bases += info.bases
     cols += info.maf_columns
 walk_ms, launches, _ = ctx.prof_get()
+import json
+print("WALK_SOLO_JSON " + json.dumps({"kind": kind, "model": model, "reads_per_launch": B, "launches": launches, "avg_ms": walk_ms / launches,
+                                      "bases_per_launch": bases / steps, "maf_columns_per_launch": cols / steps,
+                                      "wave_launches": ctx.prof_wave_launches(),
+                                      "env": {k: os.environ[k] for k in ("PBSIM_WALK_LDS_KB", "PBSIM_COOP_LEN", "PBSIM_COOP_WG") if k in os.environ}}))
 print("%s: %d reads/launch, walk avg %.2f ms, %.1f G columns/s, %.1f G bases/s (walk kernel alone)" %
       (kind, B, walk_ms / launches, cols / (walk_ms / 1e3) / 1e9, bases / (walk_ms / 1e3) / 1e9))
 ctx.close()
