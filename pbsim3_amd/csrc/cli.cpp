@@ -657,6 +657,7 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
     // groups of records that fit the GPU's memory run as one pipeline each
     pbsim::GenomeInfo gi;
     if (rank0 && !pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
+    phase("genome split into .ref files");
     if (world > 1) {
       int64_t nrec = rank0 ? gi.num_seq : 0;
       if (!comm->all_reduce_i64(comm->user, &nrec, 1, PBSIM_OP_SUM)) die(": communicator failed");
@@ -708,7 +709,9 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       barrier(comm);  // the files exist
       if (!rank0) for (long n = g.first; n <= g.second; n++) open_record(jf, n, false);
       pbsim_record_sink sink = {&jf, job_read, job_maf, job_done};
+      phase("records loaded and uploaded, output files open");
       check(pbsim_job_run(ctx, comm, &sink));
+      phase("job run, bytes written");
     }
     check(pbsim_job_begin(ctx, 1));
   } else if (c.p.strategy == PBSIM_STRATEGY_WGS) {  // the sampling method, or SAM text into a samtools pipe: record by record
