@@ -294,6 +294,10 @@ typedef struct pbsim_record_sink {
  * before the first walk (pbsim.cpp:677-696).  wgs, methods errhmm / qshmm. */
 int pbsim_job_add_record(pbsim_ctx *ctx, const uint8_t *seq, int64_t len);
 int pbsim_job_add_record_device(pbsim_ctx *ctx, const void *seq_device, int64_t len);
+/* The record as it lies in its FASTA file: `lines` = its sequence lines, line feeds included (`bytes` of them; memory of a
+ * mapped file will do), `len` = bytes - line feeds.  The copy loop of get_genome_seq (pbsim.cpp:1014-1033: every byte of the
+ * lines except the line feeds) runs on the GPU behind the upload; the call fails when the GPU keeps another count than `len`. */
+int pbsim_job_add_record_lines(pbsim_ctx *ctx, const uint8_t *lines, int64_t bytes, int64_t len);
 /* C1 in one call: rank `root` passes the record (the others may pass NULL); with comm->broadcast the bytes travel GPU to
  * GPU, without it every rank must pass them. */
 int pbsim_job_add_record_comm(pbsim_ctx *ctx, const uint8_t *seq, int64_t len, const pbsim_comm *comm, int32_t root);

@@ -80,6 +80,7 @@ class RecordSink(C.Structure):
 API = [
     ("pbsim_job_add_record", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("pbsim_job_add_record_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("pbsim_job_add_record_lines", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     ("pbsim_job_add_record_comm", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Comm), C.c_int32]),
     ("pbsim_job_records", C.c_int64, [C.c_void_p]),
     ("pbsim_job_begin", C.c_int, [C.c_void_p, C.c_int64]),
@@ -556,6 +557,11 @@ class Context:
     def job_add_record(self, seq: bytes):
         buf = C.create_string_buffer(seq, len(seq))
         _check(self.lib.pbsim_job_add_record(self.h, C.cast(buf, C.c_void_p), len(seq)))
+
+    def job_add_record_lines(self, lines: bytes):
+        """the record as its FASTA sequence lines (line feeds included); they are squeezed out on the GPU"""
+        buf = C.create_string_buffer(lines, len(lines))
+        _check(self.lib.pbsim_job_add_record_lines(self.h, C.cast(buf, C.c_void_p), len(lines), len(lines) - lines.count(b"\n")))
 
     def job_add_record_device(self, ptr: int, length: int):
         _check(self.lib.pbsim_job_add_record_device(self.h, C.c_void_p(ptr), length))

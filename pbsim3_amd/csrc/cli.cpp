@@ -21,6 +21,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -656,6 +657,77 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
     // every rank loads the records (C1: broadcast GPU to GPU when the communicator can, else from the .ref files),
     // groups of records that fit the GPU's memory run as one pipeline each
     pbsim::GenomeInfo gi;
+    // The FASTA mapped and scanned on threads, the records uploaded as their lines and squeezed on the GPU, the .ref files
+    // written beside the simulation (round 4; the fgets pass of the reference stays as the fallback -- pipes, NUL bytes, a
+    // genome of several jobs -- and as PBSIM_FASTA_LOADER=stdio for the tests that compare the two).
+    pbsim::FastaMap fm;
+    bool mapped = false;
+    {
+      const char *fl = getenv("PBSIM_FASTA_LOADER");
+      if (!(fl && !strcmp(fl, "stdio"))) {
+        // (anything but a clean genome that one job holds goes through the fgets pass below, which then prints the reference
+        // stats and the reference's error messages itself)
+        bool fallback = false;
+        pbsim::GenomeInfo gm;
+        std::string e2;
+        if (pbsim::map_genome(c.genome.c_str(), &fm, &gm, false, &fallback, &e2)) {
+          double sum = 0;
+          for (long l : gm.len) sum += (double)l;
+          const char *gbs = getenv("PBSIM_JOB_REF_GB");
+          if (sum <= (gbs && atof(gbs) > 0 ? atof(gbs) : 64.0) * (double)(1LL << 30) / 2.0) {  // one job holds the genome
+            mapped = true;
+            gi = gm;
+            if (rank0) {  // get_genome_inf's report (pbsim.cpp:902-904, 925, 972, 979)
+              fprintf(stderr, ":::: Reference stats ::::\n\n");
+              fprintf(stderr, "file name : %s\n", c.genome.c_str());
+              fprintf(stderr, "\n");
+              for (long n = 1; n <= gi.num_seq; n++)
+                fprintf(stderr, "ref.%ld (len:%ld) : %s\n", n, gi.len[(size_t)n - 1], gi.id[(size_t)n - 1].c_str());
+              fprintf(stderr, "\n");
+            }
+          }
+        }
+      }
+    }
+    std::vector<std::thread> ref_writers;
+    std::atomic<bool> ref_failed{false};
+    std::string ref_err;
+    std::mutex ref_mu;
+    if (mapped) {
+      phase("genome mapped and scanned");
+      check(pbsim_job_begin(ctx, 1));
+      for (long n = 1; n <= gi.num_seq; n++) {
+        const pbsim::FastaRecord &R = fm.recs[(size_t)n - 1];
+        check(pbsim_job_add_record_lines(ctx, R.lines, R.bytes, R.len));
+      }
+      if (rank0)  // <prefix>_NNNN.ref (pbsim.cpp:948-964), written while the records are prepared and simulated
+        for (long n = 1; n <= gi.num_seq; n++)
+          ref_writers.emplace_back([&, n]() {
+            std::string e;
+            if (!pbsim::write_ref_record(c.prefix.c_str(), n, fm.recs[(size_t)n - 1], &e)) {
+              std::lock_guard<std::mutex> lk(ref_mu);
+              ref_failed = true;
+              ref_err = e;
+            }
+          });
+      JobFiles jf;
+      jf.cli = &c;
+      jf.ctx = ctx;
+      jf.comm = comm;
+      jf.first = 1;
+      for (long n = 1; n <= gi.num_seq; n++) jf.recs.emplace_back(new RecFiles);
+      if (rank0) for (long n = 1; n <= gi.num_seq; n++) open_record(jf, n, true);
+      barrier(comm);  // the files exist
+      if (!rank0) for (long n = 1; n <= gi.num_seq; n++) open_record(jf, n, false);
+      pbsim_record_sink sink = {&jf, job_read, job_maf, job_done};
+      phase("records uploaded, output files open");
+      check(pbsim_job_run(ctx, comm, &sink));
+      phase("job run, bytes written");
+      for (auto &t : ref_writers) t.join();
+      if (ref_failed) die(": %s", ref_err.c_str());
+      phase(".ref files written");
+      check(pbsim_job_begin(ctx, 1));
+    } else {
     if (rank0 && !pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
     phase("genome split into .ref files");
     if (world > 1) {
@@ -714,6 +786,7 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       phase("job run, bytes written");
     }
     check(pbsim_job_begin(ctx, 1));
+    }  // !mapped
   } else if (c.p.strategy == PBSIM_STRATEGY_WGS) {  // the sampling method, or SAM text into a samtools pipe: record by record
     if (world > 1 && !sampling) die(": this combination of options runs on one GPU.");
     pbsim::GenomeInfo gi;

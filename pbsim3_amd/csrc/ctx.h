@@ -281,6 +281,7 @@ struct pbsim_ctx {
   // the NEXT record, uploaded and prepared beside the current record's simulation (pbsim_prefetch_reference*)
   DevBuf d_seq_next, d_hp_next, d_tiles_next, d_ref_flags_next;
   hipStream_t prefetch_stream = nullptr;
+  DevBuf d_lines, d_lines_tmp;   // pbsim_job_add_record_lines: a record's FASTA lines as uploaded; tile counts + scan scratch
   // sampling method: k_sample_qsum runs beside the chunk's text emission (own stream); its sums are due at the statistics fetch
   hipStream_t sq_stream = nullptr;
   const void *pf_src = nullptr;

@@ -391,7 +391,6 @@ struct Job {
   }
   int arena_flush(Slot &sl, int64_t unit, int64_t read_at, int64_t maf_at) {
     return both_lanes(sl, [&](int which) -> int {
-      auto cb = which == 0 ? sink->on_read_text : sink->on_maf_text;
       int64_t at = which == 0 ? read_at : maf_at;
       for (const auto &sg : sl.df[which].arena_segs) {
         if (!call_sink(which, unit, sg.first, sg.second, at)) return fail(which == 0 ? "sink aborted (read text)" : "sink aborted (MAF text)");
@@ -883,6 +882,37 @@ static int job_add(pbsim_ctx *c, const void *seq, int64_t len, hipMemcpyKind kin
 }
 int pbsim_job_add_record(pbsim_ctx *c, const uint8_t *seq, int64_t len) { return job_add(c, seq, len, hipMemcpyHostToDevice); }
 
+// The record as its FASTA lines (line feeds included): uploaded as they lie in the caller's memory -- a mapped file will do --
+// and squeezed on the GPU (k_lines_*), so the host never touches the bases; `len` = bytes - line feeds (the caller counted
+// them to print the reference stats) is checked against what the GPU kept.
+int pbsim_job_add_record_lines(pbsim_ctx *c, const uint8_t *lines, int64_t bytes, int64_t len) {
+  if (!c || !lines || bytes < len) return fail("pbsim_job_add_record_lines: bad argument");
+  NEED_DEVICE(c);
+  if (c->p.strategy != PBSIM_STRATEGY_WGS || c->p.method == PBSIM_METHOD_SAMPLE)
+    return fail("pbsim_job_add_record: the job pipeline runs --strategy wgs with --method errhmm or qshmm");
+  if (len < 1) return fail("Reference is too short.");
+  if (len > 1000000000LL) return fail("Reference is too long. Acceptable length <= 1000000000.");
+  HIP_OK(hipSetDevice(c->device));
+  if (!c->prefetch_stream) HIP_OK(hipStreamCreateWithFlags(&c->prefetch_stream, hipStreamNonBlocking));
+  std::unique_ptr<JobRecord> r(new JobRecord);
+  r->len = len;
+  HIP_OK(r->seq.ensure((size_t)len + 64, true));
+  const int64_t n_tiles = (bytes + 4095) / 4096;
+  HIP_OK(c->d_lines.ensure((size_t)bytes + 64));
+  HIP_OK(c->d_lines_tmp.ensure((size_t)(n_tiles + 1 + n_tiles / 1024 + 16) * 8));
+  HIP_OK(hipMemcpyAsync(c->d_lines.p, lines, (size_t)bytes, hipMemcpyHostToDevice, c->prefetch_stream));
+  int64_t *tmp = c->d_lines_tmp.as<int64_t>();
+  launch_squeeze_lines(c->d_lines.as<uint8_t>(), bytes, r->seq.as<uint8_t>(), tmp + 1, tmp + 1 + n_tiles + 1, tmp, c->prefetch_stream);
+  int64_t kept = -1;
+  HIP_OK(hipMemcpyAsync(&kept, tmp, 8, hipMemcpyDeviceToHost, c->prefetch_stream));
+  HIP_OK(hipStreamSynchronize(c->prefetch_stream));  // the staging buffer is the next record's too; the preparation stays asynchronous
+  if (kept != len) return fail("pbsim_job_add_record_lines: `len` is not the number of bytes that are not line feeds");
+  HIP_OK(hipMemsetAsync(r->seq.as<uint8_t>() + len, 0, 64, c->prefetch_stream));
+  if (!prepare_enqueue(c, r->seq.as<uint8_t>(), r->hp, r->tiles, r->flags, len, c->prefetch_stream)) return PBSIM_FAILED;
+  c->job_records.push_back(std::move(r));
+  return PBSIM_SUCCEEDED;
+}
+
 // C1: rank `root` holds the record in host memory; it uploads it and comm->broadcast carries the device bytes to every
 // other rank's GPU (over xGMI when the communicator is RCCL).  Without a broadcast callback every rank passes the bytes.
 int pbsim_job_add_record_comm(pbsim_ctx *c, const uint8_t *seq, int64_t len, const pbsim_comm *comm, int32_t root) {
@@ -1012,6 +1042,8 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   J.depth = std::max(1, std::min(kMaxSlots - 3, jd ? atoi(jd) : (delivers ? 1 : 3)));
   // ---- the records' preparation (upload + k_hp_*) has been running since pbsim_job_add_record: collect it
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));
+  c->d_lines.release();  // (pbsim_job_add_record_lines' staging: a record's worth of HBM the rounds can use)
+  c->d_lines_tmp.release();
   const size_t n = c->job_records.size();
   std::vector<DeviceFlags> fl(n);
   for (size_t i = 0; i < n; i++)

@@ -200,6 +200,10 @@ struct TextArgs {
 void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int flag_hp11, int64_t len, int64_t *tile_first, int64_t *tile_last,
                               int64_t *carry_start, int64_t *carry_next, int keep_first_case, DeviceFlags *flags,
                               hipStream_t s);
+// lines[0..bytes) (a record's FASTA sequence lines, 16-byte aligned) -> dst: every byte that is not a line feed, in order
+// (pbsim.cpp:1014-1033); tile_tmp: bytes/4096 + 1 int64, scan_tmp: bytes/4096/1024 + 8 int64, *total receives the bases kept
+void launch_squeeze_lines(const uint8_t *lines, int64_t bytes, uint8_t *dst, int64_t *tile_tmp, int64_t *scan_tmp, int64_t *total,
+                          hipStream_t s);
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s);
 void launch_header_trans(const HeaderArgs &a, hipStream_t s);
 void launch_task_sort(const SortArgs &a, hipStream_t s);

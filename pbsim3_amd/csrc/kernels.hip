@@ -365,6 +365,73 @@ __global__ __launch_bounds__(256) void k_hp_final(uint8_t *seq, uint8_t *hp, int
 }
 
 // ---------------------------------------------------------------------------
+// K0l: a record as its FASTA lines -> the record (get_genome_seq's copy loop, pbsim.cpp:1014-1033: every byte of the sequence
+// lines except the line feeds).  Tiles of 4096 bytes: keep counts, an exclusive scan over the tiles (launch_exclusive_scan_i64),
+// then every tile squeezes itself to its place.  HBM-bound, once per record.
+// ---------------------------------------------------------------------------
+constexpr int kLineTile = 4096;
+
+__device__ __forceinline__ uint32_t keep_mask16(const uint8_t *src, int64_t base, int64_t n, uint4 *v) {
+  uint32_t keep = 0;
+  if (base + 16 <= n) {
+    *v = *reinterpret_cast<const uint4 *>(src + base);
+    const uint32_t w[4] = {v->x, v->y, v->z, v->w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) keep |= (uint32_t)(((w[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 10u) << k;
+  } else {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 16 && base + k < n; k++) {
+      const uint32_t c = src[base + k];
+      w[k >> 2] |= c << ((k & 3) * 8);
+      keep |= (uint32_t)(c != 10u) << k;
+    }
+    *v = uint4{w[0], w[1], w[2], w[3]};
+  }
+  return keep;
+}
+
+__global__ __launch_bounds__(256) void k_lines_count(const uint8_t *src, int64_t n, int64_t *tile_keep) {
+  __shared__ int s_part[4];
+  uint4 v;
+  const int64_t base = (int64_t)blockIdx.x * kLineTile + threadIdx.x * 16;
+  int c = base < n ? __popc(keep_mask16(src, base, n, &v)) : 0;
+  for (int d = 32; d; d >>= 1) c += __shfl_down(c, d);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_keep[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ __launch_bounds__(256) void k_lines_squeeze(const uint8_t *src, int64_t n, const int64_t *tile_off, uint8_t *dst) {
+  __shared__ int s_scan[256];
+  uint4 v = uint4{0, 0, 0, 0};
+  const int64_t base = (int64_t)blockIdx.x * kLineTile + threadIdx.x * 16;
+  const uint32_t keep = base < n ? keep_mask16(src, base, n, &v) : 0u;
+  const int mine = __popc(keep);
+  s_scan[threadIdx.x] = mine;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int x = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+    __syncthreads();
+    s_scan[threadIdx.x] += x;
+    __syncthreads();
+  }
+  uint8_t *o = dst + tile_off[blockIdx.x] + (s_scan[threadIdx.x] - mine);
+  if (keep == 0xffffu && ((uintptr_t)o & 3) == 0) {  // the usual thread: no line feed among its 16 bytes
+    uint32_t *o4 = reinterpret_cast<uint32_t *>(o);
+    o4[0] = v.x;
+    o4[1] = v.y;
+    o4[2] = v.z;
+    o4[3] = v.w;
+  } else {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    int k_out = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      if ((keep >> k) & 1u) o[k_out++] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K1: read header (WGS).  pbsim.cpp:3793-3813 (= 2174-2194)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_header_wgs(HeaderArgs a) {
@@ -2934,6 +3001,15 @@ void launch_prepare_reference(uint8_t *seq, uint8_t *hp, int flag_hp11, int64_t 
 void launch_header_wgs(const HeaderArgs &a, hipStream_t s) {
   if (a.n_reads <= 0) return;
   hipLaunchKernelGGL(k_header_wgs, dim3(blocks_for(a.n_reads, 256)), dim3(256), 0, s, a);
+}
+
+void launch_squeeze_lines(const uint8_t *lines, int64_t bytes, uint8_t *dst, int64_t *tile_tmp, int64_t *scan_tmp, int64_t *total,
+                          hipStream_t s) {
+  const int64_t n_tiles = (bytes + kLineTile - 1) / kLineTile;
+  if (n_tiles <= 0) return;
+  hipLaunchKernelGGL(k_lines_count, dim3((unsigned)n_tiles), dim3(256), 0, s, lines, bytes, tile_tmp);
+  launch_exclusive_scan_i64(tile_tmp, tile_tmp, n_tiles, scan_tmp, total, s);
+  hipLaunchKernelGGL(k_lines_squeeze, dim3((unsigned)n_tiles), dim3(256), 0, s, lines, bytes, tile_tmp, dst);
 }
 
 void launch_chain_init(ChainState *chain, int64_t remaining, hipStream_t s) {

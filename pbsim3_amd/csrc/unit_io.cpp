@@ -121,6 +121,257 @@ bool split_genome(const char *file, const char *prefix, GenomeInfo *info, std::s
   return ok;
 }
 
+// ---- the mapped FASTA (unit_io.h) ------------------------------------------------------------------------------------------
+FastaMap::~FastaMap() {
+  if (map) munmap(map, size);
+}
+
+namespace {
+constexpr int64_t kChunk = kBuf - 1;  // characters one fgets takes (pbsim.cpp:914)
+
+template <class F>
+void parallel_blocks(size_t n_blocks, F &&f) {
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t nt = std::min<size_t>(std::min<size_t>(hw, 32), n_blocks);
+  if (nt <= 1) {
+    for (size_t b = 0; b < n_blocks; b++) f(b);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++)
+    th.emplace_back([&]() {
+      for (size_t b; (b = next.fetch_add(1)) < n_blocks;) f(b);
+    });
+  for (auto &t : th) t.join();
+}
+}  // namespace
+
+bool map_genome(const char *file, FastaMap *m, GenomeInfo *info, bool print_stats, bool *fallback, std::string *err) {
+  *fallback = false;
+  const int fd = open(file, O_RDONLY);
+  if (fd < 0) {
+    if (print_stats) {
+      fprintf(stderr, ":::: Reference stats ::::\n\n");
+      fprintf(stderr, "file name : %s\n", file);
+      fprintf(stderr, "\n");
+    }
+    *err = std::string("Cannot open file: ") + file;
+    return false;
+  }
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= 0) {
+    close(fd);
+    *fallback = true;
+    return false;
+  }
+  const size_t size = (size_t)sb.st_size;
+  void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) {
+    *fallback = true;
+    return false;
+  }
+  m->map = map;
+  m->size = size;
+  const uint8_t *data = (const uint8_t *)map;
+  if (data[0] != '>') {  // sequence in front of the first header: the reference writes through an unopened stream
+    *fallback = true;
+    return false;
+  }
+  // ---- pass 1, on threads: NUL bytes (fgets semantics), the '>' characters, and per block the line feeds + the longest gap
+  const char *be = getenv("PBSIM_FASTA_BLOCK");  // test knob: bytes per thread block (seams inside small files)
+  const size_t kBlock = be && atol(be) > 0 ? (size_t)atol(be) : (size_t)16 << 20;
+  const size_t n_blocks = (size + kBlock - 1) / kBlock;
+  struct Block {
+    std::vector<size_t> gt;            // positions of '>'
+    bool nul = false;
+  };
+  std::vector<Block> blocks(n_blocks);
+  parallel_blocks(n_blocks, [&](size_t b) {
+    const uint8_t *p = data + b * kBlock, *e = data + std::min(size, (b + 1) * kBlock);
+    blocks[b].nul = memchr(p, 0, (size_t)(e - p)) != nullptr;
+    for (const uint8_t *q = p; q < e;) {
+      const uint8_t *g = (const uint8_t *)memchr(q, '>', (size_t)(e - q));
+      if (!g) break;
+      blocks[b].gt.push_back((size_t)(g - data));
+      q = g + 1;
+    }
+  });
+  for (const Block &b : blocks)
+    if (b.nul) {
+      *fallback = true;
+      return false;
+    }
+  // ---- headers: a '>' at the start of an fgets chunk that is not part of a header line's tail (pbsim.cpp:917, 946-951)
+  struct Hdr {
+    size_t pos, line_end;  // '>' | one past the header line's line feed (or the end of the file)
+  };
+  std::vector<Hdr> hdrs;
+  size_t skip_until = 0;  // inside a header line: its tail is skipped whatever it holds
+  for (const Block &b : blocks)
+    for (size_t pos : b.gt) {
+      if (pos < skip_until) continue;
+      bool is_hdr = pos == 0 || data[pos - 1] == '\n';
+      if (!is_hdr) {  // inside a sequence line: only where an fgets chunk starts (lines of >= 10239 characters)
+        const uint8_t *ls = (const uint8_t *)memrchr(data, '\n', pos);
+        const size_t line_start = ls ? (size_t)(ls - data) + 1 : 0;
+        is_hdr = (pos - line_start) % (size_t)kChunk == 0;
+      }
+      if (!is_hdr) continue;
+      const uint8_t *nl = (const uint8_t *)memchr(data + pos, '\n', size - pos);
+      const size_t line_end = nl ? (size_t)(nl - data) + 1 : size;
+      hdrs.push_back(Hdr{pos, line_end});
+      skip_until = line_end;
+    }
+  // ---- pass 2, on threads: line feeds and the longest line of every record's region
+  const size_t n_rec = hdrs.size();
+  struct Piece {
+    size_t rec, a, e;
+    int64_t nl = 0, first = -1, last = -1, max_gap = 0;  // line feeds; offsets of the first / last one; longest run between two
+  };
+  std::vector<Piece> pieces;
+  for (size_t r = 0; r < n_rec; r++) {
+    const size_t a = hdrs[r].line_end, e = r + 1 < n_rec ? hdrs[r + 1].pos : size;
+    for (size_t p = a; p < e || (p == a && a == e); p += kBlock) {
+      pieces.push_back(Piece{r, p, std::min(e, p + kBlock)});
+      if (a == e) break;
+    }
+  }
+  parallel_blocks(pieces.size(), [&](size_t i) {
+    Piece &pc = pieces[i];
+    const uint8_t *q = data + pc.a, *e = data + pc.e;
+    int64_t prev = -1;
+    while (q < e) {
+      const uint8_t *nl = (const uint8_t *)memchr(q, '\n', (size_t)(e - q));
+      if (!nl) break;
+      const int64_t at = (int64_t)(nl - (data + pc.a));
+      if (pc.first < 0) pc.first = at;
+      else pc.max_gap = std::max(pc.max_gap, at - prev - 1);
+      prev = pc.last = at;
+      pc.nl++;
+      q = nl + 1;
+    }
+  });
+  if (print_stats) {
+    fprintf(stderr, ":::: Reference stats ::::\n\n");
+    fprintf(stderr, "file name : %s\n", file);
+    fprintf(stderr, "\n");
+  }
+  m->recs.resize(n_rec);
+  size_t pi = 0;
+  for (size_t r = 0; r < n_rec; r++) {
+    FastaRecord &R = m->recs[r];
+    const size_t a = hdrs[r].line_end, e = r + 1 < n_rec ? hdrs[r + 1].pos : size;
+    const size_t id_end = std::min(hdrs[r].pos + 1 + (size_t)kIdMax, std::min(hdrs[r].pos + (size_t)kChunk, hdrs[r].line_end));
+    size_t id_n = id_end - (hdrs[r].pos + 1);
+    if (id_n && data[hdrs[r].pos + id_n] == '\n') id_n--;  // (the line feed is not part of the id)
+    R.id.assign((const char *)data + hdrs[r].pos + 1, id_n);
+    R.lines = data + a;
+    R.bytes = (int64_t)(e - a);
+    int64_t nl = 0, run = 0, max_line = 0;  // `run`: characters since the last line feed, across pieces
+    for (; pi < pieces.size() && pieces[pi].rec == r; pi++) {
+      const Piece &pc = pieces[pi];
+      const int64_t n = (int64_t)(pc.e - pc.a);
+      nl += pc.nl;
+      if (pc.first < 0) {
+        run += n;
+      } else {
+        max_line = std::max(max_line, std::max(run + pc.first, pc.max_gap));
+        run = n - pc.last - 1;
+      }
+    }
+    max_line = std::max(max_line, run);
+    R.len = R.bytes - nl;
+    R.max_line = max_line;
+    // the reference's checks, in the order its single pass meets them (pbsim.cpp:919-961, 968-971)
+    if (r > 0) {
+      const FastaRecord &Q = m->recs[r - 1];
+      if (Q.len < kRefLenMin) {
+        *err = "Reference is too short. Acceptable length >= 100.";
+        return false;
+      }
+      if (print_stats) fprintf(stderr, "ref.%ld (len:%ld) : %s\n", (long)r, (long)Q.len, Q.id.c_str());
+      info->len.push_back((long)Q.len);
+      info->id.push_back(Q.id);
+      info->max_len = std::max(info->max_len, (long)Q.len);
+    }
+    info->num_seq = (long)r + 1;
+    if (info->num_seq > kRefNumMax) {
+      *err = "References are too many. Max number of reference is 9999.";
+      return false;
+    }
+    if (R.len > kRefLenMax) {
+      *err = "Reference is too long. Acceptable length <= 1000000000.";
+      return false;
+    }
+  }
+  {
+    const FastaRecord &Q = m->recs[n_rec - 1];
+    if (Q.len < kRefLenMin) {
+      *err = "Reference is too short. Acceptable length >= 100.";
+      return false;
+    }
+    if (print_stats) fprintf(stderr, "ref.%ld (len:%ld) : %s\n", (long)n_rec, (long)Q.len, Q.id.c_str());
+    info->len.push_back((long)Q.len);
+    info->id.push_back(Q.id);
+    info->max_len = std::max(info->max_len, (long)Q.len);
+  }
+  if (print_stats) fprintf(stderr, "\n");
+  return true;
+}
+
+bool write_ref_record(const char *prefix, long num, const FastaRecord &r, std::string *err) {
+  char name[4096];
+  snprintf(name, sizeof name, "%s_%04ld.ref", prefix, num);
+  const int fd = open(name, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (fd < 0) {
+    *err = std::string("Cannot open output file: ") + name;
+    return false;
+  }
+  auto put = [&](const void *p, size_t n) -> bool {
+    const char *q = (const char *)p;
+    while (n) {
+      const ssize_t k = write(fd, q, std::min<size_t>(n, 1u << 30));
+      if (k <= 0) return false;
+      q += k;
+      n -= (size_t)k;
+    }
+    return true;
+  };
+  bool ok = put(">", 1) && put(r.id.data(), r.id.size()) && put("\n", 1);
+  if (ok && r.max_line < kChunk) {
+    // no line reaches an fgets boundary: the file's own lines are what fprintf(fp_out, "%s\n", line) writes (pbsim.cpp:963)
+    ok = put(r.lines, (size_t)r.bytes);
+    if (ok && r.bytes > 0 && r.lines[r.bytes - 1] != '\n') ok = put("\n", 1);
+  } else if (ok) {
+    // chunk by chunk as fgets hands them out: up to 10239 bytes, the line feed (when it is among them) stripped, then "\n"
+    std::string buf;
+    buf.reserve(1u << 20);
+    const uint8_t *p = r.lines, *e = r.lines + r.bytes;
+    while (p < e && ok) {
+      const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+      const uint8_t *line_end = nl ? nl + 1 : e;  // one past the line feed
+      while (p < line_end) {
+        const size_t take = std::min<size_t>((size_t)kChunk, (size_t)(line_end - p));
+        size_t n = take;
+        if (p[n - 1] == '\n') n--;
+        buf.append((const char *)p, n);
+        buf.push_back('\n');
+        p += take;
+      }
+      if (buf.size() > (1u << 20) - 2 * (size_t)kBuf) {
+        ok = put(buf.data(), buf.size());
+        buf.clear();
+      }
+    }
+    if (ok && !buf.empty()) ok = put(buf.data(), buf.size());
+  }
+  if (close(fd) != 0) ok = false;
+  if (!ok) *err = std::string("Cannot write output file: ") + name;
+  return ok;
+}
+
 bool load_ref_record(const char *prefix, long num, std::string *seq, std::string *err) {
   char name[4096];
   snprintf(name, sizeof name, "%s_%04ld.ref", prefix, num);

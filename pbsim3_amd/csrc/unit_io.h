@@ -19,6 +19,31 @@ struct GenomeInfo {
 
 // Splits <file> into <prefix>_NNNN.ref, printing the reference's ":::: Reference stats ::::" block.
 bool split_genome(const char *file, const char *prefix, GenomeInfo *info, std::string *err);
+// The same pass over the FASTA without stdio (round 4): the file mapped, header lines found by memchr on threads, the line
+// feeds of every record counted on threads -- a record is then its lines as they lie in the file plus its length, and the
+// line feeds are squeezed out on the GPU (pbsim_job_add_record_lines).  Prints the same ":::: Reference stats ::::" block and
+// fails with the same messages in the same order as the fgets pass above, which stays the checker (tests) and the fallback:
+// `*fallback` is set -- and nothing printed -- for what only fgets semantics define (no regular file, NUL bytes, bytes in front
+// of the first header).
+struct FastaRecord {
+  std::string id;           // the header's first 128 characters (pbsim.cpp:939-940)
+  const uint8_t *lines = nullptr;  // the record's sequence lines in the mapped file, line feeds included
+  int64_t bytes = 0;        // of `lines`
+  int64_t len = 0;          // bases = bytes - line feeds
+  int64_t max_line = 0;     // longest line: lines of >= 10239 characters reach the .ref file in fgets chunks (pbsim.cpp:914)
+};
+struct FastaMap {
+  void *map = nullptr;
+  size_t size = 0;
+  std::vector<FastaRecord> recs;
+  FastaMap() = default;
+  FastaMap(const FastaMap &) = delete;
+  FastaMap &operator=(const FastaMap &) = delete;
+  ~FastaMap();
+};
+bool map_genome(const char *file, FastaMap *m, GenomeInfo *info, bool print_stats, bool *fallback, std::string *err);
+// <prefix>_NNNN.ref of a mapped record, byte for byte what get_genome_inf writes (pbsim.cpp:948-964)
+bool write_ref_record(const char *prefix, long num, const FastaRecord &r, std::string *err);
 // Re-reads <prefix>_NNNN.ref into one contiguous record (no newlines, case preserved).
 bool load_ref_record(const char *prefix, long num, std::string *seq, std::string *err);
 

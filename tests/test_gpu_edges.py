@@ -248,3 +248,38 @@ def test_prefetched_reference_is_adopted_and_changes_nothing():
                 P._check(ctx.lib.pbsim_prefetch_reference(ctx.h, C.cast(bufs[i + 1], C.c_char_p), len(recs[i + 1])))
             outs.append(ctx.simulate_wgs())
     assert outs == plain
+
+
+def test_records_added_as_fasta_lines(tmp_path):
+    """pbsim_job_add_record_lines: a record handed over as its FASTA lines (line feeds included) and squeezed on the GPU
+    (k_lines_count / k_lines_squeeze: get_genome_seq's copy loop, pbsim.cpp:1014-1033) gives the bytes of the same record
+    handed over squeezed -- line widths around the kernels' 16-byte loads and 4096-byte tiles, empty lines, CR LF, no final
+    line feed, a record of one long line."""
+    import pbsim3_amd as P
+    rng = np.random.default_rng(3)
+
+    def bases(n):
+        return bytes(np.frombuffer(b"ACGTacgtN", dtype=np.uint8)[rng.integers(0, 9, n)])
+
+    def wrap(s, w):
+        return b"".join(s[i:i + w] + b"\n" for i in range(0, len(s), w))
+    a, b, c, d = bases(300_007), bases(120_000), bases(65_536 * 3), bases(50_001)
+    shaped = [wrap(a, 80), wrap(b[:60_000], 15) + b"\n\n" + wrap(b[60_000:], 4096) + b[:0], wrap(c, 4095)[:-1],
+              b"".join(d[i:i + 61] + b"\r\n" for i in range(0, len(d), 61)), bases(200_000)]
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=9, depth=4.0, len_mean=1500.0, len_sd=1000.0)
+    outs = []
+    for as_lines in (False, True):
+        with P.Context(p, 0) as ctx:
+            ctx.set_scratch_bytes(64 << 20)
+            ctx.load_errhmm(harness.model_path("ERRHMM-SEQUEL.model"))
+            for s in shaped:
+                if as_lines:
+                    ctx.job_add_record_lines(s)
+                else:
+                    ctx.job_add_record(s.replace(b"\n", b""))
+            texts, done = ctx.job_run()
+            outs.append({k: (bytes(v[0]), bytes(v[1]), done[k][0].res_num) for k, v in texts.items()})
+    assert len(outs[0]) == len(shaped) and outs[0] == outs[1]
+    with P.Context(p, 0) as ctx:       # a wrong length is refused, not simulated
+        with pytest.raises(P.PbsimError, match="not the number of bytes"):
+            P._check(ctx.lib.pbsim_job_add_record_lines(ctx.h, shaped[0], len(shaped[0]), len(a) - 1))

@@ -98,3 +98,54 @@ def test_comm_abort_releases_waiting_ranks(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=60, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
     assert "first 8 second_failed 3 third_failed 3" in p.stdout
+
+
+def test_mapped_fasta_pass_equals_the_fgets_pass(tmp_path):
+    """map_genome + write_ref_record (the file mapped, headers by memchr on threads, line feeds counted per record; the CLI's
+    loader since round 4) against split_genome + load_ref_record (the reference's fgets loop, pbsim.cpp:896-991, 997-1033)
+    under ASan: record count, lengths, ids, the error text, every .ref file byte for byte, and the record itself.  Files with
+    lines at and around BUF_SIZE - 1 = 10239 characters (the fgets chunking shows in .ref), a '>' where a chunk of a long
+    line starts (a header to the reference), headers longer than a chunk and than the 128-character id, CR LF, empty lines,
+    no final line feed, an empty record, a short record, sequence in front of the first header and a NUL byte (both fall
+    back to the fgets pass)."""
+    import random
+    exe = build(tmp_path, "parsers_driver", "unit_io.cpp")
+    r = random.Random(7)
+
+    def seq(n):
+        return "".join(r.choice("ACGT") for _ in range(n))
+
+    def lines(s, w):
+        return "".join(s[i:i + w] + "\n" for i in range(0, len(s), w))
+    files = {
+        "plain.fa": ">chr1 desc\n" + lines(seq(5000), 70) + ">chr2\n" + lines(seq(333), 80),
+        "long_lines.fa": ">a\n" + seq(10238) + "\n" + seq(10239) + "\n" + seq(10240) + "\n" + seq(20478) + "\n" + seq(30) + "\n>b\n" + seq(25000) + "\n",
+        "gt_at_chunk.fa": ">a\n" + seq(10239) + ">" + seq(400) + "\n" + seq(150) + "\n" + seq(10238) + ">" + seq(200) + "\n",
+        "long_header.fa": ">" + "h" * 300 + "\n" + lines(seq(400), 60) + ">" + "k" * 10239 + ">tail of the header " + "z" * 11000 + "\n" + lines(seq(500), 60),
+        "crlf.fa": ">a\r\n" + "".join(seq(60) + "\r\n" for _ in range(10)) + ">b\r\n" + seq(200) + "\r\n",
+        "empty_lines.fa": ">a\n\n" + lines(seq(300), 50) + "\n\n>b\n" + seq(120) + "\n\n",
+        "no_final_lf.fa": ">a\n" + lines(seq(400), 80) + seq(77),
+        "no_final_lf_long.fa": ">a\n" + seq(10239 * 2),
+        "empty_record.fa": ">a\n>b\n" + lines(seq(400), 80),
+        "short_record.fa": ">a\n" + lines(seq(400), 80) + ">b\n" + seq(99) + "\n>c\n" + lines(seq(400), 80),
+        "short_last.fa": ">a\n" + lines(seq(400), 80) + ">b\n" + seq(50) + "\n",
+        "leading_sequence.fa": seq(50) + "\n>a\n" + lines(seq(400), 80),
+        "nul_byte.fa": ">a\n" + seq(200) + "\x00" + seq(100) + "\n",
+        "header_only_at_end.fa": ">a\n" + lines(seq(400), 80) + ">b",
+        "lower_and_iupac.fa": ">a\n" + lines((seq(300) + "nnnnacgtRYKM" + seq(100)).lower(), 61),
+    }
+    paths = []
+    for name, text in files.items():
+        (tmp_path / name).write_bytes(text.encode("latin-1"))
+        paths.append(str(tmp_path / name))
+    big = ">big\n" + lines(seq(3_000_00) * 12, 80) + ">big2 second\n" + lines(seq(100_000) * 5, 97)   # several 16 MiB-ish blocks? no: block logic by piece seams
+    (tmp_path / "big.fa").write_bytes(big.encode())
+    paths.append(str(tmp_path / "big.fa"))
+    out = tmp_path / "o"
+    out.mkdir()
+    for block in (None, "997", "10239", "64"):     # thread blocks of the scan: the default 16 MiB, and seams inside every line
+        env = dict(os.environ) if block is None else dict(os.environ, PBSIM_FASTA_BLOCK=block)
+        p = subprocess.run([exe, "--cmpfa", str(out)] + paths, capture_output=True, text=True, env=env)
+        assert p.returncode == 0, (block, (p.stdout + p.stderr)[-4000:])
+        assert p.stdout.count("same=1") == len(paths) - 2 and p.stdout.count("fallback") == 2, (block, p.stdout)
+        assert "Reference is too short" in p.stdout
