@@ -308,6 +308,11 @@ int64_t pbsim_job_records(pbsim_ctx *ctx);
  * pbsim_job_clear = pbsim_job_begin(ctx, 1). */
 int pbsim_job_begin(pbsim_ctx *ctx, int64_t first_record);
 int pbsim_job_clear(pbsim_ctx *ctx);
+/* By default a record's rounds run back to back (its tail reads and its statistics hide behind the next record's rounds).
+ * pbsim_job_set_interleave(ctx, k): the rounds of up to k consecutive records alternate instead, the record that is furthest
+ * behind first -- the bytes of k records then arrive side by side, which is what a caller wants who writes a file pair per
+ * record onto a file system that takes a few GB/s per file (the CLI sets 4).  Same bytes, same offsets, same statistics. */
+int pbsim_job_set_interleave(pbsim_ctx *ctx, int records);
 /* comm == NULL: this GPU alone.  sink may be NULL (text stays in HBM: measurements) and so may any of its callbacks. */
 int pbsim_job_run(pbsim_ctx *ctx, const pbsim_comm *comm, const pbsim_record_sink *sink);
 /* SAM / BAM header of record `record` of the job (pbsim_sam_header / pbsim_bam_header are those of the current unit) */

@@ -90,6 +90,7 @@ API = [
     ("pbsim_job_bam_header", C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
     ("pbsim_job_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("pbsim_job_progress", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ("pbsim_job_set_interleave", C.c_int, [C.c_void_p, C.c_int]),
     ("pbsim_batch_fetch_lengths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pbsim_job_breakdown", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_bind_host_to_device", C.c_int, [C.c_int, C.c_char_p, C.c_int64]),

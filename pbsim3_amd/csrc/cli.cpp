@@ -22,6 +22,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -395,11 +397,141 @@ void parse_args(int argc, char **argv, Cli &c) {
 }
 
 // ---- output files ------------------------------------------------------------------------------------------------------
+// Writing behind the job (round 4).  The job hands its sinks ~45 GB/s of members from two delivery threads, and a file takes
+// what one writer can push into it: 4-6 GB/s per file on /dev/shm however many threads write (one inode; tools/shm_write_test.c:
+// pwrite from 16 threads into ONE file 3.6 GB/s, into 16 files 66 GB/s).  So a sink callback only copies its piece into a
+// buffer of the pool below -- on helper threads, a piece of 80 MB is gone in ~2 ms -- and returns; one writer thread per file
+// pwrite()s the buffers in the order they came, and the job keeps k records going side by side (pbsim_job_set_interleave), so
+// that 2k files are being written at any time.  The pool bounds the memory (PBSIM_CLI_WRITE_BUFFER_MB, default 8192): a
+// callback waits for a buffer when the files fall that far behind.
+struct WritePool {
+  static constexpr size_t kChunk = 32u << 20, kSlice = 4u << 20;
+  size_t max_chunks = 256, made = 0;
+  std::vector<char *> idle;
+  std::mutex mu;
+  std::condition_variable cv;
+  // copy helpers
+  struct Task {
+    char *dst;
+    const char *src;
+    size_t n;
+    std::atomic<int> *left;
+  };
+  std::vector<std::thread> helpers;
+  std::deque<Task> tasks;
+  std::mutex tmu;
+  std::condition_variable tcv, dcv;
+  bool stop = false;
+  WritePool() {
+    const char *mb = getenv("PBSIM_CLI_WRITE_BUFFER_MB");
+    const size_t bytes = (size_t)(mb && atoll(mb) > 0 ? atoll(mb) : 8192) << 20;
+    max_chunks = std::max<size_t>(4, bytes / kChunk);
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    for (unsigned i = 0; i < std::min(8u, std::max(1u, hw / 4)); i++) helpers.emplace_back([this]() { run(); });
+  }
+  ~WritePool() {
+    {
+      std::lock_guard<std::mutex> lk(tmu);
+      stop = true;
+    }
+    tcv.notify_all();
+    for (auto &t : helpers) t.join();
+    for (char *p : idle) free(p);
+  }
+  bool step(std::unique_lock<std::mutex> &lk) {  // runs one queued slice; the lock is held on entry and on return
+    if (tasks.empty()) return false;
+    Task t = tasks.front();
+    tasks.pop_front();
+    lk.unlock();
+    memcpy(t.dst, t.src, t.n);
+    const bool last = t.left->fetch_sub(1) == 1;
+    lk.lock();
+    if (last) dcv.notify_all();
+    return true;
+  }
+  void run() {
+    std::unique_lock<std::mutex> lk(tmu);
+    for (;;) {
+      tcv.wait(lk, [&] { return stop || !tasks.empty(); });
+      if (stop && tasks.empty()) return;
+      step(lk);
+    }
+  }
+  void copy(char *dst, const char *src, size_t n) {  // returns when the bytes are in `dst`; the caller copies along
+    std::atomic<int> left{(int)((n + kSlice - 1) / kSlice)};
+    std::unique_lock<std::mutex> lk(tmu);
+    for (size_t a = 0; a < n; a += kSlice) tasks.push_back(Task{dst + a, src + a, std::min(kSlice, n - a), &left});
+    tcv.notify_all();
+    while (left.load() > 0)
+      if (!step(lk)) dcv.wait(lk, [&] { return left.load() == 0 || !tasks.empty(); });
+  }
+  char *get() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      if (!idle.empty()) {
+        char *p = idle.back();
+        idle.pop_back();
+        return p;
+      }
+      if (made < max_chunks) {
+        made++;
+        lk.unlock();
+        char *p = (char *)malloc(kChunk);
+        if (!p) die(": Cannot allocate memory.");
+        return p;
+      }
+      cv.wait(lk);
+    }
+  }
+  void put(char *p) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      idle.push_back(p);
+    }
+    cv.notify_one();
+  }
+};
+
 // A positional file: every rank opens the same path and pwrite()s its own byte ranges (rank 0 creates / truncates it first).
 struct PosFile {
   int fd = -1;
   std::string path;
   int64_t base = 0;  // bytes rank 0 puts in front of the record stream (SAM / BAM header)
+  // asynchronous mode (set_pool): write_at copies and queues; a thread of the file's own writes
+  WritePool *pool = nullptr;
+  struct Piece {
+    char *buf;
+    size_t n;
+    int64_t off;
+  };
+  std::deque<Piece> q;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::thread th;
+  bool started = false, finishing = false, failed = false;
+  void writer() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return finishing || !q.empty(); });
+      if (q.empty()) return;
+      const Piece p = q.front();
+      q.pop_front();
+      lk.unlock();
+      if (!failed && !write_now(p.buf, (int64_t)p.n, p.off)) failed = true;  // (keeps draining: the buffers go back to the pool)
+      pool->put(p.buf);
+      lk.lock();
+    }
+  }
+  bool write_now(const char *t, int64_t n, int64_t off) {
+    while (n > 0) {
+      const ssize_t k = ::pwrite(fd, t, (size_t)n, (off_t)off);
+      if (k <= 0) return false;
+      t += k;
+      n -= k;
+      off += k;
+    }
+    return true;
+  }
   void create(const std::string &p) {
     path = p;
     fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
@@ -411,16 +543,45 @@ struct PosFile {
     if (fd < 0) die(": Cannot open output file: %s", p.c_str());
   }
   bool write_at(const char *t, int64_t n, int64_t off) {
+    if (!pool) return write_now(t, n, off);
     while (n > 0) {
-      const ssize_t k = ::pwrite(fd, t, (size_t)n, (off_t)off);
-      if (k <= 0) return false;
+      const size_t k = (size_t)std::min<int64_t>(n, (int64_t)WritePool::kChunk);
+      char *buf = pool->get();
+      pool->copy(buf, t, k);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (failed) {
+          pool->put(buf);
+          return false;
+        }
+        q.push_back(Piece{buf, k, off});
+        if (!started) {
+          started = true;
+          th = std::thread([this]() { writer(); });
+        }
+      }
+      cv.notify_one();
       t += k;
-      n -= k;
-      off += k;
+      n -= (int64_t)k;
+      off += (int64_t)k;
     }
     return true;
   }
+  // no more writes will come (asynchronous mode: the file's thread writes what is queued and ends); close_checked joins it
+  void finish() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      finishing = true;
+    }
+    cv.notify_all();
+  }
   void close_checked() {
+    if (started) {
+      finish();
+      th.join();
+      started = false;
+      if (failed) die(": write error on %s", path.c_str());
+    }
     if (fd >= 0 && ::close(fd) != 0) die(": write error on %s", path.c_str());
     fd = -1;
   }
@@ -451,6 +612,17 @@ struct JobFiles {
   int64_t first = 1;
   std::vector<std::unique_ptr<RecFiles>> recs;
   RecFiles &of(int64_t record) { return *recs[(size_t)(record - first)]; }
+  std::unique_ptr<WritePool> pool;  // positional files are written behind the job (WritePool above) unless PBSIM_CLI_SYNC_WRITES=1
+  void use_async_writes() {
+    const char *sw = getenv("PBSIM_CLI_SYNC_WRITES");
+    if (!(sw && *sw == '1')) pool.reset(new WritePool);
+  }
+  // after pbsim_job_run: every file's queue written, every file closed (write errors end the process here)
+  void close_all() {
+    for (auto &r : recs)
+      for (Stream *s : {&r->read, &r->maf})
+        if (s->positional) s->pos.close_checked();
+  }
 };
 
 bool positional_mode(const Cli &c, bool bam) { return c.no_gzip || (c.gzip_on_gpu && !(bam && c.use_samtools)); }
@@ -502,6 +674,7 @@ void open_record(JobFiles &jf, long n, bool creator) {
   const bool bam = c.p.pass_num > 1;
   rf.read.positional = positional_mode(c, bam);
   rf.maf.positional = positional_mode(c, false);
+  rf.read.pos.pool = rf.maf.pos.pool = jf.pool.get();
   if (rf.read.positional) {
     const std::vector<char> h = read_header_bytes(c, jf.ctx, n);
     rf.read.pos.base = (int64_t)h.size();
@@ -549,7 +722,8 @@ int job_done(void *u, int64_t record, const pbsim_stats *st, int64_t read_bytes,
       if (rank0 && members && (bam || s.pos.base + bytes == 0) &&
           !s.pos.write_at((const char *)kBgzfEof, sizeof kBgzfEof, s.pos.base + bytes))
         return 0;
-      s.pos.close_checked();
+      if (s.pos.pool) s.pos.finish();  // (its thread writes what is queued; JobFiles::close_all joins it behind the job)
+      else s.pos.close_checked();
     } else if (rank0) {
       s.seq.close();
     }
@@ -715,6 +889,8 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       jf.ctx = ctx;
       jf.comm = comm;
       jf.first = 1;
+      jf.use_async_writes();
+      if (jf.pool) check(pbsim_job_set_interleave(ctx, (int)std::min<long>(4, gi.num_seq)));
       for (long n = 1; n <= gi.num_seq; n++) jf.recs.emplace_back(new RecFiles);
       if (rank0) for (long n = 1; n <= gi.num_seq; n++) open_record(jf, n, true);
       barrier(comm);  // the files exist
@@ -722,7 +898,9 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       pbsim_record_sink sink = {&jf, job_read, job_maf, job_done};
       phase("records uploaded, output files open");
       check(pbsim_job_run(ctx, comm, &sink));
-      phase("job run, bytes written");
+      phase("job run, bytes handed over");
+      jf.close_all();
+      phase("output files written");
       for (auto &t : ref_writers) t.join();
       if (ref_failed) die(": %s", ref_err.c_str());
       phase(".ref files written");
@@ -776,6 +954,8 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       jf.ctx = ctx;
       jf.comm = comm;
       jf.first = g.first;
+      jf.use_async_writes();
+      if (jf.pool) check(pbsim_job_set_interleave(ctx, (int)std::min<long>(4, g.second - g.first + 1)));
       for (long n = g.first; n <= g.second; n++) jf.recs.emplace_back(new RecFiles);
       if (rank0) for (long n = g.first; n <= g.second; n++) open_record(jf, n, true);
       barrier(comm);  // the files exist
@@ -783,7 +963,9 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       pbsim_record_sink sink = {&jf, job_read, job_maf, job_done};
       phase("records loaded and uploaded, output files open");
       check(pbsim_job_run(ctx, comm, &sink));
-      phase("job run, bytes written");
+      phase("job run, bytes handed over");
+      jf.close_all();
+      phase("output files written");
     }
     check(pbsim_job_begin(ctx, 1));
     }  // !mapped

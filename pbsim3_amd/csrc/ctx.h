@@ -321,6 +321,7 @@ struct pbsim_ctx {
   int64_t job_counters[8] = {0};
   int64_t job_progress[8] = {0}; // pbsim_job_progress: the exchange the round loop is about to enter
   double job_breakdown[16] = {0};  // pbsim_job_breakdown: where the round loop's wall time went (job.cpp)
+  int job_interleave = 1;        // pbsim_job_set_interleave: records whose rounds alternate
   int64_t job_first_unit = 1;    // genome.num of the job's first record (pbsim_job_begin)
 
   // profiling

@@ -148,6 +148,7 @@ struct Job {
   std::deque<Round> fifo;
   double mean = 0;
   int depth = 3;
+  int interleave = 1;
   int64_t reads_walked = 0, reads_delivered = 0, rounds = 0, bases = 0, ref_bases = 0, maf_columns = 0;
   double comm_us = 0;
   // where the round loop's wall time goes (pbsim_job_breakdown), microseconds
@@ -540,7 +541,13 @@ struct Job {
     Rec &R = recs[(size_t)rec];
     for (;;) {
       if (R.tail_waiting) {
-        if (block) tail_worker.drain();  // a slot from the chains' worker
+        if (block) {
+          // both chain slots are taken: collect the other records' chains that have come through (at most one cannot be -- the
+          // record whose last round's sizes are still pending), then a slot comes back from the chains' worker
+          for (size_t o = 0; o < recs.size(); o++)
+            if ((int)o != rec && recs[o].tail_slot >= 0 && !(pending && pending->rec == (int)o) && !tail_poll((int)o, true)) return PBSIM_FAILED;
+          tail_worker.drain();
+        }
         if (!tail_begin(R)) return PBSIM_FAILED;
         if (R.tail_waiting) return block ? fail("internal: no slot for the truncated reads") : PBSIM_SUCCEEDED;
       }
@@ -808,26 +815,44 @@ struct Job {
     tail_worker.start(c->device);
     for (;;) {
       if (!check_worker()) return PBSIM_FAILED;
-      // ---- keep the pipeline full: the earliest record that still lacks reads in flight
+      // ---- keep the pipeline full.  Open records = [merged, merged + open_max): their statistics are being collected and
+      // their tails may be running (two chain slots: a third chain waits its turn).  interleave == 1: the earliest open record
+      // that still lacks reads in flight -- a record's rounds run back to back and its tail hides behind the next record;
+      // interleave == k > 1: of the first k open records the one that is furthest behind, so that k records advance side by
+      // side (a caller that writes a file pair per record then has 2k files to write at a time, pbsim_job_set_interleave).
+      const int open_max = std::max(2, interleave);
       while (bulk_in_flight() < depth) {
         int cand = -1;
-        for (int r = 0; r < n && cand < 0; r++)
-          if (!recs[(size_t)r].bulk_done && (double)recs[(size_t)r].quota - recs[(size_t)r].spec_total > 0) cand = r;
+        const int hi = std::min(n, merged + open_max);
+        double best = 2.0;
+        for (int r = merged; r < hi; r++) {
+          const Rec &R = recs[(size_t)r];
+          if (R.bulk_done || (double)R.quota - R.spec_total <= 0) continue;
+          if (interleave <= 1) {
+            cand = r;
+            break;
+          }
+          const double f = R.spec_total / (double)std::max<int64_t>(1, R.quota);
+          if (f < best) {
+            best = f;
+            cand = r;
+          }
+        }
         if (cand < 0) {
           // everything that is expected to be needed is in flight; a record whose rounds all came back short of the quota
           // shows up here with nothing in flight: top it up
-          for (int r = 0; r < n && cand < 0; r++) {
+          for (int r = merged; r < hi && cand < 0; r++) {
             bool has = false;
             for (const Round &pr : fifo) has |= pr.rec == r;
             if (!recs[(size_t)r].bulk_done && !has) cand = r;
           }
-          if (cand < 0) break;
-          n_topup++;
+          if (cand >= 0) n_topup++;
         }
-        if (cand >= merged + 2) {
-          // at most two records' statistics are open at a time: merge the oldest first (a collective at a point of the
-          // round sequence that every rank reaches alike; by then its tail reads have finished beside the next record's rounds,
-          // and the merge waits for that record's own deliveries only -- the worker keeps moving the later rounds' bytes)
+        if (cand < 0) {
+          if (hi >= n) break;
+          // a record behind the open ones is next: merge the oldest first (a collective at a point of the round sequence that
+          // every rank reaches alike; by then its tail reads have finished beside the next record's rounds, and the merge
+          // waits for that record's own deliveries only -- the worker keeps moving the later rounds' bytes)
           if (!recs[(size_t)merged].bulk_done) break;  // its rounds are still in flight: pop first
           if (!finish_record(merged)) return PBSIM_FAILED;
           merged++;
@@ -1002,6 +1027,12 @@ int pbsim_job_breakdown(pbsim_ctx *c, double out[16]) {
   return PBSIM_SUCCEEDED;
 }
 
+int pbsim_job_set_interleave(pbsim_ctx *c, int records) {
+  if (!c || records < 1) return fail("pbsim_job_set_interleave: bad argument");
+  c->job_interleave = records;
+  return PBSIM_SUCCEEDED;
+}
+
 int pbsim_job_progress(pbsim_ctx *c, int64_t out[8]) {
   if (!c || !out) return fail("bad argument");
   memcpy(out, c->job_progress, sizeof c->job_progress);
@@ -1036,6 +1067,10 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // GPU with two others (18.5 instead of 29.3 ms a launch) and half the slots stay unallocated.
   const int W = J.W;
   const bool delivers = J.sink && (J.sink->on_read_text || J.sink->on_maf_text);
+  {
+    const char *il = getenv("PBSIM_JOB_INTERLEAVE");
+    J.interleave = std::max(1, std::min(64, il ? atoi(il) : c->job_interleave));
+  }
   // Several ranks (round 4, measured per rank against virtual ranks -- profiles/r04_replay_depth_ab.txt): every rank delivers
   // its own blocks over its own link, so a rank of eight is in the same regime as one GPU alone: configs[4] 594 / 592 / 570 ms
   // per rank with 3 / 2 / 1 rounds in flight, configs[1] 190 / 189 / 191.

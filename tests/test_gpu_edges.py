@@ -283,3 +283,29 @@ def test_records_added_as_fasta_lines(tmp_path):
     with P.Context(p, 0) as ctx:       # a wrong length is refused, not simulated
         with pytest.raises(P.PbsimError, match="not the number of bytes"):
             P._check(ctx.lib.pbsim_job_add_record_lines(ctx.h, shaped[0], len(shaped[0]), len(a) - 1))
+
+
+@pytest.mark.parametrize("method", ["errhmm", "qshmm"])
+def test_interleaved_records_change_nothing(method, monkeypatch):
+    """pbsim_job_set_interleave / PBSIM_JOB_INTERLEAVE: the rounds of k records alternate (the record furthest behind first)
+    instead of running record by record -- the same bytes at the same offsets and the same statistics, with more records than
+    the window holds, records of very different sizes, tails of several records due at once (two chain slots), tiny pools."""
+    import pbsim3_amd as P
+    recs = [harness.synth_bases(n, 40 + i).tobytes() for i, n in enumerate((400_000, 90_000, 650_000, 120_000, 300_000, 100_000, 510_000))]
+    qs = method == "qshmm"
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=21, depth=5.0,
+                         len_mean=1300.0, len_sd=1000.0, pass_num=2 if qs else 1)
+    outs = {}
+    for k in (1, 2, 3, 5, 9):
+        monkeypatch.setenv("PBSIM_JOB_INTERLEAVE", str(k))
+        with P.Context(p, 0) as ctx:
+            ctx.set_scratch_bytes(12 << 20)
+            (ctx.load_qshmm if qs else ctx.load_errhmm)(harness.model_path("QSHMM-RSII.model" if qs else "ERRHMM-ONT.model"))
+            for r in recs:
+                ctx.job_add_record(r)
+            texts, done = ctx.job_run()
+            outs[k] = {i: (bytes(v[0]), bytes(v[1]), tuple(getattr(done[i][0], f[0]) for f in done[i][0]._fields_), done[i][1:])
+                       for i, v in texts.items()}
+    assert len(outs[1]) == len(recs)
+    for k in outs:
+        assert outs[k] == outs[1], k
