@@ -29,6 +29,7 @@ for rep in 1 2; do
   t1=$(date +%s.%N)
   echo "== run $rep rc=$rc wall $(python3 -c "print(round($t1 - $t0, 2))") s"
   grep "pbsim cli\]" $d/err.txt
+  grep "worker: bytes of rec" $d/err.txt | awk '{s+=$(NF-5)} END {print "delivery worker busy (sum over rounds): " s " ms"}'
   grep -c "pbsim job r0\] t=.* round first" $d/err.txt | sed 's/^/rounds: /'
   grep "read num\|^depth" $d/err.txt | head -8 | tr "\n" " "; echo
   du -sb $d/out_*.gz 2>/dev/null | awk '{s+=$1} END {print "compressed output bytes", s}'
