@@ -16,8 +16,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
+#include <sys/syscall.h>
 #include <sys/time.h>
 #include <time.h>
 
@@ -521,6 +523,20 @@ struct PosFile {
   std::thread th;
   bool started = false, finishing = false, failed = false;
   void writer() {
+    // The rank's threads are bound to its GPU's NUMA node (pbsim_bind_host_to_device): right for the delivery threads and their
+    // pinned staging, wrong for the threads that fill the page cache -- with every file's pages coming out of one node's
+    // allocator eight writers moved 18 GB/s together; unbound they take pages (and memory bandwidth) from both sockets.
+    // PBSIM_CLI_WRITERS_BOUND=1 keeps them bound (A/B).
+    static const bool keep_bound = getenv("PBSIM_CLI_WRITERS_BOUND") && atoi(getenv("PBSIM_CLI_WRITERS_BOUND")) == 1;
+    if (!keep_bound) {
+      cpu_set_t all;
+      CPU_ZERO(&all);
+      for (int i = 0; i < CPU_SETSIZE; i++) CPU_SET(i, &all);
+      (void)sched_setaffinity(0, sizeof all, &all);
+#ifdef SYS_set_mempolicy
+      (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0);
+#endif
+    }
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
       cv.wait(lk, [&] { return finishing || !q.empty(); });
@@ -1166,7 +1182,9 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       if (rank0) print_simulation_stats(c, st, 0);
     }
   }
+  phase("simulation done");
   pbsim_destroy(ctx);
+  phase("context destroyed");
   barrier(comm);
 
   if (rank0) {
