@@ -934,7 +934,7 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       for (auto &t : ref_writers) t.join();
       if (ref_failed) die(": %s", ref_err.c_str());
       phase(".ref files written");
-      check(pbsim_job_begin(ctx, 1));
+      if (!(getenv("PBSIM_CLI_LEAVE_CONTEXT") && world == 1)) check(pbsim_job_begin(ctx, 1));
     } else {
     if (rank0 && !pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
     phase("genome split into .ref files");
@@ -1183,7 +1183,11 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
     }
   }
   phase("simulation done");
-  pbsim_destroy(ctx);
+  // The `pbsim` binary ends the process right behind this call (main.cpp sets PBSIM_CLI_LEAVE_CONTEXT=1 for a single rank):
+  // handing 150 GB of HBM pools and the pinned staging back piece by piece takes 0.8 s that the process exit does at once.
+  // A caller that lives on (pbsim3_amd.cli_main, a rank thread of --devices) gets its memory back here.
+  const char *leave = getenv("PBSIM_CLI_LEAVE_CONTEXT");
+  if (!(leave && *leave == '1' && world == 1)) pbsim_destroy(ctx);
   phase("context destroyed");
   barrier(comm);
 

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <string>
 #include <thread>
@@ -53,7 +54,14 @@ int main(int argc, char **argv) {
     fprintf(stderr, "ERROR (comm: %s): host or rccl.\n", comm_kind.c_str());
     return 255;
   }
-  if (devices.empty() && !selftest) return pbsim_cli_main(argc, argv, NULL, -1) & 255;
+  if (devices.empty() && !selftest) {
+    // one rank, and the process ends behind it: the context's pools go back to the driver with the process (cli.cpp)
+    if (!getenv("PBSIM_CLI_LEAVE_CONTEXT")) setenv("PBSIM_CLI_LEAVE_CONTEXT", "1", 1);
+    const int rc = pbsim_cli_main(argc, argv, NULL, -1) & 255;
+    fflush(stdout);
+    fflush(stderr);
+    _exit(rc);  // every file is closed; nothing is left but tearing the runtime's threads and mappings down one by one
+  }
   if (devices.empty()) devices.push_back(0);
 
   const int world = (int)devices.size();
