@@ -442,7 +442,9 @@ struct WritePool {
     }
     tcv.notify_all();
     for (auto &t : helpers) t.join();
-    for (char *p : idle) munmap(p, kChunk);
+    const char *leave = getenv("PBSIM_CLI_LEAVE_CONTEXT");  // (the process ends behind the job: its mappings go with it)
+    if (!(leave && *leave == '1'))
+      for (char *p : idle) munmap(p, kChunk);
   }
   bool step(std::unique_lock<std::mutex> &lk) {  // runs one queued slice; the lock is held on entry and on return
     if (tasks.empty()) return false;
@@ -935,6 +937,7 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       if (ref_failed) die(": %s", ref_err.c_str());
       phase(".ref files written");
       if (!(getenv("PBSIM_CLI_LEAVE_CONTEXT") && world == 1)) check(pbsim_job_begin(ctx, 1));
+      else fm.map = nullptr;  // (3 GB of mapped file: unmapped with the process)
     } else {
     if (rank0 && !pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
     phase("genome split into .ref files");
