@@ -30,6 +30,7 @@ class ReadTable:
         self.rawlen = rawlen.astype(np.int64)
         self.out0 = out0.astype(np.int64)
         self.cum = np.concatenate([[0], np.cumsum(self.out0)])
+        self.raw_max = int(self.rawlen.max()) if len(self.rawlen) else 0
 
     def block_sum(self, first, n):
         if first - 1 + n > len(self.out0):
@@ -40,9 +41,12 @@ class ReadTable:
         """pbsim.cpp:3792-3800 on reads first .. first + n - 1 with len_total = before in front of them:
         (n_final, need_truncated_read, len_total_after)"""
         lo = first - 1
-        t = before + (self.cum[lo:lo + n] - self.cum[lo])          # len_total at the start of each read
-        stop = (t >= quota) | (t + self.rawlen[lo:lo + n] > quota)
-        n_final = int(np.argmax(stop)) if stop.any() else n
+        # a read can only stop within max(rawlen) of the quota: start the scan there (len_total grows monotonically)
+        k0 = int(np.searchsorted(self.cum[lo:lo + n], self.cum[lo] + quota - before - self.raw_max, side="left"))
+        k0 = max(0, min(n, k0 - 1))
+        t = before + (self.cum[lo + k0:lo + n] - self.cum[lo])     # len_total at the start of each read
+        stop = (t >= quota) | (t + self.rawlen[lo + k0:lo + n] > quota)
+        n_final = k0 + int(np.argmax(stop)) if stop.any() else n
         after = before + int(self.cum[lo + n_final] - self.cum[lo])
         return n_final, int(n_final < n and after < quota), after
 
