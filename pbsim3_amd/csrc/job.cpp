@@ -1136,7 +1136,11 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   const int P = c->p.pass_num;
   const int regions = has_quality(c) ? 3 : 2;
   const char *jr = getenv("PBSIM_JOB_ROUNDS");  // experiment knob: rounds per record the batches are sized for
-  const int rounds_per_record = std::max(1, jr ? atoi(jr) : kRoundsPerRecord);
+  // (several ranks that deliver their bytes: two rounds per record and rank -- every delivery call pays a start-up of a few ms,
+  // and a rank of eight has a quarter of a record's bytes per round to spread it over; measured per rank against virtual
+  // ranks, configs[4] on eight: 520-537 ms with four rounds per record, 496-504 with two, 525+ with one -- profiles/r04_replay_rounds_ab.txt)
+  const bool delivers_text = sink && (sink->on_read_text || sink->on_maf_text);
+  const int rounds_per_record = std::max(1, jr ? atoi(jr) : (delivers_text && W > 1 ? 2 : kRoundsPerRecord));
   double target = (double)max_quota * P / ((double)rounds_per_record * W);
   target = std::max(target, std::min(kMinBatchBases, (double)max_quota * P / W));
   if (J.sink && (J.sink->on_read_text || J.sink->on_maf_text)) target = std::min(target, kSinkBatchBases);
