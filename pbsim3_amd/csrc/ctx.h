@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -150,6 +152,7 @@ struct DfLane {
     }
     const size_t want = std::max(kBlock, need);
     if (max_bytes && arena_bytes() + want > max_bytes) return nullptr;
+    if (getenv("PBSIM_TRACE")) fprintf(stderr, "[pbsim arena] new block of %zu MB (lane holds %zu MB in %zu blocks)\n", want >> 20, arena_bytes() >> 20, arena_blocks.size());
     arena_blocks.emplace_back(new HostBuf);
     arena_fill.push_back(0);
     arena_touched.push_back(1);
@@ -167,6 +170,11 @@ struct DfLane {
   // keep its page-locked memory for ever)
   void arena_trim() {
     size_t k = 0;
+    if (getenv("PBSIM_TRACE")) {
+      size_t drop = 0;
+      for (size_t i = 0; i < arena_blocks.size(); i++) drop += arena_touched[i] ? 0 : 1;
+      if (drop) fprintf(stderr, "[pbsim arena] trim: %zu of %zu blocks go back\n", drop, arena_blocks.size());
+    }
     for (size_t i = 0; i < arena_blocks.size(); i++)
       if (arena_touched[i]) {
         if (k != i) arena_blocks[k] = std::move(arena_blocks[i]);
