@@ -5,7 +5,7 @@ kernels counted per task on the GPU (columns walked, bases emitted, substitution
 With the keyed stream a draw is a word of the block of its MAF column, so "draws consumed" is not a position in a stream
 but a count per call-site group; the walk's control flow fixes those counts:
 
-  ERRHMM  state draw and deletion test once per column; an emission draw per column that is not deleted; a nucleotide draw
+  ERRHMM  state draw and deletion test once per column; an emission draw per column whose deletion test does not fire; a nucleotide draw
           per substitution and insertion (+ one more per substitution of a non-ACGT base); three header draws per read
   QSHMM   quality and error-class draw once per emitted base; a state draw per emitted base of a class that has a model;
           a deletion test in front of every column but a task's first; a nucleotide draw per substitution and insertion
@@ -74,7 +74,11 @@ def test_call_site_counts_follow_from_the_kernels_counters(case):
     if p.method == P.METHOD_ERR:
         state, deltest, emis = (groups.get(("WALK", 0, k), 0) for k in (0, 1, 2))
         assert state == deltest
-        assert emis == state - ndel, (emis, state, ndel)
+        # an emission draw per column whose deletion test did not fire.  Classes outside the model's range re-draw (Q3): below
+        # it a match may become a deletion after its emission draw (%3 + 1, pbsim.cpp:3893-3895), above it a fired deletion
+        # may become a match without one (:3921) -- so the count is exact without such classes and bounded by their re-draws
+        redraw_test, redraw_type = groups.get(("WALK", 1, 0), 0), groups.get(("WALK", 1, 1), 0)
+        assert -redraw_test <= emis - (state - ndel) <= redraw_type, (emis, state, ndel, redraw_test, redraw_type)
         # accuracy class 100 is copied verbatim (pbsim.cpp:3837-3845): those tasks draw nothing
         verbatim = "acc98" in case or "acc99" in case
         assert (state <= columns) if verbatim else (state == columns), (state, columns)
