@@ -390,6 +390,12 @@ int pbsim_prof_tail(pbsim_ctx *ctx, double *tail_ms, int64_t *tail_launches);
 int pbsim_prof_walk_busy(pbsim_ctx *ctx, double *busy_ms);
 /* launches of a wave walker (one wave per task: k_walk_errhmm_coop / k_walk_qshmm_coop) since the last reset (or creation) */
 int64_t pbsim_prof_wave_launches(pbsim_ctx *ctx);
+/* The scratch rows of a task (two MAF rows, a quality row for the quality-score methods) are laid out for factor x length + 64
+ * columns.  2 is the reference's own bound (its buffers are 2 * len_max + 1, pbsim.cpp:5488); a context starts there, keeps the
+ * largest need its walks have reported and lays the next batches out with a little more -- a batch in which a read runs out of
+ * row all the same is walked again at 2 inside pbsim_batch_walk_end.  [0] the factor the next batches get, [1] the largest
+ * (columns - 64) / length seen, [2] batches walked twice.  PBSIM_SCRATCH_FACTOR fixes the factor. */
+int pbsim_scratch_state(pbsim_ctx *ctx, double out[3]);
 /* the two kernels next in line, timed with HIP events on the streams they run on, since the last reset:
  * [0] ms, [1] launches, [2] bytes read (scratch rows), [3] bytes written (text) of the text emission (k_text_*);
  * [4] ms, [5] launches, [6] text bytes in, [7] member bytes out of k_deflate_chunks */

@@ -91,6 +91,7 @@ API = [
     ("pbsim_job_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("pbsim_job_progress", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("pbsim_job_set_interleave", C.c_int, [C.c_void_p, C.c_int]),
+    ("pbsim_scratch_state", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_batch_fetch_lengths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pbsim_job_breakdown", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_bind_host_to_device", C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
@@ -609,6 +610,12 @@ class Context:
         r, l, o = (np.empty(n_reads, dtype=np.int32) for _ in range(3))
         _check(self.lib.pbsim_batch_fetch_lengths(self.h, r.ctypes.data, l.ctypes.data, o.ctypes.data))
         return r, l, o
+
+    def scratch_state(self):
+        """(factor the next batches' rows are laid out with, largest need seen, batches walked twice)"""
+        a = (C.c_double * 3)()
+        _check(self.lib.pbsim_scratch_state(self.h, a))
+        return tuple(a)
 
     def job_counters(self):
         a = (C.c_int64 * 8)()

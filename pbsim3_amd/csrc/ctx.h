@@ -253,6 +253,8 @@ struct Slot {
   int64_t b_first = 0, b_n = 0, b_slots_max = 0;
   bool b_truncated = false, b_enqueued = false, b_walked = false, b_finalized = false;
   bool b_chain = false;                // the batch is a chain of truncated reads (walk_begin(.., chain))
+  int64_t b_trunc = -1;                // truncate_remaining of the batch (a re-walk begins it again)
+  double b_factor = 2.0;               // scratch factor of the batch's layout
   int64_t b_pass0 = 0;
   pbsim_batch_info b_info;
 };
@@ -312,6 +314,14 @@ struct pbsim_ctx {
   std::vector<int64_t> sq_off;
   int64_t sq_total = 0;        // sample.len_total_filtered
   int64_t scratch_budget = 0;  // bytes of wave scratch per slot
+  // Columns a task's rows are laid out for = scratch_factor x its length + pad.  The reference's own buffers take 2 x (the
+  // bound that cannot overflow: every column consumes a reference base or is one of at most... in practice ~1.06-1.2 x); a
+  // context starts at 2, keeps the largest need its walks have reported (need_seen, DeviceFlags::need_q10) and lays the next
+  // batches out with need_seen + 0.08.  A batch in which a read runs out of row all the same is walked again at 2 by
+  // pbsim_batch_walk_end, transparently.  PBSIM_SCRATCH_FACTOR fixes the factor (tests: 1.02 makes most batches walk twice).
+  double scratch_factor = 2.0, need_seen = 0.0;
+  bool scratch_factor_fixed = false;
+  int64_t rewalked_batches = 0;  // batches walked again at the full factor (pbsim_prof: how often the estimate was too low)
   bool scratch_auto = true;    // sized per record by pbsim_simulate_wgs unless PBSIM_SCRATCH_MB / pbsim_set_scratch_bytes said otherwise
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
   hipStream_t df_streams[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [lane][kernels | copies]
@@ -351,7 +361,9 @@ RefDesc current_ref(const pbsim_ctx *c);
 int64_t quota_of(const pbsim_ctx *c, int64_t ref_len);  // (long long)(depth * len), pbsim.cpp:705
 // chain: the n_reads reads are the truncated reads behind a quota cut, each depending on the one before (pbsim.cpp:3792-3800);
 // truncate_remaining = what is left of the quota in front of the first; ended by chain_end_finalize
-int walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining, bool chain = false);
+int walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining, bool chain = false,
+               double factor = 0.0 /* 0: the context's current scratch factor */);
+double scratch_factor_of(const pbsim_ctx *c);  // what the next batches are laid out with
 int chain_end_finalize(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out);
 int chain_reads_for(const pbsim_ctx *c, int64_t ref_len, int64_t remaining);
 constexpr int kChainReads = 6;  // steps enqueued per chain (a chain is 2-3 reads as a rule: each leaves ~3 % of its length)

@@ -149,9 +149,11 @@ int64_t batch_capacity(const pbsim_ctx *c) { return batch_capacity_for(c, c->ref
 
 }  // namespace
 
+double pbsim::scratch_factor_of(const pbsim_ctx *c) { return std::min(2.0, std::max(1.0, c->scratch_factor)); }
+
 int64_t pbsim::batch_capacity_for(const pbsim_ctx *c, int64_t ref_len) {
   const double mean = std::min<double>(c->hdr.mean_len, (double)std::max<int64_t>(ref_len, 1));
-  const double per_task = (double)regions_of(c) * (2.0 * mean + kScratchPad) * 1.12 + 64.0;
+  const double per_task = (double)regions_of(c) * (scratch_factor_of(c) * mean + kScratchPad) * 1.12 + 64.0;
   int64_t n = (int64_t)((double)c->scratch_budget / (per_task * c->p.pass_num));
   n = std::max<int64_t>(n, 1);
   n = std::min<int64_t>(n, (int64_t)(0x7fffff00 / std::max(1, c->p.pass_num)));
@@ -272,6 +274,12 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
     (void)hipEventCreate(&sl.ev1);
     (void)hipEventCreate(&sl.ev2);
     (void)hipEventCreate(&sl.ev3);
+  }
+  if (const char *sf = getenv("PBSIM_SCRATCH_FACTOR")) {  // fixes the rows' factor (ctx.h); 2 = the reference's own bound
+    if (atof(sf) >= 1.0) {
+      c->scratch_factor = std::min(2.0, atof(sf));
+      c->scratch_factor_fixed = true;
+    }
   }
   const char *mb = getenv("PBSIM_SCRATCH_MB");
   c->scratch_budget = (mb && atoll(mb) > 0) ? atoll(mb) * (1LL << 20) : (8LL << 30);
@@ -561,7 +569,8 @@ static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads, bool hp_flag) {
 
 // header draw -> bucketing -> walk -> pass-0 prefix of reads [first_read, first_read + n_reads) of `ref`, on the selected slot
 extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t first_read, int64_t n_reads, int64_t truncate_remaining,
-                                   bool chain) {
+                                   bool chain, double factor) {
+  if (factor <= 0) factor = scratch_factor_of(c);
   if (!c || n_reads < 1 || first_read < 1) return fail("pbsim_batch_walk: bad argument");
   if (chain && (truncate_remaining < 0 || c->p.strategy != PBSIM_STRATEGY_WGS)) return fail("internal: a chain of truncated reads needs a quota");
   NEED_DEVICE(c);
@@ -618,7 +627,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   double lmax = (double)std::min<int64_t>(c->p.len_max, std::max<int64_t>(ref.len, 1));
   if (truncate_remaining >= 0) lmax = std::min(lmax, (double)std::max<int64_t>(truncate_remaining, c->p.len_min));  // (pbsim.cpp:3795-3800)
   // (only waves that hold a task take scratch: at most one per task)
-  const double worst = (double)std::min<int64_t>(waves_max, n_tasks) * regions_of(c) * (2.0 * lmax + kScratchPad + 64) * 64.0;
+  const double worst = (double)std::min<int64_t>(waves_max, n_tasks) * regions_of(c) * (factor * lmax + kScratchPad + 64) * 64.0;
   const int64_t pool = std::max<int64_t>((int64_t)c->s().d_scratch.bytes - (int64_t)kScratchSlack,
                                          (int64_t)std::min<double>((double)c->scratch_budget, worst));
   HIP_OK(c->s().d_scratch.ensure((size_t)pool + kScratchSlack, true));
@@ -696,6 +705,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   s.wg_start = s.wg_hist + (kLenBuckets + 1);
   s.wg_order = c->s().d_wg_order.as<int32_t>();
   s.regions = regions_of(c);
+  s.cap_q8 = (int32_t)std::min(512.0, ceil(factor * 256.0));
   s.scratch_bytes = std::min<int64_t>(pool, c->scratch_budget);
   s.flags = flags;
   launch_task_sort(s, c->s().stream);
@@ -721,6 +731,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   w.task_of_slot = s.task_of_slot;
   w.wg_order = s.wg_order;
   w.mean_len = (int32_t)c->hdr.mean_len;
+  w.cap_q8 = s.cap_q8;
   w.coop_min_len = coop_len;
   {
     // the wave walkers' units: drawn from a counter in batches of 16 k - 250 k tasks, where the wave walk decides the batch's
@@ -831,6 +842,8 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   c->s().b_n = n_reads;
   c->s().b_slots_max = slots_max;
   c->s().b_chain = chain;
+  c->s().b_trunc = truncate_remaining;
+  c->s().b_factor = factor;
   c->s().b_truncated = truncate_remaining >= 0 || trans;  // trans has no quota: every read is final
   c->s().b_enqueued = true;
   c->s().b_walked = false;
@@ -867,8 +880,22 @@ int pbsim_batch_walk_end(pbsim_ctx *c, int64_t *pass0_bases) {
              (long long)f.scratch_need, (long long)c->scratch_budget);
     return fail(buf);
   }
-  if (f.error & kErrScratchOverflow)
+  // what the batch's reads needed of their rows: the next batches are laid out for the largest need seen so far + 0.08
+  if (f.need_q10) {
+    c->need_seen = std::max(c->need_seen, (double)f.need_q10 / 1024.0);
+    if (!c->scratch_factor_fixed) c->scratch_factor = std::min(2.0, std::max(1.0, c->need_seen + 0.08));
+  }
+  if (f.error & kErrScratchOverflow) {
+    if (c->s().b_factor < 2.0) {
+      // a read ran out of row: the batch again, laid out with the reference's own bound (and the factor follows what it needed)
+      c->rewalked_batches++;
+      if (!c->scratch_factor_fixed) c->scratch_factor = std::min(2.0, c->scratch_factor + 0.25);
+      Slot &sl = c->s();
+      if (!walk_begin(c, sl.ref, sl.b_first, sl.b_n, sl.b_trunc, sl.b_chain, 2.0)) return PBSIM_FAILED;
+      return pbsim_batch_walk_end(c, pass0_bases);
+    }
     return fail("a read produced more MAF columns than 2*len+64 (the reference's buffers are 2*len_max+1)");
+  }
   c->s().b_walked = true;
   c->s().b_pass0 = f.sums[0];
   if (pass0_bases) *pass0_bases = f.sums[0];
@@ -895,7 +922,7 @@ int pbsim_batch_fetch_lengths(pbsim_ctx *c, int32_t *rawlen, int32_t *len, int32
 extern "C++" int pbsim::chain_reads_for(const pbsim_ctx *c, int64_t ref_len, int64_t remaining) {
   const double lub = (double)std::min<int64_t>(std::min<int64_t>(c->p.len_max, std::max<int64_t>(ref_len, 1)),
                                                std::max<int64_t>(remaining, c->p.len_min));
-  const double per_block = (double)regions_of(c) * 64.0 * (2.0 * lub + kScratchPad + 64.0);
+  const double per_block = (double)regions_of(c) * 64.0 * (scratch_factor_of(c) * lub + kScratchPad + 64.0);
   const int64_t fit = (int64_t)((double)c->scratch_budget / (1.05 * per_block));
   return (int)std::max<int64_t>(1, std::min<int64_t>(kChainReads, fit));
 }
@@ -2694,6 +2721,13 @@ int pbsim_prof_get(pbsim_ctx *c, double *walk_ms, int64_t *walk_launches, double
   return PBSIM_SUCCEEDED;
 }
 int64_t pbsim_prof_wave_launches(pbsim_ctx *c) { return c ? c->prof_wave_launches : -1; }
+int pbsim_scratch_state(pbsim_ctx *c, double out[3]) {
+  if (!c || !out) return fail("bad argument");
+  out[0] = scratch_factor_of(c);
+  out[1] = c->need_seen;
+  out[2] = (double)c->rewalked_batches;
+  return PBSIM_SUCCEEDED;
+}
 int pbsim_prof_secondary(pbsim_ctx *c, double out[8]) {
   if (!c || !out) return fail("bad argument");
   if (c->device >= 0) (void)hipSetDevice(c->device);

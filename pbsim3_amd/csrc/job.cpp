@@ -1132,6 +1132,16 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     if (!ensure_tables(c, jr.ref.hp11)) return PBSIM_FAILED;
   }
   c->bias.hp11_seen = seen11;
+  // ---- how much of its 2 L + pad columns does a read of this model use?  A context that has not walked yet finds out on the
+  // first reads of the job's first record (8192 reads, ~1 ms; every rank the same reads, so every rank the same answer):
+  // pools and rounds are then sized for what the rows really take (engine.cpp: scratch factor) -- a third less than 2 L.
+  if (!c->scratch_factor_fixed && c->need_seen == 0) {
+    c->cur = 0;
+    const int64_t n_probe = std::min<int64_t>(8192, batch_capacity_for(c, J.recs[0].ref.len));
+    if (!walk_begin(c, J.recs[0].ref, 1, std::max<int64_t>(1, n_probe), -1) || !pbsim_batch_walk_end(c, nullptr)) return PBSIM_FAILED;
+    c->s().b_walked = false;
+  }
+  const double sf = scratch_factor_of(c);
   // ---- batch size: a few rounds per record and rank, not below what keeps a walk longer than its longest read
   const int P = c->p.pass_num;
   const int regions = has_quality(c) ? 3 : 2;
@@ -1158,7 +1168,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
       // FASTQ 2.0 | SAM text ~6.1 | BAM records ~3.5 (bases 0.5, qualities 1, the ip and pw arrays 1 each); MAF 2.23; the text
       // buffers are grown with 12.5 % of slack (DevBuf::ensure)
       const double text_per_base = 1.125 * (P > 1 ? (c->bam_output ? 5.8 : 8.4) : 4.25);
-      const double scratch_per_base = (double)regions * 2.0 * 1.12 * 1.08 + 0.1;
+      const double scratch_per_base = (double)regions * sf * 1.12 * 1.08 + 0.1;
       // (rounds in flight + one whose delivery is pending + one with the worker; nothing is held back when the text stays put)
       const bool delivering_text = J.sink && (J.sink->on_read_text || J.sink->on_maf_text);
       const double slots_used = (double)J.depth + (delivering_text ? 2.0 : 1.0);
@@ -1169,7 +1179,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     // what batch_capacity_for() charges a read: `regions` rows of 2 * length + pad columns, 12 % slack for the per-wave rounding
     const double mean_len = std::max(1.0, c->hdr.mean_len);
     // (a read yields ~0.97 of its length in bases, and a round overshoots its share of the quota by 0.5 %: 8 % headroom)
-    const double want = (target / P / mean_len) * P * ((double)regions * (2.0 * mean_len + kScratchPad) * 1.12 + 64.0) * 1.08 + (64 << 20);
+    const double want = (target / P / mean_len) * P * ((double)regions * (sf * mean_len + kScratchPad) * 1.12 + 64.0) * 1.08 + (64 << 20);
     const double share = std::min(48.0 * (1LL << 30), 0.14 * (double)(free_b + held));
     const int64_t auto_b = (int64_t)std::max(256.0 * (1 << 20), std::min(want, share));
     // (a pool changes size only when it is clearly wrong: what the slots hold moves the free-memory figures from run to run, and

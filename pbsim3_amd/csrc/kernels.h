@@ -16,7 +16,7 @@ constexpr int kLenBuckets = 4096;   // length buckets per accuracy class in the 
 constexpr int kBinPad = PBSIM_BIN_PAD;  // int32 slots per counter of the sort's histogram / cursors: one counter per 64-byte line,
                                       // neighbouring (hot) length buckets do not share a line that 8 XCDs fight over
 constexpr int kLenShift = 8;        // bucket = len >> 8  (len_max 1e6 -> 3907 buckets)
-constexpr int kScratchPad = 64;     // per-task slack: cap = 2*L + kScratchPad columns (pbsim.cpp:5488 uses 2*len_max+1)
+constexpr int kScratchPad = 64;     // per-task slack: a row holds factor * L + kScratchPad columns (factor <= 2: pbsim.cpp:5488 uses 2*len_max+1)
 constexpr int kMaxClasses = 64;
 // wave_cap[w] bit 30: the 64 tasks of this scratch block are all walked by k_walk_errhmm_coop and its rows are stored task
 // by task (row r of task l at r * cap * 256 + l * cap * 4 bytes) instead of interleaved dword by dword: a wave that walks
@@ -26,7 +26,7 @@ constexpr int kHpTile = 4096;       // bases per workgroup in the homopolymer ke
 
 // error flag bits written by kernels into EngineFlags::error
 enum : uint32_t {
-  kErrScratchOverflow = 1u,   // a task produced more MAF columns than 2*L+kScratchPad
+  kErrScratchOverflow = 1u,   // a task produced more MAF columns than its rows hold
   kErrScratchBudget = 2u,     // the batch needs more scratch than the pool holds
 };
 
@@ -39,6 +39,8 @@ struct DeviceFlags {
   int64_t sums[8];        // [0] pass-0 bases of the batch, [1] read-text bytes, [2] maf-text bytes,
                           // [3] bases all passes (final reads), [4] ref bases, [5] maf columns
   unsigned long long hpfreq[12];
+  uint32_t need_q10;      // walks: max over the tasks of (MAF columns - pad) / length, in 1/1024 (note_row_need)
+  uint32_t pad_;
 };
 
 struct RefView {
@@ -104,6 +106,7 @@ struct SortArgs {
   int32_t *wg_hist, *wg_start;  // [kLenBuckets+1] each
   int32_t *wg_order;            // [n_slots_max/kWG] walk workgroups, longest reads first
   int32_t regions;      // scratch rows per task (2 errhmm, 3 qshmm)
+  int32_t cap_q8;       // columns per row = cap_q8 / 256 x the block's longest read + kScratchPad (512: the reference's 2 L)
   int64_t scratch_bytes;
   DeviceFlags *flags;
 };
@@ -125,6 +128,7 @@ struct WalkArgs {
   int32_t mean_len;          // E[L] of the length table (priority thresholds)
   int32_t coop_min_len;      // errhmm: reads of at least this length belong to k_walk_errhmm_coop (a multiple of 256; INT32_MAX: none)
   int32_t coop_dynamic;         // k_walk_errhmm_coop: units drawn from a counter (flags->sums[7]) instead of dealt round-robin
+  int32_t cap_q8;               // SortArgs::cap_q8 of the batch's layout (the walks' priority heuristic reads lengths off the caps)
   const int32_t *coop_end;   // [ncls] their slots are class_start[c] .. coop_end[c]
   const int32_t *wave_cap;
   const int64_t *wave_off;

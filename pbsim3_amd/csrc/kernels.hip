@@ -633,7 +633,10 @@ __global__ __launch_bounds__(256) void k_wave_cap(SortArgs a) {
     }
   }
   // rows of whole 64-byte lines; a block whose tasks all belong to the wave walker is stored task by task
-  const int cap = (lmax < 0) ? 0 : ((2 * lmax + kScratchPad + 3) / 4 + 15) & ~15;
+  // columns a row holds: cap_q8 / 256 x the block's longest read + pad (cap_q8 = 512: the reference's own bound, 2 L; the host
+  // asks for less once it has seen what the model's reads need -- engine.cpp scratch factor -- and walks a batch again at 512
+  // when a read does run out of row, kErrScratchOverflow)
+  const int cap = (lmax < 0) ? 0 : ((((int)(((int64_t)lmax * a.cap_q8 + 255) >> 8) + kScratchPad + 3) / 4 + 15) & ~15);
   const bool coop = lmax >= 0 && a.coop_bucket < kLenBuckets && (lmin >> kLenShift) >= a.coop_bucket && ((a.coop_classes >> cls) & 1ull);
   a.wave_cap[w] = cap | (coop ? kWaveTransposed : 0);
 }
@@ -755,6 +758,12 @@ __device__ __forceinline__ void walk_priority(int lmax_wave, int mean_len) {
 // A cursor moves by at most 4 bases per 4-column group, hence crosses at most
 // one window boundary per group; refill() runs once per group.
 // ---------------------------------------------------------------------------
+// what a finished task needed of its rows, as the factor the host sizes them with: (columns - pad) / length, in 1/1024
+// (one atomic per task; the host keeps the largest it has seen and lays the next batches out with a little more)
+__device__ __forceinline__ void note_row_need(DeviceFlags *flags, int columns, int L) {
+  if (columns > kScratchPad && L > 0) atomicMax(&flags->need_q10, (uint32_t)(((uint64_t)(columns - kScratchPad) * 1024u + (uint32_t)L - 1u) / (uint32_t)L));
+}
+
 template <bool kHpBits>
 struct RefCursor {
   const uint64_t *lane_seq, *lane_hp;
@@ -903,12 +912,12 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
   }
   const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]) & ~kWaveTransposed;  // wave-uniform: keeps row offsets scalar
-  walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
+  walk_priority((int)(((int64_t)(cap_dw * 4 - kScratchPad) << 8) / a.cap_q8), a.mean_len);
   const int64_t woff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.wave_off[wave] >> 32)) << 32) |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wave_off[wave]);
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + woff) + lane;
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
-  const int cap = 2 * L + kScratchPad;
+  const int cap = cap_dw * 4;  // columns the task's rows hold (k_wave_cap)
 
   int ro = 0, q = 0, m = 0;
   uint32_t state = 0, tran_rv = 1;
@@ -1010,6 +1019,7 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
     a.nsub[task] = nsub;
     a.nins[task] = m - ro;  // every column consumes a reference base except insertions
     a.ndel[task] = m - q;   // every column emits a read base except deletions
+    note_row_need(a.flags, m, L);
   }
 }
 
@@ -1130,7 +1140,7 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
   const size_t row_step = transposed ? 1 : 64;
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + (transposed ? (size_t)(slot & 63) * cap_dw : (size_t)(slot & 63));
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
-  const int cap = 2 * L + kScratchPad;
+  const int cap = cap_dw * 4;  // columns the task's rows hold (k_wave_cap)
   const uint32_t comp_off = minus ? 256u : 0u;
   const int64_t p_first = minus ? (off + L - 1) : off;
   const int64_t p_last = a.ref.len - 1;
@@ -1253,6 +1263,7 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
     a.nsub[task] = nsub;
     a.nins[task] = m0 - ro0;
     a.ndel[task] = m0 - q0;
+    note_row_need(a.flags, m0, L);
   }
 }
 
@@ -1368,13 +1379,13 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
     minus = a.read_minus ? (a.read_minus[r] != 0) : ((read_idx & 1u) == 0);
   }
   const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]) & ~kWaveTransposed;  // wave-uniform: keeps row offsets scalar
-  walk_priority((cap_dw * 4 - kScratchPad) / 2, a.mean_len);
+  walk_priority((int)(((int64_t)(cap_dw * 4 - kScratchPad) << 8) / a.cap_q8), a.mean_len);
   const int64_t woff = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.wave_off[wave] >> 32)) << 32) |
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)a.wave_off[wave]);
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + woff) + lane;
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
   uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;  // quality per MAF column (0 in deleted columns)
-  const int cap = 2 * L + kScratchPad;
+  const int cap = cap_dw * 4;  // columns the task's rows hold (k_wave_cap)
 
   int ro = 0, q = 0, m = 0;
   uint32_t state = 0, last_q = 0, hp_prev = 0;  // hp of the last consumed reference base; none yet -> slot 0 (Q15)
@@ -1494,6 +1505,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
     a.nins[task] = m - ro;
     a.ndel[task] = m - q;
     a.qsum[task] = qsum;
+    note_row_need(a.flags, m, L);
   }
 }
 
@@ -1597,7 +1609,7 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + (transposed ? (size_t)(slot & 63) * cap_dw : (size_t)(slot & 63));
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
   uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;
-  const int cap = 2 * L + kScratchPad;
+  const int cap = cap_dw * 4;  // columns the task's rows hold (k_wave_cap)
   const uint32_t comp_off = minus ? 256u : 0u;
   const int64_t p_first = minus ? (off + L - 1) : off;
   const int64_t p_last = a.ref.len - 1;
@@ -1729,6 +1741,7 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
     a.nins[task] = m0 - ro0;
     a.ndel[task] = m0 - q0;
     a.qsum[task] = qsum;
+    note_row_need(a.flags, m0, L);
   }
 }
 

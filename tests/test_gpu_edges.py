@@ -309,3 +309,48 @@ def test_interleaved_records_change_nothing(method, monkeypatch):
     assert len(outs[1]) == len(recs)
     for k in outs:
         assert outs[k] == outs[1], k
+
+
+@pytest.mark.parametrize("case", ["wgs_errhmm-ont_quirk", "wgs_qshmm_rsii_pass3", "wgs_errhmm_rsii_default"])
+@pytest.mark.parametrize("factor", ["1.02", "1.2", "2"])
+def test_rows_laid_out_tighter_than_two_lengths(case, factor, monkeypatch):
+    """Scratch rows of factor x length + 64 columns (ctx.h scratch_factor): 2 is the reference's bound; at 1.02 most batches hold
+    a read that runs out of row and are walked again at 2 inside pbsim_batch_walk_end -- the bytes are the goldens' either way
+    (and the re-walks really happen)."""
+    import pbsim3_amd as P
+    from cases import CASES
+    from test_gpu_parity import MANIFEST
+    monkeypatch.setenv("PBSIM_SCRATCH_FACTOR", factor)
+    args = harness.resolve(CASES[case]["args"])
+    p, a = product.params_from_args(args)
+    outs = {}
+    with P.Context(p, 0) as ctx:
+        ctx.set_scratch_bytes(product.scratch_mb_for(case) << 22)
+        (ctx.load_errhmm if p.method == P.METHOD_ERR else ctx.load_qshmm)(a["--errhmm" if p.method == P.METHOD_ERR else "--qshmm"])
+        for r in product.read_fasta(a["--genome"]):
+            ctx.job_add_record(r)
+        texts, done = ctx.job_run()
+        state = ctx.scratch_state()
+        for i in sorted(texts):
+            rt = bytes(texts[i][0])
+            outs["_%04d.%s" % (i, "fq" if p.pass_num == 1 else "sam")] = (ctx.job_sam_header(i) if p.pass_num > 1 else b"") + rt
+            outs["_%04d.maf" % i] = bytes(texts[i][1])
+    gold = MANIFEST[f"{case}/philox"]
+    for k, v in outs.items():
+        assert harness.sha(v) == gold[k]["sha256"], (case, factor, k)
+    assert state[0] == float(factor)
+    assert (state[2] > 0) == (factor == "1.02"), state
+
+
+def test_rows_follow_what_the_reads_need():
+    """without the knob: a context starts at the reference's 2 x length, learns from its first walk (the job's probe) what the
+    model's reads take, and lays the job out with that + 0.08 -- about 1.2 for ERRHMM-ONT at the default accuracy"""
+    import pbsim3_amd as P
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=3, depth=8.0)
+    with P.Context(p, 0) as ctx:
+        ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+        assert ctx.scratch_state()[0] == 2.0
+        ctx.job_add_record(harness.synth_bases(3_000_000, 5).tobytes())
+        ctx.job_run(collect=False)
+        f, need, rewalks = ctx.scratch_state()
+        assert 1.05 < need < 1.4 and abs(f - (need + 0.08)) < 1e-9 and rewalks == 0, (f, need, rewalks)
