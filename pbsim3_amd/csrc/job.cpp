@@ -1137,9 +1137,15 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // pools and rounds are then sized for what the rows really take (engine.cpp: scratch factor) -- a third less than 2 L.
   if (!c->scratch_factor_fixed && c->need_seen == 0) {
     c->cur = 0;
-    const int64_t n_probe = std::min<int64_t>(8192, batch_capacity_for(c, J.recs[0].ref.len));
-    if (!walk_begin(c, J.recs[0].ref, 1, std::max<int64_t>(1, n_probe), -1) || !pbsim_batch_walk_end(c, nullptr)) return PBSIM_FAILED;
-    c->s().b_walked = false;
+    // (a pool of a few MB -- tests -- may not hold that many reads at the starting factor: fewer then, or none: the job
+    // keeps the reference's bound until its rounds have reported)
+    for (int64_t n_probe = std::min<int64_t>(8192, batch_capacity_for(c, J.recs[0].ref.len)); n_probe >= 32; n_probe /= 4) {
+      if (!walk_begin(c, J.recs[0].ref, 1, n_probe, -1)) return PBSIM_FAILED;
+      const int ok = pbsim_batch_walk_end(c, nullptr);
+      c->s().b_walked = false;
+      if (ok) break;
+      if (g_err.rfind("scratch budget exceeded", 0) != 0) return PBSIM_FAILED;
+    }
   }
   const double sf = scratch_factor_of(c);
   // ---- batch size: a few rounds per record and rank, not below what keeps a walk longer than its longest read
