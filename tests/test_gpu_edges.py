@@ -339,7 +339,8 @@ def test_rows_laid_out_tighter_than_two_lengths(case, factor, monkeypatch):
     for k, v in outs.items():
         assert harness.sha(v) == gold[k]["sha256"], (case, factor, k)
     assert state[0] == float(factor)
-    assert (state[2] > 0) == (factor == "1.02"), state
+    assert (state[2] > 0) == (state[1] > float(factor)), state      # walked twice exactly when a read needed more than its row
+    assert state[2] > 0 or factor != "1.02"
 
 
 def test_rows_follow_what_the_reads_need():
