@@ -523,7 +523,8 @@ struct PosFile {
   std::mutex mu;
   std::condition_variable cv;
   std::thread th;
-  bool started = false, finishing = false, failed = false;
+  bool started = false, finishing = false;
+  std::atomic<bool> failed{false};  // set by the file's thread, read by the callbacks
   void writer() {
     // The rank's threads are bound to its GPU's NUMA node (pbsim_bind_host_to_device): right for the delivery threads and their
     // pinned staging, wrong for the threads that fill the page cache -- with every file's pages coming out of one node's
