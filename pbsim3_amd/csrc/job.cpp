@@ -494,24 +494,6 @@ struct Job {
       const bool flush = deflated() && W > 1, plain = wants_text() && !deflated();
       // The per-task statistics are accounted HERE, on the main loop (it waits for the link most of the time), not on the
       // worker, whose time is the link's: rounds are completed in the order of the reads, so accuracy_total keeps its order.
-      // A job that leaves its text in HBM has it the other way round (round 4): nothing to wait for but the walks, an idle
-      // worker -- the loop spent 36-44 of 320 ms adding statistics -- so there the worker accounts, in the same FIFO order, and
-      // the tail chains' accounting goes through the same worker behind the record's rounds (tail_poll).
-      if (!wants_text()) {
-        std::atomic<int> *out = &rec_out[(size_t)d->rec];
-        ++*out;
-        worker.post([this, sl, Rp, slot, out]() {
-          const double w0 = now_us();
-          if (!account_of(c, *sl, &Rp->st)) worker_fail();
-          bd_worker_busy += now_us() - w0;
-          delivering[slot] = false;
-          delivered_one(out);
-        });
-        if (trace)
-          fprintf(stderr, "[pbsim job r%d] t=%.1f ms rec %d delivery: nothing to move, statistics handed to the worker\n", rank,
-                  (t0 - t_start) / 1e3, d->rec + 1);
-        return check_worker();
-      }
       acct_slot = sl;
       acct_rec = &R;
       if (!defer_account && !account_deferred()) return PBSIM_FAILED;
@@ -564,7 +546,7 @@ struct Job {
           // record whose last round's sizes are still pending), then a slot comes back from the chains' worker
           for (size_t o = 0; o < recs.size(); o++)
             if ((int)o != rec && recs[o].tail_slot >= 0 && !(pending && pending->rec == (int)o) && !tail_poll((int)o, true)) return PBSIM_FAILED;
-          (wants_text() ? tail_worker : worker).drain();
+          tail_worker.drain();
         }
         if (!tail_begin(R)) return PBSIM_FAILED;
         if (R.tail_waiting) return block ? fail("internal: no slot for the truncated reads") : PBSIM_SUCCEEDED;
@@ -585,7 +567,7 @@ struct Job {
       ++*out;
       // (the record's bulk rounds have been exchanged and accounted -- pending is not one of them --, so its byte offsets are
       // final and its statistics in read order when this runs)
-      (wants_text() ? tail_worker : worker).post([this, sl, Rp, slot, out]() {  // (no text: behind the record's rounds' accounting)
+      tail_worker.post([this, sl, Rp, slot, out]() {
         int ok = PBSIM_SUCCEEDED;
         int64_t nr = 0, nm = 0;
         if (wants_text() && hipEventSynchronize(sl->ev_text) != hipSuccess) ok = fail("hipEventSynchronize failed (text emission)");
