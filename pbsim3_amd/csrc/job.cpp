@@ -1248,11 +1248,16 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // many short kernels queued behind walk workgroups.  Since the loop no longer waits for text emission and statistics that
   // costs more than it gives: same-box A/B in round 3, whole job in HBM 180 -> 193 Gbases/s (ERRHMM) and 161 -> 172 G subread
   // bases/s (QSHMM x10) at the batch primitives' five per CU, delivered job unchanged -- profiles/r03_occupancy_ab.txt.)
-  // A job that compresses its output keeps three: the deflate workgroups need 35 KB of LDS each, and beside five walk
-  // workgroups per CU they found none -- configs[2], whose walks run most of the time, delivered 26 instead of 32 G subread
-  // bases/s (for configs[1], whose walks take a fifth of the time, it makes no difference either way).
+  // A job that compresses its output runs ONE lane-walk workgroup per CU (81 KB of LDS asked for; round 4).  The deflate
+  // workgroups need 35 KB of LDS each: beside five walk workgroups per CU they found none, beside three (41 KB, rounds 2-3) one
+  // per CU, beside one walk workgroup two -- and the lanes, which waited ~20 ms of every 78 ms round for their kernels, keep
+  // the link busier: configs[1] 47.6-48.0 -> 51.9-52.2 Gbases/s, configs[4] 48.8 -> 54.8, configs[2] 31.3 -> 33.3 (same-box
+  // A/B, profiles/r04_walk_occupancy_ab.txt).  The walk of a 5-Gbase round takes 29 instead of 17 ms and still hides behind the
+  // round's 75 ms of delivery.  Two walk workgroups per CU (54 KB) leave room for one deflate workgroup and gain nothing; 100 KB
+  // leave room for one and lose; fewer wave-walker workgroups, a high-priority stream for the lanes' kernels and CU masks for
+  // the walk streams (experiments) all lose or gain nothing.
   const int keep_lds = c->walk_lds_kb;
-  if (J.deflated()) c->walk_lds_kb = std::max(c->walk_lds_kb, 41);
+  if (J.deflated()) c->walk_lds_kb = std::max(c->walk_lds_kb, 81);
   c->defer_text_sync = true;  // the round loop does not wait for a round's text emission; the delivery thread does
   int ok = J.run();
   c->defer_text_sync = false;
