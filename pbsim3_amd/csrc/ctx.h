@@ -326,7 +326,6 @@ struct pbsim_ctx {
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
   hipStream_t df_streams[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [lane][kernels | copies]
   bool defer_text_sync = false;  // finalize_text returns once the sizes are known; the text emission is still in flight (job pipeline)
-  int walk_persistent = 0;     // > 0: the lane walk as that many workgroups that draw their blocks from a counter (job.cpp: 256 for jobs that compress)
   int walk_lds_kb = 27;        // walk workgroups per CU: 27 KB -> five (batch primitives), 41 KB -> three (the job pipeline)
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
   int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)

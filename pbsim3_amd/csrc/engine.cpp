@@ -793,10 +793,10 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
       // leaves the lane walker nothing to do: no empty launch, and the kernel's profile holds its bulk launches only)
       const bool lanes_idle = coop_len == 0 && s.coop_classes == (ncls >= 64 ? ~0ull : (1ull << ncls) - 1);
       if (!lanes_idle)
-        launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb, chain ? 0 : c->walk_persistent);
+        launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
       if (cs != ws) HIP_OK(hipStreamWaitEvent(ws, c->s().ev_coop, 0));
     } else {
-      launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb, chain ? 0 : c->walk_persistent);
+      launch_walk_errhmm(w, slots_max, c->ect.stride + 512 + 1024, c->ect.all_rv_1000, ref.hp_flag, ws, c->walk_lds_kb);
     }
   } else {
     w.stride = c->qct.stride;
@@ -822,11 +822,11 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
       lanes_idle = coop_len == 0 && s.coop_classes == (ncls >= 64 ? ~0ull : (1ull << ncls) - 1);
       if (!lanes_idle)
         launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8 + 94 * 32, c->qct.all_rv_100,
-                          ref.hp_flag, ws, c->walk_lds_kb, chain ? 0 : c->walk_persistent);
+                          ref.hp_flag, ws, c->walk_lds_kb);
       if (cs != ws) HIP_OK(hipStreamWaitEvent(ws, c->s().ev_coop, 0));
     } else {
       launch_walk_qshmm(w, slots_max, c->qct.stride + 1536 + 96 * 8 + 94 * 48 + 94 * 8 + 94 * 32, c->qct.all_rv_100,
-                        ref.hp_flag, ws, c->walk_lds_kb, chain ? 0 : c->walk_persistent);
+                        ref.hp_flag, ws, c->walk_lds_kb);
     }
     (void)lanes_idle;
   }

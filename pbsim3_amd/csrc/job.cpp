@@ -1256,16 +1256,12 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // round's 75 ms of delivery.  Two walk workgroups per CU (54 KB) leave room for one deflate workgroup and gain nothing; 100 KB
   // leave room for one and lose; fewer wave-walker workgroups, a high-priority stream for the lanes' kernels and CU masks for
   // the walk streams (experiments) all lose or gain nothing.
-  const int keep_lds = c->walk_lds_kb, keep_persist = c->walk_persistent;
-  if (J.deflated()) {
-    c->walk_lds_kb = std::max(c->walk_lds_kb, 81);
-    if (const char *wp = getenv("PBSIM_WALK_PERSIST")) c->walk_persistent = atoi(wp);  // experiment: n workgroups draw the blocks
-  }
+  const int keep_lds = c->walk_lds_kb;
+  if (J.deflated()) c->walk_lds_kb = std::max(c->walk_lds_kb, 81);
   c->defer_text_sync = true;  // the round loop does not wait for a round's text emission; the delivery thread does
   int ok = J.run();
   c->defer_text_sync = false;
   c->walk_lds_kb = keep_lds;
-  c->walk_persistent = keep_persist;
   for (Slot &sl : c->slots)  // text left in HBM (no sink): its emission ends with the job
     if (sl.stream && hipStreamSynchronize(sl.stream) != hipSuccess && ok) ok = fail("hipStreamSynchronize failed at the end of the job");
   if (!ok) {

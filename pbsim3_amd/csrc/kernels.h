@@ -40,7 +40,7 @@ struct DeviceFlags {
                           // [3] bases all passes (final reads), [4] ref bases, [5] maf columns
   unsigned long long hpfreq[12];
   uint32_t need_q10;      // walks: max over the tasks of (MAF columns - pad) / length, in 1/1024 (note_row_need)
-  int32_t walk_ticket;    // persistent lane walk: next block of 256 slots to draw (WalkArgs::persistent)
+  uint32_t pad_;
 };
 
 struct RefView {
@@ -129,7 +129,6 @@ struct WalkArgs {
   int32_t coop_min_len;      // errhmm: reads of at least this length belong to k_walk_errhmm_coop (a multiple of 256; INT32_MAX: none)
   int32_t coop_dynamic;         // k_walk_errhmm_coop: units drawn from a counter (flags->sums[7]) instead of dealt round-robin
   int32_t cap_q8;               // SortArgs::cap_q8 of the batch's layout (the walks' priority heuristic reads lengths off the caps)
-  int32_t persistent, n_walk_wg; // lane walk: a fixed grid draws the n_walk_wg blocks from DeviceFlags::walk_ticket (set by the launch)
   const int32_t *coop_end;   // [ncls] their slots are class_start[c] .. coop_end[c]
   const int32_t *wave_cap;
   const int64_t *wave_off;
@@ -220,10 +219,8 @@ void launch_chain_prepare(const HeaderArgs &a, int k, int32_t pass_num, const in
 void launch_chain_update(int k, int32_t pass_num, const int32_t *out_len, ChainState *chain, hipStream_t s);
 void launch_chain_init(ChainState *chain, int64_t remaining, hipStream_t s);
 // min_lds_kb: LDS to ask for at least, i.e. a cap on the walk's workgroups per CU (kernels.hip walk_lds)
-// persistent_wgs > 0: that many workgroups draw the batch's blocks from a counter and ask for no more LDS than they need
-// (min_lds_kb is then ignored); the counter is the batch's: one such launch per batch
 void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                        hipStream_t s, int min_lds_kb, int persistent_wgs = 0);
+                        hipStream_t s, int min_lds_kb);
 // the long reads of the batch (WalkArgs::coop_min_len), one wave per read; `n_wg` persistent workgroups; `lds_bytes` = the
 // lane walk's (class blob + byte tables), the waves' own areas are added here.  Classes of at most kCoopMaxStates states.
 constexpr int kCoopMaxStates = 31;
@@ -237,7 +234,7 @@ void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bo
 constexpr int kQCoopMaxStates = 63;
 void launch_walk_qshmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, hipStream_t s);
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                       hipStream_t s, int min_lds_kb, int persistent_wgs = 0);
+                       hipStream_t s, int min_lds_kb);
 void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s);
 void launch_sample_qsum(const SampleArgs &a, hipStream_t s);  // the ordered quality sums of the wave-walked reads
 // exclusive scan of int64 (in-place allowed: out may equal in); tmp needs (n/1024+2) int64

@@ -878,9 +878,10 @@ struct StepOut {
 // kHpBits: --hp-del-bias 1 (default): the deletion threshold depends on hp only through
 // hp == 11 (Q1), so the walk reads the 1-bit-per-base mask instead of the hp byte array.
 template <bool kFastRv, bool kHpBits>
-__device__ __forceinline__ void walk_errhmm_block(const WalkArgs &a, uint8_t *lds, int wg) {
+__global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
-  const int64_t slot0 = (int64_t)a.wg_order[wg] * kWG;
+  const int64_t slot0 = (int64_t)a.wg_order[blockIdx.x] * kWG;
   if (slot0 >= a.flags->total_slots) return;
   if (a.flags->error & kErrScratchBudget) return;  // the pool cannot hold this batch: the host retries smaller
   int cls = 0;
@@ -1019,28 +1020,6 @@ __device__ __forceinline__ void walk_errhmm_block(const WalkArgs &a, uint8_t *ld
     a.nins[task] = m - ro;  // every column consumes a reference base except insertions
     a.ndel[task] = m - q;   // every column emits a read base except deletions
     note_row_need(a.flags, m, L);
-  }
-}
-
-// The lane walk's kernel: one workgroup per block of 256 slots, longest reads first (wg_order) -- or, a.persistent, a fixed number
-// of workgroups that draw their blocks from a counter: a job that compresses its output wants ONE walk workgroup per CU and
-// the rest of the CU's LDS for its deflate workgroups (35 KB each); padding the walk's LDS to 81 KB forces the one (round 4:
-// configs[1] 48 -> 52 Gbases/s) but throws 50 KB per CU away, a grid of 256 workgroups that ask for what they need leaves them.
-template <bool kFastRv, bool kHpBits>
-__global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  if (!a.persistent) {
-    walk_errhmm_block<kFastRv, kHpBits>(a, lds, (int)blockIdx.x);
-    return;
-  }
-  __shared__ int s_next;
-  for (;;) {
-    __syncthreads();  // every wave is through with the block before (its class tables in LDS, s_next)
-    if (threadIdx.x == 0) s_next = atomicAdd(&a.flags->walk_ticket, 1);
-    __syncthreads();
-    const int wg = s_next;
-    if (wg >= a.n_walk_wg) break;
-    walk_errhmm_block<kFastRv, kHpBits>(a, lds, wg);
   }
 }
 
@@ -1340,9 +1319,10 @@ __global__ __launch_bounds__(kCoopWaves * 64) void k_walk_errhmm_coop(WalkArgs a
 // ---------------------------------------------------------------------------
 // kFastRv: every init / transition / emission modulus of the class is 100.
 template <bool kFastRv, bool kHpBits>
-__device__ __forceinline__ void walk_qshmm_block(const WalkArgs &a, uint8_t *lds, int wg) {
+__global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
-  const int64_t slot0 = (int64_t)a.wg_order[wg] * kWG;
+  const int64_t slot0 = (int64_t)a.wg_order[blockIdx.x] * kWG;
   if (slot0 >= a.flags->total_slots) return;
   if (a.flags->error & kErrScratchBudget) return;  // the pool cannot hold this batch: the host retries smaller
   int cls = 0;
@@ -1544,28 +1524,6 @@ __device__ __forceinline__ void walk_qshmm_block(const WalkArgs &a, uint8_t *lds
 // threshold and ~2 % below every one: a wrong state in front of a column rarely flips it).  The ordered f64 sum of error
 // probabilities (pbsim.cpp:2309-2313; the %f report and the accuracy histogram depend on its exact value) is added lane by
 // lane in column order.  kFastRv && kHpBits classes with a model only; everything else stays with the lane walker.
-// The lane walk's kernel: one workgroup per block of 256 slots, longest reads first (wg_order) -- or, a.persistent, a fixed number
-// of workgroups that draw their blocks from a counter: a job that compresses its output wants ONE walk workgroup per CU and
-// the rest of the CU's LDS for its deflate workgroups (35 KB each); padding the walk's LDS to 81 KB forces the one (round 4:
-// configs[1] 48 -> 52 Gbases/s) but throws 50 KB per CU away, a grid of 256 workgroups that ask for what they need leaves them.
-template <bool kFastRv, bool kHpBits>
-__global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  if (!a.persistent) {
-    walk_qshmm_block<kFastRv, kHpBits>(a, lds, (int)blockIdx.x);
-    return;
-  }
-  __shared__ int s_next;
-  for (;;) {
-    __syncthreads();  // every wave is through with the block before (its class tables in LDS, s_next)
-    if (threadIdx.x == 0) s_next = atomicAdd(&a.flags->walk_ticket, 1);
-    __syncthreads();
-    const int wg = s_next;
-    if (wg >= a.n_walk_wg) break;
-    walk_qshmm_block<kFastRv, kHpBits>(a, lds, wg);
-  }
-}
-
 // ---------------------------------------------------------------------------
 constexpr int kQCoopX = 0, kQCoopEnd = 128, kQCoopStates = 640, kQCoopRows = 704, kQCoopWaveLds = 896;
 
@@ -3113,13 +3071,10 @@ static uint32_t walk_lds(uint32_t lds_bytes, int min_lds_kb) {
   return lds_bytes > pad ? lds_bytes : pad;
 }
 
-void launch_walk_errhmm(const WalkArgs &a_in, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                        hipStream_t s, int min_lds_kb, int persistent_wgs) {
-  WalkArgs a = a_in;
-  a.n_walk_wg = (int32_t)(n_slots_max / kWG);
-  a.persistent = persistent_wgs > 0 && a.n_walk_wg > persistent_wgs;
-  lds_bytes = walk_lds(lds_bytes, a.persistent ? 0 : min_lds_kb);
-  const dim3 grid((unsigned)(a.persistent ? persistent_wgs : a.n_walk_wg)), block(kWG);
+void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
+                        hipStream_t s, int min_lds_kb) {
+  lds_bytes = walk_lds(lds_bytes, min_lds_kb);
+  const dim3 grid((unsigned)(n_slots_max / kWG)), block(kWG);
   if (fast_rv && hp_bits) hipLaunchKernelGGL((k_walk_errhmm<true, true>), grid, block, lds_bytes, s, a);
   else if (fast_rv) hipLaunchKernelGGL((k_walk_errhmm<true, false>), grid, block, lds_bytes, s, a);
   else if (hp_bits) hipLaunchKernelGGL((k_walk_errhmm<false, true>), grid, block, lds_bytes, s, a);
@@ -3139,13 +3094,10 @@ void launch_walk_qshmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, hip
   hipLaunchKernelGGL(k_walk_qshmm_coop, grid, block, lds_bytes, s, a);
 }
 
-void launch_walk_qshmm(const WalkArgs &a_in, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
-                       hipStream_t s, int min_lds_kb, int persistent_wgs) {
-  WalkArgs a = a_in;
-  a.n_walk_wg = (int32_t)(n_slots_max / kWG);
-  a.persistent = persistent_wgs > 0 && a.n_walk_wg > persistent_wgs;
-  lds_bytes = walk_lds(lds_bytes, a.persistent ? 0 : min_lds_kb);
-  const dim3 grid((unsigned)(a.persistent ? persistent_wgs : a.n_walk_wg)), block(kWG);
+void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
+                       hipStream_t s, int min_lds_kb) {
+  lds_bytes = walk_lds(lds_bytes, min_lds_kb);
+  const dim3 grid((unsigned)(n_slots_max / kWG)), block(kWG);
   if (fast_rv && hp_bits) hipLaunchKernelGGL((k_walk_qshmm<true, true>), grid, block, lds_bytes, s, a);
   else if (fast_rv) hipLaunchKernelGGL((k_walk_qshmm<true, false>), grid, block, lds_bytes, s, a);
   else if (hp_bits) hipLaunchKernelGGL((k_walk_qshmm<false, true>), grid, block, lds_bytes, s, a);
