@@ -2,8 +2,9 @@
 # usage (GPU box, repo root): tools/pmc_round.sh TAG   -> gpurun_out/TAG_walk_pmc.json (+ the raw per-pass summaries)
 # The round's counter evidence for the two ERRHMM walk kernels, each counter set in its own rocprofv3 run
 # with --kernel-trace only (the pool refuses --pmc beside the other trace domains):
-#   k_walk_errhmm        lane walker, one launch at a time (tools/walk_solo.py), at the delivered job's occupancy (three
-#                        workgroups per CU, PBSIM_WALK_LDS_KB=41) and at the batch primitives' / HBM-only job's (five)
+#   k_walk_errhmm        lane walker, one launch at a time (tools/walk_solo.py), at the delivered job's occupancy (ONE workgroup
+#                        per CU, PBSIM_WALK_LDS_KB=81, since the second half of round 4; three, =41, before) and at the batch
+#                        primitives' / HBM-only job's (five)
 #   k_walk_errhmm_coop   wave walker with every read of a 100 000-read batch (PBSIM_COOP_LEN=0), 1024 persistent workgroups
 #   fetch_calib          FETCH_SIZE / WRITE_SIZE against byte counts known by construction (tools/fetch_calib.hip)
 tag=$1
@@ -29,6 +30,7 @@ run_set() {  # run_set NAME -- env settings are exported by the caller
   pass ${name}_write "WRITE_SIZE" python3 $R/tools/walk_solo.py "$@"
 }
 export PBSIM_COOP_LEN=-1
+PBSIM_WALK_LDS_KB=81 run_set lane1 errhmm 2
 PBSIM_WALK_LDS_KB=41 run_set lane3 errhmm 2
 run_set lane5 errhmm 2
 export PBSIM_COOP_LEN=0
