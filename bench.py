@@ -537,13 +537,23 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        ctx.prof_reset()
         t1 = time.perf_counter()
         run_job(False)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        extras["whole_job_hbm"] = {"value": job_bases / (time.perf_counter() - t1), "unit": "bases/s",
-                                   "note": "the same job, FASTQ + MAF text left in HBM (no compression, no copy)"}
+        dt_hbm = time.perf_counter() - t1
+        w2_ms, w2_launches, _ = ctx.prof_get()
+        c2 = ctx.job_counters()
+        alg2 = c2["ref_bases"] + 2 * c2["bases"] + 2 * c2["maf_columns"]
+        extras["whole_job_hbm"] = {"value": job_bases / dt_hbm, "unit": "bases/s",
+                                   "note": "the same job, FASTQ + MAF text left in HBM (no compression, no copy)",
+                                   "walk": {"avg_launch_ms": w2_ms / max(1, w2_launches), "launches": w2_launches,
+                                            "achieved": alg2 / (w2_ms / 1e3) / 1e9 if w2_ms > 0 else None,
+                                            "frac": alg2 / (w2_ms / 1e3) / 1e9 / HBM_PEAK_GBS if w2_ms > 0 else None,
+                                            "note": "the walk kernel in THIS job (five workgroups per CU, three rounds in flight), HIP events as in "
+                                                    "`roofline`: the delivered job above runs the same kernel at ONE workgroup per CU on purpose"}}
 
     replays = None
     if a.replay_ranks and world == 1:
@@ -615,6 +625,11 @@ def main():
                          "tail_read_launches": {"launches": tail_launches, "avg_ms": tail_ms / max(1, tail_launches),
                                                 "note": "walk launches that carry one truncated tail read (the latency of a single "
                                                         "read; the wave walker k_walk_errhmm_coop takes ERRHMM ones): counted apart from the launches above"},
+                         "occupancy_note": ("a job that compresses its output runs the lane walk at ONE workgroup per CU (81 KB of LDS asked for) so that two "
+                                            "deflate workgroups fit beside it: the job is 9-12 % faster that way (profiles/r04_walk_occupancy_ab.txt) and this "
+                                            "kernel's launches last 1.7x longer -- off the critical path, behind the round's delivery.  The same kernel at five "
+                                            "workgroups per CU: whole_job_hbm.walk and steady_state_hbm.walk in this line (live), 0.18 alone "
+                                            "(profiles/*_walk_solo.txt)") if deliver else None,
                          "note": "achieved = algorithmic bytes of the path (SURVEY 8d: 1 ref + 2 read + 2 quality... per base) of rank 0's "
                                  "delivered reads / summed duration of its walk launches (a launch = the lane walker + the wave walker of the batch's long reads beside it; HIP events on the walk streams, every launch of "
                                  "the timed region incl. tail reads); walks of different slots overlap, so walk_busy counts that time once",
