@@ -137,7 +137,6 @@ struct Delivery {
   int64_t sizes[2] = {0, 0};
   std::vector<int64_t> B;   // gather B of the round
   int cut = -1;
-  Worker *wk = nullptr;     // the worker that runs its stages
 };
 
 struct Job {
@@ -155,19 +154,12 @@ struct Job {
   // where the round loop's wall time goes (pbsim_job_breakdown), microseconds
   double bd_wait_walk = 0, bd_finalize = 0, bd_wait_bytes = 0, bd_account = 0, bd_tail_block = 0, bd_drain = 0, bd_slot_wait = 0,
          bd_merge = 0, bd_begin = 0, bd_tail_steps = 0;
-  std::atomic<int64_t> bd_worker_busy_us{0};  // added to by the delivery workers, read after they have finished
-  int64_t n_topup = 0, n_tail_reads = 0, rounds_popped = 0;
+  double bd_worker_busy = 0;  // written by the worker thread only, read after it has finished
+  int64_t n_topup = 0, n_tail_reads = 0;
   bool trace = false;
   double t_start = 0;
   bool peer_failed = false;   // the failure came from another rank's status word (no need to abort the communicator)
   Worker worker;
-  // Several ranks that compress (round 4): a round's stage 1 fills a page-locked arena and calls nobody, so the NEXT round's
-  // stage 1 may start while this round's last pieces are still being copied -- on a second worker, its kernels and copies
-  // queue behind this round's in the lanes' streams -- instead of after them: a rank of eight has a round every 30-40 ms and
-  // lost 2-3 ms of link time between two of them.  (One rank streams its members to the sink in stage 1, at offsets that
-  // need the round before: one worker, one round at a time.)
-  Worker worker2;
-  bool two_workers() const { return W > 1 && deflated(); }
   // The chains of truncated tail reads deliver their few KB through a worker of their own: behind the bulk worker's FIFO a
   // record's tail bytes -- and with them the record's merge, which the main loop waits for -- queued behind the 30-40 ms
   // deliveries of the NEXT record's rounds (measured per rank of eight: 3 x 32 ms of a 195 ms job, profiles/r04_replay_*).
@@ -290,7 +282,6 @@ struct Job {
   }
   void drop_everything() {
     worker.drain();
-    worker2.drain();
     tail_worker.drain();
     for (const Round &r : fifo) drop_round(r);
     fifo.clear();
@@ -428,7 +419,7 @@ struct Job {
     const int64_t read_at = R->read_off, maf_at = R->maf_off;  // one rank: the offsets simply run up (streamed in stage 1)
     std::atomic<int> *out = &rec_out[(size_t)d->rec];
     ++*out;
-    d->wk->post([this, sl, R, prom, sizes, read_at, maf_at, out]() {
+    worker.post([this, sl, R, prom, sizes, read_at, maf_at, out]() {
       const double w0 = now_us();
       int ok = PBSIM_SUCCEEDED;
       if (wants_text() && hipEventSynchronize(sl->ev_text) != hipSuccess) ok = fail("hipEventSynchronize failed (text emission)");
@@ -445,7 +436,7 @@ struct Job {
         ok = arena_fill(*sl, &sizes[0], &sizes[1]);
       }
       if (!ok) worker_fail();
-      bd_worker_busy_us += (int64_t)(now_us() - w0);
+      bd_worker_busy += now_us() - w0;
       if (trace)
         fprintf(stderr, "[pbsim job r%d] t=%.1f ms   worker: bytes of rec %lld on their way for %.1f ms (%lld + %lld)\n", rank,
                 (w0 - t_start) / 1e3, (long long)R->ref.unit, (now_us() - w0) / 1e3, (long long)sizes[0], (long long)sizes[1]);
@@ -509,7 +500,7 @@ struct Job {
       if (flush || plain) {
         std::atomic<int> *out = &rec_out[(size_t)d->rec];
         ++*out;
-        d->wk->post([this, sl, Rp, slot, flush, read_at, maf_at, out]() {
+        worker.post([this, sl, Rp, slot, flush, read_at, maf_at, out]() {
           const int ok = flush ? arena_flush(*sl, Rp->ref.unit, read_at, maf_at) : sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
           if (!ok) worker_fail();
           delivering[slot] = false;
@@ -760,16 +751,13 @@ struct Job {
     const bool mine = rank <= last_valid && bi.n_final > 0;
     // ---- delivery: the previous round's sizes first (its bytes have been on their way while this round was finalised), then
     // this round's bytes start moving
-    std::unique_ptr<Delivery> nd(new Delivery);
-    nd->slot = rd.slot;
-    nd->rec = rd.rec;
-    nd->mine = mine;
-    nd->n_per = rd.n_per;
-    nd->wk = (two_workers() && (rounds_popped++ & 1)) ? &worker2 : &worker;
-    if (two_workers()) submit_stage1(nd.get());  // (beside the round before, whose bytes are still on their way)
     if (!complete_pending(true)) return PBSIM_FAILED;
-    if (!two_workers()) submit_stage1(nd.get());
-    pending = std::move(nd);
+    pending.reset(new Delivery);
+    pending->slot = rd.slot;
+    pending->rec = rd.rec;
+    pending->mine = mine;
+    pending->n_per = rd.n_per;
+    submit_stage1(pending.get());
     if (!account_deferred()) return PBSIM_FAILED;  // the previous round's statistics, while the worker moves this round's bytes
     if (mine) {
       reads_delivered += bi.n_final;
@@ -824,7 +812,6 @@ struct Job {
     const int n = (int)recs.size();
     int merged = 0;
     worker.start(c->device);
-    if (two_workers()) worker2.start(c->device);
     tail_worker.start(c->device);
     for (;;) {
       if (!check_worker()) return PBSIM_FAILED;
@@ -890,7 +877,6 @@ struct Job {
     }
     if (!complete_pending()) return PBSIM_FAILED;
     worker.finish();
-    worker2.finish();
     tail_worker.finish();
     return check_worker();
   }
@@ -1287,7 +1273,6 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     *settled = true;
     J.drop_everything();
     J.worker.finish();
-    J.worker2.finish();
     J.tail_worker.finish();
     g_err = keep;
   }
@@ -1308,7 +1293,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     b[9] = J.bd_merge;
     b[10] = J.bd_begin;
     b[11] = J.bd_tail_steps;
-    b[12] = (double)J.bd_worker_busy_us.load();
+    b[12] = J.bd_worker_busy;
     b[13] = (double)J.n_topup;
     b[14] = (double)J.n_tail_reads;
     b[15] = (double)J.depth;
