@@ -1055,22 +1055,25 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// LDS of one wave of the wave walker: x[64] u16 | end states [8 groups][32 start states] | states[64] | two output rows
-constexpr int kCoopX = 0, kCoopEnd = 128, kCoopStates = 384, kCoopRows = 448, kCoopWaveLds = 576;
+// LDS of one wave of the wave walker: reference window [128] | its homopolymer lengths [128] | x[64] u16 |
+// the true chains' states [8 groups][4 chains][8] | two output rows
+constexpr int kCoopWin = 0, kCoopHp = 128, kCoopX = 256, kCoopStates = 384, kCoopRows = 640, kCoopWaveLds = 768;
 static_assert(kCoopMaxStates == 31, "four chains of eight start states per lane");  // the shipped models have <= 29 states
 
 // States of the 64 columns: lane i receives the state after column i, given the state `s_in` in front of column 0.
 // The chain state[i] = tran[state[i - 1]][x[i]] is serial, so it is cut into eight groups of eight columns:
 //   A. lane (g, j) walks group g from the start states j, j + 8, j + 16, j + 24 (every state the group could start from),
 //      four independent chains of eight LDS lookups, and keeps the states they pass through;
-//   B. the groups' true start states follow from the end states of A, eight dependent lookups;
-//   C. the lane that walked group g from its true start state hands the eight states to the group's lanes.
+//   B. the groups' true start states follow from the end states of A: eight dependent steps on the SCALAR unit (the end
+//      states stay in a register, a step is one v_readlane and a few s_ instructions -- through LDS the eight dependent
+//      reads were a fifth of the step's vector instructions and most of its latency);
+//   C. the lane that walked group g from its true start state hands its chains to LDS, the group's lanes pick their column.
 // `qz`: columns that start from the initial-state table (row 0 of the transition table) whatever the state in front.
 template <bool kInit>
 __device__ __forceinline__ uint32_t coop_chain(const uint8_t *lds, uint32_t init_off, uint32_t smax, uint32_t reach, uint8_t *s_w,
                                                uint32_t x, uint64_t qz, uint32_t s_in, int lane) {
   uint16_t *s_x = reinterpret_cast<uint16_t *>(s_w + kCoopX);
-  uint8_t *s_end = s_w + kCoopEnd, *s_st = s_w + kCoopStates;
+  uint8_t *s_st = s_w + kCoopStates;
   const int g = lane >> 3, j = lane & 7;
   wave_sync();
   s_x[lane] = (uint16_t)x;
@@ -1097,24 +1100,27 @@ __device__ __forceinline__ uint32_t coop_chain(const uint8_t *lds, uint32_t init
         else hi[k] |= st[k] << (8 * (t - 4));
       }
     }
-    s_end[g * 32 + j + 8 * k0] = (uint8_t)st[k0];
-    s_end[g * 32 + j + 8 * k0 + 8] = (uint8_t)st[k0 + 1];
   };
   walk_pair(0);
-  if (reach > 15u) walk_pair(2);  // most classes have fewer than sixteen states: half the work
-  wave_sync();
-  uint32_t s = s_in, sg = 0;
+  const bool wide = reach > 15u;  // most classes have fewer than sixteen states: half the work
+  if (wide) walk_pair(2);
+  // byte k = the state chain k ends in
+  const uint32_t ends = __builtin_amdgcn_perm(hi[1], hi[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(hi[3], hi[2], 0x0c0c0703u) << 16);
+  uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_in);
+  uint64_t starts = 0;  // byte gg = the state in front of group gg
 #pragma unroll
   for (int gg = 0; gg < 8; gg++) {
-    sg = (g == gg) ? s : sg;
-    s = s_end[gg * 32 + s];
+    starts |= (uint64_t)s << (8 * gg);
+    const uint32_t e4 = (uint32_t)__builtin_amdgcn_readlane((int)ends, (int)(gg * 8 + (s & 7u)));
+    s = (e4 >> ((s >> 3) * 8u)) & 0xffu;
   }
-  const uint32_t k = sg >> 3;
-  const uint32_t plo = k == 0 ? lo[0] : k == 1 ? lo[1] : k == 2 ? lo[2] : lo[3];
-  const uint32_t phi = k == 0 ? hi[0] : k == 1 ? hi[1] : k == 2 ? hi[2] : hi[3];
-  if ((uint32_t)j == (sg & 7u)) *reinterpret_cast<uint2 *>(s_st + g * 8) = make_uint2(plo, phi);
+  const uint32_t sg = (uint32_t)(starts >> (8 * g)) & 0xffu;
+  if ((uint32_t)j == (sg & 7u)) {
+    *reinterpret_cast<uint4 *>(s_st + g * 32) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+    if (wide) *reinterpret_cast<uint4 *>(s_st + g * 32 + 16) = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+  }
   wave_sync();
-  return s_st[lane];
+  return s_st[g * 32 + j + (sg & 0x18u)];
 }
 
 template <bool kHpBits>
@@ -1137,24 +1143,44 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
   // a block of wave-walked tasks only keeps each task's rows contiguous (kWaveTransposed); in the one block per class that
   // also holds lane-walked tasks the rows are interleaved dword by dword
   const bool transposed = (cap_raw & kWaveTransposed) != 0;
-  const size_t row_step = transposed ? 1 : 64;
+  const uint32_t row_step = transposed ? 1u : 64u;
   uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + (transposed ? (size_t)(slot & 63) * cap_dw : (size_t)(slot & 63));
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
+  const uint32_t lane_dw = (uint32_t)lane * row_step;  // the lane's dword of a step's sixteen, from the step's first
   const int cap = cap_dw * 4;  // columns the task's rows hold (k_wave_cap)
   const uint32_t comp_off = minus ? 256u : 0u;
-  const int64_t p_first = minus ? (off + L - 1) : off;
   const int64_t p_last = a.ref.len - 1;
+  int64_t p_first = minus ? (off + L - 1) : off;
+  p_first = p_first < 0 ? 0 : (p_first > p_last ? p_last : p_first);
 
-  // reference window in read coordinates: lane j holds the bytes at wb + j and wb + 64 + j
-  int wb = 0;
+  // the reference under the cursor: read coordinate t is record position p_first +- t, held at the record's ends.  A window
+  // of 128 bases from `wb` lies in LDS (s_win, with the homopolymer lengths beside it where the record has no flag bits), the
+  // 64 behind it are on their way in `nxt`: a load has a whole step to arrive
+  const int64_t room = minus ? p_first : p_last - p_first;
+  const uint32_t tmax = (uint32_t)(room > 0x7fffffff ? 0x7fffffff : (room < 0 ? 0 : room));
+  const int64_t p0 = minus ? p_first - (int64_t)tmax : p_first;
+  const uint8_t *seq0 = a.ref.seq + p0;
+  const uint8_t *hp0 = kHpBits ? nullptr : a.ref.hp + p0;
   auto ref_at = [&](int t, uint32_t *hpv) -> uint32_t {
-    int64_t p = minus ? (p_first - t) : (p_first + t);
-    p = p < 0 ? 0 : (p > p_last ? p_last : p);
-    if (!kHpBits) *hpv = a.ref.hp[p];
-    return a.ref.seq[p];
+    const uint32_t tc = (uint32_t)t < tmax ? (uint32_t)t : tmax;
+    const uint32_t o = minus ? tmax - tc : tc;
+    if (!kHpBits) *hpv = hp0[o];
+    return seq0[o];
   };
-  uint32_t hp_a = 0, hp_b = 0;
-  uint32_t win_a = ref_at(lane, &hp_a), win_b = ref_at(64 + lane, &hp_b);
+  uint8_t *s_win = s_w + kCoopWin, *s_hp = s_w + kCoopHp;
+  int wb = 0;
+  uint32_t nxt_hp = 0, h0 = 0, h1 = 0;
+  const uint32_t b0 = ref_at(lane, &h0), b1 = ref_at(64 + lane, &h1);
+  uint32_t nxt = ref_at(128 + lane, &nxt_hp);
+  wave_sync();
+  s_win[lane] = (uint8_t)b0;
+  s_win[64 + lane] = (uint8_t)b1;
+  if (!kHpBits) {
+    s_hp[lane] = (uint8_t)h0;
+    s_hp[64 + lane] = (uint8_t)h1;
+  }
+  wave_sync();
+  const uint32_t win_off = (uint32_t)(s_win - lds);
 
   int m0 = 0, ro0 = 0, q0 = 0, nsub = 0;
   uint32_t st_in = 0;
@@ -1170,8 +1196,12 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
       have_v = true;
     }
     uint64_t qz = (q0 == 0) ? 1ull : 0ull;
+    const uint64_t in_cap = __ballot(event < (uint32_t)cap);
+    // the lane's index into lds[] for the first base of the window, less the bases consumed in front of the step
+    const uint32_t idx0 = win_off + (uint32_t)(ro0 - wb);
+    const uint32_t idx_end = win_off + (uint32_t)(L - wb);  // roi < L
     uint32_t st, e, raw = 0;
-    uint64_t valid;
+    uint64_t valid, nonins;
     for (;;) {
       st = (q0 == 0) ? coop_chain<true>(lds, a.init_off, smax, reach, s_w, x, qz, st_in, lane)
                      : coop_chain<false>(lds, a.init_off, smax, reach, s_w, x, 0ull, st_in, lane);
@@ -1189,30 +1219,33 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
         if (ce != 0 && redraw) e_keep = 0;
         if (redraw) e_del = 0;
       }
-      e = e_keep;
+      // the turns below only move masks: a column consumes a reference base unless it is an insertion that is not deleted
+      // (e_del is never 2), and whether it is deleted depends on the base under its cursor through one of two thresholds
+      const uint64_t keep_nonins = __ballot(e_keep != 2u);
+      uint64_t del_lo = 0, del_hi = 0;
+      if (kHpBits) {
+        del_lo = __ballot(y1 <= (em.w & 0xffffu));
+        del_hi = __ballot(y1 <= (em.w >> 16));
+      }
+      nonins = keep_nonins;
+      uint64_t del;
       for (;;) {
-        const uint64_t nonins = __ballot(e != 2u);
-        const int roi = ro0 + (int)mbcnt64(nonins);
-        const int wi = roi - wb;  // 0 .. 127 for the columns that count
-        const uint32_t va = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)win_a);
-        const uint32_t vb = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)win_b);
-        raw = (wi & 64) ? vb : va;
-        uint32_t thr;
+        const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(nonins >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nonins, idx0));
+        raw = lds[idx];
         if (kHpBits) {
-          thr = __builtin_amdgcn_ubfe(em.w, (raw >> 3) & 16u, 16u);
+          const uint64_t in_hp = __ballot(raw > 127u);
+          del = (in_hp & del_hi) | (~in_hp & del_lo);
         } else {
-          const uint32_t ha = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)hp_a);
-          const uint32_t hb = (uint32_t)__builtin_amdgcn_ds_bpermute((wi & 63) << 2, (int)hp_b);
-          const uint32_t hp = (wi & 64) ? hb : ha;
-          thr = row[4 + (hp < 12u ? hp : 11u)];
+          const uint32_t hp = lds[idx + (uint32_t)(kCoopHp - kCoopWin)];
+          del = __ballot(y1 <= row[4 + (hp < 12u ? hp : 11u)]);
         }
-        const uint32_t en = (y1 <= thr) ? e_del : e_keep;
-        const bool counts = roi < L && m0 + lane < cap;
-        valid = __ballot(counts);
-        const uint64_t moved = __ballot(counts && ((en != 2u) != (e != 2u)));
-        e = en;
+        valid = __ballot(idx < idx_end) & in_cap;
+        const uint64_t now = keep_nonins | del;
+        const uint64_t moved = (now ^ nonins) & valid;
+        nonins = now;
         if (!moved) break;
       }
+      e = ((del >> lane) & 1ull) ? e_del : e_keep;
       if (q0 != 0) break;
       // Q2: the columns up to and including the first one that emits a base start from the initial-state table
       const uint64_t emits = __ballot(e != 3u) & valid;
@@ -1239,21 +1272,30 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
     if (lane * 4 < nv) {
       const uint32_t dr = reinterpret_cast<const uint32_t *>(s_tr)[lane];
       const uint32_t df = reinterpret_cast<const uint32_t *>(s_tr + 64)[lane];
-      scratch_store(&maf_read[(size_t)((m0 >> 2) + lane) * row_step], dr);
-      scratch_store(&maf_ref[(size_t)((m0 >> 2) + lane) * row_step], df);
+      const size_t step_dw = (size_t)(m0 >> 2) * row_step;  // the wave's part of the address; the lane's is lane_dw
+      scratch_store(maf_read + step_dw + lane_dw, dr);
+      scratch_store(maf_ref + step_dw + lane_dw, df);
     }
 #endif
     nsub += __builtin_popcountll(__ballot(e == 1u) & valid);
     q0 += __builtin_popcountll(__ballot(e != 3u) & valid);
-    ro0 += __builtin_popcountll(__ballot(e != 2u) & valid);
+    ro0 += __builtin_popcountll(nonins & valid);
     m0 += nv;
     if (nv > 0) st_in = (uint32_t)__builtin_amdgcn_readlane((int)st, nv - 1);
     more = nv == 64 && ro0 < L && m0 < cap;
     if (more && ro0 - wb >= 64) {
+      // the window moves on by 64: its upper half becomes the lower, the bases that were on their way the upper
+      const uint32_t up = s_win[64 + lane], up_hp = kHpBits ? 0u : s_hp[64 + lane];
+      wave_sync();
+      s_win[lane] = (uint8_t)up;
+      s_win[64 + lane] = (uint8_t)nxt;
+      if (!kHpBits) {
+        s_hp[lane] = (uint8_t)up_hp;
+        s_hp[64 + lane] = (uint8_t)nxt_hp;
+      }
+      wave_sync();
       wb += 64;
-      win_a = win_b;
-      hp_a = hp_b;
-      win_b = ref_at(wb + 64 + lane, &hp_b);
+      nxt = ref_at(wb + 128 + lane, &nxt_hp);
     }
   }
   if (lane == 0) {
