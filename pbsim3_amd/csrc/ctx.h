@@ -281,6 +281,7 @@ struct pbsim_ctx {
   ErrClassTables ect;
   QsClassTables qct;
   bool class_tables_dirty = true;
+  int coop_wg_errhmm[2] = {0, 0};  // persistent workgroups of k_walk_errhmm_coop<hp flag bits> (from its occupancy; 0: not asked yet)
   bool header_uploaded = false;
 
   DevBuf d_prob2len, d_prob2acc, d_cls;

@@ -339,6 +339,7 @@ int pbsim_load_errhmm(pbsim_ctx *c, const char *path) {
   if (!parse_errhmm(path, m.get(), &e)) return fail(e);
   c->err = std::move(m);
   c->class_tables_dirty = true;
+  c->coop_wg_errhmm[0] = c->coop_wg_errhmm[1] = 0;
   return PBSIM_SUCCEEDED;
 }
 
@@ -349,6 +350,7 @@ int pbsim_load_qshmm(pbsim_ctx *c, const char *path) {
   if (!parse_qshmm(path, m.get(), &e)) return fail(e);
   c->qs = std::move(m);
   c->class_tables_dirty = true;
+  c->coop_wg_errhmm[0] = c->coop_wg_errhmm[1] = 0;
   return PBSIM_SUCCEEDED;
 }
 
@@ -400,6 +402,7 @@ int pbsim_finish_hp_census(pbsim_ctx *c) {
     hp_bias_from_census(c->p.hp_del_bias, c->census, &c->bias);
     c->bias.hp11_seen = seen;
     c->class_tables_dirty = true;
+    c->coop_wg_errhmm[0] = c->coop_wg_errhmm[1] = 0;
   }
   c->census_done = true;
   c->census_from_job = false;
@@ -541,9 +544,14 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
 // moves a third of the lane walker's columns per second when the GPU is full (100 against 286 G columns/s).  The split that
 // ends both at the same time grows with the batch (same-box sweep, one launch at a time, profiles/r02z_coop_split.txt:
 // 50 k reads 34 -> 5.8 ms from half a mean length, 100 k 34 -> 8.1 ms from one, 200 k 36 -> 12 ms from 1.5, 450 k
-// 36 -> 19 ms from 2-3; the job pipeline, three rounds of 450 k reads in flight, is flat from 2.5 to 4): mean length x
-// reads / 150 k, between 0.5 and 4; small batches (top-up rounds, the truncated tail reads a record's completion waits
-// for) go to the wave walker entirely, and a batch of a million reads hides its longest lane behind its own bulk.
+// 36 -> 19 ms from 2-3; the job pipeline, three rounds of 450 k reads in flight, is flat from 2.5 to 4).  A launch alone
+// is not what a job runs, though: its rounds overlap each other and, when it delivers, the compression, whose workgroups
+// the wave walker's keep off the CUs (four of them hold 118 of a CU's 160 KB of LDS) -- jobs want the split later than a
+// lone launch does.  Round 4, after the wave walker's step was cut (profiles/r04_coop_split_ab.txt): mean length x reads /
+// 80 k, between 0.5 and 4 (round 2: / 150 k) -- configs[1] in HBM 319 -> 305-309 ms, delivered 1137 -> 1108-1134 ms, a rank
+// of eight 172 -> 167 ms (configs[4]: 471 -> 452 ms); / 60 k and later lose again (the rounds then wait for their longest
+// lanes).  Small batches (top-up rounds, the truncated tail reads a record's completion waits for) go to the wave walker
+// entirely, and a batch of a million reads hides its longest lane behind its own bulk.
 // A multiple of 256 (the sort's length bucket).  PBSIM_COOP_LEN overrides: -1 never, n >= 0 that length.
 constexpr int kCoopWorkgroups = 4096 / kCoopWaves, kCoopSmallBatch = 20000, kCoopHugeBatch = 1000000;  // 4096 persistent waves
 static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads, bool hp_flag) {
@@ -555,7 +563,9 @@ static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads, bool hp_flag) {
   }
   const char *env = getenv("PBSIM_COOP_LEN");
   const int64_t n_tasks = n_reads * c->p.pass_num;
-  int64_t len = (int64_t)(std::min(4.0, std::max(0.5, (double)n_tasks / 150000.0)) * c->hdr.mean_len);
+  const char *sr = getenv("PBSIM_COOP_SPLIT_READS");  // experiment knob: the batch size at which the split is one mean length
+  const double split_reads = sr && atof(sr) > 0 ? atof(sr) : 80000.0;
+  int64_t len = (int64_t)(std::min(4.0, std::max(0.5, (double)n_tasks / split_reads)) * c->hdr.mean_len);
   // (QSHMM: the batches of a multi-pass job are large and its job runs at its steady-state regime's rate without -- the wave
   // walker takes the small batches: truncated tail reads, top-up rounds, the small rounds of many ranks)
   if (qs) len = -1;
@@ -781,8 +791,20 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     if (coop_len != INT32_MAX) {
       // the long reads first, so that their workgroups are resident before the lane walk fills the CUs; beside a batch
       // on a stream of their own, a lone tail read simply in front of the (then empty) lane walk
+      // 1024 persistent workgroups (four per CU) beside a lane walk, which needs the rest of the CUs' LDS; a batch walked
+      // by waves only (a small batch, a record's tail) gets as many as the GPU holds at once: five per CU for ERRHMM-ONT
+      // (24 KB of class tables), four for ERRHMM-ONT-HQ (31 KB).  tools/coop_wg_ab.sh: 100 000 reads by waves only 139 ->
+      // 153 G columns/s with 1280; the same batch split between the walkers 7.4 -> 8.7 ms with 1280.
       const char *cw = getenv("PBSIM_COOP_WG");  // experiment knob
-      const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(cw && atoi(cw) > 0 ? atoi(cw) : kCoopWorkgroups,
+      const bool waves_only = coop_len == 0;
+      if (c->coop_wg_errhmm[ref.hp_flag] == 0) {
+        hipDeviceProp_t pr;
+        int cus = 256;
+        if (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        const int res = walk_errhmm_coop_resident(c->ect.stride + 512 + 1024, ref.hp_flag);
+        c->coop_wg_errhmm[ref.hp_flag] = std::max(kCoopWorkgroups, cus * std::min(res, 8));
+      }
+      const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(cw && atoi(cw) > 0 ? atoi(cw) : waves_only ? c->coop_wg_errhmm[ref.hp_flag] : kCoopWorkgroups,
                                                                    (n_tasks + kCoopWaves - 1) / kCoopWaves));
       hipStream_t cs = (ws == c->s().walk_stream && c->s().coop_stream) ? c->s().coop_stream : ws;
       if (cs != ws) HIP_OK(hipStreamWaitEvent(cs, c->s().ev_prep, 0));
@@ -1839,6 +1861,7 @@ static int set_units(pbsim_ctx *c, int64_t n, const char *const *ids, const int6
     c->bias.hp11_seen = freq[11] > 0;  // hpfreq[11] aliases hp_del_bias[0] (Q15)
   }
   c->class_tables_dirty = true;
+  c->coop_wg_errhmm[0] = c->coop_wg_errhmm[1] = 0;
 
   HIP_OK(c->d_seq_own.ensure((size_t)total + 64));
   HIP_OK(hipMemcpyAsync(c->d_seq_own.p, cat.data(), (size_t)total, hipMemcpyHostToDevice, c->stream));

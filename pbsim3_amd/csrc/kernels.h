@@ -229,6 +229,7 @@ constexpr int kCoopMaxStates = 31;
 // was tried in round 3: whole job in HBM 187 against 192-194 Gbases/s on other boxes, no gain; profiles/r03_occupancy_ab.txt.)
 constexpr int kCoopWaves = 4;
 void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bool hp_bits, hipStream_t s);
+int walk_errhmm_coop_resident(uint32_t lds_bytes, bool hp_bits);
 // the QSHMM wave walker (classes with a model whose moduli are all 100, hp flag in the sequence bytes, <= 63 states);
 // `lds_bytes` = class blob + byte tables, the quality rows and the waves' areas are added here
 constexpr int kQCoopMaxStates = 63;

@@ -1048,6 +1048,14 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// mask bit of the lane ? a : b -- the inverse of a ballot, one v_cndmask (written out, the compiler tests the lane's bit)
+__device__ __forceinline__ uint32_t select_by_mask(uint64_t mask, uint32_t a, uint32_t b) {
+  uint32_t r;
+  // (s_nop: the wait states gfx950 wants between a VALU write of the mask and its use -- the compiler cannot see into the asm)
+  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+  return r;
+}
+
 // writes of one lane of the wave, reads of another: LDS operations of a wave complete in order, the compiler must keep it
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1245,7 +1253,7 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
         nonins = now;
         if (!moved) break;
       }
-      e = ((del >> lane) & 1ull) ? e_del : e_keep;
+      e = select_by_mask(del, e_del, e_keep);
       if (q0 != 0) break;
       // Q2: the columns up to and including the first one that emits a base start from the initial-state table
       const uint64_t emits = __ballot(e != 3u) & valid;
@@ -1264,22 +1272,10 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
     const uint32_t cand = nt | (subb << 8) | (ins_base(w.w, nt) << 16);
     const uint32_t rb = (cand >> (8u * e)) & 0xffu;  // byte e of {nt, substituted, inserted, 0}
     const uint32_t fb = (e == 2u) ? (uint32_t)'-' : nt;
-    wave_sync();
-    s_tr[lane] = (uint8_t)rb;
-    s_tr[64 + lane] = (uint8_t)fb;
-    wave_sync();
-#ifndef PBSIM_COOP_NOSTORE  // experiment: the walk without its scratch writes
-    if (lane * 4 < nv) {
-      const uint32_t dr = reinterpret_cast<const uint32_t *>(s_tr)[lane];
-      const uint32_t df = reinterpret_cast<const uint32_t *>(s_tr + 64)[lane];
-      const size_t step_dw = (size_t)(m0 >> 2) * row_step;  // the wave's part of the address; the lane's is lane_dw
-      scratch_store(maf_read + step_dw + lane_dw, dr);
-      scratch_store(maf_ref + step_dw + lane_dw, df);
-    }
-#endif
     nsub += __builtin_popcountll(__ballot(e == 1u) & valid);
     q0 += __builtin_popcountll(__ballot(e != 3u) & valid);
     ro0 += __builtin_popcountll(nonins & valid);
+    const int m_step = m0;  // the step's first column
     m0 += nv;
     if (nv > 0) st_in = (uint32_t)__builtin_amdgcn_readlane((int)st, nv - 1);
     more = nv == 64 && ro0 < L && m0 < cap;
@@ -1297,6 +1293,20 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
       wb += 64;
       nxt = ref_at(wb + 128 + lane, &nxt_hp);
     }
+    // (the stores last: the wait for the bases in flight above must not also wait for them)
+    wave_sync();
+    s_tr[lane] = (uint8_t)rb;
+    s_tr[64 + lane] = (uint8_t)fb;
+    wave_sync();
+#ifndef PBSIM_COOP_NOSTORE  // experiment: the walk without its scratch writes
+    if (lane * 4 < nv) {
+      const uint32_t dr = reinterpret_cast<const uint32_t *>(s_tr)[lane];
+      const uint32_t df = reinterpret_cast<const uint32_t *>(s_tr + 64)[lane];
+      const size_t step_dw = (size_t)(m_step >> 2) * row_step;  // the wave's part of the address; the lane's is lane_dw
+      scratch_store(maf_read + step_dw + lane_dw, dr);
+      scratch_store(maf_ref + step_dw + lane_dw, df);
+    }
+#endif
   }
   if (lane == 0) {
     if (ro0 < L) atomicOr(&a.flags->error, kErrScratchOverflow);
@@ -3121,6 +3131,16 @@ void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byt
   else if (fast_rv) hipLaunchKernelGGL((k_walk_errhmm<true, false>), grid, block, lds_bytes, s, a);
   else if (hp_bits) hipLaunchKernelGGL((k_walk_errhmm<false, true>), grid, block, lds_bytes, s, a);
   else hipLaunchKernelGGL((k_walk_errhmm<false, false>), grid, block, lds_bytes, s, a);
+}
+
+// workgroups of k_walk_errhmm_coop a CU holds at once (registers: five waves per SIMD; LDS: the class tables + kCoopWaveLds
+// per wave); 0 if the runtime cannot say
+int walk_errhmm_coop_resident(uint32_t lds_bytes, bool hp_bits) {
+  int n = 0;
+  const size_t lds = lds_bytes + kCoopWaves * kCoopWaveLds;
+  const hipError_t e = hp_bits ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_walk_errhmm_coop<true>, kCoopWaves * 64, lds)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_walk_errhmm_coop<false>, kCoopWaves * 64, lds);
+  return e == hipSuccess ? n : 0;
 }
 
 void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bool hp_bits, hipStream_t s) {
