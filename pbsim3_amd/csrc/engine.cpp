@@ -791,10 +791,11 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     if (coop_len != INT32_MAX) {
       // the long reads first, so that their workgroups are resident before the lane walk fills the CUs; beside a batch
       // on a stream of their own, a lone tail read simply in front of the (then empty) lane walk
-      // 1024 persistent workgroups (four per CU) beside a lane walk, which needs the rest of the CUs' LDS; a batch walked
-      // by waves only (a small batch, a record's tail) gets as many as the GPU holds at once: five per CU for ERRHMM-ONT
-      // (24 KB of class tables), four for ERRHMM-ONT-HQ (31 KB).  tools/coop_wg_ab.sh: 100 000 reads by waves only 139 ->
-      // 153 G columns/s with 1280; the same batch split between the walkers 7.4 -> 8.7 ms with 1280.
+      // 512 persistent workgroups of eight waves (two per CU: 63 KB of LDS) beside a lane walk and the compression, which
+      // need the rest of the CUs' LDS; a batch walked by waves only (a small batch, a record's tail) gets as many as the GPU
+      // holds at once: three per CU = the six waves per SIMD the kernel is compiled for.  Round 4 (profiles/
+      // r04_coop_split_ab.txt): four-wave workgroups, four per CU, held 118 KB for the same 4096 waves -- a rank of eight
+      // 167 -> 164 ms with eight-wave ones, 100 000 reads by waves only 139 (1024 x 4 waves) -> 156 G columns/s (768 x 8).
       const char *cw = getenv("PBSIM_COOP_WG");  // experiment knob
       const bool waves_only = coop_len == 0;
       if (c->coop_wg_errhmm[ref.hp_flag] == 0) {

@@ -224,10 +224,12 @@ void launch_walk_errhmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_byt
 // the long reads of the batch (WalkArgs::coop_min_len), one wave per read; `n_wg` persistent workgroups; `lds_bytes` = the
 // lane walk's (class blob + byte tables), the waves' own areas are added here.  Classes of at most kCoopMaxStates states.
 constexpr int kCoopMaxStates = 31;
-// Waves (= reads in flight) per workgroup of the wave walker; they share one class blob in LDS (24-31 KB).  (Eight per blob --
-// the same waves per CU in half the LDS, so that the lane walker beside it keeps three workgroups per CU instead of one --
-// was tried in round 3: whole job in HBM 187 against 192-194 Gbases/s on other boxes, no gain; profiles/r03_occupancy_ab.txt.)
-constexpr int kCoopWaves = 4;
+// Waves (= reads in flight) per workgroup of the wave walker; they share one class blob in LDS (24-31 KB).  Eight since the
+// end of round 4 (four before; eight had been tried in round 3 for the job in HBM: no gain, profiles/r03_occupancy_ab.txt):
+// the same 4096 waves in half the LDS leave the delivered job's compression its workgroups (a rank of eight 167 -> 164 ms),
+// and with the kernel held to 80 registers three such workgroups -- six waves per SIMD -- fit a CU where five four-wave
+// ones did (wave-only batches: ERRHMM-ONT 152 -> 156, ERRHMM-ONT-HQ 127 -> 142 G columns/s).  profiles/r04_coop_split_ab.txt
+constexpr int kCoopWaves = 8;
 void launch_walk_errhmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, bool hp_bits, hipStream_t s);
 int walk_errhmm_coop_resident(uint32_t lds_bytes, bool hp_bits);
 // the QSHMM wave walker (classes with a model whose moduli are all 100, hp flag in the sequence bytes, <= 63 states);

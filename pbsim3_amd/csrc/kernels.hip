@@ -1320,7 +1320,7 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
 }
 
 template <bool kHpBits>
-__global__ __launch_bounds__(kCoopWaves * 64) void k_walk_errhmm_coop(WalkArgs a) {
+__global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_walk_errhmm_coop(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
