@@ -5,7 +5,7 @@
 #   k_walk_errhmm        lane walker, one launch at a time (tools/walk_solo.py), at the delivered job's occupancy (ONE workgroup
 #                        per CU, PBSIM_WALK_LDS_KB=81, since the second half of round 4; three, =41, before) and at the batch
 #                        primitives' / HBM-only job's (five)
-#   k_walk_errhmm_coop   wave walker with every read of a 100 000-read batch (PBSIM_COOP_LEN=0), five persistent workgroups per CU
+#   k_walk_errhmm_coop   wave walker with every read of a 100 000-read batch (PBSIM_COOP_LEN=0), three eight-wave workgroups per CU
 #   fetch_calib          FETCH_SIZE / WRITE_SIZE against byte counts known by construction (tools/fetch_calib.hip)
 tag=$1
 R=$GRAFT_REPO_ROOT

@@ -90,7 +90,7 @@ doc = {"round": TAG,
        "k_walk_errhmm_job_occupancy": kernel_block("lane1", "k_walk_errhmm<", "lane walker, ONE workgroup per CU (PBSIM_WALK_LDS_KB=81: the delivered job, which leaves the rest of the CU's LDS to its deflate workgroups)"),
        "k_walk_errhmm_three_per_cu": kernel_block("lane3", "k_walk_errhmm<", "lane walker, three workgroups per CU (PBSIM_WALK_LDS_KB=41: the delivered job of rounds 2-3)"),
        "k_walk_errhmm": kernel_block("lane5", "k_walk_errhmm<", "lane walker, five workgroups per CU (batch primitives, the job with its text left in HBM)"),
-       "k_walk_errhmm_coop": kernel_block("coop", "k_walk_errhmm_coop", "wave walker, every read of the batch (PBSIM_COOP_LEN=0), as many persistent workgroups as are resident (1280 = five per CU for ERRHMM-ONT)")}
+       "k_walk_errhmm_coop": kernel_block("coop", "k_walk_errhmm_coop", "wave walker, every read of the batch (PBSIM_COOP_LEN=0), as many persistent workgroups as are resident (768 of eight waves: six waves per SIMD)")}
 # the fields bench.py reads (same names as profiles/r02z_walk_pmc.json / r02z_walk_traffic.json)
 lane = doc["k_walk_errhmm_job_occupancy"]
 if "per_wave_step" in lane and "valu" in lane["per_wave_step"]:
