@@ -1096,11 +1096,11 @@ __device__ __forceinline__ uint32_t coop_chain(const uint8_t *lds, uint32_t init
     st[k] = st[k] > smax ? 0u : st[k];  // no such state: any row inside the table will do
     lo[k] = hi[k] = 0;
   }
-  auto walk_pair = [&](const int k0) {
+  auto walk_chains = [&](const int k0, const int k1) {  // chains side by side: their eight dependent table reads each overlap
 #pragma unroll
     for (int t = 0; t < 8; t++) {
 #pragma unroll
-      for (int k = k0; k < k0 + 2; k++) {
+      for (int k = k0; k < k1; k++) {
         uint32_t row = st[k];
         if (kInit) row = ((qg >> t) & 1u) ? 0u : row;
         st[k] = lds[init_off + __umul24(row, 1000u) + xt[t]];
@@ -1109,9 +1109,13 @@ __device__ __forceinline__ uint32_t coop_chain(const uint8_t *lds, uint32_t init
       }
     }
   };
-  walk_pair(0);
-  const bool wide = reach > 15u;  // most classes have fewer than sixteen states: half the work
-  if (wide) walk_pair(2);
+  walk_chains(0, 2);
+  // most classes have fewer than sixteen states: half the work; up to 24 (most of ERRHMM-ONT-HQ's): three chains
+  const bool wide = reach > 15u;
+  if (wide) {
+    if (reach > 23u) walk_chains(2, 4);
+    else walk_chains(2, 3);
+  }
   // byte k = the state chain k ends in
   const uint32_t ends = __builtin_amdgcn_perm(hi[1], hi[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(hi[3], hi[2], 0x0c0c0703u) << 16);
   uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_in);
