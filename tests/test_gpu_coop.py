@@ -201,3 +201,18 @@ def test_counter_drawn_units_at_their_default_size(monkeypatch):
     got, w1 = crc(None, None)
     assert w1 > 0 and got == want
     assert crc(None, "0")[0] == want
+
+
+# ---- the wave walker's grid and the split rule (round 4): knobs of speed only -----------------------------------------------
+@pytest.mark.parametrize("knobs", [{"PBSIM_COOP_WG": "1"}, {"PBSIM_COOP_WG": "3"}, {"PBSIM_COOP_WG": "2048"},
+                                   {"PBSIM_COOP_SPLIT_READS": "2000"}, {"PBSIM_COOP_SPLIT_READS": "500000", "PBSIM_COOP_WG": "7"}])
+def test_grid_size_and_split_rule_change_nothing(knobs, monkeypatch):
+    """one persistent workgroup (every unit of every class through the same eight waves), a few, more than the GPU holds at
+    once; the split by the rule at two other batch sizes: the lane walker's bytes and statistics"""
+    recs = [genome(1_500_000, 1), genome(700_000, 2)]
+    want = {name: run(-1, monkeypatch, recs, **RUNS[name]) for name in ("ont_default", "sequel_pass3_short_reads")}
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for name in want:
+        for coop in ((None, 0) if "PBSIM_COOP_SPLIT_READS" in knobs else (0, 4096)):
+            assert run(coop, monkeypatch, recs, **RUNS[name]) == want[name], (name, coop, knobs)
