@@ -1892,7 +1892,6 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
   const uint8_t *qsrc = a.quals + a.line_qoff[line];
   const int v0 = __builtin_amdgcn_readfirstlane(a.vbase[lw]), K = __builtin_amdgcn_readfirstlane(a.vbase[lw + 1]) - v0;
   const int64_t G = a.ref.len;
-  const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int k = 0; k < K; ++k) {
     const int64_t wave = v0 + k;
     const int task = __builtin_amdgcn_readfirstlane(a.task_of_slot[wave * 64 + l]);
@@ -1901,7 +1900,8 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
     int L = Lcur;
     int64_t off = 0;
     if ((int64_t)L >= G) L = (int)G;  // pbsim.cpp:1753-1759
-    else off = (int64_t)(header_block(a.seed, a.unit, read_idx).z % (uint32_t)(G - L + 1));
+    else  // (the same draw in every lane: one scalar, so that the window's loads take a scalar base)
+      off = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(header_block(a.seed, a.unit, read_idx).z % (uint32_t)(G - L + 1)));
     const bool minus = (read_idx & 1u) == 0;  // :1767-1773
     const int cap_dw = __builtin_amdgcn_readfirstlane(a.wave_cap[wave]) & ~kWaveTransposed;
     uint32_t *maf_read = reinterpret_cast<uint32_t *>(a.scratch + a.wave_off[wave]) + (size_t)l * cap_dw;  // rows task by task
@@ -1909,20 +1909,24 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
     uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;
     const int cap = cap_dw * 4;
     const uint32_t comp_off = minus ? 256u : 0u;
-    const int64_t p_first = minus ? (off + L - 1) : off;
     const int64_t p_last = G - 1;
-    auto ref_at = [&](int t) -> uint8_t {
-      int64_t p = minus ? (p_first - t) : (p_first + t);
-      p = p < 0 ? 0 : (p > p_last ? p_last : p);
-      return a.ref.seq[p];
+    int64_t p_first = minus ? (off + L - 1) : off;
+    p_first = p_first < 0 ? 0 : (p_first > p_last ? p_last : p_first);
+    // read coordinate t is record position p_first +- t, held at the record's ends: a scalar base and a 32-bit lane offset
+    const int64_t room = minus ? p_first : p_last - p_first;
+    const uint32_t tmax = (uint32_t)(room > 0x7fffffff ? 0x7fffffff : (room < 0 ? 0 : room));
+    const int64_t p0 = minus ? p_first - (int64_t)tmax : p_first;
+    const uint8_t *seq0 = a.ref.seq + p0;
+    const uint8_t *hp0 = kHpBits ? nullptr : a.ref.hp + p0;
+    auto ref_off = [&](int t) -> uint32_t {
+      const uint32_t tc = (uint32_t)t < tmax ? (uint32_t)t : tmax;
+      return minus ? tmax - tc : tc;
     };
-    auto hp_at = [&](int t) -> uint8_t {
-      int64_t p = minus ? (p_first - t) : (p_first + t);
-      p = p < 0 ? 0 : (p > p_last ? p_last : p);
-      return a.ref.hp[p];
-    };
+    auto ref_at = [&](int t) -> uint8_t { return seq0[ref_off(t)]; };
+    auto hp_at = [&](int t) -> uint8_t { return hp0[ref_off(t)]; };
     auto hp_class = [](uint32_t b) -> uint32_t { return kHpBits ? ((b & 0x80u) ? 11u : 1u) : (b < 12u ? b : 11u); };
-    auto q_at = [&](int t) -> uint8_t { return qsrc[t < L ? t : (L > 0 ? L - 1 : 0)]; };
+    const uint32_t q_last = L > 0 ? (uint32_t)(L - 1) : 0u;
+    auto q_at = [&](int t) -> uint8_t { return qsrc[(uint32_t)t < q_last ? (uint32_t)t : q_last]; };
     auto conv = [](uint32_t ch) -> uint32_t { return (ch >= 33u && ch < 127u) ? ch - 33u : 0u; };
     // rings: positions wb .. wb + 127 of the read's reference window, qb .. qb + 127 of the string; the next 64 of each on their way
     int wb = 0, qb = 0;
@@ -1953,13 +1957,13 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
       }
       const uint32_t dw = *reinterpret_cast<const uint32_t *>(s_d + (((m0 & 255) + lane) << 2));  // group (event >> 2), word (event & 3)
       const uint32_t z = mod1e6(w.z), d = mod1e6(dw);
-      uint64_t delm = __ballot(event > 0u && d < s_del[lastq_in * 12u + hp_in]);  // first guess
+      const uint64_t not_first = __ballot(event > 0u), in_cap = __ballot(event < (uint32_t)cap);
+      uint64_t delm = __ballot(d < s_del[lastq_in * 12u + hp_in]) & not_first;  // first guess
       uint32_t qv = 0, raw = 0;
-      bool is_sub = false, is_ins = false, emitted = true;
+      bool is_sub = false, is_ins = false;
       uint64_t valid = 0, consm = 0;
       for (;;) {
-        emitted = ((delm >> lane) & 1ull) == 0;
-        const int qi = q0 + __builtin_popcountll(~delm & below);
+        const int qi = q0 + (int)mbcnt64(~delm);  // emitted columns in front of the lane's
         // (every read is unconditional and the two of a pair are issued together: a branch around a read costs its latency)
         const uint32_t c_at = s_q[qi & 127], c_prev = s_q[(qi - 1) & 127];
         qv = conv(c_at);
@@ -1967,19 +1971,19 @@ __device__ __forceinline__ void scoop_walk_string(const SampleArgs &a, const uin
         const uint2 si = s_si[qv];
         is_sub = z < si.x;                      // pbsim.cpp:1779-1810
         is_ins = !is_sub && z < si.y;
-        consm = __ballot(!emitted || !is_ins);  // a column uses a reference base unless it is an emitted insertion
+        consm = delm | __ballot(!is_ins);  // a column uses a reference base unless it is an emitted insertion
         const int roi = ro0 + (int)mbcnt64(consm);
         raw = s_ref[roi & 127];
         const uint32_t prevb = (kHpBits ? s_ref : s_hp)[(roi - 1) & 127];
         const uint32_t hsel = (roi == ro0) ? hp_in : hp_class(prevb);
         const uint32_t thr = s_del[lq * 12u + hsel];  // :1816-1831
-        valid = __ballot(roi < L && qi < L && m0 + lane < cap);  // :1776
-        const uint64_t newm = __ballot(event > 0u && d < thr);
+        valid = __ballot(roi < L && qi < L) & in_cap;  // :1776
+        const uint64_t newm = __ballot(d < thr) & not_first;
         if (((newm ^ delm) & valid) == 0) break;
         delm = newm;
       }
       const int nv = __builtin_popcountll(valid);
-      const bool deleted = !emitted;
+      const bool deleted = select_by_mask(delm, 1u, 0u) != 0, emitted = !deleted;
       // ---- emit
       const uint32_t nt = s_comp[raw + comp_off];
       uint32_t subb = s_sub[nt * 4u + mod3(w.w)];
