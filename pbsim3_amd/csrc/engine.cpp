@@ -1332,8 +1332,11 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   int64_t out_bytes = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;  // trace: begin / end of every copy on the copy stream
   bool used[kDfBuffers] = {false};
-  // pieces the lane's kernels run ahead of the piece whose copy is being enqueued (ahead + 1 dense buffers in use)
-  static const int ahead_env = getenv("PBSIM_DEFLATE_AHEAD") ? atoi(getenv("PBSIM_DEFLATE_AHEAD")) : 2;
+  // pieces the lane's kernels run ahead of the piece whose copy is being enqueued (ahead + 1 dense buffers in use).  Four
+  // since the end of round 4 (two before): the kernels of a piece share the GPU with the next round's walk and arrive late
+  // now and then; two more pieces in hand cover that -- configs[1] 1116-1120 -> 1089-1102 ms, configs[4] 3200 -> 3100-3140
+  // (same box, profiles/r04_replay_late_ab.txt; six or eight with more buffers: no better) for 0.5 GB of HBM per lane.
+  static const int ahead_env = getenv("PBSIM_DEFLATE_AHEAD") ? atoi(getenv("PBSIM_DEFLATE_AHEAD")) : 4;
   const int ahead = std::max(1, std::min(kDfBuffers - 1, ahead_env)), nbuf = ahead + 1;
   int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
   // piece j: kernels on staging set j & 1 into dense buffer j % 3; its total lands in h_total[j % 3]
