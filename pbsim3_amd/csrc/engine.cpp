@@ -840,6 +840,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
       hipStream_t cs = (ws == c->s().walk_stream && c->s().coop_stream) ? c->s().coop_stream : ws;
       if (cs != ws) HIP_OK(hipStreamWaitEvent(cs, c->s().ev_prep, 0));
       launch_walk_qshmm_coop(w, n_wg, c->qct.stride + 512 + 1024, cs);
+      launch_qshmm_coop_qsum(w, slots_max, cs);
       c->prof_wave_launches++;
       if (cs != ws) HIP_OK(hipEventRecord(c->s().ev_coop, cs));
       lanes_idle = coop_len == 0 && s.coop_classes == (ncls >= 64 ? ~0ull : (1ull << ncls) - 1);

@@ -236,6 +236,7 @@ int walk_errhmm_coop_resident(uint32_t lds_bytes, bool hp_bits);
 // `lds_bytes` = class blob + byte tables, the quality rows and the waves' areas are added here
 constexpr int kQCoopMaxStates = 63;
 void launch_walk_qshmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, hipStream_t s);
+void launch_qshmm_coop_qsum(const WalkArgs &a, int64_t n_slots_max, hipStream_t s);  // behind it, on the same stream
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
                        hipStream_t s, int min_lds_kb);
 void launch_walk_sample(const SampleArgs &a, bool hp_bits, hipStream_t s);

@@ -1685,7 +1685,6 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
   int m0 = 0, ro0 = 0, q0 = 0, nsub = 0;
   uint32_t st_in = 0, lastq_in = 0;
   uint32_t hpf_in = 0;  // bit 7 of the last consumed reference byte (hp == 11 flag); meaningless while ro0 == 0
-  double qsum = 0.0;
   bool more = L > 0;
   while (more) {
     const uint32_t event = (uint32_t)(m0 + lane);
@@ -1700,13 +1699,11 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
     uint32_t st, qv, raw = 0, roi_u = 0;
     bool is_sub, is_ins, emitted;
     uint64_t valid, consm;
-    double qp;
     for (;;) {
       st = qcoop_chain(lds, a.init_off, n_chains, s_w, x, delm, q0 == 0, st_in, lane);
       qv = lds[a.emis_off + __umul24(st - 1u, 100u) + y];
       qv = (qv < 94u) ? qv : 93u;
       const uint4 row = *reinterpret_cast<const uint4 *>(&s_row[qv * 8u]);
-      qp = *reinterpret_cast<const double *>(&s_row[qv * 8u + 4u]);
       emitted = ((delm >> lane) & 1ull) == 0;
       is_sub = z < row.x;               // pbsim.cpp:2233-2249
       is_ins = !is_sub && z < row.y;    // pbsim.cpp:2250-2258
@@ -1759,15 +1756,7 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
       scratch_store(&maf_ref[(size_t)((m0 >> 2) + lane) * row_step], df);
       scratch_store(&qual_row[(size_t)((m0 >> 2) + lane) * row_step], dqv);
     }
-    // ---- the ordered sum of error probabilities: lane by lane, in column order (+ 0.0 leaves it unchanged)
-    {
-      const double mine = (emitted && ((valid >> lane) & 1ull)) ? qp : 0.0;
-      const uint32_t mlo = (uint32_t)__double_as_longlong(mine), mhi = (uint32_t)((unsigned long long)__double_as_longlong(mine) >> 32);
-      for (int i = 0; i < nv; i++) {
-        const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, i), vhi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, i);
-        qsum += __longlong_as_double((long long)(((unsigned long long)vhi << 32) | vlo));
-      }
-    }
+    // (the ordered sum of error probabilities: k_qshmm_coop_qsum, from the quality row stored above)
     const uint64_t em_valid = ~delm & valid;
     nsub += __builtin_popcountll(__ballot(emitted && is_sub) & valid);
     q0 += __builtin_popcountll(em_valid);
@@ -1796,7 +1785,6 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
     a.nsub[task] = nsub;
     a.nins[task] = m0 - ro0;
     a.ndel[task] = m0 - q0;
-    a.qsum[task] = qsum;
     note_row_need(a.flags, m0, L);
   }
 }
@@ -1848,6 +1836,41 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm_coop(WalkArgs a) {
     const uint32_t has_model = reinterpret_cast<const uint32_t *>(lds)[2];
     if (k < nc && has_model) qcoop_walk_task(a, lds, s_comp, s_sub, s_row, s_w, a.class_start[c] + k, lane);
   }
+}
+
+// The ordered sum of error probabilities of the wave-walked tasks (pbsim.cpp:2309-2313; the %f report and the accuracy histogram
+// depend on its exact value): a lane per task over the quality row the wave walker stored, in column order.  Inside the wave
+// walker's step it was 64 dependent f64 additions and 128 v_readlane per 64 columns -- a fifth of the step; a lane's additions
+// are as dependent, but 64 tasks at a time, and a task of 9 000 columns takes 40 us.
+__global__ __launch_bounds__(256) void k_qshmm_coop_qsum(WalkArgs a, int n_slots) {
+  __shared__ double s_qprob[94];
+  for (int i = threadIdx.x; i < 94; i += 256) s_qprob[i] = a.qprob[i];
+  __syncthreads();
+  const int slot = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (slot >= n_slots || (a.flags->error & kErrScratchBudget)) return;  // (no room for the batch's rows: nothing was walked)
+  bool walked = false;  // by the wave walker: the first coop_end[c] - class_start[c] slots of class c
+  for (int c = 0; c < a.ncls; c++) walked = walked || (slot >= a.class_start[c] && slot < a.coop_end[c]);
+  if (!walked) return;
+  const int task = a.task_of_slot[slot];
+  if (task < 0) return;
+  const int64_t wave = slot >> 6;
+  const int cap_raw = a.wave_cap[wave];
+  const int cap_dw = cap_raw & ~kWaveTransposed;
+  const bool transposed = (cap_raw & kWaveTransposed) != 0;
+  const size_t row_step = transposed ? 1 : 64;
+  const uint32_t *maf_read = reinterpret_cast<const uint32_t *>(a.scratch + a.wave_off[wave]) + (transposed ? (size_t)(slot & 63) * cap_dw : (size_t)(slot & 63));
+  const uint32_t *qual_row = maf_read + (size_t)cap_dw * 128;
+  const int n = a.maf_len[task];
+  double sum = 0.0;
+  for (int m = 0; m < n; m += 4) {
+    uint32_t v = qual_row[(size_t)(m >> 2) * row_step];
+    const int k = n - m < 4 ? n - m : 4;
+    for (int i = 0; i < k; i++, v >>= 8) {
+      const uint32_t q = v & 0xffu;  // 0: a deleted column
+      if (q) sum += s_qprob[q - 33u];
+    }
+  }
+  a.qsum[task] = sum;
 }
 
 // ---------------------------------------------------------------------------
@@ -3162,6 +3185,10 @@ void launch_walk_qshmm_coop(const WalkArgs &a, int n_wg, uint32_t lds_bytes, hip
   const dim3 grid((unsigned)n_wg), block(kWG);
   lds_bytes += 94 * 32 + (kWG / 64) * kQCoopWaveLds;
   hipLaunchKernelGGL(k_walk_qshmm_coop, grid, block, lds_bytes, s, a);
+}
+
+void launch_qshmm_coop_qsum(const WalkArgs &a, int64_t n_slots_max, hipStream_t s) {
+  hipLaunchKernelGGL(k_qshmm_coop_qsum, dim3((unsigned)((n_slots_max + 255) / 256)), dim3(256), 0, s, a, (int)n_slots_max);
 }
 
 void launch_walk_qshmm(const WalkArgs &a, int64_t n_slots_max, uint32_t lds_bytes, bool fast_rv, bool hp_bits,
