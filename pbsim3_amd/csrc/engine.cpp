@@ -836,7 +836,8 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     bool lanes_idle = false;
     if (coop_len != INT32_MAX) {  // the wave walker first, beside a batch on a stream of its own (as for ERRHMM above)
       const char *cw = getenv("PBSIM_COOP_WG");
-      const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(cw && atoi(cw) > 0 ? atoi(cw) : kCoopWorkgroups, (n_tasks + 3) / 4));
+      // (k_walk_qshmm_coop's workgroups hold four waves: 1024 of them are the 4096 persistent waves)
+      const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(cw && atoi(cw) > 0 ? atoi(cw) : 4096 / (kWG / 64), (n_tasks + 3) / 4));
       hipStream_t cs = (ws == c->s().walk_stream && c->s().coop_stream) ? c->s().coop_stream : ws;
       if (cs != ws) HIP_OK(hipStreamWaitEvent(cs, c->s().ev_prep, 0));
       launch_walk_qshmm_coop(w, n_wg, c->qct.stride + 512 + 1024, cs);

@@ -1581,14 +1581,15 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
 // probabilities (pbsim.cpp:2309-2313; the %f report and the accuracy histogram depend on its exact value) is added lane by
 // lane in column order.  kFastRv && kHpBits classes with a model only; everything else stays with the lane walker.
 // ---------------------------------------------------------------------------
-constexpr int kQCoopX = 0, kQCoopEnd = 128, kQCoopStates = 640, kQCoopRows = 704, kQCoopWaveLds = 896;
+// LDS of one wave: x[64] u16 | the true chains' states [8 groups][8 chains][8] | three output rows | the deletion draws of 256 columns
+constexpr int kQCoopX = 0, kQCoopStates = 128, kQCoopRows = 640, kQCoopD = 832, kQCoopWaveLds = 1856;
 
 // state after each of the 64 columns, given s_in in front of column 0; `delm`: columns that leave the state alone;
 // `init0`: column 0 starts from the initial-state table (row 0 of the transition table) whatever s_in is
 __device__ __forceinline__ uint32_t qcoop_chain(const uint8_t *lds, uint32_t init_off, uint32_t n_chains, uint8_t *s_w, uint32_t x,
                                                 uint64_t delm, bool init0, uint32_t s_in, int lane) {
   uint16_t *s_x = reinterpret_cast<uint16_t *>(s_w + kQCoopX);
-  uint8_t *s_end = s_w + kQCoopEnd, *s_st = s_w + kQCoopStates;
+  uint8_t *s_st = s_w + kQCoopStates;
   const int g = lane >> 3, j = lane & 7;
   wave_sync();
   s_x[lane] = (uint16_t)x;
@@ -1618,37 +1619,41 @@ __device__ __forceinline__ uint32_t qcoop_chain(const uint8_t *lds, uint32_t ini
         else hi[k] |= st[k] << (8 * (t - 4));
       }
     }
-#pragma unroll
-    for (int k = 0; k < kN; k++) s_end[g * 64 + j + 8 * k] = (uint8_t)st[k];
   };
   if (n_chains <= 2) walk(std::integral_constant<int, 2>());
   else if (n_chains <= 4) walk(std::integral_constant<int, 4>());
   else if (n_chains <= 6) walk(std::integral_constant<int, 6>());
   else walk(std::integral_constant<int, 8>());
-  wave_sync();
-  uint32_t s = s_in, sg = 0;
+  // the groups' true start states: eight dependent steps on the scalar unit, as in coop_chain (byte k & 3 of ends[k >> 2] = the
+  // state chain k ends in); then the lane that walked a group from its true start state hands its chains to LDS
+  const uint32_t ends_a = __builtin_amdgcn_perm(hi[1], hi[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(hi[3], hi[2], 0x0c0c0703u) << 16);
+  const uint32_t ends_b = __builtin_amdgcn_perm(hi[5], hi[4], 0x0c0c0703u) | (__builtin_amdgcn_perm(hi[7], hi[6], 0x0c0c0703u) << 16);
+  uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_in);
+  uint64_t starts = 0;  // byte gg = the state in front of group gg
 #pragma unroll
   for (int gg = 0; gg < 8; gg++) {
-    sg = (g == gg) ? s : sg;
-    s = s_end[gg * 64 + s];
+    starts |= (uint64_t)s << (8 * gg);
+    const int src = (int)(gg * 8 + (s & 7u));
+    const uint32_t ea = (uint32_t)__builtin_amdgcn_readlane((int)ends_a, src), eb = (uint32_t)__builtin_amdgcn_readlane((int)ends_b, src);
+    s = (((s & 32u) ? eb : ea) >> (((s >> 3) & 3u) * 8u)) & 0xffu;
   }
-  const uint32_t k = sg >> 3;
-  uint32_t plo = lo[0], phi = hi[0];
-#pragma unroll
-  for (int kk = 1; kk < 8; kk++) {
-    plo = (k == (uint32_t)kk) ? lo[kk] : plo;
-    phi = (k == (uint32_t)kk) ? hi[kk] : phi;
+  const uint32_t sg = (uint32_t)(starts >> (8 * g)) & 0xffu;
+  if ((uint32_t)j == (sg & 7u)) {
+    uint4 *dst = reinterpret_cast<uint4 *>(s_st + g * 64);
+    dst[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+    if (n_chains > 2) dst[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+    if (n_chains > 4) dst[2] = make_uint4(lo[4], hi[4], lo[5], hi[5]);
+    if (n_chains > 6) dst[3] = make_uint4(lo[6], hi[6], lo[7], hi[7]);
   }
-  if ((uint32_t)j == (sg & 7u)) *reinterpret_cast<uint2 *>(s_st + g * 8) = make_uint2(plo, phi);
   wave_sync();
-  return s_st[lane];
+  return s_st[g * 64 + j + (sg & 0x38u)];
 }
 
 __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t *lds, const uint8_t *s_comp, const uint8_t *s_sub,
                                                 const uint32_t *s_row, uint8_t *s_w, int slot, int lane) {
   const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
   const uint32_t n_chains = (hdr[6] + 8u) >> 3;  // start states 0 .. reach in chains of eight
-  uint8_t *s_tr = s_w + kQCoopRows;
+  uint8_t *s_tr = s_w + kQCoopRows, *s_d = s_w + kQCoopD;
   const int task = __builtin_amdgcn_readfirstlane(a.task_of_slot[slot]);
   if (task < 0) return;
   const int r = task / a.pass_num;
@@ -1689,9 +1694,13 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
   while (more) {
     const uint32_t event = (uint32_t)(m0 + lane);
     const U4 w = walk_block(a.seed, a.unit, read_idx, pass, event, 0u);
-    const U4 dq = walk_block(a.seed, a.unit, read_idx, pass, event >> 2, 2u);
-    const uint32_t dsel = event & 3u;
-    const uint32_t dw = dsel == 0 ? dq.x : dsel == 1 ? dq.y : dsel == 2 ? dq.z : dq.w;
+    if ((m0 & 255) == 0) {  // m0 is a multiple of 64 here: the deletion blocks of columns m0 .. m0 + 255, lane i holds group m0 / 4 + i
+      const U4 dq = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(m0 >> 2) + (uint32_t)lane, 2u);
+      wave_sync();
+      *reinterpret_cast<uint4 *>(s_d + lane * 16) = make_uint4(dq.x, dq.y, dq.z, dq.w);
+      wave_sync();
+    }
+    const uint32_t dw = *reinterpret_cast<const uint32_t *>(s_d + (((m0 & 255) + lane) << 2));  // group (event >> 2), word (event & 3)
     const uint32_t x = mod100(w.x), y = mod100(w.y), z = mod1e6(w.z), d = mod1e6(dw);
     const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // first guess: every column tested against the thresholds of the quality in front of the window
