@@ -695,7 +695,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   if (chain && coop_len != INT32_MAX) coop_len = 0;
   s.coop_bucket = coop_len == INT32_MAX ? kLenBuckets : coop_len >> kLenShift;
   s.coop_classes = 0;
-  if (coop_len != INT32_MAX)  // verbatim classes (ERRHMM) / classes without a model (QSHMM) stay with the lane walker
+  if (coop_len != INT32_MAX)  // verbatim classes (ERRHMM) stay with the lane walker
     for (int i = 0; i < ncls; i++) {
       uint32_t mode;  // hdr[2]: ERRHMM mode | QSHMM has_model
       if (c->p.method == PBSIM_METHOD_ERR) {
@@ -703,7 +703,8 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
         if (mode != kModeVerbatim) s.coop_classes |= 1ull << i;
       } else {
         memcpy(&mode, c->qct.blob.data() + (size_t)i * c->qct.stride + 8, 4);
-        if (mode != 0) s.coop_classes |= 1ull << i;
+        (void)mode;  // classes without a model (quality from the accuracy alone) are walked by waves too since round 4
+        s.coop_classes |= 1ull << i;
       }
     }
   s.task_of_slot = c->s().d_task_of_slot.as<int32_t>();

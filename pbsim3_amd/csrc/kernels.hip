@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   uint32_t acc_r = 0, acc_f = 0, acc_q = 0;
   int nsub = 0;
   double qsum = 0.0;
-  const bool coop_lane = has_model && L >= a.coop_min_len;  // a long task: k_walk_qshmm_coop walks it
+  const bool coop_lane = L >= a.coop_min_len;  // a long task: k_walk_qshmm_coop walks it (classes with and without a model)
   bool act = valid && L > 0 && !coop_lane;
   int group = 0;
   const uint32_t comp_off = minus ? 256u : 0u;
@@ -1653,6 +1653,7 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
                                                 const uint32_t *s_row, uint8_t *s_w, int slot, int lane) {
   const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
   const uint32_t n_chains = (hdr[6] + 8u) >> 3;  // start states 0 .. reach in chains of eight
+  const uint32_t has_model = hdr[2], freq_rv = hdr[3];
   uint8_t *s_tr = s_w + kQCoopRows, *s_d = s_w + kQCoopD;
   const int task = __builtin_amdgcn_readfirstlane(a.task_of_slot[slot]);
   if (task < 0) return;
@@ -1702,6 +1703,7 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
     }
     const uint32_t dw = *reinterpret_cast<const uint32_t *>(s_d + (((m0 & 255) + lane) << 2));  // group (event >> 2), word (event & 3)
     const uint32_t x = mod100(w.x), y = mod100(w.y), z = mod1e6(w.z), d = mod1e6(dw);
+    const uint32_t y_free = has_model ? 0u : w.y % (freq_rv ? freq_rv : 1u);
     const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // first guess: every column tested against the thresholds of the quality in front of the window
     uint64_t delm = __ballot(event > 0u && d < s_row[lastq_in * 8u + 2u]);
@@ -1709,8 +1711,13 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
     bool is_sub, is_ins, emitted;
     uint64_t valid, consm;
     for (;;) {
-      st = qcoop_chain(lds, a.init_off, n_chains, s_w, x, delm, q0 == 0, st_in, lane);
-      qv = lds[a.emis_off + __umul24(st - 1u, 100u) + y];
+      if (has_model) {
+        st = qcoop_chain(lds, a.init_off, n_chains, s_w, x, delm, q0 == 0, st_in, lane);
+        qv = lds[a.emis_off + __umul24(st - 1u, 100u) + y];
+      } else {  // an accuracy class outside the model's range: the quality from the class's own table, no state (pbsim.cpp:2218-2222)
+        st = 0;
+        qv = lds[a.freq_off + y_free];
+      }
       qv = (qv < 94u) ? qv : 93u;
       const uint4 row = *reinterpret_cast<const uint4 *>(&s_row[qv * 8u]);
       emitted = ((delm >> lane) & 1ull) == 0;
@@ -1842,8 +1849,7 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm_coop(WalkArgs a) {
       staged = c;
     }
     const int k = (u - ubase) * 4 + wv;
-    const uint32_t has_model = reinterpret_cast<const uint32_t *>(lds)[2];
-    if (k < nc && has_model) qcoop_walk_task(a, lds, s_comp, s_sub, s_row, s_w, a.class_start[c] + k, lane);
+    if (k < nc) qcoop_walk_task(a, lds, s_comp, s_sub, s_row, s_w, a.class_start[c] + k, lane);
   }
 }
 
