@@ -1579,7 +1579,8 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
 // fixed point is the sequential answer; in practice two or three turns (95 % of the deletion draws lie above every quality's
 // threshold and ~2 % below every one: a wrong state in front of a column rarely flips it).  The ordered f64 sum of error
 // probabilities (pbsim.cpp:2309-2313; the %f report and the accuracy histogram depend on its exact value) is added lane by
-// lane in column order.  kFastRv && kHpBits classes with a model only; everything else stays with the lane walker.
+// lane in column order (since round 4 behind the walk: k_qshmm_coop_qsum).  Models whose moduli are all 100 and records with the
+// hp == 11 flag in their bytes (kFastRv && kHpBits); classes without a model take the same steps without the chain.
 // ---------------------------------------------------------------------------
 // LDS of one wave: x[64] u16 | the true chains' states [8 groups][8 chains][8] | three output rows | the deletion draws of 256 columns
 constexpr int kQCoopX = 0, kQCoopStates = 128, kQCoopRows = 640, kQCoopD = 832, kQCoopWaveLds = 1856;
