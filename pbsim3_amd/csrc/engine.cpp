@@ -553,7 +553,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
 // lanes).  Small batches (top-up rounds, the truncated tail reads a record's completion waits for) go to the wave walker
 // entirely, and a batch of a million reads hides its longest lane behind its own bulk.
 // A multiple of 256 (the sort's length bucket).  PBSIM_COOP_LEN overrides: -1 never, n >= 0 that length.
-constexpr int kCoopWorkgroups = 4096 / kCoopWaves, kCoopSmallBatch = 20000, kCoopHugeBatch = 1000000;  // 4096 persistent waves
+constexpr int kCoopWorkgroups = 4096 / kCoopWaves, kCoopSmallBatch = 20000, kQCoopSmallBatch = 60000, kCoopHugeBatch = 1000000;  // 4096 persistent waves
 static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads, bool hp_flag) {
   const bool qs = c->p.method == PBSIM_METHOD_QS;
   if (qs) {  // k_walk_qshmm_coop: moduli of 100, the hp == 11 flag in the sequence bytes (default --hp-del-bias), <= 63 states
@@ -569,7 +569,9 @@ static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads, bool hp_flag) {
   // (QSHMM: the batches of a multi-pass job are large and its job runs at its steady-state regime's rate without -- the wave
   // walker takes the small batches: truncated tail reads, top-up rounds, the small rounds of many ranks)
   if (qs) len = -1;
-  if (n_tasks <= kCoopSmallBatch) len = 0;
+  // (QSHMM, end of round 4 -- the quality sums out of the step, the classes without a model on waves: 50 000 tasks 20.7 ms by
+  // waves against 27.3 by lanes, 100 000 tasks 33.1 against 31.5: every task of a batch of up to 60 000)
+  if (n_tasks <= (qs ? kQCoopSmallBatch : kCoopSmallBatch)) len = 0;
   if (n_tasks >= kCoopHugeBatch) len = -1;
   if (env) len = atoll(env);
   if (len < 0) return INT32_MAX;
