@@ -402,6 +402,8 @@ def main():
     ap.add_argument("--replay-ranks", default="",
                     help="N=1 only: e.g. 2,4,8 -- additionally measure the per-rank critical path of the N-rank job on this one GPU, "
                          "every rank alone against virtual ranks (tools/replay_ranks.py)")
+    ap.add_argument("--collective-us", type=float, default=60.0,
+                    help="--replay-ranks: latency injected per collective (a small RCCL all-gather with pinned staging, end to end)")
     ap.add_argument("--param", action="append", default=[],
                     help="experiment only: override a pbsim_params field, e.g. --param len_sd=0 (not the headline workload)")
     a = ap.parse_args()
@@ -580,7 +582,7 @@ def main():
         replays = {"t1_ms": t1_ms, "table_build_s": t_tab, "table_reads": [len(t.out0) for t in tables], "by_world": {}}
         for n in [int(x) for x in a.replay_ranks.split(",") if x]:
             ctx.release_pools()
-            res = RR.replay(P, C, ctx, tables, n, run_with)
+            res = RR.replay(P, C, ctx, tables, n, run_with, collective_us=a.collective_us)
             res["speedup_if_ranks_never_wait"] = t1_ms / res["max_rank_wall_ms"]
             res["speedup_sync_upper_bound_of_time"] = t1_ms / res["sync_critical_path_ms"] if res["sync_critical_path_ms"] else None
             replays["by_world"][str(n)] = res

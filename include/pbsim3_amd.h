@@ -247,8 +247,10 @@ int pbsim_release_pools(pbsim_ctx *ctx);
  *
  * Several GPUs: one context per GPU ("rank"), every rank holds every record (C1: the caller broadcasts them) and runs
  * the same job; a round of the pipeline gives rank r the r-th block of the round's reads.  The ranks only exchange
- * integers through the caller's pbsim_comm: per round the blocks' pass-0 bases (C3, places every rank's quota prefix) and
- * their cut / text sizes (every rank learns the byte range of its text inside the record's stream), per record the
+ * integers through the caller's pbsim_comm: per round ONE all-gather (C3) of the blocks' pass-0 bases and largest raw
+ * length (places every rank's quota prefix and tells whether any read of the round can touch the quota) together with the
+ * PREVIOUS round's text sizes (every rank learns the byte range of its text inside the record's stream) -- plus a second one for
+ * the cut in the one round of a record that reaches the quota; per record three collectives for the
  * statistics (C2: counters, min/max, the two histograms; the order-dependent accuracy sum is folded in read order).  The
  * concatenation of all ranks' text in offset order is byte for byte what one GPU delivers, and so are the statistics.
  *
@@ -332,8 +334,14 @@ int pbsim_job_counters(pbsim_ctx *ctx, int64_t out[8]);
 int pbsim_job_breakdown(pbsim_ctx *ctx, double out[16]);
 
 /* Which exchange of the round sequence this rank's pbsim_job_run is about to enter, readable from inside a pbsim_comm callback
- * (same thread): [0] 1 = gather A (pass-0 bases of the round's blocks), 2 = gather B (the cut), 3 = gather C (byte counts of the
- * previous round), 4 = a record's statistics merge, 5 = the agreement on pool size and caps in front of the round loop;
+ * (same thread): [0] the kind of exchange -- 6 = "AC", the ONE all-gather of a round that is expected to stay clear of the
+ * quota (8 words per rank: [0] pass-0 bases of the block, [1] walk status, [2] largest raw length drawn in the block, [3] status
+ * of the text sizes, [4] 1 if [5..7] hold the PREVIOUS round's delivery: compressed read bytes, MAF bytes, status); 1 = "A" of
+ * a round that is expected to reach the quota (same 8 words, no delivery part) and 7 = its "BC" ([0] final reads of the block,
+ * [1] a truncated read is due, [2] len_total behind the block, [3] status, [4..7] the previous round's delivery); 2 = "B" on its
+ * own (a round begun as clear that can touch the quota after all: same words, no delivery part); 3 = the pending round's byte
+ * counts on their own (3 words: at a record's merge, at the end of the job); 4 = a record's statistics merge (three
+ * collectives); 5 = the agreement on pool size and caps in front of the round loop;
  * [1] record (0-based index in the job), [2] first read of the round (rank r walks [2] + r * [3] ..), [3] reads per rank,
  * [4] ranks, [5] the record's len_total and [7] its next read in front of the round, [6] its quota.  For communicators that
  * model or replay the other ranks (bench.py --replay-ranks measures an N-rank job's per-rank critical path on one GPU). */

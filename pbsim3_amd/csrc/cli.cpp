@@ -543,7 +543,11 @@ struct PosFile {
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
       cv.wait(lk, [&] { return finishing || !q.empty(); });
-      if (q.empty()) return;
+      if (q.empty()) {  // finished: the descriptor goes back now, not at the end of the job (a genome of thousands of records)
+        if (fd >= 0 && ::close(fd) != 0) failed = true;
+        fd = -1;
+        return;
+      }
       const Piece p = q.front();
       q.pop_front();
       lk.unlock();
@@ -562,17 +566,27 @@ struct PosFile {
     }
     return true;
   }
-  void create(const std::string &p) {
+  // Rank 0 creates / truncates the file (and writes `head`, the SAM / BAM header) before any rank writes, and lets go of the
+  // descriptor: every rank opens the path when its first byte range arrives (write_at) and closes it when the record is done, so
+  // a genome of thousands of records keeps a handful of files open -- the records of the interleave window -- instead of two
+  // per record from the start (ulimit -n is 1024 on most boxes, REF_SEQ_NUM_MAX 9999).
+  void create(const std::string &p, const char *head, int64_t head_bytes) {
     path = p;
     fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (fd < 0) die(": Cannot open output file: %s", p.c_str());
+    if (head_bytes > 0 && !write_now(head, head_bytes, 0)) die(": write error on %s", p.c_str());
+    if (::close(fd) != 0) die(": write error on %s", p.c_str());
+    fd = -1;
   }
-  void attach(const std::string &p) {
-    path = p;
-    fd = ::open(p.c_str(), O_WRONLY);
-    if (fd < 0) die(": Cannot open output file: %s", p.c_str());
-  }
+  void attach(const std::string &p) { path = p; }
   bool write_at(const char *t, int64_t n, int64_t off) {
+    if (fd < 0) {
+      fd = ::open(path.c_str(), O_WRONLY);
+      if (fd < 0) {
+        fprintf(stderr, "ERROR: Cannot open output file: %s\n", path.c_str());
+        return false;
+      }
+    }
     if (!pool) return write_now(t, n, off);
     while (n > 0) {
       const size_t k = (size_t)std::min<int64_t>(n, (int64_t)WritePool::kChunk);
@@ -708,12 +722,8 @@ void open_record(JobFiles &jf, long n, bool creator) {
   if (rf.read.positional) {
     const std::vector<char> h = read_header_bytes(c, jf.ctx, n);
     rf.read.pos.base = (int64_t)h.size();
-    if (creator) {
-      rf.read.pos.create(read_name(c, n));
-      if (!h.empty() && !rf.read.pos.write_at(h.data(), (int64_t)h.size(), 0)) die(": write error on %s", rf.read.pos.path.c_str());
-    } else {
-      rf.read.pos.attach(read_name(c, n));
-    }
+    if (creator) rf.read.pos.create(read_name(c, n), h.data(), (int64_t)h.size());
+    else rf.read.pos.attach(read_name(c, n));
   } else if (creator) {  // sequential consumers exist on a single rank only
     char name[4096];
     snprintf(name, sizeof name, "%s_%04ld", c.prefix.c_str(), n);
@@ -725,7 +735,7 @@ void open_record(JobFiles &jf, long n, bool creator) {
     }
   }
   if (rf.maf.positional) {
-    if (creator) rf.maf.pos.create(maf_name(c, n));
+    if (creator) rf.maf.pos.create(maf_name(c, n), nullptr, 0);
     else rf.maf.pos.attach(maf_name(c, n));
   } else if (creator) {
     char name[4096];
@@ -881,16 +891,26 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
           if (sum <= (gbs && atof(gbs) > 0 ? atof(gbs) : 64.0) * (double)(1LL << 30) / 2.0) {  // one job holds the genome
             mapped = true;
             gi = gm;
-            if (rank0) {  // get_genome_inf's report (pbsim.cpp:902-904, 925, 972, 979)
-              fprintf(stderr, ":::: Reference stats ::::\n\n");
-              fprintf(stderr, "file name : %s\n", c.genome.c_str());
-              fprintf(stderr, "\n");
-              for (long n = 1; n <= gi.num_seq; n++)
-                fprintf(stderr, "ref.%ld (len:%ld) : %s\n", n, gi.len[(size_t)n - 1], gi.id[(size_t)n - 1].c_str());
-              fprintf(stderr, "\n");
-            }
           }
         }
+      }
+      // Every rank maps the file by itself, and a rank that cannot (no shared file system, ENOMEM) would take the fgets branch
+      // with its own collectives while the others sit in the job's: the ranks agree first -- all map, or none does
+      if (comm && comm->world > 1) {
+        int64_t all = mapped ? 1 : 0;
+        if (!comm->all_reduce_i64(comm->user, &all, 1, PBSIM_OP_MIN)) die(": communicator failed");
+        if (!all && mapped) {
+          mapped = false;
+          gi = pbsim::GenomeInfo();  // (the mapping itself goes with `fm` at the end of the scope)
+        }
+      }
+      if (mapped && rank0) {  // get_genome_inf's report (pbsim.cpp:902-904, 925, 972, 979)
+        fprintf(stderr, ":::: Reference stats ::::\n\n");
+        fprintf(stderr, "file name : %s\n", c.genome.c_str());
+        fprintf(stderr, "\n");
+        for (long n = 1; n <= gi.num_seq; n++)
+          fprintf(stderr, "ref.%ld (len:%ld) : %s\n", n, gi.len[(size_t)n - 1], gi.id[(size_t)n - 1].c_str());
+        fprintf(stderr, "\n");
       }
     }
     std::vector<std::thread> ref_writers;
@@ -904,14 +924,20 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
         const pbsim::FastaRecord &R = fm.recs[(size_t)n - 1];
         check(pbsim_job_add_record_lines(ctx, R.lines, R.bytes, R.len));
       }
-      if (rank0)  // <prefix>_NNNN.ref (pbsim.cpp:948-964), written while the records are prepared and simulated
-        for (long n = 1; n <= gi.num_seq; n++)
-          ref_writers.emplace_back([&, n]() {
-            std::string e;
-            if (!pbsim::write_ref_record(c.prefix.c_str(), n, fm.recs[(size_t)n - 1], &e)) {
-              std::lock_guard<std::mutex> lk(ref_mu);
-              ref_failed = true;
-              ref_err = e;
+      // <prefix>_NNNN.ref (pbsim.cpp:948-964), written while the records are prepared and simulated: a small pool of threads
+      // that draw record numbers from a counter (a thread per record was up to REF_SEQ_NUM_MAX = 9999 threads at once -- under a
+      // pids / ulimit -u bound std::thread throws while earlier threads are joinable: std::terminate in a GPU process)
+      std::atomic<long> ref_next{1};
+      if (rank0)
+        for (long t = 0; t < std::min<long>(8, gi.num_seq); t++)
+          ref_writers.emplace_back([&]() {
+            for (long n; (n = ref_next.fetch_add(1)) <= gi.num_seq;) {
+              std::string e;
+              if (!pbsim::write_ref_record(c.prefix.c_str(), n, fm.recs[(size_t)n - 1], &e)) {
+                std::lock_guard<std::mutex> lk(ref_mu);
+                ref_failed = true;
+                ref_err = e;
+              }
             }
           });
       JobFiles jf;
@@ -937,7 +963,7 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       for (auto &t : ref_writers) t.join();
       if (ref_failed) die(": %s", ref_err.c_str());
       phase(".ref files written");
-      if (!(getenv("PBSIM_CLI_LEAVE_CONTEXT") && world == 1)) check(pbsim_job_begin(ctx, 1));
+      if (!(getenv("PBSIM_CLI_LEAVE_CONTEXT") && *getenv("PBSIM_CLI_LEAVE_CONTEXT") == '1' && world == 1)) check(pbsim_job_begin(ctx, 1));
       else fm.map = nullptr;  // (3 GB of mapped file: unmapped with the process)
     } else {
     if (rank0 && !pbsim::split_genome(c.genome.c_str(), c.prefix.c_str(), &gi, &err)) die(": %s", err.c_str());
@@ -1164,9 +1190,8 @@ extern "C" int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int
       }
       PosFile fr, fm;
       if (rank0) {
-        fr.create(rname);
-        fm.create(mname);
-        if (!h.empty() && !fr.write_at(h.data(), (int64_t)h.size(), 0)) die(": write error on %s", rname.c_str());
+        fr.create(rname, h.data(), (int64_t)h.size());
+        fm.create(mname, nullptr, 0);
         if (!c.no_gzip) {  // BAM: the BGZF end-of-file marker; .gz: an empty member keeps an empty output a valid gzip file
           if ((bam || tot_r == 0) && !fr.write_at((const char *)kBgzfEof, sizeof kBgzfEof, tot_r)) die(": write error on %s", rname.c_str());
           if (tot_m == 0 && !fm.write_at((const char *)kBgzfEof, sizeof kBgzfEof, 0)) die(": write error on %s", mname.c_str());

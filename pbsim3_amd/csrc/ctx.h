@@ -256,6 +256,7 @@ struct Slot {
   int64_t b_trunc = -1;                // truncate_remaining of the batch (a re-walk begins it again)
   double b_factor = 2.0;               // scratch factor of the batch's layout
   int64_t b_pass0 = 0;
+  int64_t b_max_raw = 0;               // largest raw length a read of the batch drew (wgs; DeviceFlags::max_rawlen)
   pbsim_batch_info b_info;
 };
 
@@ -372,6 +373,7 @@ int64_t batch_capacity_for(const pbsim_ctx *c, int64_t ref_len);  // reads one b
 // the two halves of pbsim_batch_finalize on the selected slot: the quota cut, then text sizes + scans + text emission
 int finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbsim_batch_info *out);
 int finalize_text(pbsim_ctx *c, pbsim_batch_info *info);
+int finalize_uncut(pbsim_ctx *c, pbsim_batch_info *out);
 std::string sam_header_text(const pbsim_ctx *c, int64_t unit);
 // pbsim.cpp:3986-4005 / 2293-2316 for the n_final reads of the selected slot's finalized batch, into `st`
 int account_slot(pbsim_ctx *c, StatsAcc *st);

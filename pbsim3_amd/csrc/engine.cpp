@@ -666,6 +666,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
   h.acc = c->s().d_acc.as<uint8_t>();
   h.read_unit = nullptr;
   h.is_templ = 0;
+  h.max_rawlen = trans ? nullptr : &flags->max_rawlen;
   if (trans) {
     h.is_templ = c->p.strategy == PBSIM_STRATEGY_TEMPL;
     h.read_unit = c->d_read_unit.as<int32_t>() + (first_read - 1);
@@ -926,6 +927,7 @@ int pbsim_batch_walk_end(pbsim_ctx *c, int64_t *pass0_bases) {
   }
   c->s().b_walked = true;
   c->s().b_pass0 = f.sums[0];
+  c->s().b_max_raw = (int64_t)f.max_rawlen;
   if (pass0_bases) *pass0_bases = f.sums[0];
   return PBSIM_SUCCEEDED;
 }
@@ -1056,6 +1058,24 @@ extern "C++" int pbsim::finalize_cut(pbsim_ctx *c, int64_t len_total_before, pbs
     bi.quota_reached = (n_final < c->s().b_n) || (bi.len_total_after >= quota);
     bi.need_truncated_read = (n_final < c->s().b_n) && (bi.len_total_after < quota);
   }
+  c->s().b_info = bi;
+  *out = bi;
+  return PBSIM_SUCCEEDED;
+}
+
+// The cut of a batch that cannot touch the quota -- len_total_before + its pass-0 bases + its largest raw length <= quota, so
+// pbsim.cpp:3792-3800 neither stops nor truncates in it -- needs no kernel and no flag read: every read is final.  The job's
+// rounds take this path before they know len_total_before (job.cpp: it arrives with the round's one exchange); the caller
+// patches len_total_after once it does.
+extern "C++" int pbsim::finalize_uncut(pbsim_ctx *c, pbsim_batch_info *out) {
+  if (!c || !c->s().b_walked) return fail("pbsim_batch_finalize: no walked batch");
+  NEED_DEVICE(c);
+  pbsim_batch_info bi;
+  memset(&bi, 0, sizeof bi);
+  bi.first_read = c->s().b_first;
+  bi.n_reads = c->s().b_n;
+  bi.n_final = c->s().b_n;
+  bi.len_total_after = c->s().b_pass0;  // + len_total_before (the caller's, once known)
   c->s().b_info = bi;
   *out = bi;
   return PBSIM_SUCCEEDED;
@@ -1295,14 +1315,19 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   int lane_index = 0;
   for (Slot &slot : c->slots)
     if (&slot.df[1] == &sl) lane_index = 1;
-  for (int i = 0; i < 2; i++)
-    if (!c->df_streams[lane_index][i]) HIP_OK(hipStreamCreateWithFlags(&c->df_streams[lane_index][i], hipStreamNonBlocking));
-  hipStream_t lane_streams[2] = {c->df_streams[lane_index][0], c->df_streams[lane_index][1]};
+  hipStream_t lane_streams[2];
   if (sl.own_streams) {  // a lane that runs BESIDE the bulk deliveries (the tail chains' worker): not behind their pieces in one stream
+    // (and it never touches the context-wide streams below: their lazy creation belongs to the bulk worker's lane threads
+    // alone -- lane 0 and lane 1 create different elements --, so no two threads race for one handle)
     for (int i = 0; i < 2; i++)
       if (!sl.own[i]) HIP_OK(hipStreamCreateWithFlags(&sl.own[i], hipStreamNonBlocking));
     lane_streams[0] = sl.own[0];
     lane_streams[1] = sl.own[1];
+  } else {
+    for (int i = 0; i < 2; i++)
+      if (!c->df_streams[lane_index][i]) HIP_OK(hipStreamCreateWithFlags(&c->df_streams[lane_index][i], hipStreamNonBlocking));
+    lane_streams[0] = c->df_streams[lane_index][0];
+    lane_streams[1] = c->df_streams[lane_index][1];
   }
   sl.stream = lane_streams[0];
   // The look-back trusts any status word that carries the launch's epoch and a flag, and the words are never cleared between

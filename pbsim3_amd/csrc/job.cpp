@@ -5,10 +5,15 @@
 // (pbsim.cpp:667-759, 3792-4080).  Here every record is resident in HBM and the loop runs as rounds:
 //
 //   round   = W blocks of n reads of one record (W = ranks), rank r walks block r; speculative, un-truncated lengths
-//   pop     = rounds finish in the order they were begun; per round three small all-gathers:
-//               A  pass-0 bases of every block          -> every rank's len_total in front of its block (quota prefix)
-//               B  (n_final, need_truncated, len_total_after, status) of every block -> the cut
-//               C  (compressed bytes of both streams, status) of the previous round -> every rank's byte range
+//   pop     = rounds finish in the order they were begun.  What the ranks exchange per round (round 5: ONE all-gather for a
+//             round that stays clear of the quota, two for the round that places the cut; rounds 2-4: three for every round):
+//               A  pass-0 bases + largest raw length of every block -> every rank's len_total in front of its block (the quota
+//                  prefix) and whether any read of the round can touch the quota at all (pbsim.cpp:3792-3800: a read stops or
+//                  is truncated only if len_total + its raw length > quota)
+//               B  (n_final, need_truncated, len_total_after, status) of every block -> the cut; skipped -- every value follows
+//                  from A -- when len_total + sum of the blocks' pass-0 bases + the largest raw length <= quota
+//               C  (compressed bytes of both streams, status) of the PREVIOUS round -> every rank's byte range; rides in the
+//                  round's A message (rounds expected to stay clear of the quota: "AC") or in its B message ("BC")
 //   cut     = the first block the quota rule stops in (pbsim.cpp:3792-3800); later blocks / rounds of the record are void
 //   tail    = the truncated reads behind the cut, one at a time (each depends on the one before), on the cut's rank only,
 //             on a slot of their own, polled between rounds -- no other rank waits for them
@@ -65,6 +70,8 @@ struct Round {
   int rec, slot;
   int64_t first, n_per;
   double mean;               // bases per read assumed when it was begun
+  bool clear;                // expected to end clear of the quota (decided when it was begun, from gathered state: the same on
+                             // every rank): its text is emitted before the exchange, which then carries A and C at once
 };
 
 // One host thread that takes finished batches off the main loop's hands: GPU compression + copy into pinned memory, the sink
@@ -77,6 +84,43 @@ struct Worker {
   std::deque<std::function<void()>> q;
   bool stop = false, running = false;
   int active = 0;
+  // Second halves of tasks that must wait for something only ANOTHER thread brings about (a chain's hand-over to the sink waits
+  // for its record's bulk rounds): parked here by the task itself (defer(), on this thread) instead of blocking the FIFO -- a
+  // task queued behind it may be what the main loop is waiting for.  Entries of one key keep their order; the thread looks at
+  // them after every task and every millisecond while any is parked.
+  struct Deferred {
+    int key;
+    std::function<bool()> ready;
+    std::function<void()> run;
+  };
+  std::deque<Deferred> parked;   // this thread only
+  int n_parked = 0;              // under mu
+  void defer(int key, std::function<bool()> ready, std::function<void()> run) {
+    parked.push_back(Deferred{key, std::move(ready), std::move(run)});
+    std::lock_guard<std::mutex> lk(mu);  // (drain()'s predicate reads it under the lock: no lost wake-up)
+    n_parked++;
+  }
+  bool run_parked() {  // on the worker thread, no lock held
+    bool any = false;
+    for (size_t i = 0; i < parked.size();) {
+      bool first_of_key = true;
+      for (size_t j = 0; j < i; j++) first_of_key &= parked[j].key != parked[i].key;
+      if (first_of_key && parked[i].ready()) {
+        Deferred d = std::move(parked[i]);
+        parked.erase(parked.begin() + (long)i);
+        d.run();
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          n_parked--;
+        }
+        any = true;
+        i = 0;
+      } else {
+        i++;
+      }
+    }
+    return any;
+  }
   void start(int device) {
     running = true;
     th = std::thread([this, device]() {
@@ -85,18 +129,21 @@ struct Worker {
         std::function<void()> f;
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return stop || !q.empty(); });
-          if (q.empty()) return;
-          f = std::move(q.front());
-          q.pop_front();
-          active++;
+          if (parked.empty()) cv.wait(lk, [&] { return stop || !q.empty(); });
+          else cv.wait_for(lk, std::chrono::milliseconds(1), [&] { return stop || !q.empty(); });
+          if (q.empty() && parked.empty()) return;
+          if (!q.empty()) {
+            f = std::move(q.front());
+            q.pop_front();
+            active++;
+          }
         }
-        f();
-        {
+        if (f) {
+          f();
           std::lock_guard<std::mutex> lk(mu);
           active--;
         }
-        cv_idle.notify_all();
+        if (run_parked() || f) cv_idle.notify_all();
       }
     });
   }
@@ -110,7 +157,7 @@ struct Worker {
   void drain() {
     if (!running) return;
     std::unique_lock<std::mutex> lk(mu);
-    cv_idle.wait(lk, [&] { return q.empty() && active == 0; });
+    cv_idle.wait(lk, [&] { return q.empty() && active == 0 && n_parked == 0; });
   }
   void finish() {
     if (!running) return;
@@ -135,8 +182,8 @@ struct Delivery {
   std::shared_ptr<std::promise<int>> stage1;
   std::future<int> stage1_done;
   int64_t sizes[2] = {0, 0};
-  std::vector<int64_t> B;   // gather B of the round
-  int cut = -1;
+  int ok1 = PBSIM_SUCCEEDED;          // stage 1's outcome, once waited for (wait_pending)
+  double t_wait0 = 0, t_wait1 = 0;
 };
 
 struct Job {
@@ -155,7 +202,7 @@ struct Job {
   double bd_wait_walk = 0, bd_finalize = 0, bd_wait_bytes = 0, bd_account = 0, bd_tail_block = 0, bd_drain = 0, bd_slot_wait = 0,
          bd_merge = 0, bd_begin = 0, bd_tail_steps = 0;
   double bd_worker_busy = 0;  // written by the worker thread only, read after it has finished
-  int64_t n_topup = 0, n_tail_reads = 0;
+  int64_t n_topup = 0, n_tail_reads = 0, n_clear_missed = 0, n_exchanges = 0;
   bool trace = false;
   double t_start = 0;
   bool peer_failed = false;   // the failure came from another rank's status word (no need to abort the communicator)
@@ -175,12 +222,33 @@ struct Job {
   // deliveries of a record that are with the worker (posted, not finished): a record's merge waits for ITS bytes only -- the
   // worker is FIFO, so that is as soon as it has passed them -- not for the rounds of later records behind them
   std::unique_ptr<std::atomic<int>[]> rec_out;
+  // ... and the BULK deliveries among them: a record's tail bytes follow its bulk bytes in both streams, but they travel on
+  // another thread (tail_worker) -- the tail waits here until the bulk worker has handed the record's last round to the sink,
+  // so a sink that takes a stream front to back (one rank: "the offsets simply run up", include/pbsim3_amd.h; the CLI's
+  // --gzip host and samtools consumers check it) never sees the tail first.  Every bulk delivery of the record has
+  // been POSTED by the time its tail is (tail_poll: not while the record's last sizes are pending), so zero means "all through".
+  std::unique_ptr<std::atomic<int>[]> rec_bulk;
+  // ... and the record's bulk rounds whose sizes have not been exchanged or whose statistics have not been accounted yet (main
+  // loop: +1 when a round's delivery is created, -1 behind its accounting).  A chain of tail reads is collected, its text
+  // emitted and compressed as soon as its walks have finished -- also while the record's last round is still pending --, and
+  // only the hand-over to the sink and the statistics wait: for this counter (the record's byte offsets are final, its bulk
+  // statistics in read order) and for rec_bulk.  (Round 4 collected the chain only behind the exchange of the record's last
+  // sizes: on the rank that owns the tails the record's merge then waited 8-10 ms for the chain's text and compression --
+  // profiles/r05_replay_*.)
+  std::unique_ptr<std::atomic<int>[]> rec_rounds_open;
+  void round_closed(int rec) {
+    --rec_rounds_open[(size_t)rec];
+    { std::lock_guard<std::mutex> lk(out_mu); }
+    out_cv.notify_all();
+  }
+  std::atomic<bool> giving_up{false};  // the job failed on the main loop: nobody will close the rounds a tail waits for
   void wait_record(int rec) {
     std::unique_lock<std::mutex> lk(out_mu);
     out_cv.wait(lk, [&] { return rec_out[(size_t)rec].load() == 0; });
   }
-  void delivered_one(std::atomic<int> *out) {  // on a worker thread, at the end of a delivery
+  void delivered_one(std::atomic<int> *out, std::atomic<int> *bulk = nullptr) {  // on a worker thread, at the end of a delivery
     --*out;
+    if (bulk) --*bulk;
     { std::lock_guard<std::mutex> lk(out_mu); }
     out_cv.notify_all();
   }
@@ -222,6 +290,7 @@ struct Job {
     const double t0 = now_us();
     const int ok = comm->all_gather_i64(comm->user, send, n, recv->data());
     comm_us += now_us() - t0;
+    n_exchanges++;
     return ok ? PBSIM_SUCCEEDED : fail("pbsim_comm.all_gather_i64 failed");
   }
 
@@ -234,8 +303,8 @@ struct Job {
     return false;
   }
   // The last two slots belong to the chains of truncated tail reads (a handful of reads: their pools stay small), the others
-  // to the rounds.  At most two records are open at a time (run(): a record is merged before the record after the next
-  // begins), so a record's chain never waits for another record's.
+  // to the rounds.  max(2, interleave) records are open at a time (run(): a record is merged before the record that many
+  // places behind it begins; the CLI interleaves four): a third chain waits its turn for a slot (tail_poll, tail_waiting).
   static constexpr int kTailSlot = kMaxSlots - 2;
   int free_slot() const {
     for (int s = 0; s < kTailSlot; s++)
@@ -280,7 +349,12 @@ struct Job {
       }
     }
   }
-  void drop_everything() {
+  void drop_everything(bool failing = true) {
+    if (failing) {  // nobody will close the rounds (or deliver the bytes) a chain's hand-over is waiting for
+      giving_up = true;
+      { std::lock_guard<std::mutex> lk(out_mu); }
+      out_cv.notify_all();
+    }
     worker.drain();
     tail_worker.drain();
     for (const Round &r : fifo) drop_round(r);
@@ -417,9 +491,10 @@ struct Job {
     auto prom = d->stage1;
     int64_t *sizes = d->sizes;
     const int64_t read_at = R->read_off, maf_at = R->maf_off;  // one rank: the offsets simply run up (streamed in stage 1)
-    std::atomic<int> *out = &rec_out[(size_t)d->rec];
+    std::atomic<int> *out = &rec_out[(size_t)d->rec], *bulk = &rec_bulk[(size_t)d->rec];
     ++*out;
-    worker.post([this, sl, R, prom, sizes, read_at, maf_at, out]() {
+    ++*bulk;
+    worker.post([this, sl, R, prom, sizes, read_at, maf_at, out, bulk]() {
       const double w0 = now_us();
       int ok = PBSIM_SUCCEEDED;
       if (wants_text() && hipEventSynchronize(sl->ev_text) != hipSuccess) ok = fail("hipEventSynchronize failed (text emission)");
@@ -440,7 +515,7 @@ struct Job {
       if (trace)
         fprintf(stderr, "[pbsim job r%d] t=%.1f ms   worker: bytes of rec %lld on their way for %.1f ms (%lld + %lld)\n", rank,
                 (w0 - t_start) / 1e3, (long long)R->ref.unit, (now_us() - w0) / 1e3, (long long)sizes[0], (long long)sizes[1]);
-      delivered_one(out);
+      delivered_one(out, bulk);
       prom->set_value(ok);
     });
   }
@@ -456,30 +531,41 @@ struct Job {
     const double t0 = now_us();
     const int ok = account_of(c, *sl, &acct_rec->st);
     bd_account += now_us() - t0;
+    round_closed((int)(acct_rec - recs.data()));
     return ok;
   }
-  int complete_pending(bool defer_account = false) {
-    if (!account_deferred()) return PBSIM_FAILED;
+  // The pending round's sizes: wait_pending() = this rank's are known (stage 1 has finished), apply_pending() = all ranks'
+  // have been exchanged (S: stride words per rank, the three C words at `at`) -- by an exchange of their own
+  // (complete_pending) or inside a round's A or B message (process_round).
+  int wait_pending(int64_t c3[3]) {
+    c3[0] = c3[1] = c3[2] = 0;
+    if (!pending) return PBSIM_SUCCEEDED;
+    const double t0 = now_us();
+    const int ok1 = pending->stage1_done.get();
+    pending->ok1 = ok1;
+    pending->t_wait0 = t0;
+    pending->t_wait1 = now_us();
+    bd_wait_bytes += pending->t_wait1 - t0;
+    c3[0] = pending->mine ? pending->sizes[0] : 0;
+    c3[1] = pending->mine ? pending->sizes[1] : 0;
+    c3[2] = ok1 ? 0 : 1;
+    return PBSIM_SUCCEEDED;
+  }
+  int apply_pending(const std::vector<int64_t> &S, int stride, int at, bool defer_account) {
     if (!pending) return PBSIM_SUCCEEDED;
     std::unique_ptr<Delivery> d = std::move(pending);
     Rec &R = recs[(size_t)d->rec];
-    const double t0 = now_us();
-    const int ok1 = d->stage1_done.get();
-    const double t1 = now_us();
-    bd_wait_bytes += t1 - t0;
-    int64_t mine2[3] = {d->mine ? d->sizes[0] : 0, d->mine ? d->sizes[1] : 0, ok1 ? 0 : 1};
-    std::vector<int64_t> S;
-    progress(3, d->rec, 0, d->n_per);
-    if (!gather(mine2, 3, &S)) return PBSIM_FAILED;
+    const int ok1 = d->ok1;
     int64_t read_at = R.read_off, maf_at = R.maf_off, read_all = 0, maf_all = 0, bad = 0;
     for (int q = 0; q < W; q++) {
+      const int64_t *v = &S[(size_t)q * stride + at];
       if (q < rank) {
-        read_at += S[(size_t)q * 3];
-        maf_at += S[(size_t)q * 3 + 1];
+        read_at += v[0];
+        maf_at += v[1];
       }
-      read_all += S[(size_t)q * 3];
-      maf_all += S[(size_t)q * 3 + 1];
-      bad += S[(size_t)q * 3 + 2];
+      read_all += v[0];
+      maf_all += v[1];
+      bad += v[2];
     }
     if (bad) {
       if (ok1) peer_failed = true;
@@ -498,22 +584,36 @@ struct Job {
       acct_rec = &R;
       if (!defer_account && !account_deferred()) return PBSIM_FAILED;
       if (flush || plain) {
-        std::atomic<int> *out = &rec_out[(size_t)d->rec];
+        std::atomic<int> *out = &rec_out[(size_t)d->rec], *bulk = &rec_bulk[(size_t)d->rec];
         ++*out;
-        worker.post([this, sl, Rp, slot, flush, read_at, maf_at, out]() {
+        ++*bulk;
+        worker.post([this, sl, Rp, slot, flush, read_at, maf_at, out, bulk]() {
           const int ok = flush ? arena_flush(*sl, Rp->ref.unit, read_at, maf_at) : sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
           if (!ok) worker_fail();
           delivering[slot] = false;
-          delivered_one(out);
+          delivered_one(out, bulk);
         });
       } else {
         delivering[slot] = false;  // streamed in stage 1 (or nothing to deliver): the slot is free
       }
+    } else {
+      round_closed(d->rec);  // (a block behind the cut: nothing to place, nothing to account)
     }
     if (trace)
       fprintf(stderr, "[pbsim job r%d] t=%.1f ms rec %d delivery: waited %.1f ms for the bytes (%lld + %lld)\n", rank,
-              (t0 - t_start) / 1e3, d->rec + 1, (t1 - t0) / 1e3, (long long)d->sizes[0], (long long)d->sizes[1]);
+              (d->t_wait0 - t_start) / 1e3, d->rec + 1, (d->t_wait1 - d->t_wait0) / 1e3, (long long)d->sizes[0], (long long)d->sizes[1]);
     return check_worker();
+  }
+  // an exchange of its own for the pending round's sizes (a record's merge, the end of the job, the retry with smaller caps)
+  int complete_pending(bool defer_account = false) {
+    if (!account_deferred()) return PBSIM_FAILED;
+    if (!pending) return PBSIM_SUCCEEDED;
+    int64_t mine2[3];
+    if (!wait_pending(mine2)) return PBSIM_FAILED;
+    std::vector<int64_t> S;
+    progress(3, pending->rec, 0, pending->n_per);
+    if (!gather(mine2, 3, &S)) return PBSIM_FAILED;
+    return apply_pending(S, 3, 0, defer_account);
   }
 
   // ---- the tail of a record (owner rank only) ------------------------------------------------------------------------
@@ -545,14 +645,18 @@ struct Job {
           // both chain slots are taken: collect the other records' chains that have come through (at most one cannot be -- the
           // record whose last round's sizes are still pending), then a slot comes back from the chains' worker
           for (size_t o = 0; o < recs.size(); o++)
-            if ((int)o != rec && recs[o].tail_slot >= 0 && !(pending && pending->rec == (int)o) && !tail_poll((int)o, true)) return PBSIM_FAILED;
-          tail_worker.drain();
+            if ((int)o != rec && recs[o].tail_slot >= 0 && !tail_poll((int)o, true)) return PBSIM_FAILED;
+          // (not a drain of the chains' worker: the hand-over of the chain whose record's last sizes are still pending waits for
+          // an exchange that only this thread can make -- but that is one record at most, the other slot's chain comes through)
+          while (free_tail_slot() < 0 && !wfailed) {
+            std::unique_lock<std::mutex> lk(tail_worker.mu);
+            tail_worker.cv_idle.wait_for(lk, std::chrono::milliseconds(1));
+          }
         }
         if (!tail_begin(R)) return PBSIM_FAILED;
         if (R.tail_waiting) return block ? fail("internal: no slot for the truncated reads") : PBSIM_SUCCEEDED;
       }
       if (R.tail_slot < 0) return PBSIM_SUCCEEDED;
-      if (pending && pending->rec == rec) return block ? fail("internal: tail before the record's last sizes") : PBSIM_SUCCEEDED;
       c->cur = R.tail_slot;
       if (!block && hipEventQuery(c->s().ev3) != hipSuccess) return PBSIM_SUCCEEDED;
       const double t0 = now_us();
@@ -565,27 +669,60 @@ struct Job {
       delivering[slot] = true;
       std::atomic<int> *out = &rec_out[(size_t)rec];
       ++*out;
-      // (the record's bulk rounds have been exchanged and accounted -- pending is not one of them --, so its byte offsets are
-      // final and its statistics in read order when this runs)
-      tail_worker.post([this, sl, Rp, slot, out]() {
+      // The chain's text is compressed (or fetched) at once, into memory of the lambda's own; the hand-over waits until the
+      // record's bulk rounds have been exchanged and accounted (its byte offsets are final, its statistics in read order) and
+      // their bytes have reached the sink.
+      tail_worker.post([this, sl, Rp, slot, out, rec]() {
         int ok = PBSIM_SUCCEEDED;
-        int64_t nr = 0, nm = 0;
+        std::string zr, zm;  // the chain's members (a few reads: KBs)
+        const pbsim_batch_info &bi2 = sl->b_info;
         if (wants_text() && hipEventSynchronize(sl->ev_text) != hipSuccess) ok = fail("hipEventSynchronize failed (text emission)");
-        const int64_t read_at = Rp->read_off + Rp->tail_read, maf_at = Rp->maf_off + Rp->tail_maf;
         if (!ok) {
         } else if (deflated()) {
-          ok = stream_deflated(*sl, Rp->ref.unit, read_at, maf_at, &nr, &nm);
+          ok = both_lanes(*sl, [&](int which) -> int {
+            const int64_t n = which == 0 ? bi2.read_text_bytes : bi2.maf_text_bytes;
+            if (!(which == 0 ? sink->on_read_text : sink->on_maf_text) || n == 0) return PBSIM_SUCCEEDED;
+            std::string *z = which == 0 ? &zr : &zm;
+            const uint8_t *d = which == 0 ? sl->d_read_text.as<uint8_t>() : sl->d_maf_text.as<uint8_t>();
+            return deflate_pieces(c, sl->df[which], d, n, [z](const char *p, int64_t k) {
+              z->append(p, (size_t)k);
+              return PBSIM_SUCCEEDED;
+            });
+          });
         } else if (wants_text()) {
-          ok = fetch_plain(*sl) && sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
-          nr = sink->on_read_text ? sl->b_info.read_text_bytes : 0;
-          nm = sink->on_maf_text ? sl->b_info.maf_text_bytes : 0;
+          ok = fetch_plain(*sl);
         }
-        if (ok) ok = account_of(c, *sl, &Rp->st);
-        Rp->tail_read += nr;
-        Rp->tail_maf += nm;
         if (!ok) worker_fail();
-        delivering[slot] = false;
-        delivered_one(out);
+        const std::string err1 = ok ? std::string() : g_err;
+        auto members = std::make_shared<std::pair<std::string, std::string>>(std::move(zr), std::move(zm));
+        tail_worker.defer(
+            rec,
+            [this, rec]() {
+              return wfailed.load() || giving_up.load() ||
+                     (rec_rounds_open[(size_t)rec].load() == 0 && (!wants_text() || rec_bulk[(size_t)rec].load() == 0));
+            },
+            [this, sl, Rp, slot, out, ok, members]() {
+              int ok2 = ok && !giving_up && !wfailed;
+              const int64_t read_at = Rp->read_off + Rp->tail_read, maf_at = Rp->maf_off + Rp->tail_maf;
+              int64_t nr = 0, nm = 0;
+              if (!ok2) {
+              } else if (deflated()) {
+                nr = (int64_t)members->first.size();
+                nm = (int64_t)members->second.size();
+                if (nr && !call_sink(0, Rp->ref.unit, members->first.data(), nr, read_at)) ok2 = fail("sink aborted (read text)");
+                if (ok2 && nm && !call_sink(1, Rp->ref.unit, members->second.data(), nm, maf_at)) ok2 = fail("sink aborted (MAF text)");
+              } else if (wants_text()) {
+                ok2 = sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
+                nr = sink->on_read_text ? sl->b_info.read_text_bytes : 0;
+                nm = sink->on_maf_text ? sl->b_info.maf_text_bytes : 0;
+              }
+              if (ok2) ok2 = account_of(c, *sl, &Rp->st);
+              Rp->tail_read += nr;
+              Rp->tail_maf += nm;
+              if (ok && !ok2 && !giving_up && !wfailed) worker_fail();
+              delivering[slot] = false;
+              delivered_one(out);
+            });
       });
       reads_walked += bi.n_final;
       reads_delivered += bi.n_final;
@@ -674,7 +811,15 @@ struct Job {
     if (trace) fprintf(stderr, "[pbsim job r%d] begin rec %d first=%lld n_per=%lld\n", rank, rec + 1, (long long)R.spec_read, (long long)n_per);
     if (!walk_begin(c, R.ref, R.spec_read + (int64_t)rank * n_per, n_per, -1)) return PBSIM_FAILED;
     bd_begin += now_us() - tb;
-    fifo.push_back(Round{rec, s, R.spec_read, n_per, mean});
+    // Will the round end clear of the quota?  Expected bases behind it against the quota, with room for what the estimate can
+    // be off by (the mean is measured from the first round on; the sum of n gamma lengths spreads by ~0.8 / sqrt(n)) and for the
+    // longest read.  A wrong guess costs time only (process_round: a clear round that does touch the quota emits its text again
+    // behind the cut, an unclear one that does not pays one exchange more); PBSIM_JOB_CLEAR=0 / 1 forces it (tests).
+    const double after = R.spec_total + (double)W * (double)n_per * mean;
+    static const char *force_clear = getenv("PBSIM_JOB_CLEAR");
+    const bool clear = force_clear ? atoi(force_clear) != 0
+                                   : (double)R.quota - after > 0.04 * (double)W * (double)n_per * mean + 2.0 * (double)std::min<int64_t>(c->p.len_max, R.ref.len);
+    fifo.push_back(Round{rec, s, R.spec_read, n_per, mean, clear});
     R.spec_read += (int64_t)W * n_per;
     R.spec_total += (double)W * (double)n_per * mean;
     reads_walked += n_per;
@@ -682,6 +827,19 @@ struct Job {
     return PBSIM_SUCCEEDED;
   }
 
+  // One round comes back.  Two shapes, chosen when the round was begun (Round::clear, the same on every rank):
+  //   clear   text of all n reads emitted at once (finalize_uncut: no cut kernel, no `before` needed) -> wait for the previous
+  //           round's bytes -> ONE exchange "AC": pass-0 bases, largest raw length, status | the previous round's sizes.  If the
+  //           gathered values say that no read of the round can touch the quota (the usual case) every block's B values follow
+  //           from A and the round is done; if not, the cut is placed after all: text again + exchange B.
+  //   unclear (the round that is expected to reach the quota) exchange A -> cut + text -> wait for the previous round's bytes
+  //           -> exchange "BC": the cut | the previous round's sizes.
+  // Neither shape waits for the previous round's bytes before this round's text is on its way, so the link never idles for a
+  // text emission.  Message layout (8 words per rank, one layout for all four kinds of exchange so a communicator can tell them
+  // apart by pbsim_job_progress alone): A part [0] pass-0 bases [1] code [2] largest raw length | B part [0] n_final
+  // [1] need_truncated [2] len_total_after | [3] status of the text sizes | C part [4] has sizes [5] read bytes [6] MAF bytes
+  // [7] delivery status.
+  static constexpr int kMsg = 8;
   int process_round() {
     const Round rd = fifo.front();
     fifo.pop_front();
@@ -697,27 +855,59 @@ struct Job {
     if (wfailed) code = 2;
     const double t1 = now_us();
     bd_wait_walk += t1 - t0;
+    // chains of truncated reads that have finished meanwhile: their text and compression run beside this round (the hand-over
+    // waits for their record's sizes by itself)
+    for (size_t r = 0; r < recs.size(); r++)
+      if ((recs[r].tail_slot >= 0 || recs[r].tail_waiting) && !tail_poll((int)r, false)) return PBSIM_FAILED;
+    c->cur = rd.slot;
+    const int64_t max_raw = c->s().b_max_raw;
+    pbsim_batch_info bi;
+    memset(&bi, 0, sizeof bi);
+    int fin_ok = PBSIM_SUCCEEDED;
+    double t_fin = 0;
     std::vector<int64_t> A, B;
-    const int64_t sendA[2] = {pass0, code};
-    progress(1, rd.rec, rd.first, rd.n_per);
-    if (!gather(sendA, 2, &A)) return PBSIM_FAILED;
-    int64_t worst = 0, pass0_sum = 0, before = R.len_total;
-    for (int q = 0; q < W; q++) {
-      worst = std::max(worst, A[(size_t)q * 2 + 1]);
-      pass0_sum += A[(size_t)q * 2];
-      if (q < rank) before += A[(size_t)q * 2];
+    int64_t msg[kMsg] = {pass0, code, max_raw, 0, 0, 0, 0, 0};
+    bool c_applied = false;
+    if (rd.clear) {
+      if (code == 0) {  // every read final: the text leaves now, `before` arrives with the exchange
+        const double tf = now_us();
+        fin_ok = finalize_uncut(c, &bi) && finalize_text(c, &bi);
+        if (!fin_ok) my_err = g_err;
+        t_fin += now_us() - tf;
+      }
+      msg[3] = fin_ok ? 0 : 1;
+      if (pending) {
+        msg[4] = 1;
+        if (!wait_pending(&msg[5])) return PBSIM_FAILED;
+      }
+      progress(6, rd.rec, rd.first, rd.n_per);
+      if (!gather(msg, kMsg, &A)) return PBSIM_FAILED;
+      c_applied = true;
+    } else {
+      progress(1, rd.rec, rd.first, rd.n_per);
+      if (!gather(msg, kMsg, &A)) return PBSIM_FAILED;
     }
-    if (worst == 2) {
+    int64_t worst = 0, pass0_sum = 0, before = R.len_total, raw_all = 0, bad_fin = 0;
+    for (int q = 0; q < W; q++) {
+      worst = std::max(worst, A[(size_t)q * kMsg + 1]);
+      pass0_sum += A[(size_t)q * kMsg];
+      raw_all = std::max(raw_all, A[(size_t)q * kMsg + 2]);
+      bad_fin += A[(size_t)q * kMsg + 3];
+      if (q < rank) before += A[(size_t)q * kMsg];
+    }
+    // (the previous round's sizes came with a clear round's message: place its bytes first, whatever this round turns out to be)
+    if (c_applied && worst != 2 && !apply_pending(A, kMsg, 5, true)) return PBSIM_FAILED;
+    if (worst == 2 || (worst == 0 && bad_fin)) {
       drop_everything();
       if (wfailed) return check_worker();
-      if (code != 2) peer_failed = true;
-      return fail(code == 2 ? my_err : "another rank of the job failed");
+      if (code != 2 && fin_ok) peer_failed = true;
+      return fail(code == 2 || !fin_ok ? my_err : "another rank of the job failed");
     }
     if (worst == 1) {
       // skewed lengths: some rank's block does not fit its scratch pool.  Everything in flight is void (later rounds were sized
       // with the same cap); every record falls back to what is confirmed and retries with half the cap.
       if (!complete_pending()) return PBSIM_FAILED;
-      drop_everything();
+      drop_everything(false);
       for (Rec &r : recs) {
         r.spec_read = r.next_read;
         r.spec_total = (double)r.len_total;
@@ -726,33 +916,56 @@ struct Job {
       }
       return PBSIM_SUCCEEDED;
     }
-    pbsim_batch_info bi;
-    memset(&bi, 0, sizeof bi);
-    // a failure here travels in gather B's status word: every rank leaves the job at the same collective
-    const double tf = now_us();
-    const int fin_ok = finalize_cut(c, before, &bi) && finalize_text(c, &bi);
-    if (!fin_ok) my_err = g_err;
-    const double t2 = now_us();
-    bd_finalize += t2 - tf;
-    const int64_t sendB[4] = {bi.n_final, bi.need_truncated_read, bi.len_total_after, fin_ok ? 0 : 1};
-    progress(2, rd.rec, rd.first, rd.n_per);
-    if (!gather(sendB, 4, &B)) return PBSIM_FAILED;
-    int64_t bad_b = 0;
-    for (int q = 0; q < W; q++) bad_b += B[(size_t)q * 4 + 3];
-    if (bad_b) {
-      drop_everything();
-      if (fin_ok) peer_failed = true;
-      return fail(fin_ok ? "another rank of the job failed" : my_err);
+    // pbsim.cpp:3792-3800: a read stops the loop or is truncated only if len_total + its raw length > quota; len_total in front
+    // of any read of the round is at most R.len_total + pass0_sum, so under this bound every read of every block is final
+    const bool untouched = R.len_total + pass0_sum + raw_all <= R.quota;
+    B.assign((size_t)W * kMsg, 0);
+    if (rd.clear && untouched) {
+      int64_t lt = R.len_total;
+      for (int q = 0; q < W; q++) {
+        lt += A[(size_t)q * kMsg];
+        B[(size_t)q * kMsg] = rd.n_per;
+        B[(size_t)q * kMsg + 2] = lt;
+      }
+      bi.len_total_after = before + pass0;
+      c->s().b_info.len_total_after = bi.len_total_after;
+    } else {
+      // a failure here travels in the exchange's status word: every rank leaves the job at the same collective
+      const double tf = now_us();
+      fin_ok = (untouched ? finalize_uncut(c, &bi) : finalize_cut(c, before, &bi)) && finalize_text(c, &bi);
+      if (!fin_ok) my_err = g_err;
+      if (untouched) c->s().b_info.len_total_after = bi.len_total_after = before + pass0;
+      t_fin += now_us() - tf;
+      if (rd.clear) n_clear_missed++;
+      int64_t msgB[kMsg] = {bi.n_final, bi.need_truncated_read, bi.len_total_after, fin_ok ? 0 : 1, 0, 0, 0, 0};
+      if (!rd.clear && pending) {
+        msgB[4] = 1;
+        if (!wait_pending(&msgB[5])) return PBSIM_FAILED;
+        c_applied = true;
+      }
+      progress(rd.clear ? 2 : 7, rd.rec, rd.first, rd.n_per);
+      if (!gather(msgB, kMsg, &B)) return PBSIM_FAILED;
+      int64_t bad_b = 0;
+      for (int q = 0; q < W; q++) bad_b += B[(size_t)q * kMsg + 3];
+      if (!rd.clear && !bad_b && !apply_pending(B, kMsg, 5, true)) return PBSIM_FAILED;
+      if (bad_b) {
+        drop_everything();
+        if (fin_ok) peer_failed = true;
+        return fail(fin_ok ? "another rank of the job failed" : my_err);
+      }
     }
+    bd_finalize += t_fin;
+    const double t2 = now_us();
     int cut = -1;
     for (int q = 0; q < W && cut < 0; q++)
-      if (B[(size_t)q * 4] < rd.n_per) cut = q;
+      if (B[(size_t)q * kMsg] < rd.n_per) cut = q;
     const int last_valid = cut < 0 ? W - 1 : cut;
     const bool mine = rank <= last_valid && bi.n_final > 0;
-    // ---- delivery: the previous round's sizes first (its bytes have been on their way while this round was finalised), then
-    // this round's bytes start moving
-    if (!complete_pending(true)) return PBSIM_FAILED;
+    // ---- delivery: the previous round's sizes have been exchanged (its bytes were on their way while this round's text was
+    // emitted); this round's bytes start moving
+    if (!c_applied && !complete_pending(true)) return PBSIM_FAILED;  // (nothing was pending)
     pending.reset(new Delivery);
+    ++rec_rounds_open[(size_t)rd.rec];
     pending->slot = rd.slot;
     pending->rec = rd.rec;
     pending->mine = mine;
@@ -779,13 +992,13 @@ struct Job {
     }
     if (cut < 0) {
       R.next_read += (int64_t)W * rd.n_per;
-      R.len_total = B[(size_t)(W - 1) * 4 + 2];
+      R.len_total = B[(size_t)(W - 1) * kMsg + 2];
     } else {
-      R.next_read += (int64_t)cut * rd.n_per + B[(size_t)cut * 4];
-      R.len_total = B[(size_t)cut * 4 + 2];
+      R.next_read += (int64_t)cut * rd.n_per + B[(size_t)cut * kMsg];
+      R.len_total = B[(size_t)cut * kMsg + 2];
       R.spec_read = R.next_read;
       R.spec_total = (double)R.len_total;
-      if (B[(size_t)cut * 4 + 1] && R.len_total < R.quota) {  // pbsim.cpp:3795-3800: the next read is a truncated one
+      if (B[(size_t)cut * kMsg + 1] && R.len_total < R.quota) {  // pbsim.cpp:3795-3800: the next read is a truncated one
         R.owner = cut;
         R.bulk_done = true;
       }
@@ -801,10 +1014,11 @@ struct Job {
     }
     if (trace)
       fprintf(stderr,
-              "[pbsim job r%d] t=%.1f ms rec %d round first=%lld n=%lldx%d final=%lld cut=%d wait_walk=%.1f finalize=%.1f handover=%.1f "
+              "[pbsim job r%d] t=%.1f ms rec %d round first=%lld n=%lldx%d %s final=%lld cut=%d wait_walk=%.1f finalize=%.1f handover=%.1f "
               "comm=%.1f ms\n",
-              rank, (t0 - t_start) / 1e3, rd.rec + 1, (long long)rd.first, (long long)rd.n_per, W, (long long)bi.n_final, cut,
-              (t1 - t0) / 1e3, (t2 - t1) / 1e3, (t3 - t2) / 1e3, comm_us / 1e3);
+              rank, (t0 - t_start) / 1e3, rd.rec + 1, (long long)rd.first, (long long)rd.n_per, W,
+              rd.clear ? (untouched ? "clear" : "clear-missed") : "cutting", (long long)bi.n_final, cut, (t1 - t0) / 1e3, t_fin / 1e3,
+              (t3 - t2) / 1e3, comm_us / 1e3);
     return PBSIM_SUCCEEDED;
   }
 
@@ -1112,7 +1326,9 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   for (int ts = Job::kTailSlot; ts < kMaxSlots; ts++)
     for (DfLane &L : c->slots[ts].df) L.own_streams = true;
   J.rec_out.reset(new std::atomic<int>[n]);
-  for (size_t i = 0; i < n; i++) J.rec_out[i] = 0;
+  J.rec_bulk.reset(new std::atomic<int>[n]);
+  J.rec_rounds_open.reset(new std::atomic<int>[n]);
+  for (size_t i = 0; i < n; i++) J.rec_out[i] = J.rec_bulk[i] = J.rec_rounds_open[i] = 0;
   bool seen11 = c->bias.hp11_seen;
   int64_t max_quota = 0;
   for (size_t i = 0; i < n; i++) {

@@ -40,7 +40,7 @@ struct DeviceFlags {
                           // [3] bases all passes (final reads), [4] ref bases, [5] maf columns
   unsigned long long hpfreq[12];
   uint32_t need_q10;      // walks: max over the tasks of (MAF columns - pad) / length, in 1/1024 (note_row_need)
-  uint32_t pad_;
+  uint32_t max_rawlen;    // k_header_wgs: the largest raw (un-truncated) length a read of the batch drew (job.cpp: rounds that cannot touch the quota)
 };
 
 struct RefView {
@@ -63,6 +63,7 @@ struct HeaderArgs {
   int64_t truncate_remaining;  // <0: none
   int32_t *rawlen, *len, *off;
   uint8_t *acc;
+  uint32_t *max_rawlen;       // wgs: atomicMax of the batch's raw lengths (DeviceFlags::max_rawlen; may be null)
   // trans (pbsim.cpp:4488-4504): per-read unit, per-unit length / rank / the 21 start offsets
   int32_t is_templ;           // templ: one full-length '+' read per unit, accuracy draw only (pbsim.cpp:5092-5097)
   const int32_t *read_unit;   // [n_reads] (already offset to the batch)

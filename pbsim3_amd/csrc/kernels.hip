@@ -437,11 +437,17 @@ __global__ __launch_bounds__(256) void k_lines_squeeze(const uint8_t *src, int64
 __global__ __launch_bounds__(256) void k_header_wgs(HeaderArgs a) {
   short_kernel_priority();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n_reads) return;
+  const bool live = i < a.n_reads;
   const uint32_t read = (uint32_t)(a.first_read + i);
   const U4 w = header_block(a.seed, a.unit, read);
-  int64_t L = a.prob2len[(int64_t)(w.x % (uint32_t)a.len_rv) + 1];
+  int64_t L = live ? a.prob2len[(int64_t)(w.x % (uint32_t)a.len_rv) + 1] : 0;
   const int32_t raw = (int32_t)L;
+  if (a.max_rawlen) {  // the batch's largest raw length: one atomic per wave (the job's rounds that cannot touch the quota, job.cpp)
+    int32_t m = raw;
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(a.max_rawlen, (uint32_t)m);
+  }
+  if (!live) return;
   if (a.truncate_remaining >= 0 && L > a.truncate_remaining) {  // pbsim.cpp:3795-3800 (Q10)
     L = a.truncate_remaining;
     if (L < a.len_min) L = a.len_min;

@@ -56,10 +56,14 @@ int main(int argc, char **argv) {
   }
   if (devices.empty() && !selftest) {
     // one rank, and the process ends behind it: the context's pools go back to the driver with the process (cli.cpp)
+    // PBSIM_CLI_LEAVE_CONTEXT=0: an ordinary exit instead -- the context is destroyed, atexit handlers and static destructors
+    // run: what a profiler (rocprofv3 writes its kernel_stats.csv at exit), gcov or a sanitizer's exit report need
     if (!getenv("PBSIM_CLI_LEAVE_CONTEXT")) setenv("PBSIM_CLI_LEAVE_CONTEXT", "1", 1);
+    const bool leave = atoi(getenv("PBSIM_CLI_LEAVE_CONTEXT")) != 0;
     const int rc = pbsim_cli_main(argc, argv, NULL, -1) & 255;
     fflush(stdout);
     fflush(stderr);
+    if (!leave) return rc;
     _exit(rc);  // every file is closed; nothing is left but tearing the runtime's threads and mappings down one by one
   }
   if (devices.empty()) devices.push_back(0);

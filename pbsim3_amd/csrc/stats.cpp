@@ -75,13 +75,33 @@ int stats_merge(StatsAcc *st, const pbsim_params &p, const pbsim_comm *comm, int
   const int W = comm->world;
   if (st->freq_len.empty()) st->freq_len.assign((size_t)p.len_max * 2 + 2, 0);
   if (st->freq_acc.empty()) st->freq_acc.assign(100001, 0);
-  // ---- C2: counters (sum), extremes (min / max)
-  std::vector<int64_t> sums = {st->res_num, st->res_len_total, st->res_sub, st->res_ins, st->res_del};
-  for (int i = 0; i < n_extra; i++) sums.push_back(extra[i]);
-  COMM_OK(comm->all_reduce_i64(comm->user, sums.data(), (int64_t)sums.size(), PBSIM_OP_SUM));
-  int64_t mn = st->res_len_min, mx = st->res_len_max;
-  COMM_OK(comm->all_reduce_i64(comm->user, &mn, 1, PBSIM_OP_MIN));
-  COMM_OK(comm->all_reduce_i64(comm->user, &mx, 1, PBSIM_OP_MAX));
+  // Three collectives per record (round 5; eight until then -- every one of them waits for the slowest rank):
+  // ---- C2 (1): counters, extremes and the shape of the rank's accuracy blocks in ONE all-gather, reduced here
+  int64_t mine_blocks = (int64_t)st->blocks.size(), mine_values = 0;
+  for (const StatsAcc::Block &b : st->blocks) mine_values += (int64_t)b.values.size();
+  std::vector<int64_t> head = {st->res_num, st->res_len_total, st->res_sub, st->res_ins, st->res_del};
+  for (int i = 0; i < n_extra; i++) head.push_back(extra[i]);
+  const size_t n_sum = head.size();
+  head.push_back(st->res_len_min);
+  head.push_back(st->res_len_max);
+  head.push_back(mine_blocks);
+  head.push_back(mine_values);
+  const size_t hw = head.size();
+  std::vector<int64_t> heads((size_t)W * hw);
+  COMM_OK(comm->all_gather_i64(comm->user, head.data(), (int64_t)hw, heads.data()));
+  std::vector<int64_t> sums(n_sum, 0);
+  int64_t mn = st->res_len_min, mx = st->res_len_max, max_blocks = 0, max_values = 0;
+  std::vector<int64_t> meta((size_t)W * 2);
+  for (int r = 0; r < W; r++) {
+    const int64_t *h = &heads[(size_t)r * hw];
+    for (size_t i = 0; i < n_sum; i++) sums[i] += h[i];
+    mn = std::min(mn, h[n_sum]);
+    mx = std::max(mx, h[n_sum + 1]);
+    meta[(size_t)r * 2] = h[n_sum + 2];
+    meta[(size_t)r * 2 + 1] = h[n_sum + 3];
+    max_blocks = std::max(max_blocks, h[n_sum + 2]);
+    max_values = std::max(max_values, h[n_sum + 3]);
+  }
   st->res_num = sums[0];
   st->res_len_total = sums[1];
   st->res_sub = sums[2];
@@ -90,47 +110,44 @@ int stats_merge(StatsAcc *st, const pbsim_params &p, const pbsim_comm *comm, int
   for (int i = 0; i < n_extra; i++) extra[i] = sums[(size_t)5 + i];
   st->res_len_min = mn;
   st->res_len_max = mx;
-  // ---- C2: the two histograms (pbsim.cpp:195-196); freq_len only as far as any rank has counted
-  const int64_t nlen = std::min<int64_t>((int64_t)st->freq_len.size(), mx + 1);
-  if (nlen > 0) COMM_OK(comm->all_reduce_i64(comm->user, st->freq_len.data(), nlen, PBSIM_OP_SUM));
-  COMM_OK(comm->all_reduce_i64(comm->user, st->freq_acc.data(), (int64_t)st->freq_acc.size(), PBSIM_OP_SUM));
-  // ---- accuracy_total in read order: gather every rank's blocks and fold them by first task
-  int64_t mine[2] = {(int64_t)st->blocks.size(), 0};
-  for (const StatsAcc::Block &b : st->blocks) mine[1] += (int64_t)b.values.size();
-  std::vector<int64_t> meta((size_t)W * 2);
-  COMM_OK(comm->all_gather_i64(comm->user, mine, 2, meta.data()));
-  int64_t max_blocks = 0, max_values = 0;
-  for (int r = 0; r < W; r++) {
-    max_blocks = std::max(max_blocks, meta[(size_t)r * 2]);
-    max_values = std::max(max_values, meta[(size_t)r * 2 + 1]);
+  // ---- C2 (2): the two histograms (pbsim.cpp:195-196) in ONE all-reduce; freq_len only as far as any rank has counted
+  {
+    const int64_t nlen = std::max<int64_t>(0, std::min<int64_t>((int64_t)st->freq_len.size(), mx + 1));
+    const size_t nacc = st->freq_acc.size();
+    std::unique_ptr<int64_t[]> hist(new int64_t[(size_t)nlen + nacc]);
+    if (nlen > 0) memcpy(hist.get(), st->freq_len.data(), (size_t)nlen * 8);
+    memcpy(hist.get() + nlen, st->freq_acc.data(), nacc * 8);
+    COMM_OK(comm->all_reduce_i64(comm->user, hist.get(), nlen + (int64_t)nacc, PBSIM_OP_SUM));
+    if (nlen > 0) memcpy(st->freq_len.data(), hist.get(), (size_t)nlen * 8);
+    memcpy(st->freq_acc.data(), hist.get() + nlen, nacc * 8);
   }
+  // ---- C2 (3): accuracy_total in read order: every rank's blocks (first task, size) and values in ONE all-gather, folded by
+  // first task
   if (max_blocks > 0) {
-    std::vector<int64_t> desc((size_t)max_blocks * 2, 0), all_desc((size_t)W * max_blocks * 2);
-    for (size_t i = 0; i < st->blocks.size(); i++) {
-      desc[i * 2] = st->blocks[i].first_task;
-      desc[i * 2 + 1] = (int64_t)st->blocks[i].values.size();
-    }
-    COMM_OK(comm->all_gather_i64(comm->user, desc.data(), max_blocks * 2, all_desc.data()));
     static_assert(sizeof(double) == sizeof(int64_t), "values travel as their bit patterns");
     // (8 B per task of the record on every rank -- 40 MB for a 750 Mbp record at depth 60: not value-initialised, the
     // collective writes all of it, and what lies behind a rank's own count is never read)
-    const size_t n_vals = (size_t)std::max<int64_t>(max_values, 1);
-    std::unique_ptr<int64_t[]> vals(new int64_t[n_vals]), all_vals(new int64_t[(size_t)W * n_vals]);
-    size_t at = 0;
-    for (const StatsAcc::Block &b : st->blocks) {
-      if (!b.values.empty()) memcpy(&vals[at], b.values.data(), b.values.size() * 8);
+    const size_t n_desc = (size_t)max_blocks * 2, n_vals = (size_t)std::max<int64_t>(max_values, 1), n_msg = n_desc + n_vals;
+    std::unique_ptr<int64_t[]> msg(new int64_t[n_msg]), all(new int64_t[(size_t)W * n_msg]);
+    memset(msg.get(), 0, n_desc * 8);
+    size_t at = n_desc;
+    for (size_t i = 0; i < st->blocks.size(); i++) {
+      const StatsAcc::Block &b = st->blocks[i];
+      msg[i * 2] = b.first_task;
+      msg[i * 2 + 1] = (int64_t)b.values.size();
+      if (!b.values.empty()) memcpy(&msg[at], b.values.data(), b.values.size() * 8);
       at += b.values.size();
     }
-    COMM_OK(comm->all_gather_i64(comm->user, vals.get(), (int64_t)n_vals, all_vals.get()));
+    COMM_OK(comm->all_gather_i64(comm->user, msg.get(), (int64_t)n_msg, all.get()));
     struct Piece {
       int64_t first, n;
       const int64_t *v;
     };
     std::vector<Piece> pieces;
     for (int r = 0; r < W; r++) {
-      const int64_t *v = &all_vals[(size_t)r * n_vals];
+      const int64_t *d = &all[(size_t)r * n_msg], *v = d + n_desc;
       for (int64_t i = 0; i < meta[(size_t)r * 2]; i++) {
-        const int64_t first = all_desc[((size_t)r * max_blocks + i) * 2], n = all_desc[((size_t)r * max_blocks + i) * 2 + 1];
+        const int64_t first = d[(size_t)i * 2], n = d[(size_t)i * 2 + 1];
         pieces.push_back(Piece{first, n, v});
         v += n;
       }

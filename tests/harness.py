@@ -56,6 +56,41 @@ def synth_bases(n, seed):
     return out
 
 
+def synth_bases_torch(n, seed, device="cuda"):
+    """synth_bases on a torch device (the GPU box: 3 Gbp in a second instead of a minute): the same splitmix64 in int64
+    arithmetic -- products wrap like uint64's, logical right shifts are arithmetic ones with the sign bits masked off.
+    tests/test_fullsize_digests.py checks it against synth_bases on the CPU."""
+    import torch
+
+    def i64(v):                    # a uint64 constant as the int64 with the same bits
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    step = 1 << 26
+    add = i64(seed * 0x632BE59BD9B4E019)
+    for a in range(0, n, step):
+        x = (torch.arange(a, min(n, a + step), dtype=torch.int64, device=device) + add) * i64(0x9E3779B97F4A7C15)
+        x = x ^ lsr(x, 30)
+        x = x * i64(0xBF58476D1CE4E5B9)
+        x = x ^ lsr(x, 27)
+        x = x * i64(0x94D049BB133111EB)
+        x = x ^ lsr(x, 31)
+        out[a:a + x.numel()] = lut[lsr(x, 61) & 3]
+    return out
+
+
+def load_fullsize():
+    """tests/golden/fullsize.json: CRC-32 + length of the streams the REFERENCE wrote for the BASELINE-size cases
+    (tests/golden/make_fullsize.py), plus its stderr report"""
+    with open(os.path.join(GOLDEN, "fullsize.json")) as f:
+        return json.load(f)
+
+
 def input_path(name):
     """tests/golden/inputs/<name>: committed as is, committed gzip-compressed (the reference's own sample files: data),
     or generated on first use -- `synth_<bases>_<seed>.fa`: one FASTA record of that many synth_bases, 80 per line."""

@@ -5,7 +5,9 @@ records at depth 20 and, at that size, only counts bytes.  Here the same path de
 reads, 63 GB of text, ~2 M gzip members) and every member is looked at: each carries the CRC-32 and the length of the 32 KiB
 of text it holds (RFC 1952), and CRC-32 composes -- crc(A || B) = shift(crc(A), |B|) xor crc(B) -- so the members of a
 stream, folded in offset order, give the CRC-32 and length of the record's WHOLE FASTQ resp. MAF text whatever the batch
-partition, the rank count or the walker that produced it.  That pair, and the record's statistics, must be identical for
+partition, the rank count or the walker that produced it.  That pair must equal what the REFERENCE ITSELF wrote for the same record (round 5: tests/golden/fullsize.json, produced by
+running pbsim.cpp with the keyed stream on harness.synth_bases(750 Mbp) for 15 CPU-minutes), and it and the record's statistics
+must be identical for
 
     one rank | one rank without the wave walker | one rank with a small scratch pool (other batches) | three ranks
 
@@ -156,29 +158,48 @@ def stats_key(s):
             struct.pack("<dd", s.res_accuracy_mean, s.res_accuracy_sd), struct.pack("<dd", s.res_len_mean, s.res_len_sd))
 
 
+def synth_record(case):
+    """the record the REFERENCE was run on (tests/golden/make_fullsize.py): harness.synth_bases, here on the GPU"""
+    import torch
+    from fullsize_cases import FULLSIZE
+    length, seed = FULLSIZE[case]["record"]
+    t = harness.synth_bases_torch(length, seed, "cuda")
+    torch.cuda.synchronize()
+    return t
+
+
+C1 = "c1_errhmm_ont_750m_d20"
+
+
 @pytest.fixture(scope="module")
 def record():
-    import torch
-    g = torch.Generator(device="cuda")
-    g.manual_seed(100)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
-    t = torch.cat([lut[torch.randint(0, 4, (min(64_000_000, G - o),), dtype=torch.uint8, device="cuda", generator=g).long()]
-                   for o in range(0, G, 64_000_000)])
-    torch.cuda.synchronize()
+    t = synth_record(C1)
+    assert t.numel() == G
     yield t
     del t
 
 
-def run_job(P, record, world=1, scratch_gib=None, env=None):
+def reference_digest(case, P=None, ctx=None):
+    """what the reference itself wrote for `case` (tests/golden/fullsize.json): [(crc, bytes) of the read stream, of the MAF
+    stream] and its stderr report.  The reference's SAM stream starts with the two header lines (pbsim.cpp:721-722), which the
+    record sink does not receive (the CLI writes them): their CRC is folded in front of the records' here."""
+    e = harness.load_fullsize()[case]
+    rk = ".fq" if ".fq" in e else ".sam"
+    return [(int(e[rk]["crc32"], 16), e[rk]["bytes"]), (int(e[".maf"]["crc32"], 16), e[".maf"]["bytes"])], e["stderr"]
+
+
+def run_job(P, record, world=1, scratch_gib=None, env=None, method="errhmm", model="ERRHMM-ONT.model", depth=20.0, pass_num=1):
     old = {k: os.environ.get(k) for k in (env or {})}
     os.environ.update(env or {})
     try:
         msink = MemberSink(P)
         ctxs = []
         for r in range(world):
-            p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=1, depth=20.0)
+            qs = method == "qshmm"
+            p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=1, depth=depth,
+                                 pass_num=pass_num)
             ctx = P.Context(p, 0)
-            ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+            (ctx.load_qshmm if qs else ctx.load_errhmm)(harness.model_path(model))
             if scratch_gib:
                 ctx.set_scratch_bytes(int(scratch_gib * (1 << 30)))
             ctx.set_deflate(7)
@@ -201,10 +222,17 @@ def run_job(P, record, world=1, scratch_gib=None, env=None):
             t.join()
         assert errs == [None] * world, errs
         counters = [c.job_counters() for c in ctxs]
+        report = ctxs[0].format_stats(msink.done[0][0], 1)
+        sam_header = ctxs[0].job_sam_header(1) if pass_num > 1 else b""
         for c in ctxs:
             c.close()
         assert all(stats_key(msink.done[r][0]) == stats_key(msink.done[0][0]) for r in range(world))   # merged: same everywhere
-        return msink.digest(), stats_key(msink.done[0][0]), counters
+        digest = msink.digest()
+        if sam_header:   # crc(header || records) = fold(crc(header), crc(records), |records|)
+            crc, ln, at, members = digest[0]
+            digest[0] = (helper().fold(zlib.crc32(sam_header), crc, ln), ln + len(sam_header), at, members)
+        run_job.last_report = report
+        return digest, stats_key(msink.done[0][0]), counters
     finally:
         for k, v in old.items():
             if v is None:
@@ -213,10 +241,16 @@ def run_job(P, record, world=1, scratch_gib=None, env=None):
                 os.environ[k] = v
 
 
+@pytest.mark.timeout(900)
 def test_benchmarked_path_content_is_invariant(record):
     import pbsim3_amd as P
     base_digest, base_stats, counters = run_job(P, record)
     (fq_crc, fq_n, fq_gz, fq_members), (maf_crc, maf_n, maf_gz, maf_members) = base_digest
+    # ---- against the REFERENCE: pbsim.cpp itself (keyed stream) wrote this FASTQ and this MAF for this record, 15 CPU-minutes
+    # of it (tests/golden/make_fullsize.py); every variant below must reproduce the same pair
+    want, ref_report = reference_digest(C1)
+    assert [(fq_crc, fq_n), (maf_crc, maf_n)] == want, "the 15-Gbase record differs from the reference's own output"
+    assert run_job.last_report.rstrip("\n") in ref_report
     n_reads, bases = base_stats[0], base_stats[1]
     assert 15_000_000_000 <= bases < 15_000_000_000 + 1_000_000 and 1_500_000 < n_reads < 1_900_000
     assert counters[0]["rounds"] >= 3 and fq_members > 900_000 and maf_members > 900_000
@@ -243,6 +277,36 @@ def test_benchmarked_path_content_is_invariant(record):
         ctx.set_reference_device(record.data_ptr(), record.numel(), 1)
         ctx.simulate_wgs(collect=False)
         assert stats_key(ctx.stats()) == base_stats
+
+
+@pytest.mark.timeout(900)
+def test_configs4_onthq_depth60_equals_the_reference(tmp_path):
+    """BASELINE configs[4] (ERRHMM-ONT-HQ, depth 60) on a 120 Mbp record, 7.2 Gbases: one rank and eight ranks (contexts on
+    the one GPU, host communicator) deliver the FASTQ and MAF the reference wrote, by CRC-32 and length, and its report."""
+    import pbsim3_amd as P
+    case = "c4_errhmm_onthq_120m_d60"
+    rec = synth_record(case)
+    want, ref_report = reference_digest(case)
+    for world in (1, 8):
+        digest, stats, cnt = run_job(P, rec, world=world, model="ERRHMM-ONT-HQ.model", depth=60.0)
+        assert [d[:2] for d in digest] == want, "world %d" % world
+        assert run_job.last_report.rstrip("\n") in ref_report
+        if world > 1:
+            assert all(c["reads_delivered"] > 0 for c in cnt)
+
+
+@pytest.mark.timeout(900)
+def test_configs2_qshmm_pass10_equals_the_reference(tmp_path):
+    """BASELINE configs[2] (QSHMM-RSII --pass-num 10, depth 20) on a 20 Mbp record, 4 G subread bases: the SAM text (24 GB; the
+    native BAM records are checked field by field in test_gpu_bam.py) and the MAF the reference wrote, by CRC-32 and length."""
+    import pbsim3_amd as P
+    case = "c2_qshmm_rsii_20m_d20_pass10"
+    rec = synth_record(case)
+    want, ref_report = reference_digest(case)
+    for world, kw in ((1, {}), (1, dict(env={"PBSIM_COOP_LEN": "-1"})), (3, {})):
+        digest, stats, cnt = run_job(P, rec, world=world, method="qshmm", model="QSHMM-RSII.model", depth=20.0, pass_num=10, **kw)
+        assert [d[:2] for d in digest] == want, "world %d %s" % (world, kw)
+        assert run_job.last_report.rstrip("\n") in ref_report
 
 
 def test_compressed_job_path_matches_oracle_300_mbases(tmp_path):

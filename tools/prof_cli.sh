@@ -14,6 +14,8 @@ M=$(python3 -c "import sys; sys.path.insert(0,'tests'); import harness; print(ha
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
+# (an ordinary exit: the profiler writes its files from an exit handler, which pbsim's default _exit() would skip)
+export PBSIM_CLI_LEAVE_CONTEXT=0
 PBSIM_TRACE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out -- $R/pbsim3_amd/bin/pbsim --strategy wgs --method errhmm --errhmm $M --genome $d/g.fa --depth 20 --seed 1 --prefix $d/out "$@" 2> $R/$out/err.txt
 cd $R
 f=$(find $out -name "*kernel_stats.csv" | head -1)

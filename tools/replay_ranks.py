@@ -1,13 +1,15 @@
 """An N-rank job's per-rank critical path, measured on ONE GPU (bench.py --replay-ranks 2,4,8).
 
-A rank of an N-rank job exchanges only integers with the others: per round the pass-0 bases of every rank's block
-(gather A), the cut inside every block (gather B) and byte counts (gather C); per record the statistics.  A and B are pure
+A rank of an N-rank job exchanges only integers with the others: per round the pass-0 bases and the largest raw
+length of every rank's block (A), the cut inside every block (B; only in rounds that can touch the quota) and the byte counts
+of the previous round (C; inside the round's A or B message); per record the statistics.  A and B are pure
 functions of two per-read quantities -- the raw length a read's header draws and the pass-0 bases its walk produces -- so the
 values of the OTHER ranks can be served from a table of those two numbers for the first reads of every record, whatever the
 plan: rank r of N then runs ALONE on the GPU, at full speed, with its own link, pools and delivery threads, against a
 communicator that answers for the N - 1 others at once ("virtual ranks").  That is what a rank of a real N-GPU node does between
-its collectives; what the figure leaves out is the collectives' own latency over RCCL (a dozen small ones per job) and the
-contention of N ranks for host memory.
+its collectives.  The collectives' own latency is injected: `collective_us` (default 60, what a small RCCL all-gather with
+pinned staging costs end to end) is spent inside every callback and counted in every segment of the synchronised path.  What
+the figure still leaves out is the contention of N ranks for host memory (tools/host_contention.py measures that apart).
 
   table    = batch primitives on one context: walk the reads 1 .. M of every record un-truncated, fetch (rawlen, pass-0 bases)
   virtual  = pbsim_comm from Python callables; pbsim_job_progress tells which exchange of which round is being entered:
@@ -36,6 +38,9 @@ class ReadTable:
         if first - 1 + n > len(self.out0):
             raise RuntimeError("replay: the read table ends at read %d, the round needs %d" % (len(self.out0), first - 1 + n))
         return int(self.cum[first - 1 + n] - self.cum[first - 1])
+
+    def block_raw_max(self, first, n):
+        return int(self.rawlen[first - 1:first - 1 + n].max())
 
     def cut(self, first, n, before, quota):
         """pbsim.cpp:3792-3800 on reads first .. first + n - 1 with len_total = before in front of them:
@@ -80,19 +85,46 @@ def build_tables(P, harness, p, model, qs, recs, G, local, margin=1.06):
     return tabs
 
 
+MSG = 8   # job.cpp kMsg: A part [0] pass-0 bases [1] code [2] largest raw length | B part [0] n_final [1] need_truncated
+          # [2] len_total_after | [3] text-size status | C part [4] has sizes [5] read bytes [6] MAF bytes [7] delivery status
+
+
 class VirtualRanks:
     """pbsim_comm of rank `rank` of `world` whose other ranks are answered from the read tables.  The callbacks work on the
     raw buffers (the library hands over zeroed receive buffers): the statistics merge of a large record gathers tens of MB,
-    of which only this rank's slice is written here -- a callback costs tens of microseconds, like a small collective."""
+    of which only this rank's slice is written here.  `collective_us`: what a collective of a real node costs, spent (busy
+    wait) inside every callback."""
 
-    def __init__(self, P, ctx, rank, world, tables):
+    def __init__(self, P, ctx, rank, world, tables, collective_us=0.0):
         import ctypes as C
         self.C, self.ctx, self.rank, self.world, self.tables = C, ctx, rank, world, tables
         self.events = []          # (phase, t_enter, t_exit) per collective
         self.checked = 0
         self.error = None
+        self.collective_s = collective_us * 1e-6
         self._cbs = (P.GATHER_CB(self._gather), P.REDUCE_CB(self._reduce), P.BCAST_CB(), P.ABORT_CB())
         self.comm = P.Comm(None, rank, world, *self._cbs)
+
+    def _latency(self, t_in):
+        if self.collective_s > 0:
+            while time.perf_counter() - t_in < self.collective_s:
+                pass
+
+    def _fill_a(self, recv, rec, first, n_per, W):
+        tab = self.tables[rec]
+        for q in range(W):
+            recv[MSG * q] = tab.block_sum(first + q * n_per, n_per)
+            recv[MSG * q + 1] = 0
+            recv[MSG * q + 2] = tab.block_raw_max(first + q * n_per, n_per)
+            recv[MSG * q + 3] = 0
+
+    def _fill_b(self, recv, rec, first, n_per, W, len_total, quota):
+        tab = self.tables[rec]
+        before = len_total
+        for q in range(W):
+            nf, need, after = tab.cut(first + q * n_per, n_per, before, quota)
+            recv[MSG * q], recv[MSG * q + 1], recv[MSG * q + 2], recv[MSG * q + 3] = nf, need, after, 0
+            before += tab.block_sum(first + q * n_per, n_per)
 
     def _gather(self, user, send, n, recv):
         t_in = time.perf_counter()
@@ -100,32 +132,32 @@ class VirtualRanks:
             ph, rec, first, n_per, W, len_total, quota, _ = self.ctx.job_progress()
             r = self.rank
             a = [send[i] for i in range(n)] if n <= 8 else None
-            if ph == 1 and n == 2:
+            if ph in (1, 6) and n == MSG:      # A (a round that places the cut) / AC (a round clear of the quota)
                 if a[1] == 1:
                     raise RuntimeError("replay: rank %d's block overflows its scratch pool; the retry with halved caps depends on "
                                        "every rank's pool and is not modelled -- give the ranks a larger pool" % r)
-                tab = self.tables[rec]
-                for q in range(W):
-                    recv[2 * q] = tab.block_sum(first + q * n_per, n_per)
-                    recv[2 * q + 1] = 0
-                if a[1] == 0 and recv[2 * r] != a[0]:
-                    raise RuntimeError("replay: gather A of rank %d differs from the table (%d vs %d)" % (r, a[0], recv[2 * r]))
-                recv[2 * r], recv[2 * r + 1] = a
-                self.checked += 1
-            elif ph == 2 and n == 4:
-                tab = self.tables[rec]
-                before = len_total
-                for q in range(W):
-                    nf, need, after = tab.cut(first + q * n_per, n_per, before, quota)
-                    recv[4 * q], recv[4 * q + 1], recv[4 * q + 2], recv[4 * q + 3] = nf, need, after, 0
-                    before += tab.block_sum(first + q * n_per, n_per)
-                mine = [recv[4 * r + i] for i in range(3)]
-                if a[3] == 0 and mine != a[:3]:
-                    raise RuntimeError("replay: gather B of rank %d differs from the table (%s vs %s)" % (r, a, mine))
+                self._fill_a(recv, rec, first, n_per, W)
+                mine = [recv[MSG * r], 0, recv[MSG * r + 2]]
+                if a[1] == 0 and mine != a[:3]:
+                    raise RuntimeError("replay: exchange A of rank %d differs from the table (%s vs %s)" % (r, a[:3], mine))
+                for q in range(W):             # C: every rank delivers what this one does
+                    for i in range(4, MSG):
+                        recv[MSG * q + i] = a[i]
                 for i in range(4):
-                    recv[4 * r + i] = a[i]
+                    recv[MSG * r + i] = a[i]
                 self.checked += 1
-            elif ph == 3 and n == 3:      # gather C: every rank delivers what this one does
+            elif ph in (2, 7) and n == MSG:    # B (a clear round that touched the quota after all) / BC
+                self._fill_b(recv, rec, first, n_per, W, len_total, quota)
+                mine = [recv[MSG * r + i] for i in range(3)]
+                if a[3] == 0 and mine != a[:3]:
+                    raise RuntimeError("replay: exchange B of rank %d differs from the table (%s vs %s)" % (r, a[:3], mine))
+                for q in range(W):
+                    for i in range(4, MSG):
+                        recv[MSG * q + i] = a[i]
+                for i in range(4):
+                    recv[MSG * r + i] = a[i]
+                self.checked += 1
+            elif ph == 3 and n == 3:      # C on its own (a record's last round at its merge): every rank delivers what this one does
                 for q in range(W):
                     for i in range(3):
                         recv[3 * q + i] = a[i]
@@ -134,12 +166,14 @@ class VirtualRanks:
         except Exception as e:            # noqa: BLE001 -- reported by the caller; the job fails through the callback's status
             self.error = e
             return 0
+        self._latency(t_in)
         self.events.append((ph, t_in, time.perf_counter()))
         return 1
 
     def _reduce(self, user, buf, n, op):
         t = time.perf_counter()           # identical GPUs agree with themselves; the other ranks' statistics are not needed
-        self.events.append((10, t, t))
+        self._latency(t)
+        self.events.append((10, t, time.perf_counter()))
         return 1
 
 
@@ -153,7 +187,7 @@ def segments(events, t0, t1):
     return seg
 
 
-def replay(P, C, ctx, tables, world, run_job, runs=3):
+def replay(P, C, ctx, tables, world, run_job, runs=3, collective_us=60.0):
     """every rank of `world` alone on the GPU, `runs` timed runs each (after two warm-ups of rank 0 that size the pools);
     run_job(comm) -> sink runs the job once on `ctx`"""
     def go(vr):
@@ -163,8 +197,8 @@ def replay(P, C, ctx, tables, world, run_job, runs=3):
             if vr.error is not None:
                 raise vr.error
             raise
-    go(VirtualRanks(P, ctx, 0, world, tables))
-    go(VirtualRanks(P, ctx, 0, world, tables))
+    go(VirtualRanks(P, ctx, 0, world, tables, collective_us))
+    go(VirtualRanks(P, ctx, 0, world, tables, collective_us))
     import os
     only = os.environ.get("PBSIM_REPLAY_ONLY")   # experiment knob: a subset of the ranks, e.g. "0,3,7"
     ranks = [int(x) for x in only.split(",") if int(x) < world] if only else list(range(world))
@@ -174,7 +208,7 @@ def replay(P, C, ctx, tables, world, run_job, runs=3):
     # to the ranks that happened to run first
     for _ in range(runs):
         for r in ranks:
-            vr = VirtualRanks(P, ctx, r, world, tables)
+            vr = VirtualRanks(P, ctx, r, world, tables, collective_us)
             t0 = time.perf_counter()
             sink = go(vr)
             t1 = time.perf_counter()
@@ -196,9 +230,12 @@ def replay(P, C, ctx, tables, world, run_job, runs=3):
     sync = None
     if len(n_seg) == 1:
         k = n_seg.pop()
-        sync = sum(max(x["segments_ms"][i] for x in per_rank) for i in range(k))
+        # (a rank's segment k is its compute in front of collective k; the collective's own latency was spent inside the
+        # callback, i.e. outside every segment: once per collective on top)
+        sync = sum(max(x["segments_ms"][i] for x in per_rank) for i in range(k)) + (k - 1) * collective_us * 1e-3
     worst = max(per_rank, key=lambda x: x["wall_ms"])
-    return {"world": world, "per_rank": per_rank, "max_rank_wall_ms": worst["wall_ms"], "slowest_rank": worst["rank"],
+    return {"world": world, "collective_us": collective_us, "collectives_per_rank": sorted({x["collectives"] for x in per_rank}),
+            "per_rank": per_rank, "max_rank_wall_ms": worst["wall_ms"], "slowest_rank": worst["rank"],
             "mean_rank_wall_ms": sum(x["wall_ms"] for x in per_rank) / len(per_rank),
             "sync_critical_path_ms": sync,
             "bases_delivered_all_ranks": sum(x["bases"] for x in per_rank),
@@ -206,5 +243,5 @@ def replay(P, C, ctx, tables, world, run_job, runs=3):
             "exposed_tail_ms_worst": max(x["breakdown_ms"]["tail_block"] + x["breakdown_ms"]["drain"] for x in per_rank),
             "note": "every rank ran alone on the one GPU against virtual ranks (tools/replay_ranks.py): max_rank_wall = ranks that "
                     "never wait for each other (lower bound of the job's time), sync_critical_path = every collective waits for its "
-                    "slowest rank and nothing overlaps the wait (upper bound); RCCL latency and host-memory contention of a real "
-                    "node are not in either"}
+                    "slowest rank and nothing overlaps the wait (upper bound); every collective costs collective_us inside both; the "
+                    "host-memory contention of a real node is in neither"}
