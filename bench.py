@@ -226,6 +226,22 @@ def newest_profile(suffix):
     return files[-1] if files else None
 
 
+def lds_split(pws):
+    """Where the walk's reads go, from the counters of the PMC pass (SQ_INSTS_LDS, SQ_INSTS_VMEM_RD per wave-step = per lane and
+    MAF column): every HMM table (class blob, emission rows, inverse CDFs, byte maps) is staged in LDS once per workgroup, so all
+    LDS instructions of the step are table reads; the vector-memory reads are the reference window's refills (one 8-byte load
+    per 8 bases in each of two streams = 0.25 per column) plus a read's header words.  `lds_hit_rate` = the share of the step's
+    table reads that LDS serves = LDS / (LDS + vector-memory reads beyond the window's 0.25 per column)."""
+    lds, vm = pws.get("lds"), pws.get("vmem_rd")
+    if lds is None or vm is None:
+        return None
+    beyond = max(0.0, vm - 0.25)
+    return {"lds_reads_per_column": lds, "vmem_reads_per_column": vm, "lds_share_of_read_instructions": lds / (lds + vm),
+            "lds_hit_rate": lds / (lds + beyond),
+            "note": "measured (SQ_INSTS_LDS, SQ_INSTS_VMEM_RD of the PMC pass named in `source`), not asserted: 4.09 LDS reads per column "
+                    "are the table look-ups, 0.256 vector-memory reads per column the reference window (0.25) and header words"}
+
+
 def issue_bound(columns_per_launch, walk_s):
     """The walk's real ceiling is integer issue, not HBM: figures of the newest PMC pass of the same kernel in profiles/
     (tools/pmc_round.sh; not measured in this run -- counters need rocprofv3 around the process)."""
@@ -236,7 +252,7 @@ def issue_bound(columns_per_launch, walk_s):
     valu = pj["per_wave_step"]["valu"]          # VALU instructions per wave-step = per lane and MAF column
     out = {"valu_busy_frac": pj["valu_busy_fraction"], "valu_per_wave_step": valu,
            "int_lane_ops_per_sec": valu * columns_per_launch / walk_s if walk_s > 0 else None,
-           "lds_table_hit_rate": 1.0,          # every HMM table read is an LDS read (4 per column)
+           "hmm_table_reads": lds_split(pj["per_wave_step"]),
            "source": "profiles/%s (SQ_INSTS_VALU x 4 cycles / SIMD-cycles; collected by tools/pmc_round.sh, not in this run)" % os.path.basename(path),
            "round": pj.get("round", os.path.basename(path).split("_")[0])}
     coop = pj.get("k_walk_errhmm_coop")
@@ -246,16 +262,14 @@ def issue_bound(columns_per_launch, walk_s):
     return out
 
 
-def make_records(torch, dist, dev, cdev, rank, world, n_rec, G):
-    """uniform ACGT records, generated on rank 0's GPU (seed 100 + r) and broadcast over RCCL (C1)"""
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    gen = torch.Generator(device=dev)
+def make_records(torch, harness, dist, dev, cdev, rank, world, n_rec, G):
+    """uniform ACGT records, generated on rank 0's GPU and broadcast over RCCL (C1).  Record r is harness.synth_bases(G, 100 + r)
+    -- plain 64-bit integer arithmetic, the same bytes from numpy on any CPU -- so the reference itself can be (and for record
+    2 of the default job has been: tests/golden/fullsize.json, case c1) run on exactly the genome this bench simulates."""
     recs = []
     for r in range(n_rec):
         if rank == 0:
-            gen.manual_seed(100 + r)
-            t = torch.cat([lut[torch.randint(0, 4, (min(64_000_000, G - o),), dtype=torch.uint8, device=dev, generator=gen).long()]
-                           for o in range(0, G, 64_000_000)])
+            t = harness.synth_bases_torch(G, 100 + r, dev)
         else:
             t = torch.empty(G, dtype=torch.uint8, device=dev)
         if world > 1:
@@ -335,6 +349,43 @@ def steady_state(a, torch, harness, P, local, model, genome_ptr, G, qs=False, pa
             "note": "two batches in flight on one record, every read final (no quota cut), FASTQ + MAF text left in HBM"}
 
 
+def other_configs():
+    """One timed step each of the BASELINE configurations the headline is not quoted on, so that every one of them is timed by
+    whoever runs `python bench.py`: configs[4] (ERRHMM-ONT-HQ depth 60, the 3 Gbp genome), configs[2] (QSHMM-RSII --pass-num 10
+    depth 20 as BAM records + MAF; ONE 750 Mbp record -- the four-record job takes 18 s a step) and configs[3] (100 000
+    transcripts).  Each is this same script as a child process (started after this process has closed its context; never an
+    exec), one warm-up run + one timed run, without the sub-measurements; what is kept of its line is below."""
+    res = {}
+    runs = (("configs[4] onthq60", ["--workload", "onthq60"]),
+            ("configs[2] qshmm10", ["--workload", "qshmm10", "--records", "1"]),
+            ("configs[3] trans", ["--workload", "trans"]))
+    for name, flags in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"] + flags
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [x for x in p.stdout.splitlines() if x.startswith("{")]
+            if p.returncode != 0 or not line:
+                res[name] = {"error": (p.stderr or "no output")[-400:], "command": " ".join(cmd[1:])}
+                continue
+            j = json.loads(line[-1])
+        except Exception as e:  # reported, never required
+            res[name] = {"error": str(e), "command": " ".join(cmd[1:])}
+            continue
+        row = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "workload": j["config"]["workload"],
+               "command": "python bench.py " + " ".join(cmd[2:]), "process_s": time.perf_counter() - t0}
+        if "ms_per_step" in j:
+            row.update({"ms_per_step": j["ms_per_step"], "bases_per_step": j["config"]["bases_per_step"],
+                        "reads_per_step": j["config"]["reads_per_step"], "pcie_frac": j["delivery"]["pcie_frac"],
+                        "compressed_bytes_per_job": j["delivery"]["compressed_bytes_per_job"],
+                        "walk": {"kernel": j["roofline"]["kernel"], "frac": j["roofline"]["frac"],
+                                 "avg_launch_ms": j["roofline"]["avg_launch_ms"], "launches": j["roofline"]["launches"]}})
+        else:
+            row.update({"bases": j.get("bases"), "reads": j.get("reads"), "bases_per_sec": j.get("bases_per_sec")})
+        res[name] = row
+    return res
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) as a child and leave with its exit
     status.  This process has not imported torch nor made any HIP call, and it never replaces itself (no exec)."""
@@ -399,14 +450,20 @@ def main():
     ap.add_argument("--hbm-only", action="store_true", help="experiment: leave the text in HBM in the timed runs too")
     ap.add_argument("--one-gpu", action="store_true",
                     help="plumbing check: the --gpus N ranks as N contexts on GPU 0, gloo collectives (not a scaling measurement)")
-    ap.add_argument("--replay-ranks", default="",
+    ap.add_argument("--replay-ranks", default=None,
                     help="N=1 only: e.g. 2,4,8 -- additionally measure the per-rank critical path of the N-rank job on this one GPU, "
-                         "every rank alone against virtual ranks (tools/replay_ranks.py)")
+                         "every rank alone against virtual ranks (tools/replay_ranks.py).  Default: 8 for the headline workload "
+                         "(with the other sub-measurements; --no-extras or --replay-ranks '' turn it off)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N=1, headline workload: skip the one timed step each of BASELINE configs[4], [2] and [3] (`other_configs`)")
     ap.add_argument("--collective-us", type=float, default=60.0,
                     help="--replay-ranks: latency injected per collective (a small RCCL all-gather with pinned staging, end to end)")
     ap.add_argument("--param", action="append", default=[],
                     help="experiment only: override a pbsim_params field, e.g. --param len_sd=0 (not the headline workload)")
     a = ap.parse_args()
+    headline = a.workload == "errhmm" and not a.hbm_only and not a.param and a.records == 4 and a.record_len == RECORD_LEN
+    if a.replay_ranks is None:
+        a.replay_ranks = "8" if (headline and a.gpus == 1 and not a.no_extras) else ""
     if a.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -456,7 +513,7 @@ def main():
     G, NR = a.record_len, a.records
 
     t_c1 = time.perf_counter()
-    recs = make_records(torch, dist, dev, cdev, rank, world, NR, G)
+    recs = make_records(torch, harness, dist, dev, cdev, rank, world, NR, G)
     t_c1 = time.perf_counter() - t_c1      # generation on rank 0 + C1 (the broadcast of every record), outside the timed region
     p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=1, depth=depth, pass_num=pass_num)
     for kv in a.param:
@@ -687,6 +744,10 @@ def main():
             out["steady_state_hbm"] = steady_state(a, torch, harness, P, local, model, recs[0].data_ptr(), G, qs, pass_num)
         except Exception as e:
             out["steady_state_hbm"] = {"error": str(e)}
+    if rank == 0 and world == 1 and headline and not a.no_extras and not a.no_other_configs:
+        del recs
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_configs()
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             try:

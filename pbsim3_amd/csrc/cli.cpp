@@ -36,6 +36,7 @@
 
 #include "../../include/pbsim3_amd.h"
 #include "gzout.h"
+#include "knobs.h"
 #include "unit_io.h"
 
 namespace {
@@ -429,7 +430,7 @@ struct WritePool {
   std::condition_variable tcv, dcv;
   bool stop = false;
   WritePool() {
-    const char *mb = getenv("PBSIM_CLI_WRITE_BUFFER_MB");
+    const char *mb = pbsim::exp_env("PBSIM_CLI_WRITE_BUFFER_MB");
     const size_t bytes = (size_t)(mb && atoll(mb) > 0 ? atoll(mb) : 8192) << 20;
     max_chunks = std::max<size_t>(4, bytes / kChunk);
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -530,7 +531,7 @@ struct PosFile {
     // pinned staging, wrong for the threads that fill the page cache -- with every file's pages coming out of one node's
     // allocator eight writers moved 18 GB/s together; unbound they take pages (and memory bandwidth) from both sockets.
     // PBSIM_CLI_WRITERS_BOUND=1 keeps them bound (A/B).
-    static const bool keep_bound = getenv("PBSIM_CLI_WRITERS_BOUND") && atoi(getenv("PBSIM_CLI_WRITERS_BOUND")) == 1;
+    static const bool keep_bound = pbsim::exp_env("PBSIM_CLI_WRITERS_BOUND") && atoi(pbsim::exp_env("PBSIM_CLI_WRITERS_BOUND")) == 1;
     if (!keep_bound) {
       cpu_set_t all;
       CPU_ZERO(&all);
@@ -658,7 +659,7 @@ struct JobFiles {
   RecFiles &of(int64_t record) { return *recs[(size_t)(record - first)]; }
   std::unique_ptr<WritePool> pool;  // positional files are written behind the job (WritePool above) unless PBSIM_CLI_SYNC_WRITES=1
   void use_async_writes() {
-    const char *sw = getenv("PBSIM_CLI_SYNC_WRITES");
+    const char *sw = pbsim::exp_env("PBSIM_CLI_SYNC_WRITES");
     if (!(sw && *sw == '1')) pool.reset(new WritePool);
   }
   // after pbsim_job_run: every file's queue written, every file closed (write errors end the process here)

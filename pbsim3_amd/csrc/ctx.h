@@ -16,6 +16,7 @@
 
 #include "../../include/pbsim3_amd.h"
 #include "host_tables.h"
+#include "knobs.h"
 #include "kernels.h"
 
 namespace pbsim {

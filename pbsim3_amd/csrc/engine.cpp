@@ -284,7 +284,7 @@ pbsim_ctx *pbsim_create(const pbsim_params *p, int device) {
   const char *mb = getenv("PBSIM_SCRATCH_MB");
   c->scratch_budget = (mb && atoll(mb) > 0) ? atoll(mb) * (1LL << 20) : (8LL << 30);
   c->scratch_auto = !(mb && atoll(mb) > 0);
-  const char *pd = getenv("PBSIM_PIPELINE_DEPTH");
+  const char *pd = exp_env("PBSIM_PIPELINE_DEPTH");
   if (pd && atoi(pd) >= 1) c->pipeline_depth = std::min(kMaxSlots, atoi(pd));
   return c.release();
 }
@@ -1292,7 +1292,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
   // chunks per piece = per launch and per copy (experiment knob PBSIM_DEFLATE_PIECE_CHUNKS; a piece's members stay below 4 GiB)
   static const int64_t piece_chunks = [] {
-    const char *e = getenv("PBSIM_DEFLATE_PIECE_CHUNKS");
+    const char *e = exp_env("PBSIM_DEFLATE_PIECE_CHUNKS");
     const int64_t v = e ? atoll(e) : DF_PIECE_CHUNKS;
     return std::max<int64_t>(256, std::min<int64_t>(65536, v));
   }();
@@ -1302,13 +1302,8 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   const size_t status_bytes_was = sl.d_df_status.bytes;  // (ensure() only ever grows: a new allocation has another size)
   HIP_OK(sl.d_df_status.ensure((size_t)piece_chunks * 8));
   HIP_OK(sl.d_df_ctl.ensure(DF_CTL_BYTES));
-  // Direct mode: the members leave the GPU as the deflate workgroups' own stores into page-locked host memory (no dense
-  // buffer in HBM, no copy); needs the lane's own staging as the destination, so not when the caller places the pieces.
-  static const bool direct_default = [] {
-    const char *e = getenv("PBSIM_DEFLATE_DIRECT");
-    return e ? atoi(e) != 0 : false;
-  }();
-  const bool direct = direct_default && !place;
+  // (Members stored straight into page-locked host memory by the deflate workgroups -- no dense buffer, no copy -- were measured
+  // in round 3 and rejected: 37 vs 47 Gbases/s, profiles/r03_deflate_fused_ab.txt; the code path is gone since round 5.)
   HIP_OK(sl.h_df_total.ensure(DF_CTL_BYTES * kDfBuffers));
   HIP_OK(sl.d_df_code.ensure(DF_TABLE_BYTES + 288 * 4));
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
@@ -1366,18 +1361,17 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   // since the end of round 4 (two before): the kernels of a piece share the GPU with the next round's walk and arrive late
   // now and then; two more pieces in hand cover that -- configs[1] 1116-1120 -> 1089-1102 ms, configs[4] 3200 -> 3100-3140
   // (same box, profiles/r04_replay_late_ab.txt; six or eight with more buffers: no better) for 0.5 GB of HBM per lane.
-  static const int ahead_env = getenv("PBSIM_DEFLATE_AHEAD") ? atoi(getenv("PBSIM_DEFLATE_AHEAD")) : 4;
+  static const int ahead_env = exp_env("PBSIM_DEFLATE_AHEAD") ? atoi(exp_env("PBSIM_DEFLATE_AHEAD")) : 4;
   const int ahead = std::max(1, std::min(kDfBuffers - 1, ahead_env)), nbuf = ahead + 1;
   int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
   // piece j: kernels on staging set j & 1 into dense buffer j % 3; its total lands in h_total[j % 3]
   auto launch = [&](int64_t j) -> int {
     const int b = (int)(j % nbuf);
     const int64_t off = j * piece, len = std::min(piece, n - off);
-    if (!direct) HIP_OK(sl.d_df_dense[b].ensure((size_t)max_ch * DF_SLOT + 64, true));
+    HIP_OK(sl.d_df_dense[b].ensure((size_t)max_ch * DF_SLOT + 64, true));
     if (!place) HIP_OK(sl.h_df_out[b].ensure((size_t)max_ch * DF_SLOT + 64));
-    if (used[b] && !direct) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - 3 has left this dense buffer
-    // (direct: piece j - 3 was consumed on this thread before piece j is launched -- the host buffer is free)
-    uint8_t *dense = direct ? (uint8_t *)sl.h_df_out[b].p : sl.d_df_dense[b].as<uint8_t>();
+    if (used[b]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - nbuf has left this dense buffer
+    uint8_t *dense = sl.d_df_dense[b].as<uint8_t>();
     if (((sl.epoch + 1) & 0x3fffffffu) == 0) {  // the epoch wraps: start over from a cleared array; epoch 0 is never used
       HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
       sl.epoch++;
@@ -1414,23 +1408,21 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     }
     char *dst = place ? (*place)(total) : (char *)sl.h_df_out[b].p;
     if (!dst) return fail("deflate: no room for a compressed piece");
-    if (!direct) {
-      HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[b], 0));
-      if (trace) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        HIP_OK(hipEventCreate(&e0));
-        HIP_OK(hipEventCreate(&e1));
-        tev.emplace_back(e0, e1);
-        HIP_OK(hipEventRecord(e0, sl.copy_stream));
-      }
-      HIP_OK(hipMemcpyAsync(dst, sl.d_df_dense[b].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
-      if (trace) HIP_OK(hipEventRecord(tev.back().second, sl.copy_stream));
-      HIP_OK(hipEventRecord(sl.ev_cp[b], sl.copy_stream));
+    HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[b], 0));
+    if (trace) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      HIP_OK(hipEventCreate(&e0));
+      HIP_OK(hipEventCreate(&e1));
+      tev.emplace_back(e0, e1);
+      HIP_OK(hipEventRecord(e0, sl.copy_stream));
     }
+    HIP_OK(hipMemcpyAsync(dst, sl.d_df_dense[b].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
+    if (trace) HIP_OK(hipEventRecord(tev.back().second, sl.copy_stream));
+    HIP_OK(hipEventRecord(sl.ev_cp[b], sl.copy_stream));
     used[b] = true;
     if (prev_bytes) {  // (before piece k + 2 is launched: it re-uses piece k - 1's buffers)
       const double t1 = now();
-      if (!direct) HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
+      HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
       const double t2 = now();
       if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
       t_copy += t2 - t1;
@@ -1445,7 +1437,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
   }
   if (prev_bytes) {
     const double t1 = now();
-    if (!direct) HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
+    HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
     const double t2 = now();
     if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
     t_copy += t2 - t1;
@@ -2203,7 +2195,7 @@ struct SampleChunks {
       // persistent workgroups of the wave path: four per CU = the four waves per SIMD the kernel's 103 VGPRs allow (measured:
       // 512 / 768 / 1024 / 1280 / 2048 workgroups -> 43.2 / 37.4 / 34.9 / 39.6 / 34.9 ms for the 2-Gbase bench; capping the
       // kernel at 96 VGPRs for a fifth wave bought nothing).  PBSIM_SAMPLE_COOP_WG: experiment knob
-      const char *cb = getenv("PBSIM_SAMPLE_COOP_WG");
+      const char *cb = exp_env("PBSIM_SAMPLE_COOP_WG");
       a.n_coop_blocks = (int32_t)std::min<int64_t>(((int64_t)ck.n_coop_waves * 64 + 3) / 4, cb && atoi(cb) > 0 ? atoi(cb) : 1024);
     }
     a.n_coop_slots = (int64_t)ck.h_vbase[(size_t)ck.n_coop_waves] * 64;

@@ -802,7 +802,7 @@ struct Job {
     // walks for 12-30 ms.  The first two rounds of a job are a fifth and a half of a full one: bytes flow after ~4 ms, and each
     // round's walk still hides behind the delivery of the round in front of it (a round's bytes take ~3x its walk).  The same
     // on every rank (`rounds` counts the rounds begun).  PBSIM_JOB_RAMP=0 turns it off (A/B).
-    static const bool ramp_on = !(getenv("PBSIM_JOB_RAMP") && atoi(getenv("PBSIM_JOB_RAMP")) == 0);
+    static const bool ramp_on = !(exp_env("PBSIM_JOB_RAMP") && atoi(exp_env("PBSIM_JOB_RAMP")) == 0);
     if (ramp_on && rounds < 2) n_per = std::min<int64_t>(n_per, std::max<int64_t>(64, (int64_t)((double)R.cap * (rounds == 0 ? 0.2 : 0.5))));
     n_per = std::max<int64_t>(n_per, 1);
     const int s = acquire_slot();
@@ -1274,7 +1274,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   J.rank = comm ? comm->rank : 0;
   J.trace = getenv("PBSIM_TRACE") != nullptr;
   J.t_start = now_us();
-  const char *jd = getenv("PBSIM_JOB_DEPTH");
+  const char *jd = exp_env("PBSIM_JOB_DEPTH");
   // Rounds in flight (+ one pending delivery < the slots of the rounds).  Three keep a GPU full whose text stays in HBM or whose
   // link carries a fraction of the job (several ranks).  A job that delivers all its bytes over one or two links is bound by
   // them (80 ms a round against 18 ms of walk): one round in flight is as fast (1334 vs 1336 ms), its walk does not share the
@@ -1367,7 +1367,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // ---- batch size: a few rounds per record and rank, not below what keeps a walk longer than its longest read
   const int P = c->p.pass_num;
   const int regions = has_quality(c) ? 3 : 2;
-  const char *jr = getenv("PBSIM_JOB_ROUNDS");  // experiment knob: rounds per record the batches are sized for
+  const char *jr = exp_env("PBSIM_JOB_ROUNDS");  // experiment knob: rounds per record the batches are sized for
   // (several ranks that deliver their bytes: two rounds per record and rank -- every delivery call pays a start-up of a few ms,
   // and a rank of eight has a quarter of a record's bytes per round to spread it over; measured per rank against virtual
   // ranks, configs[4] on eight: 520-537 ms with four rounds per record, 496-504 with two, 525+ with one -- profiles/r04_replay_rounds_ab.txt)

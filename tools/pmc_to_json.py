@@ -71,6 +71,14 @@ def kernel_block(name, kernel, what):
                  ("vmem_rd", "SQ_INSTS_VMEM_RD"), ("vmem_wr", "SQ_INSTS_VMEM_WR")):
         if n in c:
             b["per_wave_step"][k] = c[n] / steps
+    pws = b["per_wave_step"]
+    if "lds" in pws and "vmem_rd" in pws:
+        # where the step's reads go (north_star: "LDS hit-rate on the HMM tables"): every table is staged in LDS once per
+        # workgroup, so the LDS instructions ARE the table look-ups; the vector-memory reads are the reference window's refills
+        # (0.25 per column in the lane walker: one 8-byte load per 8 bases in two streams) and a read's header words
+        b["lds_table_reads_per_column"] = pws["lds"]
+        b["vmem_reads_per_column"] = pws["vmem_rd"]
+        b["lds_share_of_read_instructions"] = pws["lds"] / (pws["lds"] + pws["vmem_rd"])
     if "SQ_INSTS_VALU" in c and ms["sq1"]:
         b["valu_busy_fraction"] = c["SQ_INSTS_VALU"] * 4 / (SIMDS * CLOCK_GHZ * 1e9 * ms["sq1"] / 1e3)
         b["valu_busy_note"] = "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x the launch under the SQ pass)"
