@@ -304,6 +304,17 @@ int pbsim_job_add_record_lines(pbsim_ctx *ctx, const uint8_t *lines, int64_t byt
  * GPU, without it every rank must pass them. */
 int pbsim_job_add_record_comm(pbsim_ctx *ctx, const uint8_t *seq, int64_t len, const pbsim_comm *comm, int32_t root);
 int64_t pbsim_job_records(pbsim_ctx *ctx);
+/* The job's records announced in advance (their number and lengths): pbsim_job_run may then be called BEFORE they have all been
+ * added, and pbsim_job_add_record* may be called from another thread while it runs -- in order, each with the announced length.
+ * The job begins as soon as record 1 is resident and prepared and begins a later record's first round when that record is, so
+ * the upload / broadcast (C1) and preparation (K0) of records 2.. hide behind the rounds in front of them: what a caller that
+ * hands over FRESH records waits for is record 1's share, not the genome's (main() reads its records one at a time,
+ * pbsim.cpp:666-759; bench.py `value_from_fresh_records`).  With --hp-del-bias != 1 the job waits for every record first (the
+ * homopolymer census of all records precedes the first read, pbsim.cpp:677-696).  pbsim_job_feed_abort: the feeding thread gives
+ * up (a read error, a failed broadcast); a pbsim_job_run that waits for a record then fails with `why` (it also gives up by
+ * itself after 600 s).  pbsim_job_begin / pbsim_job_clear forget the announcement. */
+int pbsim_job_expect(pbsim_ctx *ctx, int64_t n_records, const int64_t *lens);
+int pbsim_job_feed_abort(pbsim_ctx *ctx, const char *why);
 /* drops the records; the next one added is record `first_record` (a genome larger than HBM runs as several jobs whose
  * numbering continues; --hp-del-bias != 1 then needs pbsim_add_hp_census / pbsim_finish_hp_census over ALL records first:
  * pbsim_job_run of a job with first_record > 1 fails without it rather than taking a census per record group).
@@ -328,7 +339,7 @@ int pbsim_job_counters(pbsim_ctx *ctx, int64_t out[8]);
  * [1] for walks (pbsim_batch_walk_end of the round in front), [2] for the cut and the text sizes, [3] for the previous round's
  * bytes to reach host memory (GPU compression + link), [4] in the per-round collectives, [5] accounting statistics,
  * [6] for a record's truncated tail reads at its merge (exposed tail), [7] for the delivery thread at a merge, [8] for a free
- * slot, [9] in the statistics merge (C2), [10] enqueueing rounds, [11] stepping tail reads between rounds; [12] time the
+ * slot (or for an announced record to arrive, pbsim_job_expect), [9] in the statistics merge (C2), [10] enqueueing rounds, [11] stepping tail reads between rounds; [12] time the
  * delivery thread was busy (compression + copies + sink callbacks; runs beside the loop); [13] top-up rounds, [14] truncated
  * tail reads walked by this rank, [15] rounds kept in flight. */
 int pbsim_job_breakdown(pbsim_ctx *ctx, double out[16]);

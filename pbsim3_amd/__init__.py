@@ -91,6 +91,8 @@ API = [
     ("pbsim_job_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("pbsim_job_progress", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("pbsim_job_set_interleave", C.c_int, [C.c_void_p, C.c_int]),
+    ("pbsim_job_expect", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    ("pbsim_job_feed_abort", C.c_int, [C.c_void_p, C.c_char_p]),
     ("pbsim_scratch_state", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_batch_fetch_lengths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pbsim_job_breakdown", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
@@ -564,6 +566,14 @@ class Context:
         """the record as its FASTA sequence lines (line feeds included); they are squeezed out on the GPU"""
         buf = C.create_string_buffer(lines, len(lines))
         _check(self.lib.pbsim_job_add_record_lines(self.h, C.cast(buf, C.c_void_p), len(lines), len(lines) - lines.count(b"\n")))
+
+    def job_expect(self, lens):
+        """announce the job's records (their lengths): job_run may start before they have all been added, another thread adds them"""
+        a = (C.c_int64 * len(lens))(*lens)
+        _check(self.lib.pbsim_job_expect(self.h, len(lens), a))
+
+    def job_feed_abort(self, why="the feeding thread gave up"):
+        _check(self.lib.pbsim_job_feed_abort(self.h, why.encode()))
 
     def job_add_record_device(self, ptr: int, length: int):
         _check(self.lib.pbsim_job_add_record_device(self.h, C.c_void_p(ptr), length))

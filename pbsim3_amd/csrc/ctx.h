@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -266,6 +267,12 @@ struct JobRecord {
   DevBuf seq, hp, tiles, flags;
   int64_t len = 0;
   RefDesc ref;
+  hipEvent_t ready = nullptr;  // behind the record's upload and preparation on the prefetch stream (pbsim_job_add_record*)
+  DeviceFlags *h_flags = nullptr;  // pinned: what the preparation found (hp census, bytes >= 0x80), copied down in front of `ready`
+  ~JobRecord() {
+    if (ready) (void)hipEventDestroy(ready);
+    if (h_flags) (void)hipHostFree(h_flags);
+  }
 };
 
 struct pbsim_ctx {
@@ -339,6 +346,13 @@ struct pbsim_ctx {
   // per-unit statistics (pbsim.cpp:63-70, 195-196)
   StatsAcc st;                   // of the current unit (pbsim_batch_account / pbsim_get_stats)
   std::vector<std::unique_ptr<JobRecord>> job_records;  // pbsim_job_add_record (job.cpp)
+  // pbsim_job_expect: the job's records are announced (their lengths) and may arrive WHILE pbsim_job_run is running, added by
+  // another thread in order; the job begins a record's first round when that record is resident and prepared
+  std::mutex job_mu;                    // job_records' size, job_feed_failed
+  std::condition_variable job_cv;
+  std::vector<int64_t> job_expect_len;  // empty: the job is what has been added when pbsim_job_run is called
+  bool job_feed_failed = false;
+  std::string job_feed_err;
   int64_t job_counters[8] = {0};
   int64_t job_progress[8] = {0}; // pbsim_job_progress: the exchange the round loop is about to enter
   double job_breakdown[16] = {0};  // pbsim_job_breakdown: where the round loop's wall time went (job.cpp)

@@ -257,6 +257,59 @@ struct Job {
     for (auto &d : delivering) d = false;
   }
 
+  // ---- the records as they become resident (pbsim_job_expect: possibly while the job runs, added by another thread) --------
+  size_t n_collected = 0;
+  bool seen11 = false;      // Q15 state in front of the next record to collect (cumulative like the reference's record loop)
+  double bd_record_wait = 0;
+  // record i has been added and its preparation has finished: what the preparation found (or null: the feed failed / timed out)
+  const DeviceFlags *record_arrived(int i) {
+    JobRecord *jr = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(c->job_mu);
+      const double t0 = now_us();
+      const bool came = c->job_cv.wait_for(lk, std::chrono::seconds(600),
+                                           [&] { return c->job_records.size() > (size_t)i || c->job_feed_failed; });
+      bd_record_wait += now_us() - t0;
+      if (c->job_records.size() <= (size_t)i) {
+        fail(!came ? "pbsim_job_run: a record announced by pbsim_job_expect did not arrive within 600 s" : c->job_feed_err);
+        return nullptr;
+      }
+      jr = c->job_records[(size_t)i].get();
+    }
+    const double t1 = now_us();
+    if (hipEventSynchronize(jr->ready) != hipSuccess) {
+      fail("hipEventSynchronize failed (a record's preparation)");
+      return nullptr;
+    }
+    bd_record_wait += now_us() - t1;
+    return jr->h_flags;
+  }
+  // records 0 .. upto are resident: their descriptors as the walks need them (in order: Q15's state is cumulative)
+  int collect(int upto) {
+    while ((int)n_collected <= upto) {
+      const size_t i = n_collected;
+      const DeviceFlags *f = record_arrived((int)i);
+      if (!f) return PBSIM_FAILED;
+      JobRecord *jr;
+      {
+        std::lock_guard<std::mutex> lk(c->job_mu);
+        jr = c->job_records[i].get();
+      }
+      seen11 |= f->hpfreq[11] > 0;
+      jr->ref.seq = jr->seq.as<uint8_t>();
+      jr->ref.hp = jr->hp.as<uint8_t>();
+      jr->ref.len = jr->len;
+      jr->ref.unit = c->job_first_unit + (int64_t)i;
+      jr->ref.hp_flag = c->p.hp_del_bias == 1 && !f->high_bytes;
+      jr->ref.hp11 = seen11;
+      recs[i].ref = jr->ref;
+      c->bias.hp11_seen = seen11;
+      if (!ensure_tables(c, jr->ref.hp11)) return PBSIM_FAILED;
+      n_collected++;
+    }
+    return PBSIM_SUCCEEDED;
+  }
+
   void worker_fail() {  // on the worker thread: keep the (thread local) message for the main loop
     std::lock_guard<std::mutex> lk(werr_mu);
     if (!wfailed) werr = g_err;
@@ -805,6 +858,7 @@ struct Job {
     static const bool ramp_on = !(exp_env("PBSIM_JOB_RAMP") && atoi(exp_env("PBSIM_JOB_RAMP")) == 0);
     if (ramp_on && rounds < 2) n_per = std::min<int64_t>(n_per, std::max<int64_t>(64, (int64_t)((double)R.cap * (rounds == 0 ? 0.2 : 0.5))));
     n_per = std::max<int64_t>(n_per, 1);
+    if (!collect(rec)) return PBSIM_FAILED;  // (an announced record: resident and prepared by now, or waited for here)
     const int s = acquire_slot();
     c->cur = s;
     const double tb = now_us();
@@ -1100,6 +1154,28 @@ struct Job {
 
 extern "C" {
 
+// the record joins the job: an event behind its preparation (pbsim_job_run waits for it record by record, not for the whole
+// prefetch stream), and -- the adding thread may not be the one that runs the job -- under the lock, with a wake-up
+static int job_publish(pbsim_ctx *c, std::unique_ptr<JobRecord> r) {
+  HIP_OK(hipHostMalloc((void **)&r->h_flags, sizeof(DeviceFlags), hipHostMallocDefault));
+  HIP_OK(hipMemcpyAsync(r->h_flags, r->flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost, c->prefetch_stream));
+  HIP_OK(hipEventCreateWithFlags(&r->ready, hipEventDisableTiming));
+  HIP_OK(hipEventRecord(r->ready, c->prefetch_stream));
+  {
+    std::lock_guard<std::mutex> lk(c->job_mu);
+    const size_t i = c->job_records.size();
+    if (!c->job_expect_len.empty() && (i >= c->job_expect_len.size() || c->job_expect_len[i] != r->len)) {
+      c->job_feed_failed = true;
+      c->job_feed_err = "pbsim_job_add_record: not the record pbsim_job_expect announced (count or length)";
+      c->job_cv.notify_all();
+      return fail(c->job_feed_err);
+    }
+    c->job_records.push_back(std::move(r));
+  }
+  c->job_cv.notify_all();
+  return PBSIM_SUCCEEDED;
+}
+
 static int job_add(pbsim_ctx *c, const void *seq, int64_t len, hipMemcpyKind kind) {
   if (!c || !seq) return fail("pbsim_job_add_record: bad argument");
   NEED_DEVICE(c);
@@ -1116,8 +1192,7 @@ static int job_add(pbsim_ctx *c, const void *seq, int64_t len, hipMemcpyKind kin
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));  // the caller may reuse (or free) its buffer; the preparation stays asynchronous
   HIP_OK(hipMemsetAsync(r->seq.as<uint8_t>() + len, 0, 64, c->prefetch_stream));
   if (!prepare_enqueue(c, r->seq.as<uint8_t>(), r->hp, r->tiles, r->flags, len, c->prefetch_stream)) return PBSIM_FAILED;
-  c->job_records.push_back(std::move(r));
-  return PBSIM_SUCCEEDED;
+  return job_publish(c, std::move(r));
 }
 int pbsim_job_add_record(pbsim_ctx *c, const uint8_t *seq, int64_t len) { return job_add(c, seq, len, hipMemcpyHostToDevice); }
 
@@ -1148,8 +1223,7 @@ int pbsim_job_add_record_lines(pbsim_ctx *c, const uint8_t *lines, int64_t bytes
   if (kept != len) return fail("pbsim_job_add_record_lines: `len` is not the number of bytes that are not line feeds");
   HIP_OK(hipMemsetAsync(r->seq.as<uint8_t>() + len, 0, 64, c->prefetch_stream));
   if (!prepare_enqueue(c, r->seq.as<uint8_t>(), r->hp, r->tiles, r->flags, len, c->prefetch_stream)) return PBSIM_FAILED;
-  c->job_records.push_back(std::move(r));
-  return PBSIM_SUCCEEDED;
+  return job_publish(c, std::move(r));
 }
 
 // C1: rank `root` holds the record in host memory; it uploads it and comm->broadcast carries the device bytes to every
@@ -1189,7 +1263,11 @@ int pbsim_job_add_record_comm(pbsim_ctx *c, const uint8_t *seq, int64_t len, con
 int pbsim_job_add_record_device(pbsim_ctx *c, const void *seq_device, int64_t len) {
   return job_add(c, seq_device, len, hipMemcpyDeviceToDevice);
 }
-int64_t pbsim_job_records(pbsim_ctx *c) { return c ? (int64_t)c->job_records.size() : -1; }
+int64_t pbsim_job_records(pbsim_ctx *c) {
+  if (!c) return -1;
+  std::lock_guard<std::mutex> lk(c->job_mu);
+  return (int64_t)c->job_records.size();
+}
 
 int pbsim_job_clear(pbsim_ctx *c) { return pbsim_job_begin(c, 1); }
 
@@ -1211,7 +1289,43 @@ int pbsim_job_begin(pbsim_ctx *c, int64_t first_record) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
   }
-  c->job_records.clear();
+  {
+    std::lock_guard<std::mutex> lk(c->job_mu);
+    c->job_records.clear();
+    c->job_expect_len.clear();
+    c->job_feed_failed = false;
+    c->job_feed_err.clear();
+  }
+  return PBSIM_SUCCEEDED;
+}
+
+// The job's records announced in advance: pbsim_job_run may then be called before they have all been added, and
+// pbsim_job_add_record* may be called from ANOTHER thread while it runs (in order; each must have the announced length).  The
+// job begins with record 1 as soon as that one is resident and prepared, and a later record's first round when that record is
+// -- its upload / broadcast and preparation hide behind the rounds of the records in front of it.  (--hp-del-bias != 1 needs the
+// homopolymer census of ALL records before the first read, pbsim.cpp:677-696: such a job waits for every record first.)
+int pbsim_job_expect(pbsim_ctx *c, int64_t n_records, const int64_t *lens) {
+  if (!c || n_records < 1 || !lens) return fail("pbsim_job_expect: bad argument");
+  std::lock_guard<std::mutex> lk(c->job_mu);
+  if ((int64_t)c->job_records.size() > n_records) return fail("pbsim_job_expect: more records have been added already");
+  for (int64_t i = 0; i < n_records; i++) {
+    if (lens[i] < 1 || lens[i] > 1000000000LL) return fail("pbsim_job_expect: bad length");
+    if (i < (int64_t)c->job_records.size() && c->job_records[(size_t)i]->len != lens[i])
+      return fail("pbsim_job_expect: a record added already has another length");
+  }
+  c->job_expect_len.assign(lens, lens + n_records);
+  c->job_feed_failed = false;
+  return PBSIM_SUCCEEDED;
+}
+// the thread that feeds an announced job gives up: a pbsim_job_run waiting for a record fails with `why`
+int pbsim_job_feed_abort(pbsim_ctx *c, const char *why) {
+  if (!c) return fail("bad argument");
+  {
+    std::lock_guard<std::mutex> lk(c->job_mu);
+    c->job_feed_failed = true;
+    c->job_feed_err = why && *why ? why : "the caller gave up feeding the job's records";
+  }
+  c->job_cv.notify_all();
   return PBSIM_SUCCEEDED;
 }
 
@@ -1262,7 +1376,18 @@ int pbsim_job_counters(pbsim_ctx *c, int64_t out[8]) {
 // `*settled`: the other ranks know of the failure (it came through / went into a status word) or the communicator has been
 // aborted already; every other failing return is this rank's alone, and pbsim_job_run releases the others.
 static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink, bool *settled) {
-  if (c->job_records.empty()) return fail("pbsim_job_run: no records (pbsim_job_add_record)");
+  size_t n = 0;
+  std::vector<int64_t> lens;
+  bool streaming = false;
+  {
+    std::lock_guard<std::mutex> lk(c->job_mu);
+    streaming = !c->job_expect_len.empty();
+    if (streaming) lens = c->job_expect_len;
+    else
+      for (auto &r : c->job_records) lens.push_back(r->len);
+    n = lens.size();
+  }
+  if (n == 0) return fail("pbsim_job_run: no records (pbsim_job_add_record)");
   if (sink && c->deflate != 0 && c->deflate != 3)
     return fail("pbsim_job_run: pbsim_set_deflate must cover both sinks or none (mask 0, 3 or 7)");
   HIP_OK(hipSetDevice(c->device));
@@ -1289,39 +1414,8 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // its own blocks over its own link, so a rank of eight is in the same regime as one GPU alone: configs[4] 594 / 592 / 570 ms
   // per rank with 3 / 2 / 1 rounds in flight, configs[1] 190 / 189 / 191.
   J.depth = std::max(1, std::min(kMaxSlots - 3, jd ? atoi(jd) : (delivers ? 1 : 3)));
-  // ---- the records' preparation (upload + k_hp_*) has been running since pbsim_job_add_record: collect it
-  HIP_OK(hipStreamSynchronize(c->prefetch_stream));
-  c->d_lines.release();  // (pbsim_job_add_record_lines' staging: a record's worth of HBM the rounds can use)
-  c->d_lines_tmp.release();
-  const size_t n = c->job_records.size();
-  std::vector<DeviceFlags> fl(n);
-  for (size_t i = 0; i < n; i++)
-    HIP_OK(hipMemcpy(&fl[i], c->job_records[i]->flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost));
-  int64_t census[kHpSlots] = {0};
-  bool any11 = c->hp11_before_job;
-  for (size_t i = 0; i < n; i++) {
-    for (int k = 0; k < kHpSlots; k++) census[k] += (int64_t)fl[i].hpfreq[k];
-    any11 |= fl[i].hpfreq[11] > 0;
-  }
   c->bias.hp11_seen = c->hp11_before_job;  // every run of the job starts from the same Q15 state
-  // pbsim.cpp:677-696: the census of ALL records comes before the first read.  Without pbsim_finish_hp_census the job's own
-  // records are the genome; recomputed per run (records may have been added since the last one).
-  // A follow-on job of the same genome (pbsim_job_begin with first_record > 1) cannot take the census from its own records:
-  // the reference's pass covers ALL records before the first read, and a bias table per record group would silently differ
-  // from it (ADVICE r3).  The caller runs pbsim_add_hp_census / pbsim_finish_hp_census over the whole genome first (the CLI does).
-  if (c->p.hp_del_bias != 1 && c->job_first_unit > 1 && (!c->census_done || c->census_from_job))
-    return fail("pbsim_job_run: a job that continues a genome (pbsim_job_begin first_record > 1) with --hp-del-bias != 1 needs the "
-                "homopolymer census of ALL records first (pbsim_add_hp_census per record, then pbsim_finish_hp_census; pbsim.cpp:677-696)");
-  if (c->p.hp_del_bias != 1 && (!c->census_done || c->census_from_job)) {
-    HpBias nb = c->bias;
-    hp_bias_from_census(c->p.hp_del_bias, census, &nb);
-    nb.hp11_seen = any11;  // the pre-pass has run get_genome_seq over every record (hpfreq[11]++, pbsim.cpp:1058)
-    if (!c->census_done || memcmp(nb.bias, c->bias.bias, sizeof nb.bias) != 0) c->class_tables_dirty = true;
-    c->bias = nb;
-    c->census_done = c->census_from_job = true;
-  } else if (c->p.hp_del_bias != 1 && c->hp11_explicit) {
-    c->bias.hp11_seen = true;
-  }
+  J.seen11 = c->bias.hp11_seen;
   J.recs.resize(n);
   for (int ts = Job::kTailSlot; ts < kMaxSlots; ts++)
     for (DfLane &L : c->slots[ts].df) L.own_streams = true;
@@ -1329,25 +1423,53 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   J.rec_bulk.reset(new std::atomic<int>[n]);
   J.rec_rounds_open.reset(new std::atomic<int>[n]);
   for (size_t i = 0; i < n; i++) J.rec_out[i] = J.rec_bulk[i] = J.rec_rounds_open[i] = 0;
-  bool seen11 = c->bias.hp11_seen;
   int64_t max_quota = 0;
-  for (size_t i = 0; i < n; i++) {
-    JobRecord &jr = *c->job_records[i];
-    seen11 |= fl[i].hpfreq[11] > 0;  // cumulative like the reference's record loop (Q15)
-    jr.ref.seq = jr.seq.as<uint8_t>();
-    jr.ref.hp = jr.hp.as<uint8_t>();
-    jr.ref.len = jr.len;
-    jr.ref.unit = c->job_first_unit + (int64_t)i;
-    jr.ref.hp_flag = c->p.hp_del_bias == 1 && !fl[i].high_bytes;
-    jr.ref.hp11 = seen11;
+  for (size_t i = 0; i < n; i++) {  // what the plan needs of a record is its length; the rest arrives with the record (Job::collect)
     Rec &R = J.recs[i];
-    R.ref = jr.ref;
-    R.quota = quota_of(c, jr.len);
+    R.ref.len = lens[i];
+    R.ref.unit = c->job_first_unit + (int64_t)i;
+    R.quota = quota_of(c, lens[i]);
     R.st.keep_values = W > 1;
     max_quota = std::max(max_quota, R.quota);
-    if (!ensure_tables(c, jr.ref.hp11)) return PBSIM_FAILED;
   }
-  c->bias.hp11_seen = seen11;
+  // ---- the records' preparation (upload + k_hp_*) has been running since pbsim_job_add_record.  A job whose records are all
+  // here collects them all now (and releases the staging of pbsim_job_add_record_lines: a record's worth of HBM the rounds can
+  // use); an announced job (pbsim_job_expect) collects record 1 and every later record in front of its first round.
+  // pbsim.cpp:677-696: with --hp-del-bias != 1 the census of ALL records comes before the first read -- every record first.
+  const bool census_needed = c->p.hp_del_bias != 1 && (!c->census_done || c->census_from_job);
+  // A follow-on job of the same genome (pbsim_job_begin with first_record > 1) cannot take the census from its own records:
+  // the reference's pass covers ALL records before the first read, and a bias table per record group would silently differ
+  // from it (ADVICE r3).  The caller runs pbsim_add_hp_census / pbsim_finish_hp_census over the whole genome first (the CLI does).
+  if (c->p.hp_del_bias != 1 && c->job_first_unit > 1 && census_needed)
+    return fail("pbsim_job_run: a job that continues a genome (pbsim_job_begin first_record > 1) with --hp-del-bias != 1 needs the "
+                "homopolymer census of ALL records first (pbsim_add_hp_census per record, then pbsim_finish_hp_census; pbsim.cpp:677-696)");
+  if (census_needed) {
+    // (the census first, with the tables still as they are: collect() builds the class tables a record's walks will use)
+    int64_t census[kHpSlots] = {0};
+    bool any11 = c->hp11_before_job;
+    for (size_t i = 0; i < n; i++) {
+      const DeviceFlags *f = J.record_arrived((int)i);
+      if (!f) return PBSIM_FAILED;
+      for (int k = 0; k < kHpSlots; k++) census[k] += (int64_t)f->hpfreq[k];
+      any11 |= f->hpfreq[11] > 0;
+    }
+    HpBias nb = c->bias;
+    hp_bias_from_census(c->p.hp_del_bias, census, &nb);
+    nb.hp11_seen = any11;  // the pre-pass has run get_genome_seq over every record (hpfreq[11]++, pbsim.cpp:1058)
+    if (!c->census_done || memcmp(nb.bias, c->bias.bias, sizeof nb.bias) != 0) c->class_tables_dirty = true;
+    c->bias = nb;
+    c->census_done = c->census_from_job = true;
+    J.seen11 = c->bias.hp11_seen;
+  } else if (c->p.hp_del_bias != 1 && c->hp11_explicit) {
+    c->bias.hp11_seen = true;
+    J.seen11 = true;
+  }
+  if (!J.collect(streaming && !census_needed ? 0 : (int)n - 1)) return PBSIM_FAILED;
+  if (!streaming) {
+    HIP_OK(hipStreamSynchronize(c->prefetch_stream));
+    c->d_lines.release();
+    c->d_lines_tmp.release();
+  }
   // ---- how much of its 2 L + pad columns does a read of this model use?  A context that has not walked yet finds out on the
   // first reads of the job's first record (8192 reads, ~1 ms; every rank the same reads, so every rank the same answer):
   // pools and rounds are then sized for what the rows really take (engine.cpp: scratch factor) -- a third less than 2 L.
@@ -1441,7 +1563,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     if (!comm->all_reduce_i64(comm->user, agree.data(), (int64_t)agree.size(), PBSIM_OP_MIN)) return fail("pbsim_comm.all_reduce_i64 failed");
     for (size_t i = 0; i < n; i++) J.recs[i].cap = agree[i + 1];
   }
-  J.mean = std::min<double>(J.mean, (double)c->job_records[0]->len);
+  J.mean = std::min<double>(J.mean, (double)lens[0]);
   for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
   {
     const char *am = getenv("PBSIM_PINNED_ARENA_MB");  // pinned host memory one lane's arena may hold (several ranks: a round's
@@ -1505,7 +1627,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     b[5] = J.bd_account;
     b[6] = J.bd_tail_block;
     b[7] = J.bd_drain;
-    b[8] = J.bd_slot_wait;
+    b[8] = J.bd_slot_wait + J.bd_record_wait;  // (an announced record that had not arrived when its first round was due)
     b[9] = J.bd_merge;
     b[10] = J.bd_begin;
     b[11] = J.bd_tail_steps;
