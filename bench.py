@@ -456,6 +456,8 @@ def main():
                          "(with the other sub-measurements; --no-extras or --replay-ranks '' turn it off)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N=1, headline workload: skip the one timed step each of BASELINE configs[4], [2] and [3] (`other_configs`)")
+    ap.add_argument("--c1-gbs", type=float, default=50.0,
+                    help="--replay-ranks: rate of the emulated record broadcast (C1) in the from-fresh-records run (0: skip it)")
     ap.add_argument("--collective-us", type=float, default=60.0,
                     help="--replay-ranks: latency injected per collective (a small RCCL all-gather with pinned staging, end to end)")
     ap.add_argument("--param", action="append", default=[],
@@ -590,6 +592,46 @@ def main():
         dist.all_gather(bd_list, bd_mine)
     bd_all = [dict(zip(bd_keys, t.tolist())) for t in bd_list]
 
+    # ---- the same job from FRESH records: the records are announced (pbsim_job_expect), a feeder thread
+    # hands them over one after the other while the job runs -- what is exposed of C1 + K0 is record 1's share, not the
+    # genome's.  On one GPU there is no C1 (the records are in HBM; a device-to-device copy + K0 each); --c1-gbs emulates the
+    # broadcast's duration per record in the replay below.
+    def fresh_job(comm_ref, c1_gbs=0.0, feeder_ready=None):
+        ctx.job_begin(1)
+        ctx.job_expect([G] * NR)
+        errs = []
+
+        def feed():
+            try:
+                for t in recs:
+                    if c1_gbs > 0:
+                        time.sleep(G / (c1_gbs * 1e9))     # the record's broadcast, on a side stream of a real node
+                    ctx.job_add_record_device(t.data_ptr(), G)
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+                ctx.job_feed_abort(str(e))
+        sink = CountingSink(P, C)
+        ctx.set_deflate(7 if deliver else 0)
+        if not deliver:
+            sink.sink = P.RecordSink(None, P.REC_TEXT_CB(), P.REC_TEXT_CB(), sink._cbs[2])
+        torch.cuda.synchronize()
+        t_0 = time.perf_counter()
+        th = threading.Thread(target=feed)
+        th.start()
+        ok = ctx.lib.pbsim_job_run(ctx.h, comm_ref, C.byref(sink.sink))
+        t_1 = time.perf_counter()
+        th.join()
+        if errs:
+            raise errs[0]
+        P._check(ok)
+        return t_1 - t_0, sink
+
+    fresh = None
+    if world == 1 and not a.no_extras:
+        dts = [fresh_job(None)[0] for _ in range(3)]
+        fresh = {"ms": min(dts) * 1e3, "runs_ms": [x * 1e3 for x in dts]}
+        torch.cuda.synchronize()            # (the records of the last fresh run stay: the sub-measurements below run on them)
+
     extras = {}
     if not a.no_extras:
         if world > 1:
@@ -640,6 +682,19 @@ def main():
         for n in [int(x) for x in a.replay_ranks.split(",") if x]:
             ctx.release_pools()
             res = RR.replay(P, C, ctx, tables, n, run_with, collective_us=a.collective_us)
+            if a.c1_gbs > 0:    # rank 0 of n from fresh records: C1 emulated per record, K0 and C1 of records 2.. behind the rounds
+                vr = RR.VirtualRanks(P, ctx, 0, n, tables, a.collective_us)
+                dtf = min(fresh_job(C.byref(vr.comm), a.c1_gbs)[0] for _ in range(3)) * 1e3
+                r0 = [x for x in res["per_rank"] if x["rank"] == 0][0]["wall_ms"]
+                res["from_fresh_records"] = {
+                    "rank0_wall_ms": dtf, "rank0_wall_resident_ms": r0, "exposed_setup_ms": dtf - r0,
+                    "setup_if_not_overlapped_ms": NR * G / (a.c1_gbs * 1e9) * 1e3 + t_k0 * 1e3, "c1_gbs": a.c1_gbs,
+                    "note": "rank 0 of %d, records announced (pbsim_job_expect) and handed over by a feeder thread, each after the time its "
+                            "broadcast would take at --c1-gbs (emulated: the record is in HBM already); exposed_setup = this wall - the same "
+                            "rank's wall with every record resident before the job starts" % n}
+                ctx.job_begin(1)
+                for t in recs:
+                    ctx.job_add_record_device(t.data_ptr(), G)
             res["speedup_if_ranks_never_wait"] = t1_ms / res["max_rank_wall_ms"]
             res["speedup_sync_upper_bound_of_time"] = t1_ms / res["sync_critical_path_ms"] if res["sync_critical_path_ms"] else None
             replays["by_world"][str(n)] = res
@@ -728,6 +783,11 @@ def main():
                      "k_deflate_chunks on the lane's stream; two lanes run side by side, so the GPU compresses up to twice this"}]
         out["setup"] = {"records_generate_and_c1_broadcast_s": t_c1, "k0_prepare_s": t_k0,
                         "value_incl_k0": job_bases / (dt_max / K + t_k0),
+                        "value_from_fresh_records": job_bases / (fresh["ms"] / 1e3) if fresh else None,
+                        "from_fresh_records_ms": fresh,
+                        "from_fresh_records_note": "the job started on ANNOUNCED records (pbsim_job_expect) that a feeder thread hands over "
+                                                   "while it runs: a device-to-device copy + K0 per record, those of records 2.. behind the rounds "
+                                                   "of the records in front; wall from before the first hand-over to the job's end",
                         "note": "outside the timed region (inputs resident in HBM when it starts): the records' generation on rank 0 and "
                                 "their broadcast to every rank (C1), and K0 = upper-case + homopolymer pass of every record on every rank; "
                                 "value_incl_k0 = the job's bases / (a step + K0), what a caller that hands over fresh records sees"}

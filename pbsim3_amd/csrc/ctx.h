@@ -351,6 +351,10 @@ struct pbsim_ctx {
   std::mutex job_mu;                    // job_records' size, job_feed_failed
   std::condition_variable job_cv;
   std::vector<int64_t> job_expect_len;  // empty: the job is what has been added when pbsim_job_run is called
+  // the buffers of the records pbsim_job_begin dropped: the next records of the same length move into them instead of new
+  // allocations (hipFree waits for the whole device, and HBM handed back and taken again comes back in smaller fragments: a job
+  // on re-allocated records ran 3 % slower); at most what one job held, released with the pools (pbsim_release_pools)
+  std::vector<std::unique_ptr<JobRecord>> job_spare;
   bool job_feed_failed = false;
   std::string job_feed_err;
   int64_t job_counters[8] = {0};

@@ -372,6 +372,10 @@ int pbsim_release_pools(pbsim_ctx *c) {
       for (DevBuf &b : L.d_df_dense) b.release();
     sl.b_walked = sl.b_finalized = false;
   }
+  {
+    std::lock_guard<std::mutex> lk(c->job_mu);
+    c->job_spare.clear();  // the buffers pbsim_job_begin kept of the records it dropped
+  }
   return PBSIM_SUCCEEDED;
 }
 

@@ -295,6 +295,7 @@ struct Job {
         std::lock_guard<std::mutex> lk(c->job_mu);
         jr = c->job_records[i].get();
       }
+      if (trace) fprintf(stderr, "[pbsim job r%d] t=%.1f ms record %zu collected (waited %.1f ms for records so far)\n", rank, (now_us() - t_start) / 1e3, i + 1, bd_record_wait / 1e3);
       seen11 |= f->hpfreq[11] > 0;
       jr->ref.seq = jr->seq.as<uint8_t>();
       jr->ref.hp = jr->hp.as<uint8_t>();
@@ -1157,7 +1158,7 @@ extern "C" {
 // the record joins the job: an event behind its preparation (pbsim_job_run waits for it record by record, not for the whole
 // prefetch stream), and -- the adding thread may not be the one that runs the job -- under the lock, with a wake-up
 static int job_publish(pbsim_ctx *c, std::unique_ptr<JobRecord> r) {
-  HIP_OK(hipHostMalloc((void **)&r->h_flags, sizeof(DeviceFlags), hipHostMallocDefault));
+  if (!r->h_flags) HIP_OK(hipHostMalloc((void **)&r->h_flags, sizeof(DeviceFlags), hipHostMallocDefault));
   HIP_OK(hipMemcpyAsync(r->h_flags, r->flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost, c->prefetch_stream));
   HIP_OK(hipEventCreateWithFlags(&r->ready, hipEventDisableTiming));
   HIP_OK(hipEventRecord(r->ready, c->prefetch_stream));
@@ -1176,8 +1177,27 @@ static int job_publish(pbsim_ctx *c, std::unique_ptr<JobRecord> r) {
   return PBSIM_SUCCEEDED;
 }
 
+// a record to fill: the buffers of a dropped record of the same length when there is one (pbsim_job_begin keeps them), else new
+static std::unique_ptr<JobRecord> job_new_record(pbsim_ctx *c, int64_t len) {
+  {
+    std::lock_guard<std::mutex> lk(c->job_mu);
+    for (size_t i = 0; i < c->job_spare.size(); i++)
+      if (c->job_spare[i]->len == len && c->job_spare[i]->seq.bytes >= (size_t)len + 64) {
+        std::unique_ptr<JobRecord> r = std::move(c->job_spare[i]);
+        c->job_spare.erase(c->job_spare.begin() + (long)i);
+        r->ref = RefDesc();
+        return r;
+      }
+  }
+  std::unique_ptr<JobRecord> r(new JobRecord);
+  r->len = len;
+  return r;
+}
+
 static int job_add(pbsim_ctx *c, const void *seq, int64_t len, hipMemcpyKind kind) {
   if (!c || !seq) return fail("pbsim_job_add_record: bad argument");
+  const bool trace = getenv("PBSIM_TRACE") != nullptr;
+  const double ta = now_us();
   NEED_DEVICE(c);
   if (c->p.strategy != PBSIM_STRATEGY_WGS || c->p.method == PBSIM_METHOD_SAMPLE)
     return fail("pbsim_job_add_record: the job pipeline runs --strategy wgs with --method errhmm or qshmm");
@@ -1185,13 +1205,17 @@ static int job_add(pbsim_ctx *c, const void *seq, int64_t len, hipMemcpyKind kin
   if (len > 1000000000LL) return fail("Reference is too long. Acceptable length <= 1000000000.");
   HIP_OK(hipSetDevice(c->device));
   if (!c->prefetch_stream) HIP_OK(hipStreamCreateWithFlags(&c->prefetch_stream, hipStreamNonBlocking));
-  std::unique_ptr<JobRecord> r(new JobRecord);
-  r->len = len;
+  std::unique_ptr<JobRecord> r = job_new_record(c, len);
   HIP_OK(r->seq.ensure((size_t)len + 64, true));
   HIP_OK(hipMemcpyAsync(r->seq.p, seq, (size_t)len, kind, c->prefetch_stream));
+  const double tb = now_us();
   HIP_OK(hipStreamSynchronize(c->prefetch_stream));  // the caller may reuse (or free) its buffer; the preparation stays asynchronous
+  const double tc = now_us();
   HIP_OK(hipMemsetAsync(r->seq.as<uint8_t>() + len, 0, 64, c->prefetch_stream));
   if (!prepare_enqueue(c, r->seq.as<uint8_t>(), r->hp, r->tiles, r->flags, len, c->prefetch_stream)) return PBSIM_FAILED;
+  if (trace)
+    fprintf(stderr, "[pbsim job_add] record of %lld: alloc + copy enqueued %.2f ms, copy (behind the record in front) waited for %.2f ms, K0 enqueued %.2f ms\n",
+            (long long)len, (tb - ta) / 1e3, (tc - tb) / 1e3, (now_us() - tc) / 1e3);
   return job_publish(c, std::move(r));
 }
 int pbsim_job_add_record(pbsim_ctx *c, const uint8_t *seq, int64_t len) { return job_add(c, seq, len, hipMemcpyHostToDevice); }
@@ -1208,8 +1232,7 @@ int pbsim_job_add_record_lines(pbsim_ctx *c, const uint8_t *lines, int64_t bytes
   if (len > 1000000000LL) return fail("Reference is too long. Acceptable length <= 1000000000.");
   HIP_OK(hipSetDevice(c->device));
   if (!c->prefetch_stream) HIP_OK(hipStreamCreateWithFlags(&c->prefetch_stream, hipStreamNonBlocking));
-  std::unique_ptr<JobRecord> r(new JobRecord);
-  r->len = len;
+  std::unique_ptr<JobRecord> r = job_new_record(c, len);
   HIP_OK(r->seq.ensure((size_t)len + 64, true));
   const int64_t n_tiles = (bytes + 4095) / 4096;
   HIP_OK(c->d_lines.ensure((size_t)bytes + 64));
@@ -1291,6 +1314,12 @@ int pbsim_job_begin(pbsim_ctx *c, int64_t first_record) {
   }
   {
     std::lock_guard<std::mutex> lk(c->job_mu);
+    c->job_spare.clear();  // (one job's worth at most: what the job before this one left is let go now)
+    for (auto &r : c->job_records) {
+      if (r->ready) (void)hipEventDestroy(r->ready);
+      r->ready = nullptr;
+      c->job_spare.push_back(std::move(r));
+    }
     c->job_records.clear();
     c->job_expect_len.clear();
     c->job_feed_failed = false;
