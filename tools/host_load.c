@@ -18,6 +18,7 @@
 #define _GNU_SOURCE
 #include <emmintrin.h>
 #include <pthread.h>
+#include <signal.h>
 #include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -30,10 +31,11 @@
 
 #define CHUNK (8u << 20)
 #define RING 64                /* 512 MiB per virtual rank */
-#define WRITERS 4
-#define READERS 3
+#define MAX_T 8
+static int WRITERS = 4, READERS = 3;   /* per virtual rank; HOST_LOAD_WRITERS / HOST_LOAD_READERS (a box with a CPU quota: fewer, faster threads) */
 
 static volatile int g_stop = 0;
+static int g_read_only = 0;
 
 static double now_s(void) {
   struct timespec t;
@@ -45,7 +47,7 @@ typedef struct {
   int rank, node, n_nodes;
   double rate;                 /* bytes per second for this virtual rank */
   char *ring;
-  volatile long written[WRITERS], read_[READERS];   /* chunks */
+  volatile long written[MAX_T], read_[MAX_T];   /* chunks */
   cpu_set_t cpus;
   int have_cpus;
 } VRank;
@@ -140,6 +142,7 @@ static void *reader(void *p) {
   while (!g_stop) {
     long avail = 0;
     for (int k = 0; k < WRITERS; k++) avail += v->written[k];
+    if (g_read_only) avail = done * READERS + a->k + 1;   /* HOST_LOAD_READ_ONLY: the ring over and over, no writers */
     if (done * READERS + a->k >= avail) {   /* behind the writers, never ahead of them */
       struct timespec ts = {0, 50000};
       nanosleep(&ts, NULL);
@@ -163,7 +166,14 @@ static void *stdin_watch(void *p) {
   return NULL;
 }
 
+static void on_signal(int sig) {
+  (void)sig;
+  g_stop = 1;
+}
+
 int main(int argc, char **argv) {
+  signal(SIGINT, on_signal);
+  signal(SIGTERM, on_signal);
   if (argc < 3) {
     fprintf(stderr, "usage: host_load RANKS RATE_GBS [SECONDS] [REAL_RANK] [REAL_NODE]\n");
     return 2;
@@ -173,9 +183,13 @@ int main(int argc, char **argv) {
   const int skip = argc > 4 ? atoi(argv[4]) : 0;
   const int real_node = argc > 5 ? atoi(argv[5]) : 0;
   const int nodes = count_nodes();
+  g_read_only = getenv("HOST_LOAD_READ_ONLY") != NULL;
+  if (getenv("HOST_LOAD_WRITERS")) WRITERS = atoi(getenv("HOST_LOAD_WRITERS"));
+  if (getenv("HOST_LOAD_READERS")) READERS = atoi(getenv("HOST_LOAD_READERS"));
+  if (WRITERS < 1 || WRITERS > MAX_T || READERS < 1 || READERS > MAX_T) return 2;
   VRank *vs = calloc((size_t)ranks, sizeof *vs);
-  pthread_t th[64 * (WRITERS + READERS)];
-  Arg args[64 * (WRITERS + READERS)];
+  static pthread_t th[64 * 2 * MAX_T];
+  static Arg args[64 * 2 * MAX_T];
   int nt = 0;
   for (int r = 0; r < ranks && r < 64; r++) {
     if (r == skip) continue;
@@ -190,12 +204,13 @@ int main(int argc, char **argv) {
       perror("mmap");
       return 1;
     }
-    for (int k = 0; k < WRITERS; k++, nt++) {
+    if (g_read_only) memset(v->ring, 1, (size_t)RING * CHUNK);
+    for (int k = 0; k < (g_read_only ? 0 : WRITERS); k++, nt++) {
       args[nt].v = v;
       args[nt].k = k;
       pthread_create(&th[nt], NULL, writer, &args[nt]);   /* (first touch happens in the bound writer threads) */
     }
-    for (int k = 0; k < READERS; k++, nt++) {
+    for (int k = 0; k < (getenv("HOST_LOAD_NO_READERS") ? 0 : READERS); k++, nt++) {
       args[nt].v = v;
       args[nt].k = k;
       pthread_create(&th[nt], NULL, reader, &args[nt]);
