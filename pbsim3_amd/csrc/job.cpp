@@ -1523,7 +1523,12 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // and a rank of eight has a quarter of a record's bytes per round to spread it over; measured per rank against virtual
   // ranks, configs[4] on eight: 520-537 ms with four rounds per record, 496-504 with two, 525+ with one -- profiles/r04_replay_rounds_ab.txt)
   const bool delivers_text = sink && (sink->on_read_text || sink->on_maf_text);
-  const int rounds_per_record = std::max(1, jr ? atoi(jr) : (delivers_text && W > 1 ? 2 : kRoundsPerRecord));
+  // (text left in HBM -- the job is bound by its walks -- : TWO rounds per record since round 5.  Same-box sweep of rounds per
+  // record x rounds in flight x lane / wave split, profiles/r05_job_rounds_ab.txt: configs[1] 197-201 Gbases/s at four rounds
+  // per record, 208-215 at two (one: 211; the split, the wave walker's workgroups and the ramp-up rounds move nothing there): a
+  // round of 850 000 reads amortises its longest lanes better and the wave walker's share of the GPU time drops.  A job that
+  // delivers its text is bound by its link either way: 54.2 / 53.6 / 54.6 Gbases/s at two / three / four, it keeps four.)
+  const int rounds_per_record = std::max(1, jr ? atoi(jr) : (delivers_text ? (W > 1 ? 2 : kRoundsPerRecord) : 2));
   double target = (double)max_quota * P / ((double)rounds_per_record * W);
   target = std::max(target, std::min(kMinBatchBases, (double)max_quota * P / W));
   if (J.sink && (J.sink->on_read_text || J.sink->on_maf_text)) target = std::min(target, kSinkBatchBases);
