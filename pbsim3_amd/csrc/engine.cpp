@@ -557,7 +557,7 @@ int pbsim_batch_walk_begin(pbsim_ctx *c, int64_t first_read, int64_t n_reads, in
 // lanes).  Small batches (top-up rounds, the truncated tail reads a record's completion waits for) go to the wave walker
 // entirely, and a batch of a million reads hides its longest lane behind its own bulk.
 // A multiple of 256 (the sort's length bucket).  PBSIM_COOP_LEN overrides: -1 never, n >= 0 that length.
-constexpr int kCoopWorkgroups = 4096 / kCoopWaves, kCoopSmallBatch = 20000, kQCoopSmallBatch = 60000, kCoopHugeBatch = 1000000;  // 4096 persistent waves
+constexpr int kCoopWorkgroups = 4096 / kCoopWaves, kCoopSmallBatch = 20000, kQCoopSmallBatch = 20000, kCoopHugeBatch = 1000000;  // 4096 persistent waves
 static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads, bool hp_flag) {
   const bool qs = c->p.method == PBSIM_METHOD_QS;
   if (qs) {  // k_walk_qshmm_coop: moduli of 100, the hp == 11 flag in the sequence bytes (default --hp-del-bias), <= 63 states
@@ -570,11 +570,17 @@ static int32_t coop_min_len(const pbsim_ctx *c, int64_t n_reads, bool hp_flag) {
   const char *sr = getenv("PBSIM_COOP_SPLIT_READS");  // experiment knob: the batch size at which the split is one mean length
   const double split_reads = sr && atof(sr) > 0 ? atof(sr) : 80000.0;
   int64_t len = (int64_t)(std::min(4.0, std::max(0.5, (double)n_tasks / split_reads)) * c->hdr.mean_len);
-  // (QSHMM: the batches of a multi-pass job are large and its job runs at its steady-state regime's rate without -- the wave
-  // walker takes the small batches: truncated tail reads, top-up rounds, the small rounds of many ranks)
-  if (qs) len = -1;
-  // (QSHMM, end of round 4 -- the quality sums out of the step, the classes without a model on waves: 50 000 tasks 20.7 ms by
-  // waves against 27.3 by lanes, 100 000 tasks 33.1 against 31.5: every task of a batch of up to 60 000)
+  // QSHMM (round 5: its wave walker repairs its chains instead of re-walking them and runs four waves per SIMD, 34 -> 41 G
+  // columns/s alone): the same kind of split -- the long tasks by waves beside the lane walk of the rest.  One launch at a time,
+  // QSHMM-RSII x 10 passes (tools/walk_solo.py, profiles/r05_qshmm_split.txt): 60 000 tasks 29.6 ms by lanes, 20.7 by waves,
+  // 14.9 split at two mean lengths; 100 000: 31.5 / 28.1 / 16.7 at three; 200 000: 32.2 / 47.5 / 20.6 at three; 400 000: 33.2
+  // lanes, 25.1 at four, 26.1 at five.  (Rounds 3-4 kept every task of a QSHMM batch with one walker: the wave walker was
+  // too slow for the long tasks of a large batch.)
+  // In a JOB whose rounds are large (configs[2] on one GPU: 540 000 tasks a round, three rounds in flight) the wave walker's
+  // register-heavy workgroups beside three lane walks cost more than the long lanes they remove -- 167 G subread bases/s by
+  // lanes only, 153 split at four mean lengths, 159 at five, 167 at seven -- so batches beyond 250 000 tasks stay with the lane
+  // walker; below that (the rounds of a rank of eight, top-up rounds) the split is a lone launch's.
+  if (qs) len = n_tasks > 250000 ? -1 : (int64_t)(std::min(3.5, std::max(0.5, 0.5 + (double)n_tasks / 40000.0)) * c->hdr.mean_len);
   if (n_tasks <= (qs ? kQCoopSmallBatch : kCoopSmallBatch)) len = 0;
   if (n_tasks >= kCoopHugeBatch) len = -1;
   if (env) len = atoll(env);

@@ -1589,68 +1589,134 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
 // hp == 11 flag in their bytes (kFastRv && kHpBits); classes without a model take the same steps without the chain.
 // ---------------------------------------------------------------------------
 // LDS of one wave: x[64] u16 | the true chains' states [8 groups][8 chains][8] | three output rows | the deletion draws of 256 columns
-constexpr int kQCoopX = 0, kQCoopStates = 128, kQCoopRows = 640, kQCoopD = 832, kQCoopWaveLds = 1856;
+constexpr int kQCoopX = 0, kQCoopStates = 128, kQCoopRows = 640, kQCoopD = 832, kQCoopT = 1856, kQCoopWaveLds = 2368;
 
 // state after each of the 64 columns, given s_in in front of column 0; `delm`: columns that leave the state alone;
-// `init0`: column 0 starts from the initial-state table (row 0 of the transition table) whatever s_in is
-__device__ __forceinline__ uint32_t qcoop_chain(const uint8_t *lds, uint32_t init_off, uint32_t n_chains, uint8_t *s_w, uint32_t x,
-                                                uint64_t delm, bool init0, uint32_t s_in, int lane) {
+// `init0`: column 0 starts from the initial-state table (row 0 of the transition table) whatever s_in is.
+//
+// The chains live across the turns of a step's fixed point (QChains, in registers): a group's chains depend on the draws of its
+// eight columns -- fixed for the step -- and on ITS eight bits of `delm`, and a turn changes few of those (it extends the correct
+// prefix; measured 2.2 turns a step, one or two groups touched per further turn).  Round 5: the first turn of a step walks every
+// group from every start state as before (lane (g, j): group g from the start states j + 8 k); a FURTHER turn walks only the
+// groups whose bits of `delm` changed, each by all 64 lanes at once -- lane s walks the group from start state s: ONE chain of
+// at most eight lookups, deleted columns skipped outright (the group's bits are wave-uniform there) -- and hands the chains to
+// the group's own lanes through LDS.  (Until then every turn re-ran all n_chains x 8 lookups per lane: 477 of the step's 636
+// vector instructions.)  More than two groups touched: the full walk again.
+struct QChains {
+  uint32_t lo[8], hi[8];   // chain k of this lane: states behind columns 0..3 / 4..7 of its group, a byte each
+  uint64_t delm;           // the mask the chains were walked with
+};
+
+__device__ __forceinline__ uint32_t qcoop_chain(const uint8_t *lds, uint32_t init_off, uint32_t n_chains, uint32_t reach, uint8_t *s_w,
+                                                uint32_t x, uint64_t delm, bool init0, uint32_t s_in, int lane, QChains &C, bool fresh) {
   uint16_t *s_x = reinterpret_cast<uint16_t *>(s_w + kQCoopX);
   uint8_t *s_st = s_w + kQCoopStates;
   const int g = lane >> 3, j = lane & 7;
-  wave_sync();
-  s_x[lane] = (uint16_t)x;
-  wave_sync();
-  const uint4 xv = *reinterpret_cast<const uint4 *>(s_x + g * 8);
-  const uint32_t xt[8] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16, xv.z & 0xffffu, xv.z >> 16, xv.w & 0xffffu, xv.w >> 16};
-  const uint32_t dg = (uint32_t)(delm >> (g * 8)) & 0xffu;
-  const bool first_init = init0 && g == 0;
-  uint32_t lo[8], hi[8];
+  uint32_t touched = 0xffu;  // groups to walk (bit per group)
+  if (fresh) {
+    wave_sync();
+    s_x[lane] = (uint16_t)x;
+    wave_sync();
+  } else {
+    const uint64_t ch = delm ^ C.delm;
+    touched = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) lo[k] = hi[k] = 0;
-  // kN chains side by side: their eight dependent table reads each overlap (walked pair after pair the step took n/2 times as long)
-  auto walk = [&](auto tag) {
-    constexpr int kN = decltype(tag)::value;
-    uint32_t st[kN];
+    for (int gg = 0; gg < 8; gg++) touched |= ((uint32_t)(ch >> (8 * gg)) & 0xffu) ? (1u << gg) : 0u;
+  }
+  C.delm = delm;
+  if (fresh || __builtin_popcount(touched) > 2) {
+    const uint4 xv = *reinterpret_cast<const uint4 *>(s_x + g * 8);
+    const uint32_t xt[8] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16, xv.z & 0xffffu, xv.z >> 16, xv.w & 0xffffu, xv.w >> 16};
+    const uint32_t dg = (uint32_t)(delm >> (g * 8)) & 0xffu;
+    const bool first_init = init0 && g == 0;
 #pragma unroll
-    for (int k = 0; k < kN; k++) st[k] = (uint32_t)(j + 8 * k);
+    for (int k = 0; k < 8; k++) C.lo[k] = C.hi[k] = 0;
+    // kN chains side by side: their eight dependent table reads each overlap (walked pair after pair the step took n/2 times as long)
+    auto walk = [&](auto tag) {
+      constexpr int kN = decltype(tag)::value;
+      uint32_t st[kN];
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
+      for (int k = 0; k < kN; k++) st[k] = (uint32_t)(j + 8 * k);
 #pragma unroll
-      for (int k = 0; k < kN; k++) {
-        uint32_t row = st[k];
-        if (t == 0) row = first_init ? 0u : row;
-        const uint32_t nx = lds[init_off + __umul24(row, 100u) + xt[t]];
-        st[k] = ((dg >> t) & 1u) ? st[k] : nx;
-        if (t < 4) lo[k] |= st[k] << (8 * t);
-        else hi[k] |= st[k] << (8 * (t - 4));
+      for (int t = 0; t < 8; t++) {
+#pragma unroll
+        for (int k = 0; k < kN; k++) {
+          uint32_t row = st[k];
+          if (t == 0) row = first_init ? 0u : row;
+          const uint32_t nx = lds[init_off + __umul24(row, 100u) + xt[t]];
+          st[k] = ((dg >> t) & 1u) ? st[k] : nx;
+          if (t < 4) C.lo[k] |= st[k] << (8 * t);
+          else C.hi[k] |= st[k] << (8 * (t - 4));
+        }
+      }
+    };
+    // (one instantiation per count: QSHMM-RSII's classes reach 37 states = five chains; walked as six they cost a fifth more)
+    switch (n_chains) {
+      case 1: walk(std::integral_constant<int, 1>()); break;
+      case 2: walk(std::integral_constant<int, 2>()); break;
+      case 3: walk(std::integral_constant<int, 3>()); break;
+      case 4: walk(std::integral_constant<int, 4>()); break;
+      case 5: walk(std::integral_constant<int, 5>()); break;
+      case 6: walk(std::integral_constant<int, 6>()); break;
+      case 7: walk(std::integral_constant<int, 7>()); break;
+      default: walk(std::integral_constant<int, 8>()); break;
+    }
+  } else {
+    // ---- repair: every touched group by the whole wave, lane s from start state s
+    uint2 *s_t = reinterpret_cast<uint2 *>(s_w + kQCoopT);
+    uint32_t todo = touched;
+    while (todo) {
+      const int gc = __builtin_ctz(todo);  // wave-uniform
+      todo &= todo - 1u;
+      const uint4 xv = *reinterpret_cast<const uint4 *>(s_x + gc * 8);
+      const uint32_t xt[8] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16, xv.z & 0xffffu, xv.z >> 16, xv.w & 0xffffu, xv.w >> 16};
+      const uint32_t dgc = (uint32_t)(delm >> (gc * 8)) & 0xffu;
+      uint32_t st = (uint32_t)lane <= reach ? (uint32_t)lane : 0u;  // (no such state: any row inside the table will do)
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        if (!((dgc >> t) & 1u)) {  // uniform: a deleted column costs nothing
+          const uint32_t row = (t == 0 && init0 && gc == 0) ? 0u : st;
+          st = lds[init_off + __umul24(row, 100u) + xt[t]];
+        }
+        if (t < 4) lo |= st << (8 * t);
+        else hi |= st << (8 * (t - 4));
+      }
+      wave_sync();
+      s_t[lane] = make_uint2(lo, hi);
+      wave_sync();
+      if (g == gc) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if ((uint32_t)k < n_chains) {
+            const uint2 c2 = s_t[j + 8 * k];
+            C.lo[k] = c2.x;
+            C.hi[k] = c2.y;
+          }
       }
     }
-  };
-  if (n_chains <= 2) walk(std::integral_constant<int, 2>());
-  else if (n_chains <= 4) walk(std::integral_constant<int, 4>());
-  else if (n_chains <= 6) walk(std::integral_constant<int, 6>());
-  else walk(std::integral_constant<int, 8>());
+  }
   // the groups' true start states: eight dependent steps on the scalar unit, as in coop_chain (byte k & 3 of ends[k >> 2] = the
   // state chain k ends in); then the lane that walked a group from its true start state hands its chains to LDS
-  const uint32_t ends_a = __builtin_amdgcn_perm(hi[1], hi[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(hi[3], hi[2], 0x0c0c0703u) << 16);
-  const uint32_t ends_b = __builtin_amdgcn_perm(hi[5], hi[4], 0x0c0c0703u) | (__builtin_amdgcn_perm(hi[7], hi[6], 0x0c0c0703u) << 16);
-  uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_in);
+  const uint32_t ends_a = __builtin_amdgcn_perm(C.hi[1], C.hi[0], 0x0c0c0703u) | (__builtin_amdgcn_perm(C.hi[3], C.hi[2], 0x0c0c0703u) << 16);
+  const uint32_t ends_b = __builtin_amdgcn_perm(C.hi[5], C.hi[4], 0x0c0c0703u) | (__builtin_amdgcn_perm(C.hi[7], C.hi[6], 0x0c0c0703u) << 16);
+  uint32_t st0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_in);
   uint64_t starts = 0;  // byte gg = the state in front of group gg
 #pragma unroll
   for (int gg = 0; gg < 8; gg++) {
-    starts |= (uint64_t)s << (8 * gg);
-    const int src = (int)(gg * 8 + (s & 7u));
+    starts |= (uint64_t)st0 << (8 * gg);
+    const int src = (int)(gg * 8 + (st0 & 7u));
     const uint32_t ea = (uint32_t)__builtin_amdgcn_readlane((int)ends_a, src), eb = (uint32_t)__builtin_amdgcn_readlane((int)ends_b, src);
-    s = (((s & 32u) ? eb : ea) >> (((s >> 3) & 3u) * 8u)) & 0xffu;
+    st0 = (((st0 & 32u) ? eb : ea) >> (((st0 >> 3) & 3u) * 8u)) & 0xffu;
   }
   const uint32_t sg = (uint32_t)(starts >> (8 * g)) & 0xffu;
+  wave_sync();
   if ((uint32_t)j == (sg & 7u)) {
     uint4 *dst = reinterpret_cast<uint4 *>(s_st + g * 64);
-    dst[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
-    if (n_chains > 2) dst[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
-    if (n_chains > 4) dst[2] = make_uint4(lo[4], hi[4], lo[5], hi[5]);
-    if (n_chains > 6) dst[3] = make_uint4(lo[6], hi[6], lo[7], hi[7]);
+    dst[0] = make_uint4(C.lo[0], C.hi[0], C.lo[1], C.hi[1]);
+    if (n_chains > 2) dst[1] = make_uint4(C.lo[2], C.hi[2], C.lo[3], C.hi[3]);
+    if (n_chains > 4) dst[2] = make_uint4(C.lo[4], C.hi[4], C.lo[5], C.hi[5]);
+    if (n_chains > 6) dst[3] = make_uint4(C.lo[6], C.hi[6], C.lo[7], C.hi[7]);
   }
   wave_sync();
   return s_st[g * 64 + j + (sg & 0x38u)];
@@ -1659,7 +1725,12 @@ __device__ __forceinline__ uint32_t qcoop_chain(const uint8_t *lds, uint32_t ini
 __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t *lds, const uint8_t *s_comp, const uint8_t *s_sub,
                                                 const uint32_t *s_row, uint8_t *s_w, int slot, int lane) {
   const uint32_t *hdr = reinterpret_cast<const uint32_t *>(lds);
-  const uint32_t n_chains = (hdr[6] + 8u) >> 3;  // start states 0 .. reach in chains of eight
+  const uint32_t reach = hdr[6];
+  const uint32_t n_chains = (reach + 8u) >> 3;  // start states 0 .. reach in chains of eight
+  QChains chains;
+#pragma unroll
+  for (int k = 0; k < 8; k++) chains.lo[k] = chains.hi[k] = 0;
+  chains.delm = 0;
   const uint32_t has_model = hdr[2], freq_rv = hdr[3];
   uint8_t *s_tr = s_w + kQCoopRows, *s_d = s_w + kQCoopD;
   const int task = __builtin_amdgcn_readfirstlane(a.task_of_slot[slot]);
@@ -1717,9 +1788,11 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
     uint32_t st, qv, raw = 0, roi_u = 0;
     bool is_sub, is_ins, emitted;
     uint64_t valid, consm;
+    bool fresh = true;  // the step's first turn: new draws, every group is walked
     for (;;) {
       if (has_model) {
-        st = qcoop_chain(lds, a.init_off, n_chains, s_w, x, delm, q0 == 0, st_in, lane);
+        st = qcoop_chain(lds, a.init_off, n_chains, reach, s_w, x, delm, q0 == 0, st_in, lane, chains, fresh);
+        fresh = false;
         qv = lds[a.emis_off + __umul24(st - 1u, 100u) + y];
       } else {  // an accuracy class outside the model's range: the quality from the class's own table, no state (pbsim.cpp:2218-2222)
         st = 0;
@@ -1812,7 +1885,7 @@ __device__ __forceinline__ void qcoop_walk_task(const WalkArgs &a, const uint8_t
   }
 }
 
-__global__ __launch_bounds__(kWG) void k_walk_qshmm_coop(WalkArgs a) {
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_walk_qshmm_coop(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
