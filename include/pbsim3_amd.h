@@ -108,7 +108,15 @@ void pbsim_destroy(pbsim_ctx *ctx);
 const char *pbsim_last_error(void);
 const char *pbsim_version(void);
 
-/* ---- model tables ----------------------------------------------------------- */
+/* ---- model tables -----------------------------------------------------------
+ * All seven model files the reference ships load (QSHMM-ONT-HQ's 52- and 56-state classes through the reference's own flat
+ * indexing of struct qshmm_t, pbsim.cpp:160-166, 5606-5626).  Two shapes of model FILE are refused with PBSIM_FAILED and an
+ * error text -- no shipped model has either:
+ *   - an ERRHMM model with a hole inside its own accuracy range (a class between acc_min and acc_max without lines): the
+ *     reference walks such a read with the rate_mag left over from whichever out-of-range read came before it
+ *     (pbsim.cpp:3829-3833 sets it only outside the range), i.e. its output depends on the order of the reads;
+ *   - a QSHMM file whose state / column numbers index past the end of tp[] (pbsim.cpp:5606-5626 has no bounds check: the
+ *     reference overwrites whatever lies behind the struct). */
 int pbsim_load_errhmm(pbsim_ctx *ctx, const char *path);        /* set_errhmm :5640 + tables :3633-3789 */
 int pbsim_load_qshmm(pbsim_ctx *ctx, const char *path);         /* set_qshmm  :5570 + tables :1991-2170 */
 
