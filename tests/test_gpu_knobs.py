@@ -39,14 +39,21 @@ def test_bytes_do_not_depend_on_the_knob(env, ranks, tmp_path):
 
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_compressed_ranks_with_a_small_pinned_arena(ranks, tmp_path):
-    """several ranks compress their blocks into a pinned arena until their offsets are known: PBSIM_PINNED_ARENA_MB bounds it"""
+    """several ranks compress their blocks into a pinned arena until their offsets are known: PBSIM_PINNED_ARENA_MB bounds it
+    (blocks of 256 MB: 512 MB hold this case's rounds; 64 MB hold none -- every rank must then leave the job with the message)"""
     import gzip
-    outs = run_devices(CASES[CASE]["args"], str(tmp_path), ranks, scratch_mb=3, extra=(), env={"PBSIM_PINNED_ARENA_MB": "64"})
+    outs = run_devices(CASES[CASE]["args"], str(tmp_path), ranks, scratch_mb=3, extra=(), env={"PBSIM_PINNED_ARENA_MB": "512"})
     want = harness.load_manifest()[f"{CASE}/philox"]
     for k, v in outs.items():
         if k != ".stderr" and not k.endswith(".ref"):
             v = gzip.decompress(v)
         assert harness.sha(v) == want[k]["sha256"], k
+    e = dict(os.environ, PBSIM_PINNED_ARENA_MB="64", PBSIM_SCRATCH_MB="3")
+    d2 = tmp_path / "small"
+    d2.mkdir()
+    p = subprocess.run([CLI] + harness.resolve(CASES[CASE]["args"]) + ["--prefix", str(d2 / "out"), "--devices", ",".join(["0"] * ranks)],
+                       capture_output=True, text=True, cwd=str(d2), env=e, timeout=120)
+    assert p.returncode != 0 and "PBSIM_PINNED_ARENA_MB" in p.stderr       # refused on every rank, nobody left waiting
 
 
 def run_cli(args, workdir, env=None, extra=("--no-gzip",)):
