@@ -456,6 +456,10 @@ def main():
                          "(with the other sub-measurements; --no-extras or --replay-ranks '' turn it off)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N=1, headline workload: skip the one timed step each of BASELINE configs[4], [2] and [3] (`other_configs`)")
+    ap.add_argument("--fresh-records", action="store_true",
+                    help="--gpus N > 1: additionally time the job from FRESH records -- every record broadcast again (C1, on a process "
+                         "group of its own, from a feeder thread) and handed over while the job runs (pbsim_job_expect) -- and print "
+                         "setup.value_from_fresh_records.  Opt-in: two communicators driven from two threads have only run over gloo here")
     ap.add_argument("--c1-gbs", type=float, default=50.0,
                     help="--replay-ranks: rate of the emulated record broadcast (C1) in the from-fresh-records run (0: skip it)")
     ap.add_argument("--collective-us", type=float, default=60.0,
@@ -596,16 +600,28 @@ def main():
     # hands them over one after the other while the job runs -- what is exposed of C1 + K0 is record 1's share, not the
     # genome's.  On one GPU there is no C1 (the records are in HBM; a device-to-device copy + K0 each); --c1-gbs emulates the
     # broadcast's duration per record in the replay below.
-    def fresh_job(comm_ref, c1_gbs=0.0, feeder_ready=None):
+    def fresh_job(comm_ref, c1_gbs=0.0, c1_group=None):
         ctx.job_begin(1)
         ctx.job_expect([G] * NR)
         errs = []
 
         def feed():
             try:
+                if c1_group is not None:
+                    torch.cuda.set_device(local)
                 for t in recs:
                     if c1_gbs > 0:
                         time.sleep(G / (c1_gbs * 1e9))     # the record's broadcast, on a side stream of a real node
+                    if c1_group is not None:               # the record's broadcast itself, beside the job's own exchanges
+                        if cdev == dev:
+                            with torch.cuda.stream(c1_stream):
+                                dist.broadcast(t, src=0, group=c1_group)
+                            c1_stream.synchronize()
+                        else:
+                            h = t.cpu()
+                            dist.broadcast(h, src=0, group=c1_group)
+                            t.copy_(h)
+                            torch.cuda.synchronize()
                     ctx.job_add_record_device(t.data_ptr(), G)
             except Exception as e:      # noqa: BLE001
                 errs.append(e)
@@ -627,10 +643,26 @@ def main():
         return t_1 - t_0, sink
 
     fresh = None
+    c1_stream = None
     if world == 1 and not a.no_extras:
         dts = [fresh_job(None)[0] for _ in range(3)]
         fresh = {"ms": min(dts) * 1e3, "runs_ms": [x * 1e3 for x in dts]}
         torch.cuda.synchronize()            # (the records of the last fresh run stay: the sub-measurements below run on them)
+    elif world > 1 and a.fresh_records:
+        c1_group = dist.new_group()         # C1 on a communicator of its own: the job's exchanges run on the default one meanwhile
+        c1_stream = torch.cuda.Stream(device=dev) if cdev == dev else None
+        dts = []
+        for _ in range(2):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_f = time.perf_counter()
+            fresh_job(cref, 0.0, c1_group)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dts.append(time.perf_counter() - t_f)
+        tf = torch.tensor([min(dts)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+        fresh = {"ms": float(tf.item()) * 1e3, "runs_ms": [x * 1e3 for x in dts]}
 
     extras = {}
     if not a.no_extras:
