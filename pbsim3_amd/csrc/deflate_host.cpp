@@ -1,0 +1,363 @@
+// deflate_host.cpp -- the host side of the output back-end: a text buffer in HBM -> gzip members in pinned host memory,
+// piece by piece (deflate_stream: kernels of piece k + 4, the copy of piece k and the consumer of piece k - 1 overlap), the ABI
+// entries around it (pbsim_set_deflate, pbsim_batch_fetch_deflated, pbsim_deflate_buffer) and deliver(): a finalized batch's
+// text or members to a pbsim_sink.  Split out of engine.cpp in round 5; the kernels are deflate.hip's.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ctx.h"
+#include "engine_internal.h"
+#include "unit_io.h"
+
+extern "C" {
+
+extern "C++" {
+namespace {
+
+int ensure_deflate_tables(pbsim_ctx *c) {
+  if (c->d_df_tables.p) return PBSIM_SUCCEEDED;
+  std::vector<uint32_t> t(1024 + 256);
+  deflate_host_tables(t.data(), t.data() + 1024);
+  if (!upload(c->d_df_tables, t.data(), t.size() * 4, c->stream)) return PBSIM_FAILED;
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return PBSIM_SUCCEEDED;
+}
+
+// d_text[0..n) (device; 16-byte aligned with 16 bytes of slack) -> gzip members, handed to `consume` piece by piece
+// (DF_PIECE_CHUNKS chunks each) from pinned staging.  While the host consumes piece k-1 (a file write, a memcpy),
+// piece k is being copied down and the GPU may already be working for another slot.
+// `place` (optional): where a piece of `total` compressed bytes shall be copied to (pinned host memory of the caller's, e.g.
+// an arena that keeps a whole batch) instead of the lane's double-buffered staging.
+template <class F>
+int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F &&consume,
+                   const std::function<char *(int64_t)> *place = nullptr) {
+  if (n <= 0) return PBSIM_SUCCEEDED;
+  if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
+  // chunks per piece = per launch and per copy (experiment knob PBSIM_DEFLATE_PIECE_CHUNKS; a piece's members stay below 4 GiB)
+  static const int64_t piece_chunks = [] {
+    const char *e = exp_env("PBSIM_DEFLATE_PIECE_CHUNKS");
+    const int64_t v = e ? atoll(e) : DF_PIECE_CHUNKS;
+    return std::max<int64_t>(256, std::min<int64_t>(65536, v));
+  }();
+  const int64_t piece = piece_chunks * DF_CHUNK;
+  const int64_t max_ch = std::min<int64_t>(piece_chunks, (n + DF_CHUNK - 1) / DF_CHUNK);
+  const int64_t n_pieces = (n + piece - 1) / piece;
+  const size_t status_bytes_was = sl.d_df_status.bytes;  // (ensure() only ever grows: a new allocation has another size)
+  HIP_OK(sl.d_df_status.ensure((size_t)piece_chunks * 8));
+  HIP_OK(sl.d_df_ctl.ensure(DF_CTL_BYTES));
+  // (Members stored straight into page-locked host memory by the deflate workgroups -- no dense buffer, no copy -- were measured
+  // in round 3 and rejected: 37 vs 47 Gbases/s, profiles/r03_deflate_fused_ab.txt; the code path is gone since round 5.)
+  HIP_OK(sl.h_df_total.ensure(DF_CTL_BYTES * kDfBuffers));
+  HIP_OK(sl.d_df_code.ensure(DF_TABLE_BYTES + 288 * 4));
+  const uint32_t *tab = c->d_df_tables.as<uint32_t>();
+  int lane_index = 0;
+  for (Slot &slot : c->slots)
+    if (&slot.df[1] == &sl) lane_index = 1;
+  hipStream_t lane_streams[2];
+  if (sl.own_streams) {  // a lane that runs BESIDE the bulk deliveries (the tail chains' worker): not behind their pieces in one stream
+    // (and it never touches the context-wide streams below: their lazy creation belongs to the bulk worker's lane threads
+    // alone -- lane 0 and lane 1 create different elements --, so no two threads race for one handle)
+    for (int i = 0; i < 2; i++)
+      if (!sl.own[i]) HIP_OK(hipStreamCreateWithFlags(&sl.own[i], hipStreamNonBlocking));
+    lane_streams[0] = sl.own[0];
+    lane_streams[1] = sl.own[1];
+  } else {
+    for (int i = 0; i < 2; i++)
+      if (!c->df_streams[lane_index][i]) HIP_OK(hipStreamCreateWithFlags(&c->df_streams[lane_index][i], hipStreamNonBlocking));
+    lane_streams[0] = c->df_streams[lane_index][0];
+    lane_streams[1] = c->df_streams[lane_index][1];
+  }
+  sl.stream = lane_streams[0];
+  // The look-back trusts any status word that carries the launch's epoch and a flag, and the words are never cleared between
+  // launches -- so a NEW array must start from zeros (flag 0 = nothing published): hipMalloc hands back the freed array of a
+  // destroyed context or lane with that lane's old words in it, and a lane's epochs restart.
+  if (sl.d_df_status.bytes != status_bytes_was) HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
+  // the call's code table: fitted once to the head of the text (deflate.hip), shared by all its members
+  launch_deflate_table(d_text, n, reinterpret_cast<uint32_t *>(sl.d_df_code.as<uint8_t>() + DF_TABLE_BYTES), sl.d_df_code.p, sl.stream);
+  unsigned long long *d_prof = nullptr;
+  if (getenv("PBSIM_DEFLATE_PROF")) {
+    HIP_OK(c->d_df_prof.ensure(128));
+    HIP_OK(hipMemsetAsync(c->d_df_prof.p, 0, 128, sl.stream));
+    d_prof = c->d_df_prof.as<unsigned long long>();
+  }
+  // The kernels of a piece, its copy and the host's consume() are three stages that must not wait for each other's round trips:
+  // the lane's stream always holds the NEXT piece's kernels (piece k + 1 is launched before piece k's total is read back, on
+  // the second set of staging buffers), the copy stream the next copy, and the host consumes piece k - 1 while piece k travels.
+  // (Launching a piece only after the previous one's total had arrived left the link idle whenever the other lane was not
+  // copying: 1.5 ms of kernels + a host round trip per 1.46 ms of copy.)
+  sl.copy_stream = lane_streams[1];
+  if (!sl.ev_df[0]) {
+    for (int i = 0; i < kDfBuffers; i++) {
+      HIP_OK(hipEventCreateWithFlags(&sl.ev_df[i], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&sl.ev_cp[i], hipEventDisableTiming));
+      HIP_OK(hipEventCreate(&sl.ev_k0[i]));
+      HIP_OK(hipEventCreate(&sl.ev_k1[i]));
+    }
+  }
+  const bool trace = getenv("PBSIM_DEFLATE_TRACE") != nullptr;  // where a call's wall time goes: kernels | link | consumer
+  const auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_kernel = 0, t_copy = 0, t_consume = 0, t_begin = now();
+  int64_t out_bytes = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;  // trace: begin / end of every copy on the copy stream
+  bool used[kDfBuffers] = {false};
+  // pieces the lane's kernels run ahead of the piece whose copy is being enqueued (ahead + 1 dense buffers in use).  Four
+  // since the end of round 4 (two before): the kernels of a piece share the GPU with the next round's walk and arrive late
+  // now and then; two more pieces in hand cover that -- configs[1] 1116-1120 -> 1089-1102 ms, configs[4] 3200 -> 3100-3140
+  // (same box, profiles/r04_replay_late_ab.txt; six or eight with more buffers: no better) for 0.5 GB of HBM per lane.
+  static const int ahead_env = exp_env("PBSIM_DEFLATE_AHEAD") ? atoi(exp_env("PBSIM_DEFLATE_AHEAD")) : 4;
+  const int ahead = std::max(1, std::min(kDfBuffers - 1, ahead_env)), nbuf = ahead + 1;
+  int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
+  // piece j: kernels on staging set j & 1 into dense buffer j % 3; its total lands in h_total[j % 3]
+  auto launch = [&](int64_t j) -> int {
+    const int b = (int)(j % nbuf);
+    const int64_t off = j * piece, len = std::min(piece, n - off);
+    HIP_OK(sl.d_df_dense[b].ensure((size_t)max_ch * DF_SLOT + 64, true));
+    if (!place) HIP_OK(sl.h_df_out[b].ensure((size_t)max_ch * DF_SLOT + 64));
+    if (used[b]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - nbuf has left this dense buffer
+    uint8_t *dense = sl.d_df_dense[b].as<uint8_t>();
+    if (((sl.epoch + 1) & 0x3fffffffu) == 0) {  // the epoch wraps: start over from a cleared array; epoch 0 is never used
+      HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
+      sl.epoch++;
+    }
+    launch_deflate(d_text + off, len, sl.d_df_status.as<uint64_t>(), sl.d_df_ctl.p, ++sl.epoch, dense, tab, tab + 1024,
+                   sl.d_df_code.p, sl.stream, d_prof, sl.ev_k0[b], sl.ev_k1[b]);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(&h_total[2 * b], sl.d_df_ctl.p, DF_CTL_BYTES, hipMemcpyDeviceToHost, sl.stream));  // ticket | error, total
+    HIP_OK(hipEventRecord(sl.ev_df[b], sl.stream));
+    return PBSIM_SUCCEEDED;
+  };
+  const char *prev_ptr = nullptr;  // piece k - 1: copy possibly still in flight
+  int64_t prev_bytes = 0;
+  int prev_buf = 0;
+  for (int64_t j = 0; j < std::min<int64_t>(ahead, n_pieces); j++)
+    if (!launch(j)) return PBSIM_FAILED;
+  for (int64_t k = 0; k < n_pieces; k++) {
+    const int b = (int)(k % nbuf);
+    const double t0 = now();
+    HIP_OK(hipEventSynchronize(sl.ev_df[b]));
+    t_kernel += now() - t0;
+    const int64_t total = h_total[2 * b + 1];
+    if ((uint64_t)h_total[2 * b] >> 32) return fail("deflate: a workgroup's look-back gave up waiting for its predecessors");
+    out_bytes += total;
+    {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, sl.ev_k0[b], sl.ev_k1[b]) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(c->prof_mu);
+        c->prof_deflate_ms += ms;
+        c->prof_deflate_launches++;
+        c->prof_deflate_in += std::min(piece, n - k * piece);
+        c->prof_deflate_out += total;
+      }
+    }
+    char *dst = place ? (*place)(total) : (char *)sl.h_df_out[b].p;
+    if (!dst) return fail("deflate: no room for a compressed piece");
+    HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[b], 0));
+    if (trace) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      HIP_OK(hipEventCreate(&e0));
+      HIP_OK(hipEventCreate(&e1));
+      tev.emplace_back(e0, e1);
+      HIP_OK(hipEventRecord(e0, sl.copy_stream));
+    }
+    HIP_OK(hipMemcpyAsync(dst, sl.d_df_dense[b].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
+    if (trace) HIP_OK(hipEventRecord(tev.back().second, sl.copy_stream));
+    HIP_OK(hipEventRecord(sl.ev_cp[b], sl.copy_stream));
+    used[b] = true;
+    if (prev_bytes) {  // (before piece k + 2 is launched: it re-uses piece k - 1's buffers)
+      const double t1 = now();
+      HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
+      const double t2 = now();
+      if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
+      t_copy += t2 - t1;
+      t_consume += now() - t2;
+    }
+    prev_ptr = dst;
+    prev_bytes = total;
+    prev_buf = b;
+    // piece k's staging set is free (its total has arrived), the dense buffer of piece k - 1 once its copy is through (a
+    // stream wait inside launch): keep the kernels one piece ahead
+    if (k + ahead < n_pieces && !launch(k + ahead)) return PBSIM_FAILED;
+  }
+  if (prev_bytes) {
+    const double t1 = now();
+    HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
+    const double t2 = now();
+    if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
+    t_copy += t2 - t1;
+    t_consume += now() - t2;
+  }
+  if (trace) {
+    double t_link = 0, t_span = 0;
+    float ms = 0;
+    for (auto &e : tev) {
+      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) t_link += ms;
+    }
+    if (!tev.empty() && hipEventElapsedTime(&ms, tev.front().first, tev.back().second) == hipSuccess) t_span = ms;
+    for (auto &e : tev) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+    fprintf(stderr,
+            "[deflate] %.1f MB -> %.1f MB in %.1f ms: waited %.1f ms for kernels, %.1f ms for copies, %.1f ms in the consumer; copies: "
+            "%.1f ms on the engine within a span of %.1f ms (%.1f GB/s while copying)\n",
+            n / 1e6, out_bytes / 1e6, now() - t_begin, t_kernel, t_copy, t_consume, t_link, t_span, t_link > 0 ? out_bytes / t_link / 1e6 : 0.0);
+  }
+  if (d_prof) {
+    unsigned long long t[16];
+    HIP_OK(hipMemcpy(t, d_prof, 128, hipMemcpyDeviceToHost));
+    const double nch = (double)((n + DF_CHUNK - 1) / DF_CHUNK);
+    static const char *names[7] = {"stage", "crc", "sizes+scan", "header", "tokens", "trailer", "store"};
+    fprintf(stderr, "[deflate prof] %.0f chunks; us per chunk (lane 0):", nch);
+    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f", names[i], t[i] / nch / 100);
+    fprintf(stderr, "\n");
+  }
+  return PBSIM_SUCCEEDED;
+}
+
+int deflate_to_host(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, char *host_dst, int64_t cap,
+                    int64_t *out_bytes) {
+  int64_t written = 0;
+  const int ok = deflate_stream(c, sl, d_text, n, [&](const char *z, int64_t k) {
+    if (written + k > cap) return fail("deflate: output buffer too small");
+    memcpy(host_dst + written, z, (size_t)k);
+    written += k;
+    return PBSIM_SUCCEEDED;
+  });
+  *out_bytes = written;
+  return ok;
+}
+
+}  // namespace
+}  // extern "C++"
+
+extern "C++" int pbsim::deflate_pieces(pbsim_ctx *c, DfLane &lane, const uint8_t *d_text, int64_t n,
+                                       const std::function<int(const char *, int64_t)> &consume,
+                                       const std::function<char *(int64_t)> *place) {
+  return deflate_stream(c, lane, d_text, n, consume, place);
+}
+extern "C++" int pbsim::ensure_deflate_ready(pbsim_ctx *c) { return ensure_deflate_tables(c); }
+
+int pbsim_set_deflate(pbsim_ctx *c, int on) {
+  if (!c) return fail("bad argument");
+  c->deflate = on & 3;
+  c->deflate_parallel = (on & 4) != 0;
+  return PBSIM_SUCCEEDED;
+}
+
+int64_t pbsim_deflate_bound(int64_t n) {
+  if (n <= 0) return 0;
+  return n + ((n + DF_CHUNK - 1) / DF_CHUNK) * 31;
+}
+
+int pbsim_batch_fetch_deflated(pbsim_ctx *c, char *read_gz, int64_t read_cap, char *maf_gz, int64_t maf_cap,
+                               int64_t *read_gz_bytes, int64_t *maf_gz_bytes) {
+  if (!c || !c->s().b_finalized) return fail("pbsim_batch_fetch_deflated: no finalized batch");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  int64_t nr = 0, nm = 0;
+  if (read_gz && !deflate_to_host(c, c->s().df[0], c->s().d_read_text.as<uint8_t>(), c->s().b_info.read_text_bytes, read_gz,
+                                  read_cap, &nr))
+    return PBSIM_FAILED;
+  if (maf_gz && !deflate_to_host(c, c->s().df[0], c->s().d_maf_text.as<uint8_t>(), c->s().b_info.maf_text_bytes, maf_gz,
+                                 maf_cap, &nm))
+    return PBSIM_FAILED;
+  if (read_gz_bytes) *read_gz_bytes = nr;
+  if (maf_gz_bytes) *maf_gz_bytes = nm;
+  return PBSIM_SUCCEEDED;
+}
+
+// host bytes -> gzip members through the same kernels (headers, tests)
+int pbsim_deflate_buffer(pbsim_ctx *c, const void *src, int64_t n, void *dst, int64_t cap, int64_t *out_bytes) {
+  if (!c || !out_bytes || n < 0 || (n > 0 && (!src || !dst))) return fail("pbsim_deflate_buffer: bad argument");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  *out_bytes = 0;
+  if (n == 0) return PBSIM_SUCCEEDED;
+  Slot &sl = c->slots[0];
+  DevBuf d_in;
+  HIP_OK(d_in.ensure((size_t)n + 16));
+  HIP_OK(hipMemcpyAsync(d_in.p, src, (size_t)n, hipMemcpyHostToDevice, sl.stream));
+  HIP_OK(hipStreamSynchronize(sl.stream));  // the lane's kernels run on its own stream
+  return deflate_to_host(c, sl.df[0], d_in.as<uint8_t>(), n, (char *)dst, cap, out_bytes);
+}
+
+extern "C++" int pbsim::deliver(pbsim_ctx *c, const pbsim_sink *sink) {
+  const pbsim_batch_info &bi = c->s().b_info;
+  if (sink && c->defer_text_sync) {  // (drivers that do not wait for the text emission in finalize_text)
+    NEED_DEVICE(c);
+    HIP_OK(hipEventSynchronize(c->s().ev_text));
+  }
+  if (sink && c->deflate) {
+    // compressed sinks stream piece by piece; a sink left as text is fetched whole as before
+    const bool zr = c->deflate & 1, zm = c->deflate & 2;
+    NEED_DEVICE(c);
+    HIP_OK(hipSetDevice(c->device));
+    if (!zr) HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
+    if (!zm) HIP_OK(c->s().h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
+    if ((!zr || !zm) &&
+        !pbsim_batch_fetch(c, zr ? nullptr : (char *)c->s().h_read_text.p, zm ? nullptr : (char *)c->s().h_maf_text.p))
+      return PBSIM_FAILED;
+    Slot &sl = c->s();
+    auto send_read = [&]() -> int {
+      if (!(sink->on_read_text && bi.read_text_bytes)) return PBSIM_SUCCEEDED;
+      if (!zr)
+        return sink->on_read_text(sink->user, (const char *)sl.h_read_text.p, bi.read_text_bytes) ? PBSIM_SUCCEEDED
+                                                                                                 : fail("sink aborted (read text)");
+      return deflate_stream(c, sl.df[0], sl.d_read_text.as<uint8_t>(), bi.read_text_bytes, [&](const char *z, int64_t k) {
+        return sink->on_read_text(sink->user, z, k) ? PBSIM_SUCCEEDED : fail("sink aborted (read text)");
+      });
+    };
+    auto send_maf = [&]() -> int {
+      if (!(sink->on_maf_text && bi.maf_text_bytes)) return PBSIM_SUCCEEDED;
+      if (!zm)
+        return sink->on_maf_text(sink->user, (const char *)sl.h_maf_text.p, bi.maf_text_bytes) ? PBSIM_SUCCEEDED
+                                                                                              : fail("sink aborted (MAF text)");
+      return deflate_stream(c, sl.df[1], sl.d_maf_text.as<uint8_t>(), bi.maf_text_bytes, [&](const char *z, int64_t k) {
+        return sink->on_maf_text(sink->user, z, k) ? PBSIM_SUCCEEDED : fail("sink aborted (MAF text)");
+      });
+    };
+    if (c->deflate_parallel && zr && zm && bi.read_text_bytes && bi.maf_text_bytes) {
+      // the two sinks are independent files: the read text goes through its lane on a second host thread while this one
+      // drives the MAF lane (a file's writers would serialise on its inode, two files do not)
+      if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
+      int ok_read = PBSIM_SUCCEEDED;
+      std::string err_read;
+      std::thread t([&]() {
+        (void)hipSetDevice(c->device);
+        ok_read = send_read();
+        if (!ok_read) err_read = g_err;  // the error string is thread local
+      });
+      const int ok_maf = send_maf();
+      t.join();
+      if (!ok_read) return fail(err_read);
+      if (!ok_maf) return PBSIM_FAILED;
+    } else {
+      if (!send_read()) return PBSIM_FAILED;
+      if (!send_maf()) return PBSIM_FAILED;
+    }
+  } else if (sink) {
+    HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
+    HIP_OK(c->s().h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
+    if (!pbsim_batch_fetch(c, (char *)c->s().h_read_text.p, (char *)c->s().h_maf_text.p)) return PBSIM_FAILED;
+    if (sink->on_read_text && bi.read_text_bytes &&
+        !sink->on_read_text(sink->user, (const char *)c->s().h_read_text.p, bi.read_text_bytes))
+      return fail("sink aborted (read text)");
+    if (sink->on_maf_text && bi.maf_text_bytes &&
+        !sink->on_maf_text(sink->user, (const char *)c->s().h_maf_text.p, bi.maf_text_bytes))
+      return fail("sink aborted (MAF text)");
+  }
+  return pbsim_batch_account(c);
+}
+}  // extern "C"

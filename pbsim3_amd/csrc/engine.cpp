@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "ctx.h"
+#include "engine_internal.h"
 #include "unit_io.h"
 #include "philox.h"
 
@@ -41,13 +42,16 @@ bool has_quality_row(const pbsim_ctx *c) { return c->p.method == PBSIM_METHOD_QS
 int regions_of(const pbsim_ctx *c) { return has_quality_row(c) ? 3 : 2; }
 int ncls_of(const pbsim_ctx *c) { return c->hdr.acc_hi - c->hdr.acc_lo + 1; }
 
-int upload(DevBuf &b, const void *src, size_t n, hipStream_t s) {
+}  // namespace
+
+// ---- shared with sample.cpp (engine_internal.h) ----
+int pbsim::upload(DevBuf &b, const void *src, size_t n, hipStream_t s) {
   HIP_OK(b.ensure(n));
   HIP_OK(hipMemcpyAsync(b.p, src, n, hipMemcpyHostToDevice, s));
   return PBSIM_SUCCEEDED;
 }
 
-int ensure_header_tables(pbsim_ctx *c) {
+int pbsim::ensure_header_tables(pbsim_ctx *c) {
   if (c->header_uploaded) return PBSIM_SUCCEEDED;
   if (!upload(c->d_prob2len, c->hdr.prob2len.data(), c->hdr.prob2len.size() * sizeof(int32_t), c->stream))
     return PBSIM_FAILED;
@@ -59,7 +63,7 @@ int ensure_header_tables(pbsim_ctx *c) {
 
 // [sub 94 u32 | ins 94 u32 | del 94*12 u32 | qprob 94 f64]: qc[].prob and set_mut's thresholds.  Only del_thr[q][0] depends on
 // whether an hp == 11 base has been counted yet (Q15), so both variants can be resident and a batch picks its record's.
-int ensure_qs_tabs(pbsim_ctx *c, bool hp11) {
+int pbsim::ensure_qs_tabs(pbsim_ctx *c, bool hp11) {
   if (c->qs_tabs_ready[hp11]) return PBSIM_SUCCEEDED;
   HpBias b = c->bias;
   b.hp11_seen = hp11;
@@ -76,7 +80,7 @@ int ensure_qs_tabs(pbsim_ctx *c, bool hp11) {
   return PBSIM_SUCCEEDED;
 }
 
-int ensure_class_tables(pbsim_ctx *c) {
+int pbsim::ensure_class_tables(pbsim_ctx *c) {
   if (!c->class_tables_dirty) return PBSIM_SUCCEEDED;
   std::string e;
   c->qs_tabs_ready[0] = c->qs_tabs_ready[1] = false;  // the bias may have changed
@@ -99,7 +103,7 @@ int ensure_class_tables(pbsim_ctx *c) {
 // Through PINNED staging: a device-to-host copy into pageable memory (a stack variable) is not asynchronous -- the runtime
 // stages it and waits in ways that depend on everything else the device is doing; with three walks in flight such a
 // "small" read took tens of milliseconds.
-int read_flags(pbsim_ctx *c, DeviceFlags *f) {
+int pbsim::read_flags(pbsim_ctx *c, DeviceFlags *f) {
   Slot &sl = c->s();
   HIP_OK(sl.h_flags.ensure(sizeof(DeviceFlags) + 64));
   HIP_OK(hipMemcpyAsync(sl.h_flags.p, sl.d_flags.p, sizeof(DeviceFlags), hipMemcpyDeviceToHost, sl.stream));
@@ -107,6 +111,8 @@ int read_flags(pbsim_ctx *c, DeviceFlags *f) {
   memcpy(f, sl.h_flags.p, sizeof(DeviceFlags));
   return PBSIM_SUCCEEDED;
 }
+
+namespace {
 
 // upper-case + homopolymer lengths on the GPU: enqueue on `stream` ...
 static int enqueue_prepare(pbsim_ctx *c, uint8_t *d_seq, DevBuf &hp, DevBuf &tiles, DevBuf &flags, int64_t len, int keep_first_case,
@@ -132,10 +138,12 @@ static int finish_prepare(pbsim_ctx *c, DevBuf &flags, hipStream_t stream, int64
   c->seq_hp_flag = c->p.hp_del_bias == 1 && !f.high_bytes;
   return PBSIM_SUCCEEDED;
 }
-int prepare_reference(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int keep_first_case, int64_t census_out[kHpSlots]) {
+}  // namespace
+int pbsim::prepare_reference(pbsim_ctx *c, uint8_t *d_seq, int64_t len, int keep_first_case, int64_t census_out[kHpSlots]) {
   if (!enqueue_prepare(c, d_seq, c->d_hp, c->d_tiles, c->d_ref_flags, len, keep_first_case, c->stream)) return PBSIM_FAILED;
   return finish_prepare(c, c->d_ref_flags, c->stream, census_out);
 }
+namespace {
 
 void note_hp11(pbsim_ctx *c, const int64_t census[kHpSlots]) {
   // hpfreq[11]++ in get_genome_seq (pbsim.cpp:1058) lands in hp_del_bias[0]:
@@ -145,9 +153,9 @@ void note_hp11(pbsim_ctx *c, const int64_t census[kHpSlots]) {
   }
 }
 
-int64_t batch_capacity(const pbsim_ctx *c) { return batch_capacity_for(c, c->ref_len); }
-
 }  // namespace
+
+int64_t pbsim::batch_capacity(const pbsim_ctx *c) { return batch_capacity_for(c, c->ref_len); }
 
 double pbsim::scratch_factor_of(const pbsim_ctx *c) { return std::min(2.0, std::max(1.0, c->scratch_factor)); }
 
@@ -1278,230 +1286,6 @@ int64_t pbsim_bam_header(pbsim_ctx *c, char *buf, int64_t cap) {
   return n;
 }
 
-extern "C++" {
-namespace {
-
-int ensure_deflate_tables(pbsim_ctx *c) {
-  if (c->d_df_tables.p) return PBSIM_SUCCEEDED;
-  std::vector<uint32_t> t(1024 + 256);
-  deflate_host_tables(t.data(), t.data() + 1024);
-  if (!upload(c->d_df_tables, t.data(), t.size() * 4, c->stream)) return PBSIM_FAILED;
-  HIP_OK(hipStreamSynchronize(c->stream));
-  return PBSIM_SUCCEEDED;
-}
-
-// d_text[0..n) (device; 16-byte aligned with 16 bytes of slack) -> gzip members, handed to `consume` piece by piece
-// (DF_PIECE_CHUNKS chunks each) from pinned staging.  While the host consumes piece k-1 (a file write, a memcpy),
-// piece k is being copied down and the GPU may already be working for another slot.
-// `place` (optional): where a piece of `total` compressed bytes shall be copied to (pinned host memory of the caller's, e.g.
-// an arena that keeps a whole batch) instead of the lane's double-buffered staging.
-template <class F>
-int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F &&consume,
-                   const std::function<char *(int64_t)> *place = nullptr) {
-  if (n <= 0) return PBSIM_SUCCEEDED;
-  if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
-  // chunks per piece = per launch and per copy (experiment knob PBSIM_DEFLATE_PIECE_CHUNKS; a piece's members stay below 4 GiB)
-  static const int64_t piece_chunks = [] {
-    const char *e = exp_env("PBSIM_DEFLATE_PIECE_CHUNKS");
-    const int64_t v = e ? atoll(e) : DF_PIECE_CHUNKS;
-    return std::max<int64_t>(256, std::min<int64_t>(65536, v));
-  }();
-  const int64_t piece = piece_chunks * DF_CHUNK;
-  const int64_t max_ch = std::min<int64_t>(piece_chunks, (n + DF_CHUNK - 1) / DF_CHUNK);
-  const int64_t n_pieces = (n + piece - 1) / piece;
-  const size_t status_bytes_was = sl.d_df_status.bytes;  // (ensure() only ever grows: a new allocation has another size)
-  HIP_OK(sl.d_df_status.ensure((size_t)piece_chunks * 8));
-  HIP_OK(sl.d_df_ctl.ensure(DF_CTL_BYTES));
-  // (Members stored straight into page-locked host memory by the deflate workgroups -- no dense buffer, no copy -- were measured
-  // in round 3 and rejected: 37 vs 47 Gbases/s, profiles/r03_deflate_fused_ab.txt; the code path is gone since round 5.)
-  HIP_OK(sl.h_df_total.ensure(DF_CTL_BYTES * kDfBuffers));
-  HIP_OK(sl.d_df_code.ensure(DF_TABLE_BYTES + 288 * 4));
-  const uint32_t *tab = c->d_df_tables.as<uint32_t>();
-  int lane_index = 0;
-  for (Slot &slot : c->slots)
-    if (&slot.df[1] == &sl) lane_index = 1;
-  hipStream_t lane_streams[2];
-  if (sl.own_streams) {  // a lane that runs BESIDE the bulk deliveries (the tail chains' worker): not behind their pieces in one stream
-    // (and it never touches the context-wide streams below: their lazy creation belongs to the bulk worker's lane threads
-    // alone -- lane 0 and lane 1 create different elements --, so no two threads race for one handle)
-    for (int i = 0; i < 2; i++)
-      if (!sl.own[i]) HIP_OK(hipStreamCreateWithFlags(&sl.own[i], hipStreamNonBlocking));
-    lane_streams[0] = sl.own[0];
-    lane_streams[1] = sl.own[1];
-  } else {
-    for (int i = 0; i < 2; i++)
-      if (!c->df_streams[lane_index][i]) HIP_OK(hipStreamCreateWithFlags(&c->df_streams[lane_index][i], hipStreamNonBlocking));
-    lane_streams[0] = c->df_streams[lane_index][0];
-    lane_streams[1] = c->df_streams[lane_index][1];
-  }
-  sl.stream = lane_streams[0];
-  // The look-back trusts any status word that carries the launch's epoch and a flag, and the words are never cleared between
-  // launches -- so a NEW array must start from zeros (flag 0 = nothing published): hipMalloc hands back the freed array of a
-  // destroyed context or lane with that lane's old words in it, and a lane's epochs restart.
-  if (sl.d_df_status.bytes != status_bytes_was) HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
-  // the call's code table: fitted once to the head of the text (deflate.hip), shared by all its members
-  launch_deflate_table(d_text, n, reinterpret_cast<uint32_t *>(sl.d_df_code.as<uint8_t>() + DF_TABLE_BYTES), sl.d_df_code.p, sl.stream);
-  unsigned long long *d_prof = nullptr;
-  if (getenv("PBSIM_DEFLATE_PROF")) {
-    HIP_OK(c->d_df_prof.ensure(128));
-    HIP_OK(hipMemsetAsync(c->d_df_prof.p, 0, 128, sl.stream));
-    d_prof = c->d_df_prof.as<unsigned long long>();
-  }
-  // The kernels of a piece, its copy and the host's consume() are three stages that must not wait for each other's round trips:
-  // the lane's stream always holds the NEXT piece's kernels (piece k + 1 is launched before piece k's total is read back, on
-  // the second set of staging buffers), the copy stream the next copy, and the host consumes piece k - 1 while piece k travels.
-  // (Launching a piece only after the previous one's total had arrived left the link idle whenever the other lane was not
-  // copying: 1.5 ms of kernels + a host round trip per 1.46 ms of copy.)
-  sl.copy_stream = lane_streams[1];
-  if (!sl.ev_df[0]) {
-    for (int i = 0; i < kDfBuffers; i++) {
-      HIP_OK(hipEventCreateWithFlags(&sl.ev_df[i], hipEventDisableTiming));
-      HIP_OK(hipEventCreateWithFlags(&sl.ev_cp[i], hipEventDisableTiming));
-      HIP_OK(hipEventCreate(&sl.ev_k0[i]));
-      HIP_OK(hipEventCreate(&sl.ev_k1[i]));
-    }
-  }
-  const bool trace = getenv("PBSIM_DEFLATE_TRACE") != nullptr;  // where a call's wall time goes: kernels | link | consumer
-  const auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_kernel = 0, t_copy = 0, t_consume = 0, t_begin = now();
-  int64_t out_bytes = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;  // trace: begin / end of every copy on the copy stream
-  bool used[kDfBuffers] = {false};
-  // pieces the lane's kernels run ahead of the piece whose copy is being enqueued (ahead + 1 dense buffers in use).  Four
-  // since the end of round 4 (two before): the kernels of a piece share the GPU with the next round's walk and arrive late
-  // now and then; two more pieces in hand cover that -- configs[1] 1116-1120 -> 1089-1102 ms, configs[4] 3200 -> 3100-3140
-  // (same box, profiles/r04_replay_late_ab.txt; six or eight with more buffers: no better) for 0.5 GB of HBM per lane.
-  static const int ahead_env = exp_env("PBSIM_DEFLATE_AHEAD") ? atoi(exp_env("PBSIM_DEFLATE_AHEAD")) : 4;
-  const int ahead = std::max(1, std::min(kDfBuffers - 1, ahead_env)), nbuf = ahead + 1;
-  int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
-  // piece j: kernels on staging set j & 1 into dense buffer j % 3; its total lands in h_total[j % 3]
-  auto launch = [&](int64_t j) -> int {
-    const int b = (int)(j % nbuf);
-    const int64_t off = j * piece, len = std::min(piece, n - off);
-    HIP_OK(sl.d_df_dense[b].ensure((size_t)max_ch * DF_SLOT + 64, true));
-    if (!place) HIP_OK(sl.h_df_out[b].ensure((size_t)max_ch * DF_SLOT + 64));
-    if (used[b]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - nbuf has left this dense buffer
-    uint8_t *dense = sl.d_df_dense[b].as<uint8_t>();
-    if (((sl.epoch + 1) & 0x3fffffffu) == 0) {  // the epoch wraps: start over from a cleared array; epoch 0 is never used
-      HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
-      sl.epoch++;
-    }
-    launch_deflate(d_text + off, len, sl.d_df_status.as<uint64_t>(), sl.d_df_ctl.p, ++sl.epoch, dense, tab, tab + 1024,
-                   sl.d_df_code.p, sl.stream, d_prof, sl.ev_k0[b], sl.ev_k1[b]);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(&h_total[2 * b], sl.d_df_ctl.p, DF_CTL_BYTES, hipMemcpyDeviceToHost, sl.stream));  // ticket | error, total
-    HIP_OK(hipEventRecord(sl.ev_df[b], sl.stream));
-    return PBSIM_SUCCEEDED;
-  };
-  const char *prev_ptr = nullptr;  // piece k - 1: copy possibly still in flight
-  int64_t prev_bytes = 0;
-  int prev_buf = 0;
-  for (int64_t j = 0; j < std::min<int64_t>(ahead, n_pieces); j++)
-    if (!launch(j)) return PBSIM_FAILED;
-  for (int64_t k = 0; k < n_pieces; k++) {
-    const int b = (int)(k % nbuf);
-    const double t0 = now();
-    HIP_OK(hipEventSynchronize(sl.ev_df[b]));
-    t_kernel += now() - t0;
-    const int64_t total = h_total[2 * b + 1];
-    if ((uint64_t)h_total[2 * b] >> 32) return fail("deflate: a workgroup's look-back gave up waiting for its predecessors");
-    out_bytes += total;
-    {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, sl.ev_k0[b], sl.ev_k1[b]) == hipSuccess) {
-        std::lock_guard<std::mutex> lk(c->prof_mu);
-        c->prof_deflate_ms += ms;
-        c->prof_deflate_launches++;
-        c->prof_deflate_in += std::min(piece, n - k * piece);
-        c->prof_deflate_out += total;
-      }
-    }
-    char *dst = place ? (*place)(total) : (char *)sl.h_df_out[b].p;
-    if (!dst) return fail("deflate: no room for a compressed piece");
-    HIP_OK(hipStreamWaitEvent(sl.copy_stream, sl.ev_df[b], 0));
-    if (trace) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      HIP_OK(hipEventCreate(&e0));
-      HIP_OK(hipEventCreate(&e1));
-      tev.emplace_back(e0, e1);
-      HIP_OK(hipEventRecord(e0, sl.copy_stream));
-    }
-    HIP_OK(hipMemcpyAsync(dst, sl.d_df_dense[b].p, (size_t)total, hipMemcpyDeviceToHost, sl.copy_stream));
-    if (trace) HIP_OK(hipEventRecord(tev.back().second, sl.copy_stream));
-    HIP_OK(hipEventRecord(sl.ev_cp[b], sl.copy_stream));
-    used[b] = true;
-    if (prev_bytes) {  // (before piece k + 2 is launched: it re-uses piece k - 1's buffers)
-      const double t1 = now();
-      HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
-      const double t2 = now();
-      if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
-      t_copy += t2 - t1;
-      t_consume += now() - t2;
-    }
-    prev_ptr = dst;
-    prev_bytes = total;
-    prev_buf = b;
-    // piece k's staging set is free (its total has arrived), the dense buffer of piece k - 1 once its copy is through (a
-    // stream wait inside launch): keep the kernels one piece ahead
-    if (k + ahead < n_pieces && !launch(k + ahead)) return PBSIM_FAILED;
-  }
-  if (prev_bytes) {
-    const double t1 = now();
-    HIP_OK(hipEventSynchronize(sl.ev_cp[prev_buf]));
-    const double t2 = now();
-    if (!consume(prev_ptr, prev_bytes)) return PBSIM_FAILED;
-    t_copy += t2 - t1;
-    t_consume += now() - t2;
-  }
-  if (trace) {
-    double t_link = 0, t_span = 0;
-    float ms = 0;
-    for (auto &e : tev) {
-      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) t_link += ms;
-    }
-    if (!tev.empty() && hipEventElapsedTime(&ms, tev.front().first, tev.back().second) == hipSuccess) t_span = ms;
-    for (auto &e : tev) {
-      (void)hipEventDestroy(e.first);
-      (void)hipEventDestroy(e.second);
-    }
-    fprintf(stderr,
-            "[deflate] %.1f MB -> %.1f MB in %.1f ms: waited %.1f ms for kernels, %.1f ms for copies, %.1f ms in the consumer; copies: "
-            "%.1f ms on the engine within a span of %.1f ms (%.1f GB/s while copying)\n",
-            n / 1e6, out_bytes / 1e6, now() - t_begin, t_kernel, t_copy, t_consume, t_link, t_span, t_link > 0 ? out_bytes / t_link / 1e6 : 0.0);
-  }
-  if (d_prof) {
-    unsigned long long t[16];
-    HIP_OK(hipMemcpy(t, d_prof, 128, hipMemcpyDeviceToHost));
-    const double nch = (double)((n + DF_CHUNK - 1) / DF_CHUNK);
-    static const char *names[7] = {"stage", "crc", "sizes+scan", "header", "tokens", "trailer", "store"};
-    fprintf(stderr, "[deflate prof] %.0f chunks; us per chunk (lane 0):", nch);
-    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f", names[i], t[i] / nch / 100);
-    fprintf(stderr, "\n");
-  }
-  return PBSIM_SUCCEEDED;
-}
-
-int deflate_to_host(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, char *host_dst, int64_t cap,
-                    int64_t *out_bytes) {
-  int64_t written = 0;
-  const int ok = deflate_stream(c, sl, d_text, n, [&](const char *z, int64_t k) {
-    if (written + k > cap) return fail("deflate: output buffer too small");
-    memcpy(host_dst + written, z, (size_t)k);
-    written += k;
-    return PBSIM_SUCCEEDED;
-  });
-  *out_bytes = written;
-  return ok;
-}
-
-}  // namespace
-}  // extern "C++"
-
-extern "C++" int pbsim::deflate_pieces(pbsim_ctx *c, DfLane &lane, const uint8_t *d_text, int64_t n,
-                                       const std::function<int(const char *, int64_t)> &consume,
-                                       const std::function<char *(int64_t)> *place) {
-  return deflate_stream(c, lane, d_text, n, consume, place);
-}
 extern "C++" int pbsim::prepare_enqueue(pbsim_ctx *c, uint8_t *d_seq, DevBuf &hp, DevBuf &tiles, DevBuf &flags, int64_t len,
                                         hipStream_t stream) {
   return enqueue_prepare(c, d_seq, hp, tiles, flags, len, 0, stream);
@@ -1511,132 +1295,7 @@ extern "C++" int pbsim::ensure_tables(pbsim_ctx *c, bool hp11) {
   if (c->p.method == PBSIM_METHOD_QS && !ensure_qs_tabs(c, hp11)) return PBSIM_FAILED;
   return PBSIM_SUCCEEDED;
 }
-extern "C++" int pbsim::ensure_deflate_ready(pbsim_ctx *c) { return ensure_deflate_tables(c); }
 
-int pbsim_set_deflate(pbsim_ctx *c, int on) {
-  if (!c) return fail("bad argument");
-  c->deflate = on & 3;
-  c->deflate_parallel = (on & 4) != 0;
-  return PBSIM_SUCCEEDED;
-}
-
-int64_t pbsim_deflate_bound(int64_t n) {
-  if (n <= 0) return 0;
-  return n + ((n + DF_CHUNK - 1) / DF_CHUNK) * 31;
-}
-
-int pbsim_batch_fetch_deflated(pbsim_ctx *c, char *read_gz, int64_t read_cap, char *maf_gz, int64_t maf_cap,
-                               int64_t *read_gz_bytes, int64_t *maf_gz_bytes) {
-  if (!c || !c->s().b_finalized) return fail("pbsim_batch_fetch_deflated: no finalized batch");
-  NEED_DEVICE(c);
-  HIP_OK(hipSetDevice(c->device));
-  int64_t nr = 0, nm = 0;
-  if (read_gz && !deflate_to_host(c, c->s().df[0], c->s().d_read_text.as<uint8_t>(), c->s().b_info.read_text_bytes, read_gz,
-                                  read_cap, &nr))
-    return PBSIM_FAILED;
-  if (maf_gz && !deflate_to_host(c, c->s().df[0], c->s().d_maf_text.as<uint8_t>(), c->s().b_info.maf_text_bytes, maf_gz,
-                                 maf_cap, &nm))
-    return PBSIM_FAILED;
-  if (read_gz_bytes) *read_gz_bytes = nr;
-  if (maf_gz_bytes) *maf_gz_bytes = nm;
-  return PBSIM_SUCCEEDED;
-}
-
-// host bytes -> gzip members through the same kernels (headers, tests)
-int pbsim_deflate_buffer(pbsim_ctx *c, const void *src, int64_t n, void *dst, int64_t cap, int64_t *out_bytes) {
-  if (!c || !out_bytes || n < 0 || (n > 0 && (!src || !dst))) return fail("pbsim_deflate_buffer: bad argument");
-  NEED_DEVICE(c);
-  HIP_OK(hipSetDevice(c->device));
-  *out_bytes = 0;
-  if (n == 0) return PBSIM_SUCCEEDED;
-  Slot &sl = c->slots[0];
-  DevBuf d_in;
-  HIP_OK(d_in.ensure((size_t)n + 16));
-  HIP_OK(hipMemcpyAsync(d_in.p, src, (size_t)n, hipMemcpyHostToDevice, sl.stream));
-  HIP_OK(hipStreamSynchronize(sl.stream));  // the lane's kernels run on its own stream
-  return deflate_to_host(c, sl.df[0], d_in.as<uint8_t>(), n, (char *)dst, cap, out_bytes);
-}
-
-// A driver that does not wait for a batch's text emission in finalize_text (the batch's statistics are added on the host
-// meanwhile; deliver() waits before it hands text to a sink); every emission has landed when the driver returns.
-struct DeferTextSync {
-  pbsim_ctx *c;
-  bool prev;
-  explicit DeferTextSync(pbsim_ctx *ctx) : c(ctx), prev(ctx->defer_text_sync) { c->defer_text_sync = true; }
-  ~DeferTextSync() {
-    for (Slot &sl : c->slots)
-      if (sl.stream) (void)hipStreamSynchronize(sl.stream);
-    c->defer_text_sync = prev;
-  }
-};
-
-static int deliver(pbsim_ctx *c, const pbsim_sink *sink) {
-  const pbsim_batch_info &bi = c->s().b_info;
-  if (sink && c->defer_text_sync) {  // (drivers that do not wait for the text emission in finalize_text)
-    NEED_DEVICE(c);
-    HIP_OK(hipEventSynchronize(c->s().ev_text));
-  }
-  if (sink && c->deflate) {
-    // compressed sinks stream piece by piece; a sink left as text is fetched whole as before
-    const bool zr = c->deflate & 1, zm = c->deflate & 2;
-    NEED_DEVICE(c);
-    HIP_OK(hipSetDevice(c->device));
-    if (!zr) HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
-    if (!zm) HIP_OK(c->s().h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
-    if ((!zr || !zm) &&
-        !pbsim_batch_fetch(c, zr ? nullptr : (char *)c->s().h_read_text.p, zm ? nullptr : (char *)c->s().h_maf_text.p))
-      return PBSIM_FAILED;
-    Slot &sl = c->s();
-    auto send_read = [&]() -> int {
-      if (!(sink->on_read_text && bi.read_text_bytes)) return PBSIM_SUCCEEDED;
-      if (!zr)
-        return sink->on_read_text(sink->user, (const char *)sl.h_read_text.p, bi.read_text_bytes) ? PBSIM_SUCCEEDED
-                                                                                                 : fail("sink aborted (read text)");
-      return deflate_stream(c, sl.df[0], sl.d_read_text.as<uint8_t>(), bi.read_text_bytes, [&](const char *z, int64_t k) {
-        return sink->on_read_text(sink->user, z, k) ? PBSIM_SUCCEEDED : fail("sink aborted (read text)");
-      });
-    };
-    auto send_maf = [&]() -> int {
-      if (!(sink->on_maf_text && bi.maf_text_bytes)) return PBSIM_SUCCEEDED;
-      if (!zm)
-        return sink->on_maf_text(sink->user, (const char *)sl.h_maf_text.p, bi.maf_text_bytes) ? PBSIM_SUCCEEDED
-                                                                                              : fail("sink aborted (MAF text)");
-      return deflate_stream(c, sl.df[1], sl.d_maf_text.as<uint8_t>(), bi.maf_text_bytes, [&](const char *z, int64_t k) {
-        return sink->on_maf_text(sink->user, z, k) ? PBSIM_SUCCEEDED : fail("sink aborted (MAF text)");
-      });
-    };
-    if (c->deflate_parallel && zr && zm && bi.read_text_bytes && bi.maf_text_bytes) {
-      // the two sinks are independent files: the read text goes through its lane on a second host thread while this one
-      // drives the MAF lane (a file's writers would serialise on its inode, two files do not)
-      if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
-      int ok_read = PBSIM_SUCCEEDED;
-      std::string err_read;
-      std::thread t([&]() {
-        (void)hipSetDevice(c->device);
-        ok_read = send_read();
-        if (!ok_read) err_read = g_err;  // the error string is thread local
-      });
-      const int ok_maf = send_maf();
-      t.join();
-      if (!ok_read) return fail(err_read);
-      if (!ok_maf) return PBSIM_FAILED;
-    } else {
-      if (!send_read()) return PBSIM_FAILED;
-      if (!send_maf()) return PBSIM_FAILED;
-    }
-  } else if (sink) {
-    HIP_OK(c->s().h_read_text.ensure((size_t)bi.read_text_bytes + 16));
-    HIP_OK(c->s().h_maf_text.ensure((size_t)bi.maf_text_bytes + 16));
-    if (!pbsim_batch_fetch(c, (char *)c->s().h_read_text.p, (char *)c->s().h_maf_text.p)) return PBSIM_FAILED;
-    if (sink->on_read_text && bi.read_text_bytes &&
-        !sink->on_read_text(sink->user, (const char *)c->s().h_read_text.p, bi.read_text_bytes))
-      return fail("sink aborted (read text)");
-    if (sink->on_maf_text && bi.maf_text_bytes &&
-        !sink->on_maf_text(sink->user, (const char *)c->s().h_maf_text.p, bi.maf_text_bytes))
-      return fail("sink aborted (MAF text)");
-  }
-  return pbsim_batch_account(c);
-}
 
 // The quota loop `while (len_total < sim.len_quota)` (pbsim.cpp:3792) as
 // speculative bulk batches + prefix scan + a serial tail.  Batches
@@ -1806,924 +1465,6 @@ int pbsim_simulate_wgs(pbsim_ctx *c, const pbsim_sink *sink) {
     }
   }
   drop_pending();
-  return PBSIM_SUCCEEDED;
-}
-
-// Replaces get_transcript_inf (pbsim.cpp:1075-1136) + the streaming reader and
-// per-transcript hp of simulate_by_*_trans (:4428-4485): all units are concatenated
-// with '\n' separators (a byte no sequence contains, so homopolymer runs never
-// join across units) and made resident once.
-static int set_units(pbsim_ctx *c, int64_t n, const char *const *ids, const int64_t *plus_exp,
-                     const int64_t *minus_exp, const uint8_t *const *seqs, const int64_t *lens, bool templ) {
-  HIP_OK(hipSetDevice(c->device));
-  // errhmm trans and both templ variants upper-case seq[1..len] only (pbsim.cpp:4457, 3332, 5063);
-  // qshmm trans upper-cases seq[0..len-1] (:2778)
-  const int keep_first = templ || c->p.method == PBSIM_METHOD_ERR;
-  int64_t total = 0, reads = 0, max_len = 0;
-  for (int64_t u = 0; u < n; u++) {
-    if (lens[u] < 1 || lens[u] > 1000000) return fail("transcript length outside 1-1000000");
-    total += lens[u] + 1;
-    reads += (int64_t)(int)(plus_exp[u] + minus_exp[u]);  // `int read_num` (pbsim.cpp:4149)
-    max_len = std::max(max_len, lens[u]);
-  }
-  // zero total expression is legal: the reference simply simulates nothing and prints its report (with NaN means)
-  if (reads > 0x7fffff00LL) return fail("too many reads");
-  // start-position buckets per rank (pbsim.cpp:4200-4224); unused by templ
-  const int rank_max = (int)ceil((float)max_len / 1000);  // pbsim.cpp:1133
-  SspTables st;
-  build_ssp_tables(rank_max, &st);
-  std::vector<uint8_t> ssp((size_t)(rank_max + 1) * 1000, 0);
-  for (int k = 1; k <= rank_max; k++)
-    for (int i = 1; i <= 1000; i++) ssp[(size_t)k * 1000 + (i - 1)] = (uint8_t)(st.value[(size_t)k * 1001 + i] / 5);
-  // in simulate_by_errhmm_trans the verbatim copy of an accuracy-100 read, `for (i=0; i<mut.len; i++)`
-  // (pbsim.cpp:4533), runs on the same `i` as the per-transcript read loop (:4487), which therefore continues at
-  // i = mut.len + 1 behind such a read.  Which reads a transcript makes then depends on the header draws of the reads
-  // before it -- a serial chain, but over header draws only (one Philox block and three table lookups per read, the
-  // arithmetic of k_header_trans), so the host walks it once here and the kernels see an ordinary read -> unit map.
-  const bool q5 = !templ && c->p.method == PBSIM_METHOD_ERR && c->hdr.acc_hi == 100;
-  std::vector<uint8_t> cat((size_t)total);
-  std::vector<int64_t> ubase(n), ulen(n);
-  std::vector<int32_t> urank(n), offt((size_t)n * 21), runit;
-  std::vector<int64_t> rbase;
-  std::vector<uint8_t> rminus;
-  runit.reserve((size_t)reads);
-  rbase.reserve((size_t)reads);
-  rminus.reserve((size_t)reads);
-  std::vector<char> names((size_t)n * 132, 0);
-  int64_t pos = 0;
-  for (int64_t u = 0; u < n; u++) {
-    memcpy(cat.data() + pos, seqs[u], (size_t)lens[u]);
-    cat[pos + lens[u]] = '\n';
-    ubase[u] = pos;
-    ulen[u] = lens[u];
-    urank[u] = (int32_t)ceil((double)lens[u] / 1000);  // pbsim.cpp:4494
-    for (int k = 0; k < 21; k++) {                      // pbsim.cpp:4496-4501
-      const double value = (k == 0) ? 0.0 : ((double)(k * 5) - 2.5) / 100;
-      offt[(size_t)u * 21 + k] = (int32_t)(int)((double)lens[u] * value + 0.5);
-    }
-    strncpy(&names[(size_t)u * 132], ids[u], 128);
-    const int64_t rn = (int64_t)(int)(plus_exp[u] + minus_exp[u]);
-    for (int64_t i = 1; i <= rn; i++) {
-      if (q5) {
-        if ((int64_t)runit.size() >= 0x7fffff00LL) return fail("too many reads");
-        const U4 w = header_block(c->p.seed, 0u, (uint32_t)(runit.size() + 1));
-        int64_t L = c->hdr.prob2len[(size_t)(w.x % (uint32_t)c->hdr.len_rv) + 1];
-        const int acc = c->hdr.prob2acc[(size_t)(w.y % (uint32_t)c->hdr.acc_rv) + 1];
-        const uint32_t rv = (uint32_t)st.rv[(size_t)urank[u]];
-        const int64_t off = offt[(size_t)u * 21 + ssp[(size_t)urank[u] * 1000 + w.z % (rv ? rv : 1u)]];
-        if (off + L > lens[u]) L = lens[u] - off;
-        runit.push_back((int32_t)u);
-        rbase.push_back(pos);
-        rminus.push_back((i > plus_exp[u]) ? 1 : 0);
-        if (acc == 100) i = std::max<int64_t>(L, 0);  // the clobbered counter; the loop's i++ follows
-        continue;
-      }
-      runit.push_back((int32_t)u);
-      rbase.push_back(pos);
-      rminus.push_back((i > plus_exp[u]) ? 1 : 0);  // pbsim.cpp:4516-4522
-    }
-    pos += lens[u] + 1;
-  }
-  reads = (int64_t)runit.size();
-
-  // hp-del-bias census weighted by expression (pbsim.cpp:4352-4426)
-  hp_bias_default(&c->bias);
-  c->bias.hp11_seen = false;
-  if (c->p.hp_del_bias != 1) {
-    int64_t freq[kHpSlots] = {0};
-    for (int64_t u = 0; u < n; u++)
-      hp_census_weighted(seqs[u], lens[u], (int64_t)(int)(plus_exp[u] + minus_exp[u]), keep_first, freq);
-    hp_bias_from_census(c->p.hp_del_bias, freq, &c->bias);
-    c->bias.hp11_seen = freq[11] > 0;  // hpfreq[11] aliases hp_del_bias[0] (Q15)
-  }
-  c->class_tables_dirty = true;
-  c->coop_wg_errhmm[0] = c->coop_wg_errhmm[1] = 0;
-
-  HIP_OK(c->d_seq_own.ensure((size_t)total + 64));
-  HIP_OK(hipMemcpyAsync(c->d_seq_own.p, cat.data(), (size_t)total, hipMemcpyHostToDevice, c->stream));
-  HIP_OK(hipMemsetAsync(c->d_seq_own.as<uint8_t>() + total, 0, 64, c->stream));
-  int64_t census[kHpSlots] = {0};
-  if (!prepare_reference(c, c->d_seq_own.as<uint8_t>(), total, keep_first, census)) return PBSIM_FAILED;
-  if (reads > 0) {
-    if (!upload(c->d_read_unit, runit.data(), runit.size() * 4, c->stream)) return PBSIM_FAILED;
-    if (!upload(c->d_read_base, rbase.data(), rbase.size() * 8, c->stream)) return PBSIM_FAILED;
-    if (!upload(c->d_read_minus, rminus.data(), rminus.size(), c->stream)) return PBSIM_FAILED;
-  }
-  if (!upload(c->d_unit_len, ulen.data(), ulen.size() * 8, c->stream)) return PBSIM_FAILED;
-  if (!upload(c->d_unit_rank, urank.data(), urank.size() * 4, c->stream)) return PBSIM_FAILED;
-  if (!upload(c->d_unit_names, names.data(), names.size(), c->stream)) return PBSIM_FAILED;
-  if (!upload(c->d_off_table, offt.data(), offt.size() * 4, c->stream)) return PBSIM_FAILED;
-  if (!upload(c->d_ssp, ssp.data(), ssp.size(), c->stream)) return PBSIM_FAILED;
-  if (!upload(c->d_ssp_rv, st.rv.data(), st.rv.size() * 4, c->stream)) return PBSIM_FAILED;
-  HIP_OK(hipStreamSynchronize(c->stream));
-  c->d_seq = c->d_seq_own.as<uint8_t>();
-  c->ref_len = total;  // only sizes the batches; record lengths come from unit_len
-  c->unit = 0;
-  c->n_units = n;
-  c->trans_reads = reads;
-  for (Slot &sl : c->slots) sl.b_enqueued = sl.b_walked = sl.b_finalized = false;
-  return PBSIM_SUCCEEDED;
-}
-
-int pbsim_set_transcripts(pbsim_ctx *c, int64_t n, const char *const *ids, const int64_t *plus_exp,
-                          const int64_t *minus_exp, const uint8_t *const *seqs, const int64_t *lens) {
-  if (!c || n < 1 || !ids || !plus_exp || !minus_exp || !seqs || !lens) return fail("pbsim_set_transcripts: bad argument");
-  NEED_DEVICE(c);
-  if (c->p.strategy != PBSIM_STRATEGY_TRANS) return fail("pbsim_set_transcripts: strategy is not trans");
-  return set_units(c, n, ids, plus_exp, minus_exp, seqs, lens, false);
-}
-
-// get_templ_inf (pbsim.cpp:1366-1418) + the per-template loop of simulate_by_*_templ (:5055-5103):
-// every template is one unit with exactly one '+' read over its whole length
-int pbsim_set_templates(pbsim_ctx *c, int64_t n, const char *const *ids, const uint8_t *const *seqs,
-                        const int64_t *lens) {
-  if (!c || n < 1 || !ids || !seqs || !lens) return fail("pbsim_set_templates: bad argument");
-  NEED_DEVICE(c);
-  if (c->p.strategy != PBSIM_STRATEGY_TEMPL) return fail("pbsim_set_templates: strategy is not templ");
-  std::vector<int64_t> one((size_t)n, 1), zero((size_t)n, 0);
-  return set_units(c, n, ids, one.data(), zero.data(), seqs, lens, true);
-}
-
-// get_sample_inf's product (pbsim.cpp:1155-1330): the quality strings that passed the length and accuracy
-// filter, in file order.  Parsing, filtering, the statistics and the stored-profile files are the caller's.
-int pbsim_set_sample_profile(pbsim_ctx *c, int64_t n, const uint8_t *const *quals, const int64_t *lens) {
-  if (!c || n < 1 || !quals || !lens) return fail("pbsim_set_sample_profile: bad argument");
-  NEED_DEVICE(c);
-  if (c->p.method != PBSIM_METHOD_SAMPLE) return fail("pbsim_set_sample_profile: method is not sample");
-  if (n > 0x7fffffffLL) return fail("too many sample reads");
-  HIP_OK(hipSetDevice(c->device));
-  c->sq_len.resize((size_t)n);
-  c->sq_off.resize((size_t)n);
-  int64_t total = 0, bytes = 0;
-  for (int64_t i = 0; i < n; i++) {
-    if (lens[i] < 1 || lens[i] > 1000000) return fail("sample read length outside 1-1000000");
-    c->sq_len[(size_t)i] = (int32_t)lens[i];
-    c->sq_off[(size_t)i] = bytes;
-    total += lens[i];
-    bytes += (lens[i] + 7) & ~7LL;
-  }
-  std::vector<uint8_t> pool((size_t)bytes + 8, 0);
-  for (int64_t i = 0; i < n; i++) memcpy(pool.data() + c->sq_off[(size_t)i], quals[i], (size_t)lens[i]);
-  if (!upload(c->d_sq, pool.data(), pool.size(), c->stream)) return PBSIM_FAILED;
-  HIP_OK(hipStreamSynchronize(c->stream));
-  c->sq_total = total;
-  return PBSIM_SUCCEEDED;
-}
-
-// simulate_by_sample (pbsim.cpp:1694-1949) for the current record.  Each sweep over the profile uses string s
-// `sample_num` or `sample_num + 1` times ((sample_value + s) % sample_interval == 0), reads are numbered in that
-// order, and a read is made as long as len_total < quota at its start.  A chunk = a run of consecutive strings
-// with all their copies; its strings walk in parallel, one lane each (k_walk_sample), and everything after the walk
-// (prefix in read order, the cut, text, statistics) is the ordinary batch machinery.
-extern "C++" {
-namespace {
-
-// Host side of the chunks: which strings a chunk holds and how their copies are laid out in the scratch pool (plan),
-// and the upload + walk + pass-0 prefix of a planned chunk on slot 0 (launch).  Shared by the one-GPU driver and the
-// sharded one; where a chunk ends never changes a byte (tests/test_gpu_sample.py).
-struct SampleChunks {
-  struct Ent {
-    int64_t line, num;  // string index, copies to make in this chunk
-    int32_t len;        // its current length (shorter than the file's once a chain is carried over)
-  };
-  struct Chunk {
-    std::vector<Ent> cand;
-    size_t n_c = 0;              // strings of cand[] the chunk takes
-    int64_t n_tasks = 0;
-    int64_t next_probe = 0;      // the string after the last one that was looked at
-    std::vector<int32_t> h_len, h_vbase, h_cap, h_tos, h_sot;
-    std::vector<int64_t> h_qoff, h_woff;
-    int32_t n_coop_waves = 0;    // leading line waves (the longest strings) whose strings get a wave each
-  };
-  pbsim_ctx *c;
-  int64_t F, G, interval = 1, sample_num = 0;
-  // a string whose copies do not fit one chunk continues in the next one: copies done so far, current length
-  int64_t carry_line = -1, carry_done = 0;
-  int32_t carry_len = 0;
-  std::vector<int32_t> order, order_tmp;
-
-  int init(int64_t quota) {
-    F = (int64_t)c->sq_len.size();
-    G = c->ref_len;
-    sample_num = quota / c->sq_total;            // :1718-1728
-    const int64_t residue = quota % c->sq_total;
-    interval = 1;
-    if (residue != 0) {
-      interval = (int64_t)((double)(c->sq_total / residue) * 2 + 0.5);
-      if (interval > (int64_t)(F * 0.5)) interval = (int64_t)(F * 0.5);
-    }
-    if (interval < 1) return fail("sample profile holds a single read: the reference divides by zero here (pbsim.cpp:1741)");
-    return PBSIM_SUCCEEDED;
-  }
-  // How many of the chunk's line waves (64 strings each, longest first) are walked one WAVE per string (k_walk_sample's
-  // scoop_walk_string): a string's copies are a serial chain, a lane takes 0.6 us per column, a wave 0.03, and a chunk holds at
-  // most 2^18 strings -- four lane waves per SIMD, which cannot hide the lanes' latencies.  Default: every string (measured on
-  // 200 000 strings, 2 Gbases: 42-53 ms against 60 with the strings below twice the mean length on lanes and 78-152 with all of
-  // them there).  PBSIM_COOP_LEN as for the HMM walks: -1 none, 0 all, n = the line waves whose strings all have >= n
-  // characters.  Depends on the chunk alone: every rank of a sharded run decides alike.
-  int32_t coop_waves(const std::vector<Ent> &cand, size_t n_c) const {
-    if (n_c == 0) return 0;
-    const int32_t n_w = (int32_t)((n_c + 63) / 64);
-    const char *e = getenv("PBSIM_COOP_LEN");
-    int64_t thr = e ? atoll(e) : -2;
-    if (thr == -1) return 0;
-    if (thr == 0) return n_w;
-    if (thr < 0) return n_w;
-    int32_t n = 0;
-    while (n < n_w && cand[(size_t)order[std::min(n_c, (size_t)(n + 1) * 64) - 1]].len >= thr) n++;
-    return n;
-  }
-  // order[] = the first n_c strings by length, longest first, ties in file order: a stable LSD radix sort over the 20 bits a
-  // length has (<= 1 000 000, pbsim_set_sample_profile) -- std::stable_sort took 15 ms of a 65 ms job for 200 000 strings
-  void sort_by_length(const std::vector<Ent> &cand, size_t n_c) {
-    order.resize(n_c);
-    order_tmp.resize(n_c);
-    uint32_t cnt[1025];
-    for (int pass = 0; pass < 2; pass++) {
-      const int shift = pass * 10;
-      memset(cnt, 0, sizeof cnt);
-      auto key = [&](int32_t i) { return ((0xfffffu - (uint32_t)cand[(size_t)i].len) >> shift) & 1023u; };
-      if (pass == 0) for (size_t i = 0; i < n_c; i++) cnt[key((int32_t)i) + 1]++;
-      else for (size_t i = 0; i < n_c; i++) cnt[key(order_tmp[i]) + 1]++;
-      for (int b = 0; b < 1024; b++) cnt[b + 1] += cnt[b];
-      if (pass == 0) for (size_t i = 0; i < n_c; i++) order_tmp[cnt[key((int32_t)i)]++] = (int32_t)i;
-      else for (size_t i = 0; i < n_c; i++) order[cnt[key(order_tmp[i])]++] = order_tmp[i];
-    }
-  }
-  int64_t copies_of(int64_t sv, int64_t line) const { return sample_num + (((sv + line) % interval == 0) ? 1 : 0); }
-  // strings of [line, F) that have copies in this sweep (the sharded driver deals them out in equal runs)
-  int64_t count_candidates(int64_t sv, int64_t line) const {
-    int64_t n = 0;
-    for (int64_t l = line; l < F; l++) n += (copies_of(sv, l) - (l == carry_line ? carry_done : 0)) > 0;
-    return n;
-  }
-
-  // the chunk that starts at `line`: at most max_cand strings, shrunk until its scratch fits the pool.  ck->cand empty: no
-  // string from `line` on has copies (ck->next_probe == F).
-  int plan(int64_t sv, int64_t line, size_t max_cand, Chunk *ck) {
-    ck->cand.clear();
-    ck->cand.reserve((size_t)std::min<int64_t>((int64_t)max_cand, std::max<int64_t>(F - line, 0)));
-    int64_t probe = line;
-    int64_t phase = interval > 0 ? (sv + probe) % interval : 0;  // (sv + probe) % interval, kept up to date without a division per string
-    while (probe < F && ck->cand.size() < max_cand) {
-      int64_t k = sample_num + (phase == 0 ? 1 : 0);  // = copies_of(sv, probe)
-      if (++phase == interval) phase = 0;
-      int32_t len = c->sq_len[(size_t)probe];
-      if (probe == carry_line) {
-        k -= carry_done;
-        len = carry_len;
-      }
-      if (k > 0) ck->cand.push_back(Ent{probe, k, len});
-      probe++;
-    }
-    ck->next_probe = probe;
-    ck->n_c = 0;
-    ck->n_tasks = 0;
-    if (ck->cand.empty()) return PBSIM_SUCCEEDED;
-    // ---- lay the chunk out.  Reads stay in file order; LANES are dealt by length (the longest strings share a
-    // wave), one virtual wave of scratch per copy.  Shrink the chunk until it fits the pool.
-    std::vector<Ent> &cand = ck->cand;
-    size_t n_c = cand.size();
-    int64_t need = 0, n_tasks = 0;
-    for (;;) {
-      sort_by_length(cand, n_c);
-      ck->h_vbase.assign(1, 0);
-      ck->h_cap.clear();
-      ck->h_woff.clear();
-      need = 0;
-      n_tasks = 0;
-      ck->n_coop_waves = coop_waves(cand, n_c);
-      for (size_t w0 = 0; w0 < n_c; w0 += 64) {
-        int64_t kmax = 0, lmax = 0;
-        for (size_t i = w0; i < std::min(n_c, w0 + 64); i++) {
-          const Ent &e = cand[(size_t)order[i]];
-          kmax = std::max(kmax, e.num);
-          lmax = std::max<int64_t>(lmax, std::min<int64_t>(e.len, G));
-          n_tasks += e.num;
-        }
-        const int32_t transposed = (int64_t)(w0 / 64) < ck->n_coop_waves ? kWaveTransposed : 0;  // rows task by task
-        int64_t cap_dw = (2 * lmax + kScratchPad + 3) / 4;
-        if (transposed) cap_dw = (cap_dw + 3) & ~3LL;  // ... each on a 16-byte boundary (k_sample_qsum reads them 16 bytes at a time)
-        for (int64_t k = 0; k < kmax; k++) {
-          ck->h_cap.push_back((int32_t)cap_dw | transposed);
-          ck->h_woff.push_back(need);
-          need += cap_dw * 256 * 3;
-        }
-        ck->h_vbase.push_back((int32_t)ck->h_cap.size());
-      }
-      if (need <= c->scratch_budget && n_tasks <= 0x3fffffff && ck->h_cap.size() <= 0x1ffffff) break;
-      if (n_c > 1) {
-        n_c = (n_c + 1) / 2;
-        continue;
-      }
-      // one string alone: make as many of its copies as fit, the chain continues in the next chunk
-      const int64_t per_copy = need / cand[0].num;
-      const int64_t kfit = c->scratch_budget / std::max<int64_t>(per_copy, 1);
-      if (kfit < 1) return fail("scratch pool too small for a single sampled read (pbsim_set_scratch_bytes)");
-      cand[0].num = std::min(cand[0].num, kfit);
-    }
-    ck->h_len.assign(((n_c + 63) / 64) * 64, 0);
-    ck->h_qoff.assign(ck->h_len.size(), 0);
-    ck->h_tos.assign(ck->h_cap.size() * 64, -1);
-    ck->h_sot.resize((size_t)n_tasks);
-    {
-      std::vector<int32_t> pos_of(n_c);
-      for (size_t i = 0; i < n_c; i++) pos_of[(size_t)order[i]] = (int32_t)i;
-      int64_t t = 0;
-      for (size_t e = 0; e < n_c; e++) {  // tasks in file order, lanes in length order
-        const size_t pos = (size_t)pos_of[e];
-        ck->h_len[pos] = cand[e].len;
-        ck->h_qoff[pos] = c->sq_off[(size_t)cand[e].line];
-        const int64_t v0 = ck->h_vbase[pos / 64];
-        for (int64_t k = 0; k < cand[e].num; k++) {
-          const int64_t slot = (v0 + k) * 64 + (int64_t)(pos % 64);
-          ck->h_tos[(size_t)slot] = (int32_t)t;
-          ck->h_sot[(size_t)t] = (int32_t)slot;
-          t++;
-        }
-      }
-    }
-    ck->n_c = n_c;
-    ck->n_tasks = n_tasks;
-    return PBSIM_SUCCEEDED;
-  }
-  // where a chunk leaves the sweep: past its last string, unless that string still has copies to make
-  bool last_unfinished(int64_t sv, const Chunk &ck, int64_t *last_done) const {
-    const Ent &last = ck.cand[ck.n_c - 1];
-    *last_done = (last.line == carry_line ? carry_done : 0) + last.num;
-    return *last_done < copies_of(sv, last.line);
-  }
-
-  // upload + walk + pass-0 prefix of the chunk on the selected slot, not waited for; its reads are first_read .. first_read + n_tasks - 1
-  int enqueue(const Chunk &ck, int64_t first_read) {
-    Slot &sl = c->s();
-    const int64_t n_tasks = ck.n_tasks;
-    const int64_t n_lines = (int64_t)ck.h_len.size(), n_lw = (int64_t)ck.h_vbase.size() - 1, V = (int64_t)ck.h_cap.size();
-    if (first_read - 1 + n_tasks > 0xfffffff0LL) return fail("read index exceeds 32 bits");
-    // ---- device state of the batch
-    HIP_OK(sl.d_flags.ensure(sizeof(DeviceFlags)));
-    HIP_OK(sl.d_len.ensure(n_tasks * 4));
-    HIP_OK(sl.d_off.ensure(n_tasks * 4));
-    HIP_OK(sl.d_task_of_slot.ensure(V * 64 * 4));
-    HIP_OK(sl.d_slot_of_task.ensure(n_tasks * 4));
-    HIP_OK(sl.d_wave_cap.ensure(V * 4));
-    HIP_OK(sl.d_wave_off.ensure(V * 8));
-    HIP_OK(sl.d_out_len.ensure(n_tasks * 4));
-    HIP_OK(sl.d_maf_len.ensure(n_tasks * 4));
-    HIP_OK(sl.d_nsub.ensure(n_tasks * 4));
-    HIP_OK(sl.d_nins.ensure(n_tasks * 4));
-    HIP_OK(sl.d_ndel.ensure(n_tasks * 4));
-    HIP_OK(sl.d_qsum.ensure(n_tasks * 8));
-    HIP_OK(sl.d_cum.ensure((n_tasks + 1) * 8));
-    HIP_OK(sl.d_scan_tmp.ensure((n_tasks / 1024 + 8) * 8));
-    HIP_OK(sl.d_scratch.ensure((size_t)c->scratch_budget + kScratchSlack, true));
-    HIP_OK(c->d_sq_line_len.ensure(n_lines * 4));
-    HIP_OK(c->d_sq_line_qoff.ensure(n_lines * 8));
-    HIP_OK(c->d_sq_vbase.ensure((n_lw + 1) * 4));
-    DeviceFlags f0;
-    memset(&f0, 0, sizeof f0);
-    f0.total_slots = V * 64;
-    f0.n_final = n_tasks;
-    HIP_OK(hipMemcpyAsync(sl.d_flags.p, &f0, sizeof f0, hipMemcpyHostToDevice, sl.stream));
-    HIP_OK(hipMemcpyAsync(c->d_sq_line_len.p, ck.h_len.data(), n_lines * 4, hipMemcpyHostToDevice, sl.stream));
-    HIP_OK(hipMemcpyAsync(c->d_sq_line_qoff.p, ck.h_qoff.data(), n_lines * 8, hipMemcpyHostToDevice, sl.stream));
-    HIP_OK(hipMemcpyAsync(c->d_sq_vbase.p, ck.h_vbase.data(), (n_lw + 1) * 4, hipMemcpyHostToDevice, sl.stream));
-    HIP_OK(hipMemcpyAsync(sl.d_task_of_slot.p, ck.h_tos.data(), V * 64 * 4, hipMemcpyHostToDevice, sl.stream));
-    HIP_OK(hipMemcpyAsync(sl.d_slot_of_task.p, ck.h_sot.data(), n_tasks * 4, hipMemcpyHostToDevice, sl.stream));
-    HIP_OK(hipMemcpyAsync(sl.d_wave_cap.p, ck.h_cap.data(), V * 4, hipMemcpyHostToDevice, sl.stream));
-    HIP_OK(hipMemcpyAsync(sl.d_wave_off.p, ck.h_woff.data(), V * 8, hipMemcpyHostToDevice, sl.stream));
-    DeviceFlags *flags = sl.d_flags.as<DeviceFlags>();
-    SampleArgs a;
-    memset(&a, 0, sizeof a);
-    a.seed = c->p.seed;
-    a.unit = (uint32_t)c->unit;
-    a.first_read = first_read;
-    a.n_lines = (int32_t)n_lines;
-    a.n_line_waves = (int32_t)n_lw;
-    a.n_coop_waves = ck.n_coop_waves;
-    {
-      // persistent workgroups of the wave path: four per CU = the four waves per SIMD the kernel's 103 VGPRs allow (measured:
-      // 512 / 768 / 1024 / 1280 / 2048 workgroups -> 43.2 / 37.4 / 34.9 / 39.6 / 34.9 ms for the 2-Gbase bench; capping the
-      // kernel at 96 VGPRs for a fifth wave bought nothing).  PBSIM_SAMPLE_COOP_WG: experiment knob
-      const char *cb = exp_env("PBSIM_SAMPLE_COOP_WG");
-      a.n_coop_blocks = (int32_t)std::min<int64_t>(((int64_t)ck.n_coop_waves * 64 + 3) / 4, cb && atoi(cb) > 0 ? atoi(cb) : 1024);
-    }
-    a.n_coop_slots = (int64_t)ck.h_vbase[(size_t)ck.n_coop_waves] * 64;
-    a.ref.seq = c->d_seq;
-    a.ref.hp = c->d_hp.as<uint8_t>();
-    a.ref.len = G;
-    a.quals = c->d_sq.as<uint8_t>();
-    a.line_qoff = c->d_sq_line_qoff.as<int64_t>();
-    a.line_len = c->d_sq_line_len.as<int32_t>();
-    a.vbase = c->d_sq_vbase.as<int32_t>();
-    a.task_of_slot = sl.d_task_of_slot.as<int32_t>();
-    a.wave_cap = sl.d_wave_cap.as<int32_t>();
-    a.wave_off = sl.d_wave_off.as<int64_t>();
-    a.scratch = sl.d_scratch.as<uint8_t>();
-    a.span = sl.d_len.as<int32_t>();
-    a.off = sl.d_off.as<int32_t>();
-    a.out_len = sl.d_out_len.as<int32_t>();
-    a.maf_len = sl.d_maf_len.as<int32_t>();
-    a.nsub = sl.d_nsub.as<int32_t>();
-    a.nins = sl.d_nins.as<int32_t>();
-    a.ndel = sl.d_ndel.as<int32_t>();
-    a.qsum = sl.d_qsum.as<double>();
-    const uint8_t *t = c->d_qs_tabs_v[c->bias.hp11_seen].as<uint8_t>();
-    a.sub_thre = reinterpret_cast<const uint32_t *>(t);
-    a.ins_thre = reinterpret_cast<const uint32_t *>(t + 94 * 4);
-    a.del_thr = reinterpret_cast<const uint32_t *>(t + 94 * 8);
-    a.qprob = reinterpret_cast<const double *>(t + 94 * 8 + 94 * 48);
-    a.flags = flags;
-    if (sl.sq_pending) {  // (a chunk whose statistics were never fetched: its sums still read the pool)
-      HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_sq_done, 0));
-      sl.sq_pending = false;
-    }
-    launch_walk_sample(a, c->seq_hp_flag, sl.stream);
-    if (a.n_coop_slots > 0) {
-      if (!c->sq_stream) HIP_OK(hipStreamCreateWithFlags(&c->sq_stream, hipStreamNonBlocking));
-      if (!sl.ev_sq_walk) {
-        HIP_OK(hipEventCreateWithFlags(&sl.ev_sq_walk, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&sl.ev_sq_done, hipEventDisableTiming));
-      }
-      HIP_OK(hipEventRecord(sl.ev_sq_walk, sl.stream));
-      HIP_OK(hipStreamWaitEvent(c->sq_stream, sl.ev_sq_walk, 0));
-      launch_sample_qsum(a, c->sq_stream);
-      HIP_OK(hipEventRecord(sl.ev_sq_done, c->sq_stream));
-      sl.sq_pending = true;
-    }
-    launch_gather_pass0_scan(a.out_len, n_tasks, 1, sl.d_cum.as<int64_t>(), sl.d_scan_tmp.as<int64_t>(),
-                             &flags->sums[0], sl.stream);
-    HIP_OK(hipGetLastError());
-    return PBSIM_SUCCEEDED;
-  }
-  // ... and the wait for it: the chunk's flags and pass-0 bases, the slot's batch state for pbsim_batch_finalize
-  int finish(const Chunk &ck, int64_t first_read) {
-    Slot &sl = c->s();
-    const int64_t n_tasks = ck.n_tasks, V = (int64_t)ck.h_cap.size();
-    sl.b_enqueued = false;
-    DeviceFlags f;
-    if (!read_flags(c, &f)) return PBSIM_FAILED;
-    if (f.error & kErrScratchOverflow) return fail("a sampled read produced more MAF columns than its scratch holds");
-    sl.b_first = first_read;
-    sl.b_n = n_tasks;
-    sl.b_slots_max = V * 64;
-    sl.b_truncated = false;
-    sl.b_enqueued = false;
-    sl.b_walked = true;
-    sl.b_finalized = false;
-    sl.b_pass0 = f.sums[0];
-    return PBSIM_SUCCEEDED;
-  }
-  int launch(const Chunk &ck, int64_t first_read) { return enqueue(ck, first_read) && finish(ck, first_read); }
-};
-
-int sample_common_checks(pbsim_ctx *c) {
-  if (c->p.method != PBSIM_METHOD_SAMPLE) return fail("pbsim_simulate_sample: method is not sample");
-  if (!c->d_seq) return fail("no reference set (pbsim_set_reference)");
-  if (c->sq_len.empty()) return fail("no sample profile set (pbsim_set_sample_profile)");
-  HIP_OK(hipSetDevice(c->device));
-  if (!ensure_class_tables(c) || !ensure_qs_tabs(c, c->bias.hp11_seen)) return PBSIM_FAILED;
-  return PBSIM_SUCCEEDED;
-}
-
-}  // namespace
-}  // extern "C++"
-
-int pbsim_simulate_sample(pbsim_ctx *c, const pbsim_sink *sink) {
-  if (!c) return fail("bad argument");
-  NEED_DEVICE(c);
-  if (!sample_common_checks(c)) return PBSIM_FAILED;
-  pbsim_reset_stats(c);
-  const int64_t quota = pbsim_unit_quota(c);
-  SampleChunks S;
-  S.c = c;
-  if (!S.init(quota)) return PBSIM_FAILED;
-  const int64_t F = S.F;
-  for (int s = 0; s < 2; s++) c->slots[(size_t)s].ref = current_ref(c);
-  // Where the next chunk starts: a sweep (its sample_value, pbsim.cpp:1732, drawn from the number of reads made so far) and a
-  // string of it.  next_chunk plans the next chunk that holds anything, opening sweeps as it goes (:1922: from the second
-  // sweep on a string is used once or not at all).
-  struct Pos {
-    int64_t sv = 0, line = 0;
-    bool open = false;
-  } pos;
-  auto next_chunk = [&](int64_t res_now, Pos *at, SampleChunks::Chunk *ck) -> int {
-    for (;;) {
-      if (!at->open) {
-        at->sv = (int64_t)(header_block(c->p.seed, (uint32_t)c->unit, (uint32_t)(res_now + 1)).w % (uint32_t)F);
-        at->line = 0;
-        at->open = true;
-      }
-      while (at->line < F) {
-        if (!S.plan(at->sv, at->line, (size_t)1 << 18, ck)) return PBSIM_FAILED;
-        if (!ck->cand.empty()) return PBSIM_SUCCEEDED;
-        at->line = ck->next_probe;
-      }
-      S.sample_num = 0;
-      S.carry_line = -1;
-      at->open = false;
-    }
-  };
-  // Two slots: while a chunk's text emission, delivery and statistics are under way, the NEXT chunk is planned and walks --
-  // whenever the next chunk is determined by then (see `look` below).
-  DeferTextSync defer_guard(c);
-  SampleChunks::Chunk cks[2];
-  int cur = 0;
-  bool have = false;  // cks[cur] is planned and enqueued already
-  const bool trace = getenv("PBSIM_TRACE") != nullptr;
-  auto wall_ms = []() {
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-  };
-  int64_t len_total = 0, res = 0;
-  bool done = false;
-  auto drain = [&]() {
-    for (int s = 0; s < 2; s++)
-      if (c->slots[(size_t)s].stream) (void)hipStreamSynchronize(c->slots[(size_t)s].stream);
-    c->cur = 0;
-  };
-  while (len_total < quota && !done) {
-    SampleChunks::Chunk &ck = cks[cur];
-    c->cur = cur;
-    if (!have) {
-      const double t0 = trace ? wall_ms() : 0;
-      if (!next_chunk(res, &pos, &ck)) {
-        drain();
-        return PBSIM_FAILED;
-      }
-      const double t1 = trace ? wall_ms() : 0;
-      if (!S.enqueue(ck, res + 1)) {
-        drain();
-        return PBSIM_FAILED;
-      }
-      if (trace) fprintf(stderr, "[pbsim sample] chunk of %zu strings, %lld reads: planned in %.2f ms, enqueued in %.2f ms\n", ck.n_c, (long long)ck.n_tasks, t1 - t0, wall_ms() - t1);
-    }
-    have = false;
-    const SampleChunks::Ent last = ck.cand[ck.n_c - 1];
-    int64_t last_done = 0;
-    const bool last_unfinished = S.last_unfinished(pos.sv, ck, &last_done);
-    if (!S.finish(ck, res + 1)) {
-      drain();
-      return PBSIM_FAILED;
-    }
-    // the quota cut and the text sizes; the text emission is enqueued, not waited for (DeferTextSync)
-    pbsim_batch_info bi;
-    if (!pbsim_batch_finalize(c, len_total, &bi)) {
-      drain();
-      return PBSIM_FAILED;
-    }
-    // every read of the chunk was made, its last string is finished and the quota is not reached: the next chunk is determined.
-    // It is planned, uploaded and set walking now, beside this chunk's text emission, delivery and statistics.
-    bool look = !last_unfinished && bi.n_final == ck.n_tasks && bi.len_total_after < quota;
-    if (look && c->slots[(size_t)(1 - cur)].d_scratch.bytes < (size_t)c->scratch_budget) {
-      // the other slot has no pool yet: a second pool (and the text of a second chunk) must fit what the GPU has left, else
-      // the chunks simply follow each other on this slot as they did before round 3
-      size_t free_b = 0, total_b = 0;
-      HIP_OK(hipMemGetInfo(&free_b, &total_b));
-      const double text_now = (double)c->s().d_read_text.bytes + (double)c->s().d_maf_text.bytes;
-      if ((double)free_b < 1.1 * (double)c->scratch_budget + 1.5 * text_now + (double)(2ull << 30)) look = false;
-    }
-    Pos pos2 = pos;
-    if (look) {
-      S.carry_line = -1;
-      S.carry_done = 0;
-      pos2.line = last.line + 1;
-      c->cur = 1 - cur;
-      if (!next_chunk(res + bi.n_final, &pos2, &cks[1 - cur]) || !S.enqueue(cks[1 - cur], res + bi.n_final + 1)) {
-        drain();
-        return PBSIM_FAILED;
-      }
-      c->cur = cur;
-    }
-    if (!deliver(c, sink)) {
-      drain();
-      return PBSIM_FAILED;
-    }
-    len_total = bi.len_total_after;
-    res += bi.n_final;
-    if (bi.n_final < ck.n_tasks) done = true;  // the quota was reached inside this chunk (:1735, :1749)
-    if (look) {
-      pos = pos2;
-      cur = 1 - cur;
-      have = true;
-      continue;
-    }
-    if (last_unfinished && !done) {
-      S.carry_line = last.line;
-      S.carry_done = last_done;
-      HIP_OK(hipMemcpy(&S.carry_len, c->s().d_out_len.as<int32_t>() + (ck.n_tasks - 1), 4, hipMemcpyDeviceToHost));
-      pos.line = last.line;
-    } else {
-      S.carry_line = -1;
-      S.carry_done = 0;
-      pos.line = last.line + 1;
-    }
-  }
-  if (have) {  // (cannot happen: a chunk is only enqueued ahead when the total stays below the quota) -- nothing is left in flight
-    drain();
-    return fail("internal: a sampled chunk was left in flight");
-  }
-  c->cur = 0;
-  return PBSIM_SUCCEEDED;
-}
-
-// The same record on several ranks (one context per GPU, every rank holds the record and the profile).  The copies of ONE
-// string are a chain (each copy is as long as the read the previous one produced), but strings are independent, and the
-// quota test at a read's start (`len_total < quota`, pbsim.cpp:1749) is the same prefix dependence as the wgs quota rule: a
-// round = W chunks of consecutive strings of one sweep, rank r walks chunk r, and three small all-gathers per round place
-// the quota prefix (A: pass-0 bases), the cut (B: reads made, bases behind them) and every rank's byte range in the
-// record's two streams (C).  Chunks in front of the cut are delivered, the rest of the round is void.  Every number the
-// planner uses is the same on all ranks (the pool size is agreed first), so all ranks plan the same chunks.  A string whose
-// copies do not fit one chunk's pool (the carry-over of the one-GPU driver) is refused here: give the ranks a larger pool.
-// `*agreed`: the failure was learned through a collective's status word (or is the same on every rank by construction), so
-// every rank leaves at the same exchange; any other failure is this rank's alone and the caller releases the others (abort).
-static int sample_comm_run(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink, bool *agreed) {
-  const int W = comm->world, rank = comm->rank;
-  int ok = sample_common_checks(c);
-  SampleChunks S;
-  S.c = c;
-  const int64_t quota = ok ? pbsim_unit_quota(c) : 0;
-  if (ok) ok = S.init(quota);
-  {  // every rank is ready, and plans with the same pool
-    std::string keep = g_err;
-    int64_t v[2] = {ok ? 0 : 1, -c->scratch_budget};
-    if (!comm->all_reduce_i64(comm->user, v, 2, PBSIM_OP_MAX)) return fail("pbsim_comm.all_reduce_i64 failed");
-    if (v[0]) {
-      *agreed = true;
-      return ok ? fail("another rank failed") : fail(keep);
-    }
-    c->scratch_budget = -v[1];
-  }
-  pbsim_reset_stats(c);
-  c->st.keep_values = true;
-  c->cur = 0;
-  Slot &sl = c->s();
-  sl.ref = current_ref(c);
-  const int64_t F = S.F;
-  int64_t len_total = 0, res = 0, read_off = 0, maf_off = 0;
-  bool done = false;
-  std::vector<SampleChunks::Chunk> cks((size_t)W);
-  std::string buf_r, buf_m;
-  struct Keep {
-    std::string *r, *m;
-  } keep = {&buf_r, &buf_m};
-  const pbsim_sink collect = {&keep,
-                              [](void *u, const char *t, int64_t k) { ((Keep *)u)->r->append(t, (size_t)k); return 1; },
-                              [](void *u, const char *t, int64_t k) { ((Keep *)u)->m->append(t, (size_t)k); return 1; }};
-  auto gather = [&](const int64_t *send, int n, std::vector<int64_t> *recv) -> int {
-    recv->assign((size_t)W * n, 0);
-    return comm->all_gather_i64(comm->user, send, n, recv->data()) ? PBSIM_SUCCEEDED : fail("pbsim_comm.all_gather_i64 failed");
-  };
-  std::vector<int64_t> A, B, Cs;
-  const bool trace = getenv("PBSIM_TRACE") != nullptr;
-  while (len_total < quota && !done) {
-    const int64_t sv = (int64_t)(header_block(c->p.seed, (uint32_t)c->unit, (uint32_t)(res + 1)).w % (uint32_t)F);  // :1732
-    int64_t line = 0;
-    while (line < F && len_total < quota && !done) {
-      // ---- the round's chunks: the sweep's remaining strings in W equal runs (at most; the pool may cut a run short)
-      const int64_t left = S.count_candidates(sv, line);
-      if (left == 0) break;
-      const size_t per = (size_t)std::min<int64_t>((left + W - 1) / W, (int64_t)1 << 18);
-      int n_chunks = 0;
-      int64_t at = line, first = res + 1, my_first = 0;
-      int local = PBSIM_SUCCEEDED;
-      std::string local_err;
-      for (int q = 0; q < W && at < F; q++) {
-        SampleChunks::Chunk &ck = cks[(size_t)q];
-        if (!S.plan(sv, at, per, &ck)) {
-          local = PBSIM_FAILED;  // (the same on every rank: the plan depends on nothing local)
-          local_err = g_err;
-          break;
-        }
-        if (ck.cand.empty()) break;
-        int64_t last_done = 0;
-        if (S.last_unfinished(sv, ck, &last_done)) {
-          local = PBSIM_FAILED;
-          local_err = "the copies of one sampled read do not fit a rank's scratch pool: the sharded sampling method needs a larger "
-                      "pool (pbsim_set_scratch_bytes / PBSIM_SCRATCH_MB), or run this profile on one GPU";
-          break;
-        }
-        if (q == rank) my_first = first;
-        first += ck.n_tasks;
-        at = ck.cand[ck.n_c - 1].line + 1;
-        n_chunks++;
-      }
-      if (!local) {
-        *agreed = true;  // (the plan depends on nothing local: every rank refuses alike)
-        return fail(local_err);
-      }
-      const bool mine = rank < n_chunks;
-      if (trace)
-        fprintf(stderr, "[pbsim sample r%d] sweep sv=%lld line=%lld left=%lld chunks=%d first=%lld len_total=%lld\n", rank, (long long)sv,
-                (long long)line, (long long)left, n_chunks, (long long)(res + 1), (long long)len_total);
-      // ---- walk, A: pass-0 bases of every chunk -> the quota prefix
-      int64_t sendA[2] = {0, 0};
-      if (mine) {
-        if (S.launch(cks[(size_t)rank], my_first)) sendA[0] = sl.b_pass0;
-        else sendA[1] = 1, local_err = g_err;
-      }
-      if (!gather(sendA, 2, &A)) return PBSIM_FAILED;
-      int64_t before = len_total, bad = 0;
-      for (int q = 0; q < W; q++) {
-        bad += A[(size_t)q * 2 + 1];
-        if (q < rank) before += A[(size_t)q * 2];
-      }
-      if (bad) {
-        *agreed = true;
-        return sendA[1] ? fail(local_err) : fail("another rank failed");
-      }
-      // ---- the cut inside my chunk, B: reads made and bases behind them -> the first chunk that stops short
-      pbsim_batch_info bi;
-      memset(&bi, 0, sizeof bi);
-      int64_t sendB[3] = {0, before, 0};
-      if (mine) {
-        if (finalize_cut(c, before, &bi)) sendB[0] = bi.n_final, sendB[1] = bi.len_total_after;
-        else sendB[2] = 1, local_err = g_err;
-      }
-      if (!gather(sendB, 3, &B)) return PBSIM_FAILED;
-      bad = 0;
-      for (int q = 0; q < W; q++) bad += B[(size_t)q * 3 + 2];
-      if (bad) {
-        *agreed = true;
-        return sendB[2] ? fail(local_err) : fail("another rank failed");
-      }
-      int cut = -1;
-      for (int q = 0; q < n_chunks && cut < 0; q++)
-        if (B[(size_t)q * 3] < cks[(size_t)q].n_tasks) cut = q;
-      const int last_valid = cut < 0 ? n_chunks - 1 : cut;
-      // ---- text of the valid chunks, C: byte counts -> every rank's range in the record's streams
-      buf_r.clear();
-      buf_m.clear();
-      int64_t sendC[3] = {0, 0, 0};
-      if (mine && rank <= last_valid && bi.n_final > 0) {
-        if (finalize_text(c, &bi) && deliver(c, &collect)) sendC[0] = (int64_t)buf_r.size(), sendC[1] = (int64_t)buf_m.size();
-        else sendC[2] = 1, local_err = g_err;
-      }
-      if (!gather(sendC, 3, &Cs)) return PBSIM_FAILED;
-      bad = 0;
-      int64_t r_at = read_off, m_at = maf_off;
-      for (int q = 0; q < W; q++) {
-        bad += Cs[(size_t)q * 3 + 2];
-        if (q < rank) r_at += Cs[(size_t)q * 3], m_at += Cs[(size_t)q * 3 + 1];
-        read_off += Cs[(size_t)q * 3];
-        maf_off += Cs[(size_t)q * 3 + 1];
-      }
-      if (bad) {
-        *agreed = true;
-        return sendC[2] ? fail(local_err) : fail("another rank failed");
-      }
-      if (sink && sink->on_read_text && !buf_r.empty() && !sink->on_read_text(sink->user, c->unit, buf_r.data(), (int64_t)buf_r.size(), r_at))
-        return fail("sink aborted (read text)");
-      if (sink && sink->on_maf_text && !buf_m.empty() && !sink->on_maf_text(sink->user, c->unit, buf_m.data(), (int64_t)buf_m.size(), m_at))
-        return fail("sink aborted (MAF text)");
-      // ---- the record's state, identical on every rank
-      for (int q = 0; q <= last_valid; q++) res += B[(size_t)q * 3];
-      len_total = B[(size_t)last_valid * 3 + 1];
-      if (cut >= 0) done = true;  // the quota was reached inside this round (:1735, :1749)
-      line = cks[(size_t)last_valid].cand[cks[(size_t)last_valid].n_c - 1].line + 1;
-      if (trace)
-        fprintf(stderr, "[pbsim sample r%d]   round done: cut=%d res=%lld len_total=%lld next line=%lld\n", rank, cut, (long long)res,
-                (long long)len_total, (long long)line);
-    }
-    S.sample_num = 0;  // :1922
-  }
-  int64_t extra[2] = {0, 0};
-  if (!stats_merge(&c->st, c->p, comm, extra, 0)) return PBSIM_FAILED;
-  c->st.keep_values = false;
-  if (sink && sink->on_record_done) {
-    pbsim_stats st;
-    stats_finish(c->st, c->p, c->ref_len, &st);
-    if (!sink->on_record_done(sink->user, c->unit, &st, read_off, maf_off)) return fail("sink aborted (record done)");
-  }
-  return PBSIM_SUCCEEDED;
-}
-
-int pbsim_simulate_sample_comm(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record_sink *sink) {
-  if (!c) return fail("bad argument");
-  NEED_DEVICE(c);
-  if (!comm || comm->world <= 1) return fail("pbsim_simulate_sample_comm: a communicator of at least two ranks (else pbsim_simulate_sample)");
-  if (!comm->all_gather_i64 || !comm->all_reduce_i64) return fail("pbsim_comm: all_gather_i64 and all_reduce_i64 must be set");
-  bool agreed = false;
-  const int ok = sample_comm_run(c, comm, sink, &agreed);
-  if (!ok && !agreed && comm->abort) {
-    // a sink callback, the statistics merge, a HIP error between two exchanges: the other ranks cannot know and would wait
-    // in their next all-gather (for ever with a host barrier, until the watchdog with RCCL) -- ADVICE r3
-    const std::string keep = g_err;
-    comm->abort(comm->user);
-    g_err = keep;
-  }
-  return ok;
-}
-
-int pbsim_simulate_templ(pbsim_ctx *c, const pbsim_sink *sink) { return pbsim_simulate_trans(c, sink); }
-
-// simulate_by_errhmm_trans / simulate_by_qshmm_trans (pbsim.cpp:4428-4770, 2738-3017): fixed read
-// count per transcript, no quota; reads are numbered globally like sim.res_num.  The templ
-// strategy (simulate_by_*_templ) runs through the same driver.
-int pbsim_simulate_trans(pbsim_ctx *c, const pbsim_sink *sink) {
-  if (!c) return fail("bad argument");
-  return pbsim_simulate_units_range(c, 1, c->trans_reads, sink);
-}
-
-int64_t pbsim_unit_reads(pbsim_ctx *c) { return c ? c->trans_reads : -1; }
-
-static int load_unit_file(pbsim_ctx *c, const char *path, int64_t stats[2], bool templ) {
-  if (!c || !path) return fail("bad argument");
-  std::vector<Transcript> tr;
-  std::string err;
-  long a = 0;
-  long long b = 0;
-  if (templ ? !read_templates(path, &tr, &a, &b, &err) : !read_transcripts(path, &tr, &a, &err)) return fail(err);
-  std::vector<const char *> ids;
-  std::vector<int64_t> plus, minus, lens;
-  std::vector<const uint8_t *> seqs;
-  for (auto &t : tr) {
-    ids.push_back(t.id.c_str());
-    plus.push_back(t.plus);
-    minus.push_back(t.minus);
-    seqs.push_back((const uint8_t *)t.seq.data());
-    lens.push_back((int64_t)strlen(t.seq.c_str()));
-  }
-  if (stats) {
-    stats[0] = templ ? (int64_t)a : (int64_t)tr.size();
-    stats[1] = templ ? (int64_t)b : (int64_t)a;
-  }
-  return templ ? pbsim_set_templates(c, (int64_t)tr.size(), ids.data(), seqs.data(), lens.data())
-               : pbsim_set_transcripts(c, (int64_t)tr.size(), ids.data(), plus.data(), minus.data(), seqs.data(), lens.data());
-}
-int pbsim_load_transcript_file(pbsim_ctx *c, const char *path, int64_t stats[2]) { return load_unit_file(c, path, stats, false); }
-int pbsim_load_template_file(pbsim_ctx *c, const char *path, int64_t stats[2]) { return load_unit_file(c, path, stats, true); }
-
-int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads, const pbsim_sink *sink) {
-  if (!c) return fail("bad argument");
-  NEED_DEVICE(c);
-  if (c->p.strategy == PBSIM_STRATEGY_WGS) return fail("pbsim_simulate_trans: strategy is wgs");
-  if (!c->d_seq || c->n_units < 1) return fail("no transcripts/templates set");
-  if (first_read < 1 || n_reads < 0 || first_read - 1 + n_reads > c->trans_reads)
-    return fail("pbsim_simulate_units_range: reads outside 1 .. pbsim_unit_reads()");
-  pbsim_reset_stats(c);
-  // No quota here: every read is final, so the batches simply pipeline over the slots (the walk of one beside the text
-  // emission of the other): one batch per slot when everything fits (small batches waste the GPU on their tails).
-  // The text emission is not waited for (as in the job pipeline): a batch's statistics are added on the host while its text is
-  // being written and the next batch's emission queues up behind it -- the GPU sat idle for 5 of the 39 ms of configs[3]
-  // while the host added 1 M reads' counters.  deliver() waits for the emission before it hands text to a sink.
-  DeferTextSync defer_guard(c);
-  const int n_slots = std::max(1, std::min(kMaxSlots, c->pipeline_depth));
-  const int64_t R = first_read - 1 + n_reads;  // last read of the range
-  int64_t cap = batch_capacity(c);
-  struct Pending {
-    int slot;
-    int64_t first, n;
-  };
-  std::vector<Pending> fifo;
-  auto drop_pending = [&]() {
-    for (const Pending &pd : fifo) {
-      c->cur = pd.slot;
-      (void)hipStreamSynchronize(c->s().stream);
-      c->s().b_enqueued = false;
-    }
-    fifo.clear();
-    c->cur = 0;
-  };
-  int64_t next_begin = first_read, next_read = first_read;
-  int next_slot = 0;
-  while (next_read <= R) {
-    while ((int)fifo.size() < n_slots && next_begin <= R) {
-      const int64_t part = std::max<int64_t>(65536, (n_reads + n_slots - 1) / n_slots);
-      const int64_t n = std::min(std::min(cap, part), R - next_begin + 1);
-      c->cur = next_slot;
-      if (!pbsim_batch_walk_begin(c, next_begin, n, -1)) {
-        drop_pending();
-        return PBSIM_FAILED;
-      }
-      fifo.push_back(Pending{next_slot, next_begin, n});
-      next_slot = (next_slot + 1) % n_slots;
-      next_begin += n;
-    }
-    const Pending pd = fifo.front();
-    fifo.erase(fifo.begin());
-    c->cur = pd.slot;
-    if (!pbsim_batch_walk_end(c, nullptr)) {
-      const bool budget = g_err.rfind("scratch budget exceeded", 0) == 0 && pd.n > 1;
-      const std::string keep = g_err;
-      drop_pending();
-      if (!budget) {
-        g_err = keep;
-        return PBSIM_FAILED;
-      }
-      cap = std::max<int64_t>(1, pd.n / 2);  // retry from this batch with smaller ones
-      next_begin = pd.first;
-      next_slot = 0;
-      continue;
-    }
-    pbsim_batch_info bi;
-    if (!pbsim_batch_finalize(c, 0, &bi) || !deliver(c, sink)) {
-      drop_pending();
-      return PBSIM_FAILED;
-    }
-    next_read += bi.n_final;
-  }
   return PBSIM_SUCCEEDED;
 }
 
