@@ -120,6 +120,13 @@ struct DfLane {
   hipStream_t copy_stream = nullptr;
   bool own_streams = false;            // use `own` instead of the shared pair (job.cpp: the lanes of the tail chains' slots)
   hipStream_t own[2] = {nullptr, nullptr};
+  // a call's first pieces launched ahead of the call (deflate_host.cpp df_begin / pbsim::deflate_prelaunch): for this text
+  bool pre_valid = false, pre_own_staging = false, pre_elsewhere = false;
+  const uint8_t *pre_text = nullptr;
+  int64_t pre_n = 0;
+  int pre_count = 0;                   // pieces df_begin launched
+  hipStream_t lane_stream = nullptr;   // the lane's own kernel stream (`stream` is where the call's kernels are being launched)
+  hipEvent_t ev_pre = nullptr;         // behind a prelaunch on another stream
   hipEvent_t ev_df[kDfBuffers] = {}, ev_cp[kDfBuffers] = {};
   hipEvent_t ev_k0[kDfBuffers] = {}, ev_k1[kDfBuffers] = {};  // timing: around k_deflate_chunks of the piece in dense buffer b
   // Pinned arena that holds ALL compressed pieces of one batch (job.cpp, several ranks): a rank learns where its bytes go in
@@ -407,6 +414,10 @@ void stats_finish(const StatsAcc &st, const pbsim_params &p, int64_t ref_len, pb
 int stats_merge(StatsAcc *st, const pbsim_params &p, const pbsim_comm *comm, int64_t *extra, int n_extra);
 // d_text[0..n) (device) -> BGZF-framed gzip members, handed to `consume` piece by piece from pinned staging (deflate.hip)
 // `place` (optional): pinned host memory for a piece of the given size instead of the lane's staging (a batch-wide arena)
+// the first pieces of the selected... of slot `sl`'s two deflate calls (read text, MAF text) launched NOW, behind the slot's text
+// emission: the delivery that follows (deflate_pieces on the same buffers) finds them under way.  `staged`: the pieces will go
+// through the lanes' own staging (one rank) rather than a caller's arena.  Harmless when the delivery never comes.
+int deflate_prelaunch(pbsim_ctx *c, Slot &sl, bool want_read, bool want_maf, bool staged);
 int deflate_pieces(pbsim_ctx *c, DfLane &lane, const uint8_t *d_text, int64_t n,
                    const std::function<int(const char *, int64_t)> &consume,
                    const std::function<char *(int64_t)> *place = nullptr);

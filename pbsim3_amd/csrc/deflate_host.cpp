@@ -40,28 +40,69 @@ int ensure_deflate_tables(pbsim_ctx *c) {
 // piece k is being copied down and the GPU may already be working for another slot.
 // `place` (optional): where a piece of `total` compressed bytes shall be copied to (pinned host memory of the caller's, e.g.
 // an arena that keeps a whole batch) instead of the lane's double-buffered staging.
-template <class F>
-int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F &&consume,
-                   const std::function<char *(int64_t)> *place = nullptr) {
-  if (n <= 0) return PBSIM_SUCCEEDED;
-  if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
+// What a call needs before its first copy: buffers, streams, the code table and the kernels of its first pieces (df_begin).
+// This part can run AHEAD of the call (deflate_prelaunch, from another thread, on another stream): an experiment of round 5 that
+// was measured and not taken (job.cpp prelaunch(), profiles/r05_prelaunch_ab.txt); a product build never prelaunches.
+struct DfGeom {
+  int64_t piece, max_ch, n_pieces;
+  int ahead, nbuf;
+};
+DfGeom df_geom(int64_t n) {
   // chunks per piece = per launch and per copy (experiment knob PBSIM_DEFLATE_PIECE_CHUNKS; a piece's members stay below 4 GiB)
   static const int64_t piece_chunks = [] {
     const char *e = exp_env("PBSIM_DEFLATE_PIECE_CHUNKS");
     const int64_t v = e ? atoll(e) : DF_PIECE_CHUNKS;
     return std::max<int64_t>(256, std::min<int64_t>(65536, v));
   }();
-  const int64_t piece = piece_chunks * DF_CHUNK;
-  const int64_t max_ch = std::min<int64_t>(piece_chunks, (n + DF_CHUNK - 1) / DF_CHUNK);
-  const int64_t n_pieces = (n + piece - 1) / piece;
+  // pieces the lane's kernels run ahead of the piece whose copy is being enqueued (ahead + 1 dense buffers in use).  Four
+  // since the end of round 4 (two before): the kernels of a piece share the GPU with the next round's walk and arrive late
+  // now and then; two more pieces in hand cover that -- configs[1] 1116-1120 -> 1089-1102 ms, configs[4] 3200 -> 3100-3140
+  // (same box, profiles/r04_replay_late_ab.txt; six or eight with more buffers: no better) for 0.5 GB of HBM per lane.
+  static const int ahead_env = exp_env("PBSIM_DEFLATE_AHEAD") ? atoi(exp_env("PBSIM_DEFLATE_AHEAD")) : 4;
+  DfGeom g;
+  g.piece = piece_chunks * DF_CHUNK;
+  g.max_ch = std::min<int64_t>(piece_chunks, (n + DF_CHUNK - 1) / DF_CHUNK);
+  g.n_pieces = (n + g.piece - 1) / g.piece;
+  g.ahead = std::max(1, std::min(kDfBuffers - 1, ahead_env));
+  g.nbuf = g.ahead + 1;
+  return g;
+}
+
+// piece j of the call on `sl`: its kernels into dense buffer j % nbuf, its total into h_total[j % nbuf]
+int df_launch_piece(pbsim_ctx *c, DfLane &sl, const DfGeom &g, const uint8_t *d_text, int64_t n, int64_t j, bool wait_buffer,
+                    bool own_staging, unsigned long long *d_prof) {
+  const int b = (int)(j % g.nbuf);
+  const int64_t off = j * g.piece, len = std::min(g.piece, n - off);
+  const uint32_t *tab = c->d_df_tables.as<uint32_t>();
+  int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
+  HIP_OK(sl.d_df_dense[b].ensure((size_t)g.max_ch * DF_SLOT + 64, true));
+  if (own_staging) HIP_OK(sl.h_df_out[b].ensure((size_t)g.max_ch * DF_SLOT + 64));
+  if (wait_buffer) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - nbuf has left this dense buffer
+  uint8_t *dense = sl.d_df_dense[b].as<uint8_t>();
+  if (((sl.epoch + 1) & 0x3fffffffu) == 0) {  // the epoch wraps: start over from a cleared array; epoch 0 is never used
+    HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
+    sl.epoch++;
+  }
+  launch_deflate(d_text + off, len, sl.d_df_status.as<uint64_t>(), sl.d_df_ctl.p, ++sl.epoch, dense, tab, tab + 1024,
+                 sl.d_df_code.p, sl.stream, d_prof, sl.ev_k0[b], sl.ev_k1[b]);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(&h_total[2 * b], sl.d_df_ctl.p, DF_CTL_BYTES, hipMemcpyDeviceToHost, sl.stream));  // ticket | error, total
+  HIP_OK(hipEventRecord(sl.ev_df[b], sl.stream));
+  return PBSIM_SUCCEEDED;
+}
+
+// buffers, streams, the call's code table and its first `ahead` pieces; `text_ready` (optional): an event the lane's stream
+// waits for before it reads the text (a prelaunch runs beside the text's emission on another stream)
+int df_begin(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, bool own_staging, hipStream_t launch_stream) {
+  if (!ensure_deflate_tables(c)) return PBSIM_FAILED;
+  const DfGeom g = df_geom(n);
   const size_t status_bytes_was = sl.d_df_status.bytes;  // (ensure() only ever grows: a new allocation has another size)
-  HIP_OK(sl.d_df_status.ensure((size_t)piece_chunks * 8));
+  HIP_OK(sl.d_df_status.ensure((size_t)(g.piece / DF_CHUNK) * 8));
   HIP_OK(sl.d_df_ctl.ensure(DF_CTL_BYTES));
   // (Members stored straight into page-locked host memory by the deflate workgroups -- no dense buffer, no copy -- were measured
   // in round 3 and rejected: 37 vs 47 Gbases/s, profiles/r03_deflate_fused_ab.txt; the code path is gone since round 5.)
   HIP_OK(sl.h_df_total.ensure(DF_CTL_BYTES * kDfBuffers));
   HIP_OK(sl.d_df_code.ensure(DF_TABLE_BYTES + 288 * 4));
-  const uint32_t *tab = c->d_df_tables.as<uint32_t>();
   int lane_index = 0;
   for (Slot &slot : c->slots)
     if (&slot.df[1] == &sl) lane_index = 1;
@@ -79,25 +120,19 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     lane_streams[0] = c->df_streams[lane_index][0];
     lane_streams[1] = c->df_streams[lane_index][1];
   }
-  sl.stream = lane_streams[0];
+  // A prelaunch puts the table fit and the first pieces on `launch_stream` -- the slot's own stream, right behind the text
+  // emission they read -- not on the lane's: that one is shared by the slots' lanes of this index, and the kernels of the round
+  // being delivered meanwhile must not queue behind a text emission that is still running.  The call proper carries on on the
+  // lane's stream behind an event (ev_pre).
+  sl.lane_stream = lane_streams[0];
+  sl.stream = launch_stream ? launch_stream : lane_streams[0];
+  sl.copy_stream = lane_streams[1];
   // The look-back trusts any status word that carries the launch's epoch and a flag, and the words are never cleared between
   // launches -- so a NEW array must start from zeros (flag 0 = nothing published): hipMalloc hands back the freed array of a
   // destroyed context or lane with that lane's old words in it, and a lane's epochs restart.
   if (sl.d_df_status.bytes != status_bytes_was) HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
   // the call's code table: fitted once to the head of the text (deflate.hip), shared by all its members
   launch_deflate_table(d_text, n, reinterpret_cast<uint32_t *>(sl.d_df_code.as<uint8_t>() + DF_TABLE_BYTES), sl.d_df_code.p, sl.stream);
-  unsigned long long *d_prof = nullptr;
-  if (getenv("PBSIM_DEFLATE_PROF")) {
-    HIP_OK(c->d_df_prof.ensure(128));
-    HIP_OK(hipMemsetAsync(c->d_df_prof.p, 0, 128, sl.stream));
-    d_prof = c->d_df_prof.as<unsigned long long>();
-  }
-  // The kernels of a piece, its copy and the host's consume() are three stages that must not wait for each other's round trips:
-  // the lane's stream always holds the NEXT piece's kernels (piece k + 1 is launched before piece k's total is read back, on
-  // the second set of staging buffers), the copy stream the next copy, and the host consumes piece k - 1 while piece k travels.
-  // (Launching a piece only after the previous one's total had arrived left the link idle whenever the other lane was not
-  // copying: 1.5 ms of kernels + a host round trip per 1.46 ms of copy.)
-  sl.copy_stream = lane_streams[1];
   if (!sl.ev_df[0]) {
     for (int i = 0; i < kDfBuffers; i++) {
       HIP_OK(hipEventCreateWithFlags(&sl.ev_df[i], hipEventDisableTiming));
@@ -106,43 +141,70 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
       HIP_OK(hipEventCreate(&sl.ev_k1[i]));
     }
   }
+  unsigned long long *d_prof = nullptr;
+  if (getenv("PBSIM_DEFLATE_PROF")) {
+    HIP_OK(c->d_df_prof.ensure(128));
+    HIP_OK(hipMemsetAsync(c->d_df_prof.p, 0, 128, sl.stream));
+    d_prof = c->d_df_prof.as<unsigned long long>();
+  }
+  // (the previous call's copies have all been waited for by the host: every dense buffer is free, no wait_buffer)
+  // A prelaunch takes the table fit and ONE piece: enough for the call's first copy to start at once; the rest of the head
+  // start follows when the call begins (more pieces launched ahead took the GPU from the round being delivered:
+  // profiles/r05_prelaunch_ab.txt).
+  static const int pre_pieces = exp_env("PBSIM_DEFLATE_PRE_PIECES") ? atoi(exp_env("PBSIM_DEFLATE_PRE_PIECES")) : 1;
+  const int64_t first = std::min<int64_t>(launch_stream ? std::max(1, std::min(pre_pieces, g.ahead)) : g.ahead, g.n_pieces);
+  for (int64_t j = 0; j < first; j++)
+    if (!df_launch_piece(c, sl, g, d_text, n, j, false, own_staging, d_prof)) return PBSIM_FAILED;
+  sl.pre_count = (int)first;
+  sl.pre_text = d_text;
+  sl.pre_n = n;
+  sl.pre_own_staging = own_staging;
+  sl.pre_valid = true;
+  sl.pre_elsewhere = launch_stream != nullptr;
+  if (launch_stream) {
+    if (!sl.ev_pre) HIP_OK(hipEventCreateWithFlags(&sl.ev_pre, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(sl.ev_pre, launch_stream));
+  }
+  return PBSIM_SUCCEEDED;
+}
+
+template <class F>
+int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F &&consume,
+                   const std::function<char *(int64_t)> *place = nullptr) {
+  if (n <= 0) return PBSIM_SUCCEEDED;
+  // The kernels of a piece, its copy and the host's consume() are three stages that must not wait for each other's round trips:
+  // the lane's stream always holds the NEXT pieces' kernels (piece k + ahead is launched before piece k's total is read back),
+  // the copy stream the next copy, and the host consumes piece k - 1 while piece k travels.
+  // (Launching a piece only after the previous one's total had arrived left the link idle whenever the other lane was not
+  // copying: 1.5 ms of kernels + a host round trip per 1.46 ms of copy.)
+  const bool prelaunched = sl.pre_valid && sl.pre_text == d_text && sl.pre_n == n && sl.pre_own_staging == (place == nullptr);
+  sl.pre_valid = false;
+  if (!prelaunched && !df_begin(c, sl, d_text, n, place == nullptr, nullptr)) return PBSIM_FAILED;
+  sl.pre_valid = false;
+  if (sl.pre_elsewhere) {  // the first pieces were launched on the slot's stream: the rest follows them on the lane's
+    sl.stream = sl.lane_stream;
+    HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_pre, 0));
+    sl.pre_elsewhere = false;
+  }
+  const DfGeom g = df_geom(n);
+  const int64_t piece = g.piece, n_pieces = g.n_pieces;
+  const int ahead = g.ahead, nbuf = g.nbuf;
+  unsigned long long *d_prof = getenv("PBSIM_DEFLATE_PROF") ? c->d_df_prof.as<unsigned long long>() : nullptr;
   const bool trace = getenv("PBSIM_DEFLATE_TRACE") != nullptr;  // where a call's wall time goes: kernels | link | consumer
   const auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_kernel = 0, t_copy = 0, t_consume = 0, t_begin = now();
   int64_t out_bytes = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;  // trace: begin / end of every copy on the copy stream
   bool used[kDfBuffers] = {false};
-  // pieces the lane's kernels run ahead of the piece whose copy is being enqueued (ahead + 1 dense buffers in use).  Four
-  // since the end of round 4 (two before): the kernels of a piece share the GPU with the next round's walk and arrive late
-  // now and then; two more pieces in hand cover that -- configs[1] 1116-1120 -> 1089-1102 ms, configs[4] 3200 -> 3100-3140
-  // (same box, profiles/r04_replay_late_ab.txt; six or eight with more buffers: no better) for 0.5 GB of HBM per lane.
-  static const int ahead_env = exp_env("PBSIM_DEFLATE_AHEAD") ? atoi(exp_env("PBSIM_DEFLATE_AHEAD")) : 4;
-  const int ahead = std::max(1, std::min(kDfBuffers - 1, ahead_env)), nbuf = ahead + 1;
   int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
-  // piece j: kernels on staging set j & 1 into dense buffer j % 3; its total lands in h_total[j % 3]
   auto launch = [&](int64_t j) -> int {
-    const int b = (int)(j % nbuf);
-    const int64_t off = j * piece, len = std::min(piece, n - off);
-    HIP_OK(sl.d_df_dense[b].ensure((size_t)max_ch * DF_SLOT + 64, true));
-    if (!place) HIP_OK(sl.h_df_out[b].ensure((size_t)max_ch * DF_SLOT + 64));
-    if (used[b]) HIP_OK(hipStreamWaitEvent(sl.stream, sl.ev_cp[b], 0));  // piece j - nbuf has left this dense buffer
-    uint8_t *dense = sl.d_df_dense[b].as<uint8_t>();
-    if (((sl.epoch + 1) & 0x3fffffffu) == 0) {  // the epoch wraps: start over from a cleared array; epoch 0 is never used
-      HIP_OK(hipMemsetAsync(sl.d_df_status.p, 0, sl.d_df_status.bytes, sl.stream));
-      sl.epoch++;
-    }
-    launch_deflate(d_text + off, len, sl.d_df_status.as<uint64_t>(), sl.d_df_ctl.p, ++sl.epoch, dense, tab, tab + 1024,
-                   sl.d_df_code.p, sl.stream, d_prof, sl.ev_k0[b], sl.ev_k1[b]);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(&h_total[2 * b], sl.d_df_ctl.p, DF_CTL_BYTES, hipMemcpyDeviceToHost, sl.stream));  // ticket | error, total
-    HIP_OK(hipEventRecord(sl.ev_df[b], sl.stream));
-    return PBSIM_SUCCEEDED;
+    return df_launch_piece(c, sl, g, d_text, n, j, used[(int)(j % nbuf)], place == nullptr, d_prof);
   };
+  for (int64_t j = sl.pre_count; j < std::min<int64_t>(ahead, n_pieces); j++)  // (what a prelaunch left of the head start)
+    if (!launch(j)) return PBSIM_FAILED;
   const char *prev_ptr = nullptr;  // piece k - 1: copy possibly still in flight
   int64_t prev_bytes = 0;
   int prev_buf = 0;
-  for (int64_t j = 0; j < std::min<int64_t>(ahead, n_pieces); j++)
-    if (!launch(j)) return PBSIM_FAILED;
   for (int64_t k = 0; k < n_pieces; k++) {
     const int b = (int)(k % nbuf);
     const double t0 = now();
@@ -247,7 +309,22 @@ extern "C++" int pbsim::deflate_pieces(pbsim_ctx *c, DfLane &lane, const uint8_t
                                        const std::function<char *(int64_t)> *place) {
   return deflate_stream(c, lane, d_text, n, consume, place);
 }
-extern "C++" int pbsim::ensure_deflate_ready(pbsim_ctx *c) { return ensure_deflate_tables(c); }
+extern "C++" int pbsim::ensure_deflate_ready(pbsim_ctx *c) {
+  // (called by a job before its delivery threads start: the lanes' shared streams exist from here on -- the round loop's
+  // prelaunch and the delivery thread's calls would otherwise both find them missing and both create them)
+  for (auto &lane : c->df_streams)
+    for (hipStream_t &st : lane)
+      if (!st) HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  return ensure_deflate_tables(c);
+}
+extern "C++" int pbsim::deflate_prelaunch(pbsim_ctx *c, Slot &sl, bool want_read, bool want_maf, bool staged) {
+  const pbsim_batch_info &bi = sl.b_info;
+  if (want_read && bi.read_text_bytes > 0 && !df_begin(c, sl.df[0], sl.d_read_text.as<uint8_t>(), bi.read_text_bytes, staged, sl.stream))
+    return PBSIM_FAILED;
+  if (want_maf && bi.maf_text_bytes > 0 && !df_begin(c, sl.df[1], sl.d_maf_text.as<uint8_t>(), bi.maf_text_bytes, staged, sl.stream))
+    return PBSIM_FAILED;
+  return PBSIM_SUCCEEDED;
+}
 
 int pbsim_set_deflate(pbsim_ctx *c, int on) {
   if (!c) return fail("bad argument");

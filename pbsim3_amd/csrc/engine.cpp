@@ -1121,6 +1121,7 @@ extern "C++" int pbsim::finalize_text(pbsim_ctx *c, pbsim_batch_info *info) {
   const int P = c->p.pass_num;
   const int64_t n_final = bi.n_final;
   const int64_t n_tasks = n_final * P;
+  for (DfLane &L : c->s().df) L.pre_valid = false;  // (pieces launched ahead for the slot's previous text are void)
   if (n_tasks > 0) {
     HIP_OK(c->s().d_rt_len.ensure(n_tasks * 8));
     HIP_OK(c->s().d_mt_len.ensure(n_tasks * 8));

@@ -882,6 +882,19 @@ struct Job {
     return PBSIM_SUCCEEDED;
   }
 
+  // Measured and NOT taken (round 5, profiles/r05_prelaunch_ab.txt): the table fit and the first piece(s) of a round's two
+  // compressions launched behind its text emission, while the delivery thread is still moving the round in front
+  // (deflate_host.cpp df_begin on the slot's stream), so that the round's delivery starts with its first totals waiting
+  // instead of 2-4 ms of kernel latency.  A rank of eight gained 1-2 % (163-165 against 166-169 ms), the one-GPU jobs LOST 1.5-2 %
+  // (configs[1] 1102-1110 against 1083 ms, configs[4] 3175-3186 against 3130) with one, two or four pieces launched ahead: the
+  // kernels take the GPU from the round that is being delivered -- the same outcome as round 4's "next round's compression on a
+  // second worker".  Read only by an EXPERIMENTAL build (knobs.h), off in the product.
+  int prelaunch(const pbsim_batch_info &bi) {
+    static const bool on = exp_env("PBSIM_DEFLATE_PRELAUNCH") && atoi(exp_env("PBSIM_DEFLATE_PRELAUNCH")) == 1;
+    if (!on || !deflated() || bi.n_final <= 0) return PBSIM_SUCCEEDED;
+    return deflate_prelaunch(c, c->s(), sink->on_read_text != nullptr, sink->on_maf_text != nullptr, W == 1);
+  }
+
   // One round comes back.  Two shapes, chosen when the round was begun (Round::clear, the same on every rank):
   //   clear   text of all n reads emitted at once (finalize_uncut: no cut kernel, no `before` needed) -> wait for the previous
   //           round's bytes -> ONE exchange "AC": pass-0 bases, largest raw length, status | the previous round's sizes.  If the
@@ -926,7 +939,7 @@ struct Job {
     if (rd.clear) {
       if (code == 0) {  // every read final: the text leaves now, `before` arrives with the exchange
         const double tf = now_us();
-        fin_ok = finalize_uncut(c, &bi) && finalize_text(c, &bi);
+        fin_ok = finalize_uncut(c, &bi) && finalize_text(c, &bi) && prelaunch(bi);
         if (!fin_ok) my_err = g_err;
         t_fin += now_us() - tf;
       }
@@ -987,7 +1000,7 @@ struct Job {
     } else {
       // a failure here travels in the exchange's status word: every rank leaves the job at the same collective
       const double tf = now_us();
-      fin_ok = (untouched ? finalize_uncut(c, &bi) : finalize_cut(c, before, &bi)) && finalize_text(c, &bi);
+      fin_ok = (untouched ? finalize_uncut(c, &bi) : finalize_cut(c, before, &bi)) && finalize_text(c, &bi) && prelaunch(bi);
       if (!fin_ok) my_err = g_err;
       if (untouched) c->s().b_info.len_total_after = bi.len_total_after = before + pass0;
       t_fin += now_us() - tf;
