@@ -46,6 +46,11 @@ int ensure_deflate_tables(pbsim_ctx *c) {
 struct DfGeom {
   int64_t piece, max_ch, n_pieces;
   int ahead, nbuf;
+  // (Round 5 measured a call's first two pieces SHORT -- a quarter and a half of a piece, so that its first copy starts after a
+  // quarter of a piece's kernel time: configs[1] 1 077 against 1 085 ms, ranks of eight the same, configs[4] and [2] 1-3 % slower;
+  // not taken, profiles/r05_prelaunch_ab.txt.)
+  int64_t off(int64_t j) const { return j * piece; }
+  int64_t len(int64_t j, int64_t n) const { return std::min(piece, n - off(j)); }
 };
 DfGeom df_geom(int64_t n) {
   // chunks per piece = per launch and per copy (experiment knob PBSIM_DEFLATE_PIECE_CHUNKS; a piece's members stay below 4 GiB)
@@ -72,7 +77,7 @@ DfGeom df_geom(int64_t n) {
 int df_launch_piece(pbsim_ctx *c, DfLane &sl, const DfGeom &g, const uint8_t *d_text, int64_t n, int64_t j, bool wait_buffer,
                     bool own_staging, unsigned long long *d_prof) {
   const int b = (int)(j % g.nbuf);
-  const int64_t off = j * g.piece, len = std::min(g.piece, n - off);
+  const int64_t off = g.off(j), len = g.len(j, n);
   const uint32_t *tab = c->d_df_tables.as<uint32_t>();
   int64_t *h_total = reinterpret_cast<int64_t *>(sl.h_df_total.p);
   HIP_OK(sl.d_df_dense[b].ensure((size_t)g.max_ch * DF_SLOT + 64, true));
@@ -187,7 +192,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
     sl.pre_elsewhere = false;
   }
   const DfGeom g = df_geom(n);
-  const int64_t piece = g.piece, n_pieces = g.n_pieces;
+  const int64_t n_pieces = g.n_pieces;
   const int ahead = g.ahead, nbuf = g.nbuf;
   unsigned long long *d_prof = getenv("PBSIM_DEFLATE_PROF") ? c->d_df_prof.as<unsigned long long>() : nullptr;
   const bool trace = getenv("PBSIM_DEFLATE_TRACE") != nullptr;  // where a call's wall time goes: kernels | link | consumer
@@ -219,7 +224,7 @@ int deflate_stream(pbsim_ctx *c, DfLane &sl, const uint8_t *d_text, int64_t n, F
         std::lock_guard<std::mutex> lk(c->prof_mu);
         c->prof_deflate_ms += ms;
         c->prof_deflate_launches++;
-        c->prof_deflate_in += std::min(piece, n - k * piece);
+        c->prof_deflate_in += g.len(k, n);
         c->prof_deflate_out += total;
       }
     }
