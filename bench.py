@@ -72,6 +72,21 @@ def physical_cores():
     return logical, logical
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(model="ERRHMM-ONT.model", depth=20, sample_bp=4_000_000):
     """The reference itself (oracle/_ref/pbsim_ref, compiled from /root/reference in the build container; else the C
     restatement in glibc mode) timed on the GPU box's host cores on a bounded sample of the same workload, compression
@@ -134,7 +149,10 @@ def cpu_baseline(model="ERRHMM-ONT.model", depth=20, sample_bp=4_000_000):
             return None
         vp, dtp = one(ref_philox or harness.ORACLE, philox=True)
         phys, logical = physical_cores()
-        ncopy = min(phys, 256)
+        quota = cpu_quota()
+        # (a container with a CPU quota -- the pool's boxes: 16 CPUs' worth of time behind 256 visible ones -- runs as many
+        # copies as it has CPUs to run them on: 128 copies under a quota of 16 measure the throttle, not the cores)
+        ncopy = min(phys, 256) if quota is None else max(1, min(phys, int(quota)))
         per_copy_depth = max(2, min(depth, 5))
         t1 = time.time()
         procs = [subprocess.Popen(command(exe, "all%d" % k, 100 + k, per_copy_depth), env=env_for(100 + k, True),
@@ -143,7 +161,9 @@ def cpu_baseline(model="ERRHMM-ONT.model", depth=20, sample_bp=4_000_000):
         dt_all = time.time() - t1
         if all(q.returncode == 0 for q in procs):
             all_cores = {"value": sum(bases_of_report(o) for o in outs) / dt_all, "cores": ncopy,
-                         "note": f"{ncopy} concurrent copies (one per physical core; {logical} logical CPUs) of the sample job at "
+                         "cpu_quota": quota,
+                         "note": f"{ncopy} concurrent copies (one per " + ("physical core" if quota is None else f"CPU of the container's quota of {quota:g}") +
+                                 f"; {phys} physical cores, {logical} logical CPUs visible) of the sample job at "
                                  f"depth {per_copy_depth}, distinct seeds, {dt_all:.1f}s"}
         else:
             all_cores = {"value": None, "cores": ncopy, "note": "some copies failed"}
