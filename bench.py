@@ -702,17 +702,20 @@ def main():
         if world > 1:
             dist.barrier()
         ctx.prof_reset()
-        t1 = time.perf_counter()
-        run_job(False)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt_hbm = time.perf_counter() - t1
+        hbm_runs = []
+        for _ in range(3):                  # (three timed runs, their mean: one run scatters by 2-3 %)
+            t1 = time.perf_counter()
+            run_job(False)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            hbm_runs.append(time.perf_counter() - t1)
+        dt_hbm = sum(hbm_runs) / len(hbm_runs)
         w2_ms, w2_launches, _ = ctx.prof_get()
         c2 = ctx.job_counters()
-        alg2 = c2["ref_bases"] + 2 * c2["bases"] + 2 * c2["maf_columns"]
-        extras["whole_job_hbm"] = {"value": job_bases / dt_hbm, "unit": "bases/s",
-                                   "note": "the same job, FASTQ + MAF text left in HBM (no compression, no copy)",
+        alg2 = 3 * (c2["ref_bases"] + 2 * c2["bases"] + 2 * c2["maf_columns"])
+        extras["whole_job_hbm"] = {"value": job_bases / dt_hbm, "unit": "bases/s", "runs_ms": [x * 1e3 for x in hbm_runs],
+                                   "note": "the same job, FASTQ + MAF text left in HBM (no compression, no copy); mean of three runs",
                                    "walk": {"avg_launch_ms": w2_ms / max(1, w2_launches), "launches": w2_launches,
                                             "achieved": alg2 / (w2_ms / 1e3) / 1e9 if w2_ms > 0 else None,
                                             "frac": alg2 / (w2_ms / 1e3) / 1e9 / HBM_PEAK_GBS if w2_ms > 0 else None,
