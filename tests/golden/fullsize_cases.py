@@ -25,6 +25,17 @@ FULLSIZE = {
         "record": (120_000_000, 104),
         "args": ["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-ONT-HQ.model", "--depth", "60", "--seed", "1"],
     },
+    # configs[4] at the BASELINE record size: one 750 Mbp record at depth 60 (45 Gbases, 5.1 M reads; the reference: 93 CPU-minutes)
+    "c4_errhmm_onthq_750m_d60": {
+        "record": (750_000_000, 105),
+        "args": ["--strategy", "wgs", "--method", "errhmm", "--errhmm", "MODEL:ERRHMM-ONT-HQ.model", "--depth", "60", "--seed", "1"],
+    },
+    # configs[2] larger: 60 Mbp at depth 20, ten passes (12 G subread bases, 72 GB of SAM text)
+    "c2_qshmm_rsii_60m_d20_pass10": {
+        "record": (60_000_000, 106),
+        "args": ["--strategy", "wgs", "--method", "qshmm", "--qshmm", "MODEL:QSHMM-RSII.model", "--depth", "20", "--pass-num", "10",
+                 "--seed", "1"],
+    },
     # configs[2]: QSHMM-RSII --pass-num 10 at depth 20 (4 G subread bases on a 20 Mbp record): SAM text + MAF
     "c2_qshmm_rsii_20m_d20_pass10": {
         "record": (20_000_000, 102),

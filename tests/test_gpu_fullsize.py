@@ -280,32 +280,41 @@ def test_benchmarked_path_content_is_invariant(record):
 
 
 @pytest.mark.timeout(900)
-def test_configs4_onthq_depth60_equals_the_reference(tmp_path):
-    """BASELINE configs[4] (ERRHMM-ONT-HQ, depth 60) on a 120 Mbp record, 7.2 Gbases: one rank and eight ranks (contexts on
-    the one GPU, host communicator) deliver the FASTQ and MAF the reference wrote, by CRC-32 and length, and its report."""
+@pytest.mark.parametrize("case,runs", [
+    ("c4_errhmm_onthq_120m_d60", [dict(world=1), dict(world=8)]),
+    # one record of the BASELINE genome at the BASELINE depth: 45 Gbases, 5.1 M reads, 190 GB of text
+    ("c4_errhmm_onthq_750m_d60", [dict(world=1), dict(world=4, scratch_gib=3)]),
+])
+def test_configs4_onthq_depth60_equals_the_reference(case, runs, tmp_path):
+    """BASELINE configs[4] (ERRHMM-ONT-HQ, depth 60) -- on a 120 Mbp record (7.2 Gbases; one rank and eight ranks: contexts on the
+    one GPU, host communicator) and on a 750 Mbp record (45 Gbases; one rank and four): the FASTQ and MAF the reference wrote, by
+    CRC-32 and length, and its report."""
     import pbsim3_amd as P
-    case = "c4_errhmm_onthq_120m_d60"
     rec = synth_record(case)
     want, ref_report = reference_digest(case)
-    for world in (1, 8):
-        digest, stats, cnt = run_job(P, rec, world=world, model="ERRHMM-ONT-HQ.model", depth=60.0)
-        assert [d[:2] for d in digest] == want, "world %d" % world
+    for kw in runs:
+        digest, stats, cnt = run_job(P, rec, model="ERRHMM-ONT-HQ.model", depth=60.0, **kw)
+        assert [d[:2] for d in digest] == want, kw
         assert run_job.last_report.rstrip("\n") in ref_report
-        if world > 1:
+        if kw["world"] > 1:
             assert all(c["reads_delivered"] > 0 for c in cnt)
 
 
 @pytest.mark.timeout(900)
-def test_configs2_qshmm_pass10_equals_the_reference(tmp_path):
-    """BASELINE configs[2] (QSHMM-RSII --pass-num 10, depth 20) on a 20 Mbp record, 4 G subread bases: the SAM text (24 GB; the
-    native BAM records are checked field by field in test_gpu_bam.py) and the MAF the reference wrote, by CRC-32 and length."""
+@pytest.mark.parametrize("case,runs", [
+    ("c2_qshmm_rsii_20m_d20_pass10", [dict(world=1), dict(world=1, env={"PBSIM_COOP_LEN": "-1"}), dict(world=3)]),
+    ("c2_qshmm_rsii_60m_d20_pass10", [dict(world=1), dict(world=2, scratch_gib=6)]),
+])
+def test_configs2_qshmm_pass10_equals_the_reference(case, runs, tmp_path):
+    """BASELINE configs[2] (QSHMM-RSII --pass-num 10, depth 20) on a 20 Mbp record (4 G subread bases) and a 60 Mbp one (12 G, 72 GB
+    of SAM text): the SAM text (the native BAM records are checked field by field in test_gpu_bam.py) and the MAF the reference
+    wrote, by CRC-32 and length."""
     import pbsim3_amd as P
-    case = "c2_qshmm_rsii_20m_d20_pass10"
     rec = synth_record(case)
     want, ref_report = reference_digest(case)
-    for world, kw in ((1, {}), (1, dict(env={"PBSIM_COOP_LEN": "-1"})), (3, {})):
-        digest, stats, cnt = run_job(P, rec, world=world, method="qshmm", model="QSHMM-RSII.model", depth=20.0, pass_num=10, **kw)
-        assert [d[:2] for d in digest] == want, "world %d %s" % (world, kw)
+    for kw in runs:
+        digest, stats, cnt = run_job(P, rec, method="qshmm", model="QSHMM-RSII.model", depth=20.0, pass_num=10, **kw)
+        assert [d[:2] for d in digest] == want, kw
         assert run_job.last_report.rstrip("\n") in ref_report
 
 
