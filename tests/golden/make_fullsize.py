@@ -6,7 +6,7 @@ The outputs are too large to keep (63 GB of text for one 750 Mbp record at depth
 on PATH by tests/golden/crcsum.c, which leaves "<crc32> <bytes>" of the text the reference piped into it in the output
 file.  Those digests + the stderr report are what tests/test_gpu_fullsize.py compares the GPU job's folded member CRCs with.
 
-  python tests/golden/make_fullsize.py [case ...]      (all cases: ~25 CPU-minutes, the cases run side by side)
+  python tests/golden/make_fullsize.py [case ...]      (all cases: ~3 CPU-hours, run side by side: the 750 Mbp x depth 60 case alone takes 93 minutes)
 
 Needs /root/reference (through oracle/_ref) and ~3 GB of memory per case.  Only digests are committed.
 """
