@@ -403,7 +403,7 @@ void parse_args(int argc, char **argv, Cli &c) {
 
 // ---- output files ------------------------------------------------------------------------------------------------------
 // Writing behind the job (round 4).  The job hands its sinks ~45 GB/s of members from two delivery threads, and a file takes
-// what one writer can push into it: 4-6 GB/s per file on /dev/shm however many threads write (one inode; tools/shm_write_test.c:
+// what one writer can push into it: 4-6 GB/s per file on /dev/shm however many threads write (one inode; tools/closed_ab/shm_write_test.c:
 // pwrite from 16 threads into ONE file 3.6 GB/s, into 16 files 66 GB/s).  So a sink callback only copies its piece into a
 // buffer of the pool below -- on helper threads, a piece of 80 MB is gone in ~2 ms -- and returns; one writer thread per file
 // pwrite()s the buffers in the order they came, and the job keeps k records going side by side (pbsim_job_set_interleave), so

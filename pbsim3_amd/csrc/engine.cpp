@@ -771,7 +771,7 @@ extern "C++" int pbsim::walk_begin(pbsim_ctx *c, const RefDesc &ref, int64_t fir
     // 5.91 -> 4.27, 100 000 8.57 -> 7.59, 200 000 12.6 -> 12.2 -- the rounds of a job on 4-8 ranks); dealt round-robin
     // otherwise: beside the lane walk of a full round there is no gain (400 000 reads 17.0 -> 17.2 ms, whole job -1 %: the
     // draw costs two barriers per unit), and one unit per workgroup has nothing to balance (QSHMM 500 reads x 10 passes
-    // 12.6 -> 13.3 ms).  tools/coop_dynamic_ab.sh; PBSIM_COOP_DYNAMIC=0/1 forces either.
+    // 12.6 -> 13.3 ms).  tools/closed_ab/coop_dynamic_ab.sh; PBSIM_COOP_DYNAMIC=0/1 forces either.
     const char *cd = getenv("PBSIM_COOP_DYNAMIC");
     w.coop_dynamic = cd ? atoi(cd) == 1 : (coop_len != INT32_MAX && n_tasks >= 4LL * kCoopWaves * kCoopWorkgroups && n_tasks <= 250000);
     if (chain) w.coop_dynamic = 0;  // (the steps of a chain share the batch's flags: the units' counter is not theirs to draw from)

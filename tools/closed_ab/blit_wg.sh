@@ -1,6 +1,6 @@
 for n in 4 8 16 32; do
   echo "DEBUG_CLR_LIMIT_BLIT_WG=$n"
-  DEBUG_CLR_LIMIT_BLIT_WG=$n tools/deflate_solo.sh gpurun_out/dfsolo_b$n | tail -1
+  DEBUG_CLR_LIMIT_BLIT_WG=$n tools/closed_ab/deflate_solo.sh gpurun_out/dfsolo_b$n | tail -1
   python3 - gpurun_out/dfsolo_b$n <<PY
 import csv,glob,sys
 for f in glob.glob(sys.argv[1]+"/t/**/*kernel_trace.csv",recursive=True):

@@ -1,6 +1,6 @@
 """CPU only: how fast does the ERRHMM state chain forget its start state?  Jacobi relaxation of state[i] = T[state[i-1]][x[i]]
 over 64 columns (every column from the current guess of its predecessor, repeated until nothing changes) on the shipped
-models' class tables: sweeps needed = how far a wrong start state still matters.  usage: python tools/chain_relaxation.py"""
+models' class tables: sweeps needed = how far a wrong start state still matters.  usage: python tools/closed_ab/chain_relaxation.py"""
 import sys
 sys.path[:0]=['tests','tests/golden','.']
 import numpy as np, harness

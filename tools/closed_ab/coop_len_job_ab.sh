@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/coop_len_job_ab.sh  -- the configs[1] job by the read length from which the wave walker
+# usage (GPU box, repo root): tools/closed_ab/coop_len_job_ab.sh  -- the configs[1] job by the read length from which the wave walker
 # takes the reads of its full rounds (PBSIM_COOP_LEN; the rule gives 4 x the mean length = 36096 for them), in HBM and delivered
 for t in 27136 36096 45056 54272 63488; do
   for rep in 1 2; do

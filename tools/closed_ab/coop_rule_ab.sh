@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/coop_rule_ab.sh OUT  -- the lane / wave split rule (reads of one mean length and more go to
+# usage (GPU box, repo root): tools/closed_ab/coop_rule_ab.sh OUT  -- the lane / wave split rule (reads of one mean length and more go to
 # the wave walker at PBSIM_COOP_SPLIT_READS reads per batch: 150 000 = round 2's rule, 80 000 = the default): the configs[1]
 # job in HBM and delivered, ranks 0 / 3 / 7 of eight replayed
 out=$1

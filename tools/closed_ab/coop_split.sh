@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/coop_split.sh [model]  -- one walk launch at a time, by batch size and by the length from
+# usage (GPU box, repo root): tools/closed_ab/coop_split.sh [model]  -- one walk launch at a time, by batch size and by the length from
 # which reads go to the wave walker (PBSIM_COOP_LEN; -1 = lane walker only, 0 = wave walker only)
 m=${1:-errhmm}
 for n in 50000 100000 200000 450000; do

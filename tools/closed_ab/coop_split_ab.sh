@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/coop_split_ab.sh  -- the lane / wave split after the wave walker's step was cut: the batch
+# usage (GPU box, repo root): tools/closed_ab/coop_split_ab.sh  -- the lane / wave split after the wave walker's step was cut: the batch
 # size at which reads of one mean length and more go to the wave walker (PBSIM_COOP_SPLIT_READS, default 150 000), one walk
 # launch at a time by batch size, then the configs[1] job in HBM and rank 0 / 3 / 7 of eight replayed
 for n in 100000 200000 450000; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/coop_sweep.sh [lengths...]  -- the whole job with the text left in HBM, by the share of
+# usage (GPU box, repo root): tools/closed_ab/coop_sweep.sh [lengths...]  -- the whole job with the text left in HBM, by the share of
 # reads the wave walker takes (PBSIM_COOP_LEN: -1 none, n = reads of at least n bases; default = the library's choice)
 L="$@"; [ -z "$L" ] && L="-1 default 45056 36096 27136 18176 9216 0"
 for cl in $L; do

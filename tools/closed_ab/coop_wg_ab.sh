@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/coop_wg_ab.sh  -- the wave walker's persistent workgroups (default 1024 = 4 per CU):
+# usage (GPU box, repo root): tools/closed_ab/coop_wg_ab.sh  -- the wave walker's persistent workgroups (default 1024 = 4 per CU):
 # alone (every read of a 100 000-read and a 300 000-read batch), and in the configs[1] job in HBM and delivered
 for wg in 1024 1280 1536 2048; do
   for n in 100000 300000; do

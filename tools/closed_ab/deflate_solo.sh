@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/deflate_solo.sh OUT  -- k_deflate_chunks alone on ~1 GB of MAF-like text: duration of
+# usage (GPU box, repo root): tools/closed_ab/deflate_solo.sh OUT  -- k_deflate_chunks alone on ~1 GB of MAF-like text: duration of
 # its full-size launches (8192 chunks of 32 KB) with nothing else on the GPU
 out=$1
 R=$GRAFT_REPO_ROOT

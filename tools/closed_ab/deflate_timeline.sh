@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/deflate_timeline.sh OUT  -- kernel trace of one delivered job: how long the full-size
+# usage (GPU box, repo root): tools/closed_ab/deflate_timeline.sh OUT  -- kernel trace of one delivered job: how long the full-size
 # k_deflate_chunks launches (8192 chunks) take by what runs beside them (a walk kernel, the other lane's deflate kernel)
 out=$1; shift
 R=$GRAFT_REPO_ROOT

@@ -1,7 +1,7 @@
 """GPU box: the host-side rates the end-to-end CLI depends on.
   1. pwrite() of pinned-sized pieces into a /dev/shm file from 1..32 threads (the sink of the compressed members)
   2. host -> device copies of a 760 MB record: from a mmap'ed /dev/shm file (page cache), from malloc'ed memory, from pinned memory
-usage: python tools/host_io_rates.py"""
+usage: python tools/closed_ab/host_io_rates.py"""
 import mmap
 import os
 import threading

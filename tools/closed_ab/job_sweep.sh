@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: whole-job wall time (text left in HBM) over the job pipeline's knobs: rounds per record x rounds in flight
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 for rounds in 2 3 4; do
   for depth in 2 3; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the delivery-inclusive job over rounds in flight (PBSIM_JOB_DEPTH)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for depth in 1 2 3; do
   echo "== PBSIM_JOB_DEPTH=$depth"
   PBSIM_JOB_DEPTH=$depth python bench.py --no-cpu-baseline --no-extras --steps 2 2>/dev/null |

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, EXPERIMENTAL build (PBSIM_EXTRA_CFLAGS=-DPBSIM_EXPERIMENTAL): whole job with its text left in HBM over rounds per
 # record x rounds in flight x lane / wave split
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for coop in default -1; do
 for rounds in 1 2 3 4; do
   for depth in 2 3; do

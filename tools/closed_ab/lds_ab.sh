@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: same-box A/B of the walk's workgroups-per-CU cap (PBSIM_WALK_LDS_KB): solo walk, steady state, whole job in HBM
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for rep in 1 2; do for kb in 0 27 41; do
   echo "== rep $rep PBSIM_WALK_LDS_KB=$kb"
   PBSIM_WALK_LDS_KB=$kb python tools/walk_solo.py errhmm 3 2>/dev/null | tail -1

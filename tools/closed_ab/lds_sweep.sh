@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: walk workgroups per CU (PBSIM_WALK_LDS_KB) vs solo walk speed, whole job in HBM, whole job delivered
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for kb in 0 27 33 41; do
   echo "== PBSIM_WALK_LDS_KB=$kb"
   PBSIM_WALK_LDS_KB=$kb python tools/walk_solo.py errhmm 2 2>/dev/null | tail -1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/nt_experiment.sh OUT   -- builds the library with PBSIM_NT = 0..3 (bit 0: nontemporal scratch
+# usage (GPU box, repo root): tools/closed_ab/nt_experiment.sh OUT   -- builds the library with PBSIM_NT = 0..3 (bit 0: nontemporal scratch
 # stores in the walks, bit 1: nontemporal scratch loads in k_text_rows) and runs the bench + the walk's fabric traffic for each
 out=gpurun_out/$1; mkdir -p $out
 for nt in 0 1 3; do

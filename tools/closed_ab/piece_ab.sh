@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, EXPERIMENTAL build: 32-KiB chunks per deflate piece (PBSIM_DEFLATE_PIECE_CHUNKS; 8192 = 256 MiB of text ships) for
 # ranks 0 / 3 / 7 of the eight-rank configs[1] job (rounds of ~1 GB of text per lane) and for the one-GPU job
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 one() { python3 bench.py --no-cpu-baseline --no-extras --steps 2 "$@" 2>/dev/null | python3 -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])

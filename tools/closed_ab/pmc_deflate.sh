@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/pmc_deflate.sh OUTDIR -- PMC picture of k_deflate_chunks on FASTQ-/MAF-like text
+# usage (GPU box, repo root): tools/closed_ab/pmc_deflate.sh OUTDIR -- PMC picture of k_deflate_chunks on FASTQ-/MAF-like text
 out=$1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $out/p1 $out/p2

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/pmc_sample.sh OUTDIR -- SQ / FETCH / WRITE counters of the sampling method's kernels over
+# usage (GPU box, repo root): tools/closed_ab/pmc_sample.sh OUTDIR -- SQ / FETCH / WRITE counters of the sampling method's kernels over
 # tools/sample_prof.py 60000 (two runs of the 2-Gbase job: four k_walk_sample launches, the two long ones are the first sweeps);
 # each counter set in its own run with --kernel-trace only
 out=$1

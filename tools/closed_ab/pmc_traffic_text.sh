@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/pmc_traffic_text.sh OUTDIR -- HBM traffic of the text emission and of the deflate kernel
+# usage (GPU box, repo root): tools/closed_ab/pmc_traffic_text.sh OUTDIR -- HBM traffic of the text emission and of the deflate kernel
 # (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, each alone with --kernel-trace; raw counts x 1024 B).  Both kernels
 # read with 16 bytes per lane, for which gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md,
 # HBM / rocprofv3 section): the read figure is doubled before it is compared with the algorithmic bytes.

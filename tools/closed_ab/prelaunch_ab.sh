@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, EXPERIMENTAL build: the first pieces of a round's compressions launched ahead (PBSIM_DEFLATE_PRELAUNCH=1, the default)
 # against launched by the delivery itself (=0): the one-GPU job and ranks 0 / 7 of eight
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 one() { python3 bench.py --no-cpu-baseline --no-extras --steps 3 "$@" 2>/dev/null | python3 -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])

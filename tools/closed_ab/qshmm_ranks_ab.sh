@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/qshmm_ranks_ab.sh -- ranks 0 and 7 of the eight-rank configs[2] job (QSHMM-RSII --pass-num 10, one
+# usage (GPU box, repo root): tools/closed_ab/qshmm_ranks_ab.sh -- ranks 0 and 7 of the eight-rank configs[2] job (QSHMM-RSII --pass-num 10, one
 # 750 Mbp record) replayed alone on the GPU: the default lane / wave split of the rounds against the lane walker only
 one() { PBSIM_REPLAY_ONLY=0,7 python3 bench.py --workload qshmm10 --records 1 --no-cpu-baseline --no-extras --replay-ranks 8 --c1-gbs 0 --steps 1 2>/dev/null | python3 -c "
 import json,sys

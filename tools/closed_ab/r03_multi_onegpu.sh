@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/r03_multi_onegpu.sh TAG -- the full-size N = 8 round structure on the ONE GPU of the box
+# usage (GPU box, repo root): tools/closed_ab/r03_multi_onegpu.sh TAG -- the full-size N = 8 round structure on the ONE GPU of the box
 # (8 contexts, gloo collectives): plumbing and the per-rank critical path, not a scaling measurement
 tag=$1
 out=gpurun_out/$tag

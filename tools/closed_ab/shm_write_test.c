@@ -1,6 +1,6 @@
 /* GPU box: how fast 16 GiB reach a /dev/shm file -- pwrite() from N threads (one file: the inode lock serialises them; N files)
  * against memcpy() into a MAP_SHARED mapping of the file from N threads (page faults run in parallel).
- * gcc -O2 -pthread -o /tmp/shm_write_test tools/shm_write_test.c && /tmp/shm_write_test */
+ * gcc -O2 -pthread -o /tmp/shm_write_test tools/closed_ab/shm_write_test.c && /tmp/shm_write_test */
 #define _GNU_SOURCE
 #include <fcntl.h>
 #include <pthread.h>
