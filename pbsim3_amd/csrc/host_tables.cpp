@@ -441,7 +441,8 @@ bool build_err_class_tables(const ErrModel &m, const HeaderTables &h, const HpBi
         uint32_t magic, shift;
         emission_magic(d, &magic, &shift);
         uint8_t *er = dst + t->emis_off + 16u * (uint32_t)j;
-        const uint32_t w1 = shift | (d << 16), w2 = t0 | (t1 << 16);
+        // (the walks take the remainder as z + quo * (2^24 - d), low 24 bits: one 24-bit multiply-add)
+        const uint32_t w1 = shift | ((0x1000000u - d) << 8), w2 = t0 | (t1 << 16);
         memcpy(er, &magic, 4);
         memcpy(er + 4, &w1, 4);
         memcpy(er + 8, &w2, 4);

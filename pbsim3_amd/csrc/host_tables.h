@@ -92,7 +92,7 @@ void hp_census_weighted(const uint8_t *seq, int64_t len, int64_t weight, int kee
 // collapsed, so that e = (i > E0) + (i > E1) equals the expanded emis2err[i].
 struct ErrClassTables {
   int acc_lo = 0, acc_hi = 0, smax = 0;
-  uint32_t rows_off = 64, emis_off = 0, init_off = 0, tran_off = 0, stride = 0;  // emis_off: 16 B per state {magic, shift | d << 16, E0' | E1' << 16}
+  uint32_t rows_off = 64, emis_off = 0, init_off = 0, tran_off = 0, stride = 0;  // emis_off: 16 B per state {magic, shift | (2^24 - d) << 8, E0' | E1' << 16, del_thr[hp 1] | del_thr[hp 11] << 16}
   bool all_rv_1000 = false;  // every reachable modulus == 1000 (fast-path eligibility)
   std::vector<uint8_t> blob; // (acc_hi-acc_lo+1) * stride
 };

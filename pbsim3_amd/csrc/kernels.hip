@@ -95,6 +95,36 @@ __device__ __forceinline__ uint32_t mod3(uint32_t w) { return (w + __umulhi(w, 0
 __device__ __forceinline__ uint32_t mod100(uint32_t x) { return (x - __umul24(__umulhi(x, 0x51EB851Fu) >> 5, 100u)) & 0xffffffu; }
 __device__ __forceinline__ uint32_t mod1000(uint32_t x) { return (x - __umul24(__umulhi(x, 0x10624DD3u) >> 6, 1000u)) & 0xffffffu; }
 __device__ __forceinline__ uint32_t mod1e6(uint32_t x) { return (x - __umul24(__umulhi(x, 0x431BDE83u) >> 18, 1000000u)) & 0xffffffu; }
+// The same remainders of a DRAW taken from the raw 32-bit Philox word w (draw = w >> 1, philox.h): (w >> 1) % n =
+// (w - 2 n * floor(w / 2 n)) >> 1, and the 24-bit mask and the shift are ONE v_bfe_u32 -- a vector instruction less per
+// remainder than shifting first (round 5; the kernel is bound by the number of vector instructions it issues).  The magic
+// numbers are those of n with one more bit of shift; exact for every 32-bit w (error terms 112, 56 and 314 752 times 2^32 stay
+// below 2^39, 2^38 and 2^51; all 2^32 words compared with `%` on the CPU when this was written).  The 24-bit multiplier sees the
+// low 24 bits of the quotient, which is all the low 24 bits of the product depend on.
+// (The two instructions are spelled out: left to itself the compiler proves that only 24 bits of the product are wanted, drops
+// the 24-bit form for a 32 x 32 -> 64 multiply-add where the quotient may exceed 24 bits -- n = 100 -- and splits the bit-field
+// extract into a shift and a mask.)
+__device__ __forceinline__ uint32_t rem_raw(uint32_t w, uint32_t quo, uint32_t neg_2n) {
+  uint32_t t, r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(quo), "s"(neg_2n), "v"(w));
+  asm("v_bfe_u32 %0, %1, 1, 23" : "=v"(r) : "v"(t));
+  return r;
+}
+__device__ __forceinline__ uint32_t mod100_raw(uint32_t w) { return rem_raw(w, __umulhi(w, 0x51EB851Fu) >> 6, 0x1000000u - 200u); }
+__device__ __forceinline__ uint32_t mod1000_raw(uint32_t w) { return rem_raw(w, __umulhi(w, 0x10624DD3u) >> 7, 0x1000000u - 2000u); }
+__device__ __forceinline__ uint32_t mod1e6_raw(uint32_t w) { return rem_raw(w, __umulhi(w, 0x431BDE83u) >> 19, 0x1000000u - 2000000u); }
+template <bool B>
+struct BoolTag {
+  static constexpr bool value = B;
+};
+// x + (this lane's bit of `mask`): one v_addc_co_u32 with the wave mask as carry-in, where `x += cond ? 1 : 0` costs a
+// v_cndmask_b32 and a v_add_u32 (the walks keep four such counters per column)
+__device__ __forceinline__ int add_bit(int x, uint64_t mask) {
+  int r;
+  uint64_t carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(mask));
+  return r;
+}
 
 // inserted base (mut.ins_nt, pbsim.cpp:5485): "ATGC"[w % 8] for w % 8 < 4, else a copy of the reference base --
 // one byte select from the eight bytes {nt nt nt nt | C G T A}
@@ -837,6 +867,107 @@ struct RefCursor {
   }
 };
 
+// ---------------------------------------------------------------------------
+// RefStream (round 5): the lane walkers' reference window, re-cut so that a COLUMN costs two vector instructions instead of
+// eight.  A group of four columns consumes at most four bases, known to lie at the cursor and the three places behind it in
+// walking direction: begin_group() funnels exactly those four bytes -- already in the order they will be consumed, whatever
+// the strand -- into ONE dword `g`; a column reads byte 0 of it and, if it consumed the base, shifts `g` by a byte.  (RefCursor
+// located the byte from the read offset in every column: position, window test, two selects on a crossing, selector, permute.)
+// The 8-byte words are kept in STREAM order: word k of the stream is word (first + k) of the record as it lies there on the '+'
+// strand, word (first - k) with its bytes reversed on the '-' strand (two v_perm_b32 with per-lane selectors when a word
+// arrives), so one piece of code serves both.  s0|s1 = the current word, rn = the next one as loaded (its first stream dword
+// n2 is made per group: a group that starts in the upper half of a word reaches into it); refill() moves on when the group
+// left the word and asks for the word after the next -- at most once per group, as before.
+// kHpBits / the hp byte array: as RefCursor.
+// ---------------------------------------------------------------------------
+template <bool kHpBits>
+struct RefStream {
+  const uint64_t *lane_seq, *lane_hp;   // the word that holds the read's first base
+  int rel_next, rel_min;         // where `rn` lies, in words from there (the '-' strand counts down, never below the record's first word)
+  uint32_t a0;                   // stream offset of the first base inside its word: p & 7 ('+'), 7 - (p & 7) ('-').  The walk counts
+                                 // its STREAM POSITION sp = a0 + reference bases consumed: word sp >> 3, byte sp & 7 of the stream
+  uint32_t sel_lo, sel_hi;       // permute selectors word -> stream dwords 0 and 1
+  uint32_t wc;                   // stream index of the current word
+  uint32_t s0, s1, n2, g;        // current word (stream order) | first stream dword of the next | the group's four bases
+  uint32_t h0, h1, hn2, gh;      // the same of the hp bytes (!kHpBits)
+  uint64_t rn, hn;               // next word as loaded
+  int wstep;
+
+  __device__ __forceinline__ uint32_t lo_of(uint64_t w) const { return __builtin_amdgcn_perm((uint32_t)(w >> 32), (uint32_t)w, sel_lo); }
+  __device__ __forceinline__ uint32_t hi_of(uint64_t w) const { return __builtin_amdgcn_perm((uint32_t)(w >> 32), (uint32_t)w, sel_hi); }
+
+  __device__ __forceinline__ void init(const RefView &ref, int64_t off, int L, bool minus, bool act) {
+    const int64_t p_first = minus ? (off + L - 1) : off;
+    const int64_t w_first = p_first >> 3;
+    const uint32_t b = (uint32_t)p_first & 7u;
+    a0 = minus ? 7u - b : b;
+    sel_lo = minus ? 0x04050607u : 0x03020100u;  // pool of v_perm_b32(hi, lo, sel): bytes 0-3 = lo, 4-7 = hi
+    sel_hi = minus ? 0x00010203u : 0x07060504u;
+    wstep = minus ? -1 : 1;
+    lane_seq = reinterpret_cast<const uint64_t *>(ref.seq) + w_first;
+    lane_hp = reinterpret_cast<const uint64_t *>(ref.hp) + w_first;
+    wc = 0;
+    rel_min = w_first < 0x7fffffff ? -(int)w_first : (int)0x80000001;
+    rel_next = wstep;
+    uint64_t w0 = 0, v0 = 0;
+    rn = hn = 0;
+    if (act) {
+      const int nrel = rel_next > rel_min ? rel_next : rel_min;
+      w0 = lane_seq[0];
+      rn = lane_seq[nrel];
+      if (!kHpBits) {
+        v0 = lane_hp[0];
+        hn = lane_hp[nrel];
+      }
+    }
+    s0 = lo_of(w0);
+    s1 = hi_of(w0);
+    h0 = lo_of(v0);
+    h1 = hi_of(v0);
+    n2 = hn2 = g = gh = 0;
+  }
+
+  // the four bases the group can consume, from stream position sp on: byte 0 first
+  __device__ __forceinline__ void begin_group(int sp) {
+    const uint32_t ca = (uint32_t)sp;  // the group starts in word wc (refill keeps it so)
+    const bool upper = (ca & 4u) != 0;
+    n2 = lo_of(rn);
+    g = __builtin_amdgcn_alignbit(upper ? n2 : s1, upper ? s1 : s0, ca << 3);  // v_alignbit_b32 shifts by the low 5 bits: (ca & 3) * 8
+    if (!kHpBits) {
+      hn2 = lo_of(hn);
+      gh = __builtin_amdgcn_alignbit(upper ? hn2 : h1, upper ? h1 : h0, ca << 3);
+    }
+  }
+  // raw reference byte under the cursor (forward strand, not complemented; with kHpBits bit 7 is the hp == 11 flag, which the
+  // s_comp table drops) and its homopolymer class
+  __device__ __forceinline__ void peek(uint32_t *raw, uint32_t *hp) const {
+    *raw = g & 0xffu;
+    *hp = kHpBits ? ((g & 0x80u) ? 11u : 1u) : (gh & 0xffu);
+  }
+  __device__ __forceinline__ void consume(bool took) {
+    g = took ? (g >> 8) : g;
+    if (!kHpBits) gh = took ? (gh >> 8) : gh;
+  }
+  // end of a group: if it left the current word, the next becomes current and the one after it is asked for
+  __device__ __forceinline__ void refill(int sp, bool act) {
+    const uint32_t wn = (uint32_t)sp >> 3;
+    const bool cross = act && wn != wc;
+    s0 = cross ? n2 : s0;
+    s1 = cross ? hi_of(rn) : s1;
+    if (!kHpBits) {
+      h0 = cross ? hn2 : h0;
+      h1 = cross ? hi_of(hn) : h1;
+    }
+    wc = wn;
+    if (cross) {
+      rel_next += wstep;
+      const int nrel = rel_next > rel_min ? rel_next : rel_min;
+      rn = lane_seq[nrel];
+      if (!kHpBits) hn = lane_hp[nrel];
+    }
+  }
+};
+
 // stages the accuracy class blob of this workgroup and the two byte LUTs behind it:
 // s_comp[0..255] identity, [256..511] revcomp's base map; s_sub[c*4+k] = substitution k
 // of base c (pbsim.cpp:5481-5484), 0 for a non-ACGT base
@@ -883,6 +1014,122 @@ struct StepOut {
 // accuracy classes, non-ACGT substitutions), and the look-ahead refill.
 // kHpBits: --hp-del-bias 1 (default): the deletion threshold depends on hp only through
 // hp == 11 (Q1), so the walk reads the 1-bit-per-base mask instead of the hp byte array.
+// The loop itself, per kind of accuracy class: kVerbatim = the class of accuracy 100 (pbsim.cpp:3836-3846: the read is the
+// reference as it stands -- no draws, no tables) has a loop of its own, so that the loop of every other class carries no test
+// of the mode (round 5: the merged loop initialised sixteen registers per group and one per column for the path not taken).
+struct LaneWalk {
+  int sp, q, m, nsub;  // sp: stream position = RefStream::a0 + reference bases consumed
+};
+
+template <bool kFastRv, bool kHpBits, bool kVerbatim>
+__device__ __forceinline__ LaneWalk errhmm_lanes(const WalkArgs &a, const uint8_t *lds, const uint8_t *s_comp, const uint8_t *s_sub,
+                                                 uint32_t mode, uint32_t init_rv, uint32_t rate_mag, bool valid, bool walks, int L,
+                                                 int64_t off, bool minus, uint32_t read_idx, uint32_t pass, uint32_t *maf_read,
+                                                 uint32_t *maf_ref, int cap, RefStream<kHpBits> &cur) {
+  int q = 0, m = 0, nsub = 0;
+  uint32_t state = 0, tran_rv = 1;
+  uint32_t acc_r = 0, acc_f = 0;
+  // Which lanes still walk is kept as a WAVE MASK (round 5): a counter then takes its increment as the carry-in of one
+  // v_addc_co_u32 (add_bit), a select its condition straight from the scalar pair, and "any lane left" is a scalar compare.
+  // (As a per-lane bool every `x += (act && ..) ? 1 : 0` cost a v_cndmask_b32 and a v_add_u32.)  All 64 lanes run the loop
+  // body; the real branches inside it only read the mask.
+  uint64_t actm = __builtin_amdgcn_ballot_w64(walks);
+  int group = 0;
+  const WalkLane plane = walk_lane(a.seed, read_idx, pass, 0u);
+  const uint32_t comp_off = minus ? 256u : 0u;
+  cur.init(a.ref, off, L, minus, walks);
+  int sp = (int)cur.a0;
+  const int sp_end = sp + L;
+
+  while (actm != 0) {
+    cur.begin_group(sp);
+    // One Philox block per MAF column; the four columns of this group are
+    // independent of the walk, so their 4 x 20 multiplies interleave.
+    U4 W[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      W[j] = kVerbatim ? U4{0, 0, 0, 0} : walk_block_raw(plane, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const U4 w = W[j];  // the raw words: a draw is word >> 1 (mod1000_raw folds the shift into the remainder)
+      const uint32_t wz = w.z >> 1, ww = w.w >> 1;
+      // ---- reference base under the cursor
+      uint32_t raw, hp;
+      cur.peek(&raw, &hp);
+      const uint32_t nt = s_comp[raw + comp_off];
+
+      // ---- state, deletion test, emission class
+      uint32_t e = 0, subb = 0;
+      if (!kVerbatim) {
+        uint32_t idx;
+        if (kFastRv) {
+          // the initial-state table sits right in front of the transition rows (host_tables.cpp): it is row 0
+          idx = a.init_off + __umul24((q == 0) ? 0u : state, 1000u) + mod1000_raw(w.x);
+        } else {
+          uint32_t mod = (q == 0) ? init_rv : tran_rv;  // Q2: re-initialise while nothing has been emitted
+          mod = mod ? mod : 1u;
+          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 1000u) + (w.x >> 1) % mod;
+        }
+        state = lds[idx];  // a finished lane keeps walking harmlessly: nothing it computes is stored
+        const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + state * 32u);
+        if (!kFastRv) tran_rv = row[0];
+        // emission class: the modulus differs from state to state (emis_rv = round(1000 * (1 - P(del)))), so
+        // `z % emis_rv` is a multiply-high with the state's magic number (host_tables.cpp emission_magic) and a 24-bit
+        // multiply-add with 2^24 - emis_rv.  The row's last dword holds the deletion thresholds of hp != 11 | hp == 11: one
+        // 16-byte read serves the whole step.
+        const uint4 em = *reinterpret_cast<const uint4 *>(lds + a.emis_off + state * 16u);
+        const uint32_t thr = kHpBits ? __builtin_amdgcn_ubfe(em.w, (raw >> 3) & 16u, 16u) : row[4 + (hp < 12u ? hp : 11u)];
+        const bool del = (mod1000_raw(w.y) + 1u) <= thr;
+        const uint32_t quo = __umulhi(wz, em.x) >> (em.y & 31u);
+        const uint32_t rem = (wz + __umul24(quo, em.y >> 8)) & 0xffffffu;  // rem < d <= 1000: 24 bits of z - quo * d
+        e = (uint32_t)(rem >= (em.z & 0xffffu)) + (uint32_t)(rem >= (em.z >> 16));
+        e = del ? 3u : e;
+        subb = s_sub[nt * 4u + mod3(ww)];  // 0 for a non-ACGT reference base
+        const bool need1 = __builtin_amdgcn_inverse_ballot_w64(actm) &&
+                           ((mode == kModeBelow && e == 0) || (mode == kModeAbove && e != 0) || (subb == 0 && e == 1));
+        if (need1) {
+          const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 1u);
+          if (mode == kModeBelow && e == 0) {
+            if (v.x % 100u + 1u <= rate_mag) e = v.y % 3u + 1u;
+          } else if (mode == kModeAbove && e != 0) {
+            if (v.x % 100u + 1u <= rate_mag) e = 0;
+          }
+          if (subb == 0) subb = (kATGC >> ((v.z & 3u) * 8u)) & 0xffu;
+        }
+      }
+      // ---- emit
+      // the read row's byte is byte e of {nt, substituted, inserted, 0}: 0 marks a deleted column (the text kernel prints
+      // '-' there).  One v_perm_b32 selects it and drops it into byte j of the accumulator.
+      if (kVerbatim) {
+        acc_r |= nt << (8 * j);
+        acc_f |= nt << (8 * j);
+      } else {
+        const uint32_t cand = nt | (subb << 8) | (ins_base(ww, nt) << 16);
+        acc_r = __builtin_amdgcn_perm(cand, acc_r, (0x03020100u & ~(0xffu << (8 * j))) + ((4u + e) << (8 * j)));
+        const uint32_t mf = (e == 2) ? (uint32_t)'-' : nt;
+        acc_f |= mf << (8 * j);  // columns past the lane's last one are never read back (maf_len bounds them)
+      }
+      const uint64_t took = kVerbatim ? actm : (__builtin_amdgcn_ballot_w64(e != 2) & actm);  // every column consumes a reference base except insertions
+      q = add_bit(q, kVerbatim ? actm : (__builtin_amdgcn_ballot_w64(e != 3) & actm));       // ... and emits a read base except deletions
+      if (!kVerbatim) nsub = add_bit(nsub, __builtin_amdgcn_ballot_w64(e == 1) & actm);
+      sp = add_bit(sp, took);
+      m = add_bit(m, actm);
+      cur.consume(__builtin_amdgcn_inverse_ballot_w64(took));
+      actm &= __builtin_amdgcn_ballot_w64(sp < sp_end);
+      actm = (group * 4 + j + 1 < cap) ? actm : 0;  // (wave-uniform: a walking lane's column count is the loop's own counter)
+    }
+    if (valid && m > group * 4) {
+      scratch_store(&maf_read[(size_t)group * 64], acc_r);
+      scratch_store(&maf_ref[(size_t)group * 64], acc_f);
+    }
+    cur.refill(sp, __builtin_amdgcn_inverse_ballot_w64(actm));
+    acc_r = 0;
+    acc_f = 0;
+    group++;
+  }
+  return LaneWalk{sp, q, m, nsub};
+}
+
 template <bool kFastRv, bool kHpBits>
 __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -925,107 +1172,23 @@ __global__ __launch_bounds__(kWG) void k_walk_errhmm(WalkArgs a) {
   uint32_t *maf_ref = maf_read + (size_t)cap_dw * 64;
   const int cap = cap_dw * 4;  // columns the task's rows hold (k_wave_cap)
 
-  int ro = 0, q = 0, m = 0;
-  uint32_t state = 0, tran_rv = 1;
-  uint32_t acc_r = 0, acc_f = 0;
-  int nsub = 0;
   const bool coop_lane = mode != kModeVerbatim && L >= a.coop_min_len;  // a long read: k_walk_errhmm_coop walks it
-  bool act = valid && L > 0 && !coop_lane;
-  int group = 0;
-  const WalkLane plane = walk_lane(a.seed, read_idx, pass, 0u);
-
-  const uint32_t comp_off = minus ? 256u : 0u;
-  RefCursor<kHpBits> cur;
-  cur.init(a, off, L, minus, act);
-
-  while (__any(act)) {
-    // One Philox block per MAF column; the four columns of this group are
-    // independent of the walk, so their 4 x 20 multiplies interleave.
-    U4 W[4];
-    if (mode != kModeVerbatim) {
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        W[j] = walk_block_fast(plane, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j));
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; j++) W[j] = U4{0, 0, 0, 0};
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const U4 w = W[j];
-      // ---- reference base under the cursor
-      uint32_t raw, hp;
-      cur.at(ro, act, &raw, &hp);
-      const uint32_t nt = s_comp[raw + comp_off];
-
-      // ---- state, deletion test, emission class
-      uint32_t e = 0;
-      if (mode != kModeVerbatim) {
-        uint32_t idx;
-        if (kFastRv) {
-          // the initial-state table sits right in front of the transition rows (host_tables.cpp): it is row 0
-          idx = a.init_off + __umul24((q == 0) ? 0u : state, 1000u) + mod1000(w.x);
-        } else {
-          uint32_t mod = (q == 0) ? init_rv : tran_rv;  // Q2: re-initialise while nothing has been emitted
-          mod = mod ? mod : 1u;
-          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 1000u) + w.x % mod;
-        }
-        state = lds[idx];  // a finished lane keeps walking harmlessly: nothing it computes is stored
-        const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + state * 32u);
-        if (!kFastRv) tran_rv = row[0];
-        // emission class: the modulus differs from state to state (emis_rv = round(1000 * (1 - P(del)))), so
-        // `z % emis_rv` is a multiply-high with the state's magic number (host_tables.cpp emission_magic).  The row's
-        // last dword holds the deletion thresholds of hp != 11 | hp == 11: one 16-byte read serves the whole step.
-        const uint4 em = *reinterpret_cast<const uint4 *>(lds + a.emis_off + state * 16u);
-        const uint32_t thr = kHpBits ? __builtin_amdgcn_ubfe(em.w, (raw >> 3) & 16u, 16u) : row[4 + (hp < 12u ? hp : 11u)];
-        const bool del = (mod1000(w.y) + 1u) <= thr;
-        const uint32_t quo = __umulhi(w.z, em.x) >> (em.y & 0xffffu);
-        const uint32_t rem = (w.z - __umul24(quo, em.y >> 16)) & 0xffffffu;  // rem < d <= 1000: 24 bits of the difference
-        e = (uint32_t)(rem >= (em.z & 0xffffu)) + (uint32_t)(rem >= (em.z >> 16));
-        e = del ? 3u : e;
-      }
-      uint32_t subb = s_sub[nt * 4u + mod3(w.w)];  // 0 for a non-ACGT reference base
-      const bool need1 =
-          act && ((mode == kModeBelow && e == 0) || (mode == kModeAbove && e != 0) || (subb == 0 && e == 1));
-      if (need1) {
-        const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 1u);
-        if (mode == kModeBelow && e == 0) {
-          if (v.x % 100u + 1u <= rate_mag) e = v.y % 3u + 1u;
-        } else if (mode == kModeAbove && e != 0) {
-          if (v.x % 100u + 1u <= rate_mag) e = 0;
-        }
-        if (subb == 0) subb = (kATGC >> ((v.z & 3u) * 8u)) & 0xffu;
-      }
-      // ---- emit
-      // the read row's byte is byte e of {nt, substituted, inserted, 0}: 0 marks a deleted column (the text kernel prints
-      // '-' there).  One v_perm_b32 selects it and drops it into byte j of the accumulator.
-      const uint32_t cand = nt | (subb << 8) | (ins_base(w.w, nt) << 16);
-      acc_r = __builtin_amdgcn_perm(cand, acc_r, (0x03020100u & ~(0xffu << (8 * j))) + ((4u + e) << (8 * j)));
-      const uint32_t mf = (e == 2) ? (uint32_t)'-' : nt;
-      acc_f |= mf << (8 * j);  // columns past the lane's last one are never read back (maf_len bounds them)
-      q += (act && e != 3) ? 1 : 0;
-      nsub += (act && e == 1) ? 1 : 0;
-      ro += (act && e != 2) ? 1 : 0;
-      m += act ? 1 : 0;
-      act = act && (ro < L) && (m < cap);
-    }
-    if (valid && m > group * 4) {
-      scratch_store(&maf_read[(size_t)group * 64], acc_r);
-      scratch_store(&maf_ref[(size_t)group * 64], acc_f);
-    }
-    cur.refill(act);
-    acc_r = 0;
-    acc_f = 0;
-    group++;
-  }
+  const bool walks = valid && L > 0 && !coop_lane;
+  RefStream<kHpBits> cur;
+  const LaneWalk o = (mode == kModeVerbatim)
+                         ? errhmm_lanes<kFastRv, kHpBits, true>(a, lds, s_comp, s_sub, mode, init_rv, rate_mag, valid, walks, L, off, minus,
+                                                                read_idx, pass, maf_read, maf_ref, cap, cur)
+                         : errhmm_lanes<kFastRv, kHpBits, false>(a, lds, s_comp, s_sub, mode, init_rv, rate_mag, valid, walks, L, off, minus,
+                                                                 read_idx, pass, maf_read, maf_ref, cap, cur);
   if (valid && !coop_lane) {
+    const int ro = o.sp - (int)cur.a0;
     if (ro < L) atomicOr(&a.flags->error, kErrScratchOverflow);
-    a.out_len[task] = q;
-    a.maf_len[task] = m;
-    a.nsub[task] = nsub;
-    a.nins[task] = m - ro;  // every column consumes a reference base except insertions
-    a.ndel[task] = m - q;   // every column emits a read base except deletions
-    note_row_need(a.flags, m, L);
+    a.out_len[task] = o.q;
+    a.maf_len[task] = o.m;
+    a.nsub[task] = o.nsub;
+    a.nins[task] = o.m - ro;    // every column consumes a reference base except insertions
+    a.ndel[task] = o.m - o.q;   // every column emits a read base except deletions
+    note_row_need(a.flags, o.m, L);
   }
 }
 
@@ -1225,8 +1388,8 @@ __device__ __forceinline__ void coop_walk_task(const WalkArgs &a, const uint8_t 
                      : coop_chain<false>(lds, a.init_off, smax, reach, s_w, x, 0ull, st_in, lane);
       const uint4 em = *reinterpret_cast<const uint4 *>(lds + a.emis_off + st * 16u);
       const uint16_t *row = reinterpret_cast<const uint16_t *>(lds + a.rows_off + st * 32u);
-      const uint32_t quo = __umulhi(w.z, em.x) >> (em.y & 0xffffu);
-      const uint32_t rem = (w.z - __umul24(quo, em.y >> 16)) & 0xffffffu;
+      const uint32_t quo = __umulhi(w.z, em.x) >> (em.y & 31u);
+      const uint32_t rem = (w.z + __umul24(quo, em.y >> 8)) & 0xffffffu;  // em.y >> 8 = 2^24 - d
       const uint32_t ce = (uint32_t)(rem >= (em.z & 0xffffu)) + (uint32_t)(rem >= (em.z >> 16));
       // the column's class if it is not deleted (e_keep) / if it is (e_del)
       uint32_t e_keep = ce, e_del = 3u;

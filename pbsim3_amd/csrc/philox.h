@@ -76,8 +76,10 @@ PB_HD WalkLane walk_lane(uint32_t seed, uint32_t read, uint32_t pass, uint32_t s
   return WalkLane{(uint32_t)a, (uint32_t)(b >> 32), (uint32_t)b};
 }
 
-// `event` and `unit` must be wave-uniform for the scalar part to stay on the scalar unit
-PB_HD U4 walk_block_fast(const WalkLane &l, uint32_t seed, uint32_t unit, uint32_t event) {
+// `event` and `unit` must be wave-uniform for the scalar part to stay on the scalar unit.
+// walk_block_raw: the block's four 32-bit words as Philox made them (the draw is word >> 1: the lane walkers fold that shift
+// into the remainder they take of a word, kernels.hip mod1000_raw); walk_block_fast: the four draws.
+PB_HD U4 walk_block_raw(const WalkLane &l, uint32_t seed, uint32_t unit, uint32_t event) {
   // round 1, uniform half: (n2, n3) from M0*event
   const uint64_t p = (uint64_t)kPhiloxM0 * event;
   const uint32_t n2 = (uint32_t)(p >> 32) ^ unit ^ kStreamWalk;
@@ -103,7 +105,11 @@ PB_HD U4 walk_block_fast(const WalkLane &l, uint32_t seed, uint32_t unit, uint32
     ka += kPhiloxW0;
     kb += kPhiloxW1;
   }
-  return U4{c0 >> 1, c1 >> 1, c2 >> 1, c3 >> 1};
+  return U4{c0, c1, c2, c3};
+}
+PB_HD U4 walk_block_fast(const WalkLane &l, uint32_t seed, uint32_t unit, uint32_t event) {
+  const U4 r = walk_block_raw(l, seed, unit, event);
+  return U4{r.x >> 1, r.y >> 1, r.z >> 1, r.w >> 1};
 }
 
 // walk-stream block of one HMM event; words are already shifted to 31 bits

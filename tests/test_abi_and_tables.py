@@ -122,8 +122,9 @@ def test_errhmm_class_tables_are_well_formed(model):
         assert acc == 63 + c and mode in (0, 1, 2)
         assert init_rv == 1000
         rows = np.frombuffer(b[64:64 + 32 * (smax + 1)], dtype=np.uint16).reshape(smax + 1, 16)
-        # emission rows: 16 B per state {magic u32, shift u16, d u16, E0' u16, E1' u16, del_thr[hp 1] u16, del_thr[hp 11] u16}:
-        # z % d by multiply-high, and the two deletion thresholds the default bias can reach
+        # emission rows: 16 B per state {magic u32, shift u8 | (2^24 - d) << 8, E0' u16, E1' u16, del_thr[hp 1] u16, del_thr[hp 11] u16}:
+        # z % d by multiply-high and a 24-bit multiply-add (the low 24 bits of z + quo * (2^24 - d)), and the two deletion
+        # thresholds the default bias can reach
         emis_off = 64 + 32 * (smax + 1)
         em = np.frombuffer(b[emis_off:emis_off + 16 * (smax + 1)], dtype=np.uint32).reshape(smax + 1, 4)
         init_off = emis_off + 16 * (smax + 1)
@@ -137,14 +138,17 @@ def test_errhmm_class_tables_are_well_formed(model):
             if tran_rv == 0:
                 continue
             assert tran_rv == 1000 and 0 <= emis_rv <= 1000 and e0 <= e1 <= emis_rv
-            magic, shift, d = int(em[j][0]), int(em[j][1]) & 0xffff, int(em[j][1]) >> 16
+            magic, shift, neg_d = int(em[j][0]), int(em[j][1]) & 0xff, int(em[j][1]) >> 8
+            d = (1 << 24) - neg_d
             t0, t1 = int(em[j][2]) & 0xffff, int(em[j][2]) >> 16
             if emis_rv >= 2:
                 assert (d, t0, t1) == (emis_rv, e0, e1)
             else:                                  # emis_rv 0: rand() % 3; emis_rv 1: constant class
                 assert d == 3
             for z in (0, 1, d - 1, d, 999, 1000, 123456789, 2 ** 31 - 1, (2 ** 31 - 1) // d * d, (2 ** 31 - 1) // d * d - 1):
-                assert z - ((z * magic >> 32) >> shift) * d == z % d
+                quo = (z * magic >> 32) >> shift
+                assert z - quo * d == z % d
+                assert (z + (quo & 0xffffff) * neg_d) & 0xffffff == z % d      # what the walk kernels compute
                 r = z % d
                 want = z % 3 if emis_rv == 0 else ((z % emis_rv + 1 > e0) + (z % emis_rv + 1 > e1))
                 assert (r >= t0) + (r >= t1) == want
