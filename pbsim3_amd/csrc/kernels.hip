@@ -1007,7 +1007,7 @@ struct StepOut {
 // kFastRv: every init/transition modulus of the class tables is 1000 (true for
 // all shipped models, checked on the host): `% 1000` folds to a multiply-high.
 //
-// The step body is written branch-free (selects on the lane's `act` flag): the
+// The step body is written branch-free (selects on the mask of lanes that still walk): the
 // kernel is VALU/SALU-issue bound, and every divergent `if` costs exec-mask
 // bookkeeping for all 64 lanes.  Only three rare paths stay as real branches:
 // states whose emission modulus is not 1000, the sub-block-1 draws (out-of-range
@@ -1612,62 +1612,69 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
   uint32_t *qual_row = maf_ref + (size_t)cap_dw * 64;  // quality per MAF column (0 in deleted columns)
   const int cap = cap_dw * 4;  // columns the task's rows hold (k_wave_cap)
 
-  int ro = 0, q = 0, m = 0;
+  int q = 0, m = 0;
   uint32_t state = 0, last_q = 0, hp_prev = 0;  // hp of the last consumed reference base; none yet -> slot 0 (Q15)
   uint32_t del_norm = 0, del_none = 0;          // kHpBits: the last emitted quality's deletion thresholds (hp 1..10 | slot 0)
   uint32_t acc_r = 0, acc_f = 0, acc_q = 0;
   int nsub = 0;
   double qsum = 0.0;
   const bool coop_lane = L >= a.coop_min_len;  // a long task: k_walk_qshmm_coop walks it (classes with and without a model)
-  bool act = valid && L > 0 && !coop_lane;
+  // which lanes still walk: a wave mask (errhmm_lanes says why); sp: the stream position (RefStream)
+  uint64_t actm = __builtin_amdgcn_ballot_w64(valid && L > 0 && !coop_lane);
   int group = 0;
   const uint32_t comp_off = minus ? 256u : 0u;
-  RefCursor<kHpBits> cur;
-  cur.init(a, off, L, minus, act);
+  RefStream<kHpBits> cur;
+  cur.init(a.ref, off, L, minus, __builtin_amdgcn_inverse_ballot_w64(actm));
+  int sp = (int)cur.a0;
+  const int sp_end = sp + L;
   const WalkLane lane_e = walk_lane(a.seed, read_idx, pass, 0u);  // emission blocks
   const WalkLane lane_d = walk_lane(a.seed, read_idx, pass, 2u);  // deletion-test blocks
 
-  while (__any(act)) {
+  while (actm != 0) {
+    cur.begin_group(sp);
     U4 E[4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      E[j] = walk_block_fast(lane_e, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j));
+      E[j] = walk_block_raw(lane_e, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group * 4 + j));
     // the deletion tests of the group's four columns are the four words of ONE block (event = column >> 2)
-    const U4 Dq = walk_block_fast(lane_d, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group));
+    const U4 Dq = walk_block_raw(lane_d, a.seed, a.unit, (uint32_t)__builtin_amdgcn_readfirstlane(group));
     const uint32_t D[4] = {Dq.x, Dq.y, Dq.z, Dq.w};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const U4 w = E[j];
+      const U4 w = E[j];  // raw words: a draw is word >> 1 (mod100_raw / mod1e6_raw fold the shift into the remainder)
+      const uint32_t ww = w.w >> 1;
+      const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
       uint32_t raw, hp;
-      cur.at(ro, act, &raw, &hp);
+      cur.peek(&raw, &hp);
       const uint32_t nt = s_comp[raw + comp_off];
       // every column m >= 1 first takes the deletion test of the inner while (pbsim.cpp:2268-2281)
       const uint32_t del_thr = kHpBits ? ((hp_prev == 11u) ? 0u : (hp_prev == 0u) ? del_none : del_norm)
                                        : s_del[last_q * 12u + (hp_prev < 12u ? hp_prev : 11u)];
-      const bool deleted = (m > 0) & (mod1e6(D[j]) < del_thr);
+      // (m > 0: a walking lane's column count is the loop's own counter, wave-uniform)
+      const bool deleted = (group * 4 + j > 0) & (mod1e6_raw(D[j]) < del_thr);
       // ---- emission (computed for every lane, used where the column is not deleted)
       uint32_t qv, st = state;
       if (has_model) {
         uint32_t idx;
         if (kFastRv) {
-          idx = a.init_off + __umul24((q == 0) ? 0u : state, 100u) + mod100(w.x);  // init table = row 0 (host_tables.cpp)
+          idx = a.init_off + __umul24((q == 0) ? 0u : state, 100u) + mod100_raw(w.x);  // init table = row 0 (host_tables.cpp)
         } else {
           uint32_t mod = (q == 0) ? init_rv : rvs[2 * state];
           mod = mod ? mod : 1u;
-          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 100u) + w.x % mod;
+          idx = ((q == 0) ? a.init_off : a.tran_off + (state - 1u) * 100u) + (w.x >> 1) % mod;
         }
         st = lds[idx];
         uint32_t eidx;
         if (kFastRv) {
-          eidx = a.emis_off + __umul24(st - 1u, 100u) + mod100(w.y);
+          eidx = a.emis_off + __umul24(st - 1u, 100u) + mod100_raw(w.y);
         } else {
           uint32_t emod = rvs[2 * st + 1];
           emod = emod ? emod : 1u;
-          eidx = a.emis_off + (st - 1u) * 100u + w.y % emod;
+          eidx = a.emis_off + (st - 1u) * 100u + (w.y >> 1) % emod;
         }
         qv = lds[eidx];
       } else {
-        qv = lds[a.freq_off + w.y % (freq_rv ? freq_rv : 1u)];
+        qv = lds[a.freq_off + (w.y >> 1) % (freq_rv ? freq_rv : 1u)];
       }
       qv = (qv < 94u) ? qv : 93u;
       const bool emit = act && !deleted;
@@ -1688,41 +1695,46 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
         qp = s_qprob[qv];
       }
       qsum += emit ? qp : 0.0;  // ordered double sum (pbsim.cpp:2309-2313); + 0.0 leaves it unchanged
-      const uint32_t x = mod1e6(w.z);
+      const uint32_t x = mod1e6_raw(w.z);
       const bool is_sub = x < thr_sub;             // pbsim.cpp:2233-2249
       const bool is_ins = !is_sub && x < thr_ins;   // pbsim.cpp:2250-2258
-      uint32_t subb = s_sub[nt * 4u + mod3(w.w)];
+      uint32_t subb = s_sub[nt * 4u + mod3(ww)];
       if (emit && is_sub && subb == 0) {  // non-ACGT reference base: one more draw (rare)
         const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 1u);
         subb = (kATGC >> ((v.x & 3u) * 8u)) & 0xffu;
       }
-      const uint32_t insb = (w.w & 4u) ? nt : ((kATGC >> ((w.w & 3u) * 8u)) & 0xffu);
+      const uint32_t insb = (ww & 4u) ? nt : ((kATGC >> ((ww & 3u) * 8u)) & 0xffu);
       const uint32_t b = is_sub ? subb : is_ins ? insb : nt;
       const uint32_t mr = deleted ? 0u : b;                      // 0 marks a deleted column
       const uint32_t mf = (!deleted && is_ins) ? (uint32_t)'-' : nt;
       acc_r |= mr << (8 * j);
       acc_f |= mf << (8 * j);
       acc_q |= (deleted ? 0u : (qv + 33u)) << (8 * j);
-      const bool consumed = act && (deleted || !is_ins);
+      const uint64_t delm = __builtin_amdgcn_ballot_w64(deleted);
+      const uint64_t took = actm & (delm | ~__builtin_amdgcn_ballot_w64(is_ins));  // every column consumes a reference base except insertions
+      const bool consumed = __builtin_amdgcn_inverse_ballot_w64(took);
       hp_prev = consumed ? hp : hp_prev;
-      q += emit ? 1 : 0;
-      nsub += (emit && is_sub) ? 1 : 0;
-      ro += consumed ? 1 : 0;
-      m += act ? 1 : 0;
-      act = act && (ro < L) && (m < cap);
+      q = add_bit(q, actm & ~delm);
+      nsub = add_bit(nsub, actm & ~delm & __builtin_amdgcn_ballot_w64(is_sub));
+      sp = add_bit(sp, took);
+      m = add_bit(m, actm);
+      cur.consume(consumed);
+      actm &= __builtin_amdgcn_ballot_w64(sp < sp_end);
+      actm = (group * 4 + j + 1 < cap) ? actm : 0;
     }
     if (valid && m > group * 4) {
       scratch_store(&maf_read[(size_t)group * 64], acc_r);
       scratch_store(&maf_ref[(size_t)group * 64], acc_f);
       scratch_store(&qual_row[(size_t)group * 64], acc_q);
     }
-    cur.refill(act);
+    cur.refill(sp, __builtin_amdgcn_inverse_ballot_w64(actm));
     acc_r = 0;
     acc_f = 0;
     acc_q = 0;
     group++;
   }
   if (valid && !coop_lane) {
+    const int ro = sp - (int)cur.a0;
     if (ro < L) atomicOr(&a.flags->error, kErrScratchOverflow);
     a.out_len[task] = q;
     a.maf_len[task] = m;
