@@ -1084,20 +1084,17 @@ __device__ __forceinline__ LaneWalk errhmm_lanes(const WalkArgs &a, const uint8_
         const uint32_t rem = (wz + __umul24(quo, em.y >> 8)) & 0xffffffu;  // rem < d <= 1000: 24 bits of z - quo * d
         e = (uint32_t)(rem >= (em.z & 0xffffu)) + (uint32_t)(rem >= (em.z >> 16));
         e = del ? 3u : e;
-        const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
-        // classes below / above the model's accuracy range re-draw from sub-block 1 (pbsim.cpp:3892-3925, Q3)
-        if (act && ((mode == kModeBelow && e == 0) || (mode == kModeAbove && e != 0))) {
+        subb = s_sub[nt * 4u + mod3(ww)];  // 0 for a non-ACGT reference base
+        const bool need1 = __builtin_amdgcn_inverse_ballot_w64(actm) &&
+                           ((mode == kModeBelow && e == 0) || (mode == kModeAbove && e != 0) || (subb == 0 && e == 1));
+        if (need1) {
           const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 1u);
-          if (v.x % 100u + 1u <= rate_mag) e = (mode == kModeBelow) ? v.y % 3u + 1u : 0u;
-        }
-        // a substitution: which base.  Under a branch of its own since round 5 -- a twentieth of the columns substitute, so the
-        // LUT read runs with those lanes only (the LDS pipe is 70 % busy with the table look-ups of all 64)
-        if (act && e == 1) {
-          subb = s_sub[nt * 4u + mod3(ww)];  // 0 for a non-ACGT reference base: one more draw
-          if (subb == 0) {
-            const U4 v = walk_block(a.seed, a.unit, read_idx, pass, (uint32_t)(group * 4 + j), 1u);
-            subb = (kATGC >> ((v.z & 3u) * 8u)) & 0xffu;
+          if (mode == kModeBelow && e == 0) {
+            if (v.x % 100u + 1u <= rate_mag) e = v.y % 3u + 1u;
+          } else if (mode == kModeAbove && e != 0) {
+            if (v.x % 100u + 1u <= rate_mag) e = 0;
           }
+          if (subb == 0) subb = (kATGC >> ((v.z & 3u) * 8u)) & 0xffu;
         }
       }
       // ---- emit
