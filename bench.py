@@ -197,12 +197,16 @@ def bench_sample(a, torch, harness, P, local):
     ctx.set_reference(genome, 1)
     ctx.simulate_sample(collect=False)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ctx.simulate_sample(collect=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    runs = []
+    for _ in range(5):       # a 27 ms job: one timed run measured the box's mood as much as the job (0.026-0.045 s); the median of five
+        t0 = time.perf_counter()
+        ctx.simulate_sample(collect=False)
+        torch.cuda.synchronize()
+        runs.append(time.perf_counter() - t0)
+    dt = sorted(runs)[len(runs) // 2]
     st = ctx.stats()
     print(json.dumps({"metric": "whole job wall time", "value": dt, "unit": "s", "higher_is_better": False, "n_gpus": 1,
+                      "runs_s": runs, "value_is": "median of runs_s",
                       "bases": st.res_len_total, "reads": st.res_num, "bases_per_sec": st.res_len_total / dt,
                       "config": {"workload": f"wgs sample, {n} synthetic quality strings ({int(lens.sum())} bases), "
                                              f"100 Mbp record, depth {p.depth}, seed 1"}}))
