@@ -876,14 +876,21 @@ struct RefCursor {
 // The 8-byte words are kept in STREAM order: word k of the stream is word (first + k) of the record as it lies there on the '+'
 // strand, word (first - k) with its bytes reversed on the '-' strand (two v_perm_b32 with per-lane selectors when a word
 // arrives), so one piece of code serves both.  s0|s1 = the current word, rn = the next one as loaded (its first stream dword
-// n2 is made per group: a group that starts in the upper half of a word reaches into it); refill() moves on when the group
-// left the word and asks for the word after the next -- at most once per group, as before.
+// n2 is made per group: a group that starts in the upper half of a word reaches into it), rnn = the word after it.
+// Two words ahead, because a word must never be waited for in the group it was asked in: at the end of a group advance() moves
+// on if the group left the current word (current <- next <- the one after) and fetch() asks for a new "one after" -- into a
+// register of its own (`pend`) that nothing reads before the NEXT group's advance(), a whole group (~2 000 cycles) later: that
+// is where the compiler's s_waitcnt for the load lands.  The load is unconditional for that reason (lanes that did not move on
+// read the record's first word, one sector for all of them, and drop it): as a conditional load its result was merged with the
+// old value right behind the load -- a register copy at the loop's end with s_waitcnt vmcnt(0) in front --, so every group of
+// every wave sat out a full memory round trip, hidden by the other waves at five per SIMD and fully exposed at one per SIMD,
+// the delivered job's occupancy.
 // kHpBits / the hp byte array: as RefCursor.
 // ---------------------------------------------------------------------------
 template <bool kHpBits>
 struct RefStream {
   const uint64_t *lane_seq, *lane_hp;   // the word that holds the read's first base
-  int rel_next, rel_min;         // where `rn` lies, in words from there (the '-' strand counts down, never below the record's first word)
+  int rel_next, rel_min;         // where `rnn` lies, in words from there (the '-' strand counts down, never below the record's first word)
   uint32_t a0;                   // stream offset of the first base inside its word: p & 7 ('+'), 7 - (p & 7) ('-').  The walk counts
                                  // its STREAM POSITION sp = a0 + reference bases consumed: word sp >> 3, byte sp & 7 of the stream
   uint32_t sel_lo, sel_hi;       // permute selectors word -> stream dwords 0 and 1
@@ -891,6 +898,10 @@ struct RefStream {
   uint32_t s0, s1, n2, g;        // current word (stream order) | first stream dword of the next | the group's four bases
   uint32_t h0, h1, hn2, gh;      // the same of the hp bytes (!kHpBits)
   uint64_t rn, hn;               // next word as loaded
+  uint64_t rnn, hnn;             // the word after it
+  uint64_t pend, hpend;          // what fetch() asked for at the end of the group before; pcross: the lanes it asked for
+  uint64_t pcross;
+  const uint64_t *base_seq, *base_hp;
   int wstep;
 
   __device__ __forceinline__ uint32_t lo_of(uint64_t w) const { return __builtin_amdgcn_perm((uint32_t)(w >> 32), (uint32_t)w, sel_lo); }
@@ -904,20 +915,25 @@ struct RefStream {
     sel_lo = minus ? 0x04050607u : 0x03020100u;  // pool of v_perm_b32(hi, lo, sel): bytes 0-3 = lo, 4-7 = hi
     sel_hi = minus ? 0x00010203u : 0x07060504u;
     wstep = minus ? -1 : 1;
-    lane_seq = reinterpret_cast<const uint64_t *>(ref.seq) + w_first;
-    lane_hp = reinterpret_cast<const uint64_t *>(ref.hp) + w_first;
+    base_seq = reinterpret_cast<const uint64_t *>(ref.seq);
+    base_hp = reinterpret_cast<const uint64_t *>(ref.hp);
+    lane_seq = base_seq + w_first;
+    lane_hp = base_hp + w_first;
     wc = 0;
+    pend = hpend = pcross = 0;
     rel_min = w_first < 0x7fffffff ? -(int)w_first : (int)0x80000001;
-    rel_next = wstep;
+    rel_next = 2 * wstep;
     uint64_t w0 = 0, v0 = 0;
-    rn = hn = 0;
+    rn = hn = rnn = hnn = 0;
     if (act) {
-      const int nrel = rel_next > rel_min ? rel_next : rel_min;
+      const int nrel = wstep > rel_min ? wstep : rel_min, nnrel = rel_next > rel_min ? rel_next : rel_min;
       w0 = lane_seq[0];
       rn = lane_seq[nrel];
+      rnn = lane_seq[nnrel];
       if (!kHpBits) {
         v0 = lane_hp[0];
         hn = lane_hp[nrel];
+        hnn = lane_hp[nnrel];
       }
     }
     s0 = lo_of(w0);
@@ -925,6 +941,10 @@ struct RefStream {
     h0 = lo_of(v0);
     h1 = hi_of(v0);
     n2 = hn2 = g = gh = 0;
+    // the three words have arrived before the loop begins (a use the compiler must wait for): a load still pending at the loop's
+    // head would put a wait there that every later group executes too -- and that one then sits out the group's own row stores
+    if (kHpBits) asm volatile("" : "+v"(rn), "+v"(rnn));
+    else asm volatile("" : "+v"(rn), "+v"(rnn), "+v"(hn), "+v"(hnn));
   }
 
   // the four bases the group can consume, from stream position sp on: byte 0 first
@@ -948,23 +968,37 @@ struct RefStream {
     g = took ? (g >> 8) : g;
     if (!kHpBits) gh = took ? (gh >> 8) : gh;
   }
-  // end of a group: if it left the current word, the next becomes current and the one after it is asked for
-  __device__ __forceinline__ void refill(int sp, bool act) {
+  // end of a group, in front of its row stores: what the group before asked for has arrived (the first use of `pend`: the
+  // compiler's wait for that load, a whole group after it); if this group left the current word, the next becomes current and
+  // the one after it the next
+  __device__ __forceinline__ bool advance(int sp, bool act) {
+    const bool had = __builtin_amdgcn_inverse_ballot_w64(pcross);
+    rnn = had ? pend : rnn;
+    if (!kHpBits) hnn = had ? hpend : hnn;
+    // (pinned in front of the group's stores: left alone the compiler sinks this merge -- and the wait -- behind them, where the
+    // wait then sits out the stores it has just issued)
+    if (kHpBits) asm volatile("" : "+v"(rnn) : : "memory");
+    else asm volatile("" : "+v"(rnn), "+v"(hnn) : : "memory");
     const uint32_t wn = (uint32_t)sp >> 3;
     const bool cross = act && wn != wc;
     s0 = cross ? n2 : s0;
     s1 = cross ? hi_of(rn) : s1;
+    rn = cross ? rnn : rn;
     if (!kHpBits) {
       h0 = cross ? hn2 : h0;
       h1 = cross ? hi_of(hn) : h1;
+      hn = cross ? hnn : hn;
     }
     wc = wn;
-    if (cross) {
-      rel_next += wstep;
-      const int nrel = rel_next > rel_min ? rel_next : rel_min;
-      rn = lane_seq[nrel];
-      if (!kHpBits) hn = lane_hp[nrel];
-    }
+    pcross = __builtin_amdgcn_ballot_w64(cross);
+    return cross;
+  }
+  // ... and behind the stores: the lanes that moved on ask for their new "word after the next"
+  __device__ __forceinline__ void fetch(bool cross) {
+    rel_next += cross ? wstep : 0;
+    const int nrel = rel_next > rel_min ? rel_next : rel_min;
+    pend = *(cross ? lane_seq + nrel : base_seq);
+    if (!kHpBits) hpend = *(cross ? lane_hp + nrel : base_hp);
   }
 };
 
@@ -1118,11 +1152,12 @@ __device__ __forceinline__ LaneWalk errhmm_lanes(const WalkArgs &a, const uint8_
       actm &= __builtin_amdgcn_ballot_w64(sp < sp_end);
       actm = (group * 4 + j + 1 < cap) ? actm : 0;  // (wave-uniform: a walking lane's column count is the loop's own counter)
     }
+    const bool moved = cur.advance(sp, __builtin_amdgcn_inverse_ballot_w64(actm));
     if (valid && m > group * 4) {
       scratch_store(&maf_read[(size_t)group * 64], acc_r);
       scratch_store(&maf_ref[(size_t)group * 64], acc_f);
     }
-    cur.refill(sp, __builtin_amdgcn_inverse_ballot_w64(actm));
+    cur.fetch(moved);
     acc_r = 0;
     acc_f = 0;
     group++;
@@ -1544,7 +1579,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) __attribute__((amdgpu_waves_per_eu
 // ---------------------------------------------------------------------------
 // kFastRv: every init / transition / emission modulus of the class is 100.
 template <bool kFastRv, bool kHpBits>
-__global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_walk_qshmm(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
   const int64_t slot0 = (int64_t)a.wg_order[blockIdx.x] * kWG;
@@ -1722,12 +1757,13 @@ __global__ __launch_bounds__(kWG) void k_walk_qshmm(WalkArgs a) {
       actm &= __builtin_amdgcn_ballot_w64(sp < sp_end);
       actm = (group * 4 + j + 1 < cap) ? actm : 0;
     }
+    const bool moved = cur.advance(sp, __builtin_amdgcn_inverse_ballot_w64(actm));
     if (valid && m > group * 4) {
       scratch_store(&maf_read[(size_t)group * 64], acc_r);
       scratch_store(&maf_ref[(size_t)group * 64], acc_f);
       scratch_store(&qual_row[(size_t)group * 64], acc_q);
     }
-    cur.refill(sp, __builtin_amdgcn_inverse_ballot_w64(actm));
+    cur.fetch(moved);
     acc_r = 0;
     acc_f = 0;
     acc_q = 0;
