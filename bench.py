@@ -811,8 +811,8 @@ def main():
                                                         "read; the wave walker k_walk_errhmm_coop takes ERRHMM ones): counted apart from the launches above"},
                          "occupancy_note": ("a job that compresses its output runs the lane walk at ONE workgroup per CU (81 KB of LDS asked for) so that two "
                                             "deflate workgroups fit beside it: the job is 9-12 % faster that way (profiles/r04_walk_occupancy_ab.txt) and this "
-                                            "kernel's launches last 1.7x longer -- off the critical path, behind the round's delivery.  The same kernel at five "
-                                            "workgroups per CU: whole_job_hbm.walk and steady_state_hbm.walk in this line (live), 0.18 alone "
+                                            "kernel's launches last 1.4-1.7x longer -- off the critical path, behind the round's delivery.  The same kernel at five "
+                                            "workgroups per CU: whole_job_hbm.walk and steady_state_hbm.walk in this line (live), 0.21 alone "
                                             "(profiles/*_walk_solo.txt)") if deliver else None,
                          "note": "achieved = algorithmic bytes of the path (SURVEY 8d: 1 ref + 2 read + 2 quality... per base) of rank 0's "
                                  "delivered reads / summed duration of its walk launches (a launch = the lane walker + the wave walker of the batch's long reads beside it; HIP events on the walk streams, every launch of "
