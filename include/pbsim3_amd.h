@@ -244,7 +244,9 @@ int64_t pbsim_batch_capacity(pbsim_ctx *ctx);
 int pbsim_set_scratch_bytes(pbsim_ctx *ctx, int64_t bytes);
 /* A context sizes its pools for the jobs it runs and keeps them (re-allocating tens of GB stalls a job for seconds): one that
  * switches to another KIND of job -- output delivered through a sink, then left in HBM; another pass count -- should give the
- * old pools back first.  Releases the slots' scratch pools, text and compression buffers; nothing may be in flight. */
+ * old pools back first.  Releases the slots' scratch pools, text and compression buffers and the page-locked host blocks a
+ * several-rank job compresses into (those go back by themselves only after sixteen jobs that did not use them: giving a block
+ * back and page-locking it again cost tens of milliseconds each); nothing may be in flight. */
 int pbsim_release_pools(pbsim_ctx *ctx);
 
 /* ---- the whole job on one or several GPUs -------------------------------------

@@ -134,6 +134,7 @@ struct DfLane {
   std::vector<std::unique_ptr<HostBuf>> arena_blocks;
   std::vector<size_t> arena_fill;      // bytes handed out of each block since the last reset
   std::vector<char> arena_touched;     // block was used since the last trim (pbsim_job_run trims at its end)
+  std::vector<int> arena_idle;         // jobs in a row that did not use the block
   std::vector<std::pair<const char *, int64_t>> arena_segs;
   size_t arena_bytes() const {
     size_t n = 0;
@@ -165,31 +166,50 @@ struct DfLane {
     arena_blocks.emplace_back(new HostBuf);
     arena_fill.push_back(0);
     arena_touched.push_back(1);
+    arena_idle.push_back(0);
     if (arena_blocks.back()->ensure(want) != hipSuccess) {
       arena_blocks.pop_back();
       arena_fill.pop_back();
       arena_touched.pop_back();
+      arena_idle.pop_back();
       return nullptr;
     }
     arena_fill.back() = need;
     arena_segs.emplace_back((char *)arena_blocks.back()->p, n);
     return (char *)arena_blocks.back()->p;
   }
-  // end of a job: blocks no round of this job touched go back to the host (a context that once ran a large job does not
-  // keep its page-locked memory for ever)
+  // end of a job: blocks that no round of the last kArenaIdleJobs jobs touched go back to the host (a context that once ran a
+  // large job does not keep its page-locked memory for ever).  Not after ONE idle job (rounds 2-5 did that): which slots -- and
+  // how many blocks of a lane -- a job uses varies from job to job (its round count against the slot rotation; a rank that
+  // compresses a few MB more than the one before it), and a 256 MB block costs tens of milliseconds to give back and as much to
+  // page-lock again: a context that runs job after job (bench.py, the replay of one rank after the other) paid that again and
+  // again -- stalls of 25-95 ms in a job's first rounds and behind its last collective (profiles/r05z_replay_host_noise.txt).
+  static constexpr int kArenaIdleJobs = 16;
+  void arena_release() {
+    arena_blocks.clear();
+    arena_fill.clear();
+    arena_touched.clear();
+    arena_idle.clear();
+    arena_segs.clear();
+  }
   void arena_trim() {
     size_t k = 0;
+    for (size_t i = 0; i < arena_blocks.size(); i++) arena_idle[i] = arena_touched[i] ? 0 : arena_idle[i] + 1;
     if (getenv("PBSIM_TRACE")) {
       size_t drop = 0;
-      for (size_t i = 0; i < arena_blocks.size(); i++) drop += arena_touched[i] ? 0 : 1;
+      for (size_t i = 0; i < arena_blocks.size(); i++) drop += arena_idle[i] >= kArenaIdleJobs ? 1 : 0;
       if (drop) fprintf(stderr, "[pbsim arena] trim: %zu of %zu blocks go back\n", drop, arena_blocks.size());
     }
     for (size_t i = 0; i < arena_blocks.size(); i++)
-      if (arena_touched[i]) {
-        if (k != i) arena_blocks[k] = std::move(arena_blocks[i]);
+      if (arena_idle[i] < kArenaIdleJobs) {
+        if (k != i) {
+          arena_blocks[k] = std::move(arena_blocks[i]);
+          arena_idle[k] = arena_idle[i];
+        }
         k++;
       }
     arena_blocks.resize(k);
+    arena_idle.resize(k);
     arena_fill.assign(k, 0);
     arena_touched.assign(k, 0);
     arena_segs.clear();

@@ -376,8 +376,10 @@ int pbsim_release_pools(pbsim_ctx *c) {
     sl.d_scratch.release();
     sl.d_read_text.release();
     sl.d_maf_text.release();
-    for (DfLane &L : sl.df)
+    for (DfLane &L : sl.df) {
       for (DevBuf &b : L.d_df_dense) b.release();
+      L.arena_release();  // the page-locked blocks of several-rank jobs (their automatic trim waits for sixteen idle jobs)
+    }
     sl.b_walked = sl.b_finalized = false;
   }
   {
