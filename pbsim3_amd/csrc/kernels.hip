@@ -949,7 +949,7 @@ struct RefStream {
 
   // the four bases the group can consume, from stream position sp on: byte 0 first
   __device__ __forceinline__ void begin_group(int sp) {
-    const uint32_t ca = (uint32_t)sp;  // the group starts in word wc (refill keeps it so)
+    const uint32_t ca = (uint32_t)sp;  // the group starts in word wc (advance() keeps it so)
     const bool upper = (ca & 4u) != 0;
     n2 = lo_of(rn);
     g = __builtin_amdgcn_alignbit(upper ? n2 : s1, upper ? s1 : s0, ca << 3);  // v_alignbit_b32 shifts by the low 5 bits: (ca & 3) * 8
