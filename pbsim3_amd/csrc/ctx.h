@@ -148,7 +148,9 @@ struct DfLane {
   // First fit over the blocks (a block too small for one piece still takes the next smaller one); a new block only when no
   // block has room, and never beyond `max_bytes` of pinned memory for this lane (0: no bound).
   char *arena_reserve(int64_t n, size_t max_bytes) {
-    const size_t kBlock = 256u << 20;
+    // (PBSIM_PINNED_BLOCK_KB: test hook -- small blocks, so that a test's few hundred KB per round spread over several)
+    static const size_t kBlock = getenv("PBSIM_PINNED_BLOCK_KB") && atoll(getenv("PBSIM_PINNED_BLOCK_KB")) > 0
+                                     ? (size_t)atoll(getenv("PBSIM_PINNED_BLOCK_KB")) << 10 : (size_t)256u << 20;
     const size_t need = ((size_t)n + 63) & ~(size_t)63;
     for (size_t i = 0; i < arena_blocks.size(); i++) {
       HostBuf &b = *arena_blocks[i];
@@ -184,7 +186,10 @@ struct DfLane {
   // compresses a few MB more than the one before it), and a 256 MB block costs tens of milliseconds to give back and as much to
   // page-lock again: a context that runs job after job (bench.py, the replay of one rank after the other) paid that again and
   // again -- stalls of 25-95 ms in a job's first rounds and behind its last collective (profiles/r05z_replay_host_noise.txt).
-  static constexpr int kArenaIdleJobs = 16;
+#ifndef PBSIM_ARENA_IDLE_JOBS
+#define PBSIM_ARENA_IDLE_JOBS 16   // (-DPBSIM_ARENA_IDLE_JOBS=1: the behaviour of rounds 2-5, for an A/B)
+#endif
+  static constexpr int kArenaIdleJobs = PBSIM_ARENA_IDLE_JOBS;
   void arena_release() {
     arena_blocks.clear();
     arena_fill.clear();

@@ -73,3 +73,46 @@ def test_replayed_ranks_tile_the_one_gpu_output(method, world, target, monkeypat
                     assert start == pos, (method, world, k, w, start, pos)
                     pos += n
                 assert pos == len(text), (method, world, k, w)
+
+
+def test_arena_blocks_stay_from_job_to_job(monkeypatch, capfd):
+    """The page-locked blocks a rank of a several-rank job compresses its rounds into stay with the context from job to job
+    (ctx.h DfLane::arena_trim: a block goes back after sixteen idle jobs, not after one).  Rounds 2-5 gave every untouched block
+    back at the end of every job: which slots and how many blocks a job touches varies from job to job, and giving a 256 MB
+    block back and page-locking it again cost tens of milliseconds each -- replayed ranks 25-95 ms behind the others
+    (profiles/r05z_replay_arena_churn.txt).  Here: four ranks replayed one after the other, jobs with large rounds and jobs with
+    small rounds in turn, three passes; every block is allocated in the first pass, none goes back.  (A guard, not a reproduction:
+    at test size a round is one piece per lane, and the churn needed the several 83 MB pieces per round of a full-size job.)"""
+    import ctypes as C
+    import torch
+    import pbsim3_amd as P
+    import replay_ranks as RR
+    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=5, depth=6.0, len_mean=1500.0, len_sd=1100.0)
+    G, world = 1_500_000, 4
+    monkeypatch.setenv("PBSIM_JOB_TARGET_RANKS", "200000")
+    monkeypatch.setenv("PBSIM_PINNED_BLOCK_KB", "64")      # (test hook: a round's ~200 KB of members take several blocks, as 256 MB
+    recs = [torch.frombuffer(bytearray(genome(G, 10 + i)), dtype=torch.uint8).cuda() for i in range(2)]   # blocks do at full size)
+    tables = RR.build_tables(P, harness, p, "ERRHMM-ONT.model", False, recs, G, 0)
+    with P.Context(p, 0) as ctx:
+        ctx.set_scratch_bytes(256 << 20)
+        ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
+        ctx.set_deflate(7)
+        for t in recs:
+            ctx.job_add_record_device(t.data_ptr(), G)
+        cbs = (P.REC_TEXT_CB(lambda u, rec, t, n, o: 1), P.REC_TEXT_CB(lambda u, rec, t, n, o: 1), P.REC_DONE_CB(lambda u, rec, st, rb, mb: 1))
+        sink = P.RecordSink(None, *cbs)
+        monkeypatch.setenv("PBSIM_TRACE", "1")
+        new_blocks = []
+        for _ in range(3):
+            capfd.readouterr()
+            for target in ("400000", "100000"):          # jobs with large rounds, then jobs with small ones: the small ones leave
+                monkeypatch.setenv("PBSIM_JOB_TARGET_RANKS", target)      # most blocks of a lane untouched
+                for r in range(world):
+                    vr = RR.VirtualRanks(P, ctx, r, world, tables)
+                    ok = ctx.lib.pbsim_job_run(ctx.h, C.byref(vr.comm), C.byref(sink))
+                    assert vr.error is None, vr.error
+                    P._check(ok)
+            err = capfd.readouterr().err
+            assert "[pbsim arena] trim" not in err
+            new_blocks.append(err.count("[pbsim arena] new block"))
+        assert new_blocks[0] >= 2 and new_blocks[1:] == [0, 0], new_blocks
