@@ -399,6 +399,26 @@ int64_t pbsim_format_stats(const pbsim_params *p, const pbsim_stats *s, int64_t 
  * (torch.distributed).  Returns the process exit status (0, or 255 like the reference's exit(-1)). */
 int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int device);
 
+/* ---- RCCL communicator of a one-process-per-GPU launch ------------------------------
+ * `pbsim --devices` runs its ranks as threads of one process (ncclCommInitAll or a host barrier).  A launcher that starts one
+ * PROCESS per GPU (torchrun, mpirun, a shell loop) gets its pbsim_comm here: rank 0 makes the id (ncclGetUniqueId, 128 bytes),
+ * the launcher's side channel carries it to the others, every rank enters pbsim_rccl_comm_create with it (ncclCommInitRank:
+ * collective over the `world` ranks, one distinct GPU each).  The communicator's callbacks run ncclAllGather (C3),
+ * ncclAllReduce (C2) and ncclBroadcast (C1) on a stream of their own, small messages through page-locked staging, every wait
+ * polled with a watchdog (PBSIM_COMM_TIMEOUT_S) -- what SURVEY 8(e) names; the reference has no analogue (one process, libc
+ * only, pbsim.cpp:4-14).  librccl is opened at run time.
+ * pbsim_rccl_unique_id: writes the id (returns its size; with id == NULL or cap too small only the size), 0 on failure.
+ * pbsim_rccl_comm_create_file: the same with a file as the side channel -- rank 0 publishes the id at `path` (written whole,
+ * then renamed), the others wait for it (PBSIM_RENDEZVOUS_TIMEOUT_S, default 120); the caller removes the file afterwards.
+ * pbsim_rccl_comm_info: [0] the ranks RCCL itself counts in the communicator (ncclCommCount), [1] this rank's number there,
+ * [2] the device, [3] collectives issued so far.  NULL / PBSIM_FAILED + pbsim_last_error() on failure. */
+#define PBSIM_RCCL_ID_BYTES 128
+int64_t pbsim_rccl_unique_id(void *id, int64_t cap);
+pbsim_comm *pbsim_rccl_comm_create(const void *id, int64_t id_bytes, int32_t rank, int32_t world, int32_t device);
+pbsim_comm *pbsim_rccl_comm_create_file(const char *path, int32_t rank, int32_t world, int32_t device);
+int pbsim_rccl_comm_info(const pbsim_comm *comm, int64_t out[4]);
+void pbsim_rccl_comm_destroy(pbsim_comm *comm);
+
 /* ---- host placement of a rank ----------------------------------------------------------
  * The reference is one thread on one socket; a rank here is a thread that feeds one GPU and receives its output over PCIe.
  * Binds the calling thread -- and the threads and page-locked buffers it creates afterwards -- to the CPUs and the memory of

@@ -97,6 +97,11 @@ API = [
     ("pbsim_batch_fetch_lengths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pbsim_job_breakdown", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_bind_host_to_device", C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
+    ("pbsim_rccl_unique_id", C.c_int64, [C.c_void_p, C.c_int64]),
+    ("pbsim_rccl_comm_create", C.POINTER(Comm), [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    ("pbsim_rccl_comm_create_file", C.POINTER(Comm), [C.c_char_p, C.c_int32, C.c_int32, C.c_int32]),
+    ("pbsim_rccl_comm_info", C.c_int, [C.POINTER(Comm), C.POINTER(C.c_int64)]),
+    ("pbsim_rccl_comm_destroy", None, [C.POINTER(Comm)]),
     ("pbsim_stats_keep_values", C.c_int, [C.c_void_p, C.c_int]),
     ("pbsim_stats_merge", C.c_int, [C.c_void_p, C.POINTER(Comm)]),
     ("pbsim_stats_add_tasks", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -322,6 +327,87 @@ def torch_comm(dist, device):
     return make_comm(rank, world, all_gather, all_reduce, None, abort)
 
 
+RCCL_ID_BYTES = 128
+
+
+class RcclComm:
+    """pbsim_comm over RCCL for ONE PROCESS PER GPU (pbsim_rccl_comm_create = ncclCommInitRank): the communicator bench.py
+    --gpus N and run_multi use by default.  `exchange(id_or_None) -> id`: the launcher's side channel -- rank 0 passes the id it
+    made and every rank gets it back (torch's store: RcclComm.from_torch; a rendezvous file: RcclComm.from_file).
+    .ref is what pbsim_job_run / pbsim_cli_main take (C.byref of the library's own struct); .comm the struct itself."""
+
+    def __init__(self, ptr):
+        if not ptr:
+            raise PbsimError(load().pbsim_last_error().decode(errors="replace"))
+        self.ptr = ptr
+        self.comm = ptr.contents
+        self.ref = ptr
+
+    @classmethod
+    def create(cls, rank, world, device, exchange):
+        lib = load()
+        ident = None
+        if rank == 0:
+            buf = C.create_string_buffer(RCCL_ID_BYTES)
+            if lib.pbsim_rccl_unique_id(buf, RCCL_ID_BYTES) != RCCL_ID_BYTES:
+                # the others wait in `exchange`: tell them (an empty id) before raising
+                exchange(b"")
+                raise PbsimError(lib.pbsim_last_error().decode(errors="replace"))
+            ident = buf.raw
+        ident = exchange(ident)
+        if len(ident) != RCCL_ID_BYTES:
+            raise PbsimError("rank 0 could not make an RCCL id")
+        return cls(lib.pbsim_rccl_comm_create(ident, len(ident), rank, world, device))
+
+    @classmethod
+    def from_torch(cls, dist, device, key="pbsim_rccl_id"):
+        """the id through torch.distributed's key-value store (TCP, the rendezvous torchrun already made)"""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        store = dist.distributed_c10d._get_default_store()
+
+        def exchange(ident):
+            if rank == 0:
+                store.set(key, ident)
+                return ident
+            return bytes(store.get(key))     # blocks until rank 0 has set it
+        return cls.create(rank, world, device, exchange)
+
+    @classmethod
+    def from_file(cls, path, rank, world, device):
+        return cls(load().pbsim_rccl_comm_create_file(os.fsencode(path), rank, world, device))
+
+    def info(self):
+        out = (C.c_int64 * 4)()
+        _check(load().pbsim_rccl_comm_info(self.ptr, out))
+        return {"ranks_seen": out[0], "rank": out[1], "device": out[2], "collectives": out[3]}
+
+    def close(self):
+        if self.ptr:
+            load().pbsim_rccl_comm_destroy(self.ptr)
+            self.ptr = self.ref = None
+
+
+def comm_latency(comm_ref, n_words=8, iters=1000, warm=50):
+    """microseconds per all_gather_i64 / all_reduce_i64 of `n_words` through the function pointers of a pbsim_comm exactly as
+    job.cpp calls them (blocking, one after the other); comm_ref: C.byref(Comm) or a POINTER(Comm).  Collective: every rank
+    of the communicator calls it with the same arguments."""
+    import time
+    cm = comm_ref.contents if hasattr(comm_ref, "contents") else comm_ref._obj
+    send = (C.c_int64 * n_words)(*range(n_words))
+    recv = (C.c_int64 * (n_words * cm.world))()
+    res = {"world": cm.world, "words": n_words, "iters": iters}
+    for name, call in (("all_gather_us", lambda: cm.all_gather_i64(cm.user, send, n_words, recv)),
+                       ("all_reduce_us", lambda: cm.all_reduce_i64(cm.user, send, n_words, OP_MAX))):
+        for _ in range(warm):
+            if not call():
+                raise PbsimError("comm_latency: the collective failed")
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            call()
+        res[name] = (time.perf_counter() - t0) / iters * 1e6
+    return res
+
+
 def bind_host_to_device(device):
     """Binds the calling thread (and the threads and pinned allocations it creates from now on) to the CPUs and the memory of
     the NUMA node `device`'s PCIe slot hangs off; call before the first HIP call of the process.  Returns a description of what
@@ -335,7 +421,8 @@ def cli_main(argv, comm=None, device=-1):
     """pbsim_cli_main: the whole command line for this rank (argv without the program name)."""
     args = [b"pbsim"] + [os.fsencode(a) for a in argv]
     arr = (C.c_char_p * (len(args) + 1))(*args, None)
-    return load().pbsim_cli_main(len(args), arr, C.byref(comm) if comm is not None else None, device)
+    ref = None if comm is None else (C.byref(comm) if isinstance(comm, Comm) else comm)   # a Comm, or a POINTER(Comm) (RcclComm.ref)
+    return load().pbsim_cli_main(len(args), arr, ref, device)
 
 
 class Context:

@@ -15,7 +15,7 @@ CLI = os.path.join(BIN_DIR, "pbsim")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["kernels.hip", "deflate.hip", "engine.cpp", "deflate_host.cpp", "units.cpp", "sample.cpp", "job.cpp"]
+HIP_SOURCES = ["kernels.hip", "deflate.hip", "engine.cpp", "deflate_host.cpp", "units.cpp", "sample.cpp", "job.cpp", "rccl_capi.cpp"]
 CXX_SOURCES = ["host_tables.cpp", "unit_io.cpp", "stats.cpp", "cli.cpp", "gzout.cpp", "numa_bind.cpp"]
 CLI_SOURCES = ["main.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("PBSIM_EXTRA_CFLAGS", "").split()
@@ -67,7 +67,7 @@ def build(force=False, verbose=False):
                     print(" ".join(cmd))
                 subprocess.run(cmd, check=True)
                 os.replace(obj + ".tmp", obj)
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", LIB + ".tmp"] + objs + ["-lz", "-lpthread"]
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-o", LIB + ".tmp"] + objs + ["-lz", "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -191,6 +191,7 @@ struct Job {
   const pbsim_comm *comm;
   const pbsim_record_sink *sink;
   int rank = 0, W = 1;
+  bool multi = false;  // the several-rank protocol is on: W > 1, or a communicator of one under PBSIM_COMM_ALWAYS (pbsim_job_run)
   std::vector<Rec> recs;
   std::deque<Round> fifo;
   double mean = 0;
@@ -337,7 +338,7 @@ struct Job {
   }
   int gather(const int64_t *send, int64_t n, std::vector<int64_t> *recv) {
     recv->assign((size_t)W * n, 0);
-    if (W == 1) {
+    if (!multi) {
       memcpy(recv->data(), send, (size_t)n * 8);
       return PBSIM_SUCCEEDED;
     }
@@ -559,7 +560,7 @@ struct Job {
         ok = fetch_plain(*sl);
         sizes[0] = sink->on_read_text ? sl->b_info.read_text_bytes : 0;
         sizes[1] = sink->on_maf_text ? sl->b_info.maf_text_bytes : 0;
-      } else if (W == 1) {
+      } else if (!multi) {
         ok = stream_deflated(*sl, R->ref.unit, read_at, maf_at, &sizes[0], &sizes[1]);
       } else {
         ok = arena_fill(*sl, &sizes[0], &sizes[1]);
@@ -631,7 +632,7 @@ struct Job {
       Slot *sl = &c->slots[d->slot];
       Rec *Rp = &R;
       const int slot = d->slot;
-      const bool flush = deflated() && W > 1, plain = wants_text() && !deflated();
+      const bool flush = deflated() && multi, plain = wants_text() && !deflated();
       // The per-task statistics are accounted HERE, on the main loop (it waits for the link most of the time), not on the
       // worker, whose time is the link's: rounds are completed in the order of the reads, so accuracy_total keeps its order.
       acct_slot = sl;
@@ -822,7 +823,7 @@ struct Job {
     int64_t extra[3] = {R.tail_read, R.tail_maf, (tail_ok && !wfailed) ? 0 : 1};
     const double t0 = now_us();
     progress(4, rec);
-    if (!stats_merge(&R.st, c->p, W > 1 ? comm : nullptr, extra, 3)) return PBSIM_FAILED;
+    if (!stats_merge(&R.st, c->p, multi ? comm : nullptr, extra, 3)) return PBSIM_FAILED;
     bd_merge += now_us() - t0;
     if (!tail_ok) return fail(tail_err);
     if (!check_worker()) return PBSIM_FAILED;
@@ -892,7 +893,7 @@ struct Job {
   int prelaunch(const pbsim_batch_info &bi) {
     static const bool on = exp_env("PBSIM_DEFLATE_PRELAUNCH") && atoi(exp_env("PBSIM_DEFLATE_PRELAUNCH")) == 1;
     if (!on || !deflated() || bi.n_final <= 0) return PBSIM_SUCCEEDED;
-    return deflate_prelaunch(c, c->s(), sink->on_read_text != nullptr, sink->on_maf_text != nullptr, W == 1);
+    return deflate_prelaunch(c, c->s(), sink->on_read_text != nullptr, sink->on_maf_text != nullptr, !multi);
   }
 
   // One round comes back.  Two shapes, chosen when the round was begun (Round::clear, the same on every rank):
@@ -1439,6 +1440,12 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   J.sink = (sink && (sink->on_read_text || sink->on_maf_text || sink->on_record_done)) ? sink : nullptr;
   J.W = comm ? comm->world : 1;
   J.rank = comm ? comm->rank : 0;
+  // A communicator of ONE rank has nobody to exchange with and its collectives are skipped -- unless PBSIM_COMM_ALWAYS=1
+  // (test hook): the job then runs the several-rank protocol, every exchange included, through the communicator of one.  That
+  // is how a single-GPU box drives pbsim_job_run through real RCCL calls (tests/test_gpu_rccl_native.py) and measures what
+  // the exchanges cost a job on the path `bench.py --gpus N` takes (bench.py comm_latency.job_through_rccl).
+  J.multi = J.W > 1 || (comm && comm->all_gather_i64 && comm->all_reduce_i64 && getenv("PBSIM_COMM_ALWAYS") &&
+                        atoi(getenv("PBSIM_COMM_ALWAYS")) != 0);
   J.trace = getenv("PBSIM_TRACE") != nullptr;
   J.t_start = now_us();
   const char *jd = exp_env("PBSIM_JOB_DEPTH");
@@ -1447,6 +1454,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // them (80 ms a round against 18 ms of walk): one round in flight is as fast (1334 vs 1336 ms), its walk does not share the
   // GPU with two others (18.5 instead of 29.3 ms a launch) and half the slots stay unallocated.
   const int W = J.W;
+  const bool multi = J.multi;
   const bool delivers = J.sink && (J.sink->on_read_text || J.sink->on_maf_text);
   {
     const char *il = getenv("PBSIM_JOB_INTERLEAVE");
@@ -1471,7 +1479,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     R.ref.len = lens[i];
     R.ref.unit = c->job_first_unit + (int64_t)i;
     R.quota = quota_of(c, lens[i]);
-    R.st.keep_values = W > 1;
+    R.st.keep_values = multi;
     max_quota = std::max(max_quota, R.quota);
   }
   // ---- the records' preparation (upload + k_hp_*) has been running since pbsim_job_add_record.  A job whose records are all
@@ -1541,7 +1549,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   // per record, 208-215 at two (one: 211; the split, the wave walker's workgroups and the ramp-up rounds move nothing there): a
   // round of 850 000 reads amortises its longest lanes better and the wave walker's share of the GPU time drops.  A job that
   // delivers its text is bound by its link either way: 54.2 / 53.6 / 54.6 Gbases/s at two / three / four, it keeps four.)
-  const int rounds_per_record = std::max(1, jr ? atoi(jr) : (delivers_text ? (W > 1 ? 2 : kRoundsPerRecord) : 2));
+  const int rounds_per_record = std::max(1, jr ? atoi(jr) : (delivers_text ? (multi ? 2 : kRoundsPerRecord) : 2));
   double target = (double)max_quota * P / ((double)rounds_per_record * W);
   target = std::max(target, std::min(kMinBatchBases, (double)max_quota * P / W));
   if (J.sink && (J.sink->on_read_text || J.sink->on_maf_text)) target = std::min(target, kSinkBatchBases);
@@ -1595,7 +1603,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   std::vector<int64_t> agree(n + 1);
   agree[0] = c->scratch_budget;
   J.progress(5, -1);
-  if (W > 1) {
+  if (multi) {
     if (!comm->all_reduce_i64(comm->user, agree.data(), 1, PBSIM_OP_MIN)) return fail("pbsim_comm.all_reduce_i64 failed");
     c->scratch_budget = agree[0];
   }
@@ -1606,7 +1614,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     R.cap = std::max<int64_t>(1, std::min<int64_t>(batch_capacity_for(c, R.ref.len), (int64_t)(1.08 * target / P / m) + 64));
     agree[i + 1] = R.cap;
   }
-  if (W > 1) {
+  if (multi) {
     if (!comm->all_reduce_i64(comm->user, agree.data(), (int64_t)agree.size(), PBSIM_OP_MIN)) return fail("pbsim_comm.all_reduce_i64 failed");
     for (size_t i = 0; i < n; i++) J.recs[i].cap = agree[i + 1];
   }
@@ -1618,7 +1626,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   }
   // (several ranks: a failure in front of the first collective of the round loop is agreed on first, like every later one)
   int ready = (!J.deflated() || ensure_deflate_ready(c)) ? PBSIM_SUCCEEDED : PBSIM_FAILED;  // before the worker and its lane threads use the tables
-  if (W > 1) {
+  if (multi) {
     const std::string keep = g_err;
     int64_t bad = ready ? 0 : 1;
     if (!comm->all_reduce_i64(comm->user, &bad, 1, PBSIM_OP_MAX)) return fail("pbsim_comm.all_reduce_i64 failed");
@@ -1654,7 +1662,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
     // A failure that only this rank knows of (not one that came in through a collective's status word) would leave the other
     // ranks waiting in their next collective: the communicator's abort, when it has one, releases them.  Without it the caller
     // must tear the process group down (include/pbsim3_amd.h).
-    if (W > 1 && !J.peer_failed && comm->abort) comm->abort(comm->user);
+    if (multi && !J.peer_failed && comm->abort) comm->abort(comm->user);
     *settled = true;
     J.drop_everything();
     J.worker.finish();

@@ -4,6 +4,10 @@
 //                                     several contexts on one device, the plumbing check of a single-GPU box);
 //                                     --comm host (default): host barrier + GPU-to-GPU peer copies (thread_comm.h)
 //                                     --comm rccl: RCCL communicator over xGMI for C1 / C2 / C3 (rccl_comm.h; distinct GPUs)
+//   pbsim ... --rank R --world N --rendezvous FILE [--device D]
+//                                     one PROCESS per GPU (started N times by a shell loop, mpirun, srun ..): the ranks meet in an
+//                                     RCCL communicator made with ncclCommInitRank, rank 0's id published through FILE
+//                                     (pbsim_rccl_comm_create_file); device D defaults to R
 // Every rank runs the same pbsim_cli_main(argv): the job is deterministic in the values the ranks exchange, so they stay
 // in lockstep; rank 0 prints the report and creates the files, every rank writes its own byte ranges.
 #include <hip/hip_runtime.h>
@@ -23,6 +27,8 @@
 int main(int argc, char **argv) {
   std::vector<int> devices;
   std::string comm_kind = "host";
+  int proc_rank = -1, proc_world = 0, proc_device = -1;  // --rank / --world / --device: this process is ONE rank of several
+  std::string rendezvous;
   bool selftest = false;  // --comm-selftest: run C1 / C2 / C3 once on the communicator of --devices / --comm and check the values
   for (int i = 1; i < argc; i++) {
     const char *a = argv[i];
@@ -49,6 +55,51 @@ int main(int argc, char **argv) {
     if (!strncmp(a, "--comm=", 7)) comm_kind = a + 7;
     else if (!strcmp(a, "--comm") && i + 1 < argc) comm_kind = argv[i + 1];
     if (!strcmp(a, "--comm-selftest")) selftest = true;
+    if (!strcmp(a, "--rank") && i + 1 < argc) proc_rank = atoi(argv[i + 1]);
+    if (!strcmp(a, "--world") && i + 1 < argc) proc_world = atoi(argv[i + 1]);
+    if (!strcmp(a, "--rendezvous") && i + 1 < argc) rendezvous = argv[i + 1];
+    if (!strcmp(a, "--device") && i + 1 < argc) proc_device = atoi(argv[i + 1]);
+  }
+  if (proc_world > 0 || proc_rank >= 0 || !rendezvous.empty()) {
+    if (proc_world < 1 || proc_rank < 0 || proc_rank >= proc_world || rendezvous.empty() || !devices.empty()) {
+      fprintf(stderr, "ERROR: one process per GPU takes --rank R --world N --rendezvous FILE (0 <= R < N) and no --devices.\n");
+      return 255;
+    }
+    if (proc_device < 0) proc_device = proc_rank;
+    char what[256];
+    pbsim_bind_host_to_device(proc_device, what, sizeof(what));  // before the first HIP call of the process
+    pbsim_comm *cm = pbsim_rccl_comm_create_file(rendezvous.c_str(), proc_rank, proc_world, proc_device);
+    if (!cm) {
+      fprintf(stderr, "ERROR: %s\n", pbsim_last_error());
+      return 255;
+    }
+    // the launcher's own options go no further than this file: pbsim_cli_main sees the reference's command line
+    std::vector<char *> args;
+    for (int i = 0; i < argc; i++) {
+      if (!strcmp(argv[i], "--rank") || !strcmp(argv[i], "--world") || !strcmp(argv[i], "--rendezvous") || !strcmp(argv[i], "--device")) {
+        i++;
+        continue;
+      }
+      args.push_back(argv[i]);
+    }
+    args.push_back(NULL);
+    int rc;
+    if (selftest) {
+      int64_t send[3] = {proc_rank, 10 * proc_rank, -proc_rank}, red[2] = {proc_rank, 1};
+      std::vector<int64_t> recv((size_t)proc_world * 3, 77);
+      rc = cm->all_gather_i64(cm->user, send, 3, recv.data()) && cm->all_reduce_i64(cm->user, red, 2, PBSIM_OP_SUM) ? 0 : 255;
+      for (int q = 0; q < proc_world && !rc; q++)
+        if (recv[(size_t)q * 3] != q || recv[(size_t)q * 3 + 1] != 10 * q || recv[(size_t)q * 3 + 2] != -q) rc = 255;
+      if (red[0] != (int64_t)proc_world * (proc_world - 1) / 2 || red[1] != proc_world) rc = 255;
+      int64_t info[4] = {0, 0, 0, 0};
+      pbsim_rccl_comm_info(cm, info);
+      fprintf(stderr, "comm selftest (rccl, rank %d of %d processes, RCCL counts %lld): %s\n", proc_rank, proc_world, (long long)info[0],
+              rc ? "FAILED" : "ok");
+    } else {
+      rc = pbsim_cli_main((int)args.size() - 1, args.data(), cm, proc_device) & 255;
+    }
+    pbsim_rccl_comm_destroy(cm);
+    return rc;
   }
   if (comm_kind != "host" && comm_kind != "rccl") {
     fprintf(stderr, "ERROR (comm: %s): host or rccl.\n", comm_kind.c_str());

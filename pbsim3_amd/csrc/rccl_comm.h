@@ -1,8 +1,11 @@
-// rccl_comm.h -- pbsim_comm over RCCL (xGMI) for the ranks of one process, one host thread per GPU: ncclBroadcast carries
-// a record from the loading rank's GPU to all others (C1), ncclAllGather the per-round integers (C3), ncclAllReduce the
-// statistics (C2) -- the three collectives SURVEY 8(e) names.  librccl is opened at run time (dlopen), so the binary has no
-// link-time dependency on it and a box without it still runs --comm host.  RCCL refuses two ranks on one device: distinct
-// GPUs only (a single-GPU box can run --devices 0 --comm rccl, a communicator of one).
+// rccl_comm.h -- pbsim_comm over RCCL (xGMI): ncclBroadcast carries a record from the loading rank's GPU to all others
+// (C1), ncclAllGather the per-round integers (C3), ncclAllReduce the statistics (C2) -- the three collectives SURVEY 8(e)
+// names.  Two ways to a communicator: the ranks of ONE process, one host thread per GPU (rccl_init_all = ncclCommInitAll;
+// `pbsim --devices`), and ONE PROCESS PER GPU (rccl_init_rank = ncclGetUniqueId on rank 0 + ncclCommInitRank on every rank;
+// the id travels through whatever the launcher offers -- torch's store, a rendezvous file: pbsim_rccl_* in rccl_capi.cpp;
+// `bench.py --gpus N`, run_multi, `pbsim --rank R --world N --rendezvous FILE`).  librccl is opened at run time (dlopen), so
+// the binary has no link-time dependency on it and a box without it still runs --comm host.  RCCL refuses two ranks on one
+// device: distinct GPUs only (a single-GPU box can run a communicator of one).
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -27,6 +30,10 @@ namespace pbsim {
 struct RcclApi {
   void *lib = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;     // optional
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;  // optional
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -49,6 +56,8 @@ struct RcclApi {
     return false;                                                 \
   }
     PBSIM_RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    PBSIM_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+    PBSIM_RCCL_SYM(CommInitRank, "ncclCommInitRank")
     PBSIM_RCCL_SYM(CommDestroy, "ncclCommDestroy")
     PBSIM_RCCL_SYM(Broadcast, "ncclBroadcast")
     PBSIM_RCCL_SYM(AllReduce, "ncclAllReduce")
@@ -56,6 +65,8 @@ struct RcclApi {
     PBSIM_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef PBSIM_RCCL_SYM
     CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
+    CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
     return true;
   }
 };
@@ -77,6 +88,7 @@ struct RcclRank {
   // histograms and accuracy values) go from the caller's buffers as before.
   static constexpr size_t kPinned = 256 << 10;
   void *h_send = nullptr, *h_recv = nullptr;
+  int64_t collectives = 0;  // issued through this rank since the communicator was made (pbsim_rccl_comm_info)
   bool pinned_for(size_t bytes_send, size_t bytes_recv) {
     if (bytes_send > kPinned || bytes_recv > kPinned) return false;
     if (h_send) return true;
@@ -160,6 +172,7 @@ inline int rccl_all_gather(void *user, const int64_t *send, int64_t n, int64_t *
   if (hipMemcpyAsync(pin ? r->h_recv : recv, r->d_recv, br, hipMemcpyDeviceToHost, r->stream) != hipSuccess) return 0;
   if (!rccl_wait(r, "all-gather")) return 0;
   if (pin) memcpy(recv, r->h_recv, br);
+  r->collectives++;
   return 1;
 }
 
@@ -177,6 +190,7 @@ inline int rccl_all_reduce(void *user, int64_t *buf, int64_t n, int32_t op) {
   if (hipMemcpyAsync(pin ? r->h_recv : buf, r->d_recv, bs, hipMemcpyDeviceToHost, r->stream) != hipSuccess) return 0;
   if (!rccl_wait(r, "all-reduce")) return 0;
   if (pin) memcpy(buf, r->h_recv, bs);
+  r->collectives++;
   return 1;
 }
 
@@ -193,6 +207,7 @@ inline int rccl_broadcast(void *user, void *p, int64_t bytes, int32_t root, int3
   }
   if (r->api->Broadcast(d, d, (size_t)bytes, ncclUint8, root, r->comm, r->stream) != ncclSuccess) return 0;  // C1
   if (!on_device && r->rank != root && hipMemcpyAsync(p, d, (size_t)bytes, hipMemcpyDeviceToHost, r->stream) != hipSuccess) return 0;
+  r->collectives++;
   return rccl_wait(r, "broadcast");
 }
 
@@ -227,6 +242,46 @@ inline bool rccl_init_all(const std::vector<int> &devices, std::vector<RcclRank>
     r.world = (int)devices.size();
     r.device = devices[i];
   }
+  return true;
+}
+
+// One process per GPU.  Rank 0 makes the id (ncclGetUniqueId: 128 bytes, opens the bootstrap socket the others connect to),
+// the launcher's side channel carries it to every rank, and every rank -- rank 0 included -- enters ncclCommInitRank with it:
+// that call is itself collective over the `world` ranks.
+inline bool rccl_unique_id(ncclUniqueId *id, std::string *err) {
+  RcclApi &api = rccl_api();
+  if (!api.lib && !api.load(err)) return false;
+  const ncclResult_t rc = api.GetUniqueId(id);
+  if (rc != ncclSuccess) {
+    *err = std::string("ncclGetUniqueId: ") + api.GetErrorString(rc);
+    return false;
+  }
+  return true;
+}
+
+inline bool rccl_init_rank(const ncclUniqueId &id, int rank, int world, int device, RcclRank *r, std::string *err) {
+  RcclApi &api = rccl_api();
+  if (!api.lib && !api.load(err)) return false;
+  if (rank < 0 || world < 1 || rank >= world) {
+    *err = "rank / world out of range";
+    return false;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    *err = "hipSetDevice(" + std::to_string(device) + ") failed";
+    return false;
+  }
+  ncclComm_t comm = nullptr;
+  const ncclResult_t rc = api.CommInitRank(&comm, world, id, rank);
+  if (rc != ncclSuccess) {
+    *err = std::string("ncclCommInitRank: ") + api.GetErrorString(rc);
+    return false;
+  }
+  r->api = &api;
+  r->aborted = std::make_shared<std::atomic<bool>>(false);  // per process: an abort ends this rank's waits; the others see
+  r->comm = comm;                                            // their collectives fail or time out (rccl_wait)
+  r->rank = rank;
+  r->world = world;
+  r->device = device;
   return true;
 }
 
