@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -637,11 +638,16 @@ struct Job {
       // worker, whose time is the link's: rounds are completed in the order of the reads, so accuracy_total keeps its order.
       acct_slot = sl;
       acct_rec = &R;
-      if (!defer_account && !account_deferred()) return PBSIM_FAILED;
+      // (the round's delivery is counted as outstanding BEFORE its accounting can close the record's last round: a chain of
+      // the same record parked on the tail worker must not find rounds_open == 0 and bulk == 0 in between and hand its tail
+      // bytes to a front-to-back sink ahead of this round's)
+      std::atomic<int> *out = &rec_out[(size_t)d->rec], *bulk = &rec_bulk[(size_t)d->rec];
       if (flush || plain) {
-        std::atomic<int> *out = &rec_out[(size_t)d->rec], *bulk = &rec_bulk[(size_t)d->rec];
         ++*out;
         ++*bulk;
+      }
+      if (!defer_account && !account_deferred()) return PBSIM_FAILED;
+      if (flush || plain) {
         worker.post([this, sl, Rp, slot, flush, read_at, maf_at, out, bulk]() {
           const int ok = flush ? arena_flush(*sl, Rp->ref.unit, read_at, maf_at) : sink_plain(*sl, Rp->ref.unit, read_at, maf_at);
           if (!ok) worker_fail();
@@ -703,9 +709,14 @@ struct Job {
             if ((int)o != rec && recs[o].tail_slot >= 0 && !tail_poll((int)o, true)) return PBSIM_FAILED;
           // (not a drain of the chains' worker: the hand-over of the chain whose record's last sizes are still pending waits for
           // an exchange that only this thread can make -- but that is one record at most, the other slot's chain comes through)
-          while (free_tail_slot() < 0 && !wfailed) {
+          // (bounded: two chains of ONE record whose last round is still pending would hold both slots, and their hand-over
+          // needs an exchange only this thread can make -- a record that takes more than one chain of truncated reads at its
+          // merge; rather an error than a silent spin)
+          const double t_wait = now_us();
+          while (free_tail_slot() < 0 && !wfailed && !giving_up) {
             std::unique_lock<std::mutex> lk(tail_worker.mu);
             tail_worker.cv_idle.wait_for(lk, std::chrono::milliseconds(1));
+            if (now_us() - t_wait > 120e6) return fail("internal: the chains of truncated reads hold both slots and none comes back (120 s)");
           }
         }
         if (!tail_begin(R)) return PBSIM_FAILED;
@@ -1202,6 +1213,15 @@ static std::unique_ptr<JobRecord> job_new_record(pbsim_ctx *c, int64_t len) {
         r->ref = RefDesc();
         return r;
       }
+    // No record of the job before has this length: its buffers (2 B per base, up to 64 GB for a record group at the CLI's
+    // limit) would stay resident beside the new job's uploads, on top of pools that were sized while one group was resident
+    // (ADVICE r5).  Spares whose length an announced record still waits for are kept; the rest go back now.
+    for (size_t i = c->job_spare.size(); i-- > 0;) {
+      bool wanted = false;
+      for (size_t k = c->job_records.size(); k < c->job_expect_len.size() && !wanted; k++)
+        wanted = c->job_expect_len[k] == c->job_spare[i]->len;
+      if (!wanted) c->job_spare.erase(c->job_spare.begin() + (long)i);
+    }
   }
   std::unique_ptr<JobRecord> r(new JobRecord);
   r->len = len;
@@ -1556,6 +1576,31 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   if (c->scratch_auto) {
     size_t free_b = 0, total_b = 0;
     HIP_OK(hipMemGetInfo(&free_b, &total_b));
+    if (streaming) {
+      // An announced job (pbsim_job_expect) sizes its pools while records 2.. are still on their way: what they will take --
+      // sequence + homopolymer lengths, 2 B per base, less what a spare buffer of the same length already holds, and the
+      // growth of the lines staging -- is not free, and how far the feeder thread has got must not move the batch sizes from
+      // run to run: charge every announced record that has no buffers yet, whatever has arrived since.
+      std::lock_guard<std::mutex> lk(c->job_mu);
+      std::vector<int64_t> spare;
+      for (auto &sp : c->job_spare) spare.push_back(sp->len);
+      size_t pending = 0, lines_max = 0;
+      for (size_t i = 0; i < n; i++) {
+        if (i < c->job_records.size()) {
+          // (already resident: inside free_b's complement; counted as free again so that the figure does not depend on the feeder)
+          free_b += (size_t)(2 * lens[i] + 192);
+        }
+        auto it = std::find(spare.begin(), spare.end(), lens[i]);
+        if (it != spare.end() && i >= c->job_records.size()) {
+          spare.erase(it);
+          continue;
+        }
+        pending += (size_t)(2 * lens[i] + 192) + (size_t)(lens[i] / 1024 + 64) * 16;
+        lines_max = std::max(lines_max, (size_t)(lens[i] + lens[i] / 40 + 64));
+      }
+      if (c->d_lines.bytes > 0 && lines_max > c->d_lines.bytes) pending += lines_max - c->d_lines.bytes;
+      free_b = free_b > pending ? free_b - pending : 0;
+    }
     size_t held = 0, held_text = 0;
     for (Slot &sl : c->slots) {
       held += sl.d_scratch.bytes;

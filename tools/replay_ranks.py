@@ -7,9 +7,9 @@ functions of two per-read quantities -- the raw length a read's header draws and
 values of the OTHER ranks can be served from a table of those two numbers for the first reads of every record, whatever the
 plan: rank r of N then runs ALONE on the GPU, at full speed, with its own link, pools and delivery threads, against a
 communicator that answers for the N - 1 others at once ("virtual ranks").  That is what a rank of a real N-GPU node does between
-its collectives.  The collectives' own latency is injected: `collective_us` (default 60, what a small RCCL all-gather with
-pinned staging costs end to end) is spent inside every callback and counted in every segment of the synchronised path.  What
-the figure still leaves out is the contention of N ranks for host memory (tools/host_contention.py measures that apart).
+its collectives.  The collectives' own latency is injected: `collective_us` (bench.py's default: the all-gather latency it measures on the
+native RCCL communicator's function pointers on a group of one, times --collective-factor) is spent inside every callback and counted in every segment of the synchronised path.  What
+the figure still leaves out is the contention of N ranks for host memory (tools/host_contention_sweep.sh measures that apart).
 
   table    = batch primitives on one context: walk the reads 1 .. M of every record un-truncated, fetch (rawlen, pass-0 bases)
   virtual  = pbsim_comm from Python callables; pbsim_job_progress tells which exchange of which round is being entered:

@@ -4,11 +4,11 @@ out=$1; shift
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/$out -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/$out/bench.json 2> $R/$out/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $R/$out -- python3 $R/bench.py --no-cpu-baseline --no-extras "$@" > $R/$out/bench.json 2> $R/$out/err.txt
 cd $R
 python3 - $out <<'PY'
 import csv,glob,sys
-f=glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True)[0]
+f=max(glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True), key=lambda p: __import__("os").path.getsize(p))   # the parent's (the largest), not a child's
 rows=[r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 t_end=max(int(r["End_Timestamp"]) for r in rows)
