@@ -175,10 +175,83 @@ def cpu_baseline(model="ERRHMM-ONT.model", depth=20, sample_bp=4_000_000):
             "all_cores": all_cores}
 
 
+class CountingTextSink:
+    """pbsim_sink of the per-unit drivers (pbsim_simulate_trans / _sample): receives the members in pinned host memory and only
+    counts them; with deflate bit 2 the two callbacks arrive from two threads (one counter each)"""
+
+    def __init__(self, P):
+        self.read_bytes = self.maf_bytes = 0
+        self._cbs = (P.SINK_CB(self._read), P.SINK_CB(self._maf))
+        self.sink = P.Sink(None, *self._cbs)
+
+    def _read(self, user, text, n):
+        self.read_bytes += n
+        return 1
+
+    def _maf(self, user, text, n):
+        self.maf_bytes += n
+        return 1
+
+
+def timed_unit_job(a, torch, P, C, ctx, fn, workload, kernel, extra_cfg=None):
+    """A per-unit driver (`fn`: pbsim_simulate_trans / pbsim_simulate_sample) under the headline metric: every
+    step is the whole job INCLUDING the delivery of its output -- FASTQ + MAF compressed on the GPU (pbsim_set_deflate(7)) and
+    copied into pinned host memory where a sink counts them, as run_job(True) does for the wgs job.  At least --steps steps and
+    at least a second of them; the same job with its text left in HBM beside it (median of five)."""
+    def run(deliver):
+        ctx.set_deflate(7 if deliver else 0)
+        sink = CountingTextSink(P)
+        P._check(fn(ctx.h, C.byref(sink.sink) if deliver else None))
+        return sink
+    for _ in range(max(1, a.warmup)):
+        run(True)
+    torch.cuda.synchronize()
+    ctx.prof_reset()
+    steps, host_bytes = 0, 0
+    t0 = time.perf_counter()
+    while steps < max(10, a.steps) or time.perf_counter() - t0 < 1.0:
+        sk = run(True)
+        host_bytes += sk.read_bytes + sk.maf_bytes
+        steps += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    walk_ms, launches, _ = ctx.prof_get()
+    st = ctx.stats()
+    bases, reads = st.res_len_total, st.res_num
+    maf_columns = bases + st.res_del_num
+    ref_bases = bases - st.res_ins_num + st.res_del_num
+    alg = steps * (ref_bases + 2 * bases + 2 * maf_columns)
+    ach = alg / (walk_ms / 1e3) / 1e9 if walk_ms > 0 else None
+    ctx.release_pools()
+    run(False)
+    torch.cuda.synchronize()
+    hbm = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        run(False)
+        torch.cuda.synchronize()
+        hbm.append(time.perf_counter() - t1)
+    out = {"metric": "simulated bases/sec", "value": bases * steps / dt, "unit": "bases/s", "n_gpus": 1, "steps": steps,
+           "warmup": max(1, a.warmup), "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u8", "data": "synthetic", "reads_per_sec": reads * steps / dt,
+           "config": dict({"workload": workload, "bases_per_step": bases, "reads_per_step": reads, "delivered": True}, **(extra_cfg or {})),
+           "delivery": {"host_bytes_per_step": host_bytes // steps, "pcie_frac": host_bytes / dt / (PCIE_PEAK_GBS * 1e9)},
+           "roofline": {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
+                        "alg_bytes_per_launch": alg / max(1, launches), "avg_launch_ms": walk_ms / max(1, launches), "launches": launches,
+                        "kernel_limiter": "valu-issue", "job_limiter": "pcie",
+                        "pcie_frac": host_bytes / dt / (PCIE_PEAK_GBS * 1e9)},
+           "whole_job_hbm": {"value": bases / sorted(hbm)[len(hbm) // 2], "unit": "bases/s", "runs_ms": [x * 1e3 for x in hbm],
+                             "note": "the same job, text left in HBM (no compression, no copy); median of five runs"}}
+    import bench_line
+    bench_line.emit(out, a.detail, sys.stdout)
+
+
 def bench_sample(a, torch, harness, P, local):
     """Sampling method at scale: 200 000 synthetic quality strings (lengths gamma mean 9 000 / sd 7 000
     clipped to 100..60 000, per-read quality level Q8..Q30 with jitter), a 100 Mbp record, depth 20 -> 2.0 Gbases.
-    Whole job, text left in HBM; one wave per string, 64 columns per step."""
+    Whole job per step, output delivered (timed_unit_job); one wave per string, 64 columns per step."""
+    import ctypes as C
     import numpy as np
     rng = np.random.default_rng(1)
     n = 200_000
@@ -195,28 +268,18 @@ def bench_sample(a, torch, harness, P, local):
     ctx.set_scratch_bytes(int(a.scratch_gib * (1 << 30)))
     ctx.set_sample_profile(quals)
     ctx.set_reference(genome, 1)
-    ctx.simulate_sample(collect=False)
-    torch.cuda.synchronize()
-    runs = []
-    for _ in range(5):       # a 27 ms job: one timed run measured the box's mood as much as the job (0.026-0.045 s); the median of five
-        t0 = time.perf_counter()
-        ctx.simulate_sample(collect=False)
-        torch.cuda.synchronize()
-        runs.append(time.perf_counter() - t0)
-    dt = sorted(runs)[len(runs) // 2]
-    st = ctx.stats()
-    print(json.dumps({"metric": "whole job wall time", "value": dt, "unit": "s", "higher_is_better": False, "n_gpus": 1,
-                      "runs_s": runs, "value_is": "median of runs_s",
-                      "bases": st.res_len_total, "reads": st.res_num, "bases_per_sec": st.res_len_total / dt,
-                      "config": {"workload": f"wgs sample, {n} synthetic quality strings ({int(lens.sum())} bases), "
-                                             f"100 Mbp record, depth {p.depth}, seed 1"}}))
+    timed_unit_job(a, torch, P, C, ctx, ctx.lib.pbsim_simulate_sample,
+                   f"wgs sample (pbsim.cpp:1694-1949), {n} synthetic quality strings ({int(lens.sum())} bases), 100 Mbp record, "
+                   f"depth {p.depth}, seed 1; FASTQ + MAF compressed on the GPU and delivered into pinned host memory", "k_walk_sample")
     ctx.close()
 
 
 def bench_trans(a, torch, harness, P, local):
     """BASELINE configs[3]: --strategy trans --method errhmm --errhmm ERRHMM-SEQUEL.model on 100 000 transcripts
     (lengths log-uniform 300..12000, plus ~ Geometric(mean 20), minus ~ Geometric(mean 0.1), seed 1).
-    The job has a fixed read count, so the figure is the wall time of pbsim_simulate_trans with text left in HBM."""
+    Per step: header -> walk -> emit of every transcript's reads (pbsim.cpp:4487-4780) and the delivery of the output
+    (timed_unit_job)."""
+    import ctypes as C
     import numpy as np
     rng = np.random.default_rng(1)
     n = 100_000
@@ -234,18 +297,10 @@ def bench_trans(a, torch, harness, P, local):
     t0 = time.perf_counter()
     ctx.set_transcripts(["T%d" % i for i in range(n)], [int(x) for x in plus], [int(x) for x in minus], seqs)
     t_set = time.perf_counter() - t0
-    ctx.simulate_trans(collect=False)   # warm-up (pools)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ctx.simulate_trans(collect=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    st = ctx.stats()
-    print(json.dumps({"metric": "whole job wall time", "value": dt, "unit": "s", "higher_is_better": False, "n_gpus": 1,
-                      "bases": st.res_len_total, "reads": st.res_num, "bases_per_sec": st.res_len_total / dt,
-                      "set_transcripts_s": t_set,
-                      "config": {"workload": "trans errhmm ERRHMM-SEQUEL, 100000 synthetic transcripts "
-                                             f"({int(lens.sum())} bp), expression plus~Geom(20) minus~Geom(0.1), seed 1"}}))
+    timed_unit_job(a, torch, P, C, ctx, ctx.lib.pbsim_simulate_trans,
+                   "BASELINE configs[3]: trans errhmm ERRHMM-SEQUEL, 100000 synthetic transcripts "
+                   f"({int(lens.sum())} bp), expression plus~Geom(20) minus~Geom(0.1), seed 1; FASTQ + MAF compressed on the GPU and "
+                   "delivered into pinned host memory", "k_walk_errhmm", {"set_transcripts_s": t_set})
     ctx.close()
 
 
@@ -397,17 +452,21 @@ def steady_state(a, torch, harness, P, local, model, genome_ptr, G, qs=False, pa
 
 
 def other_configs():
-    """One timed step each of the BASELINE configurations the headline is not quoted on, so that every one of them is timed by
-    whoever runs `python bench.py`: configs[4] (ERRHMM-ONT-HQ depth 60, the 3 Gbp genome), configs[2] (QSHMM-RSII --pass-num 10
-    depth 20 as BAM records + MAF; ONE 750 Mbp record -- the four-record job takes 18 s a step) and configs[3] (100 000
-    transcripts).  Each is this same script as a child process (started after this process has closed its context; never an
-    exec), one warm-up run + one timed run, without the sub-measurements; what is kept of its line is below."""
+    """The BASELINE configurations the headline is not quoted on, under the same metric, so that every one of them is timed by
+    whoever runs `python bench.py`: configs[4] (ERRHMM-ONT-HQ depth 60, the 3 Gbp genome; one timed step), configs[2] (QSHMM-RSII
+    --pass-num 10 depth 20 as BAM records + MAF; ONE 750 Mbp record, one timed step -- the four-record job takes 18 s a step),
+    configs[3] (100 000 transcripts) and the sampling method (>= 10 steps and >= 1 s each: timed_unit_job).  Every one delivers
+    its output like the headline (compressed on the GPU, into pinned host memory).  Each is this same script as a child
+    process (started after this process has closed its context; never an exec); what is kept of its line is below.  A
+    configuration that fails is reported as {"error": ..} -- it never takes the headline's line with it."""
     res = {}
     runs = (("configs[4] onthq60", ["--workload", "onthq60"]),
             ("configs[2] qshmm10", ["--workload", "qshmm10", "--records", "1"]),
-            ("configs[3] trans", ["--workload", "trans"]))
+            ("configs[3] trans", ["--workload", "trans"]),
+            ("sampling method", ["--workload", "sample"]))
     for name, flags in runs:
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"] + flags
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline",
+               "--detail", ""] + flags
         t0 = time.perf_counter()
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
@@ -416,20 +475,19 @@ def other_configs():
                 res[name] = {"error": (p.stderr or "no output")[-400:], "command": " ".join(cmd[1:])}
                 continue
             j = json.loads(line[-1])
-        except Exception as e:  # reported, never required
-            res[name] = {"error": str(e), "command": " ".join(cmd[1:])}
-            continue
-        row = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "workload": j["config"]["workload"],
-               "command": "python bench.py " + " ".join(cmd[2:]), "process_s": time.perf_counter() - t0}
-        if "ms_per_step" in j:
-            row.update({"ms_per_step": j["ms_per_step"], "bases_per_step": j["config"]["bases_per_step"],
-                        "reads_per_step": j["config"]["reads_per_step"], "pcie_frac": j["delivery"]["pcie_frac"],
-                        "compressed_bytes_per_job": j["delivery"]["compressed_bytes_per_job"],
-                        "walk": {"kernel": j["roofline"]["kernel"], "frac": j["roofline"]["frac"],
-                                 "avg_launch_ms": j["roofline"]["avg_launch_ms"], "launches": j["roofline"]["launches"]}})
-        else:
-            row.update({"bases": j.get("bases"), "reads": j.get("reads"), "bases_per_sec": j.get("bases_per_sec")})
-        res[name] = row
+            rf = j.get("roofline") or {}
+            res[name] = {"metric": j.get("metric"), "value": j.get("value"), "unit": j.get("unit"),
+                         "workload": (j.get("config") or {}).get("workload"),
+                         "command": "python bench.py " + " ".join(cmd[2:]), "process_s": time.perf_counter() - t0,
+                         "steps": j.get("steps"), "ms_per_step": j.get("ms_per_step"),
+                         "delivered": (j.get("config") or {}).get("delivered"),
+                         "bases_per_step": (j.get("config") or {}).get("bases_per_step"),
+                         "reads_per_step": (j.get("config") or {}).get("reads_per_step"),
+                         "pcie_frac": (j.get("delivery") or {}).get("pcie_frac"), "walk_frac": rf.get("frac"),
+                         "walk": {k: rf.get(k) for k in ("kernel", "frac", "avg_launch_ms", "launches")},
+                         "whole_job_hbm": j.get("whole_job_hbm")}
+        except Exception as e:  # noqa: BLE001 -- reported, never required
+            res[name] = {"error": "%s: %s" % (type(e).__name__, e), "command": " ".join(cmd[1:])}
     return res
 
 
@@ -755,99 +813,115 @@ def main():
         P._check(ok)
         return t_1 - t_0, sink
 
+    sub_errors = {}       # a sub-measurement that fails is reported in the detail file; it never takes the line with it
     fresh = None
     c1_stream = None
-    if world == 1 and not a.no_extras:
-        dts = [fresh_job(None)[0] for _ in range(3)]
-        fresh = {"ms": min(dts) * 1e3, "runs_ms": [x * 1e3 for x in dts]}
-        torch.cuda.synchronize()            # (the records of the last fresh run stay: the sub-measurements below run on them)
-    elif world > 1 and a.fresh_records:
-        c1_group = dist.new_group()         # C1 on a communicator of its own: the job's exchanges run on the default one meanwhile
-        c1_stream = torch.cuda.Stream(device=dev) if cdev == dev else None
-        dts = []
-        for _ in range(2):
-            dist.barrier()
-            torch.cuda.synchronize()
-            t_f = time.perf_counter()
-            fresh_job(cref, 0.0, c1_group)
-            torch.cuda.synchronize()
-            dist.barrier()
-            dts.append(time.perf_counter() - t_f)
-        tf = torch.tensor([min(dts)], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tf, op=dist.ReduceOp.MAX)
-        fresh = {"ms": float(tf.item()) * 1e3, "runs_ms": [x * 1e3 for x in dts]}
+    try:
+        if world == 1 and not a.no_extras:
+            dts = [fresh_job(None)[0] for _ in range(3)]
+            fresh = {"ms": min(dts) * 1e3, "runs_ms": [x * 1e3 for x in dts]}
+            torch.cuda.synchronize()            # (the records of the last fresh run stay: the sub-measurements below run on them)
+        elif world > 1 and a.fresh_records:
+            c1_group = dist.new_group()         # C1 on a communicator of its own: the job's exchanges run on the default one meanwhile
+            c1_stream = torch.cuda.Stream(device=dev) if cdev == dev else None
+            dts = []
+            for _ in range(2):
+                dist.barrier()
+                torch.cuda.synchronize()
+                t_f = time.perf_counter()
+                fresh_job(cref, 0.0, c1_group)
+                torch.cuda.synchronize()
+                dist.barrier()
+                dts.append(time.perf_counter() - t_f)
+            tf = torch.tensor([min(dts)], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            fresh = {"ms": float(tf.item()) * 1e3, "runs_ms": [x * 1e3 for x in dts]}
+    except Exception as e:  # noqa: BLE001
+        if world > 1:
+            raise          # (N ranks: a rank that skipped collectives of a sub-measurement would leave the others waiting)
+        sub_errors['from_fresh_records'] = "%s: %s" % (type(e).__name__, e)
 
     extras = {}
-    if not a.no_extras:
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ctx.release_pools()                 # another kind of job on this context: other slot counts and batch sizes
-        t1 = time.perf_counter()
-        run_job(False)                      # untimed: this mode sizes its batches (and pools) differently
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        ctx.prof_reset()
-        hbm_runs = []
-        for _ in range(3):                  # (three timed runs, their mean: one run scatters by 2-3 %)
+    try:
+        if not a.no_extras:
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ctx.release_pools()                 # another kind of job on this context: other slot counts and batch sizes
             t1 = time.perf_counter()
-            run_job(False)
+            run_job(False)                      # untimed: this mode sizes its batches (and pools) differently
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
-            hbm_runs.append(time.perf_counter() - t1)
-        dt_hbm = sum(hbm_runs) / len(hbm_runs)
-        w2_ms, w2_launches, _ = ctx.prof_get()
-        c2 = ctx.job_counters()
-        alg2 = 3 * (c2["ref_bases"] + 2 * c2["bases"] + 2 * c2["maf_columns"])
-        extras["whole_job_hbm"] = {"value": job_bases / dt_hbm, "unit": "bases/s", "runs_ms": [x * 1e3 for x in hbm_runs],
-                                   "note": "the same job, FASTQ + MAF text left in HBM (no compression, no copy); mean of three runs",
-                                   "walk": {"avg_launch_ms": w2_ms / max(1, w2_launches), "launches": w2_launches,
-                                            "achieved": alg2 / (w2_ms / 1e3) / 1e9 if w2_ms > 0 else None,
-                                            "frac": alg2 / (w2_ms / 1e3) / 1e9 / HBM_PEAK_GBS if w2_ms > 0 else None,
-                                            "note": "the walk kernel in THIS job (five workgroups per CU, three rounds in flight), HIP events as in "
-                                                    "`roofline`: the delivered job above runs the same kernel at ONE workgroup per CU on purpose"}}
+            ctx.prof_reset()
+            hbm_runs = []
+            for _ in range(3):                  # (three timed runs, their mean: one run scatters by 2-3 %)
+                t1 = time.perf_counter()
+                run_job(False)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                hbm_runs.append(time.perf_counter() - t1)
+            dt_hbm = sum(hbm_runs) / len(hbm_runs)
+            w2_ms, w2_launches, _ = ctx.prof_get()
+            c2 = ctx.job_counters()
+            alg2 = 3 * (c2["ref_bases"] + 2 * c2["bases"] + 2 * c2["maf_columns"])
+            extras["whole_job_hbm"] = {"value": job_bases / dt_hbm, "unit": "bases/s", "runs_ms": [x * 1e3 for x in hbm_runs],
+                                       "note": "the same job, FASTQ + MAF text left in HBM (no compression, no copy); mean of three runs",
+                                       "walk": {"avg_launch_ms": w2_ms / max(1, w2_launches), "launches": w2_launches,
+                                                "achieved": alg2 / (w2_ms / 1e3) / 1e9 if w2_ms > 0 else None,
+                                                "frac": alg2 / (w2_ms / 1e3) / 1e9 / HBM_PEAK_GBS if w2_ms > 0 else None,
+                                                "note": "the walk kernel in THIS job (five workgroups per CU, three rounds in flight), HIP events as in "
+                                                        "`roofline`: the delivered job above runs the same kernel at ONE workgroup per CU on purpose"}}
+    except Exception as e:  # noqa: BLE001
+        if world > 1:
+            raise          # (N ranks: a rank that skipped collectives of a sub-measurement would leave the others waiting)
+        sub_errors['whole_job_hbm'] = "%s: %s" % (type(e).__name__, e)
 
     replays = None
-    if a.replay_ranks and world == 1:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import replay_ranks as RR
-        t_tab = time.perf_counter()
-        tables = RR.build_tables(P, harness, p, model, qs, recs, G, local)
-        t_tab = time.perf_counter() - t_tab
+    try:
+        if a.replay_ranks and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import replay_ranks as RR
+            t_tab = time.perf_counter()
+            tables = RR.build_tables(P, harness, p, model, qs, recs, G, local)
+            t_tab = time.perf_counter() - t_tab
 
-        def run_with(comm):
-            sink = CountingSink(P, C)
-            ctx.set_deflate(7 if deliver else 0)
-            if not deliver:
-                sink.sink = P.RecordSink(None, P.REC_TEXT_CB(), P.REC_TEXT_CB(), sink._cbs[2])
-            P._check(ctx.lib.pbsim_job_run(ctx.h, C.byref(comm), C.byref(sink.sink)))
-            return sink
+            def run_with(comm):
+                sink = CountingSink(P, C)
+                ctx.set_deflate(7 if deliver else 0)
+                if not deliver:
+                    sink.sink = P.RecordSink(None, P.REC_TEXT_CB(), P.REC_TEXT_CB(), sink._cbs[2])
+                P._check(ctx.lib.pbsim_job_run(ctx.h, C.byref(comm), C.byref(sink.sink)))
+                return sink
 
-        t1_ms = dt_max * 1e3 / a.steps
-        replays = {"t1_ms": t1_ms, "table_build_s": t_tab, "table_reads": [len(t.out0) for t in tables], "by_world": {}}
-        for n in [int(x) for x in a.replay_ranks.split(",") if x]:
+            t1_ms = dt_max * 1e3 / a.steps
+            replays = {"t1_ms": t1_ms, "table_build_s": t_tab, "table_reads": [len(t.out0) for t in tables], "by_world": {}}
+            for n in [int(x) for x in a.replay_ranks.split(",") if x]:
+                ctx.release_pools()
+                res = RR.replay(P, C, ctx, tables, n, run_with, collective_us=a.collective_us)
+                if a.c1_gbs > 0:    # rank 0 of n from fresh records: C1 emulated per record, K0 and C1 of records 2.. behind the rounds
+                    vr = RR.VirtualRanks(P, ctx, 0, n, tables, a.collective_us)
+                    dtf = min(fresh_job(C.byref(vr.comm), a.c1_gbs)[0] for _ in range(3)) * 1e3
+                    r0 = [x for x in res["per_rank"] if x["rank"] == 0][0]["wall_ms"]
+                    res["from_fresh_records"] = {
+                        "rank0_wall_ms": dtf, "rank0_wall_resident_ms": r0, "exposed_setup_ms": dtf - r0,
+                        "setup_if_not_overlapped_ms": NR * G / (a.c1_gbs * 1e9) * 1e3 + t_k0 * 1e3, "c1_gbs": a.c1_gbs,
+                        "note": "rank 0 of %d, records announced (pbsim_job_expect) and handed over by a feeder thread, each after the time its "
+                                "broadcast would take at --c1-gbs (emulated: the record is in HBM already); exposed_setup = this wall - the same "
+                                "rank's wall with every record resident before the job starts" % n}
+                    ctx.job_begin(1)
+                    for t in recs:
+                        ctx.job_add_record_device(t.data_ptr(), G)
+                res["speedup"] = t1_ms / res["sync_critical_path_ms"] if res["sync_critical_path_ms"] else None
+                res["speedup_if_ranks_never_wait"] = t1_ms / res["max_rank_wall_ms"]
+                res["speedup_sync_upper_bound_of_time"] = t1_ms / res["sync_critical_path_ms"] if res["sync_critical_path_ms"] else None
+                replays["by_world"][str(n)] = res
             ctx.release_pools()
-            res = RR.replay(P, C, ctx, tables, n, run_with, collective_us=a.collective_us)
-            if a.c1_gbs > 0:    # rank 0 of n from fresh records: C1 emulated per record, K0 and C1 of records 2.. behind the rounds
-                vr = RR.VirtualRanks(P, ctx, 0, n, tables, a.collective_us)
-                dtf = min(fresh_job(C.byref(vr.comm), a.c1_gbs)[0] for _ in range(3)) * 1e3
-                r0 = [x for x in res["per_rank"] if x["rank"] == 0][0]["wall_ms"]
-                res["from_fresh_records"] = {
-                    "rank0_wall_ms": dtf, "rank0_wall_resident_ms": r0, "exposed_setup_ms": dtf - r0,
-                    "setup_if_not_overlapped_ms": NR * G / (a.c1_gbs * 1e9) * 1e3 + t_k0 * 1e3, "c1_gbs": a.c1_gbs,
-                    "note": "rank 0 of %d, records announced (pbsim_job_expect) and handed over by a feeder thread, each after the time its "
-                            "broadcast would take at --c1-gbs (emulated: the record is in HBM already); exposed_setup = this wall - the same "
-                            "rank's wall with every record resident before the job starts" % n}
-                ctx.job_begin(1)
-                for t in recs:
-                    ctx.job_add_record_device(t.data_ptr(), G)
-            res["speedup"] = t1_ms / res["sync_critical_path_ms"] if res["sync_critical_path_ms"] else None
-            res["speedup_if_ranks_never_wait"] = t1_ms / res["max_rank_wall_ms"]
-            res["speedup_sync_upper_bound_of_time"] = t1_ms / res["sync_critical_path_ms"] if res["sync_critical_path_ms"] else None
-            replays["by_world"][str(n)] = res
-        ctx.release_pools()
+    except Exception as e:  # noqa: BLE001
+        if world > 1:
+            raise          # (N ranks: a rank that skipped collectives of a sub-measurement would leave the others waiting)
+        sub_errors['replay'] = "%s: %s" % (type(e).__name__, e)
 
     if rank == 0:
         K = a.steps
@@ -964,6 +1038,8 @@ def main():
         if one_gpu and world > 1:
             out["config"]["one_gpu"] = f"{world} ranks as {world} contexts on ONE GPU, gloo collectives: plumbing, not scaling"
         out.update(extras)
+        if sub_errors:
+            out["sub_errors"] = sub_errors
         if replays:
             out["replay"] = replays
     ctx.close()
@@ -975,20 +1051,25 @@ def main():
     if rank == 0 and world == 1 and headline and not a.no_extras and not a.no_other_configs:
         del recs
         torch.cuda.empty_cache()
-        out["other_configs"] = other_configs()
+        try:
+            out["other_configs"] = other_configs()
+        except Exception as e:  # noqa: BLE001
+            out["other_configs"] = {"error": str(e)}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(model if not qs else "ERRHMM-ONT.model", int(min(depth, 20)))
             except Exception as e:  # the baseline is reported, never required
                 out["cpu_baseline"] = {"error": str(e)}
-        import bench_line
-        bench_line.emit(out, a.detail, sys.stdout)
     if native is not None:
         native.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:     # the line is the LAST thing this process writes to stdout (RCCL prints a banner there when it initialises)
+        import bench_line
+        sys.stdout.flush()
+        bench_line.emit(out, a.detail, sys.stdout)
 
 
 if __name__ == "__main__":

@@ -97,6 +97,8 @@ def compact(out, detail_path=None):
     pr = out.get("per_rank")
     if isinstance(pr, dict):
         line["per_rank"] = {k: ([_num(x) for x in v] if isinstance(v, list) else _num(v)) for k, v in pr.items()}
+    if isinstance(out.get("sub_errors"), dict) and out["sub_errors"]:
+        line["sub_errors"] = sorted(out["sub_errors"])      # names only; the messages are in the detail file
     if detail_path:
         line["detail"] = detail_path
     # the size guard: optional blocks go, in this order, until the line fits (the contract fields, roofline and
