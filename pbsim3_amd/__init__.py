@@ -362,15 +362,7 @@ class RcclComm:
     @classmethod
     def from_torch(cls, dist, device, key="pbsim_rccl_id"):
         """the id through torch.distributed's key-value store (TCP, the rendezvous torchrun already made)"""
-        rank, world = dist.get_rank(), dist.get_world_size()
-        store = dist.distributed_c10d._get_default_store()
-
-        def exchange(ident):
-            if rank == 0:
-                store.set(key, ident)
-                return ident
-            return bytes(store.get(key))     # blocks until rank 0 has set it
-        return cls.create(rank, world, device, exchange)
+        return cls.create(dist.get_rank(), dist.get_world_size(), device, store_exchange(dist, key))
 
     @classmethod
     def from_file(cls, path, rank, world, device):
@@ -385,6 +377,26 @@ class RcclComm:
         if self.ptr:
             load().pbsim_rccl_comm_destroy(self.ptr)
             self.ptr = self.ref = None
+
+
+_store_round = [0]
+
+
+def store_exchange(dist, key="pbsim_rccl_id"):
+    """exchange(id_or_None) -> id over torch.distributed's key-value store: rank 0 sets the bytes under a key of this call's
+    own (a process that makes several communicators gets several keys -- every rank counts the calls alike), the others block
+    in get() until it is there.  Device-free: works under any backend (tests/test_multi_gloo.py)."""
+    rank = dist.get_rank()
+    store = dist.distributed_c10d._get_default_store()
+    _store_round[0] += 1
+    k = "%s/%d" % (key, _store_round[0])
+
+    def exchange(ident):
+        if rank == 0:
+            store.set(k, ident)
+            return ident
+        return bytes(store.get(k))
+    return exchange
 
 
 def comm_latency(comm_ref, n_words=8, iters=1000, warm=50):

@@ -51,6 +51,17 @@ ctx.stats_keep_values(True)
 ctx.stats_add_tasks(0, [100, 200], [1, 2], [3, 4], [5, 6])
 ctx.stats_merge(comm)
 assert ctx.stats().res_num == 2
+# the library's own communicator beside torch's, its id through torch's store (what bench.py --gpus N and run_multi do)
+nat = P.RcclComm.from_torch(dist, 0)
+assert nat.info()["ranks_seen"] == 1 and (nat.comm.rank, nat.comm.world) == (0, 1)
+out3 = np.zeros(3, dtype=np.int64)
+assert nat.comm.all_gather_i64(nat.comm.user, send.ctypes.data_as(I64), 3, out3.ctypes.data_as(I64)) == 1 and out3.tolist() == send.tolist()
+hist = np.arange(100001, dtype=np.int64)
+assert nat.comm.all_reduce_i64(nat.comm.user, hist.ctypes.data_as(I64), len(hist), P.OP_SUM) == 1 and hist[-1] == 100000
+lat = P.comm_latency(nat.ref, 8, 200, 20)
+tlat = P.comm_latency(C.byref(comm), 8, 200, 20)
+print("latency us: native", lat["all_gather_us"], "torch callbacks", tlat["all_gather_us"])
+nat.close()
 dist.barrier()
 dist.destroy_process_group()
 print("NCCL-COMM-OK")

@@ -111,3 +111,34 @@ def test_sum_order_matters_in_this_data():
             for x in v[first:first + n]:
                 parts[rank] += x
     assert struct.pack("<d", seq) != struct.pack("<d", parts[0] + parts[1])
+
+
+def _id_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pbsim3_amd as P
+    got = []
+    for n in (P.RCCL_ID_BYTES, 0, P.RCCL_ID_BYTES):     # a good id, "rank 0 could not make one", and a second communicator's id
+        ident = bytes((7 * i + n + 1) & 255 for i in range(n)) if rank == 0 else None
+        got.append(P.store_exchange(dist)(ident))
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_id_travels_through_the_store():
+    """the side channel of pbsim3_amd.RcclComm.from_torch (bench.py --gpus N, run_multi): rank 0's 128 bytes reach every rank
+    through torch.distributed's store, call after call under fresh keys; an empty id (rank 0 failed) arrives as empty"""
+    world, port = 3, 29700 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_id_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    import pbsim3_amd as P
+    want = [bytes((7 * i + n + 1) & 255 for i in range(n)) for n in (P.RCCL_ID_BYTES, 0, P.RCCL_ID_BYTES)]
+    assert all(res[r] == want for r in range(world))
