@@ -364,6 +364,76 @@ def issue_bound(columns_per_launch, walk_s):
     return out
 
 
+class NoTorch:
+    """--no-torch (N = 1): what main() uses of torch, without torch -- so that the process maps the SYSTEM HIP runtime only.
+    rocprofv3 --kernel-trace around a process that holds PyTorch's bundled runtime turns SDMA off (every pinned D2H copy then
+    runs as an __amd_rocclr_copyBuffer kernel beside the walks: the delivered job 1.6x, the walk kernel 2.2x slower -- the same
+    figures as HSA_ENABLE_SDMA=0 without the tracer; profiles/r06_trace_sdma_ab.txt); around the system runtime it does not.
+    The timed region is bracketed by pbsim_device_synchronize (hipDeviceSynchronize) instead of torch.cuda.synchronize."""
+    int64, float64, uint8 = "int64", "float64", "uint8"
+
+    class _T(list):
+        def clone(self):
+            return NoTorch._T(self)
+
+        def tolist(self):
+            return list(self)
+
+        def item(self):
+            return self[0]
+
+    class _Cuda:
+        def __init__(self):
+            self.ctx = None
+
+        def synchronize(self):
+            if self.ctx is not None and self.ctx.h:
+                self.ctx.lib.pbsim_device_synchronize(self.ctx.h)
+
+        def set_device(self, i):
+            pass
+
+        def device_count(self):
+            return 1
+
+        def empty_cache(self):
+            pass
+
+    def __init__(self):
+        self.cuda = NoTorch._Cuda()
+
+    def device(self, kind, index=0):
+        return (kind, index)
+
+    def tensor(self, values, dtype=None, device=None):
+        return NoTorch._T(values)
+
+
+class HostRecord:
+    """a record in host memory (--no-torch): uploaded by pbsim_job_add_record instead of handed over as a device pointer"""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+
+def synth_records_host(harness, n_rec, G):
+    """harness.synth_bases on a thread per chunk (numpy releases the GIL): the same bytes as synth_bases_torch"""
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    recs = []
+    step = 1 << 24
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        for r in range(n_rec):
+            out = np.empty(G, dtype=np.uint8)
+
+            def fill(a, out=out, seed=100 + r):
+                n = min(step, G - a)
+                out[a:a + n] = harness.synth_bases_at(a, n, seed)
+            list(ex.map(fill, range(0, G, step)))
+            recs.append(HostRecord(out))
+    return recs
+
+
 def make_records(torch, harness, dist, dev, cdev, rank, world, n_rec, G):
     """uniform ACGT records, generated on rank 0's GPU and broadcast over RCCL (C1).  Record r is harness.synth_bases(G, 100 + r)
     -- plain 64-bit integer arithmetic, the same bytes from numpy on any CPU -- so the reference itself can be (and for record
@@ -581,9 +651,18 @@ def main():
     ap.add_argument("--rocprof-stats", default=None,
                     help="suffix of the profiles/ kernel-stats CSV roofline.frac_rocprof is derived from (default: the newest "
                          "*_bench_prof_kernel_stats.csv, headline workload only)")
+    ap.add_argument("--no-torch", action="store_true",
+                    help="N = 1: run without importing torch, on the system HIP runtime only (records generated on the host, the "
+                         "timed region bracketed by pbsim_device_synchronize); implies --no-extras.  The configuration rocprofv3 "
+                         "traces without perturbing it (class NoTorch)")
     ap.add_argument("--param", action="append", default=[],
                     help="experiment only: override a pbsim_params field, e.g. --param len_sd=0 (not the headline workload)")
     a = ap.parse_args()
+    if a.no_torch:
+        if a.gpus != 1 or a.workload in ("trans", "sample"):
+            sys.exit("bench.py: --no-torch is for --gpus 1 and the wgs workloads")
+        a.no_extras = True
+        os.environ["PBSIM_TORCH_COMPAT"] = "0"       # pbsim3_amd.load(): do not map PyTorch's bundled runtime either
     headline = a.workload == "errhmm" and not a.hbm_only and not a.param and a.records == 4 and a.record_len == RECORD_LEN
     if a.replay_ranks is None:
         a.replay_ranks = "8" if (headline and a.gpus == 1 and not a.no_extras) else ""
@@ -606,7 +685,10 @@ def main():
     import pbsim3_amd as P
     # host placement first: this thread, the threads the library starts and its pinned staging go to the GPU's NUMA node
     numa = P.bind_host_to_device(local)
-    import torch
+    if a.no_torch:
+        torch = NoTorch()
+    else:
+        import torch
     import harness
 
     if not one_gpu and torch.cuda.device_count() < world:      # (device_count does not initialise the GPU)
@@ -636,25 +718,33 @@ def main():
     G, NR = a.record_len, a.records
 
     t_c1 = time.perf_counter()
-    recs = make_records(torch, harness, dist, dev, cdev, rank, world, NR, G)
+    recs = synth_records_host(harness, NR, G) if a.no_torch else make_records(torch, harness, dist, dev, cdev, rank, world, NR, G)
     t_c1 = time.perf_counter() - t_c1      # generation on rank 0 + C1 (the broadcast of every record), outside the timed region
     p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_QS if qs else P.METHOD_ERR, seed=1, depth=depth, pass_num=pass_num)
     for kv in a.param:
         k, v = kv.split("=")
         setattr(p, k, type(getattr(p, k))(float(v)))
     ctx = P.Context(p, local)
+    if a.no_torch:
+        torch.cuda.ctx = ctx
     (ctx.load_qshmm if qs else ctx.load_errhmm)(harness.model_path(model))
     if pass_num > 1:
         ctx.set_bam_output(True)
     with P.Context(p, local) as warm:      # the library's first kernel launch loads its code object (0.15 s in a fresh process): not K0's
-        tiny = torch.randint(0, 4, (4096,), dtype=torch.uint8, device=dev) + 65   # (a buffer of its own: K0 prepares in place)
-        warm.set_reference_device(tiny.data_ptr(), 4096, 1)
-        torch.cuda.synchronize()
-        del tiny
+        if a.no_torch:
+            warm.set_reference(b"ACGT" * 1024, 1)
+        else:
+            tiny = torch.randint(0, 4, (4096,), dtype=torch.uint8, device=dev) + 65   # (a buffer of its own: K0 prepares in place)
+            warm.set_reference_device(tiny.data_ptr(), 4096, 1)
+            torch.cuda.synchronize()
+            del tiny
     torch.cuda.synchronize()
     t_k0 = time.perf_counter()
     for t in recs:
-        ctx.job_add_record_device(t.data_ptr(), G)
+        if a.no_torch:      # (upload + K0: the records are resident before the timed region either way)
+            P._check(ctx.lib.pbsim_job_add_record(ctx.h, C.c_void_p(t.arr.ctypes.data), G))
+        else:
+            ctx.job_add_record_device(t.data_ptr(), G)
     torch.cuda.synchronize()               # K0 (upper-case + homopolymer pass, k_hp_*) of every record: also outside the timed region
     t_k0 = time.perf_counter() - t_k0
     # the job's collectives (C3 per round, C2 per record): the library's own RCCL communicator, one process per GPU
@@ -1035,6 +1125,7 @@ def main():
                                 "value_incl_k0 = the job's bases / (a step + K0), what a caller that hands over fresh records sees"}
         out["critical_path"] = critical_path(bd_all, K)
         out["numa"] = numa or "unbound (one node, no topology, or PBSIM_NUMA_BIND=0)"
+        out["config"]["host_runtime"] = "system HIP runtime, no torch (--no-torch)" if a.no_torch else "PyTorch's bundled HIP runtime"
         if one_gpu and world > 1:
             out["config"]["one_gpu"] = f"{world} ranks as {world} contexts on ONE GPU, gloo collectives: plumbing, not scaling"
         out.update(extras)

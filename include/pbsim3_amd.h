@@ -451,6 +451,9 @@ int pbsim_scratch_state(pbsim_ctx *ctx, double out[3]);
 int pbsim_prof_secondary(pbsim_ctx *ctx, double out[8]);
 /* raw HIP stream handle (hipStream_t) of the engine, for external event timing */
 void *pbsim_stream(pbsim_ctx *ctx);
+/* hipDeviceSynchronize on the context's GPU: the bracket of a timed region for a host that holds no HIP runtime handle of its
+ * own (bench.py --no-torch: a process with the system runtime only, which rocprofv3 traces without changing how copies run) */
+int pbsim_device_synchronize(pbsim_ctx *ctx);
 
 /* ---- known-answer hooks (tests) ---------------------------------------------
  * Philox4x32-10 block as the kernels compute it, on the host build of the same

@@ -164,6 +164,7 @@ API = [
     ("pbsim_prof_secondary", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("pbsim_prof_wave_launches", C.c_int64, [C.c_void_p]),
     ("pbsim_stream", C.c_void_p, [C.c_void_p]),
+    ("pbsim_device_synchronize", C.c_int, [C.c_void_p]),
     ("pbsim_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("pbsim_dump_table", C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
 ]

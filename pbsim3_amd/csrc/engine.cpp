@@ -1547,6 +1547,13 @@ int pbsim_prof_secondary(pbsim_ctx *c, double out[8]) {
   return PBSIM_SUCCEEDED;
 }
 void *pbsim_stream(pbsim_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int pbsim_device_synchronize(pbsim_ctx *c) {
+  if (!c) return fail("bad argument");
+  NEED_DEVICE(c);
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipDeviceSynchronize());
+  return PBSIM_SUCCEEDED;
+}
 
 int64_t pbsim_dump_table(pbsim_ctx *c, int which, void *buf, int64_t cap) {
   if (!c) return -1;

@@ -37,23 +37,28 @@ def model_path(name):
 INPUT_CACHE = os.path.join(GOLDEN, "inputs", "_unpacked")
 
 
-def synth_bases(n, seed):
-    """n pseudo-random A/C/G/T bytes from plain 64-bit integer arithmetic (splitmix64 of the position), so the file is
-    the same on every box and numpy version without being committed."""
+def synth_bases_at(first, n, seed):
+    """bytes first .. first + n - 1 of synth_bases(.., seed): a pure function of the position"""
     import numpy as np
     out = np.empty(n, dtype=np.uint8)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     step = 1 << 22
     with np.errstate(over="ignore"):
-        for a in range(0, n, step):
-            x = (np.arange(a, min(n, a + step), dtype=np.uint64) + np.uint64(seed * 0x632BE59BD9B4E019 & (2**64 - 1))) * np.uint64(0x9E3779B97F4A7C15)
+        for a in range(first, first + n, step):
+            x = (np.arange(a, min(first + n, a + step), dtype=np.uint64) + np.uint64(seed * 0x632BE59BD9B4E019 & (2**64 - 1))) * np.uint64(0x9E3779B97F4A7C15)
             x ^= x >> np.uint64(30)
             x *= np.uint64(0xBF58476D1CE4E5B9)
             x ^= x >> np.uint64(27)
             x *= np.uint64(0x94D049BB133111EB)
             x ^= x >> np.uint64(31)
-            out[a:a + len(x)] = lut[(x >> np.uint64(61)).astype(np.int64) & 3]
+            out[a - first:a - first + len(x)] = lut[(x >> np.uint64(61)).astype(np.int64) & 3]
     return out
+
+
+def synth_bases(n, seed):
+    """n pseudo-random A/C/G/T bytes from plain 64-bit integer arithmetic (splitmix64 of the position), so the file is
+    the same on every box and numpy version without being committed."""
+    return synth_bases_at(0, n, seed)
 
 
 def synth_bases_torch(n, seed, device="cuda"):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""usage: tools/roofline_check.py KERNEL_STATS.csv BENCH_LINE.json -- re-derives the bench line's roofline figures from the
-rocprofv3 --kernel-trace --stats summary OF THE SAME RUN (tools/profile_round.sh keeps both side by side in profiles/).
+"""usage: tools/roofline_check.py KERNEL_STATS.csv BENCH_LINE.json [BENCH_DETAIL.json] -- re-derives the bench line's roofline
+figures from the rocprofv3 --kernel-trace --stats summary OF THE SAME RUN (tools/profile_round.sh keeps both side by side in
+profiles/).  The line is bench.py's compact one; the secondary kernels' rows are in its sidecar (third argument).
 
 dominant kernel: achieved = roofline.alg_bytes_per_launch / (the walk kernel's average duration in the CSV); the line's own
 `avg_launch_ms` comes from HIP events on the walk streams around lane walker + wave walker of a round, so the two agree when
@@ -15,6 +16,7 @@ import sys
 
 def main():
     stats, line = sys.argv[1], sys.argv[2]
+    detail = sys.argv[3] if len(sys.argv) > 3 else None
     rows = {}
     for r in csv.DictReader(open(stats)):
         name = r["Name"].replace("pbsim::(anonymous namespace)::", "").replace("void ", "")
@@ -30,6 +32,8 @@ def main():
     print(f"{kern}: CSV {calls} calls, avg {avg_ms:.3f} ms  |  line: {rf['launches']} timed launches, avg {rf['avg_launch_ms']:.3f} ms (HIP events)")
     print(f"  achieved from the CSV  {ach:8.1f} GB/s = {ach / rf['peak']:.4f} of {rf['peak']:.0f}")
     print(f"  achieved in the line   {rf['achieved']:8.1f} GB/s = {rf['frac']:.4f}   (CSV / line = {ach / rf['achieved']:.3f})")
+    if detail:
+        rf = json.load(open(detail))["roofline"]
     for s in rf.get("secondary", []):
         k = s["kernel"].split(" ")[0]
         if k not in rows:
