@@ -211,7 +211,9 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
   // being written and the next batch's emission queues up behind it -- the GPU sat idle for 5 of the 39 ms of configs[3]
   // while the host added 1 M reads' counters.  deliver() waits for the emission before it hands text to a sink.
   DeferTextSync defer_guard(c);
-  const int n_slots = std::max(1, std::min(kMaxSlots, c->pipeline_depth));
+  // (a delivering job keeps three slots busy: one whose bytes are leaving, one finalized behind it, one walking)
+  const bool delivering = sink && c->deflate != 0 && (sink->on_read_text || sink->on_maf_text);
+  const int n_slots = std::max(1, std::min(kMaxSlots, delivering ? std::max(3, c->pipeline_depth) : c->pipeline_depth));
   const int64_t R = first_read - 1 + n_reads;  // last read of the range
   int64_t cap = batch_capacity(c);
   struct Pending {
@@ -228,20 +230,55 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
     fifo.clear();
     c->cur = 0;
   };
+  // A sink that receives its bytes through the GPU's compression (pbsim_set_deflate) is bound by the link, not by the walks
+  // (configs[3]: 37 ms of walks, 4.3 GB of members): a batch's text is emitted (pbsim_batch_finalize) and the first piece of its
+  // two streams compressed BEFORE the batch in front of it is delivered, so the link does not wait for the emission kernels nor
+  // for a call's first deflate kernels between two batches.  The sink still receives the batches in read order.  Round 6, same
+  // box (tools/closed_ab/units_ab.sh, profiles/r06_units_delivery_ab.txt): 121 -> 113 ms per job; MORE batches do not help --
+  // every batch's walk lasts as long as its longest read, twelve batches walk at 40 instead of 120 Gbases/s and the walks become
+  // the bound (115-142 ms).
+  const char *up = exp_env("PBSIM_UNITS_PARTS");  // experiment knobs: batches per job; prelaunch of a batch's first deflate piece
+  const char *upre = exp_env("PBSIM_UNITS_PRELAUNCH");
+  const int n_parts = up && atoi(up) > 0 ? atoi(up) : n_slots;
+  const bool prelaunch = delivering && (c->deflate & 3) == 3 && (upre ? atoi(upre) != 0 : true);
   int64_t next_begin = first_read, next_read = first_read;
   int next_slot = 0;
+  bool have_prev = false;  // a batch that is finalized and not yet delivered (it keeps its slot)
+  int prev_slot = 0;
+  auto deliver_prev = [&]() -> int {
+    if (!have_prev) return PBSIM_SUCCEEDED;
+    have_prev = false;
+    c->cur = prev_slot;
+    return deliver(c, sink);
+  };
+  auto give_up = [&]() {
+    drop_pending();
+    if (have_prev) {
+      c->cur = prev_slot;
+      (void)hipStreamSynchronize(c->s().stream);
+      have_prev = false;
+      c->cur = 0;
+    }
+  };
   while (next_read <= R) {
-    while ((int)fifo.size() < n_slots && next_begin <= R) {
-      const int64_t part = std::max<int64_t>(65536, (n_reads + n_slots - 1) / n_slots);
+    while ((int)fifo.size() + (have_prev ? 1 : 0) < n_slots && next_begin <= R) {
+      const int64_t part = std::max<int64_t>(65536, (n_reads + n_parts - 1) / n_parts);
       const int64_t n = std::min(std::min(cap, part), R - next_begin + 1);
       c->cur = next_slot;
       if (!pbsim_batch_walk_begin(c, next_begin, n, -1)) {
-        drop_pending();
+        give_up();
         return PBSIM_FAILED;
       }
       fifo.push_back(Pending{next_slot, next_begin, n});
       next_slot = (next_slot + 1) % n_slots;
       next_begin += n;
+    }
+    if (fifo.empty()) {  // (one slot: the finalized batch must leave before the next one can begin)
+      if (!deliver_prev()) {
+        give_up();
+        return PBSIM_FAILED;
+      }
+      continue;
     }
     const Pending pd = fifo.front();
     fifo.erase(fifo.begin());
@@ -251,20 +288,37 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
       const std::string keep = g_err;
       drop_pending();
       if (!budget) {
+        give_up();
         g_err = keep;
         return PBSIM_FAILED;
       }
       cap = std::max<int64_t>(1, pd.n / 2);  // retry from this batch with smaller ones
       next_begin = pd.first;
-      next_slot = 0;
+      next_slot = have_prev ? (prev_slot + 1) % n_slots : 0;
       continue;
     }
     pbsim_batch_info bi;
-    if (!pbsim_batch_finalize(c, 0, &bi) || !deliver(c, sink)) {
-      drop_pending();
+    if (!pbsim_batch_finalize(c, 0, &bi)) {
+      give_up();
       return PBSIM_FAILED;
     }
     next_read += bi.n_final;
+    // the table fit and the first piece of this batch's two streams go onto the slot's stream right behind its text emission:
+    // when the batch's turn comes its first copies start at once instead of waiting for their kernels (deflate_host.cpp df_begin)
+    if (prelaunch && !deflate_prelaunch(c, c->s(), sink->on_read_text != nullptr, sink->on_maf_text != nullptr, true)) {
+      give_up();
+      return PBSIM_FAILED;
+    }
+    if (!deliver_prev()) {  // the batch in front: its bytes leave while this batch's text is being emitted
+      give_up();
+      return PBSIM_FAILED;
+    }
+    have_prev = true;
+    prev_slot = pd.slot;
+  }
+  if (!deliver_prev()) {
+    give_up();
+    return PBSIM_FAILED;
   }
   return PBSIM_SUCCEEDED;
 }
