@@ -368,6 +368,7 @@ struct pbsim_ctx {
   int pipeline_depth = 2;      // slots pbsim_simulate_* keeps in flight
   hipStream_t df_streams[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [lane][kernels | copies]
   bool defer_text_sync = false;  // finalize_text returns once the sizes are known; the text emission is still in flight (job pipeline)
+  bool defer_account = false;    // deliver() leaves the batch's statistics to its caller (units.cpp accounts batch k + 1 on a thread beside the delivery of batch k)
   int walk_lds_kb = 27;        // walk workgroups per CU: 27 KB -> five (batch primitives), 41 KB -> three (the job pipeline)
   bool bam_output = false;     // pass_num > 1: BAM records instead of SAM text
   int deflate = 0;             // bit 0 / 1: read / MAF sink receives BGZF-framed gzip members (deflate.hip)

@@ -440,6 +440,6 @@ extern "C++" int pbsim::deliver(pbsim_ctx *c, const pbsim_sink *sink) {
         !sink->on_maf_text(sink->user, (const char *)c->s().h_maf_text.p, bi.maf_text_bytes))
       return fail("sink aborted (MAF text)");
   }
-  return pbsim_batch_account(c);
+  return c->defer_account ? PBSIM_SUCCEEDED : pbsim_batch_account(c);
 }
 }  // extern "C"

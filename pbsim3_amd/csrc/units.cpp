@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <functional>
+#include <future>
 #include <memory>
 #include <string>
 #include <thread>
@@ -233,10 +234,11 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
   // A sink that receives its bytes through the GPU's compression (pbsim_set_deflate) is bound by the link, not by the walks
   // (configs[3]: 37 ms of walks, 4.3 GB of members): a batch's text is emitted (pbsim_batch_finalize) and the first piece of its
   // two streams compressed BEFORE the batch in front of it is delivered, so the link does not wait for the emission kernels nor
-  // for a call's first deflate kernels between two batches.  The sink still receives the batches in read order.  Round 6, same
-  // box (tools/closed_ab/units_ab.sh, profiles/r06_units_delivery_ab.txt): 121 -> 113 ms per job; MORE batches do not help --
-  // every batch's walk lasts as long as its longest read, twelve batches walk at 40 instead of 120 Gbases/s and the walks become
-  // the bound (115-142 ms).
+  // for a call's first deflate kernels between two batches; and the batch's statistics are added on a thread beside that
+  // delivery instead of behind it.  The sink still receives the batches in read order.  Round 6, same box
+  // (tools/closed_ab/units_ab*.sh, profiles/r06_units_delivery_ab.txt): 121 -> 112 -> 102.5 ms per job.  MORE batches do not
+  // help (every batch's walk lasts as long as its longest read: twelve batches walk at 40 instead of 120 Gbases/s), nor does a
+  // ramp of batch sizes, nor walking the batches one after the other on the GPU (105 -> 108 ms).
   const char *up = exp_env("PBSIM_UNITS_PARTS");  // experiment knobs: batches per job; prelaunch of a batch's first deflate piece
   const char *upre = exp_env("PBSIM_UNITS_PRELAUNCH");
   const int n_parts = up && atoi(up) > 0 ? atoi(up) : n_slots;
@@ -245,6 +247,20 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
   int next_slot = 0;
   bool have_prev = false;  // a batch that is finalized and not yet delivered (it keeps its slot)
   int prev_slot = 0;
+  // The statistics of a batch (two million tasks per job: 10-15 ms of host loop, pbsim.cpp:3986-4005 in read order) are added on a
+  // thread of their own beside the delivery of the batch in front, not behind every delivery with the link idle; batch after
+  // batch, so the order-dependent accuracy sum keeps its order.
+  struct DeferAccount {
+    pbsim_ctx *c;
+    bool was;
+    DeferAccount(pbsim_ctx *cc, bool on) : c(cc), was(cc->defer_account) { c->defer_account = on; }
+    ~DeferAccount() { c->defer_account = was; }
+  } account_guard(c, delivering);
+  std::future<int> acct;
+  auto join_acct = [&]() -> int {
+    if (!acct.valid()) return PBSIM_SUCCEEDED;
+    return acct.get() ? PBSIM_SUCCEEDED : fail("the statistics of a batch could not be added");
+  };
   auto deliver_prev = [&]() -> int {
     if (!have_prev) return PBSIM_SUCCEEDED;
     have_prev = false;
@@ -252,6 +268,7 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
     return deliver(c, sink);
   };
   auto give_up = [&]() {
+    if (acct.valid()) (void)acct.get();
     drop_pending();
     if (have_prev) {
       c->cur = prev_slot;
@@ -309,6 +326,14 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
       give_up();
       return PBSIM_FAILED;
     }
+    if (delivering) {
+      if (!join_acct()) {
+        give_up();
+        return PBSIM_FAILED;
+      }
+      Slot *sl = &c->s();
+      acct = std::async(std::launch::async, [c, sl]() { return account_of(c, *sl, &c->st); });
+    }
     if (!deliver_prev()) {  // the batch in front: its bytes leave while this batch's text is being emitted
       give_up();
       return PBSIM_FAILED;
@@ -316,7 +341,7 @@ int pbsim_simulate_units_range(pbsim_ctx *c, int64_t first_read, int64_t n_reads
     have_prev = true;
     prev_slot = pd.slot;
   }
-  if (!deliver_prev()) {
+  if (!deliver_prev() || !join_acct()) {
     give_up();
     return PBSIM_FAILED;
   }
