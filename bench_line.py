@@ -42,7 +42,7 @@ def compact(out, detail_path=None):
     cfg = out.get("config", {})
     line["config"] = {"workload": _short(cfg.get("workload", ""), 200)}
     line["config"].update(_pick(cfg, ("bases_per_step", "reads_per_step", "rounds_per_step", "parallelism", "comm",
-                                      "rccl_ranks_seen", "collective_us", "one_gpu", "delivered")))
+                                      "rccl_ranks_seen", "collective_us", "one_gpu", "delivered", "host_runtime")))
     rf = out.get("roofline")
     if isinstance(rf, dict):
         r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms",

@@ -63,3 +63,17 @@ def test_scale_command_dry_run_two_ranks_one_gpu(tmp_path):
     assert line["comm_latency"]["job_comm"]["world"] == 2 and line["comm_latency"]["job_comm"]["all_gather_us"] > 0
     assert len(detail["critical_path"]["per_rank"]) == 2
     assert "roofline" in line and line["roofline"]["launches"] > 0
+
+
+def test_no_torch_mode_is_the_same_job(tmp_path):
+    """bench.py --no-torch: the job from a process that maps the system HIP runtime only (the configuration rocprofv3 traces
+    without turning SDMA off, profiles/r06_trace_sdma_ab.txt) -- same records (harness.synth_bases on the host), same reads and
+    bases as the default run of the same size"""
+    args = ["--gpus", "1", "--steps", "1", "--warmup", "1", "--record-len", "4000000", "--records", "2", "--no-cpu-baseline"]
+    a, _, _ = run_bench(args + ["--no-torch"], tmp_path)
+    b, _, _ = run_bench(args + ["--no-extras"], tmp_path)
+    assert a["config"]["host_runtime"].startswith("system HIP runtime") and b["config"]["host_runtime"].startswith("PyTorch")
+    for k in ("bases_per_step", "reads_per_step", "rounds_per_step"):
+        assert a["config"][k] == b["config"][k], k
+    assert a["delivery"]["host_bytes_per_step"] == b["delivery"]["host_bytes_per_step"]
+    assert a["roofline"]["launches"] == b["roofline"]["launches"] and a["value"] > 0
