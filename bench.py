@@ -524,14 +524,14 @@ def steady_state(a, torch, harness, P, local, model, genome_ptr, G, qs=False, pa
 def other_configs():
     """The BASELINE configurations the headline is not quoted on, under the same metric, so that every one of them is timed by
     whoever runs `python bench.py`: configs[4] (ERRHMM-ONT-HQ depth 60, the 3 Gbp genome; one timed step), configs[2] (QSHMM-RSII
-    --pass-num 10 depth 20 as BAM records + MAF; ONE 750 Mbp record, one timed step -- the four-record job takes 18 s a step),
+    --pass-num 10 depth 20 as BAM records + MAF; the four-record job, one timed step of 18 s -- round 5 timed ONE record),
     configs[3] (100 000 transcripts) and the sampling method (>= 10 steps and >= 1 s each: timed_unit_job).  Every one delivers
     its output like the headline (compressed on the GPU, into pinned host memory).  Each is this same script as a child
     process (started after this process has closed its context; never an exec); what is kept of its line is below.  A
     configuration that fails is reported as {"error": ..} -- it never takes the headline's line with it."""
     res = {}
     runs = (("configs[4] onthq60", ["--workload", "onthq60"]),
-            ("configs[2] qshmm10", ["--workload", "qshmm10", "--records", "1"]),
+            ("configs[2] qshmm10", ["--workload", "qshmm10"]),
             ("configs[3] trans", ["--workload", "trans"]),
             ("sampling method", ["--workload", "sample"]))
     for name, flags in runs:
