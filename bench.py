@@ -9,10 +9,13 @@ MAF text emitted on the GPU, per-record statistics -- AND the delivery of the ou
 (BGZF-framed gzip members, deflate.hip) and copied into pinned host memory, where a sink receives them ("incl.
 batch D2H"; what the CLI does for .fq.gz / .maf.gz except the file writes).  `value` = bases of the job / wall time of a
 step.  Sub-fields give the same job with the text left in HBM (whole_job_hbm) and the steady-state batch pipeline on one
-record (steady_state_hbm).  The default run (N = 1, no flags beyond --steps / --warmup) also appends, outside the timed region:
-`other_configs` -- one timed step each of BASELINE configs[4], [2] (one record) and [3], as child processes; `replay` -- every
-rank of the EIGHT-rank job alone on this GPU against virtual ranks, 60 us injected per collective (tools/replay_ranks.py); and
-`setup.value_from_fresh_records` -- the job started on announced records that a feeder thread hands over while it runs.
+record (steady_state_hbm).  The default run (N = 1, no flags beyond --steps / --warmup) also measures, outside the timed
+region: `other_configs` -- BASELINE configs[4], [2] (the four-record job), [3] and the sampling job, every one delivered like the
+headline, as child processes; `comm_latency` -- what a collective costs through the library's RCCL communicator and through the
+torch.distributed callbacks (groups of one); `replay` -- every rank of the EIGHT-rank job alone on this GPU against virtual
+ranks, twice the measured latency injected per collective (tools/replay_ranks.py); and `setup.value_from_fresh_records` -- the
+job started on announced records that a feeder thread hands over while it runs.  It prints ONE compact line (bench_line.py,
+under 6 KB) and writes the full record to bench_detail.json.
 The records are harness.synth_bases: integer arithmetic, so the reference itself can be run on the bench genome (and has been on
 record 2: tests/golden/fullsize.json).
 
@@ -20,10 +23,11 @@ record 2: tests/golden/fullsize.json).
 ranks; started bare (`python bench.py --gpus 8`) it launches the N ranks itself -- `python -m torch.distributed.run` as a
 child process, before anything here has touched a GPU -- and exits with their status.  Rank 0 generates the records, RCCL
 broadcasts them (C1), every round of the pipeline is sharded by read block over the ranks, the ranks exchange only integers
-(C3: one all-gather per round, two in the round that places a record's cut; C2: three collectives per record) through
-torch.distributed (backend nccl = RCCL over xGMI); every rank
-delivers its own blocks to its own host memory, from threads and pinned buffers bound to its GPU's NUMA node.
+(C3: one all-gather per round, two in the round that places a record's cut; C2: three collectives per record) through the
+library's own RCCL communicator (ncclCommInitRank, its id carried by torch's store; --comm torch: torch.distributed
+callbacks); every rank delivers its own blocks to its own host memory, from threads and pinned buffers bound to its GPU's NUMA node.
 --one-gpu: the N ranks as N contexts on GPU 0 with gloo collectives (the plumbing check of a single-GPU box).
+--no-torch: N = 1 without importing torch, on the system HIP runtime only: the configuration rocprofv3 traces unperturbed.
 """
 import argparse
 import json
