@@ -1094,7 +1094,8 @@ def main():
         out["roofline"]["valu_busy_frac"] = ib["valu_busy_frac"] if ib else None
         if ib and ib.get("hmm_table_reads"):
             out["roofline"]["lds_hit_rate"] = ib["hmm_table_reads"]["lds_hit_rate"]
-        rk = rocprof_kernel_avg(out["roofline"]["kernel"]) if (headline or a.rocprof_stats) else None
+        # (the committed trace is of the one-GPU job: an N-rank job's launches have another shape)
+        rk = rocprof_kernel_avg(out["roofline"]["kernel"]) if ((headline and world == 1) or a.rocprof_stats) else None
         if a.rocprof_stats:      # an explicit CSV (tools/profile_round.sh: the trace of THIS configuration)
             rk = rocprof_kernel_avg(out["roofline"]["kernel"], a.rocprof_stats)
         if rk:
