@@ -1113,7 +1113,7 @@ __device__ __forceinline__ LaneWalk errhmm_lanes(const WalkArgs &a, const uint8_
         // 16-byte read serves the whole step.
         const uint4 em = *reinterpret_cast<const uint4 *>(lds + a.emis_off + state * 16u);
         const uint32_t thr = kHpBits ? __builtin_amdgcn_ubfe(em.w, (raw >> 3) & 16u, 16u) : row[4 + (hp < 12u ? hp : 11u)];
-        const bool del = (mod1000_raw(w.y) + 1u) <= thr;
+        const bool del = mod1000_raw(w.y) < thr;  // x % 1000 + 1 <= thr (pbsim.cpp:3857-3858), one compare
         const uint32_t quo = __umulhi(wz, em.x) >> (em.y & 31u);
         const uint32_t rem = (wz + __umul24(quo, em.y >> 8)) & 0xffffffu;  // rem < d <= 1000: 24 bits of z - quo * d
         e = (uint32_t)(rem >= (em.z & 0xffffu)) + (uint32_t)(rem >= (em.z >> 16));
