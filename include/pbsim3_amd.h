@@ -409,7 +409,8 @@ int pbsim_cli_main(int argc, char **argv, const pbsim_comm *comm, int device);
  * only, pbsim.cpp:4-14).  librccl is opened at run time.
  * pbsim_rccl_unique_id: writes the id (returns its size; with id == NULL or cap too small only the size), 0 on failure.
  * pbsim_rccl_comm_create_file: the same with a file as the side channel -- rank 0 publishes the id at `path` (written whole,
- * then renamed), the others wait for it (PBSIM_RENDEZVOUS_TIMEOUT_S, default 120); the caller removes the file afterwards.
+ * then renamed), the others wait for it (PBSIM_RENDEZVOUS_TIMEOUT_S, default 120); rank 0 removes the file once every rank has joined (use a
+ * path of the launch's own: a stale file of a crashed launch would be read as this launch's id).
  * pbsim_rccl_comm_info: [0] the ranks RCCL itself counts in the communicator (ncclCommCount), [1] this rank's number there,
  * [2] the device, [3] collectives issued so far.  NULL / PBSIM_FAILED + pbsim_last_error() on failure. */
 #define PBSIM_RCCL_ID_BYTES 128

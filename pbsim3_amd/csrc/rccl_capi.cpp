@@ -128,7 +128,11 @@ pbsim_comm *pbsim_rccl_comm_create_file(const char *path, int32_t rank, int32_t 
       return nullptr;
     }
   }
-  return pbsim_rccl_comm_create(&u, (int64_t)sizeof(u), rank, world, device);
+  pbsim_comm *cm = pbsim_rccl_comm_create(&u, (int64_t)sizeof(u), rank, world, device);
+  // ncclCommInitRank is collective: when it returns on rank 0, every rank has read the id -- the file goes, so that a later
+  // launch that reuses the path cannot pick up this launch's id (a crash in between leaves it: use a path per launch)
+  if (rank == 0) unlink(path);
+  return cm;
 }
 
 int pbsim_rccl_comm_info(const pbsim_comm *comm, int64_t out[4]) {
