@@ -4,88 +4,35 @@ the several-rank protocol with every exchange a real ncclAllGather / ncclAllRedu
 communicator, the id travels through a rendezvous file as well, and the `pbsim` binary's --rank / --world /
 --rendezvous mode runs the command line on it.  What a group of one cannot show -- ranks waiting for each other -- is covered
 by the host communicator with several contexts on the one GPU (tests/test_gpu_multi.py) and over gloo."""
-import ctypes as C
 import os
 import subprocess
+import sys
 
-import numpy as np
 import pytest
 
 import harness
-import pbsim3_amd as P
 from cases import CASES
 
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(harness.ROOT, "pbsim3_amd", "bin", "pbsim")
 
 
-def job_bytes(ctx, comm_ref):
-    reads, mafs, done = {}, {}, {}
-
-    def on(store):
-        def cb(user, rec, text, n, off):
-            store.setdefault(rec, []).append((off, C.string_at(text, n)))
-            return 1
-        return cb
-
-    def on_done(user, rec, st, rb, mb):
-        done[rec] = (st.contents.res_num, st.contents.res_len_total, rb, mb)
-        return 1
-    cbs = (P.REC_TEXT_CB(on(reads)), P.REC_TEXT_CB(on(mafs)), P.REC_DONE_CB(on_done))
-    sink = P.RecordSink(None, *cbs)
-    P._check(ctx.lib.pbsim_job_run(ctx.h, comm_ref, C.byref(sink)))
-    cat = lambda d: {r: b"".join(t for _, t in sorted(v)) for r, v in d.items()}   # noqa: E731
-    return cat(reads), cat(mafs), done
+def run_driver(which, tmp_path):
+    env = dict(os.environ, PYTHONPATH=harness.ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(harness.ROOT, "tests", "rccl_native_driver.py"), which, str(tmp_path)],
+                       capture_output=True, text=True, cwd=harness.ROOT, env=env, timeout=280)
+    assert p.returncode == 0 and "RCCL-NATIVE-OK " + which in p.stdout, (p.stdout + p.stderr)[-3000:]
 
 
-def test_job_through_init_rank_communicator_of_one(tmp_path, monkeypatch):
-    rng = np.random.default_rng(5)
-    recs = [np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].tobytes() for n in (300_000, 180_000)]
-    p = P.default_params(strategy=P.STRATEGY_WGS, method=P.METHOD_ERR, seed=3, depth=4.0)
-    with P.Context(p, 0) as ctx:
-        ctx.load_errhmm(harness.model_path("ERRHMM-ONT.model"))
-        ctx.set_scratch_bytes(6 << 20)          # many rounds per record
-        for r in recs:
-            ctx.job_add_record(r)
-        want = job_bytes(ctx, None)
-        monkeypatch.setenv("PBSIM_COMM_ALWAYS", "1")
-        for make in (lambda: P.RcclComm.create(0, 1, 0, lambda ident: ident),
-                     lambda: P.RcclComm.from_file(str(tmp_path / "rdv"), 0, 1, 0)):
-            cm = make()
-            assert (cm.comm.rank, cm.comm.world) == (0, 1)
-            info0 = cm.info()
-            assert info0["ranks_seen"] == 1 and info0["rank"] == 0 and info0["device"] == 0
-            got = job_bytes(ctx, cm.ref)
-            assert got == want
-            assert cm.info()["collectives"] > info0["collectives"] + 6     # the job's exchanges went through RCCL
-            lat = P.comm_latency(cm.ref, 8, 200, 20)
-            assert 0 < lat["all_gather_us"] < 5000 and 0 < lat["all_reduce_us"] < 5000
-            # compressed members through the several-rank delivery (arena + offsets from the exchanges): same payload
-            ctx.set_deflate(7)
-            gz = job_bytes(ctx, cm.ref)
-            ctx.set_deflate(0)
-            import gzip
-            assert {r: gzip.decompress(v) for r, v in gz[0].items()} == want[0]
-            assert {r: gzip.decompress(v) for r, v in gz[1].items()} == want[1]
-            cm.close()
-    assert not os.path.exists(tmp_path / "rdv")      # rank 0 removes the id file once every rank has joined
-    assert sum(v[0] for v in want[2].values()) > 100
+def test_job_through_init_rank_communicator_of_one(tmp_path):
+    """tests/rccl_native_driver.py job: a job (many rounds per record) without a communicator, then through ncclCommInitRank
+    communicators of one made from an in-process id and from a rendezvous file, PBSIM_COMM_ALWAYS=1: same bytes, plain and as
+    gzip members; RCCL counts one rank; the job's exchanges are counted by the communicator; the id file is gone afterwards"""
+    run_driver("job", tmp_path)
 
 
-def test_id_and_argument_errors():
-    lib = P.load()
-    assert lib.pbsim_rccl_unique_id(None, 0) == P.RCCL_ID_BYTES
-    assert not lib.pbsim_rccl_comm_create(b"x" * 5, 5, 0, 1, 0)
-    assert b"128 bytes" in lib.pbsim_last_error()
-    out = (C.c_int64 * 4)()
-    fake = P.make_comm(0, 1, lambda a: a.reshape(1, -1), lambda a, op: a)
-    assert lib.pbsim_rccl_comm_info(C.byref(fake), out) == 0
-    with pytest.raises(P.PbsimError, match="did not publish"):
-        os.environ["PBSIM_RENDEZVOUS_TIMEOUT_S"] = "0.2"
-        try:
-            P.RcclComm.from_file("/tmp/pbsim_no_such_rendezvous_%d" % os.getpid(), 1, 2, 0)
-        finally:
-            del os.environ["PBSIM_RENDEZVOUS_TIMEOUT_S"]
+def test_id_and_argument_errors(tmp_path):
+    run_driver("errors", tmp_path)
 
 
 def test_cli_one_process_per_gpu_mode(tmp_path):
