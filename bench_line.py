@@ -123,6 +123,11 @@ def emit(out, detail_path, stream):
     text = json.dumps(compact(out, os.path.relpath(detail_path) if detail_path else None))
     if len(text) >= LINE_LIMIT:       # cannot happen with the fields above; never print an unparseable tail
         raise RuntimeError("bench line of %d bytes exceeds the %d-byte limit" % (len(text), LINE_LIMIT))
+    try:        # whatever native libraries still hold in C stdio buffers (RCCL's banner) goes out BEFORE the line, not at exit
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
     stream.write(text + "\n")
     stream.flush()
     return text
