@@ -1462,8 +1462,7 @@ static int job_run_impl(pbsim_ctx *c, const pbsim_comm *comm, const pbsim_record
   J.rank = comm ? comm->rank : 0;
   // A communicator of ONE rank has nobody to exchange with and its collectives are skipped -- unless PBSIM_COMM_ALWAYS=1
   // (test hook): the job then runs the several-rank protocol, every exchange included, through the communicator of one.  That
-  // is how a single-GPU box drives pbsim_job_run through real RCCL calls (tests/test_gpu_rccl_native.py) and measures what
-  // the exchanges cost a job on the path `bench.py --gpus N` takes (bench.py comm_latency.job_through_rccl).
+  // is how a single-GPU box drives pbsim_job_run through real RCCL calls (tests/rccl_native_driver.py).
   J.multi = J.W > 1 || (comm && comm->all_gather_i64 && comm->all_reduce_i64 && getenv("PBSIM_COMM_ALWAYS") &&
                         atoi(getenv("PBSIM_COMM_ALWAYS")) != 0);
   J.trace = getenv("PBSIM_TRACE") != nullptr;
