@@ -7,7 +7,9 @@
 //   pbsim ... --rank R --world N --rendezvous FILE [--device D]
 //                                     one PROCESS per GPU (started N times by a shell loop, mpirun, srun ..): the ranks meet in an
 //                                     RCCL communicator made with ncclCommInitRank, rank 0's id published through FILE
-//                                     (pbsim_rccl_comm_create_file); device D defaults to R
+//                                     (pbsim_rccl_comm_create_file); device D defaults to R.  Under torchrun / mpirun / srun
+//                                     --rendezvous FILE alone will do: rank, world and the node-local rank (the device) are
+//                                     taken from RANK / WORLD_SIZE / LOCAL_RANK, OMPI_COMM_WORLD_*, PMI_*, SLURM_*
 // Every rank runs the same pbsim_cli_main(argv): the job is deterministic in the values the ranks exchange, so they stay
 // in lockstep; rank 0 prints the report and creates the files, every rank writes its own byte ranges.
 #include <hip/hip_runtime.h>
@@ -16,6 +18,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <initializer_list>
 #include <string>
 #include <thread>
 #include <vector>
@@ -59,6 +62,18 @@ int main(int argc, char **argv) {
     if (!strcmp(a, "--world") && i + 1 < argc) proc_world = atoi(argv[i + 1]);
     if (!strcmp(a, "--rendezvous") && i + 1 < argc) rendezvous = argv[i + 1];
     if (!strcmp(a, "--device") && i + 1 < argc) proc_device = atoi(argv[i + 1]);
+  }
+  if (!rendezvous.empty() && proc_rank < 0 && proc_world <= 0) {
+    // under a launcher (torchrun, mpirun, srun) rank, world and the node-local rank come from its environment
+    auto env_int = [](std::initializer_list<const char *> names, int fallback) {
+      for (const char *n : names)
+        if (const char *v = getenv(n))
+          if (*v) return atoi(v);
+      return fallback;
+    };
+    proc_rank = env_int({"RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID"}, -1);
+    proc_world = env_int({"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}, 0);
+    if (proc_device < 0) proc_device = env_int({"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID"}, -1);
   }
   if (proc_world > 0 || proc_rank >= 0 || !rendezvous.empty()) {
     if (proc_world < 1 || proc_rank < 0 || proc_rank >= proc_world || rendezvous.empty() || !devices.empty()) {

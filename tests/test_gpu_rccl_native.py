@@ -53,5 +53,11 @@ def test_cli_one_process_per_gpu_mode(tmp_path):
     assert sorted(outs) == sorted(want)
     for k, v in outs.items():
         assert harness.sha(v) == want[k]["sha256"], k
+    # under a launcher: rank / world / device from its environment
+    env = dict(os.environ, OMPI_COMM_WORLD_RANK="0", OMPI_COMM_WORLD_SIZE="1", OMPI_COMM_WORLD_LOCAL_RANK="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([CLI, "--rendezvous", str(tmp_path / "r3"), "--comm-selftest"], capture_output=True, text=True, timeout=280, env=env)
+    assert p.returncode == 0 and "rank 0 of 1 processes, RCCL counts 1): ok" in p.stderr, p.stderr[-2000:]
     bad = subprocess.run([CLI, "--rank", "2", "--world", "2", "--rendezvous", "x"], capture_output=True, text=True)
     assert bad.returncode == 255 and "--rank R --world N --rendezvous FILE" in bad.stderr
