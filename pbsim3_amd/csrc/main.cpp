@@ -10,15 +10,22 @@
 //                                     (pbsim_rccl_comm_create_file); device D defaults to R.  Under torchrun / mpirun / srun
 //                                     --rendezvous FILE alone will do: rank, world and the node-local rank (the device) are
 //                                     taken from RANK / WORLD_SIZE / LOCAL_RANK, OMPI_COMM_WORLD_*, PMI_*, SLURM_*
+//   pbsim ... --processes N          the same, started by this binary itself: N children of it (posix_spawn of /proc/self/exe,
+//                                     before this process has made any HIP call), child i = --rank i --world N on GPU i, a
+//                                     rendezvous file of the launch's own under /dev/shm (or $TMPDIR); exit status = the first
+//                                     child's that is not 0
 // Every rank runs the same pbsim_cli_main(argv): the job is deterministic in the values the ranks exchange, so they stay
 // in lockstep; rank 0 prints the report and creates the files, every rank writes its own byte ranges.
 #include <hip/hip_runtime.h>
+#include <spawn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <initializer_list>
+#include <signal.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,6 +38,7 @@ int main(int argc, char **argv) {
   std::vector<int> devices;
   std::string comm_kind = "host";
   int proc_rank = -1, proc_world = 0, proc_device = -1;  // --rank / --world / --device: this process is ONE rank of several
+  int n_processes = 0;                                    // --processes N: this process starts N such ranks and waits for them
   std::string rendezvous;
   bool selftest = false;  // --comm-selftest: run C1 / C2 / C3 once on the communicator of --devices / --comm and check the values
   for (int i = 1; i < argc; i++) {
@@ -58,10 +66,53 @@ int main(int argc, char **argv) {
     if (!strncmp(a, "--comm=", 7)) comm_kind = a + 7;
     else if (!strcmp(a, "--comm") && i + 1 < argc) comm_kind = argv[i + 1];
     if (!strcmp(a, "--comm-selftest")) selftest = true;
+    if (!strcmp(a, "--processes") && i + 1 < argc) n_processes = atoi(argv[i + 1]);
     if (!strcmp(a, "--rank") && i + 1 < argc) proc_rank = atoi(argv[i + 1]);
     if (!strcmp(a, "--world") && i + 1 < argc) proc_world = atoi(argv[i + 1]);
     if (!strcmp(a, "--rendezvous") && i + 1 < argc) rendezvous = argv[i + 1];
     if (!strcmp(a, "--device") && i + 1 < argc) proc_device = atoi(argv[i + 1]);
+  }
+  if (n_processes > 0) {
+    if (!devices.empty() || proc_rank >= 0 || proc_world > 0 || !rendezvous.empty()) {
+      fprintf(stderr, "ERROR: --processes N starts the ranks itself: no --devices / --rank / --world / --rendezvous beside it.\n");
+      return 255;
+    }
+    const char *dir = access("/dev/shm", W_OK) == 0 ? "/dev/shm" : (getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp");
+    const std::string rdv = std::string(dir) + "/pbsim_rdv_" + std::to_string((long)getpid());
+    unlink(rdv.c_str());
+    std::vector<pid_t> kids;
+    for (int r = 0; r < n_processes; r++) {
+      std::vector<std::string> a;
+      for (int i = 0; i < argc; i++) {
+        if (!strcmp(argv[i], "--processes")) {
+          i++;
+          continue;
+        }
+        a.push_back(argv[i]);
+      }
+      for (const std::string &x : {std::string("--rank"), std::to_string(r), std::string("--world"), std::to_string(n_processes),
+                                   std::string("--rendezvous"), rdv})
+        a.push_back(x);
+      std::vector<char *> av;
+      for (std::string &x : a) av.push_back(&x[0]);
+      av.push_back(NULL);
+      pid_t pid = 0;
+      extern char **environ;
+      if (posix_spawn(&pid, "/proc/self/exe", NULL, NULL, av.data(), environ) != 0) {
+        fprintf(stderr, "ERROR: cannot start rank %d (posix_spawn of /proc/self/exe).\n", r);
+        for (pid_t k : kids) kill(k, SIGTERM);
+        return 255;
+      }
+      kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t k : kids) {
+      int st = 0;
+      if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st)) st = 255 << 8;
+      if (!rc && WEXITSTATUS(st)) rc = WEXITSTATUS(st);
+    }
+    unlink(rdv.c_str());
+    return rc;
   }
   if (!rendezvous.empty() && proc_rank < 0 && proc_world <= 0) {
     // under a launcher (torchrun, mpirun, srun) rank, world and the node-local rank come from its environment

@@ -59,5 +59,16 @@ def test_cli_one_process_per_gpu_mode(tmp_path):
         env.pop(k, None)
     p = subprocess.run([CLI, "--rendezvous", str(tmp_path / "r3"), "--comm-selftest"], capture_output=True, text=True, timeout=280, env=env)
     assert p.returncode == 0 and "rank 0 of 1 processes, RCCL counts 1): ok" in p.stderr, p.stderr[-2000:]
+    # the binary as its own launcher: one child process per rank (here one), golden bytes again
+    work2 = tmp_path / "w2"
+    work2.mkdir()
+    p = subprocess.run([CLI] + harness.resolve(CASES[case]["args"]) + ["--prefix", str(work2 / "out"), "--no-gzip", "--processes", "1"],
+                       capture_output=True, text=True, cwd=str(work2), timeout=280)
+    assert p.returncode == 0, p.stderr[-4000:]
+    outs2 = harness.collect(str(work2))
+    outs2[".stderr"] = harness.strip_report(p.stderr).encode()
+    assert {k: harness.sha(v) for k, v in outs2.items()} == {k: want[k]["sha256"] for k in want}
+    both = subprocess.run([CLI, "--processes", "2", "--devices", "0,0"], capture_output=True, text=True)
+    assert both.returncode == 255 and "--processes N starts the ranks itself" in both.stderr
     bad = subprocess.run([CLI, "--rank", "2", "--world", "2", "--rendezvous", "x"], capture_output=True, text=True)
     assert bad.returncode == 255 and "--rank R --world N --rendezvous FILE" in bad.stderr
