@@ -89,3 +89,18 @@ def test_bench_launches_its_ranks_itself():
     if not torch.cuda.is_available():
         assert p.returncode != 0
         assert "--gpus 2 but this node shows 0 GPU(s)" in p.stderr
+
+
+def test_cli_launch_modes_refuse_contradictions():
+    """the `pbsim` binary's one-process-per-GPU front-ends check their arguments before any HIP call (no GPU needed)"""
+    import pbsim3_amd.build as b
+    b.build()
+    cli = os.path.join(ROOT, "pbsim3_amd", "bin", "pbsim")
+    p = subprocess.run([cli, "--processes", "2", "--devices", "0,0"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 255 and "--processes N starts the ranks itself" in p.stderr
+    p = subprocess.run([cli, "--rank", "2", "--world", "2", "--rendezvous", "x"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 255 and "--rank R --world N --rendezvous FILE" in p.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMPI_COMM_WORLD_RANK",
+                                                            "OMPI_COMM_WORLD_SIZE", "PMI_RANK", "PMI_SIZE", "SLURM_PROCID", "SLURM_NTASKS")}
+    p = subprocess.run([cli, "--rendezvous", "x"], capture_output=True, text=True, timeout=60, env=env)   # no launcher around it
+    assert p.returncode == 255 and "--rank R --world N --rendezvous FILE" in p.stderr
